@@ -1,0 +1,223 @@
+#!/usr/bin/env python3
+"""Generate the committed golden vectors by running the REFERENCE itself (CPU, fp32).
+
+Runs only in the build container (needs /root/reference); the GPU box and the test-suite only
+read the resulting ``tests/golden/*.npz``.  Re-run: ``python tests/golden/make_golden.py``.
+
+Every fixture holds *data only*: the cfg overrides and oracle hyper-parameters (JSON), the seeds
+the parameters / clips are re-generated from (``paramgen.py``), the reference state_dict's key
+and shape list, and the reference's outputs (strided samples of every top-level child's output,
+pre-activation logits, eval output, train-mode logits, CE loss and sampled gradients).
+"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+from _refimport import import_reference, ref_yaml  # noqa: E402
+from paramgen import fill_state_dict, make_clip, sample_activation  # noqa: E402
+
+PARAM_SEED = 7
+CLIP_SEED = 3
+
+DUAL_YAML = "SLOWFAST_DUAL_8x8_R50_stepwise_multigrid.yaml"
+COMMON = ["NUM_GPUS", 0, "MULTIGRID.SHORT_CYCLE", False, "MULTIGRID.LONG_CYCLE", False]
+
+
+def small(s, t):
+    return ["DATA.NUM_FRAMES", t, "DATA.CROP_SIZE", s, "DATA.TRAIN_CROP_SIZE", s, "DATA.TEST_CROP_SIZE", s]
+
+
+CASES = [
+    # BASELINE.json configs[0] exactly: SlowFastShuffleNetV2 w0.25, 4x16 (slow 4 / fast 32, alpha 8), 32^2, B=2
+    dict(name="shufflenetv2_cfg1", yaml="SLOWFAST_SHUFFLENETV2_8x8_R50_stepwise_multigrid.yaml",
+         model="SlowFastShuffleNetV2", batch=2, t=32, alpha=8, size=32,
+         over=["SLOWFAST.WIDTH_MULTI", 0.25, "SLOWFAST.ALPHA", 8] + small(32, 32)),
+    # configs[1] architecture (SlowFast 8x8 R50, FuseFastToSlow K=7) at S=64, T=16
+    dict(name="slowfast_r50_s64", yaml=DUAL_YAML, model="SlowFast", batch=1, t=16, alpha=4, size=64,
+         over=small(64, 16)),
+    # configs[2]/[3] architecture (SlowFastDualAttention 8x8 R50, CMDA) at S=64, T=16, B=2
+    dict(name="dual_r50_s64", yaml=DUAL_YAML, model="SlowFastDualAttention", batch=2, t=16, alpha=4, size=64,
+         over=small(64, 16)),
+    # configs[4] architecture (SlowFastGhostNet w2.0 + CMDA) at S=64, T=16 (224^2 has no runnable reference)
+    dict(name="ghostnet_w2_s64", yaml="SLOWFAST_GHOSTNET_8x8_R50_stepwise_multigrid.yaml",
+         model="SlowFastGhostNet", batch=1, t=16, alpha=4, size=64,
+         over=["SLOWFAST.WIDTH_MULTI", 2.0, "SLOWFAST.ALPHA", 4] + small(64, 16)),
+]
+
+GRAD_KEYS = {
+    "SlowFast": ["s1.pathway0_stem.conv.weight", "s1_fuse.conv_f2s.weight", "s3.pathway1_res1.branch2.b.weight",
+                 "s4.pathway0_res0.branch2.a.weight", "s5.pathway0_res2.branch2.c_bn.weight",
+                 "head.projection.weight"],
+    "SlowFastDualAttention": ["s1.pathway1_stem.conv.weight", "s2_fuse.attention_spatial_s2f.query_conv.weight",
+                              "s2_fuse.attention_spatial_s2f.gamma", "s3_fuse.attention_channel_f2s.conv.weight",
+                              "s4.pathway0_res0.branch2.a.weight", "s3_fuse.bn_s2f.weight",
+                              "head.projection.weight"],
+    "SlowFastShuffleNetV2": ["s1.pathway0_stem.0.weight", "s2_fuse.attention_spatial_s2f.value_conv.weight",
+                             "s3.pathway0_channel_64.features.1.banch2.3.weight", "head.classifier.1.weight"],
+    "SlowFastGhostNet": ["s0.pathway0_stem.0.weight", "s3.pathway0_channel_80.features.0.se.conv_reduce.weight",
+                         "s2_fuse.attention_spatial_s2f.gamma", "head.classifier.1.weight"],
+}
+
+
+def hparams_from_cfg(cfg):
+    return dict(
+        alpha=cfg.SLOWFAST.ALPHA, beta_inv=cfg.SLOWFAST.BETA_INV, depth=cfg.RESNET.DEPTH,
+        width_per_group=cfg.RESNET.WIDTH_PER_GROUP, num_groups=cfg.RESNET.NUM_GROUPS,
+        fusion_conv_channel_ratio=cfg.SLOWFAST.FUSION_CONV_CHANNEL_RATIO,
+        fusion_kernel=cfg.SLOWFAST.FUSION_KERNEL_SZ,
+        spatial_strides=[s[0] for s in cfg.RESNET.SPATIAL_STRIDES],
+        spatial_dilations=[s[0] for s in cfg.RESNET.SPATIAL_DILATIONS],
+        num_block_temp_kernel=[list(x) for x in cfg.RESNET.NUM_BLOCK_TEMP_KERNEL],
+        num_frames=cfg.DATA.NUM_FRAMES, crop_size=cfg.DATA.CROP_SIZE, num_classes=cfg.MODEL.NUM_CLASSES,
+        short_cycle=bool(cfg.MULTIGRID.SHORT_CYCLE), head_act=cfg.MODEL.HEAD_ACT,
+        width_multi=cfg.SLOWFAST.WIDTH_MULTI, eps=1e-5,
+    )
+
+
+def run_case(case, get_cfg, build_model):
+    t0 = time.time()
+    cfg = get_cfg()
+    cfg.merge_from_file(ref_yaml(case["yaml"]))
+    over = COMMON + ["MODEL.MODEL_NAME", case["model"]] + case["over"]
+    cfg.merge_from_list(over)
+    torch.manual_seed(0)
+    model = build_model(cfg)
+    sd = model.state_dict()
+    fill_state_dict(sd, PARAM_SEED)
+    slow, fast = make_clip(CLIP_SEED, case["batch"], case["t"], case["alpha"], case["size"])
+    out = {
+        "meta": json.dumps(dict(name=case["name"], model=case["model"], yaml=case["yaml"],
+                                overrides=[str(o) if not isinstance(o, (int, float, bool)) else o for o in over],
+                                hparams=hparams_from_cfg(cfg), param_seed=PARAM_SEED, clip_seed=CLIP_SEED,
+                                batch=case["batch"], t=case["t"], alpha=case["alpha"], size=case["size"],
+                                torch=torch.__version__)),
+        "sd_keys": np.array(list(sd.keys())),
+        "sd_shapes": np.array([json.dumps(list(v.shape)) for v in sd.values()]),
+        "children": np.array([n for n, _ in model.named_children()]),
+    }
+
+    acts = {}
+
+    def hook(name):
+        def f(m, i, o):
+            acts[name] = [x.detach().clone() for x in o] if isinstance(o, (list, tuple)) else o.detach().clone()
+        return f
+
+    handles = [m.register_forward_hook(hook(n)) for n, m in model.named_children()]
+    head_fc = model.head.projection if hasattr(model.head, "projection") else model.head.classifier[1]
+    handles.append(head_fc.register_forward_hook(hook("logits")))
+
+    # ---- eval forward (what perform_test does at test_net.py:92)
+    model.eval()
+    with torch.no_grad():
+        probs = model([torch.from_numpy(slow.copy()), torch.from_numpy(fast.copy())])
+    for k, v in acts.items():
+        if k == "head":
+            continue
+        vs = v if isinstance(v, list) else [v]
+        for i, a in enumerate(vs):
+            s, amax, mean = sample_activation(a.numpy())
+            tag = "eval/%s/%d" % (k, i) if isinstance(v, list) else "eval/%s" % k
+            out[tag] = s
+            out[tag + "/stats"] = np.array([amax, mean], np.float64)
+            out[tag + "/shape"] = np.array(a.shape)
+    out["eval/logits_full"] = acts["logits"].numpy().reshape(case["batch"], -1)
+    out["eval/out"] = probs.numpy()
+
+    # ---- train forward + backward (train_net.py:78, :84-96), dropout off so it is deterministic
+    for m in model.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    model.train()
+    acts.clear()
+    xs = [torch.from_numpy(slow.copy()).requires_grad_(True), torch.from_numpy(fast.copy()).requires_grad_(True)]
+    xin = [xs[0], xs[1]]
+    logits = model(xin)
+    labels = torch.from_numpy(np.random.RandomState(11).randint(0, cfg.MODEL.NUM_CLASSES, case["batch"]))
+    loss = torch.nn.functional.cross_entropy(logits, labels)
+    loss.backward()
+    out["train/logits"] = logits.detach().numpy()
+    out["train/labels"] = labels.numpy()
+    out["train/loss"] = np.array([loss.item()], np.float64)
+    for k in ("s2", "s3_fuse", "s5"):
+        if k in acts:
+            for i, a in enumerate(acts[k]):
+                s, amax, mean = sample_activation(a.numpy())
+                out["train/%s/%d" % (k, i)] = s
+    params = dict(model.named_parameters())
+    for k in GRAD_KEYS[case["model"]]:
+        g = params[k].grad
+        s, amax, mean = sample_activation(g.numpy(), 4096)
+        out["grad/" + k] = s
+        out["grad/" + k + "/stats"] = np.array([amax, float(g.norm())], np.float64)
+    for i, nm in enumerate(("slow", "fast")):
+        s, amax, mean = sample_activation(xs[i].grad.numpy(), 4096)
+        out["grad_input/" + nm] = s
+        out["grad_input/%s/stats" % nm] = np.array([amax, float(xs[i].grad.norm())], np.float64)
+    for h in handles:
+        h.remove()
+    path = os.path.join(HERE, case["name"] + ".npz")
+    np.savez_compressed(path, **out)
+    print("%-20s %5.1fs  %6.1f KB  loss=%.5f  max-prob=%.4f" % (
+        case["name"], time.time() - t0, os.path.getsize(path) / 1024, loss.item(), float(probs.max())))
+
+
+def op_vectors(get_cfg, build_model):
+    """Per-op vectors at production channel widths from the reference's own modules."""
+    from slowfast.models.wdf_attention_helper import ECA, SpatialAttention
+    from slowfast.models.custom_video_model_builder import FuseFastAndSlow
+    from slowfast.models.resnet_helper import ResBlock, BottleneckTransform
+    from slowfast.models.video_model_builder import FuseFastToSlow
+    from slowfast.models.stem_helper import ResNetBasicStem
+
+    out = {}
+    specs = {}
+
+    def run(name, mod, shapes, seed):
+        mod.eval()
+        fill_state_dict(mod.state_dict(), seed)
+        rs = np.random.RandomState(seed + 1000)
+        xs = [rs.standard_normal(s).astype(np.float32) for s in shapes]
+        with torch.no_grad():
+            y = mod(*[torch.from_numpy(x) for x in xs]) if len(xs) == 1 else mod([torch.from_numpy(x) for x in xs])
+        ys = y if isinstance(y, (list, tuple)) else [y]
+        for i, a in enumerate(ys):
+            out["%s/out%d" % (name, i)] = a.numpy()
+        specs[name] = dict(shapes=[list(s) for s in shapes], seed=seed,
+                           keys=list(mod.state_dict().keys()),
+                           key_shapes=[list(v.shape) for v in mod.state_dict().values()])
+
+    # SpatialAttention at the four R50 head dims (+ the tiny ShuffleNet/Ghost ones), N = 2*28*28 / 4*14*14
+    for c, thw in ((8, (2, 28, 28)), (32, (2, 28, 28)), (64, (4, 14, 14)), (128, (2, 14, 14)), (3, (4, 8, 8)),
+                   (28, (2, 14, 14))):
+        run("attn_c%d" % c, SpatialAttention(c, reduction=1), [(2, c) + thw], 100 + c)
+    run("eca_c32", ECA(32), [(2, 32, 4, 14, 14)], 140)
+    # production-width convs: 1x3x3 64->64 @56^2, temporal 3x1x1 1152->512 @14^2 (reduced T), stride-2 block
+    run("bottleneck_s3", BottleneckTransform(288, 512, 1, 2, 128, 1), [(1, 288, 2, 28, 28)], 150)
+    run("resblock_s5_fast", ResBlock(256, 256, 3, 1, BottleneckTransform, 64), [(1, 256, 8, 7, 7)], 151)
+    run("resblock_s4_slow", ResBlock(1152, 1024, 3, 2, BottleneckTransform, 256), [(1, 1152, 2, 14, 14)], 152)
+    run("stem_slow", ResNetBasicStem(3, 64, [1, 7, 7], [1, 2, 2], [0, 3, 3]), [(1, 3, 2, 64, 64)], 153)
+    run("stem_fast", ResNetBasicStem(3, 8, [5, 7, 7], [1, 2, 2], [2, 3, 3]), [(1, 3, 8, 64, 64)], 154)
+    run("f2s_k7", FuseFastToSlow(32, 2, 7, 4), [(1, 256, 2, 14, 14), (1, 32, 8, 14, 14)], 155)
+    run("cmda_256_32", FuseFastAndSlow([256, 32], 4, 8), [(1, 256, 2, 14, 14), (1, 32, 8, 14, 14)], 156)
+    out["specs"] = json.dumps(specs)
+    path = os.path.join(HERE, "op_vectors.npz")
+    np.savez_compressed(path, **out)
+    print("op_vectors           %6.1f KB" % (os.path.getsize(path) / 1024))
+
+
+if __name__ == "__main__":
+    torch.set_num_threads(8)
+    get_cfg, build_model = import_reference()
+    which = sys.argv[1:]
+    for c in CASES:
+        if not which or c["name"] in which:
+            run_case(c, get_cfg, build_model)
+    if not which or "ops" in which:
+        op_vectors(get_cfg, build_model)
