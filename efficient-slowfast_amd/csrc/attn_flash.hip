@@ -1,0 +1,282 @@
+// attn_flash.hip — CMDA SpatialAttention as a streaming (flash-style) fp32 kernel for gfx950.
+//
+// Reference semantics (wdf_attention_helper.py:41-54, then custom_video_model_builder.py:143-146):
+//     S[i,j] = sum_c q[i,c] k[j,c]            (NO 1/sqrt(d) scaling)
+//     P      = softmax_j(S)                    (over all N = T*H*W keys)
+//     o[i,c] = sum_j P[i,j] v[j,c]
+//     y      = gamma * o + x ;  z = relu(bn_s2f(y)) ;  z repeated alpha times along T ; written into
+//                                                      the fast tensor's first C channels (torch.cat)
+// The reference materialises S and P (2 x N^2 fp32 = 5 GB per clip at N = 25088); here neither ever
+// leaves registers: online softmax with running max / sum per query row.
+//
+// Mapping (one wavefront = 32 query rows, 4 wavefronts per workgroup, K/V tiles shared through LDS):
+//   * "swapped" first product  S^T = K * Q^T  on v_mfma_f32_32x32x2_f32: the accumulator then has the
+//     QUERY on the lane (col = lane&31) and 16 KEYS in registers (row = (r&3) + 8*(r>>2) + 4*(lane>>5)),
+//     so the row max / row sum of the softmax are in-register reductions plus ONE exchange between the
+//     two lane halves — no cross-lane shuffles per element.
+//   * second product  O^T = V^T * P^T : P^T's registers are already the B operand (k = key index on
+//     the register, col = query on the lane) — the key order kappa(s,h) = (s&3) + 8*(s>>2) + 4h is
+//     simply used for the V^T A-operand reads as well (ds_read_b32, conflict free: 32 consecutive
+//     channels per half-wave).  O^T keeps the query on the lane, so the per-row rescale is per-lane.
+//   * K rows are read for the first product as 16-byte fragments: lane half h takes channels
+//     8q+4h..8q+4h+3 for A (K) and B (Q) alike (K order permuted identically on both operands).
+//   * K/V tiles: global -> registers (issued before the tile's MFMAs) -> LDS (after them), double
+//     buffered, one barrier per tile.
+// fp32 throughout (the reference never leaves fp32; gfx950 has no reduced-precision f32 MFMA path).
+#include "common.h"
+
+namespace {
+
+struct AttnArgs {
+  const float* q; const float* k; const float* v; const float* x;
+  const float* gamma; const float* scale; const float* bias;
+  float* out;
+  int q_cs, k_cs, v_cs, x_cs, out_cs, out_coff;
+  int B, T, H, W, C, N, alpha, act, nqt;
+};
+
+constexpr float NEG_BIG = -3.0e38f;
+
+template <int CP, int VEC>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
+  constexpr int KT = (CP >= 128) ? 32 : 64;   // keys per LDS tile
+  constexpr int NSUB = KT / 32;
+  constexpr int KS = CP + 4;                  // K row pitch (dwords): ds_read_b128 conflict-free
+  constexpr int VS = CP;                      // V row pitch
+  constexpr int CT = (CP + 31) / 32;          // 32-channel output tiles
+  constexpr int QS = CP / 8;                  // 8-channel groups in the first product
+  constexpr int F4 = CP / 4;                  // float4 per row
+  constexpr int NF = (KT * F4 + 255) / 256;   // float4 per thread per tile (K and V each)
+
+  __shared__ __attribute__((aligned(16))) float smem[2 * KT * (KS + VS)];
+  float* const Ks = smem;
+  float* const Vs = smem + 2 * KT * KS;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int li = lane & 31;
+  const int lh = lane >> 5;
+  const int b = blockIdx.x / p.nqt;
+  const int q0 = (blockIdx.x - b * p.nqt) * 128 + wave * 32;
+  const int N = p.N, C = p.C;
+  const long brow = (long)b * N;
+
+  // ---- Q fragments (B operand of S^T = K Q^T): lane (i, h) holds Q[i][8q + 4h + e]
+  float qf[QS * 4];
+  {
+    const int qrow = q0 + li;
+    const bool ok = qrow < N;
+    const float* qp = p.q + (brow + (ok ? qrow : 0)) * p.q_cs;
+#pragma unroll
+    for (int s = 0; s < QS; ++s) {
+      const int c = s * 8 + lh * 4;
+      if (VEC == 4) {
+        f32x4 t = {0.f, 0.f, 0.f, 0.f};
+        if (ok && c < C) t = *reinterpret_cast<const f32x4*>(qp + c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) qf[s * 4 + e] = t[e];
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) qf[s * 4 + e] = (ok && (c + e) < C) ? qp[c + e] : 0.f;
+      }
+    }
+  }
+
+  f32x16 o[CT];
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[ct][r] = 0.f;
+  float m_run = NEG_BIG;
+  float l_run = 0.f;
+
+  f32x4 rk[NF], rv[NF];
+  auto load_tile = [&](int j0) {
+#pragma unroll
+    for (int u = 0; u < NF; ++u) {
+      const int f = tid + u * 256;
+      const int row = f / F4;
+      const int c = (f - row * F4) * 4;
+      const int j = j0 + row;
+      f32x4 tk = {0.f, 0.f, 0.f, 0.f}, tv = {0.f, 0.f, 0.f, 0.f};
+      if (f < KT * F4 && j < N) {
+        const float* kp = p.k + (brow + j) * p.k_cs + c;
+        const float* vp = p.v + (brow + j) * p.v_cs + c;
+        if (VEC == 4) {
+          if (c < C) {
+            tk = *reinterpret_cast<const f32x4*>(kp);
+            tv = *reinterpret_cast<const f32x4*>(vp);
+          }
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if ((c + e) < C) {
+              tk[e] = kp[e];
+              tv[e] = vp[e];
+            }
+        }
+      }
+      rk[u] = tk;
+      rv[u] = tv;
+    }
+  };
+  auto store_tile = [&](int buf) {
+#pragma unroll
+    for (int u = 0; u < NF; ++u) {
+      const int f = tid + u * 256;
+      if (f < KT * F4) {
+        const int row = f / F4;
+        const int c = (f - row * F4) * 4;
+        *reinterpret_cast<f32x4*>(Ks + (buf * KT + row) * KS + c) = rk[u];
+        *reinterpret_cast<f32x4*>(Vs + (buf * KT + row) * VS + c) = rv[u];
+      }
+    }
+  };
+
+  const int ntiles = (N + KT - 1) / KT;
+  load_tile(0);
+  store_tile(0);
+  __syncthreads();
+  for (int t = 0; t < ntiles; ++t) {
+    const int buf = t & 1;
+    const bool more = (t + 1) < ntiles;
+    if (more) load_tile((t + 1) * KT);
+#pragma unroll
+    for (int sub = 0; sub < NSUB; ++sub) {
+      const int jbase = t * KT + sub * 32;
+      if (jbase >= N) break;  // wave-uniform
+      // ---- S^T tile: rows = keys (registers), cols = queries (lanes)
+      f32x16 s;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[r] = 0.f;
+      const float* krow = Ks + (buf * KT + sub * 32 + li) * KS + lh * 4;
+#pragma unroll
+      for (int g = 0; g < QS; ++g) {
+        const f32x4 kf = *reinterpret_cast<const f32x4*>(krow + g * 8);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[e], qf[g * 4 + e], s, 0, 0, 0);
+      }
+      if (jbase + 32 > N) {  // ragged last tile: mask keys >= N (wave-uniform branch)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int j = jbase + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          if (j >= N) s[r] = NEG_BIG;
+        }
+      }
+      // ---- online softmax, one query row per lane (both halves hold half of the keys)
+      float mloc = s[0];
+#pragma unroll
+      for (int r = 1; r < 16; ++r) mloc = fmaxf(mloc, s[r]);
+      mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+      const float mnew = fmaxf(m_run, mloc);
+      const float alpha = __expf(m_run - mnew);
+      float lsum = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        s[r] = __expf(s[r] - mnew);
+        lsum += s[r];
+      }
+      l_run = l_run * alpha + lsum;
+      m_run = mnew;
+      if (__any(alpha != 1.0f)) {
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) o[ct][r] *= alpha;
+      }
+      // ---- O^T += V^T P^T : A = V[key kappa(r,h)][channel lane], B = P^T register r
+      const float* vrow = Vs + (buf * KT + sub * 32 + 4 * lh) * VS + (CP >= 32 ? li : (li & (CP - 1)));
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float vf = vrow[((r & 3) + 8 * (r >> 2)) * VS + ct * 32];
+          o[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(vf, s[r], o[ct], 0, 0, 0);
+        }
+      }
+    }
+    if (more) store_tile(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: y = gamma * o / l + x ; z = act(scale*y + bias) ; nearest-upsample x alpha along T
+  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  const int qrow = q0 + li;
+  if (qrow >= N) return;
+  const float inv_l = 1.0f / l_tot;
+  const float gamma = p.gamma ? p.gamma[0] : 1.0f;
+  const int HW = p.H * p.W;
+  const int tq = qrow / HW;
+  const int hw = qrow - tq * HW;
+  const float* xp = p.x + (brow + qrow) * p.x_cs;
+  const long orow0 = ((long)b * p.T * p.alpha + (long)tq * p.alpha) * HW + hw;
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int c0 = ct * 32 + 8 * g + 4 * lh;
+      if (c0 >= C) continue;
+      float y[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int c = c0 + e;
+        const bool okc = c < C;
+        float v = gamma * (o[ct][4 * g + e] * inv_l) + (okc ? xp[c] : 0.f);
+        if (p.scale && okc) v = v * p.scale[c] + p.bias[c];
+        if (p.act == SF_ACT_RELU) v = fmaxf(v, 0.f);
+        y[e] = v;
+      }
+      for (int r = 0; r < p.alpha; ++r) {
+        float* op = p.out + (orow0 + (long)r * HW) * p.out_cs + p.out_coff + c0;
+        if (VEC == 4) {
+          *reinterpret_cast<f32x4*>(op) = (f32x4){y[0], y[1], y[2], y[3]};
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if ((c0 + e) < C) op[e] = y[e];
+        }
+      }
+    }
+  }
+}
+
+template <int CP>
+int launch(const AttnArgs& a, bool vec4, hipStream_t s) {
+  const int grid = a.B * a.nqt;
+  if (vec4)
+    hipLaunchKernelGGL((attn_fwd_kernel<CP, 4>), dim3(grid), dim3(256), 0, s, a);
+  else
+    hipLaunchKernelGGL((attn_fwd_kernel<CP, 1>), dim3(grid), dim3(256), 0, s, a);
+  SF_CHECK_LAUNCH();
+  return SF_OK;
+}
+
+}  // namespace
+
+extern "C" int sf_attn_fwd(const float* q, int q_cs, const float* k, int k_cs, const float* v, int v_cs,
+                           const float* x, int x_cs, const float* gamma, const float* scale, const float* bias,
+                           int act, float* out, int out_cs, int out_coff, int B, int T, int H, int W, int C,
+                           int alpha, void* stream) {
+  if (!q || !k || !v || !x || !out) return SF_EINVAL;
+  if (B <= 0 || T <= 0 || H <= 0 || W <= 0 || C <= 0 || C > 128 || alpha <= 0) return SF_EINVAL;
+  if ((scale == nullptr) != (bias == nullptr)) return SF_EINVAL;
+  if (act != SF_ACT_NONE && act != SF_ACT_RELU) return SF_EINVAL;
+  const long N = (long)T * H * W;
+  if (N * B > 0x7fffffffL) return SF_EINVAL;
+  AttnArgs a;
+  a.q = q; a.k = k; a.v = v; a.x = x; a.gamma = gamma; a.scale = scale; a.bias = bias; a.out = out;
+  a.q_cs = q_cs; a.k_cs = k_cs; a.v_cs = v_cs; a.x_cs = x_cs; a.out_cs = out_cs; a.out_coff = out_coff;
+  a.B = B; a.T = T; a.H = H; a.W = W; a.C = C; a.N = (int)N; a.alpha = alpha; a.act = act;
+  a.nqt = sf_cdiv(N, 128);
+  const bool vec4 = (C % 4 == 0) && (q_cs % 4 == 0) && (k_cs % 4 == 0) && (v_cs % 4 == 0) && (x_cs % 4 == 0) &&
+                    (out_cs % 4 == 0) && (out_coff % 4 == 0) && sf_aligned16(q) && sf_aligned16(k) &&
+                    sf_aligned16(v) && sf_aligned16(x) && sf_aligned16(out);
+  hipStream_t s = (hipStream_t)stream;
+  if (C <= 8) return launch<8>(a, vec4, s);
+  if (C <= 16) return launch<16>(a, vec4, s);
+  if (C <= 32) return launch<32>(a, vec4, s);
+  if (C <= 64) return launch<64>(a, vec4, s);
+  return launch<128>(a, vec4, s);
+}

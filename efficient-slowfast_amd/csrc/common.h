@@ -1,0 +1,31 @@
+// common.h — shared device/host helpers for libsfhip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "sfhip.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define SF_CHECK_LAUNCH()                                   \
+  do {                                                      \
+    if (hipPeekAtLastError() != hipSuccess) return SF_ELAUNCH; \
+  } while (0)
+
+// Workgroups are dealt round-robin over the 8 XCDs (b and b+8 share an XCD's L2).  Remap so that each
+// XCD walks a CONTIGUOUS range of logical tiles: neighbouring tiles (same activation rows, next weight
+// columns) then hit the same 4 MiB L2.  Bijective for any n (guide §5 "XCD swizzle must be bijective").
+__device__ __forceinline__ int xcd_remap(int b, int n) {
+  const int q = n >> 3, r = n & 7, x = b & 7, i = b >> 3;
+  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
+}
+
+__device__ __forceinline__ float sf_act(float v, int act) {
+  if (act == SF_ACT_RELU) return v > 0.f ? v : 0.f;
+  if (act == SF_ACT_HSIGMOID) return fminf(fmaxf(v + 3.f, 0.f), 6.f) * (1.f / 6.f);
+  if (act == SF_ACT_SIGMOID) return 1.f / (1.f + __expf(-v));
+  return v;
+}
+
+static inline bool sf_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+static inline int sf_cdiv(long a, long b) { return (int)((a + b - 1) / b); }

@@ -1,0 +1,261 @@
+// conv_igemm.hip — dense 3-D convolution as an implicit GEMM on the fp32 matrix cores (gfx950).
+//
+//   out[m, n] = act( scale[n] * sum_{tap, c} in[row(m, tap), c] * w[n, tap, c] + bias[n] + res[m, n] )
+//
+// m runs over the B*To*Ho*Wo output positions (NDHWC), n over output channels, the K dimension over
+// (kT*kH*kW taps) x (input channels).  In NDHWC every tap of every output position is a CONTIGUOUS run
+// of Cin floats, so the A operand is gathered row-by-row with 16-byte loads and never materialised
+// (no im2col buffer); the zero padding of the convolution is a per-(row, tap) predicate.
+//
+// Tiling: 256 threads = 4 wavefronts; block tile BM x BN, K step 16.  A and B tiles are staged
+// global -> registers -> LDS as [row][16 k] with a 24-dword row pitch (conflict-free ds_read_b128),
+// double buffered, one barrier per K step; the next tile's global loads are issued before the MFMAs
+// of the current one (guide T14).  Each lane reads ONE 16-byte fragment per 16-row tile per K step:
+// lane quarter g = lane>>4 takes k = 4g..4g+3 and feeds them to four v_mfma_f32_16x16x4_f32 — the k
+// order inside a step is permuted identically for A and B, which a sum over k does not care about.
+// Accumulators: (BM/WM/16) x (BN/WN/16) tiles of 4 VGPRs.  C/D map: col = lane&15, row = 4*(lane>>4)+reg.
+//
+// Replaces: stem_helper.py:157-164, resnet_helper.py:182-223, :326-335, video_model_builder.py:128-135,
+// custom_video_model_builder.py:102-108, wdf_attention_helper.py:21-29, head_helper.py:181 (as 1x1x1).
+#include "common.h"
+
+namespace {
+
+struct ConvArgs {
+  sf_conv_desc d;
+  const float* in;
+  const float* w;
+  const float* scale;
+  const float* bias;
+  const float* res;
+  float* out;
+  int M;        // B*To*Ho*Wo
+  int ntaps;    // kT*kH*kW
+  int nb_n;     // number of N tiles
+  int nblocks;  // total tiles
+};
+
+constexpr int BK = 16;
+constexpr int LDK = 24;  // LDS row pitch in dwords (16 data + 8 pad): ds_read_b128 conflict-free
+
+template <int BM, int BN, int WM, int WN, int VEC>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
+  static_assert(WM * WN == 4, "4 wavefronts per workgroup");
+  constexpr int TM = BM / WM / 16;
+  constexpr int TN = BN / WN / 16;
+  constexpr int A_IT = BM / 64;
+  constexpr int B_IT = (BN + 63) / 64;
+  static_assert(TM >= 1 && TN >= 1, "tile too small");
+
+  __shared__ __attribute__((aligned(16))) float smem[2 * (BM + BN) * LDK];
+  float* const As = smem;
+  float* const Bs = smem + 2 * BM * LDK;
+
+  const sf_conv_desc& d = p.d;
+  const int tid = threadIdx.x;
+  const int bid = xcd_remap(blockIdx.x, p.nblocks);
+  const int tile_m = bid / p.nb_n;
+  const int tile_n = bid - tile_m * p.nb_n;
+  const int m0 = tile_m * BM;
+  const int n0 = tile_n * BN;
+
+  // ---- staging role: thread owns float4 column lc of rows lr + 64*i
+  const int lr = tid >> 2;
+  const int lc = (tid & 3) * 4;
+  int a_n[A_IT], a_t0[A_IT], a_h0[A_IT], a_w0[A_IT];
+  bool a_ok[A_IT];
+#pragma unroll
+  for (int i = 0; i < A_IT; ++i) {
+    const int m = m0 + lr + 64 * i;
+    a_ok[i] = m < p.M;
+    const int mm = a_ok[i] ? m : 0;
+    const int wo = mm % d.Wo;
+    const int t1 = mm / d.Wo;
+    const int ho = t1 % d.Ho;
+    const int t2 = t1 / d.Ho;
+    const int to = t2 % d.To;
+    a_n[i] = t2 / d.To;
+    a_t0[i] = to * d.sT - d.pT;
+    a_h0[i] = ho * d.sH - d.pH;
+    a_w0[i] = wo * d.sW - d.pW;
+  }
+  const long kpad = (long)p.ntaps * d.cin_pad;
+  const float* b_ptr[B_IT];
+  bool b_ok[B_IT];
+#pragma unroll
+  for (int j = 0; j < B_IT; ++j) {
+    const int rn = lr + 64 * j;
+    const int n = n0 + rn;
+    b_ok[j] = (rn < BN) && (n < d.Cout);
+    b_ptr[j] = p.w + (long)(b_ok[j] ? n : 0) * kpad + lc;
+  }
+
+  // ---- K iteration state: tap (kt,kh,kw) outer, 16-channel chunk inner
+  int kt = 0, kh = 0, kw = 0, c0 = 0, tap = 0;
+  long a_off[A_IT];
+  bool a_v[A_IT];
+  auto set_tap = [&]() {
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) {
+      const int ti = a_t0[i] + kt * d.dT;
+      const int hi = a_h0[i] + kh * d.dH;
+      const int wi = a_w0[i] + kw * d.dW;
+      a_v[i] = a_ok[i] && (unsigned)ti < (unsigned)d.Ti && (unsigned)hi < (unsigned)d.Hi &&
+               (unsigned)wi < (unsigned)d.Wi;
+      a_off[i] = ((((long)a_n[i] * d.Ti + ti) * d.Hi + hi) * d.Wi + wi) * d.in_cs + d.in_coff + lc;
+    }
+  };
+  set_tap();
+
+  f32x4 ra[A_IT], rb[B_IT];
+  auto load_global = [&]() {
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) {
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (VEC == 4) {
+        if (a_v[i] && (c0 + lc) < d.Cin) v = *reinterpret_cast<const f32x4*>(p.in + a_off[i] + c0);
+      } else {
+        if (a_v[i]) {
+          const float* s = p.in + a_off[i] + c0;
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if ((c0 + lc + e) < d.Cin) v[e] = s[e];
+        }
+      }
+      ra[i] = v;
+    }
+#pragma unroll
+    for (int j = 0; j < B_IT; ++j) {
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (b_ok[j]) v = *reinterpret_cast<const f32x4*>(b_ptr[j] + (long)tap * d.cin_pad + c0);
+      rb[j] = v;
+    }
+  };
+  auto advance = [&]() {
+    c0 += BK;
+    if (c0 >= d.cin_pad) {
+      c0 = 0;
+      ++tap;
+      if (++kw == d.kW) {
+        kw = 0;
+        if (++kh == d.kH) {
+          kh = 0;
+          ++kt;
+        }
+      }
+      set_tap();
+    }
+  };
+  auto store_lds = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i)
+      *reinterpret_cast<f32x4*>(As + (buf * BM + lr + 64 * i) * LDK + lc) = ra[i];
+#pragma unroll
+    for (int j = 0; j < B_IT; ++j)
+      if (lr + 64 * j < BN) *reinterpret_cast<f32x4*>(Bs + (buf * BN + lr + 64 * j) * LDK + lc) = rb[j];
+  };
+
+  // ---- compute role
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave / WN;
+  const int wn = wave - wm * WN;
+  const int fr = lane & 15;
+  const int fg = lane >> 4;
+  f32x4 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int nk = p.ntaps * (d.cin_pad / BK);
+  load_global();
+  store_lds(0);
+  __syncthreads();
+  for (int it = 0; it < nk; ++it) {
+    const int buf = it & 1;
+    const bool more = (it + 1) < nk;
+    if (more) {
+      advance();
+      load_global();
+    }
+    const float* as = As + (buf * BM + wm * (BM / WM) + fr) * LDK + fg * 4;
+    const float* bs = Bs + (buf * BN + wn * (BN / WN) + fr) * LDK + fg * 4;
+    f32x4 a[TM], b[TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const f32x4*>(as + i * 16 * LDK);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const f32x4*>(bs + j * 16 * LDK);
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][s], b[j][s], acc[i][j], 0, 0, 0);
+    if (more) store_lds(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: lane holds channel n = .. + fr, rows 4*fg + reg
+  const bool has_res = p.res != nullptr;
+  const bool relu = d.act == SF_ACT_RELU;
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int n = n0 + wn * (BN / WN) + j * 16 + fr;
+    if (n >= d.Cout) continue;
+    const float sc = p.scale ? p.scale[n] : 1.f;
+    const float bi = p.bias ? p.bias[n] : 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = m0 + wm * (BM / WM) + i * 16 + fg * 4 + r;
+        if (m >= p.M) continue;
+        float v = acc[i][j][r] * sc + bi;
+        if (has_res) v += p.res[(long)m * d.res_cs + d.res_coff + n];
+        v = relu ? fmaxf(v, 0.f) : v;
+        p.out[(long)m * d.out_cs + d.out_coff + (long)n * d.out_cmul] = v;
+      }
+    }
+  }
+}
+
+template <int BM, int BN, int WM, int WN>
+int launch(const ConvArgs& a, bool vec4, hipStream_t s) {
+  ConvArgs p = a;
+  p.nb_n = sf_cdiv(p.d.Cout, BN);
+  p.nblocks = sf_cdiv(p.M, BM) * p.nb_n;
+  if (vec4)
+    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, 4>), dim3(p.nblocks), dim3(256), 0, s, p);
+  else
+    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, 1>), dim3(p.nblocks), dim3(256), 0, s, p);
+  SF_CHECK_LAUNCH();
+  return SF_OK;
+}
+
+}  // namespace
+
+extern "C" int sf_conv_fwd(const sf_conv_desc* d, const float* in, const float* w_packed, const float* scale,
+                           const float* bias, const float* res, float* out, void* stream) {
+  if (!d || !in || !w_packed || !out) return SF_EINVAL;
+  if (d->Cin <= 0 || d->Cout <= 0 || d->cin_pad < d->Cin || (d->cin_pad % BK) != 0) return SF_EINVAL;
+  if (d->kT <= 0 || d->kH <= 0 || d->kW <= 0 || d->sT <= 0 || d->sH <= 0 || d->sW <= 0) return SF_EINVAL;
+  if (d->out_cmul <= 0) return SF_EINVAL;
+  if (d->act != SF_ACT_NONE && d->act != SF_ACT_RELU) return SF_EINVAL;
+  if (!sf_aligned16(w_packed)) return SF_EALIGN;
+  const long M = (long)d->N * d->To * d->Ho * d->Wo;
+  if (M <= 0 || M > 0x7fffffffL) return SF_EINVAL;
+  ConvArgs a;
+  a.d = *d;
+  a.in = in; a.w = w_packed; a.scale = scale; a.bias = bias; a.res = res; a.out = out;
+  a.M = (int)M;
+  a.ntaps = d->kT * d->kH * d->kW;
+  a.nb_n = 0; a.nblocks = 0;
+  const bool vec4 = (d->Cin % 4 == 0) && (d->in_cs % 4 == 0) && (d->in_coff % 4 == 0) && sf_aligned16(in);
+  hipStream_t s = (hipStream_t)stream;
+  if (d->Cout <= 16) return launch<256, 16, 4, 1>(a, vec4, s);
+  if (d->Cout <= 32) return launch<256, 32, 4, 1>(a, vec4, s);
+  if (d->Cout <= 64) return launch<128, 64, 2, 2>(a, vec4, s);
+  return launch<128, 128, 2, 2>(a, vec4, s);
+}

@@ -1,0 +1,440 @@
+// elementwise.hip — the bandwidth-bound side of the SlowFast / CMDA path on gfx950 (NDHWC, fp32):
+// layout conversion, pooling, depthwise convolution, the ECA / SqueezeExcite channel gates, the head's
+// activation+mean and channel-slice copies.  All of these are HBM-bound (<= 10 FLOP/B): the design rule
+// is one pass over the data, channel-contiguous (coalesced) accesses, 16-byte vectors whenever the
+// channel count / pitch / offset are multiples of 4, and outputs written straight into the consumer's
+// (possibly wider, concatenated) tensor.
+#include "common.h"
+
+namespace {
+
+constexpr int TPB = 256;
+
+// ------------------------------------------------------------------------------------------------
+// NCTHW -> padded NDHWC.  One thread per destination pixel; reads are coalesced along W per channel
+// plane, writes are cpad contiguous floats (one 16-byte store when cpad == 4).
+__global__ void ncthw_to_ndhwc_kernel(const float* __restrict__ src, float* __restrict__ dst, int N, int C,
+                                      int T, int H, int W, int cpad, int ph, int pw, int Hp, int Wp, long total) {
+  const long idx = (long)blockIdx.x * TPB + threadIdx.x;
+  if (idx >= total) return;
+  const int wp = (int)(idx % Wp);
+  long r = idx / Wp;
+  const int hp = (int)(r % Hp);
+  r /= Hp;
+  const int t = (int)(r % T);
+  const int n = (int)(r / T);
+  const int h = hp - ph, w = wp - pw;
+  const bool in = (unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W;
+  float* o = dst + idx * cpad;
+  const long plane = (long)T * H * W;
+  const float* s = src + ((long)n * C * T + t) * H * W + (long)h * W + w;
+  if (cpad == 4) {
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (in) {
+      v[0] = s[0];
+      if (C > 1) v[1] = s[plane];
+      if (C > 2) v[2] = s[2 * plane];
+      if (C > 3) v[3] = s[3 * plane];
+    }
+    *reinterpret_cast<f32x4*>(o) = v;
+  } else {
+    for (int c = 0; c < cpad; ++c) o[c] = (in && c < C) ? s[c * plane] : 0.f;
+  }
+}
+
+__global__ void ndhwc_to_ncthw_kernel(const float* __restrict__ src, int cs, int coff, float* __restrict__ dst,
+                                      int C, long thw, long total) {
+  const long idx = (long)blockIdx.x * TPB + threadIdx.x;
+  if (idx >= total) return;
+  const long pos = idx % thw;
+  const long r = idx / thw;
+  const int c = (int)(r % C);
+  const long n = r / C;
+  dst[idx] = src[(n * thw + pos) * cs + coff + c];
+}
+
+// ------------------------------------------------------------------------------------------------
+// Generic 3-D max / average pooling, thread per (output position, VEC channels).
+template <int VEC>
+__global__ void pool_kernel(const sf_pool_desc d, const float* __restrict__ in, float* __restrict__ out,
+                            long total) {
+  const long idx = (long)blockIdx.x * TPB + threadIdx.x;
+  if (idx >= total) return;
+  const int cv = (d.C + VEC - 1) / VEC;
+  const int c = (int)(idx % cv) * VEC;
+  long r = idx / cv;
+  const int wo = (int)(r % d.Wo);
+  r /= d.Wo;
+  const int ho = (int)(r % d.Ho);
+  r /= d.Ho;
+  const int to = (int)(r % d.To);
+  const int n = (int)(r / d.To);
+  float acc[VEC];
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) acc[e] = d.is_avg ? 0.f : -3.0e38f;
+  for (int kt = 0; kt < d.kT; ++kt) {
+    const int ti = to * d.sT - d.pT + kt;
+    if ((unsigned)ti >= (unsigned)d.Ti) continue;
+    for (int kh = 0; kh < d.kH; ++kh) {
+      const int hi = ho * d.sH - d.pH + kh;
+      if ((unsigned)hi >= (unsigned)d.Hi) continue;
+      for (int kw = 0; kw < d.kW; ++kw) {
+        const int wi = wo * d.sW - d.pW + kw;
+        if ((unsigned)wi >= (unsigned)d.Wi) continue;
+        const float* s = in + ((((long)n * d.Ti + ti) * d.Hi + hi) * d.Wi + wi) * d.in_cs + d.in_coff + c;
+        if (VEC == 4) {
+          const f32x4 v = *reinterpret_cast<const f32x4*>(s);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[e] = d.is_avg ? acc[e] + v[e] : fmaxf(acc[e], v[e]);
+        } else {
+          acc[0] = d.is_avg ? acc[0] + s[0] : fmaxf(acc[0], s[0]);
+        }
+      }
+    }
+  }
+  const float inv = d.is_avg ? 1.f / (float)(d.kT * d.kH * d.kW) : 1.f;
+  float* o = out + ((((long)n * d.To + to) * d.Ho + ho) * d.Wo + wo) * d.out_cs + d.out_coff + c;
+  if (VEC == 4) {
+    *reinterpret_cast<f32x4*>(o) = (f32x4){acc[0] * inv, acc[1] * inv, acc[2] * inv, acc[3] * inv};
+  } else {
+    o[0] = acc[0] * inv;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Depthwise convolution + folded BN + residual + ReLU, thread per (output position, VEC channels).
+// Neighbouring threads share taps through L1/L2; the op moves ~2 floats per MAC and is HBM-bound.
+template <int VEC>
+__global__ void dwconv_kernel(const sf_conv_desc d, const float* __restrict__ in, const float* __restrict__ w,
+                              const float* __restrict__ scale, const float* __restrict__ bias,
+                              const float* __restrict__ res, float* __restrict__ out, long total) {
+  const long idx = (long)blockIdx.x * TPB + threadIdx.x;
+  if (idx >= total) return;
+  const int cv = (d.Cout + VEC - 1) / VEC;
+  const int c = (int)(idx % cv) * VEC;
+  long r = idx / cv;
+  const long m = r;
+  const int wo = (int)(r % d.Wo);
+  r /= d.Wo;
+  const int ho = (int)(r % d.Ho);
+  r /= d.Ho;
+  const int to = (int)(r % d.To);
+  const int n = (int)(r / d.To);
+  float acc[VEC];
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) acc[e] = 0.f;
+  int tap = 0;
+  for (int kt = 0; kt < d.kT; ++kt) {
+    const int ti = to * d.sT - d.pT + kt * d.dT;
+    for (int kh = 0; kh < d.kH; ++kh) {
+      const int hi = ho * d.sH - d.pH + kh * d.dH;
+      for (int kw = 0; kw < d.kW; ++kw, ++tap) {
+        const int wi = wo * d.sW - d.pW + kw * d.dW;
+        if ((unsigned)ti >= (unsigned)d.Ti || (unsigned)hi >= (unsigned)d.Hi || (unsigned)wi >= (unsigned)d.Wi)
+          continue;
+        const float* s = in + ((((long)n * d.Ti + ti) * d.Hi + hi) * d.Wi + wi) * d.in_cs + d.in_coff + c;
+        const float* wp = w + (long)tap * d.cin_pad + c;
+        if (VEC == 4) {
+          const f32x4 v = *reinterpret_cast<const f32x4*>(s);
+          const f32x4 ww = *reinterpret_cast<const f32x4*>(wp);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[e] = fmaf(v[e], ww[e], acc[e]);
+        } else {
+          acc[0] = fmaf(s[0], wp[0], acc[0]);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) {
+    float v = acc[e];
+    if (scale) v = v * scale[c + e] + bias[c + e];
+    if (res) v += res[m * d.res_cs + d.res_coff + c + e];
+    if (d.act == SF_ACT_RELU) v = fmaxf(v, 0.f);
+    out[m * d.out_cs + d.out_coff + (long)(c + e) * d.out_cmul] = v;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// ECA / SE squeeze: partial[b][blk][c] = sum over the block's rows of max_{r<alpha} x[b, t*alpha+r, hw, c]
+constexpr int POOL_P = 64;  // partial blocks per batch element (fixed => bit-reproducible sums)
+
+__global__ void tmax_partial_kernel(const float* __restrict__ x, int cs, int coff, int T, int HW, int C,
+                                    int alpha, int CB, float* __restrict__ partial) {
+  __shared__ float red[TPB];
+  const int blk = blockIdx.x, cb = blockIdx.y, b = blockIdx.z;
+  const int cl = threadIdx.x % CB, rl = threadIdx.x / CB, rpi = TPB / CB;
+  const int c = cb * CB + cl;
+  const int To = T / alpha;
+  const long rows = (long)To * HW;
+  const long per = (rows + POOL_P - 1) / POOL_P;
+  const long r0 = (long)blk * per;
+  const long r1 = (r0 + per < rows) ? r0 + per : rows;
+  float sum = 0.f;
+  if (c < C) {
+    for (long r = r0 + rl; r < r1; r += rpi) {
+      const long t = r / HW, hw = r - t * HW;
+      const float* s = x + (((long)b * T + t * alpha) * HW + hw) * cs + coff + c;
+      float mx = s[0];
+      for (int a = 1; a < alpha; ++a) mx = fmaxf(mx, s[(long)a * HW * cs]);
+      sum += mx;
+    }
+  }
+  red[threadIdx.x] = sum;
+  __syncthreads();
+  if (rl == 0 && c < C) {
+    float tot = 0.f;
+    for (int i = 0; i < rpi; ++i) tot += red[i * CB + cl];
+    partial[((long)b * POOL_P + blk) * C + c] = tot;
+  }
+}
+
+__global__ void tmax_final_kernel(const float* __restrict__ partial, int C, float inv_count,
+                                  float* __restrict__ pooled) {
+  const int b = blockIdx.y;
+  const int c = blockIdx.x * TPB + threadIdx.x;
+  if (c >= C) return;
+  float tot = 0.f;
+  for (int i = 0; i < POOL_P; ++i) tot += partial[((long)b * POOL_P + i) * C + c];
+  pooled[(long)b * C + c] = tot * inv_count;
+}
+
+// out = act(scale * (max_r x * gate) + bias); gate from ECA's 3-tap conv over channels or SE's hard-sigmoid.
+template <int VEC>
+__global__ void gate_apply_kernel(const float* __restrict__ x, int cs, int coff, int T, int HW, int C, int alpha,
+                                  const float* __restrict__ pooled, const float* __restrict__ w3,
+                                  const float* __restrict__ scale, const float* __restrict__ bias, int act,
+                                  float* __restrict__ out, int out_cs, int out_coff) {
+  extern __shared__ float gsm[];  // gate[C], eff_scale[C], eff_bias[C]
+  float* gate = gsm;
+  const int b = blockIdx.y;
+  const float* pb = pooled + (long)b * C;
+  for (int c = threadIdx.x; c < C; c += TPB) {
+    float g;
+    if (w3) {
+      const float l = c > 0 ? pb[c - 1] : 0.f;
+      const float r = c + 1 < C ? pb[c + 1] : 0.f;
+      g = 1.f / (1.f + __expf(-(w3[0] * l + w3[1] * pb[c] + w3[2] * r)));
+    } else {
+      g = fminf(fmaxf(pb[c] + 3.f, 0.f), 6.f) * (1.f / 6.f);
+    }
+    gate[c] = g;
+  }
+  __syncthreads();
+  const int cv = (C + VEC - 1) / VEC;
+  const int To = T / alpha;
+  const long total = (long)To * HW * cv;
+  for (long idx = (long)blockIdx.x * TPB + threadIdx.x; idx < total; idx += (long)gridDim.x * TPB) {
+    const int c = (int)(idx % cv) * VEC;
+    const long r = idx / cv;
+    const long t = r / HW, hw = r - t * HW;
+    const float* s = x + (((long)b * T + t * alpha) * HW + hw) * cs + coff + c;
+    float* o = out + ((long)b * To * HW + r) * out_cs + out_coff + c;
+    if (VEC == 4) {
+      f32x4 mx = *reinterpret_cast<const f32x4*>(s);
+      for (int a = 1; a < alpha; ++a) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(s + (long)a * HW * cs);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) mx[e] = fmaxf(mx[e], v[e]);
+      }
+      f32x4 y;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float v = mx[e] * gate[c + e];
+        if (scale) v = v * scale[c + e] + bias[c + e];
+        y[e] = (act == SF_ACT_RELU) ? fmaxf(v, 0.f) : v;
+      }
+      *reinterpret_cast<f32x4*>(o) = y;
+    } else {
+      float mx = s[0];
+      for (int a = 1; a < alpha; ++a) mx = fmaxf(mx, s[(long)a * HW * cs]);
+      float v = mx * gate[c];
+      if (scale) v = v * scale[c] + bias[c];
+      o[0] = (act == SF_ACT_RELU) ? fmaxf(v, 0.f) : v;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// head tail: out[b,k] = mean_p act(logits[b,p,:])[k]
+__global__ void head_act_mean_kernel(const float* __restrict__ logits, int P, int K, int act,
+                                     float* __restrict__ out) {
+  __shared__ float red[TPB];
+  const int b = blockIdx.x;
+  const float invP = 1.f / (float)P;
+  for (int k = threadIdx.x; k < K; k += TPB) out[(long)b * K + k] = 0.f;
+  for (int pi = 0; pi < P; ++pi) {
+    const float* l = logits + ((long)b * P + pi) * K;
+    float mx = -3.0e38f, sum = 1.f;
+    if (act == SF_ACT_SOFTMAX) {
+      for (int k = threadIdx.x; k < K; k += TPB) mx = fmaxf(mx, l[k]);
+      red[threadIdx.x] = mx;
+      __syncthreads();
+      for (int s = TPB / 2; s > 0; s >>= 1) {
+        if (threadIdx.x < s) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + s]);
+        __syncthreads();
+      }
+      mx = red[0];
+      __syncthreads();
+      float part = 0.f;
+      for (int k = threadIdx.x; k < K; k += TPB) part += expf(l[k] - mx);
+      red[threadIdx.x] = part;
+      __syncthreads();
+      for (int s = TPB / 2; s > 0; s >>= 1) {
+        if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+      }
+      sum = red[0];
+      __syncthreads();
+    }
+    for (int k = threadIdx.x; k < K; k += TPB) {
+      float v = l[k];
+      if (act == SF_ACT_SOFTMAX) v = expf(v - mx) / sum;
+      else if (act == SF_ACT_SIGMOID) v = 1.f / (1.f + expf(-v));
+      else if (act == SF_ACT_RELU) v = fmaxf(v, 0.f);
+      out[(long)b * K + k] += v * invP;
+    }
+  }
+}
+
+__global__ void copy_channels_kernel(const float* __restrict__ in, int in_cs, int in_coff, float* __restrict__ out,
+                                     int out_cs, int out_coff, int out_cmul, int C, long total) {
+  const long idx = (long)blockIdx.x * TPB + threadIdx.x;
+  if (idx >= total) return;
+  const int c = (int)(idx % C);
+  const long r = idx / C;
+  out[r * out_cs + out_coff + (long)c * out_cmul] = in[r * in_cs + in_coff + c];
+}
+
+inline int pow2ceil(int v) {
+  int p = 1;
+  while (p < v) p <<= 1;
+  return p;
+}
+
+}  // namespace
+
+// =================================================================================================
+extern "C" int sf_abi_version(void) { return 1; }
+extern "C" const char* sf_build_arch(void) { return "gfx950"; }
+
+extern "C" int sf_ncthw_to_ndhwc(const float* src, float* dst, int N, int C, int T, int H, int W, int cpad,
+                                 int ph, int pw, int Wp, void* stream) {
+  if (!src || !dst || N <= 0 || C <= 0 || T <= 0 || H <= 0 || W <= 0 || cpad < C || ph < 0 || pw < 0 ||
+      Wp < W + 2 * pw)
+    return SF_EINVAL;
+  if (cpad == 4 && !sf_aligned16(dst)) return SF_EALIGN;
+  const int Hp = H + 2 * ph;
+  const long total = (long)N * T * Hp * Wp;
+  hipLaunchKernelGGL(ncthw_to_ndhwc_kernel, dim3(sf_cdiv(total, TPB)), dim3(TPB), 0, (hipStream_t)stream, src,
+                     dst, N, C, T, H, W, cpad, ph, pw, Hp, Wp, total);
+  SF_CHECK_LAUNCH();
+  return SF_OK;
+}
+
+extern "C" int sf_ndhwc_to_ncthw(const float* src, int cs, int coff, float* dst, int N, int C, int T, int H,
+                                 int W, void* stream) {
+  if (!src || !dst || N <= 0 || C <= 0 || T <= 0 || H <= 0 || W <= 0 || cs < coff + C) return SF_EINVAL;
+  const long thw = (long)T * H * W;
+  const long total = (long)N * C * thw;
+  hipLaunchKernelGGL(ndhwc_to_ncthw_kernel, dim3(sf_cdiv(total, TPB)), dim3(TPB), 0, (hipStream_t)stream, src,
+                     cs, coff, dst, C, thw, total);
+  SF_CHECK_LAUNCH();
+  return SF_OK;
+}
+
+extern "C" int sf_pool_fwd(const sf_pool_desc* d, const float* in, float* out, void* stream) {
+  if (!d || !in || !out || d->C <= 0 || d->kT <= 0 || d->kH <= 0 || d->kW <= 0) return SF_EINVAL;
+  const bool vec4 = (d->C % 4 == 0) && (d->in_cs % 4 == 0) && (d->in_coff % 4 == 0) && (d->out_cs % 4 == 0) &&
+                    (d->out_coff % 4 == 0) && sf_aligned16(in) && sf_aligned16(out);
+  const long pos = (long)d->N * d->To * d->Ho * d->Wo;
+  if (vec4) {
+    const long total = pos * (d->C / 4);
+    hipLaunchKernelGGL(pool_kernel<4>, dim3(sf_cdiv(total, TPB)), dim3(TPB), 0, (hipStream_t)stream, *d, in, out,
+                       total);
+  } else {
+    const long total = pos * d->C;
+    hipLaunchKernelGGL(pool_kernel<1>, dim3(sf_cdiv(total, TPB)), dim3(TPB), 0, (hipStream_t)stream, *d, in, out,
+                       total);
+  }
+  SF_CHECK_LAUNCH();
+  return SF_OK;
+}
+
+extern "C" int sf_dwconv_fwd(const sf_conv_desc* d, const float* in, const float* w_packed, const float* scale,
+                             const float* bias, const float* res, float* out, void* stream) {
+  if (!d || !in || !w_packed || !out || d->Cout <= 0 || d->Cout > d->Cin || d->cin_pad < d->Cin) return SF_EINVAL;
+  if ((scale == nullptr) != (bias == nullptr)) return SF_EINVAL;
+  if (d->act != SF_ACT_NONE && d->act != SF_ACT_RELU) return SF_EINVAL;
+  const bool vec4 = (d->Cout % 4 == 0) && (d->in_cs % 4 == 0) && (d->in_coff % 4 == 0) && (d->cin_pad % 4 == 0) &&
+                    sf_aligned16(in) && sf_aligned16(w_packed);
+  const long pos = (long)d->N * d->To * d->Ho * d->Wo;
+  if (vec4) {
+    const long total = pos * (d->Cout / 4);
+    hipLaunchKernelGGL(dwconv_kernel<4>, dim3(sf_cdiv(total, TPB)), dim3(TPB), 0, (hipStream_t)stream, *d, in,
+                       w_packed, scale, bias, res, out, total);
+  } else {
+    const long total = pos * d->Cout;
+    hipLaunchKernelGGL(dwconv_kernel<1>, dim3(sf_cdiv(total, TPB)), dim3(TPB), 0, (hipStream_t)stream, *d, in,
+                       w_packed, scale, bias, res, out, total);
+  }
+  SF_CHECK_LAUNCH();
+  return SF_OK;
+}
+
+extern "C" long sf_tmax_mean_ws_floats(int N, int C) { return (long)N * POOL_P * C; }
+
+extern "C" int sf_tmax_mean(const float* x, int cs, int coff, int N, int T, int H, int W, int C, int alpha,
+                            float* pooled, float* ws, void* stream) {
+  if (!x || !pooled || !ws || N <= 0 || T <= 0 || H <= 0 || W <= 0 || C <= 0 || alpha <= 0 || (T % alpha) != 0)
+    return SF_EINVAL;
+  const int CB = pow2ceil(C) < TPB ? pow2ceil(C) : TPB;
+  const int ncb = sf_cdiv(C, CB);
+  hipLaunchKernelGGL(tmax_partial_kernel, dim3(POOL_P, ncb, N), dim3(TPB), 0, (hipStream_t)stream, x, cs, coff, T,
+                     H * W, C, alpha, CB, ws);
+  const float inv = 1.f / (float)((long)(T / alpha) * H * W);
+  hipLaunchKernelGGL(tmax_final_kernel, dim3(sf_cdiv(C, TPB), N), dim3(TPB), 0, (hipStream_t)stream, ws, C, inv,
+                     pooled);
+  SF_CHECK_LAUNCH();
+  return SF_OK;
+}
+
+extern "C" int sf_gate_apply(const float* x, int cs, int coff, int N, int T, int H, int W, int C, int alpha,
+                             const float* pooled, const float* w3, const float* scale, const float* bias, int act,
+                             float* out, int out_cs, int out_coff, void* stream) {
+  if (!x || !pooled || !out || N <= 0 || C <= 0 || alpha <= 0 || (T % alpha) != 0) return SF_EINVAL;
+  if ((scale == nullptr) != (bias == nullptr)) return SF_EINVAL;
+  if (act != SF_ACT_NONE && act != SF_ACT_RELU) return SF_EINVAL;
+  const bool vec4 = (C % 4 == 0) && (cs % 4 == 0) && (coff % 4 == 0) && (out_cs % 4 == 0) && (out_coff % 4 == 0) &&
+                    sf_aligned16(x) && sf_aligned16(out);
+  const long rows = (long)(T / alpha) * H * W;
+  const long total = rows * (vec4 ? C / 4 : C);
+  int gx = sf_cdiv(total, TPB);
+  if (gx > 2048) gx = 2048;
+  const size_t shm = (size_t)C * sizeof(float);
+  if (vec4)
+    hipLaunchKernelGGL(gate_apply_kernel<4>, dim3(gx, N), dim3(TPB), shm, (hipStream_t)stream, x, cs, coff, T,
+                       H * W, C, alpha, pooled, w3, scale, bias, act, out, out_cs, out_coff);
+  else
+    hipLaunchKernelGGL(gate_apply_kernel<1>, dim3(gx, N), dim3(TPB), shm, (hipStream_t)stream, x, cs, coff, T,
+                       H * W, C, alpha, pooled, w3, scale, bias, act, out, out_cs, out_coff);
+  SF_CHECK_LAUNCH();
+  return SF_OK;
+}
+
+extern "C" int sf_head_act_mean(const float* logits, int B, int P, int K, int act, float* out, void* stream) {
+  if (!logits || !out || B <= 0 || P <= 0 || K <= 0) return SF_EINVAL;
+  hipLaunchKernelGGL(head_act_mean_kernel, dim3(B), dim3(TPB), 0, (hipStream_t)stream, logits, P, K, act, out);
+  SF_CHECK_LAUNCH();
+  return SF_OK;
+}
+
+extern "C" int sf_copy_channels(const float* in, int in_cs, int in_coff, float* out, int out_cs, int out_coff,
+                                int out_cmul, long rows, int C, void* stream) {
+  if (!in || !out || rows <= 0 || C <= 0 || out_cmul <= 0) return SF_EINVAL;
+  const long total = rows * C;
+  hipLaunchKernelGGL(copy_channels_kernel, dim3(sf_cdiv(total, TPB)), dim3(TPB), 0, (hipStream_t)stream, in,
+                     in_cs, in_coff, out, out_cs, out_coff, out_cmul, C, total);
+  SF_CHECK_LAUNCH();
+  return SF_OK;
+}

@@ -1,0 +1,307 @@
+"""sfhip — ctypes binding of libsfhip.so (include/sfhip.h), the MI355X kernels of the SlowFast/CMDA path.
+
+PyTorch is used for device memory (torch.empty on the caching allocator), the current HIP stream and
+parameter preprocessing only; every activation-sized computation is a libsfhip kernel.  There is NO CPU
+or eager-PyTorch fallback: if the shared library is missing, or a tensor is not on a GPU, the ops raise.
+
+Activations are NDHWC views (`Act`): a contiguous buffer [N, T, H, W, pitch] plus a channel slice
+(coff, C).  Producers write straight into slices of wider buffers, so torch.cat never runs on the path.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libsfhip.so")
+_lib = None
+
+ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_SOFTMAX, ACT_HSIGMOID = 0, 1, 2, 3, 4
+_ERR = {-1: "SF_EINVAL (inconsistent descriptor)", -2: "SF_EALIGN", -3: "SF_ELAUNCH (hip launch failed)"}
+
+
+class SfhipError(RuntimeError):
+    pass
+
+
+class ConvDesc(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int) for n in (
+        "N", "Ti", "Hi", "Wi", "Cin", "in_cs", "in_coff", "To", "Ho", "Wo", "Cout", "out_cs", "out_coff",
+        "out_cmul", "kT", "kH", "kW", "sT", "sH", "sW", "pT", "pH", "pW", "dT", "dH", "dW", "cin_pad", "act",
+        "res_cs", "res_coff")]
+
+
+class PoolDesc(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int) for n in (
+        "N", "Ti", "Hi", "Wi", "C", "in_cs", "in_coff", "To", "Ho", "Wo", "out_cs", "out_coff",
+        "kT", "kH", "kW", "sT", "sH", "sW", "pT", "pH", "pW", "is_avg")]
+
+
+EXPORTS = [
+    "sf_abi_version", "sf_build_arch", "sf_ncthw_to_ndhwc", "sf_ndhwc_to_ncthw", "sf_conv_fwd", "sf_dwconv_fwd",
+    "sf_pool_fwd", "sf_tmax_mean_ws_floats", "sf_tmax_mean", "sf_gate_apply", "sf_attn_fwd", "sf_head_act_mean",
+    "sf_copy_channels",
+]
+
+
+def lib_path():
+    return _LIB_PATH
+
+
+def lib():
+    """Load libsfhip.so (built by `make -C efficient-slowfast_amd/csrc` / __graft_entry__.build())."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            raise SfhipError(
+                "libsfhip.so not found at %s — build it with `make -C efficient-slowfast_amd/csrc` "
+                "(there is no CPU fallback for the SlowFast hot path)" % _LIB_PATH)
+        L = ctypes.CDLL(_LIB_PATH)
+        vp, ci, cl = ctypes.c_void_p, ctypes.c_int, ctypes.c_long
+        L.sf_abi_version.restype = ci
+        L.sf_build_arch.restype = ctypes.c_char_p
+        L.sf_ncthw_to_ndhwc.argtypes = [vp, vp] + [ci] * 9 + [vp]
+        L.sf_ndhwc_to_ncthw.argtypes = [vp, ci, ci, vp] + [ci] * 5 + [vp]
+        L.sf_conv_fwd.argtypes = [ctypes.POINTER(ConvDesc)] + [vp] * 7
+        L.sf_dwconv_fwd.argtypes = [ctypes.POINTER(ConvDesc)] + [vp] * 7
+        L.sf_pool_fwd.argtypes = [ctypes.POINTER(PoolDesc), vp, vp, vp]
+        L.sf_tmax_mean_ws_floats.argtypes = [ci, ci]
+        L.sf_tmax_mean_ws_floats.restype = cl
+        L.sf_tmax_mean.argtypes = [vp, ci, ci] + [ci] * 6 + [vp, vp, vp]
+        L.sf_gate_apply.argtypes = [vp, ci, ci] + [ci] * 6 + [vp, vp, vp, vp, ci, vp, ci, ci, vp]
+        L.sf_attn_fwd.argtypes = [vp, ci, vp, ci, vp, ci, vp, ci, vp, vp, vp, ci, vp, ci, ci] + [ci] * 6 + [vp]
+        L.sf_head_act_mean.argtypes = [vp, ci, ci, ci, ci, vp, vp]
+        L.sf_copy_channels.argtypes = [vp, ci, ci, vp, ci, ci, ci, cl, ci, vp]
+        for name in EXPORTS:
+            fn = getattr(L, name)
+            if name not in ("sf_build_arch", "sf_tmax_mean_ws_floats"):
+                fn.restype = ci
+        _lib = L
+    return _lib
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise SfhipError("%s failed: %s" % (what, _ERR.get(rc, rc)))
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _require_gpu(t, what):
+    if not t.is_cuda:
+        raise SfhipError("%s: tensor is on %s — the SlowFast hot path only runs on an MI355X GPU "
+                         "(no CPU fallback)" % (what, t.device))
+    if t.dtype != torch.float32:
+        raise SfhipError("%s: expected float32, got %s" % (what, t.dtype))
+
+
+# ------------------------------------------------------------------------------------------------ Act
+class Act(object):
+    """NDHWC activation view: `buf` is a contiguous [N, T, H, W, pitch] tensor, the view is channels
+    [coff, coff + C)."""
+    __slots__ = ("buf", "coff", "C")
+
+    def __init__(self, buf, coff=0, C=None):
+        assert buf.dim() == 5 and buf.is_contiguous()
+        self.buf = buf
+        self.coff = coff
+        self.C = buf.shape[4] - coff if C is None else C
+
+    N = property(lambda s: s.buf.shape[0])
+    T = property(lambda s: s.buf.shape[1])
+    H = property(lambda s: s.buf.shape[2])
+    W = property(lambda s: s.buf.shape[3])
+    cs = property(lambda s: s.buf.shape[4])
+    rows = property(lambda s: s.buf.shape[0] * s.buf.shape[1] * s.buf.shape[2] * s.buf.shape[3])
+
+    def slice(self, off, C):
+        assert 0 <= off and off + C <= self.C
+        return Act(self.buf, self.coff + off, C)
+
+    def ptr(self):
+        return ctypes.c_void_p(self.buf.data_ptr())
+
+    @property
+    def shape_ncthw(self):
+        return (self.N, self.C, self.T, self.H, self.W)
+
+    def __repr__(self):
+        return "Act(N=%d,T=%d,H=%d,W=%d,C=%d@%d/%d)" % (self.N, self.T, self.H, self.W, self.C, self.coff, self.cs)
+
+
+def new_act(like_or_dev, N, T, H, W, C, before=0, after=0):
+    """Allocate [N,T,H,W,before+C+after] and return the middle C-channel view."""
+    dev = like_or_dev.buf.device if isinstance(like_or_dev, Act) else like_or_dev
+    buf = torch.empty((N, T, H, W, before + C + after), dtype=torch.float32, device=dev)
+    return Act(buf, before, C)
+
+
+def from_ncthw(x, cpad=None, ph=0, pw=0, wp=None):
+    """NCTHW torch tensor -> (optionally channel/border padded) NDHWC Act."""
+    _require_gpu(x, "from_ncthw")
+    x = x.contiguous()
+    N, C, T, H, W = x.shape
+    cpad = C if cpad is None else cpad
+    wp = W + 2 * pw if wp is None else wp
+    buf = torch.empty((N, T, H + 2 * ph, wp, cpad), dtype=torch.float32, device=x.device)
+    _check(lib().sf_ncthw_to_ndhwc(_ptr(x), _ptr(buf), N, C, T, H, W, cpad, ph, pw, wp, _stream()), "sf_ncthw_to_ndhwc")
+    return Act(buf, 0, cpad)
+
+
+def to_ncthw(a):
+    out = torch.empty(a.shape_ncthw, dtype=torch.float32, device=a.buf.device)
+    _check(lib().sf_ndhwc_to_ncthw(a.ptr(), a.cs, a.coff, _ptr(out), a.N, a.C, a.T, a.H, a.W, _stream()),
+           "sf_ndhwc_to_ncthw")
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ conv
+def _out_dim(i, k, s, p, d):
+    return (i + 2 * p - d * (k - 1) - 1) // s + 1
+
+
+def pack_conv_weight(w, cin_pad=None):
+    """[Cout, Cin, kT, kH, kW] -> [Cout, kT*kH*kW, cin_pad] (zero padded), contiguous."""
+    cout, cin = w.shape[0], w.shape[1]
+    taps = w.shape[2] * w.shape[3] * w.shape[4]
+    cin_pad = (cin + 15) // 16 * 16 if cin_pad is None else cin_pad
+    wp = torch.zeros((cout, taps, cin_pad), dtype=torch.float32, device=w.device)
+    wp[:, :, :cin] = w.detach().reshape(cout, cin, taps).permute(0, 2, 1)
+    return wp.contiguous()
+
+
+def pack_dw_weight(w):
+    """depthwise [C, 1, kT, kH, kW] -> [taps, C]."""
+    c = w.shape[0]
+    return w.detach().reshape(c, -1).t().contiguous()
+
+
+def conv(x, wp, kernel, stride=(1, 1, 1), padding=(0, 0, 0), dilation=(1, 1, 1), scale=None, bias=None,
+         relu=False, res=None, out=None, cin=None, out_cmul=1, out_reserve=(0, 0), out_thw=None):
+    """Dense conv (implicit GEMM, sf_conv_fwd).  `wp` = pack_conv_weight(...).  `out`: Act to write into
+    (a slice of a wider buffer) or None to allocate [.., before + Cout + after]."""
+    _require_gpu(x.buf, "conv")
+    cout, taps, cin_pad = wp.shape
+    cin = x.C if cin is None else cin
+    kT, kH, kW = kernel
+    To = _out_dim(x.T, kT, stride[0], padding[0], dilation[0])
+    Ho = _out_dim(x.H, kH, stride[1], padding[1], dilation[1])
+    Wo = _out_dim(x.W, kW, stride[2], padding[2], dilation[2])
+    if out_thw is not None:  # caller restricts the output extent (stem trick: trailing columns are padding)
+        assert out_thw[0] <= To and out_thw[1] <= Ho and out_thw[2] <= Wo
+        To, Ho, Wo = out_thw
+    if out is None:
+        out = new_act(x, x.N, To, Ho, Wo, cout, out_reserve[0], out_reserve[1])
+    else:
+        assert (out.N, out.T, out.H, out.W) == (x.N, To, Ho, Wo), (out, (x.N, To, Ho, Wo))
+        assert out.coff + (cout - 1) * out_cmul < out.cs and (out_cmul > 1 or out.C == cout), (out, cout)
+    d = ConvDesc(x.N, x.T, x.H, x.W, cin, x.cs, x.coff, To, Ho, Wo, cout, out.cs, out.coff, out_cmul,
+                 kT, kH, kW, stride[0], stride[1], stride[2], padding[0], padding[1], padding[2],
+                 dilation[0], dilation[1], dilation[2], cin_pad, ACT_RELU if relu else ACT_NONE,
+                 res.cs if res is not None else 0, res.coff if res is not None else 0)
+    if res is not None:
+        assert res.rows == out.rows and res.C == cout
+    _check(lib().sf_conv_fwd(ctypes.byref(d), x.ptr(), _ptr(wp), _ptr(scale), _ptr(bias),
+                             res.ptr() if res is not None else None, out.ptr(), _stream()), "sf_conv_fwd")
+    return out
+
+
+def dwconv(x, wp, kernel, stride=(1, 1, 1), padding=(0, 0, 0), scale=None, bias=None, relu=False, res=None,
+           out=None, cout=None, out_cmul=1):
+    """Depthwise conv (sf_dwconv_fwd); wp = pack_dw_weight(...) [taps, C]."""
+    _require_gpu(x.buf, "dwconv")
+    taps, c = wp.shape
+    assert c == x.C
+    cout = c if cout is None else cout
+    kT, kH, kW = kernel
+    To = _out_dim(x.T, kT, stride[0], padding[0], 1)
+    Ho = _out_dim(x.H, kH, stride[1], padding[1], 1)
+    Wo = _out_dim(x.W, kW, stride[2], padding[2], 1)
+    if out is None:
+        out = new_act(x, x.N, To, Ho, Wo, cout)
+    else:
+        assert (out.N, out.T, out.H, out.W) == (x.N, To, Ho, Wo)
+    d = ConvDesc(x.N, x.T, x.H, x.W, c, x.cs, x.coff, To, Ho, Wo, cout, out.cs, out.coff, out_cmul,
+                 kT, kH, kW, stride[0], stride[1], stride[2], padding[0], padding[1], padding[2], 1, 1, 1,
+                 c, ACT_RELU if relu else ACT_NONE,
+                 res.cs if res is not None else 0, res.coff if res is not None else 0)
+    _check(lib().sf_dwconv_fwd(ctypes.byref(d), x.ptr(), _ptr(wp), _ptr(scale), _ptr(bias),
+                               res.ptr() if res is not None else None, out.ptr(), _stream()), "sf_dwconv_fwd")
+    return out
+
+
+def pool(x, kernel, stride, padding=(0, 0, 0), avg=False, out=None, out_reserve=(0, 0)):
+    _require_gpu(x.buf, "pool")
+    To = _out_dim(x.T, kernel[0], stride[0], padding[0], 1)
+    Ho = _out_dim(x.H, kernel[1], stride[1], padding[1], 1)
+    Wo = _out_dim(x.W, kernel[2], stride[2], padding[2], 1)
+    if out is None:
+        out = new_act(x, x.N, To, Ho, Wo, x.C, out_reserve[0], out_reserve[1])
+    else:
+        assert (out.N, out.T, out.H, out.W, out.C) == (x.N, To, Ho, Wo, x.C)
+    d = PoolDesc(x.N, x.T, x.H, x.W, x.C, x.cs, x.coff, To, Ho, Wo, out.cs, out.coff,
+                 kernel[0], kernel[1], kernel[2], stride[0], stride[1], stride[2],
+                 padding[0], padding[1], padding[2], 1 if avg else 0)
+    _check(lib().sf_pool_fwd(ctypes.byref(d), x.ptr(), out.ptr(), _stream()), "sf_pool_fwd")
+    return out
+
+
+def tmax_mean(x, alpha):
+    """pooled[b,c] = mean_{t',h,w} max_{r<alpha} x[b,t'*alpha+r,h,w,c]  ->  torch [N, C]."""
+    _require_gpu(x.buf, "tmax_mean")
+    pooled = torch.empty((x.N, x.C), dtype=torch.float32, device=x.buf.device)
+    ws = torch.empty((lib().sf_tmax_mean_ws_floats(x.N, x.C),), dtype=torch.float32, device=x.buf.device)
+    _check(lib().sf_tmax_mean(x.ptr(), x.cs, x.coff, x.N, x.T, x.H, x.W, x.C, alpha, _ptr(pooled), _ptr(ws),
+                              _stream()), "sf_tmax_mean")
+    return pooled
+
+
+def gate_apply(x, alpha, pooled, w3=None, scale=None, bias=None, relu=False, out=None):
+    _require_gpu(x.buf, "gate_apply")
+    if out is None:
+        out = new_act(x, x.N, x.T // alpha, x.H, x.W, x.C)
+    else:
+        assert (out.N, out.T, out.H, out.W, out.C) == (x.N, x.T // alpha, x.H, x.W, x.C), (out, x)
+    _check(lib().sf_gate_apply(x.ptr(), x.cs, x.coff, x.N, x.T, x.H, x.W, x.C, alpha, _ptr(pooled), _ptr(w3),
+                               _ptr(scale), _ptr(bias), ACT_RELU if relu else ACT_NONE, out.ptr(), out.cs,
+                               out.coff, _stream()), "sf_gate_apply")
+    return out
+
+
+def attention(q, k, v, x, gamma, scale=None, bias=None, relu=False, alpha=1, out=None):
+    """Flash SpatialAttention + gamma-residual + (BN affine, ReLU) + nearest T-upsample x alpha."""
+    _require_gpu(x.buf, "attention")
+    if out is None:
+        out = new_act(x, x.N, x.T * alpha, x.H, x.W, x.C)
+    else:
+        assert (out.N, out.T, out.H, out.W, out.C) == (x.N, x.T * alpha, x.H, x.W, x.C), (out, x)
+
+    def base(a):  # slice base pointer: buffer pointer + channel offset
+        return ctypes.c_void_p(a.buf.data_ptr() + 4 * a.coff)
+
+    _check(lib().sf_attn_fwd(base(q), q.cs, base(k), k.cs, base(v), v.cs, base(x), x.cs, _ptr(gamma), _ptr(scale),
+                             _ptr(bias), ACT_RELU if relu else ACT_NONE, out.ptr(), out.cs, out.coff,
+                             x.N, x.T, x.H, x.W, x.C, alpha, _stream()), "sf_attn_fwd")
+    return out
+
+
+def head_act_mean(logits, act):
+    """logits Act [N,T,H,W,K] (dense) -> torch [N, K] = mean_{t,h,w} act(logits)."""
+    assert logits.coff == 0 and logits.C == logits.cs
+    out = torch.empty((logits.N, logits.C), dtype=torch.float32, device=logits.buf.device)
+    _check(lib().sf_head_act_mean(logits.ptr(), logits.N, logits.T * logits.H * logits.W, logits.C, act, _ptr(out),
+                                  _stream()), "sf_head_act_mean")
+    return out
+
+
+def copy_channels(x, out, out_cmul=1):
+    assert x.rows == out.rows
+    _check(lib().sf_copy_channels(x.ptr(), x.cs, x.coff, out.ptr(), out.cs, out.coff, out_cmul, x.rows, x.C,
+                                  _stream()), "sf_copy_channels")
+    return out

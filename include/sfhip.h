@@ -1,0 +1,128 @@
+/* sfhip.h — C ABI of libsfhip.so: the MI355X (gfx950) kernels behind the SlowFast / CMDA hot path.
+ *
+ * The reference (weidafeng/Efficient-SlowFast) has NO FFI: its hot path is Python nn.Modules whose
+ * arithmetic is executed by ATen ops.  Each entry point below therefore names the reference module
+ * call(s) it replaces (file:line under SlowFast/slowfast/models/) instead of a native symbol.
+ *
+ * Conventions
+ *   - all tensors fp32, device pointers owned by the caller, NDHWC ("channels-last 3D"):
+ *     element (n,t,h,w,c) of a tensor with row pitch `cs` (floats) and channel offset `coff` lives at
+ *     ((((n*T + t)*H + h)*W + w) * cs + coff + c).  A pitch larger than the channel count lets a
+ *     producer write straight into a slice of a wider (concatenated) tensor — torch.cat is never run.
+ *   - every function only enqueues work on `stream` (a hipStream_t passed as void*); no allocation,
+ *     no synchronisation, safe to capture into a hipGraph.
+ *   - return 0 on success, a negative SF_E* code on a bad argument (nothing is enqueued then).
+ */
+#ifndef SFHIP_H
+#define SFHIP_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SF_OK 0
+#define SF_EINVAL (-1)   /* inconsistent descriptor */
+#define SF_EALIGN (-2)   /* pointer / pitch alignment not supported by any kernel variant */
+#define SF_ELAUNCH (-3)  /* hipLaunch failed (hipGetLastError is left set) */
+
+#define SF_ACT_NONE 0
+#define SF_ACT_RELU 1
+#define SF_ACT_SIGMOID 2      /* head only */
+#define SF_ACT_SOFTMAX 3      /* head only */
+#define SF_ACT_HSIGMOID 4     /* relu6(x+3)/6, ghostnet_helper.py:27-31 */
+
+int sf_abi_version(void);
+/* Name of the gfx target the library was built for ("gfx950"). */
+const char* sf_build_arch(void);
+
+/* ---- layout -------------------------------------------------------------------------------
+ * NCTHW (the callers' layout, datasets/utils.py:73-112) -> NDHWC with the channel dim padded to
+ * `cpad` (zeros) and the H/W borders zero-padded by ph/pw (so the stem conv needs no border test).
+ * dst dims: [N, T, H+2*ph, Wp, cpad] with Wp >= W+2*pw (extra columns zero).            */
+int sf_ncthw_to_ndhwc(const float* src, float* dst, int N, int C, int T, int H, int W,
+                      int cpad, int ph, int pw, int Wp, void* stream);
+/* NDHWC slice (pitch cs, offset coff, C channels) -> dense NCTHW (module-boundary outputs). */
+int sf_ndhwc_to_ncthw(const float* src, int cs, int coff, float* dst, int N, int C, int T, int H,
+                      int W, void* stream);
+
+/* ---- dense convolution as implicit GEMM on fp32 MFMA ------------------------------------------
+ * Replaces nn.Conv3d(+BatchNorm3d eval affine)(+residual add)(+ReLU) of
+ *   stem_helper.py:157-178 (conv), resnet_helper.py:182-223 (a/b/c), :326-335 (branch1),
+ *   video_model_builder.py:128-141 (conv_f2s), custom_video_model_builder.py:102-108
+ *   (downsample_c_of_slow), wdf_attention_helper.py:21-29 (q/k/v), head Linear (head_helper.py:181).
+ * out[m, n] = act( scale[n] * (sum_{tap,c} in[row(m,tap), c] * w[n, tap, c]) + bias[n] + res[m, n] )
+ * Weights are pre-packed [Cout][kT*kH*kW][cin_pad] (cin_pad = Cin rounded up to 16, zero filled). */
+typedef struct sf_conv_desc {
+  int N, Ti, Hi, Wi, Cin;      /* input dims; Cin = contiguous floats consumed per tap            */
+  int in_cs, in_coff;          /* input pitch / channel offset                                    */
+  int To, Ho, Wo, Cout;        /* output dims                                                     */
+  int out_cs, out_coff;        /* output pitch / channel offset                                   */
+  int out_cmul;                /* output channel n is stored at out_coff + n*out_cmul (channel    */
+                               /* shuffle folded into index math, shufflenetv2_helper.py:32-43)   */
+  int kT, kH, kW, sT, sH, sW, pT, pH, pW, dT, dH, dW;
+  int cin_pad;                 /* packed weight row length per tap                                */
+  int act;                     /* SF_ACT_NONE | SF_ACT_RELU                                       */
+  int res_cs, res_coff;        /* residual pitch / offset (used when res != NULL)                 */
+} sf_conv_desc;
+int sf_conv_fwd(const sf_conv_desc* d, const float* in, const float* w_packed, const float* scale,
+                const float* bias, const float* res, float* out, void* stream);
+
+/* ---- depthwise convolution (groups == channels) ----------------------------------------------
+ * ghostnet_helper.py:88-90,114-120,137-143; shufflenetv2_helper.py:62-64,74-75,89-91.
+ * Weights packed [kT*kH*kW][C].  `Cout` <= C output channels are produced (GhostModule's
+ * out[:, :oup] slice, ghostnet_helper.py:99).                                                  */
+int sf_dwconv_fwd(const sf_conv_desc* d, const float* in, const float* w_packed, const float* scale,
+                  const float* bias, const float* res, float* out, void* stream);
+
+/* ---- pooling ------------------------------------------------------------------------------------
+ * MaxPool3d (stem_helper.py:169-171; ShuffleNetV2 stem :248) / AvgPool3d stride 1 (head_helper.py:176).
+ * is_avg: 0 = max (padding ignored), 1 = average, count_include_pad (no padding used by callers). */
+typedef struct sf_pool_desc {
+  int N, Ti, Hi, Wi, C, in_cs, in_coff;
+  int To, Ho, Wo, out_cs, out_coff;
+  int kT, kH, kW, sT, sH, sW, pT, pH, pW;
+  int is_avg;
+} sf_pool_desc;
+int sf_pool_fwd(const sf_pool_desc* d, const float* in, float* out, void* stream);
+
+/* ---- CMDA Fast->Slow edge: MaxPool3d(alpha,1,1) -> ECA -> BN -> ReLU -> concat ------------------
+ * custom_video_model_builder.py:131-135 + wdf_attention_helper.py:77-91, two launches:
+ *  (1) pooled[b,c] = mean_{t',h,w} max_{r<alpha} x[b, t'*alpha + r, h, w, c]        (sf_tmax_mean)
+ *  (2) out[b,t',h,w,coff+c] = act(scale[c] * (max_r x[...] * gate[b,c]) + bias[c])   (sf_gate_apply)
+ *      gate = sigmoid(conv1d_k3(pooled)) when w3 != NULL (ECA), or
+ *      gate = hsigmoid(pooled_gate[b,c]) when w3 == NULL (SqueezeExcite, ghostnet_helper.py:46-52;
+ *      `pooled` then already holds conv_expand's output).                                          */
+/* `ws` is caller-provided scratch of sf_tmax_mean_ws_floats(N, C) floats: the mean is reduced through a
+ * FIXED number of partial sums per clip (no float atomics), so results are bit-reproducible.        */
+long sf_tmax_mean_ws_floats(int N, int C);
+int sf_tmax_mean(const float* x, int cs, int coff, int N, int T, int H, int W, int C, int alpha,
+                 float* pooled, float* ws, void* stream);
+int sf_gate_apply(const float* x, int cs, int coff, int N, int T, int H, int W, int C, int alpha,
+                  const float* pooled, const float* w3, const float* scale, const float* bias, int act,
+                  float* out, int out_cs, int out_coff, void* stream);
+
+/* ---- CMDA Slow->Fast edge: SpatialAttention (flash-style, never materialises N x N) -------------
+ * wdf_attention_helper.py:41-54 fused with custom_video_model_builder.py:143-146:
+ *   S = q k^T (no 1/sqrt(d)), P = softmax_j(S), o = P v, y = gamma*o + x,
+ *   z = relu(scale*y + bias)  (bn_s2f eval affine; skipped when scale == NULL),
+ *   written `alpha` times along T (nn.Upsample nearest) into out (pitch out_cs, offset out_coff).
+ * q,k,v,x: [B, N=T*H*W, C] views with pitches q_cs.. (q,k,v normally slices of one [B,N,3C] buffer).
+ * gamma is read from device memory (it is an nn.Parameter).                                       */
+int sf_attn_fwd(const float* q, int q_cs, const float* k, int k_cs, const float* v, int v_cs,
+                const float* x, int x_cs, const float* gamma, const float* scale, const float* bias,
+                int act, float* out, int out_cs, int out_coff, int B, int T, int H, int W, int C,
+                int alpha, void* stream);
+
+/* ---- head tail (eval): activation over classes then mean over T,H,W -----------------------------
+ * head_helper.py:217-221.  logits [B, P, K] -> out [B, K]; act = SF_ACT_SOFTMAX | SIGMOID | RELU | NONE */
+int sf_head_act_mean(const float* logits, int B, int P, int K, int act, float* out, void* stream);
+
+/* ---- elementwise helpers ------------------------------------------------------------------------
+ * Copy a channel slice (concat pass-through / channel shuffle of the un-convolved half,
+ * shufflenetv2_helper.py:100-107): out[.., out_coff + c*out_cmul] = in[.., in_coff + c].          */
+int sf_copy_channels(const float* in, int in_cs, int in_coff, float* out, int out_cs, int out_coff,
+                     int out_cmul, long rows, int C, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,302 @@
+"""GPU parity tests of every libsfhip kernel (through the C ABI via the ctypes binding) against the
+oracle's primitives / plain torch fp32 CPU ops on the same seeded inputs.
+
+Tolerance: 1e-3 max-norm relative is the north_star budget for the whole network; single ops are held to
+2e-4 (fp32 MFMA is a k-ordered fmaf chain, error ~1e-7 * sum|a*b|; softmax adds __expf's ~2 ulp).
+"""
+import os
+import zlib
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+TOL = 2e-4
+REPORT = []
+
+
+def _dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    return torch.device("cuda:0")
+
+
+def _rel(a, b):
+    a = a.detach().double().cpu()
+    b = b.detach().double().cpu()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+def _report(name, err):
+    REPORT.append("%-60s %.3e" % (name, err))
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    try:
+        os.makedirs(out, exist_ok=True)
+        with open(os.path.join(out, "ops_report.txt"), "a") as f:
+            f.write(REPORT[-1] + "\n")
+    except OSError:
+        pass
+
+
+def _ndhwc(x):  # NCTHW cpu tensor -> Act on gpu
+    import sfhip
+    return sfhip.Act(x.permute(0, 2, 3, 4, 1).contiguous().to(_dev()))
+
+
+def _back(a):  # Act -> NCTHW cpu
+    return a.buf[..., a.coff:a.coff + a.C].permute(0, 4, 1, 2, 3).contiguous().cpu()
+
+
+def test_layout_roundtrip():
+    import sfhip
+    dev = _dev()
+    x = torch.randn(2, 3, 4, 10, 12)
+    a = sfhip.from_ncthw(x.to(dev), cpad=4, ph=3, pw=3, wp=20)
+    assert tuple(a.buf.shape) == (2, 4, 16, 20, 4)
+    ref = torch.zeros(2, 4, 16, 20, 4)
+    ref[:, :, 3:13, 3:15, :3] = x.permute(0, 2, 3, 4, 1)
+    assert torch.equal(a.buf.cpu(), ref)
+    b = sfhip.from_ncthw(x.to(dev))
+    assert torch.equal(sfhip.to_ncthw(b).cpu(), x)
+
+
+CONV_CASES = [
+    # name, Cin, Cout, kernel, stride, pad, dil, (N,T,H,W), relu, res, bn
+    ("pw_64_256_res", 64, 256, (1, 1, 1), (1, 1, 1), (0, 0, 0), (1, 1, 1), (2, 2, 14, 14), True, True, True),
+    ("pw_72_64", 72, 64, (1, 1, 1), (1, 1, 1), (0, 0, 0), (1, 1, 1), (1, 2, 13, 11), True, False, True),
+    ("pw_stride2_288_512", 288, 512, (1, 1, 1), (1, 2, 2), (0, 0, 0), (1, 1, 1), (1, 2, 14, 14), False, False, True),
+    ("t3_1152_512", 1152, 512, (3, 1, 1), (1, 1, 1), (1, 0, 0), (1, 1, 1), (1, 4, 7, 7), True, False, True),
+    ("t3_16_8", 16, 8, (3, 1, 1), (1, 1, 1), (1, 0, 0), (1, 1, 1), (2, 8, 9, 9), True, False, True),
+    ("s3_64_64", 64, 64, (1, 3, 3), (1, 1, 1), (0, 1, 1), (1, 1, 1), (1, 2, 20, 20), True, False, True),
+    ("s3_128_128_s2", 128, 128, (1, 3, 3), (1, 2, 2), (0, 1, 1), (1, 1, 1), (2, 2, 14, 14), True, False, True),
+    ("s3_dil2_32_32", 32, 32, (1, 3, 3), (1, 1, 1), (0, 2, 2), (1, 2, 2), (1, 2, 12, 12), False, False, False),
+    ("f2s_k7_32_64", 32, 64, (7, 1, 1), (4, 1, 1), (3, 0, 0), (1, 1, 1), (1, 16, 6, 6), True, False, True),
+    ("pw_8_24_bias", 8, 24, (1, 1, 1), (1, 1, 1), (0, 0, 0), (1, 1, 1), (2, 4, 9, 9), False, False, False),
+    ("pw_32_96", 32, 96, (1, 1, 1), (1, 1, 1), (0, 0, 0), (1, 1, 1), (1, 4, 10, 10), False, False, False),
+    ("odd_27_16", 27, 16, (1, 1, 1), (1, 1, 1), (0, 0, 0), (1, 1, 1), (2, 4, 5, 5), True, False, True),
+    ("odd_3_24_k333", 3, 24, (3, 3, 3), (1, 2, 2), (1, 1, 1), (1, 1, 1), (2, 4, 16, 16), True, False, True),
+    ("fc_2304_400", 2304, 400, (1, 1, 1), (1, 1, 1), (0, 0, 0), (1, 1, 1), (8, 1, 1, 1), False, False, False),
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES, ids=[c[0] for c in CONV_CASES])
+def test_conv(case):
+    import sfhip
+    name, cin, cout, k, s, p, d, shp, relu, use_res, use_bn = case
+    dev = _dev()
+    g = torch.Generator().manual_seed(zlib.crc32(name.encode()) % 10000)
+    n, t, h, w = shp
+    x = torch.randn(n, cin, t, h, w, generator=g)
+    wt = torch.randn(cout, cin, *k, generator=g) / np.sqrt(cin * k[0] * k[1] * k[2])
+    scale = torch.rand(cout, generator=g) + 0.5 if use_bn else None
+    bias = torch.randn(cout, generator=g) * 0.1
+    y = F.conv3d(x, wt, None, s, p, d)
+    y = y * scale.view(1, -1, 1, 1, 1) + bias.view(1, -1, 1, 1, 1) if use_bn else y + bias.view(1, -1, 1, 1, 1)
+    res = torch.randn(y.shape, generator=g) if use_res else None
+    if use_res:
+        y = y + res
+    if relu:
+        y = F.relu(y)
+    # input lives in a slice of a wider buffer, output goes into a slice of a wider buffer
+    xa_full = sfhip.Act(torch.randn(n, t, h, w, cin + 8, generator=g).to(dev))
+    xa = xa_full.slice(4 if cin % 4 == 0 else 3, cin)
+    xa.buf[..., xa.coff:xa.coff + cin] = x.permute(0, 2, 3, 4, 1).to(dev)
+    wp = sfhip.pack_conv_weight(wt.to(dev))
+    sc = scale.to(dev) if use_bn else None
+    out = sfhip.conv(xa, wp, k, s, p, d, scale=sc, bias=bias.to(dev), relu=relu,
+                     res=_ndhwc(res) if use_res else None, out_reserve=(4, 8))
+    torch.cuda.synchronize()
+    err = _rel(_back(out), y)
+    _report("conv/" + name, err)
+    assert err < TOL, (name, err)
+
+
+def test_conv_stem_trick():
+    """7x7 stem on a border-padded NDHWC4 input expressed as kW=1 / 'Cin'=28 contiguous floats."""
+    import sfhip
+    dev = _dev()
+    g = torch.Generator().manual_seed(5)
+    for kt, cout in ((1, 64), (5, 8)):
+        x = torch.randn(2, 3, 6, 32, 32, generator=g)
+        wt = torch.randn(cout, 3, kt, 7, 7, generator=g) / np.sqrt(147 * kt)
+        y = F.conv3d(x, wt, None, (1, 2, 2), (kt // 2, 3, 3))
+        xa = sfhip.from_ncthw(x.to(dev), cpad=4, ph=3, pw=3, wp=38)  # Wp even
+        w4 = torch.zeros(cout, 4, kt, 7, 7)
+        w4[:, :3] = wt
+        # packed [Cout][kt*kh][kw*4 + c] -> pad 28 -> 32
+        wp = torch.zeros(cout, kt * 7, 32)
+        wp[:, :, :28] = w4.permute(0, 2, 3, 4, 1).reshape(cout, kt * 7, 28)
+        view = sfhip.Act(xa.buf.view(2, 6, 38, 19, 8))
+        out = sfhip.conv(view, wp.to(dev).contiguous(), (kt, 7, 1), (1, 2, 1), (kt // 2, 0, 0), cin=28,
+                         out_thw=(6, 16, 16))
+        torch.cuda.synchronize()
+        err = _rel(_back(out), y)
+        _report("conv/stem_trick_kt%d" % kt, err)
+        assert err < TOL
+
+
+def test_conv_out_cmul():
+    import sfhip
+    dev = _dev()
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(1, 16, 2, 6, 6, generator=g)
+    wt = torch.randn(16, 16, 1, 1, 1, generator=g) / 4
+    y = F.conv3d(x, wt)
+    out_full = sfhip.Act(torch.zeros(1, 2, 6, 6, 32, device=dev))
+    sfhip.conv(_ndhwc(x), sfhip.pack_conv_weight(wt.to(dev)), (1, 1, 1), out=sfhip.Act(out_full.buf, 1, 31),
+               out_cmul=2)
+    torch.cuda.synchronize()
+    got = out_full.buf[..., 1::2].permute(0, 4, 1, 2, 3).cpu()
+    assert _rel(got, y) < TOL
+    assert float(out_full.buf[..., 0::2].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("c", [8, 27, 64])
+def test_pool(c):
+    import sfhip
+    g = torch.Generator().manual_seed(c)
+    x = torch.randn(2, c, 4, 13, 12, generator=g)
+    for k, s, p in (((1, 3, 3), (1, 2, 2), (0, 1, 1)), ((3, 3, 3), (1, 2, 2), (1, 1, 1)), ((4, 1, 1), (4, 1, 1), (0, 0, 0))):
+        out = sfhip.pool(_ndhwc(x), k, s, p)
+        torch.cuda.synchronize()
+        assert torch.equal(_back(out), F.max_pool3d(x, k, s, p))
+    out = sfhip.pool(_ndhwc(x), (4, 3, 3), (1, 1, 1), avg=True)
+    torch.cuda.synchronize()
+    err = _rel(_back(out), F.avg_pool3d(x, (4, 3, 3), 1))
+    _report("pool/avg_c%d" % c, err)
+    assert err < 1e-5
+
+
+@pytest.mark.parametrize("c,alpha", [(8, 4), (32, 4), (3, 8), (128, 4), (300, 1)])
+def test_eca_gate(c, alpha):
+    import sfhip
+    from oracle import slowfast_oracle as oracle
+    dev = _dev()
+    g = torch.Generator().manual_seed(c)
+    x = torch.randn(2, c, 8, 7, 9, generator=g)
+    w3 = torch.randn(1, 1, 3, generator=g)
+    scale, bias = torch.rand(c, generator=g) + 0.5, torch.randn(c, generator=g) * 0.1
+    ref = F.max_pool3d(x, (alpha, 1, 1), (alpha, 1, 1))
+    pooled_ref = ref.mean((2, 3, 4))
+    ref = oracle.eca({"m.conv.weight": w3}, "m", ref)
+    ref = F.relu(ref * scale.view(1, -1, 1, 1, 1) + bias.view(1, -1, 1, 1, 1))
+    xa = _ndhwc(x)
+    pooled = sfhip.tmax_mean(xa, alpha)
+    out = sfhip.gate_apply(xa, alpha, pooled, w3=w3.to(dev), scale=scale.to(dev), bias=bias.to(dev), relu=True)
+    torch.cuda.synchronize()
+    e1, e2 = _rel(pooled, pooled_ref), _rel(_back(out), ref)
+    _report("eca/c%d_a%d pooled" % (c, alpha), e1)
+    _report("eca/c%d_a%d out" % (c, alpha), e2)
+    assert e1 < 1e-5 and e2 < TOL
+
+
+ATTN_CASES = [(8, (2, 12, 12), 4), (32, (2, 14, 14), 4), (64, (4, 7, 7), 4), (128, (2, 7, 7), 2), (3, (4, 8, 8), 8),
+              (28, (2, 9, 9), 4), (16, (1, 5, 5), 1), (32, (1, 2, 2), 1), (32, (8, 28, 28), 1)]
+
+
+@pytest.mark.parametrize("c,thw,alpha", ATTN_CASES, ids=["c%d_n%d" % (c, t * h * w) for c, (t, h, w), a in ATTN_CASES])
+def test_attention(c, thw, alpha):
+    """Flash kernel == dense softmax attention of the oracle (wdf_attention_helper.py:41-54), incl. the
+    fused gamma-residual, BN affine, ReLU and nearest T-upsample."""
+    import sfhip
+    from oracle import slowfast_oracle as oracle
+    dev = _dev()
+    g = torch.Generator().manual_seed(c * 1000 + thw[0])
+    t, h, w = thw
+    B = 2
+    x = torch.randn(B, c, t, h, w, generator=g)
+    sd = {}
+    for nm in ("query_conv", "key_conv", "value_conv"):
+        std = (0.7 if nm != "value_conv" else 1.0) / np.sqrt(c)
+        sd["m.%s.weight" % nm] = torch.randn(c, c, 1, 1, 1, generator=g) * std
+        sd["m.%s.bias" % nm] = torch.randn(c, generator=g) * 0.1
+    sd["m.gamma"] = torch.tensor([0.7])
+    scale, bias = torch.rand(c, generator=g) + 0.5, torch.randn(c, generator=g) * 0.1
+    ref = oracle.spatial_attention(sd, "m", x)
+    ref = F.relu(ref * scale.view(1, -1, 1, 1, 1) + bias.view(1, -1, 1, 1, 1)).repeat_interleave(alpha, dim=2)
+    # product path: one pointwise GEMM for q|k|v, then the flash kernel writing into a wider buffer
+    xa = _ndhwc(x)
+    wqkv = torch.cat([sd["m.query_conv.weight"], sd["m.key_conv.weight"], sd["m.value_conv.weight"]], 0)
+    bqkv = torch.cat([sd["m.query_conv.bias"], sd["m.key_conv.bias"], sd["m.value_conv.bias"]], 0)
+    qkv = sfhip.conv(xa, sfhip.pack_conv_weight(wqkv.to(dev)), (1, 1, 1), bias=bqkv.to(dev))
+    out = sfhip.new_act(dev, B, t * alpha, h, w, c, 0, 8)
+    sfhip.attention(qkv.slice(0, c), qkv.slice(c, c), qkv.slice(2 * c, c), xa, sd["m.gamma"].to(dev),
+                    scale.to(dev), bias.to(dev), relu=True, alpha=alpha, out=out)
+    torch.cuda.synchronize()
+    err = _rel(_back(out), ref)
+    _report("attn/c%d_n%d_a%d" % (c, t * h * w, alpha), err)
+    assert err < TOL, err
+
+
+def test_attention_online_softmax_rescale_branch():
+    """Force the running-max rescale: one key far above the rest, placed in a LATE tile (guide rule 26)."""
+    import sfhip
+    dev = _dev()
+    g = torch.Generator().manual_seed(1)
+    c, n = 32, 640
+    q = torch.randn(1, n, c, generator=g)
+    k = torch.randn(1, n, c, generator=g)
+    v = torch.randn(1, n, c, generator=g)
+    k[0, 517] = q[0, 100] * 6.0   # query 100 (and similar) spikes at key 517 (tile 8)
+    k[0, 3] = q[0, 200] * 5.0     # early spike then nothing larger
+    x = torch.zeros(1, n, c)
+    ref = torch.softmax(q.double() @ k.double().transpose(1, 2), -1) @ v.double()
+    qa, ka, va, xa = [sfhip.Act(z.view(1, 1, 1, n, c).contiguous().to(dev)) for z in (q, k, v, x)]
+    out = sfhip.attention(qa, ka, va, xa, torch.ones(1, device=dev))
+    torch.cuda.synchronize()
+    err = _rel(out.buf.view(1, n, c), ref)
+    _report("attn/rescale_branch", err)
+    assert err < TOL
+
+
+@pytest.mark.parametrize("c,k,s,cout", [(32, (3, 3, 3), (1, 1, 1), 32), (12, (1, 5, 5), (1, 2, 2), 12),
+                                        (27, (3, 3, 3), (1, 2, 2), 27), (16, (3, 3, 3), (1, 1, 1), 13)])
+def test_dwconv(c, k, s, cout):
+    import sfhip
+    dev = _dev()
+    g = torch.Generator().manual_seed(c)
+    x = torch.randn(2, c, 4, 10, 10, generator=g)
+    wt = torch.randn(c, 1, *k, generator=g) / np.sqrt(k[0] * k[1] * k[2])
+    p = tuple(kk // 2 for kk in k)
+    scale, bias = torch.rand(c, generator=g) + 0.5, torch.randn(c, generator=g) * 0.1
+    y = F.conv3d(x, wt, None, s, p, 1, c) * scale.view(1, -1, 1, 1, 1) + bias.view(1, -1, 1, 1, 1)
+    y = F.relu(y)[:, :cout]
+    out = sfhip.dwconv(_ndhwc(x), sfhip.pack_dw_weight(wt.to(dev)), k, s, p, scale=scale.to(dev), bias=bias.to(dev),
+                       relu=True, cout=cout)
+    torch.cuda.synchronize()
+    err = _rel(_back(out), y)
+    _report("dwconv/c%d" % c, err)
+    assert err < TOL
+
+
+def test_head_act_mean():
+    import sfhip
+    dev = _dev()
+    g = torch.Generator().manual_seed(2)
+    lg = torch.randn(3, 2, 2, 2, 400, generator=g) * 3
+    a = sfhip.Act(lg.to(dev))
+    for act, ref in ((sfhip.ACT_SOFTMAX, torch.softmax(lg, 4).mean((1, 2, 3))),
+                     (sfhip.ACT_RELU, F.relu(lg).mean((1, 2, 3))),
+                     (sfhip.ACT_SIGMOID, torch.sigmoid(lg).mean((1, 2, 3)))):
+        out = sfhip.head_act_mean(a, act)
+        torch.cuda.synchronize()
+        assert _rel(out, ref) < 1e-5
+
+
+def test_copy_channels_shuffle():
+    import sfhip
+    dev = _dev()
+    x = torch.randn(1, 2, 3, 3, 10)
+    out = sfhip.Act(torch.zeros(1, 2, 3, 3, 20, device=dev))
+    sfhip.copy_channels(sfhip.Act(x.to(dev)), sfhip.Act(out.buf, 0, 20), out_cmul=2)
+    torch.cuda.synchronize()
+    assert torch.equal(out.buf[..., 0::2].cpu(), x)
+
+
+def test_ops_reject_cpu_tensors():
+    import sfhip
+    with pytest.raises(sfhip.SfhipError):
+        sfhip.from_ncthw(torch.randn(1, 3, 2, 4, 4))
