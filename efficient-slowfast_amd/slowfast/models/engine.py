@@ -1,0 +1,138 @@
+"""Host-side glue between the nn.Module tree (parameter containers with the reference's names) and the
+libsfhip kernels: parameter preprocessing caches (packed weights, folded eval-mode BN), the fused
+conv(+BN)(+residual)(+ReLU) unit, the stem trick, and the NCTHW <-> NDHWC boundary handling that lets
+every top-level child be called on its own with the reference's list-of-NCTHW-tensors convention
+(Grad-CAM contract, wdf_visualization/gradcam_video.py:92-105)."""
+import threading
+
+import torch
+import torch.nn as nn
+
+import sfhip
+from sfhip import Act
+
+_tls = threading.local()
+
+
+class internal(object):
+    """Context: children exchange NDHWC `Act`s instead of converting back to NCTHW tensors."""
+
+    def __enter__(self):
+        self.prev = getattr(_tls, "depth", 0)
+        _tls.depth = self.prev + 1
+
+    def __exit__(self, *a):
+        _tls.depth = self.prev
+
+
+def is_internal():
+    return getattr(_tls, "depth", 0) > 0
+
+
+def enter(xs):
+    """list of NCTHW tensors or Acts -> list of Acts."""
+    return [x if isinstance(x, Act) else sfhip.from_ncthw(x) for x in xs]
+
+
+def leave(acts):
+    """list of Acts -> what the caller expects (Acts inside a model forward, NCTHW tensors otherwise)."""
+    if is_internal():
+        return acts
+    return [sfhip.to_ncthw(a) for a in acts]
+
+
+def _key(*tensors):
+    return tuple((t.data_ptr(), t._version) for t in tensors if t is not None)
+
+
+def _cached(mod, slot, key, make):
+    c = mod.__dict__.get(slot)
+    if c is None or c[0] != key:
+        with torch.no_grad():
+            c = (key, make())
+        mod.__dict__[slot] = c
+    return c[1]
+
+
+def check_bn(bn):
+    if not isinstance(bn, nn.BatchNorm3d):
+        raise NotImplementedError("only BN.NORM_TYPE=batchnorm is implemented on the HIP path (got %s)" % type(bn))
+    if bn.training:
+        raise NotImplementedError(
+            "training-mode BatchNorm (batch statistics) is not implemented on the HIP path yet; "
+            "call model.eval() — see DESIGN.md 'what comes next'")
+
+
+def bn_affine(bn, conv_bias=None):
+    """Eval-mode BatchNorm3d as per-channel (scale, bias); a preceding conv bias is folded in."""
+    check_bn(bn)
+
+    def make():
+        scale = bn.weight / torch.sqrt(bn.running_var + bn.eps)
+        bias = bn.bias - bn.running_mean * scale
+        if conv_bias is not None:
+            bias = bias + scale * conv_bias
+        return scale.contiguous(), bias.contiguous()
+
+    return _cached(bn, "_sf_affine", _key(bn.weight, bn.bias, bn.running_mean, bn.running_var, conv_bias), make)
+
+
+def packed_weight(conv):
+    if conv.groups == 1:
+        return _cached(conv, "_sf_wp", _key(conv.weight), lambda: sfhip.pack_conv_weight(conv.weight))
+    if conv.groups == conv.in_channels and conv.out_channels == conv.in_channels:
+        return _cached(conv, "_sf_wp", _key(conv.weight), lambda: sfhip.pack_dw_weight(conv.weight))
+    raise NotImplementedError("grouped convolution with groups=%d (ResNeXt) is not on the HIP path" % conv.groups)
+
+
+def conv_bn_act(x, conv, bn=None, relu=False, res=None, out=None, out_reserve=(0, 0), out_cmul=1, cout=None):
+    """nn.Conv3d [+ BatchNorm3d (eval)] [+ residual] [+ ReLU] as ONE kernel launch."""
+    wp = packed_weight(conv)
+    if bn is not None:
+        scale, bias = bn_affine(bn, conv.bias)
+    else:
+        scale, bias = None, conv.bias
+    k, s, p, d = conv.kernel_size, conv.stride, conv.padding, conv.dilation
+    if conv.groups == 1:
+        return sfhip.conv(x, wp, k, s, p, d, scale=scale, bias=bias, relu=relu, res=res, out=out,
+                          out_reserve=out_reserve, out_cmul=out_cmul)
+    assert d == (1, 1, 1)
+    if scale is None and bias is not None:
+        scale = torch.ones_like(bias)
+    return sfhip.dwconv(x, wp, k, s, p, scale=scale, bias=bias, relu=relu, res=res, out=out, cout=cout,
+                        out_cmul=out_cmul)
+
+
+def stem_conv_bn_relu(x, conv, bn, relu=True):
+    """First convolution of a pathway straight from the caller's NCTHW clip (Cin <= 4).
+
+    The clip is converted ONCE to NDHWC with channels padded to 4 and the H/W borders zero padded, so a
+    (kT,kH,kW) conv with W-stride sW becomes a (kT,kH,1) conv over 'pixels' of sW*4 floats that consumes
+    kW*4 CONTIGUOUS floats per tap: aligned 16-byte loads, no border predicate in H/W, and the K dimension
+    is kT*kH taps x 4kW instead of kT*kH*kW taps x 16-padded 3 channels."""
+    assert conv.groups == 1 and conv.in_channels <= 4 and conv.dilation == (1, 1, 1) and conv.stride[0] == 1
+    kT, kH, kW = conv.kernel_size
+    _, sH, sW = conv.stride
+    pT, pH, pW = conv.padding
+    N, C, T, H, W = x.shape
+    Ho = (H + 2 * pH - kH) // sH + 1
+    Wo = (W + 2 * pW - kW) // sW + 1
+    wp_need = max(W + 2 * pW, (Wo - 1) * sW + kW)
+    Wp = (wp_need + sW - 1) // sW * sW
+    a = sfhip.from_ncthw(x, cpad=4, ph=pH, pw=pW, wp=Wp)
+    view = Act(a.buf.view(N, T, H + 2 * pH, Wp // sW, 4 * sW))
+
+    def make():
+        w = conv.weight
+        w4 = torch.zeros((w.shape[0], 4, kT, kH, kW), dtype=torch.float32, device=w.device)
+        w4[:, :C] = w
+        cin = 4 * kW
+        cin_pad = (cin + 15) // 16 * 16
+        wp = torch.zeros((w.shape[0], kT * kH, cin_pad), dtype=torch.float32, device=w.device)
+        wp[:, :, :cin] = w4.permute(0, 2, 3, 4, 1).reshape(w.shape[0], kT * kH, cin)
+        return wp.contiguous()
+
+    wp = _cached(conv, "_sf_wp_stem", _key(conv.weight), make)
+    scale, bias = bn_affine(bn, conv.bias)
+    return sfhip.conv(view, wp, (kT, kH, 1), (1, sH, 1), (pT, 0, 0), scale=scale, bias=bias, relu=relu,
+                      cin=4 * kW, out_thw=(T + 2 * pT - kT + 1, Ho, Wo))

@@ -65,6 +65,13 @@ GRAD_KEYS = {
 }
 
 
+def plain_cfg(node):
+    """The fully resolved cfg (YAML + overrides) as plain nested dicts, so tests can rebuild it without
+    the reference's YAML files."""
+    return {k: plain_cfg(v) if isinstance(v, dict) else (list(v) if isinstance(v, tuple) else v)
+            for k, v in node.items()}
+
+
 def hparams_from_cfg(cfg):
     return dict(
         alpha=cfg.SLOWFAST.ALPHA, beta_inv=cfg.SLOWFAST.BETA_INV, depth=cfg.RESNET.DEPTH,
@@ -94,7 +101,7 @@ def run_case(case, get_cfg, build_model):
     out = {
         "meta": json.dumps(dict(name=case["name"], model=case["model"], yaml=case["yaml"],
                                 overrides=[str(o) if not isinstance(o, (int, float, bool)) else o for o in over],
-                                hparams=hparams_from_cfg(cfg), param_seed=PARAM_SEED, clip_seed=CLIP_SEED,
+                                cfg_dump=plain_cfg(cfg), hparams=hparams_from_cfg(cfg), param_seed=PARAM_SEED, clip_seed=CLIP_SEED,
                                 batch=case["batch"], t=case["t"], alpha=case["alpha"], size=case["size"],
                                 torch=torch.__version__)),
         "sd_keys": np.array(list(sd.keys())),
