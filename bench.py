@@ -1,0 +1,223 @@
+#!/usr/bin/env python3
+"""bench.py — clips/sec of the SlowFast hot path on MI355X (one process per GPU).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload dual|slowfast|ghostnet|shufflenetv2]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" is one eval-mode forward pass of the model over one batch of synthetic clips that are already
+resident in HBM (fp32 NCTHW, as the reference's loaders hand them over).  Default workload =
+BASELINE.json's metric config: SlowFastDualAttention 8x8 R50 + CMDA, 224^2, 8 clips per GPU (configs[2];
+at N GPUs configs[3]: global batch 8N).  Parameters are the de-degenerated seeded fill of
+tests/golden/paramgen.py (gamma != 0, non-zero final BNs) so no part of the network is a no-op.
+
+Prints ONE JSON line (rank 0) with the driver's contract fields plus
+  roofline:     the dominant kernel (flash attention, C=32, N=25088) — algorithmic FLOPs per launch /
+                its HIP-event duration measured around every launch inside the timed region, vs the dense
+                fp32 MFMA peak (157.3 TFLOP/s);
+  cpu_baseline: the oracle (torch CPU restatement of the reference) timed on this box's host cores
+                (N=1 only, bounded sample: batch 1, 1 warm-up + 2 timed forwards).
+"""
+import argparse
+import contextlib
+import io
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "efficient-slowfast_amd"), os.path.join(ROOT, "tests"),
+          os.path.join(ROOT, "tests", "golden")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+WORKLOADS = {
+    "dual": ("SLOWFAST_DUAL_8x8_R50.yaml", 8, "SlowFastDualAttention 8x8 R50 + CMDA, 224^2, T=32 alpha=4"),
+    "slowfast": ("SLOWFAST_8x8_R50.yaml", 8, "SlowFast 8x8 R50 (no attention), 224^2, T=32 alpha=4"),
+    "ghostnet": ("SLOWFAST_GHOSTNET_32x2.yaml", 2, "SlowFastGhostNet w2.0 + CMDA, 32x2, 224^2"),
+    "shufflenetv2": ("SLOWFAST_SHUFFLENETV2_4x16.yaml", 2, "SlowFastShuffleNetV2 w0.25, 4x16, 32^2"),
+}
+PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense f32-in MFMA = vector peak
+PARAM_SEED = 7
+
+
+def build(workload, device):
+    from paramgen import fill_state_dict
+    from slowfast.config.defaults import get_cfg
+    from slowfast.models import build_model
+    yaml_name, batch, desc = WORKLOADS[workload]
+    cfg = get_cfg()
+    cfg.merge_from_file(os.path.join(ROOT, "configs", yaml_name))
+    cfg.NUM_GPUS = 1
+    torch.manual_seed(0)
+    with contextlib.redirect_stdout(io.StringIO()):
+        model = build_model(cfg)
+    fill_state_dict(model.state_dict(), PARAM_SEED)
+    return cfg, model.eval(), batch, desc
+
+
+def synthetic_clips(cfg, batch, device, seed):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    t, s, a = cfg.DATA.NUM_FRAMES, cfg.DATA.CROP_SIZE, cfg.SLOWFAST.ALPHA
+    fast = torch.randn(batch, 3, t, s, s, generator=g)
+    idx = torch.linspace(0, t - 1, t // a).long()  # pack_pathway_output (datasets/utils.py:93-104)
+    slow = fast.index_select(2, idx)
+    return [slow.to(device), fast.to(device)]
+
+
+def cpu_baseline(workload, cfg, model):
+    """The oracle on the host cores, batch 1 (dense attention needs ~6 GB per clip)."""
+    from oracle import slowfast_oracle as oracle
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    hp = oracle.default_hparams(
+        alpha=cfg.SLOWFAST.ALPHA, beta_inv=cfg.SLOWFAST.BETA_INV, depth=cfg.RESNET.DEPTH,
+        width_per_group=cfg.RESNET.WIDTH_PER_GROUP, num_groups=cfg.RESNET.NUM_GROUPS,
+        fusion_kernel=cfg.SLOWFAST.FUSION_KERNEL_SZ,
+        spatial_strides=[s[0] for s in cfg.RESNET.SPATIAL_STRIDES],
+        spatial_dilations=[s[0] for s in cfg.RESNET.SPATIAL_DILATIONS],
+        num_block_temp_kernel=[list(x) for x in cfg.RESNET.NUM_BLOCK_TEMP_KERNEL],
+        num_frames=cfg.DATA.NUM_FRAMES, crop_size=cfg.DATA.CROP_SIZE, num_classes=cfg.MODEL.NUM_CLASSES,
+        short_cycle=bool(cfg.MULTIGRID.SHORT_CYCLE), head_act=cfg.MODEL.HEAD_ACT,
+        width_multi=cfg.SLOWFAST.WIDTH_MULTI)
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    xs = synthetic_clips(cfg, 1, "cpu", 1)
+    name = cfg.MODEL.MODEL_NAME
+    # ATen's CPU conv/softmax stop scaling (and collapse when oversubscribed: 256 SMT threads ran 350x slower
+    # than 8 cores) well below this box's core count, so time a few thread counts and keep the best.
+    best = None
+    for threads in sorted({min(os.cpu_count() or 1, t) for t in (16, 32, 64)}):
+        torch.set_num_threads(threads)
+        oracle.forward(name, sd, xs, hp)  # warm-up
+        t0 = time.time()
+        oracle.forward(name, sd, xs, hp)
+        dt = time.time() - t0
+        if best is None or dt < best[0]:
+            best = (dt, threads)
+    dt, threads = best
+    return {"value": round(1.0 / dt, 4), "unit": "clips/s", "cores": threads, "kind": "port",
+            "sample": "oracle (torch CPU restatement of the reference) eval forward, batch 1, same model/"
+                      "clip shape; best of 16/32/64 threads, 1 warm-up + 1 timed each"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="dual", choices=sorted(WORKLOADS))
+    ap.add_argument("--batch", type=int, default=0, help="clips per GPU (default: the workload's)")
+    ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("--gpus %d needs the torch.distributed.run launcher (one process per GPU)" % args.gpus)
+    assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback for the hot path)"
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl")  # RCCL over xGMI
+
+    import sfhip
+    cfg, model, batch, desc = build(args.workload, device)
+    batch = args.batch or batch
+    clips = synthetic_clips(cfg, batch, device, 100 + rank)  # a different shard of clips per rank
+
+    def step():
+        with torch.no_grad():
+            return model([clips[0], clips[1]])
+
+    # ---- warm-up (also builds the packed-weight / folded-BN caches), optional hipGraph capture
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        for _ in range(max(args.warmup, 1)):
+            out = step()
+    torch.cuda.synchronize()
+    graph = None
+    if not args.no_graph:
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):
+            out = step()
+        graph.replay()
+        torch.cuda.synchronize()
+    assert bool(torch.isfinite(out).all()), "non-finite model output"
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # ---- timed region: exactly K steps
+    barrier()
+    t0 = time.perf_counter()
+    with torch.cuda.stream(side):
+        for _ in range(args.steps):
+            if graph is not None:
+                graph.replay()
+            else:
+                out = step()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    barrier()
+    if world > 1:
+        tmax = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    # ---- dominant-kernel trace: HIP events around every flash-attention launch over K eager steps on the
+    #      stream the kernels run on (event pairs cannot be recorded inside a replayed graph)
+    roofline = None
+    if rank == 0 and args.workload in ("dual", "ghostnet", "shufflenetv2"):
+        sfhip.EVENT_TRACE = []
+        with torch.cuda.stream(side):
+            for _ in range(min(args.steps, 5)):
+                step()
+        torch.cuda.synchronize()
+        per = {}
+        for tag, e0, e1 in sfhip.EVENT_TRACE:
+            per.setdefault(tag, []).append(e0.elapsed_time(e1) * 1e-3)
+        sfhip.EVENT_TRACE = None
+        tot = {tag: sum(v) for tag, v in per.items()}
+        tag = max(tot, key=tot.get)
+        _, b, n, c = tag
+        dur = float(np.mean(per[tag]))
+        flops = 4.0 * b * n * n * c  # QK^T + PV, 2 FLOP per MAC (2*N^2*C MAC per clip)
+        ach = flops / dur / 1e12
+        roofline = {"bound": "mfma", "kernel": "attn_fwd_kernel (flash SpatialAttention) C=%d N=%d B=%d" % (c, n, b),
+                    "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "avg_launch_ms": round(dur * 1e3, 4),
+                    "launches_timed": len(per[tag]), "traffic": None}
+
+    if rank == 0:
+        clips_total = batch * world * args.steps
+        res = {
+            "metric": "clips/sec (8x8 224^2 SlowFast-R50+CMDA eval forward)" if args.workload == "dual"
+            else "clips/sec (%s eval forward)" % args.workload,
+            "value": round(clips_total / elapsed, 3), "unit": "clips/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": desc, "mode": "eval forward (inference); train-mode/backward not built yet",
+                       "clips_per_gpu": batch, "global_batch": batch * world, "layout": "NCTHW in, NDHWC inside",
+                       "launch": "eager" if graph is None else "hipGraph replay",
+                       "parallelism": "dp%d (clip-sharded replicas, no data-path collective in forward)" % world},
+        }
+        if roofline is not None:
+            res["roofline"] = roofline
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(args.workload, cfg, model)
+        print(json.dumps(res))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -274,6 +274,22 @@ def gate_apply(x, alpha, pooled, w3=None, scale=None, bias=None, relu=False, out
     return out
 
 
+EVENT_TRACE = None  # bench.py sets this to a list: (tag, start_event, end_event) per traced launch
+
+
+def _traced(tag, fn):
+    """Run `fn` (one kernel launch on the current stream) between two HIP events when tracing is on."""
+    if EVENT_TRACE is None:
+        return fn()
+    e0 = torch.cuda.Event(enable_timing=True)
+    e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    rc = fn()
+    e1.record()
+    EVENT_TRACE.append((tag, e0, e1))
+    return rc
+
+
 def attention(q, k, v, x, gamma, scale=None, bias=None, relu=False, alpha=1, out=None):
     """Flash SpatialAttention + gamma-residual + (BN affine, ReLU) + nearest T-upsample x alpha."""
     _require_gpu(x.buf, "attention")
@@ -285,9 +301,10 @@ def attention(q, k, v, x, gamma, scale=None, bias=None, relu=False, alpha=1, out
     def base(a):  # slice base pointer: buffer pointer + channel offset
         return ctypes.c_void_p(a.buf.data_ptr() + 4 * a.coff)
 
-    _check(lib().sf_attn_fwd(base(q), q.cs, base(k), k.cs, base(v), v.cs, base(x), x.cs, _ptr(gamma), _ptr(scale),
-                             _ptr(bias), ACT_RELU if relu else ACT_NONE, out.ptr(), out.cs, out.coff,
-                             x.N, x.T, x.H, x.W, x.C, alpha, _stream()), "sf_attn_fwd")
+    _check(_traced(("attn", x.N, x.T * x.H * x.W, x.C), lambda: lib().sf_attn_fwd(
+        base(q), q.cs, base(k), k.cs, base(v), v.cs, base(x), x.cs, _ptr(gamma), _ptr(scale),
+        _ptr(bias), ACT_RELU if relu else ACT_NONE, out.ptr(), out.cs, out.coff,
+        x.N, x.T, x.H, x.W, x.C, alpha, _stream())), "sf_attn_fwd")
     return out
 
 
