@@ -33,6 +33,7 @@ struct ConvArgs {
   int ntaps;    // kT*kH*kW
   int nb_n;     // number of N tiles
   int nblocks;  // total tiles
+  int vec_epi;  // 1: outputs/residual are 16-byte addressable -> LDS-transposed float4 epilogue
 };
 
 constexpr int BK = 16;
@@ -197,9 +198,53 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
     __syncthreads();
   }
 
-  // ---- epilogue: lane holds channel n = .. + fr, rows 4*fg + reg
+  // ---- epilogue
   const bool has_res = p.res != nullptr;
   const bool relu = d.act == SF_ACT_RELU;
+  if (p.vec_epi) {
+    // The accumulator layout has the channel on the lane (16 lanes = 64 B per row): stored directly, a wave
+    // store touches 4 rows x 64 B.  Transpose each 16-row slab through this wave's private LDS region and
+    // emit 16-byte stores (and residual loads) that cover whole WN_COLS*4-byte row segments instead.
+    constexpr int WN_COLS = TN * 16;
+    constexpr int EP = WN_COLS + 4;            // slab row pitch (dwords)
+    constexpr int LPR = WN_COLS / 4;           // lanes per row
+    constexpr int RPP = 64 / LPR;              // rows per pass
+    float* const slab = smem + wave * (16 * EP);
+    const int c4 = (lane % LPR) * 4;
+    const int n = n0 + wn * (BN / WN) + c4;
+    const bool n_ok = n < d.Cout;              // Cout % 4 == 0 on this path
+    f32x4 sc = {1.f, 1.f, 1.f, 1.f}, bi = {0.f, 0.f, 0.f, 0.f};
+    if (n_ok) {
+      if (p.scale) sc = *reinterpret_cast<const f32x4*>(p.scale + n);
+      if (p.bias) bi = *reinterpret_cast<const f32x4*>(p.bias + n);
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) slab[(fg * 4 + r) * EP + j * 16 + fr] = acc[i][j][r];
+      __syncthreads();
+#pragma unroll
+      for (int q = 0; q < 16 / RPP; ++q) {
+        const int row = lane / LPR + q * RPP;
+        const int m = m0 + wm * (BM / WM) + i * 16 + row;
+        if (n_ok && m < p.M) {
+          f32x4 v = *reinterpret_cast<const f32x4*>(slab + row * EP + c4);
+          v = v * sc + bi;
+          if (has_res) v += *reinterpret_cast<const f32x4*>(p.res + (long)m * d.res_cs + d.res_coff + n);
+          if (relu) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+          }
+          *reinterpret_cast<f32x4*>(p.out + (long)m * d.out_cs + d.out_coff + n) = v;
+        }
+      }
+      __syncthreads();
+    }
+    return;
+  }
+  // scalar epilogue (odd channel counts / channel-multiplier stores): lane holds channel .. + fr, rows 4*fg + reg
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int n = n0 + wn * (BN / WN) + j * 16 + fr;
@@ -217,6 +262,46 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
         v = relu ? fmaxf(v, 0.f) : v;
         p.out[(long)m * d.out_cs + d.out_coff + (long)n * d.out_cmul] = v;
       }
+    }
+  }
+}
+
+
+// Tiny-M pointwise GEMM (head Linear, SqueezeExcite FCs: M = batch rows): one wavefront per output
+// channel, lanes split K with 16-byte loads, rows accumulated in registers, one shuffle reduction.  The
+// 128-row MFMA tile would run 4 workgroups for the 2304 -> 400 head and serialise 144 K steps in each.
+constexpr int GEMV_MMAX = 16;
+__global__ __launch_bounds__(256) void gemv_rows_kernel(const ConvArgs p) {
+  const sf_conv_desc& d = p.d;
+  const int lane = threadIdx.x & 63;
+  const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (n >= d.Cout) return;
+  float acc[GEMV_MMAX];
+#pragma unroll
+  for (int m = 0; m < GEMV_MMAX; ++m) acc[m] = 0.f;
+  const float* wrow = p.w + (long)n * d.cin_pad;
+  for (int k = lane * 4; k < d.Cin; k += 256) {
+    const f32x4 w4 = *reinterpret_cast<const f32x4*>(wrow + k);
+#pragma unroll
+    for (int m = 0; m < GEMV_MMAX; ++m) {
+      if (m < p.M) {
+        const f32x4 x4 = *reinterpret_cast<const f32x4*>(p.in + (long)m * d.in_cs + d.in_coff + k);
+        acc[m] += x4[0] * w4[0] + x4[1] * w4[1] + x4[2] * w4[2] + x4[3] * w4[3];
+      }
+    }
+  }
+  const float sc = p.scale ? p.scale[n] : 1.f;
+  const float bi = p.bias ? p.bias[n] : 0.f;
+#pragma unroll
+  for (int m = 0; m < GEMV_MMAX; ++m) {
+    float v = acc[m];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    if (lane == 0 && m < p.M) {
+      v = v * sc + bi;
+      if (p.res) v += p.res[(long)m * d.res_cs + d.res_coff + n];
+      if (d.act == SF_ACT_RELU) v = fmaxf(v, 0.f);
+      p.out[(long)m * d.out_cs + d.out_coff + (long)n * d.out_cmul] = v;
     }
   }
 }
@@ -251,11 +336,24 @@ extern "C" int sf_conv_fwd(const sf_conv_desc* d, const float* in, const float* 
   a.in = in; a.w = w_packed; a.scale = scale; a.bias = bias; a.res = res; a.out = out;
   a.M = (int)M;
   a.ntaps = d->kT * d->kH * d->kW;
-  a.nb_n = 0; a.nblocks = 0;
+  a.nb_n = 0; a.nblocks = 0; a.vec_epi = 0;
   const bool vec4 = (d->Cin % 4 == 0) && (d->in_cs % 4 == 0) && (d->in_coff % 4 == 0) && sf_aligned16(in);
+  a.vec_epi = (d->out_cmul == 1) && (d->Cout % 4 == 0) && (d->out_cs % 4 == 0) && (d->out_coff % 4 == 0) &&
+              sf_aligned16(out) && (!scale || sf_aligned16(scale)) && (!bias || sf_aligned16(bias)) &&
+              (!res || ((d->res_cs % 4 == 0) && (d->res_coff % 4 == 0) && sf_aligned16(res)));
   hipStream_t s = (hipStream_t)stream;
+  if (M <= GEMV_MMAX && a.ntaps == 1 && vec4 && d->sT == 1 && d->sH == 1 && d->sW == 1 && d->pT == 0 &&
+      d->pH == 0 && d->pW == 0) {
+    hipLaunchKernelGGL(gemv_rows_kernel, dim3(sf_cdiv(d->Cout, 4)), dim3(256), 0, s, a);
+    SF_CHECK_LAUNCH();
+    return SF_OK;
+  }
   if (d->Cout <= 16) return launch<256, 16, 4, 1>(a, vec4, s);
   if (d->Cout <= 32) return launch<256, 32, 4, 1>(a, vec4, s);
+  // Large tiles maximise operand reuse, but the M <= 12544 layers of res4/res5 then give < 1 workgroup per
+  // CU (256 CUs): drop to 64x64 tiles when the big tiling cannot fill the chip twice over.
+  const long big = (long)sf_cdiv(M, 128) * sf_cdiv(d->Cout, d->Cout <= 64 ? 64 : 128);
+  if (big < 512) return launch<64, 64, 2, 2>(a, vec4, s);
   if (d->Cout <= 64) return launch<128, 64, 2, 2>(a, vec4, s);
   return launch<128, 128, 2, 2>(a, vec4, s);
 }

@@ -71,7 +71,10 @@ class ResNetBasicHead(nn.Module):
             if cat is None:
                 cat = sfhip.new_act(x, x.N, to, ho, wo, total)
             assert (cat.T, cat.H, cat.W) == (to, ho, wo), "pathway pooled sizes differ"
-            sfhip.pool(x, k, (1, 1, 1), avg=True, out=cat.slice(off, x.C))
+            if (to, ho, wo) == (1, 1, 1):  # window == extent: a global mean (parallel tree reduction)
+                _global_mean(x, cat.slice(off, x.C))
+            else:
+                sfhip.pool(x, k, (1, 1, 1), avg=True, out=cat.slice(off, x.C))
             off += x.C
         logits = _project(cat, self.projection, getattr(self, "dropout", None), self.training)
         return _finish(logits, self.training, self._act_name)
