@@ -255,6 +255,11 @@ int launch(const AttnArgs& a, bool vec4, hipStream_t s) {
 
 }  // namespace
 
+int sf_attn_small_dispatch(const float* q, int q_cs, const float* k, int k_cs, const float* v, int v_cs,
+                           const float* x, int x_cs, const float* gamma, const float* scale, const float* bias,
+                           int act, float* out, int out_cs, int out_coff, int B, int T, int H, int W, int C,
+                           int alpha, bool vec4, hipStream_t stream);  // attn_small.hip
+
 extern "C" int sf_attn_fwd(const float* q, int q_cs, const float* k, int k_cs, const float* v, int v_cs,
                            const float* x, int x_cs, const float* gamma, const float* scale, const float* bias,
                            int act, float* out, int out_cs, int out_coff, int B, int T, int H, int W, int C,
@@ -274,8 +279,9 @@ extern "C" int sf_attn_fwd(const float* q, int q_cs, const float* k, int k_cs, c
                     (out_cs % 4 == 0) && (out_coff % 4 == 0) && sf_aligned16(q) && sf_aligned16(k) &&
                     sf_aligned16(v) && sf_aligned16(x) && sf_aligned16(out);
   hipStream_t s = (hipStream_t)stream;
-  if (C <= 8) return launch<8>(a, vec4, s);
-  if (C <= 16) return launch<16>(a, vec4, s);
+  if (C <= 16)  // 16-query wavefronts on 16x16x4 tiles: no padded rows in the second product
+    return sf_attn_small_dispatch(q, q_cs, k, k_cs, v, v_cs, x, x_cs, gamma, scale, bias, act, out, out_cs,
+                                  out_coff, B, T, H, W, C, alpha, vec4, s);
   if (C <= 32) return launch<32>(a, vec4, s);
   if (C <= 64) return launch<64>(a, vec4, s);
   return launch<128>(a, vec4, s);

@@ -1,0 +1,224 @@
+// attn_small.hip — flash SpatialAttention for SMALL head dims (C = d <= 16) on v_mfma_f32_16x16x4_f32.
+//
+// Same semantics and epilogue as attn_flash.hip (wdf_attention_helper.py:41-54 + the CMDA tail), but the
+// 32x32 tiles of that kernel waste 75 % of the second product's rows at C = 8 (s1_fuse of the R50 model,
+// N = 25088) and 87 % at C = 4 (GhostNet s1_fuse, N = 100352).  Here one wavefront owns 16 query rows and
+// both products run on 16x16x4 tiles:
+//   S^T[16 keys x 16 queries] = K * Q^T : A = K^T tile from LDS (lane (key j, quarter g) -> channel 4s+g),
+//                                         B = Q fragment (lane (query i, quarter g) -> channel 4s+g);
+//       the accumulator leaves query i on the lane (col = lane&15) and keys 4g..4g+3 in its 4 registers.
+//   O^T[16 ch x 16 queries] += V^T * P^T : B = those registers unchanged (k = key group g, col = query),
+//                                         A = V[key 4g + r][channel lane&15] (ds_read_b32, conflict free).
+// Four key tiles (64 keys) are scored before each online-softmax update, so the per-row max costs one
+// in-register reduction over 16 values plus two lane-quarter exchanges, as in the 32x32 kernel.
+#include "common.h"
+
+namespace {
+
+struct AttnArgs {
+  const float* q; const float* k; const float* v; const float* x;
+  const float* gamma; const float* scale; const float* bias;
+  float* out;
+  int q_cs, k_cs, v_cs, x_cs, out_cs, out_coff;
+  int B, T, H, W, C, N, alpha, act, nqt;
+};
+
+constexpr float NEG_BIG = -3.0e38f;
+
+template <int CP, int VEC>
+__global__ __launch_bounds__(256) void attn_small_kernel(const AttnArgs p) {
+  constexpr int KT = 64;                        // keys per LDS tile = one softmax step
+  constexpr int QS = CP / 4;                    // MFMA k-steps of the first product
+  constexpr int KP = KT + 16;                   // K^T row pitch: quarter g lands 16 banks further
+  constexpr int VP = (CP == 16) ? 20 : 12;      // V row pitch: rows 4 apart land 16 banks apart
+  constexpr int F4 = CP / 4;
+  constexpr int NLD = KT * F4;                  // float4 per tile (K and V each), <= 256
+
+  __shared__ __attribute__((aligned(16))) float smem[2 * (CP * KP + KT * VP)];
+  float* const Kt = smem;
+  float* const Vs = smem + 2 * CP * KP;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int li = lane & 15;
+  const int lg = lane >> 4;
+  const int b = blockIdx.x / p.nqt;
+  const int q0 = (blockIdx.x - b * p.nqt) * 64 + wave * 16;
+  const int N = p.N, C = p.C;
+  const long brow = (long)b * N;
+
+  // ---- Q fragment: lane (i, g) holds Q[i][4s + g]
+  float qf[QS];
+  {
+    const int qrow = q0 + li;
+    const bool ok = qrow < N;
+    const float* qp = p.q + (brow + (ok ? qrow : 0)) * p.q_cs;
+#pragma unroll
+    for (int s = 0; s < QS; ++s) {
+      const int c = 4 * s + lg;
+      qf[s] = (ok && c < C) ? qp[c] : 0.f;
+    }
+  }
+
+  f32x4 o = {0.f, 0.f, 0.f, 0.f};
+  float m_run = NEG_BIG;
+  float l_run = 0.f;
+
+  // ---- staging: thread tid < NLD owns float4 (row = tid / F4, channels 4*(tid % F4) ..)
+  const int srow = tid / F4;
+  const int sc4 = (tid - srow * F4) * 4;
+  f32x4 rk = {0.f, 0.f, 0.f, 0.f}, rv = {0.f, 0.f, 0.f, 0.f};
+  auto load_tile = [&](int j0) {
+    rk = (f32x4){0.f, 0.f, 0.f, 0.f};
+    rv = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int j = j0 + srow;
+    if (tid < NLD && j < N) {
+      const float* kp = p.k + (brow + j) * p.k_cs + sc4;
+      const float* vp = p.v + (brow + j) * p.v_cs + sc4;
+      if (VEC == 4) {
+        if (sc4 < C) {
+          rk = *reinterpret_cast<const f32x4*>(kp);
+          rv = *reinterpret_cast<const f32x4*>(vp);
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if ((sc4 + e) < C) {
+            rk[e] = kp[e];
+            rv[e] = vp[e];
+          }
+      }
+    }
+  };
+  auto store_tile = [&](int buf) {
+    if (tid < NLD) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) Kt[(buf * CP + sc4 + e) * KP + srow] = rk[e];
+      *reinterpret_cast<f32x4*>(Vs + (buf * KT + srow) * VP + sc4) = rv;
+    }
+  };
+
+  const int ntiles = (N + KT - 1) / KT;
+  load_tile(0);
+  store_tile(0);
+  __syncthreads();
+  for (int t = 0; t < ntiles; ++t) {
+    const int buf = t & 1;
+    const bool more = (t + 1) < ntiles;
+    if (more) load_tile((t + 1) * KT);
+    // ---- scores for 4 key tiles of 16
+    f32x4 s[4];
+    const float* kbase = Kt + (buf * CP + lg) * KP + li;
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+      s[kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int u = 0; u < QS; ++u)
+        s[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(kbase[(4 * u) * KP + kt * 16], qf[u], s[kt], 0, 0, 0);
+    }
+    const int jbase = t * KT;
+    if (jbase + KT > N) {  // ragged last tile (wave-uniform)
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (jbase + kt * 16 + 4 * lg + r >= N) s[kt][r] = NEG_BIG;
+    }
+    // ---- online softmax over the 64 keys: 16 per lane, 4 lane quarters per query row
+    float mloc = s[0][0];
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) mloc = fmaxf(mloc, s[kt][r]);
+    mloc = fmaxf(mloc, __shfl_xor(mloc, 16, 64));
+    mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+    const float mnew = fmaxf(m_run, mloc);
+    const float alpha = __expf(m_run - mnew);
+    float lsum = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        s[kt][r] = __expf(s[kt][r] - mnew);
+        lsum += s[kt][r];
+      }
+    l_run = l_run * alpha + lsum;
+    m_run = mnew;
+    if (__any(alpha != 1.0f)) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o[r] *= alpha;
+    }
+    // ---- O^T += V^T P^T
+    const float* vbase = Vs + (buf * KT + 4 * lg) * VP + (li & (CP - 1));
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        o = __builtin_amdgcn_mfma_f32_16x16x4f32(vbase[(kt * 16 + r) * VP], s[kt][r], o, 0, 0, 0);
+    if (more) store_tile(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: lane (i, g) holds channels 4g..4g+3 of query i
+  float l_tot = l_run + __shfl_xor(l_run, 16, 64);
+  l_tot += __shfl_xor(l_tot, 32, 64);
+  const int qrow = q0 + li;
+  const int c0 = 4 * lg;
+  if (qrow >= N || c0 >= C) return;
+  const float inv_l = 1.0f / l_tot;
+  const float gamma = p.gamma ? p.gamma[0] : 1.0f;
+  const int HW = p.H * p.W;
+  const int tq = qrow / HW;
+  const int hw = qrow - tq * HW;
+  const float* xp = p.x + (brow + qrow) * p.x_cs;
+  const long orow0 = ((long)b * p.T * p.alpha + (long)tq * p.alpha) * HW + hw;
+  float y[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int c = c0 + e;
+    const bool okc = c < C;
+    float v = gamma * (o[e] * inv_l) + (okc ? xp[c] : 0.f);
+    if (p.scale && okc) v = v * p.scale[c] + p.bias[c];
+    if (p.act == SF_ACT_RELU) v = fmaxf(v, 0.f);
+    y[e] = v;
+  }
+  for (int r = 0; r < p.alpha; ++r) {
+    float* op = p.out + (orow0 + (long)r * HW) * p.out_cs + p.out_coff + c0;
+    if (VEC == 4) {
+      *reinterpret_cast<f32x4*>(op) = (f32x4){y[0], y[1], y[2], y[3]};
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if ((c0 + e) < C) op[e] = y[e];
+    }
+  }
+}
+
+template <int CP>
+int launch(const AttnArgs& a, bool vec4, hipStream_t s) {
+  const int grid = a.B * a.nqt;
+  if (vec4)
+    hipLaunchKernelGGL((attn_small_kernel<CP, 4>), dim3(grid), dim3(256), 0, s, a);
+  else
+    hipLaunchKernelGGL((attn_small_kernel<CP, 1>), dim3(grid), dim3(256), 0, s, a);
+  SF_CHECK_LAUNCH();
+  return SF_OK;
+}
+
+}  // namespace
+
+// Called by sf_attn_fwd (attn_flash.hip) for C <= 16.
+int sf_attn_small_dispatch(const float* q, int q_cs, const float* k, int k_cs, const float* v, int v_cs,
+                           const float* x, int x_cs, const float* gamma, const float* scale, const float* bias,
+                           int act, float* out, int out_cs, int out_coff, int B, int T, int H, int W, int C,
+                           int alpha, bool vec4, hipStream_t stream) {
+  AttnArgs a;
+  a.q = q; a.k = k; a.v = v; a.x = x; a.gamma = gamma; a.scale = scale; a.bias = bias; a.out = out;
+  a.q_cs = q_cs; a.k_cs = k_cs; a.v_cs = v_cs; a.x_cs = x_cs; a.out_cs = out_cs; a.out_coff = out_coff;
+  a.B = B; a.T = T; a.H = H; a.W = W; a.C = C; a.N = T * H * W; a.alpha = alpha; a.act = act;
+  a.nqt = sf_cdiv(a.N, 64);
+  if (C <= 4) return launch<4>(a, vec4, stream);
+  if (C <= 8) return launch<8>(a, vec4, stream);
+  return launch<16>(a, vec4, stream);
+}
