@@ -36,6 +36,7 @@ struct AttnArgs {
 };
 
 constexpr float NEG_BIG = -3.0e38f;
+constexpr float LOG2E = 1.4426950408889634f;
 
 template <int CP, int VEC>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
@@ -75,10 +76,10 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
         f32x4 t = {0.f, 0.f, 0.f, 0.f};
         if (ok && c < C) t = *reinterpret_cast<const f32x4*>(qp + c);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) qf[s * 4 + e] = t[e];
+        for (int e = 0; e < 4; ++e) qf[s * 4 + e] = t[e] * LOG2E;  // exp2 domain: p = 2^(s' - m')
       } else {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) qf[s * 4 + e] = (ok && (c + e) < C) ? qp[c + e] : 0.f;
+        for (int e = 0; e < 4; ++e) qf[s * 4 + e] = (ok && (c + e) < C) ? qp[c + e] * LOG2E : 0.f;
       }
     }
   }
@@ -171,11 +172,11 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
       for (int r = 1; r < 16; ++r) mloc = fmaxf(mloc, s[r]);
       mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
       const float mnew = fmaxf(m_run, mloc);
-      const float alpha = __expf(m_run - mnew);
+      const float alpha = __builtin_amdgcn_exp2f(m_run - mnew);
       float lsum = 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        s[r] = __expf(s[r] - mnew);
+        s[r] = __builtin_amdgcn_exp2f(s[r] - mnew);
         lsum += s[r];
       }
       l_run = l_run * alpha + lsum;

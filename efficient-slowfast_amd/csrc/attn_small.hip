@@ -24,6 +24,7 @@ struct AttnArgs {
 };
 
 constexpr float NEG_BIG = -3.0e38f;
+constexpr float LOG2E = 1.4426950408889634f;
 
 template <int CP, int VEC>
 __global__ __launch_bounds__(256) void attn_small_kernel(const AttnArgs p) {
@@ -57,11 +58,16 @@ __global__ __launch_bounds__(256) void attn_small_kernel(const AttnArgs p) {
 #pragma unroll
     for (int s = 0; s < QS; ++s) {
       const int c = 4 * s + lg;
-      qf[s] = (ok && c < C) ? qp[c] : 0.f;
+      qf[s] = (ok && c < C) ? qp[c] * LOG2E : 0.f;  // scores in the exp2 domain: p = 2^(s' - m')
     }
   }
 
-  f32x4 o = {0.f, 0.f, 0.f, 0.f};
+  // Two accumulators break the 16-long dependent MFMA chain of the second product (40-cycle dependent
+  // latency vs 32-cycle issue).  For CP < 16 the tile has spare rows: row CP of V^T is all ones (written
+  // into the V tile's pad column), so O^T row CP accumulates the softmax denominator on the matrix core
+  // with exactly the same rescaling as O — no per-element VALU adds.
+  constexpr bool ONES_ROW = CP < 16;
+  f32x4 o0 = {0.f, 0.f, 0.f, 0.f}, o1 = {0.f, 0.f, 0.f, 0.f};
   float m_run = NEG_BIG;
   float l_run = 0.f;
 
@@ -96,6 +102,7 @@ __global__ __launch_bounds__(256) void attn_small_kernel(const AttnArgs p) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) Kt[(buf * CP + sc4 + e) * KP + srow] = rk[e];
       *reinterpret_cast<f32x4*>(Vs + (buf * KT + srow) * VP + sc4) = rv;
+      if (ONES_ROW && sc4 == 0) Vs[(buf * KT + srow) * VP + CP] = 1.0f;
     }
   };
 
@@ -134,35 +141,48 @@ __global__ __launch_bounds__(256) void attn_small_kernel(const AttnArgs p) {
     mloc = fmaxf(mloc, __shfl_xor(mloc, 16, 64));
     mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
     const float mnew = fmaxf(m_run, mloc);
-    const float alpha = __expf(m_run - mnew);
+    const float alpha = __builtin_amdgcn_exp2f(m_run - mnew);
     float lsum = 0.f;
 #pragma unroll
     for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        s[kt][r] = __expf(s[kt][r] - mnew);
-        lsum += s[kt][r];
+        s[kt][r] = __builtin_amdgcn_exp2f(s[kt][r] - mnew);
+        if (!ONES_ROW) lsum += s[kt][r];
       }
-    l_run = l_run * alpha + lsum;
+    if (!ONES_ROW) l_run = l_run * alpha + lsum;
     m_run = mnew;
     if (__any(alpha != 1.0f)) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) o[r] *= alpha;
+      for (int r = 0; r < 4; ++r) {
+        o0[r] *= alpha;
+        o1[r] *= alpha;
+      }
     }
-    // ---- O^T += V^T P^T
-    const float* vbase = Vs + (buf * KT + 4 * lg) * VP + (li & (CP - 1));
+    // ---- O^T += V^T P^T (lanes li > CP re-read column 0: their output rows are never stored)
+    const float* vbase = Vs + (buf * KT + 4 * lg) * VP + (ONES_ROW ? (li <= CP ? li : 0) : li);
 #pragma unroll
     for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
-        o = __builtin_amdgcn_mfma_f32_16x16x4f32(vbase[(kt * 16 + r) * VP], s[kt][r], o, 0, 0, 0);
+      for (int r = 0; r < 4; r += 2) {
+        o0 = __builtin_amdgcn_mfma_f32_16x16x4f32(vbase[(kt * 16 + r) * VP], s[kt][r], o0, 0, 0, 0);
+        o1 = __builtin_amdgcn_mfma_f32_16x16x4f32(vbase[(kt * 16 + r + 1) * VP], s[kt][r + 1], o1, 0, 0, 0);
+      }
     if (more) store_tile(buf ^ 1);
     __syncthreads();
   }
 
   // ---- epilogue: lane (i, g) holds channels 4g..4g+3 of query i
-  float l_tot = l_run + __shfl_xor(l_run, 16, 64);
-  l_tot += __shfl_xor(l_tot, 32, 64);
+  f32x4 o;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) o[r] = o0[r] + o1[r];
+  float l_tot;
+  if (ONES_ROW) {  // denominator = O^T row CP: lane (i, g = CP/4), register 0
+    l_tot = __shfl(o[0], li + 16 * (CP / 4), 64);
+  } else {
+    l_tot = l_run + __shfl_xor(l_run, 16, 64);
+    l_tot += __shfl_xor(l_tot, 32, 64);
+  }
   const int qrow = q0 + li;
   const int c0 = 4 * lg;
   if (qrow >= N || c0 >= C) return;
