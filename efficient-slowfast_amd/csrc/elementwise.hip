@@ -306,6 +306,96 @@ __global__ void copy_channels_kernel(const float* __restrict__ in, int in_cs, in
   out[r * out_cs + out_coff + (long)c * out_cmul] = in[r * in_cs + in_coff + c];
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Training-mode BN statistics: partial[blk][{sum,sumsq}][c] over the block's rows (fp32), combined in fp64.
+constexpr int STAT_P = 128;
+
+__global__ void stats_partial_kernel(const float* __restrict__ x, int cs, int coff, long rows, int C, int CB,
+                                     float* __restrict__ partial) {
+  __shared__ float red[2 * TPB];
+  const int blk = blockIdx.x, cb = blockIdx.y;
+  const int cl = threadIdx.x % CB, rl = threadIdx.x / CB, rpi = TPB / CB;
+  const int c = cb * CB + cl;
+  const long per = (rows + STAT_P - 1) / STAT_P;
+  const long r0 = (long)blk * per;
+  const long r1 = (r0 + per < rows) ? r0 + per : rows;
+  float s1 = 0.f, s2 = 0.f;
+  if (c < C) {
+    for (long r = r0 + rl; r < r1; r += rpi) {
+      const float v = x[r * cs + coff + c];
+      s1 += v;
+      s2 = fmaf(v, v, s2);
+    }
+  }
+  red[threadIdx.x] = s1;
+  red[TPB + threadIdx.x] = s2;
+  __syncthreads();
+  if (rl == 0 && c < C) {
+    float t1 = 0.f, t2 = 0.f;
+    for (int i = 0; i < rpi; ++i) {
+      t1 += red[i * CB + cl];
+      t2 += red[TPB + i * CB + cl];
+    }
+    partial[((long)blk * 2 + 0) * C + c] = t1;
+    partial[((long)blk * 2 + 1) * C + c] = t2;
+  }
+}
+
+__global__ void stats_final_kernel(const float* __restrict__ partial, int C, double inv_rows,
+                                   float* __restrict__ mean, float* __restrict__ var) {
+  const int c = blockIdx.x * TPB + threadIdx.x;
+  if (c >= C) return;
+  double s1 = 0.0, s2 = 0.0;
+  for (int i = 0; i < STAT_P; ++i) {
+    s1 += (double)partial[((long)i * 2 + 0) * C + c];
+    s2 += (double)partial[((long)i * 2 + 1) * C + c];
+  }
+  const double m = s1 * inv_rows;
+  double v = s2 * inv_rows - m * m;
+  mean[c] = (float)m;
+  var[c] = (float)(v > 0.0 ? v : 0.0);
+}
+
+// out[n, t*rep + r, hw, c] = act(x[n,t,hw,c] * scale[c] + bias[c] + res[n,t,hw,c])
+template <int VEC>
+__global__ void affine_kernel(const float* __restrict__ x, int cs, int coff, long THW_in, int HW, int C,
+                              const float* __restrict__ scale, const float* __restrict__ bias,
+                              const float* __restrict__ res, int res_cs, int res_coff, int act, int rep,
+                              float* __restrict__ out, int out_cs, int out_coff, int out_cmul, long total) {
+  const long idx = (long)blockIdx.x * TPB + threadIdx.x;
+  if (idx >= total) return;
+  const int cv = (C + VEC - 1) / VEC;
+  const int c = (int)(idx % cv) * VEC;
+  const long r = idx / cv;                 // input row: (n, t, hw)
+  const long n = r / THW_in;
+  const long thw = r - n * THW_in;
+  const long t = thw / HW, hw = thw - t * HW;
+  float v[VEC];
+  if (VEC == 4) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(x + r * cs + coff + c);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = a[e];
+  } else {
+    v[0] = x[r * cs + coff + c];
+  }
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) {
+    float y = v[e];
+    if (scale) y = y * scale[c + e] + bias[c + e];
+    if (res) y += res[r * res_cs + res_coff + c + e];
+    v[e] = (act == SF_ACT_RELU) ? fmaxf(y, 0.f) : y;
+  }
+  for (int q = 0; q < rep; ++q) {
+    float* o = out + ((n * (THW_in / HW) * rep + t * rep + q) * HW + hw) * out_cs + out_coff + (long)c * out_cmul;
+    if (VEC == 4) {
+      *reinterpret_cast<f32x4*>(o) = (f32x4){v[0], v[1], v[2], v[3]};
+    } else {
+      o[0] = v[0];
+    }
+  }
+}
+
 inline int pow2ceil(int v) {
   int p = 1;
   while (p < v) p <<= 1;
@@ -418,6 +508,44 @@ extern "C" int sf_gate_apply(const float* x, int cs, int coff, int N, int T, int
   else
     hipLaunchKernelGGL(gate_apply_kernel<1>, dim3(gx, N), dim3(TPB), shm, (hipStream_t)stream, x, cs, coff, T,
                        H * W, C, alpha, pooled, w3, scale, bias, act, out, out_cs, out_coff);
+  SF_CHECK_LAUNCH();
+  return SF_OK;
+}
+
+
+extern "C" long sf_channel_stats_ws_floats(int C) { return (long)STAT_P * 2 * C; }
+
+extern "C" int sf_channel_stats(const float* x, int cs, int coff, long rows, int C, float* mean, float* var,
+                                float* ws, void* stream) {
+  if (!x || !mean || !var || !ws || rows <= 0 || C <= 0) return SF_EINVAL;
+  const int CB = pow2ceil(C) < TPB ? pow2ceil(C) : TPB;
+  hipLaunchKernelGGL(stats_partial_kernel, dim3(STAT_P, sf_cdiv(C, CB)), dim3(TPB), 0, (hipStream_t)stream, x, cs,
+                     coff, rows, C, CB, ws);
+  hipLaunchKernelGGL(stats_final_kernel, dim3(sf_cdiv(C, TPB)), dim3(TPB), 0, (hipStream_t)stream, ws, C,
+                     1.0 / (double)rows, mean, var);
+  SF_CHECK_LAUNCH();
+  return SF_OK;
+}
+
+extern "C" int sf_affine_fwd(const float* x, int cs, int coff, int N, int T, int H, int W, int C,
+                             const float* scale, const float* bias, const float* res, int res_cs, int res_coff,
+                             int act, int rep, float* out, int out_cs, int out_coff, int out_cmul, void* stream) {
+  if (!x || !out || N <= 0 || T <= 0 || H <= 0 || W <= 0 || C <= 0 || rep <= 0 || out_cmul <= 0) return SF_EINVAL;
+  if ((scale == nullptr) != (bias == nullptr)) return SF_EINVAL;
+  if (act != SF_ACT_NONE && act != SF_ACT_RELU) return SF_EINVAL;
+  const bool vec4 = (out_cmul == 1) && (C % 4 == 0) && (cs % 4 == 0) && (coff % 4 == 0) && (out_cs % 4 == 0) &&
+                    (out_coff % 4 == 0) && sf_aligned16(x) && sf_aligned16(out) &&
+                    (!res || ((res_cs % 4 == 0) && (res_coff % 4 == 0) && sf_aligned16(res)));
+  const long rows = (long)N * T * H * W;
+  const long total = rows * (vec4 ? C / 4 : C);
+  if (vec4)
+    hipLaunchKernelGGL(affine_kernel<4>, dim3(sf_cdiv(total, TPB)), dim3(TPB), 0, (hipStream_t)stream, x, cs, coff,
+                       (long)T * H * W, H * W, C, scale, bias, res, res_cs, res_coff, act, rep, out, out_cs,
+                       out_coff, out_cmul, total);
+  else
+    hipLaunchKernelGGL(affine_kernel<1>, dim3(sf_cdiv(total, TPB)), dim3(TPB), 0, (hipStream_t)stream, x, cs, coff,
+                       (long)T * H * W, H * W, C, scale, bias, res, res_cs, res_coff, act, rep, out, out_cs,
+                       out_coff, out_cmul, total);
   SF_CHECK_LAUNCH();
   return SF_OK;
 }

@@ -40,7 +40,7 @@ class PoolDesc(ctypes.Structure):
 EXPORTS = [
     "sf_abi_version", "sf_build_arch", "sf_ncthw_to_ndhwc", "sf_ndhwc_to_ncthw", "sf_conv_fwd", "sf_dwconv_fwd",
     "sf_pool_fwd", "sf_tmax_mean_ws_floats", "sf_tmax_mean", "sf_gate_apply", "sf_attn_fwd", "sf_head_act_mean",
-    "sf_copy_channels",
+    "sf_copy_channels", "sf_channel_stats_ws_floats", "sf_channel_stats", "sf_affine_fwd",
 ]
 
 
@@ -72,9 +72,13 @@ def lib():
         L.sf_attn_fwd.argtypes = [vp, ci, vp, ci, vp, ci, vp, ci, vp, vp, vp, ci, vp, ci, ci] + [ci] * 6 + [vp]
         L.sf_head_act_mean.argtypes = [vp, ci, ci, ci, ci, vp, vp]
         L.sf_copy_channels.argtypes = [vp, ci, ci, vp, ci, ci, ci, cl, ci, vp]
+        L.sf_channel_stats_ws_floats.argtypes = [ci]
+        L.sf_channel_stats_ws_floats.restype = cl
+        L.sf_channel_stats.argtypes = [vp, ci, ci, cl, ci, vp, vp, vp, vp]
+        L.sf_affine_fwd.argtypes = [vp, ci, ci] + [ci] * 5 + [vp, vp, vp, ci, ci, ci, ci, vp, ci, ci, ci, vp]
         for name in EXPORTS:
             fn = getattr(L, name)
-            if name not in ("sf_build_arch", "sf_tmax_mean_ws_floats"):
+            if name not in ("sf_build_arch", "sf_tmax_mean_ws_floats", "sf_channel_stats_ws_floats"):
                 fn.restype = ci
         _lib = L
     return _lib
@@ -321,4 +325,33 @@ def copy_channels(x, out, out_cmul=1):
     assert x.rows == out.rows
     _check(lib().sf_copy_channels(x.ptr(), x.cs, x.coff, out.ptr(), out.cs, out.coff, out_cmul, x.rows, x.C,
                                   _stream()), "sf_copy_channels")
+    return out
+
+
+def channel_stats(x):
+    """Per-channel (mean, biased variance) over all N*T*H*W rows of the view -> two torch [C] tensors."""
+    _require_gpu(x.buf, "channel_stats")
+    dev = x.buf.device
+    mean = torch.empty((x.C,), dtype=torch.float32, device=dev)
+    var = torch.empty((x.C,), dtype=torch.float32, device=dev)
+    ws = torch.empty((lib().sf_channel_stats_ws_floats(x.C),), dtype=torch.float32, device=dev)
+    _check(lib().sf_channel_stats(x.ptr(), x.cs, x.coff, x.rows, x.C, _ptr(mean), _ptr(var), _ptr(ws), _stream()),
+           "sf_channel_stats")
+    return mean, var
+
+
+def affine(x, scale=None, bias=None, res=None, relu=False, rep=1, out=None, out_reserve=(0, 0), out_cmul=1):
+    """out = act(x*scale + bias + res), repeated `rep` times along T (nearest upsample)."""
+    _require_gpu(x.buf, "affine")
+    if out is None:
+        out = new_act(x, x.N, x.T * rep, x.H, x.W, x.C, out_reserve[0], out_reserve[1])
+    else:
+        assert (out.N, out.T, out.H, out.W) == (x.N, x.T * rep, x.H, x.W), (out, x, rep)
+        assert out.coff + (x.C - 1) * out_cmul < out.cs and (out_cmul > 1 or out.C == x.C), (out, x)
+    if res is not None:
+        assert res.rows == x.rows and res.C == x.C
+    _check(lib().sf_affine_fwd(x.ptr(), x.cs, x.coff, x.N, x.T, x.H, x.W, x.C, _ptr(scale), _ptr(bias),
+                               res.ptr() if res is not None else None, res.cs if res is not None else 0,
+                               res.coff if res is not None else 0, ACT_RELU if relu else ACT_NONE, rep,
+                               out.ptr(), out.cs, out.coff, out_cmul, _stream()), "sf_affine_fwd")
     return out

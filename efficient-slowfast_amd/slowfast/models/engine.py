@@ -57,10 +57,28 @@ def _cached(mod, slot, key, make):
 def check_bn(bn):
     if not isinstance(bn, nn.BatchNorm3d):
         raise NotImplementedError("only BN.NORM_TYPE=batchnorm is implemented on the HIP path (got %s)" % type(bn))
-    if bn.training:
-        raise NotImplementedError(
-            "training-mode BatchNorm (batch statistics) is not implemented on the HIP path yet; "
-            "call model.eval() — see DESIGN.md 'what comes next'")
+
+
+def bn_train_apply(bn, z, res=None, relu=False, rep=1, out=None, out_reserve=(0, 0), keep=None, out_cmul=1):
+    """Training-mode BatchNorm3d on the raw tensor z: batch statistics (sf_channel_stats), running-stat update
+    (momentum, unbiased variance — torch semantics), then ONE normalise(+residual)(+ReLU)(+T-repeat) pass."""
+    check_bn(bn)
+    mean, var = sfhip.channel_stats(z)
+    with torch.no_grad():
+        invstd = torch.rsqrt(var + bn.eps)
+        scale = bn.weight * invstd
+        shift = bn.bias - mean * scale
+        if bn.track_running_stats and bn.running_mean is not None:
+            n = z.rows
+            m = bn.momentum if bn.momentum is not None else 1.0 / float(int(bn.num_batches_tracked) + 1)
+            bn.running_mean.mul_(1.0 - m).add_(mean, alpha=m)
+            bn.running_var.mul_(1.0 - m).add_(var, alpha=m * n / max(n - 1, 1))
+            bn.num_batches_tracked.add_(1)
+    zz = z if keep is None else z.slice(0, keep)
+    if keep is not None:
+        scale, shift = scale[:keep].contiguous(), shift[:keep].contiguous()
+    return sfhip.affine(zz, scale.contiguous(), shift.contiguous(), res=res, relu=relu, rep=rep, out=out,
+                        out_reserve=out_reserve, out_cmul=out_cmul)
 
 
 def bn_affine(bn, conv_bias=None):
@@ -86,8 +104,19 @@ def packed_weight(conv):
 
 
 def conv_bn_act(x, conv, bn=None, relu=False, res=None, out=None, out_reserve=(0, 0), out_cmul=1, cout=None):
-    """nn.Conv3d [+ BatchNorm3d (eval)] [+ residual] [+ ReLU] as ONE kernel launch."""
+    """nn.Conv3d [+ BatchNorm3d] [+ residual] [+ ReLU].  Eval: ONE kernel launch (BN folded into the
+    epilogue).  Training: raw conv -> batch statistics -> one normalise/residual/ReLU pass."""
     wp = packed_weight(conv)
+    if bn is not None and bn.training:
+        k, s, p, d = conv.kernel_size, conv.stride, conv.padding, conv.dilation
+        if conv.groups == 1:
+            z = sfhip.conv(x, wp, k, s, p, d, bias=conv.bias)
+        else:
+            ones = _cached(conv, "_sf_ones", (conv.out_channels, str(x.buf.device)),
+                           lambda: torch.ones(conv.out_channels, dtype=torch.float32, device=x.buf.device))
+            z = sfhip.dwconv(x, wp, k, s, p, scale=ones if conv.bias is not None else None, bias=conv.bias)
+        return bn_train_apply(bn, z, res=res, relu=relu, out=out, out_reserve=out_reserve, keep=cout,
+                              out_cmul=out_cmul)
     if bn is not None:
         scale, bias = bn_affine(bn, conv.bias)
     else:
@@ -133,6 +162,10 @@ def stem_conv_bn_relu(x, conv, bn, relu=True):
         return wp.contiguous()
 
     wp = _cached(conv, "_sf_wp_stem", _key(conv.weight), make)
+    thw = (T + 2 * pT - kT + 1, Ho, Wo)
+    if bn.training:
+        z = sfhip.conv(view, wp, (kT, kH, 1), (1, sH, 1), (pT, 0, 0), bias=conv.bias, cin=4 * kW, out_thw=thw)
+        return bn_train_apply(bn, z, relu=relu)
     scale, bias = bn_affine(bn, conv.bias)
     return sfhip.conv(view, wp, (kT, kH, 1), (1, sH, 1), (pT, 0, 0), scale=scale, bias=bias, relu=relu,
-                      cin=4 * kW, out_thw=(T + 2 * pT - kT + 1, Ho, Wo))
+                      cin=4 * kW, out_thw=thw)

@@ -112,6 +112,18 @@ int sf_attn_fwd(const float* q, int q_cs, const float* k, int k_cs, const float*
                 int act, float* out, int out_cs, int out_coff, int B, int T, int H, int W, int C,
                 int alpha, void* stream);
 
+/* ---- training-mode BatchNorm3d forward pieces (batchnorm_helper.py:15-34 -> nn.BatchNorm3d, training=True)
+ * sf_channel_stats: per-channel mean and BIASED variance over all rows of an NDHWC slice, reduced through
+ *   a fixed number of fp32 partials combined in fp64 (bit-reproducible; ws = sf_channel_stats_ws_floats(C)).
+ * sf_affine_fwd:    out = act(x * scale[c] + bias[c] + res), optionally repeated `rep` times along T
+ *   (nn.Upsample nearest, custom_video_model_builder.py:120-121) — the normalise(+residual)(+ReLU) pass.   */
+long sf_channel_stats_ws_floats(int C);
+int sf_channel_stats(const float* x, int cs, int coff, long rows, int C, float* mean, float* var, float* ws,
+                     void* stream);
+int sf_affine_fwd(const float* x, int cs, int coff, int N, int T, int H, int W, int C, const float* scale,
+                  const float* bias, const float* res, int res_cs, int res_coff, int act, int rep, float* out,
+                  int out_cs, int out_coff, int out_cmul, void* stream);
+
 /* ---- head tail (eval): activation over classes then mean over T,H,W -----------------------------
  * head_helper.py:217-221.  logits [B, P, K] -> out [B, K]; act = SF_ACT_SOFTMAX | SIGMOID | RELU | NONE */
 int sf_head_act_mean(const float* logits, int B, int P, int K, int act, float* out, void* stream);

@@ -144,3 +144,47 @@ def test_state_dict_roundtrip_and_cache_invalidation():
         c = model([x.clone() for x in xs]).cpu()
     assert (a - b).abs().max() > 1e-6
     assert torch.equal(a, c)
+
+
+@pytest.mark.parametrize("name", MODEL_CASES)
+def test_train_mode_forward_matches_reference_golden(name):
+    """model.train() forward (batch-statistics BatchNorm, raw logits — train_net.py:78) vs the reference's
+    train-mode logits and stage samples; dropout disabled on both sides."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import sfhip
+    z, meta = load_case(name)
+    model, sd = _build(meta, z)
+    for m in model.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    model.train()
+    acts = {}
+
+    def hook(child):
+        def f(m, i, o):
+            if isinstance(o, (list, tuple)):
+                acts[child] = [sfhip.to_ncthw(a).cpu().numpy() if isinstance(a, sfhip.Act) else a.cpu().numpy()
+                               for a in o]
+        return f
+
+    for n, m in model.named_children():
+        m.register_forward_hook(hook(n))
+    rm_before = {k: v.clone() for k, v in model.state_dict().items() if k.endswith("running_var")}
+    with torch.no_grad():
+        out = model([x.cuda() for x in case_inputs(meta)])
+    torch.cuda.synchronize()
+    for k in ("s2", "s3_fuse", "s5"):
+        if k in acts and ("train/%s/0" % k) in z:
+            for i, a in enumerate(acts[k]):
+                s, _, _ = sample_activation(a)
+                e = rel_err(s, z["train/%s/%d" % (k, i)])
+                _report("%-22s train %-10s p%d %.3e" % (name, k, i, e))
+                assert e < TOL, (k, i, e)
+    e = rel_err(out.cpu().numpy(), z["train/logits"])
+    _report("%-22s train logits %.3e" % (name, e))
+    assert e < TOL
+    # running statistics were updated in place (momentum 0.1) and the eval caches follow them
+    changed = sum(int(not torch.equal(v, model.state_dict()[k])) for k, v in rm_before.items())
+    assert changed == len(rm_before)
+    assert int(next(v for k, v in model.state_dict().items() if k.endswith("num_batches_tracked"))) == 1
