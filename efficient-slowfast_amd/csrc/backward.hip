@@ -1,0 +1,325 @@
+// backward.hip — bandwidth-bound backward passes of the SlowFast / CMDA path (NDHWC, fp32, gfx950):
+// training-mode BatchNorm backward fused with the ReLU mask, the residual fan-out and the nearest-upsample
+// reduction; max-pool backward; ECA (temporal max + channel gate) backward; broadcast / row-dot helpers.
+// Per-channel reductions go through a fixed number of fp32 partials combined in fp64 (bit-reproducible).
+#include "common.h"
+
+namespace {
+
+constexpr int TPB = 256;
+constexpr int RED_P = 128;
+
+inline int pow2ceil_b(int v) {
+  int p = 1;
+  while (p < v) p <<= 1;
+  return p;
+}
+
+// g(n,t,hw,c) = sum_{q<rep} dy[n, t*rep+q, hw, c] * (relu ? y[n, t*rep, hw, c] > 0 : 1)
+__device__ __forceinline__ float bn_g(const float* __restrict__ dy, int dy_cs, int dy_coff,
+                                      const float* __restrict__ y, int y_cs, int y_coff, long n, long t, long hw,
+                                      long T, int HW, int rep, int relu, int c) {
+  const long r0 = (n * T * rep + t * rep) * HW + hw;
+  if (relu && !(y[r0 * y_cs + y_coff + c] > 0.f)) return 0.f;
+  float g = 0.f;
+  for (int q = 0; q < rep; ++q) g += dy[(r0 + (long)q * HW) * dy_cs + dy_coff + c];
+  return g;
+}
+
+__global__ void bn_bwd_partial_kernel(const float* __restrict__ dy, int dy_cs, int dy_coff,
+                                      const float* __restrict__ y, int y_cs, int y_coff,
+                                      const float* __restrict__ z, int z_cs, int z_coff, long rows, long T, int HW,
+                                      int C, int rep, int relu, const float* __restrict__ mean,
+                                      const float* __restrict__ invstd, int CB, float* __restrict__ partial) {
+  __shared__ float red[2 * TPB];
+  const int blk = blockIdx.x, cb = blockIdx.y;
+  const int cl = threadIdx.x % CB, rl = threadIdx.x / CB, rpi = TPB / CB;
+  const int c = cb * CB + cl;
+  const long per = (rows + RED_P - 1) / RED_P;
+  const long r0 = (long)blk * per;
+  const long r1 = (r0 + per < rows) ? r0 + per : rows;
+  float s1 = 0.f, s2 = 0.f;
+  if (c < C) {
+    const float mu = mean[c], is = invstd[c];
+    const long THW = T * HW;
+    for (long r = r0 + rl; r < r1; r += rpi) {
+      const long n = r / THW, rem = r - n * THW;
+      const long t = rem / HW, hw = rem - t * HW;
+      const float g = bn_g(dy, dy_cs, dy_coff, y, y_cs, y_coff, n, t, hw, T, HW, rep, relu, c);
+      const float xh = (z[r * z_cs + z_coff + c] - mu) * is;
+      s1 += g;
+      s2 = fmaf(g, xh, s2);
+    }
+  }
+  red[threadIdx.x] = s1;
+  red[TPB + threadIdx.x] = s2;
+  __syncthreads();
+  if (rl == 0 && c < C) {
+    float t1 = 0.f, t2 = 0.f;
+    for (int i = 0; i < rpi; ++i) {
+      t1 += red[i * CB + cl];
+      t2 += red[TPB + i * CB + cl];
+    }
+    partial[((long)blk * 2 + 0) * C + c] = t1;
+    partial[((long)blk * 2 + 1) * C + c] = t2;
+  }
+}
+
+__global__ void pair_final_kernel(const float* __restrict__ partial, int C, float* __restrict__ o1,
+                                  float* __restrict__ o2) {
+  const int c = blockIdx.x * TPB + threadIdx.x;
+  if (c >= C) return;
+  double s1 = 0.0, s2 = 0.0;
+  for (int i = 0; i < RED_P; ++i) {
+    s1 += (double)partial[((long)i * 2 + 0) * C + c];
+    s2 += (double)partial[((long)i * 2 + 1) * C + c];
+  }
+  o1[c] = (float)s1;
+  o2[c] = (float)s2;
+}
+
+// dz = gamma*invstd * (g - dbeta/M - xhat*dgamma/M)   [written to dz, may alias z];   dres += g
+__global__ void bn_bwd_apply_kernel(const float* __restrict__ dy, int dy_cs, int dy_coff,
+                                    const float* __restrict__ y, int y_cs, int y_coff, const float* z, int z_cs,
+                                    int z_coff, long rows, long T, int HW, int C, int rep, int relu,
+                                    const float* __restrict__ mean, const float* __restrict__ invstd,
+                                    const float* __restrict__ gamma, const float* __restrict__ dbeta,
+                                    const float* __restrict__ dgamma, float inv_m, float* dz, int dz_cs, int dz_coff,
+                                    float* __restrict__ dres, int dres_cs, int dres_coff, long total) {
+  const long idx = (long)blockIdx.x * TPB + threadIdx.x;
+  if (idx >= total) return;
+  const int c = (int)(idx % C);
+  const long r = idx / C;
+  const long THW = T * HW;
+  const long n = r / THW, rem = r - n * THW;
+  const long t = rem / HW, hw = rem - t * HW;
+  const float g = bn_g(dy, dy_cs, dy_coff, y, y_cs, y_coff, n, t, hw, T, HW, rep, relu, c);
+  const float is = invstd[c];
+  const float xh = (z[r * z_cs + z_coff + c] - mean[c]) * is;
+  dz[r * dz_cs + dz_coff + c] = gamma[c] * is * (g - dbeta[c] * inv_m - xh * dgamma[c] * inv_m);
+  if (dres) dres[r * dres_cs + dres_coff + c] += g;
+}
+
+// max-pool backward by equality gather: dx[p] += sum_{windows w containing p} dy[w] * [x[p] == y[w]]
+__global__ void maxpool_bwd_kernel(const sf_pool_desc d, const float* __restrict__ x, const float* __restrict__ y,
+                                   const float* __restrict__ dy, int dy_cs, int dy_coff, float* __restrict__ dx,
+                                   int dx_cs, int dx_coff, long total) {
+  const long idx = (long)blockIdx.x * TPB + threadIdx.x;
+  if (idx >= total) return;
+  const int c = (int)(idx % d.C);
+  long r = idx / d.C;
+  const long rin = r;
+  const int wi = (int)(r % d.Wi);
+  r /= d.Wi;
+  const int hi = (int)(r % d.Hi);
+  r /= d.Hi;
+  const int ti = (int)(r % d.Ti);
+  const int n = (int)(r / d.Ti);
+  const float xv = x[rin * d.in_cs + d.in_coff + c];
+  auto lo = [](int i, int p, int k, int s) { const int a = i + p - k + 1; return a <= 0 ? 0 : (a + s - 1) / s; };
+  const int t0 = lo(ti, d.pT, d.kT, d.sT), t1 = min((ti + d.pT) / d.sT, d.To - 1);
+  const int h0 = lo(hi, d.pH, d.kH, d.sH), h1 = min((hi + d.pH) / d.sH, d.Ho - 1);
+  const int w0 = lo(wi, d.pW, d.kW, d.sW), w1 = min((wi + d.pW) / d.sW, d.Wo - 1);
+  float g = 0.f;
+  for (int to = t0; to <= t1; ++to)
+    for (int ho = h0; ho <= h1; ++ho)
+      for (int wo = w0; wo <= w1; ++wo) {
+        const long ro = (((long)n * d.To + to) * d.Ho + ho) * d.Wo + wo;
+        if (y[ro * d.out_cs + d.out_coff + c] == xv) g += dy[ro * dy_cs + dy_coff + c];
+      }
+  dx[rin * dx_cs + dx_coff + c] += g;
+}
+
+// ECA backward, reduction: partial[b][blk][c] = sum_{t',hw} dz[b,t',hw,c] * max_r x[b,t'*alpha+r,hw,c]
+constexpr int POOL_P = 64;
+__global__ void tmax_dot_partial_kernel(const float* __restrict__ x, int cs, int coff, int T, int HW, int C,
+                                        int alpha, const float* __restrict__ dz, int dz_cs, int dz_coff, int CB,
+                                        float* __restrict__ partial) {
+  __shared__ float red[TPB];
+  const int blk = blockIdx.x, cb = blockIdx.y, b = blockIdx.z;
+  const int cl = threadIdx.x % CB, rl = threadIdx.x / CB, rpi = TPB / CB;
+  const int c = cb * CB + cl;
+  const int To = T / alpha;
+  const long rows = (long)To * HW;
+  const long per = (rows + POOL_P - 1) / POOL_P;
+  const long r0 = (long)blk * per;
+  const long r1 = (r0 + per < rows) ? r0 + per : rows;
+  float sum = 0.f;
+  if (c < C) {
+    for (long r = r0 + rl; r < r1; r += rpi) {
+      const long t = r / HW, hw = r - t * HW;
+      const float* s = x + (((long)b * T + t * alpha) * HW + hw) * cs + coff + c;
+      float mx = s[0];
+      for (int a = 1; a < alpha; ++a) mx = fmaxf(mx, s[(long)a * HW * cs]);
+      sum = fmaf(mx, dz[((long)b * rows + r) * dz_cs + dz_coff + c], sum);
+    }
+  }
+  red[threadIdx.x] = sum;
+  __syncthreads();
+  if (rl == 0 && c < C) {
+    float tot = 0.f;
+    for (int i = 0; i < rpi; ++i) tot += red[i * CB + cl];
+    partial[((long)b * POOL_P + blk) * C + c] = tot;
+  }
+}
+
+__global__ void pool_final_kernel(const float* __restrict__ partial, int C, float* __restrict__ out) {
+  const int b = blockIdx.y;
+  const int c = blockIdx.x * TPB + threadIdx.x;
+  if (c >= C) return;
+  float tot = 0.f;
+  for (int i = 0; i < POOL_P; ++i) tot += partial[((long)b * POOL_P + i) * C + c];
+  out[(long)b * C + c] = tot;
+}
+
+// ECA backward, apply: dm = dz * gate[b,c] + dpool[b,c]; routed to the frame(s) holding the temporal max
+__global__ void eca_bwd_apply_kernel(const float* __restrict__ x, int cs, int coff, int T, int HW, int C, int alpha,
+                                     const float* __restrict__ dz, int dz_cs, int dz_coff,
+                                     const float* __restrict__ gate, const float* __restrict__ dpool,
+                                     float* __restrict__ dx, int dx_cs, int dx_coff, long total_per_b) {
+  const int b = blockIdx.y;
+  const long idx = (long)blockIdx.x * TPB + threadIdx.x;
+  if (idx >= total_per_b) return;
+  const int c = (int)(idx % C);
+  const long r = idx / C;  // (t', hw)
+  const long t = r / HW, hw = r - t * HW;
+  const long rows = (long)(T / alpha) * HW;
+  const long base = ((long)b * T + t * alpha) * HW + hw;
+  const float* s = x + base * cs + coff + c;
+  float mx = s[0];
+  for (int a = 1; a < alpha; ++a) mx = fmaxf(mx, s[(long)a * HW * cs]);
+  const float dm = dz[((long)b * rows + r) * dz_cs + dz_coff + c] * gate[(long)b * C + c] + dpool[(long)b * C + c];
+  for (int a = 0; a < alpha; ++a)
+    if (s[(long)a * HW * cs] == mx) dx[(base + (long)a * HW) * dx_cs + dx_coff + c] += dm;
+}
+
+__global__ void bcast_add_kernel(float* __restrict__ g, int cs, int coff, long rows_per_n, int C,
+                                 const float* __restrict__ v, float scale, long total) {
+  const long idx = (long)blockIdx.x * TPB + threadIdx.x;
+  if (idx >= total) return;
+  const int c = (int)(idx % C);
+  const long r = idx / C;
+  const long n = r / rows_per_n;
+  g[r * cs + coff + c] += v[n * C + c] * scale;
+}
+
+__global__ void rowdot_kernel(const float* __restrict__ a, int a_cs, int a_coff, const float* __restrict__ b,
+                              int b_cs, int b_coff, long rows, int C, float scale, float* __restrict__ out) {
+  const long r = (long)blockIdx.x * TPB + threadIdx.x;
+  if (r >= rows) return;
+  const float* ap = a + r * a_cs + a_coff;
+  const float* bp = b + r * b_cs + b_coff;
+  float s = 0.f;
+  for (int c = 0; c < C; ++c) s = fmaf(ap[c], bp[c], s);
+  out[r] = s * scale;
+}
+
+// out[r, c] (+)= alpha * a[r, c]   (gradient fan-in / scaled copies between channel slices)
+__global__ void axpy_kernel(const float* __restrict__ a, int a_cs, int a_coff, float alpha, float* __restrict__ out,
+                            int out_cs, int out_coff, int C, int accumulate, long total) {
+  const long idx = (long)blockIdx.x * TPB + threadIdx.x;
+  if (idx >= total) return;
+  const int c = (int)(idx % C);
+  const long r = idx / C;
+  const float v = alpha * a[r * a_cs + a_coff + c];
+  float* o = out + r * out_cs + out_coff + c;
+  *o = accumulate ? *o + v : v;
+}
+
+}  // namespace
+
+extern "C" long sf_bn_bwd_ws_floats(int C) { return (long)RED_P * 2 * C; }
+
+extern "C" int sf_bn_bwd_reduce(const float* dy, int dy_cs, int dy_coff, const float* y, int y_cs, int y_coff,
+                                const float* z, int z_cs, int z_coff, int N, int T, int H, int W, int C, int rep,
+                                int relu, const float* mean, const float* invstd, float* dbeta, float* dgamma,
+                                float* ws, void* stream) {
+  if (!dy || !z || !mean || !invstd || !dbeta || !dgamma || !ws || (relu && !y)) return SF_EINVAL;
+  if (N <= 0 || T <= 0 || H <= 0 || W <= 0 || C <= 0 || rep <= 0) return SF_EINVAL;
+  const long rows = (long)N * T * H * W;
+  const int CB = pow2ceil_b(C) < TPB ? pow2ceil_b(C) : TPB;
+  hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(RED_P, sf_cdiv(C, CB)), dim3(TPB), 0, (hipStream_t)stream, dy, dy_cs,
+                     dy_coff, y, y_cs, y_coff, z, z_cs, z_coff, rows, (long)T, H * W, C, rep, relu, mean, invstd, CB,
+                     ws);
+  hipLaunchKernelGGL(pair_final_kernel, dim3(sf_cdiv(C, TPB)), dim3(TPB), 0, (hipStream_t)stream, ws, C, dbeta,
+                     dgamma);
+  SF_CHECK_LAUNCH();
+  return SF_OK;
+}
+
+extern "C" int sf_bn_bwd_apply(const float* dy, int dy_cs, int dy_coff, const float* y, int y_cs, int y_coff,
+                               const float* z, int z_cs, int z_coff, int N, int T, int H, int W, int C, int rep,
+                               int relu, const float* mean, const float* invstd, const float* gamma,
+                               const float* dbeta, const float* dgamma, float* dz, int dz_cs, int dz_coff,
+                               float* dres, int dres_cs, int dres_coff, void* stream) {
+  if (!dy || !z || !mean || !invstd || !gamma || !dbeta || !dgamma || !dz || (relu && !y)) return SF_EINVAL;
+  if (N <= 0 || T <= 0 || H <= 0 || W <= 0 || C <= 0 || rep <= 0) return SF_EINVAL;
+  const long rows = (long)N * T * H * W;
+  const long total = rows * C;
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(sf_cdiv(total, TPB)), dim3(TPB), 0, (hipStream_t)stream, dy, dy_cs,
+                     dy_coff, y, y_cs, y_coff, z, z_cs, z_coff, rows, (long)T, H * W, C, rep, relu, mean, invstd,
+                     gamma, dbeta, dgamma, 1.0f / (float)rows, dz, dz_cs, dz_coff, dres, dres_cs, dres_coff, total);
+  SF_CHECK_LAUNCH();
+  return SF_OK;
+}
+
+extern "C" int sf_maxpool_bwd(const sf_pool_desc* d, const float* x, const float* y, const float* dy, int dy_cs,
+                              int dy_coff, float* dx, int dx_cs, int dx_coff, void* stream) {
+  if (!d || !x || !y || !dy || !dx || d->is_avg) return SF_EINVAL;
+  const long total = (long)d->N * d->Ti * d->Hi * d->Wi * d->C;
+  hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(sf_cdiv(total, TPB)), dim3(TPB), 0, (hipStream_t)stream, *d, x, y, dy,
+                     dy_cs, dy_coff, dx, dx_cs, dx_coff, total);
+  SF_CHECK_LAUNCH();
+  return SF_OK;
+}
+
+extern "C" int sf_tmax_dot(const float* x, int cs, int coff, int N, int T, int H, int W, int C, int alpha,
+                           const float* dz, int dz_cs, int dz_coff, float* out, float* ws, void* stream) {
+  if (!x || !dz || !out || !ws || N <= 0 || C <= 0 || alpha <= 0 || (T % alpha) != 0) return SF_EINVAL;
+  const int CB = pow2ceil_b(C) < TPB ? pow2ceil_b(C) : TPB;
+  hipLaunchKernelGGL(tmax_dot_partial_kernel, dim3(POOL_P, sf_cdiv(C, CB), N), dim3(TPB), 0, (hipStream_t)stream, x, cs,
+                     coff, T, H * W, C, alpha, dz, dz_cs, dz_coff, CB, ws);
+  hipLaunchKernelGGL(pool_final_kernel, dim3(sf_cdiv(C, TPB), N), dim3(TPB), 0, (hipStream_t)stream, ws, C, out);
+  SF_CHECK_LAUNCH();
+  return SF_OK;
+}
+
+extern "C" int sf_eca_bwd_apply(const float* x, int cs, int coff, int N, int T, int H, int W, int C, int alpha,
+                                const float* dz, int dz_cs, int dz_coff, const float* gate, const float* dpool,
+                                float* dx, int dx_cs, int dx_coff, void* stream) {
+  if (!x || !dz || !gate || !dpool || !dx || N <= 0 || C <= 0 || alpha <= 0 || (T % alpha) != 0) return SF_EINVAL;
+  const long per_b = (long)(T / alpha) * H * W * C;
+  hipLaunchKernelGGL(eca_bwd_apply_kernel, dim3(sf_cdiv(per_b, TPB), N), dim3(TPB), 0, (hipStream_t)stream, x, cs, coff,
+                     T, H * W, C, alpha, dz, dz_cs, dz_coff, gate, dpool, dx, dx_cs, dx_coff, per_b);
+  SF_CHECK_LAUNCH();
+  return SF_OK;
+}
+
+extern "C" int sf_bcast_add(float* g, int cs, int coff, int N, long rows_per_n, int C, const float* v, float scale,
+                            void* stream) {
+  if (!g || !v || N <= 0 || rows_per_n <= 0 || C <= 0) return SF_EINVAL;
+  const long total = (long)N * rows_per_n * C;
+  hipLaunchKernelGGL(bcast_add_kernel, dim3(sf_cdiv(total, TPB)), dim3(TPB), 0, (hipStream_t)stream, g, cs, coff,
+                     rows_per_n, C, v, scale, total);
+  SF_CHECK_LAUNCH();
+  return SF_OK;
+}
+
+extern "C" int sf_rowdot(const float* a, int a_cs, int a_coff, const float* b, int b_cs, int b_coff, long rows, int C,
+                         float scale, float* out, void* stream) {
+  if (!a || !b || !out || rows <= 0 || C <= 0) return SF_EINVAL;
+  hipLaunchKernelGGL(rowdot_kernel, dim3(sf_cdiv(rows, TPB)), dim3(TPB), 0, (hipStream_t)stream, a, a_cs, a_coff, b,
+                     b_cs, b_coff, rows, C, scale, out);
+  SF_CHECK_LAUNCH();
+  return SF_OK;
+}
+
+extern "C" int sf_axpy(const float* a, int a_cs, int a_coff, float alpha, float* out, int out_cs, int out_coff,
+                       long rows, int C, int accumulate, void* stream) {
+  if (!a || !out || rows <= 0 || C <= 0) return SF_EINVAL;
+  const long total = rows * C;
+  hipLaunchKernelGGL(axpy_kernel, dim3(sf_cdiv(total, TPB)), dim3(TPB), 0, (hipStream_t)stream, a, a_cs, a_coff, alpha,
+                     out, out_cs, out_coff, C, accumulate, total);
+  SF_CHECK_LAUNCH();
+  return SF_OK;
+}

@@ -76,9 +76,11 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
     const int t2 = t1 / d.Ho;
     const int to = t2 % d.To;
     a_n[i] = t2 / d.To;
-    a_t0[i] = to * d.sT - d.pT;
-    a_h0[i] = ho * d.sH - d.pH;
-    a_w0[i] = wo * d.sW - d.pW;
+    // transposed (data-gradient) mode: row = input position of the forward conv, the tap's source row is
+    // the forward OUTPUT position (t + pT - kt*dT) / sT when that division is exact (see set_tap)
+    a_t0[i] = d.transposed ? to + d.pT : to * d.sT - d.pT;
+    a_h0[i] = d.transposed ? ho + d.pH : ho * d.sH - d.pH;
+    a_w0[i] = d.transposed ? wo + d.pW : wo * d.sW - d.pW;
   }
   const long kpad = (long)p.ntaps * d.cin_pad;
   const float* b_ptr[B_IT];
@@ -98,10 +100,22 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
   auto set_tap = [&]() {
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) {
-      const int ti = a_t0[i] + kt * d.dT;
-      const int hi = a_h0[i] + kh * d.dH;
-      const int wi = a_w0[i] + kw * d.dW;
-      a_v[i] = a_ok[i] && (unsigned)ti < (unsigned)d.Ti && (unsigned)hi < (unsigned)d.Hi &&
+      int ti, hi, wi;
+      bool ok = a_ok[i];
+      if (d.transposed) {
+        ti = a_t0[i] - kt * d.dT;
+        hi = a_h0[i] - kh * d.dH;
+        wi = a_w0[i] - kw * d.dW;
+        ok = ok && ti >= 0 && hi >= 0 && wi >= 0;
+        if (d.sT > 1) { ok = ok && (ti % d.sT) == 0; ti /= d.sT; }
+        if (d.sH > 1) { ok = ok && (hi % d.sH) == 0; hi /= d.sH; }
+        if (d.sW > 1) { ok = ok && (wi % d.sW) == 0; wi /= d.sW; }
+      } else {
+        ti = a_t0[i] + kt * d.dT;
+        hi = a_h0[i] + kh * d.dH;
+        wi = a_w0[i] + kw * d.dW;
+      }
+      a_v[i] = ok && (unsigned)ti < (unsigned)d.Ti && (unsigned)hi < (unsigned)d.Hi &&
                (unsigned)wi < (unsigned)d.Wi;
       a_off[i] = ((((long)a_n[i] * d.Ti + ti) * d.Hi + hi) * d.Wi + wi) * d.in_cs + d.in_coff + lc;
     }

@@ -1,0 +1,200 @@
+// conv_wgrad.hip — weight gradient of a dense 3-D convolution on the fp32 matrix cores (gfx950).
+//
+//   dW[co, tap, ci] = sum_m dz[m, co] * x[row(m, tap), ci]          (m over the B*To*Ho*Wo output positions)
+//
+// Per tap this is a GEMM whose REDUCTION dimension is the position index m (up to 8e5 rows) and whose
+// output is a small [Cout x Cin] matrix, so the positions are split over `S` workgroups per output tile;
+// each writes an fp32 partial tile to a workspace [S][Cout][taps][cin_pad] that the caller sums in a
+// fixed order (bit-reproducible — no float atomics).
+//
+// Both operands are consumed "K-major" exactly as they sit in HBM (NDHWC rows = positions, channels
+// contiguous): tiles [32 positions][64 channels] are staged with 16-byte loads into LDS (80-dword pitch)
+// and each v_mfma_f32_16x16x4_f32 takes A = dz^T (lane (co, g) reads dz[4s+g][co]) and B = x (lane (ci, g)
+// reads x[4s+g][ci]) as conflict-free ds_read_b32.  Block tile 64 co x 64 ci, 4 wavefronts of 32 x 32.
+#include "common.h"
+
+namespace {
+
+struct WgradArgs {
+  sf_conv_desc d;      // the FORWARD conv's descriptor (in = x, out dims = dz dims)
+  const float* x;
+  const float* dz;     // [M][dz_cs] + dz_coff
+  float* part;         // [S][Cout][ntaps][cin_pad]
+  int dz_cs, dz_coff;
+  int M, ntaps, S, nb_co, nb_ci;
+  long chunk;          // positions per split (multiple of 32)
+};
+
+constexpr int BM = 32;    // positions per stage
+constexpr int BC = 64;    // channels per tile side
+constexpr int LP = 80;    // LDS row pitch (dwords): consecutive rows land 16 banks apart
+
+template <int VEC>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs p) {
+  __shared__ __attribute__((aligned(16))) float smem[2 * 2 * BM * LP];
+  float* const Zs = smem;                 // [2][BM][LP]  dz tile
+  float* const Xs = smem + 2 * BM * LP;   // [2][BM][LP]  x tile (gathered for this tap)
+
+  const sf_conv_desc& d = p.d;
+  const int tid = threadIdx.x;
+  int tile = blockIdx.x;
+  const int tap = tile % p.ntaps;
+  tile /= p.ntaps;
+  const int tci = tile % p.nb_ci;
+  const int tco = tile / p.nb_ci;
+  const int co0 = tco * BC, ci0 = tci * BC;
+  const int split = blockIdx.y;
+  const long m_begin = (long)split * p.chunk;
+  const long m_end = (m_begin + p.chunk < p.M) ? m_begin + p.chunk : p.M;
+
+  const int kw = tap % d.kW;
+  const int kh = (tap / d.kW) % d.kH;
+  const int kt = tap / (d.kW * d.kH);
+
+  // staging role: thread owns float4 column lc of rows lr and lr + 16 (2 x 16 rows x 16 float4)
+  const int lr = tid >> 4;
+  const int lc = (tid & 15) * 4;
+  f32x4 rz[2], rx[2];
+  auto load_stage = [&](long mb) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const long m = mb + lr + 16 * i;
+      f32x4 vz = {0.f, 0.f, 0.f, 0.f}, vx = {0.f, 0.f, 0.f, 0.f};
+      if (m < m_end) {
+        // dz row
+        const float* zp = p.dz + m * p.dz_cs + p.dz_coff + co0 + lc;
+        if (VEC == 4) {
+          if (co0 + lc < d.Cout) vz = *reinterpret_cast<const f32x4*>(zp);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (co0 + lc + e < d.Cout) vz[e] = zp[e];
+        }
+        // x row of this tap
+        const int wo = (int)(m % d.Wo);
+        const long t1 = m / d.Wo;
+        const int ho = (int)(t1 % d.Ho);
+        const long t2 = t1 / d.Ho;
+        const int to = (int)(t2 % d.To);
+        const int n = (int)(t2 / d.To);
+        const int ti = to * d.sT - d.pT + kt * d.dT;
+        const int hi = ho * d.sH - d.pH + kh * d.dH;
+        const int wi = wo * d.sW - d.pW + kw * d.dW;
+        if ((unsigned)ti < (unsigned)d.Ti && (unsigned)hi < (unsigned)d.Hi && (unsigned)wi < (unsigned)d.Wi) {
+          const float* xp = p.x + ((((long)n * d.Ti + ti) * d.Hi + hi) * d.Wi + wi) * d.in_cs + d.in_coff + ci0 + lc;
+          if (VEC == 4) {
+            if (ci0 + lc < d.Cin) vx = *reinterpret_cast<const f32x4*>(xp);
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (ci0 + lc + e < d.Cin) vx[e] = xp[e];
+          }
+        }
+      }
+      rz[i] = vz;
+      rx[i] = vx;
+    }
+  };
+  auto store_stage = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      *reinterpret_cast<f32x4*>(Zs + (buf * BM + lr + 16 * i) * LP + lc) = rz[i];
+      *reinterpret_cast<f32x4*>(Xs + (buf * BM + lr + 16 * i) * LP + lc) = rx[i];
+    }
+  };
+
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wco = (wave >> 1) * 32, wci = (wave & 1) * 32;
+  const int fr = lane & 15, fg = lane >> 4;
+  f32x4 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const long nst = (m_end > m_begin) ? (m_end - m_begin + BM - 1) / BM : 0;
+  if (nst > 0) {
+    load_stage(m_begin);
+    store_stage(0);
+  }
+  __syncthreads();
+  for (long st = 0; st < nst; ++st) {
+    const int buf = (int)(st & 1);
+    const bool more = (st + 1) < nst;
+    if (more) load_stage(m_begin + (st + 1) * BM);
+    const float* zs = Zs + (buf * BM + fg) * LP + wco + fr;
+    const float* xs = Xs + (buf * BM + fg) * LP + wci + fr;
+#pragma unroll
+    for (int s = 0; s < BM / 4; ++s) {
+      float a[2], b[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) a[i] = zs[(4 * s) * LP + 16 * i];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) b[j] = xs[(4 * s) * LP + 16 * j];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    if (more) store_stage(buf ^ 1);
+    __syncthreads();
+  }
+
+  // partial tile: rows co = .. + 4*fg + r, cols ci = .. + fr
+  float* const base = p.part + (long)split * d.Cout * p.ntaps * d.cin_pad;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int ci = ci0 + wci + 16 * j + fr;
+      if (ci >= d.cin_pad) continue;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int co = co0 + wco + 16 * i + 4 * fg + r;
+        if (co < d.Cout) base[((long)co * p.ntaps + tap) * d.cin_pad + ci] = (ci < d.Cin) ? acc[i][j][r] : 0.f;
+      }
+    }
+}
+
+}  // namespace
+
+// Number of position splits the kernel will use for this problem (the caller sizes the workspace with it).
+extern "C" int sf_conv_wgrad_splits(const sf_conv_desc* d) {
+  if (!d) return 0;
+  const long M = (long)d->N * d->To * d->Ho * d->Wo;
+  const long tiles = (long)sf_cdiv(d->Cout, BC) * sf_cdiv(d->Cin, BC) * d->kT * d->kH * d->kW;
+  long S = (2048 + tiles - 1) / tiles;            // aim at ~2048 workgroups (8 per CU)
+  const long maxS = (M + 4 * BM - 1) / (4 * BM);  // at least 128 positions per split
+  if (S > maxS) S = maxS;
+  if (S < 1) S = 1;
+  if (S > 1024) S = 1024;
+  return (int)S;
+}
+
+extern "C" int sf_conv_wgrad(const sf_conv_desc* d, const float* x, const float* dz, int dz_cs, int dz_coff,
+                             float* partial, void* stream) {
+  if (!d || !x || !dz || !partial) return SF_EINVAL;
+  if (d->Cin <= 0 || d->Cout <= 0 || d->cin_pad < d->Cin) return SF_EINVAL;
+  const long M = (long)d->N * d->To * d->Ho * d->Wo;
+  if (M <= 0 || M > 0x7fffffffL) return SF_EINVAL;
+  WgradArgs a;
+  a.d = *d;
+  a.x = x; a.dz = dz; a.part = partial; a.dz_cs = dz_cs; a.dz_coff = dz_coff;
+  a.M = (int)M;
+  a.ntaps = d->kT * d->kH * d->kW;
+  a.S = sf_conv_wgrad_splits(d);
+  a.nb_co = sf_cdiv(d->Cout, BC);
+  a.nb_ci = sf_cdiv(d->Cin, BC);
+  a.chunk = ((M + a.S - 1) / a.S + BM - 1) / BM * BM;
+  const bool vec4 = (d->Cin % 4 == 0) && (d->in_cs % 4 == 0) && (d->in_coff % 4 == 0) && sf_aligned16(x) &&
+                    (d->Cout % 4 == 0) && (dz_cs % 4 == 0) && (dz_coff % 4 == 0) && sf_aligned16(dz);
+  dim3 grid(a.nb_co * a.nb_ci * a.ntaps, a.S);
+  if (vec4)
+    hipLaunchKernelGGL(conv_wgrad_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, a);
+  else
+    hipLaunchKernelGGL(conv_wgrad_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, a);
+  SF_CHECK_LAUNCH();
+  return SF_OK;
+}

@@ -28,7 +28,7 @@ class ConvDesc(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int) for n in (
         "N", "Ti", "Hi", "Wi", "Cin", "in_cs", "in_coff", "To", "Ho", "Wo", "Cout", "out_cs", "out_coff",
         "out_cmul", "kT", "kH", "kW", "sT", "sH", "sW", "pT", "pH", "pW", "dT", "dH", "dW", "cin_pad", "act",
-        "res_cs", "res_coff")]
+        "res_cs", "res_coff", "transposed")]
 
 
 class PoolDesc(ctypes.Structure):
@@ -41,7 +41,10 @@ EXPORTS = [
     "sf_abi_version", "sf_build_arch", "sf_ncthw_to_ndhwc", "sf_ndhwc_to_ncthw", "sf_conv_fwd", "sf_dwconv_fwd",
     "sf_pool_fwd", "sf_tmax_mean_ws_floats", "sf_tmax_mean", "sf_gate_apply", "sf_attn_fwd", "sf_head_act_mean",
     "sf_copy_channels", "sf_channel_stats_ws_floats", "sf_channel_stats", "sf_affine_fwd",
+    "sf_conv_wgrad_splits", "sf_conv_wgrad", "sf_bn_bwd_ws_floats", "sf_bn_bwd_reduce", "sf_bn_bwd_apply",
+    "sf_maxpool_bwd", "sf_tmax_dot", "sf_eca_bwd_apply", "sf_bcast_add", "sf_rowdot", "sf_axpy",
 ]
+_LONG_RET = ("sf_tmax_mean_ws_floats", "sf_channel_stats_ws_floats", "sf_bn_bwd_ws_floats")
 
 
 def lib_path():
@@ -76,9 +79,23 @@ def lib():
         L.sf_channel_stats_ws_floats.restype = cl
         L.sf_channel_stats.argtypes = [vp, ci, ci, cl, ci, vp, vp, vp, vp]
         L.sf_affine_fwd.argtypes = [vp, ci, ci] + [ci] * 5 + [vp, vp, vp, ci, ci, ci, ci, vp, ci, ci, ci, vp]
+        cf = ctypes.c_float
+        L.sf_conv_wgrad_splits.argtypes = [ctypes.POINTER(ConvDesc)]
+        L.sf_conv_wgrad.argtypes = [ctypes.POINTER(ConvDesc), vp, vp, ci, ci, vp, vp]
+        L.sf_bn_bwd_ws_floats.argtypes = [ci]
+        L.sf_bn_bwd_ws_floats.restype = cl
+        L.sf_bn_bwd_reduce.argtypes = [vp, ci, ci, vp, ci, ci, vp, ci, ci] + [ci] * 7 + [vp] * 5 + [vp]
+        L.sf_bn_bwd_apply.argtypes = ([vp, ci, ci, vp, ci, ci, vp, ci, ci] + [ci] * 7 + [vp] * 5 +
+                                      [vp, ci, ci, vp, ci, ci, vp])
+        L.sf_maxpool_bwd.argtypes = [ctypes.POINTER(PoolDesc), vp, vp, vp, ci, ci, vp, ci, ci, vp]
+        L.sf_tmax_dot.argtypes = [vp, ci, ci] + [ci] * 6 + [vp, ci, ci, vp, vp, vp]
+        L.sf_eca_bwd_apply.argtypes = [vp, ci, ci] + [ci] * 6 + [vp, ci, ci, vp, vp, vp, ci, ci, vp]
+        L.sf_bcast_add.argtypes = [vp, ci, ci, ci, cl, ci, vp, cf, vp]
+        L.sf_rowdot.argtypes = [vp, ci, ci, vp, ci, ci, cl, ci, cf, vp, vp]
+        L.sf_axpy.argtypes = [vp, ci, ci, cf, vp, ci, ci, cl, ci, ci, vp]
         for name in EXPORTS:
             fn = getattr(L, name)
-            if name not in ("sf_build_arch", "sf_tmax_mean_ws_floats", "sf_channel_stats_ws_floats"):
+            if name != "sf_build_arch" and name not in _LONG_RET:
                 fn.restype = ci
         _lib = L
     return _lib
@@ -208,7 +225,7 @@ def conv(x, wp, kernel, stride=(1, 1, 1), padding=(0, 0, 0), dilation=(1, 1, 1),
     d = ConvDesc(x.N, x.T, x.H, x.W, cin, x.cs, x.coff, To, Ho, Wo, cout, out.cs, out.coff, out_cmul,
                  kT, kH, kW, stride[0], stride[1], stride[2], padding[0], padding[1], padding[2],
                  dilation[0], dilation[1], dilation[2], cin_pad, ACT_RELU if relu else ACT_NONE,
-                 res.cs if res is not None else 0, res.coff if res is not None else 0)
+                 res.cs if res is not None else 0, res.coff if res is not None else 0, 0)
     if res is not None:
         assert res.rows == out.rows and res.C == cout
     _check(lib().sf_conv_fwd(ctypes.byref(d), x.ptr(), _ptr(wp), _ptr(scale), _ptr(bias),
@@ -234,7 +251,7 @@ def dwconv(x, wp, kernel, stride=(1, 1, 1), padding=(0, 0, 0), scale=None, bias=
     d = ConvDesc(x.N, x.T, x.H, x.W, c, x.cs, x.coff, To, Ho, Wo, cout, out.cs, out.coff, out_cmul,
                  kT, kH, kW, stride[0], stride[1], stride[2], padding[0], padding[1], padding[2], 1, 1, 1,
                  c, ACT_RELU if relu else ACT_NONE,
-                 res.cs if res is not None else 0, res.coff if res is not None else 0)
+                 res.cs if res is not None else 0, res.coff if res is not None else 0, 0)
     _check(lib().sf_dwconv_fwd(ctypes.byref(d), x.ptr(), _ptr(wp), _ptr(scale), _ptr(bias),
                                res.ptr() if res is not None else None, out.ptr(), _stream()), "sf_dwconv_fwd")
     return out
@@ -354,4 +371,109 @@ def affine(x, scale=None, bias=None, res=None, relu=False, rep=1, out=None, out_
                                res.ptr() if res is not None else None, res.cs if res is not None else 0,
                                res.coff if res is not None else 0, ACT_RELU if relu else ACT_NONE, rep,
                                out.ptr(), out.cs, out.coff, out_cmul, _stream()), "sf_affine_fwd")
+    return out
+
+
+def conv_dgrad(dz, wt_packed, x_like, kernel, stride=(1, 1, 1), padding=(0, 0, 0), dilation=(1, 1, 1),
+               out=None, accumulate=False):
+    """Data gradient of a dense conv: dL/dx[N,Ti,Hi,Wi,Cin] (+)= conv^T(dL/dz, W).  `wt_packed` =
+    pack_conv_weight(W.transpose(0, 1)) i.e. [Cin][tap][Cout_pad]; `x_like` gives the forward input's dims."""
+    _require_gpu(dz.buf, "conv_dgrad")
+    cin, taps, cout_pad = wt_packed.shape
+    if out is None:
+        out = new_act(dz, x_like.N, x_like.T, x_like.H, x_like.W, cin)
+        accumulate = False
+    assert (out.N, out.T, out.H, out.W, out.C) == (x_like.N, x_like.T, x_like.H, x_like.W, cin), (out, x_like)
+    d = ConvDesc(dz.N, dz.T, dz.H, dz.W, dz.C, dz.cs, dz.coff, out.T, out.H, out.W, cin, out.cs, out.coff, 1,
+                 kernel[0], kernel[1], kernel[2], stride[0], stride[1], stride[2], padding[0], padding[1],
+                 padding[2], dilation[0], dilation[1], dilation[2], cout_pad, ACT_NONE,
+                 out.cs if accumulate else 0, out.coff if accumulate else 0, 1)
+    _check(lib().sf_conv_fwd(ctypes.byref(d), dz.ptr(), _ptr(wt_packed), None, None,
+                             out.ptr() if accumulate else None, out.ptr(), _stream()), "sf_conv_fwd(transposed)")
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ backward
+def conv_wgrad(x, dz, cout, kernel, stride=(1, 1, 1), padding=(0, 0, 0), dilation=(1, 1, 1), cin=None,
+               cin_pad=None):
+    """dW packed [Cout, taps, cin_pad] = sum over positions of dz (x) x (split partials summed in fixed order)."""
+    _require_gpu(x.buf, "conv_wgrad")
+    cin = x.C if cin is None else cin
+    cin_pad = (cin + 15) // 16 * 16 if cin_pad is None else cin_pad
+    kT, kH, kW = kernel
+    d = ConvDesc(x.N, x.T, x.H, x.W, cin, x.cs, x.coff, dz.T, dz.H, dz.W, cout, 0, 0, 1,
+                 kT, kH, kW, stride[0], stride[1], stride[2], padding[0], padding[1], padding[2],
+                 dilation[0], dilation[1], dilation[2], cin_pad, ACT_NONE, 0, 0, 0)
+    S = lib().sf_conv_wgrad_splits(ctypes.byref(d))
+    part = torch.empty((S, cout, kT * kH * kW, cin_pad), dtype=torch.float32, device=x.buf.device)
+    _check(lib().sf_conv_wgrad(ctypes.byref(d), x.ptr(), dz.ptr(), dz.cs, dz.coff, _ptr(part), _stream()),
+           "sf_conv_wgrad")
+    return part.sum(0) if S > 1 else part[0]
+
+
+def unpack_conv_weight_grad(dwp, shape):
+    """[Cout, taps, cin_pad] -> [Cout, Cin, kT, kH, kW]."""
+    cout, cin, kT, kH, kW = shape
+    return dwp[:, :, :cin].permute(0, 2, 1).reshape(cout, cin, kT, kH, kW).contiguous()
+
+
+def bn_bwd(dy, y, z, mean, invstd, gamma, relu, rep=1, dres=None, dz_out=None):
+    """Training BN backward (+ReLU mask, + residual fan-out, + upsample-copy sum).  Returns (dz, dgamma, dbeta);
+    dz is written over z unless dz_out is given."""
+    C = z.C
+    dev = z.buf.device
+    dbeta = torch.empty((C,), dtype=torch.float32, device=dev)
+    dgamma = torch.empty((C,), dtype=torch.float32, device=dev)
+    ws = torch.empty((lib().sf_bn_bwd_ws_floats(C),), dtype=torch.float32, device=dev)
+    yp, ycs, yco = (y.ptr(), y.cs, y.coff) if y is not None else (None, 0, 0)
+    args = (dy.ptr(), dy.cs, dy.coff, yp, ycs, yco, z.ptr(), z.cs, z.coff, z.N, z.T, z.H, z.W, C, rep,
+            1 if relu else 0, _ptr(mean), _ptr(invstd))
+    _check(lib().sf_bn_bwd_reduce(*args, _ptr(dbeta), _ptr(dgamma), _ptr(ws), _stream()), "sf_bn_bwd_reduce")
+    out = z if dz_out is None else dz_out
+    _check(lib().sf_bn_bwd_apply(*args, _ptr(gamma), _ptr(dbeta), _ptr(dgamma), out.ptr(), out.cs, out.coff,
+                                 dres.ptr() if dres is not None else None, dres.cs if dres is not None else 0,
+                                 dres.coff if dres is not None else 0, _stream()), "sf_bn_bwd_apply")
+    return out, dgamma, dbeta
+
+
+def maxpool_bwd(x, y, dy, dx, kernel, stride, padding=(0, 0, 0)):
+    d = PoolDesc(x.N, x.T, x.H, x.W, x.C, x.cs, x.coff, y.T, y.H, y.W, y.cs, y.coff,
+                 kernel[0], kernel[1], kernel[2], stride[0], stride[1], stride[2],
+                 padding[0], padding[1], padding[2], 0)
+    _check(lib().sf_maxpool_bwd(ctypes.byref(d), x.ptr(), y.ptr(), dy.ptr(), dy.cs, dy.coff, dx.ptr(), dx.cs,
+                                dx.coff, _stream()), "sf_maxpool_bwd")
+    return dx
+
+
+def tmax_dot(x, alpha, dz):
+    out = torch.empty((x.N, x.C), dtype=torch.float32, device=x.buf.device)
+    ws = torch.empty((lib().sf_tmax_mean_ws_floats(x.N, x.C),), dtype=torch.float32, device=x.buf.device)
+    _check(lib().sf_tmax_dot(x.ptr(), x.cs, x.coff, x.N, x.T, x.H, x.W, x.C, alpha, dz.ptr(), dz.cs, dz.coff,
+                             _ptr(out), _ptr(ws), _stream()), "sf_tmax_dot")
+    return out
+
+
+def eca_bwd_apply(x, alpha, dz, gate, dpool, dx):
+    _check(lib().sf_eca_bwd_apply(x.ptr(), x.cs, x.coff, x.N, x.T, x.H, x.W, x.C, alpha, dz.ptr(), dz.cs, dz.coff,
+                                  _ptr(gate), _ptr(dpool), dx.ptr(), dx.cs, dx.coff, _stream()), "sf_eca_bwd_apply")
+    return dx
+
+
+def bcast_add(g, v, scale):
+    _check(lib().sf_bcast_add(g.ptr(), g.cs, g.coff, g.N, g.T * g.H * g.W, g.C, _ptr(v), float(scale), _stream()),
+           "sf_bcast_add")
+    return g
+
+
+def rowdot(a, b, scale=1.0):
+    out = torch.empty((a.rows,), dtype=torch.float32, device=a.buf.device)
+    _check(lib().sf_rowdot(a.ptr(), a.cs, a.coff, b.ptr(), b.cs, b.coff, a.rows, a.C, float(scale), _ptr(out),
+                           _stream()), "sf_rowdot")
+    return out
+
+
+def axpy(a, out, alpha=1.0, accumulate=True):
+    assert a.rows == out.rows and a.C == out.C
+    _check(lib().sf_axpy(a.ptr(), a.cs, a.coff, float(alpha), out.ptr(), out.cs, out.coff, a.rows, a.C,
+                         1 if accumulate else 0, _stream()), "sf_axpy")
     return out

@@ -62,6 +62,9 @@ typedef struct sf_conv_desc {
   int cin_pad;                 /* packed weight row length per tap                                */
   int act;                     /* SF_ACT_NONE | SF_ACT_RELU                                       */
   int res_cs, res_coff;        /* residual pitch / offset (used when res != NULL)                 */
+  int transposed;              /* 1: data-gradient of the conv described by k/s/p/d: "in" is dL/dz with   */
+                               /* dims (Ti,Hi,Wi) = the forward OUTPUT dims, "out" is dL/dx with dims     */
+                               /* (To,Ho,Wo) = the forward INPUT dims, weights packed [Cin][tap][Cout]    */
 } sf_conv_desc;
 int sf_conv_fwd(const sf_conv_desc* d, const float* in, const float* w_packed, const float* scale,
                 const float* bias, const float* res, float* out, void* stream);
@@ -133,6 +136,53 @@ int sf_head_act_mean(const float* logits, int B, int P, int K, int act, float* o
  * shufflenetv2_helper.py:100-107): out[.., out_coff + c*out_cmul] = in[.., in_coff + c].          */
 int sf_copy_channels(const float* in, int in_cs, int in_coff, float* out, int out_cs, int out_coff,
                      int out_cmul, long rows, int C, void* stream);
+
+/* ================================ backward (training) ============================================
+ * Gradients of the ops above.  Activation gradients live in NDHWC buffers shaped like their forward
+ * tensors; producers ACCUMULATE into them (the caller zero-fills once), which realises autograd's fan-in
+ * sums (residual branches, the two consumers of each pathway tensor in the lateral fusions).
+ *
+ * Data gradient of a dense conv = sf_conv_fwd with desc.transposed = 1 (see sf_conv_desc).
+ *
+ * Weight gradient: partial[s][co][tap][ci] over S = sf_conv_wgrad_splits(d) position splits; the caller
+ * sums the S partials (fixed order).  `d` is the FORWARD descriptor; dz is dL/d(conv output).          */
+int sf_conv_wgrad_splits(const sf_conv_desc* d);
+int sf_conv_wgrad(const sf_conv_desc* d, const float* x, const float* dz, int dz_cs, int dz_coff,
+                  float* partial, void* stream);
+
+/* Training BatchNorm3d backward fused with ReLU mask (y > 0), residual fan-out (dres += g) and the sum over
+ * `rep` nearest-upsampled copies:  g = sum_q dy * [y > 0];  dbeta = sum g;  dgamma = sum g * xhat;
+ * dz = gamma * invstd * (g - dbeta/M - xhat * dgamma/M)  (dz may alias z).  ws: sf_bn_bwd_ws_floats(C). */
+long sf_bn_bwd_ws_floats(int C);
+int sf_bn_bwd_reduce(const float* dy, int dy_cs, int dy_coff, const float* y, int y_cs, int y_coff,
+                     const float* z, int z_cs, int z_coff, int N, int T, int H, int W, int C, int rep, int relu,
+                     const float* mean, const float* invstd, float* dbeta, float* dgamma, float* ws, void* stream);
+int sf_bn_bwd_apply(const float* dy, int dy_cs, int dy_coff, const float* y, int y_cs, int y_coff,
+                    const float* z, int z_cs, int z_coff, int N, int T, int H, int W, int C, int rep, int relu,
+                    const float* mean, const float* invstd, const float* gamma, const float* dbeta,
+                    const float* dgamma, float* dz, int dz_cs, int dz_coff, float* dres, int dres_cs,
+                    int dres_coff, void* stream);
+
+/* MaxPool3d backward (equality gather; dx accumulates).  `d` is the forward descriptor.                 */
+int sf_maxpool_bwd(const sf_pool_desc* d, const float* x, const float* y, const float* dy, int dy_cs,
+                   int dy_coff, float* dx, int dx_cs, int dx_coff, void* stream);
+
+/* ECA backward: out[b,c] = sum_{t',hw} dz * max_r x (sf_tmax_dot), then
+ * dx[frames holding the max] += dz * gate[b,c] + dpool[b,c]  (sf_eca_bwd_apply).  ws as sf_tmax_mean.   */
+int sf_tmax_dot(const float* x, int cs, int coff, int N, int T, int H, int W, int C, int alpha, const float* dz,
+                int dz_cs, int dz_coff, float* out, float* ws, void* stream);
+int sf_eca_bwd_apply(const float* x, int cs, int coff, int N, int T, int H, int W, int C, int alpha,
+                     const float* dz, int dz_cs, int dz_coff, const float* gate, const float* dpool, float* dx,
+                     int dx_cs, int dx_coff, void* stream);
+
+/* g[n, r, c] += v[n, c] * scale (global-mean backward);  out[r] = scale * <a[r,:], b[r,:]>;
+ * out[r, c] (+)= alpha * a[r, c].                                                                       */
+int sf_bcast_add(float* g, int cs, int coff, int N, long rows_per_n, int C, const float* v, float scale,
+                 void* stream);
+int sf_rowdot(const float* a, int a_cs, int a_coff, const float* b, int b_cs, int b_coff, long rows, int C,
+              float scale, float* out, void* stream);
+int sf_axpy(const float* a, int a_cs, int a_coff, float alpha, float* out, int out_cs, int out_coff, long rows,
+            int C, int accumulate, void* stream);
 
 #ifdef __cplusplus
 }

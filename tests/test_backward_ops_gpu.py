@@ -1,0 +1,196 @@
+"""GPU parity of the backward kernels (through the C ABI) against torch autograd on the CPU reference ops."""
+import os
+import zlib
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+TOL = 2e-4
+
+
+def _dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    return torch.device("cuda:0")
+
+
+def _rel(a, b):
+    a = a.detach().double().cpu()
+    b = b.detach().double().cpu()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+def _act(x):
+    import sfhip
+    return sfhip.Act(x.detach().permute(0, 2, 3, 4, 1).contiguous().to(_dev()))
+
+
+def _back(a):
+    return a.buf[..., a.coff:a.coff + a.C].permute(0, 4, 1, 2, 3).contiguous().cpu()
+
+
+def _report(name, err):
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    try:
+        os.makedirs(out, exist_ok=True)
+        with open(os.path.join(out, "bwd_report.txt"), "a") as f:
+            f.write("%-50s %.3e\n" % (name, err))
+    except OSError:
+        pass
+
+
+CONV_CASES = [
+    ("pw_64_256", 64, 256, (1, 1, 1), (1, 1, 1), (0, 0, 0), (2, 2, 12, 12)),
+    ("pw_s2_288_512", 288, 512, (1, 1, 1), (1, 2, 2), (0, 0, 0), (1, 2, 14, 14)),
+    ("t3_128_64", 128, 64, (3, 1, 1), (1, 1, 1), (1, 0, 0), (2, 4, 7, 7)),
+    ("s3_64_64", 64, 64, (1, 3, 3), (1, 1, 1), (0, 1, 1), (1, 2, 14, 14)),
+    ("s3_s2_128_128", 128, 128, (1, 3, 3), (1, 2, 2), (0, 1, 1), (2, 2, 14, 14)),
+    ("f2s_k7_32_64", 32, 64, (7, 1, 1), (4, 1, 1), (3, 0, 0), (1, 16, 6, 6)),
+    ("pw_8_24", 8, 24, (1, 1, 1), (1, 1, 1), (0, 0, 0), (2, 4, 9, 9)),
+    ("odd_27_16", 27, 16, (1, 1, 1), (1, 1, 1), (0, 0, 0), (2, 4, 5, 5)),
+    ("fc_2304_400", 2304, 400, (1, 1, 1), (1, 1, 1), (0, 0, 0), (8, 1, 1, 1)),
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES, ids=[c[0] for c in CONV_CASES])
+def test_conv_dgrad_wgrad(case):
+    import sfhip
+    name, cin, cout, k, s, p, shp = case
+    dev = _dev()
+    g = torch.Generator().manual_seed(zlib.crc32(name.encode()) % 10000)
+    n, t, h, w = shp
+    x = torch.randn(n, cin, t, h, w, generator=g, requires_grad=True)
+    wt = (torch.randn(cout, cin, *k, generator=g) / np.sqrt(cin * k[0] * k[1] * k[2])).requires_grad_(True)
+    y = F.conv3d(x, wt, None, s, p)
+    dy = torch.randn(y.shape, generator=g)
+    dx_ref, dw_ref = torch.autograd.grad(y, (x, wt), dy)
+    xa, dza = _act(x), _act(dy)
+    wtp = sfhip.pack_conv_weight(wt.detach().transpose(0, 1).contiguous().to(dev))
+    base = torch.randn(n, t, h, w, cin, generator=g)
+    dxa = sfhip.Act(base.clone().to(dev))
+    sfhip.conv_dgrad(dza, wtp, xa, k, s, p, out=dxa, accumulate=True)
+    dwp = sfhip.conv_wgrad(xa, dza, cout, k, s, p)
+    torch.cuda.synchronize()
+    e1 = _rel(_back(dxa) - base.permute(0, 4, 1, 2, 3), dx_ref)
+    e2 = _rel(sfhip.unpack_conv_weight_grad(dwp, wt.shape), dw_ref)
+    _report("conv/%s dgrad" % name, e1)
+    _report("conv/%s wgrad" % name, e2)
+    assert e1 < TOL and e2 < TOL, (e1, e2)
+
+
+def test_stem_trick_wgrad():
+    """Weight gradient of the 7x7 stem computed directly in the stem-trick layout."""
+    import sfhip
+    dev = _dev()
+    g = torch.Generator().manual_seed(4)
+    kt, cout = 5, 8
+    x = torch.randn(2, 3, 6, 32, 32, generator=g)
+    wt = (torch.randn(cout, 3, kt, 7, 7, generator=g) / np.sqrt(147 * kt)).requires_grad_(True)
+    y = F.conv3d(x, wt, None, (1, 2, 2), (kt // 2, 3, 3))
+    dy = torch.randn(y.shape, generator=g)
+    (dw_ref,) = torch.autograd.grad(y, (wt,), dy)
+    xa = sfhip.from_ncthw(x.to(dev), cpad=4, ph=3, pw=3, wp=38)
+    view = sfhip.Act(xa.buf.view(2, 6, 38, 19, 8))
+    dwp = sfhip.conv_wgrad(view, _act(dy), cout, (kt, 7, 1), (1, 2, 1), (kt // 2, 0, 0), cin=28, cin_pad=32)
+    torch.cuda.synchronize()
+    dw = dwp[:, :, :28].reshape(cout, kt, 7, 7, 4)[..., :3].permute(0, 4, 1, 2, 3)
+    assert _rel(dw, dw_ref) < TOL
+
+
+@pytest.mark.parametrize("c,relu,use_res,rep", [(64, True, True, 1), (8, True, False, 1), (27, False, False, 1),
+                                                (32, True, False, 4), (300, True, True, 1)])
+def test_bn_backward(c, relu, use_res, rep):
+    import sfhip
+    dev = _dev()
+    g = torch.Generator().manual_seed(c + rep)
+    z = (torch.randn(2, c, 4, 6, 5, generator=g) * 1.5 + 0.3).requires_grad_(True)
+    gamma = (torch.rand(c, generator=g) + 0.5).requires_grad_(True)
+    beta = (torch.randn(c, generator=g) * 0.1).requires_grad_(True)
+    res = torch.randn(2, c, 4, 6, 5, generator=g).requires_grad_(True) if use_res else None
+    y = F.batch_norm(z, None, None, gamma, beta, True, 0.0, 1e-5)
+    if use_res:
+        y = y + res
+    if relu:
+        y = F.relu(y)
+    y = y.repeat_interleave(rep, dim=2)
+    dy = torch.randn(y.shape, generator=g)
+    outs = torch.autograd.grad(y, [z, gamma, beta] + ([res] if use_res else []), dy)
+    za = _act(z)
+    mean, var = sfhip.channel_stats(za)
+    invstd = torch.rsqrt(var + 1e-5)
+    dres = sfhip.Act(torch.zeros(2, 4, 6, 5, c, device=dev)) if use_res else None
+    dz, dgamma, dbeta = sfhip.bn_bwd(_act(dy), _act(y), za, mean, invstd, gamma.detach().to(dev), relu, rep=rep,
+                                     dres=dres)
+    torch.cuda.synchronize()
+    errs = [_rel(_back(dz), outs[0]), _rel(dgamma, outs[1]), _rel(dbeta, outs[2])]
+    if use_res:
+        errs.append(_rel(_back(dres), outs[3]))
+    _report("bn_bwd c%d relu%d res%d rep%d" % (c, relu, use_res, rep), max(errs))
+    assert max(errs) < TOL, errs
+
+
+@pytest.mark.parametrize("k,s,p", [((1, 3, 3), (1, 2, 2), (0, 1, 1)), ((3, 3, 3), (1, 2, 2), (1, 1, 1))])
+def test_maxpool_backward(k, s, p):
+    import sfhip
+    dev = _dev()
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(2, 12, 4, 13, 12, generator=g).requires_grad_(True)
+    y = F.max_pool3d(x, k, s, p)
+    dy = torch.randn(y.shape, generator=g)
+    (dx_ref,) = torch.autograd.grad(y, (x,), dy)
+    dx = sfhip.Act(torch.zeros(2, 4, 13, 12, 12, device=dev))
+    sfhip.maxpool_bwd(_act(x), _act(y), _act(dy), dx, k, s, p)
+    torch.cuda.synchronize()
+    assert _rel(_back(dx), dx_ref) < 1e-6
+
+
+@pytest.mark.parametrize("c,alpha", [(8, 4), (32, 4), (3, 8)])
+def test_eca_backward(c, alpha):
+    """d/dx and d/dw3 of  max-pool_alpha -> ECA gate  against autograd of the oracle's functions."""
+    import sfhip
+    from oracle import slowfast_oracle as oracle
+    dev = _dev()
+    g = torch.Generator().manual_seed(c)
+    x = torch.randn(2, c, 8, 5, 7, generator=g).requires_grad_(True)
+    w3 = torch.randn(1, 1, 3, generator=g).requires_grad_(True)
+    mx = F.max_pool3d(x, (alpha, 1, 1), (alpha, 1, 1))
+    y = oracle.eca({"m.conv.weight": w3}, "m", mx)
+    dy = torch.randn(y.shape, generator=g)
+    dx_ref, dw_ref = torch.autograd.grad(y, (x, w3), dy)
+    # HIP path: reductions on the GPU, the [N, C]-sized gate algebra in torch (parameter-sized plumbing)
+    xa, dza = _act(x), _act(dy)
+    pooled = sfhip.tmax_mean(xa, alpha)
+    dg = sfhip.tmax_dot(xa, alpha, dza)
+    w = w3.detach().to(dev)
+    a = F.conv1d(pooled.unsqueeze(1), w, None, 1, 1).squeeze(1)
+    gate = torch.sigmoid(a)
+    da = dg * gate * (1 - gate)
+    dpool = F.conv_transpose1d(da.unsqueeze(1), w, None, 1, 1).squeeze(1)
+    dw = torch.stack([(da * F.pad(pooled, (1, 1))[:, kk:kk + c]).sum() for kk in range(3)]).view(1, 1, 3)
+    count = (8 // alpha) * 5 * 7
+    dx = sfhip.Act(torch.zeros(2, 8, 5, 7, c, device=dev))
+    sfhip.eca_bwd_apply(xa, alpha, dza, gate.contiguous(), (dpool / count).contiguous(), dx)
+    torch.cuda.synchronize()
+    e1, e2 = _rel(_back(dx), dx_ref), _rel(dw, dw_ref)
+    _report("eca_bwd c%d a%d" % (c, alpha), max(e1, e2))
+    assert e1 < TOL and e2 < TOL, (e1, e2)
+
+
+def test_small_helpers():
+    import sfhip
+    dev = _dev()
+    a = torch.randn(1, 2, 3, 4, 10)
+    b = torch.randn(1, 2, 3, 4, 10)
+    d = sfhip.rowdot(sfhip.Act(a.to(dev)), sfhip.Act(b.to(dev)), 0.5)
+    gbuf = sfhip.Act(torch.ones(2, 2, 3, 4, 6, device=dev))
+    v = torch.randn(2, 6)
+    sfhip.bcast_add(gbuf, v.to(dev), 0.25)
+    o = sfhip.Act(torch.ones(1, 2, 3, 4, 10, device=dev))
+    sfhip.axpy(sfhip.Act(a.to(dev)), o, alpha=2.0, accumulate=True)
+    torch.cuda.synchronize()
+    assert _rel(d.view(2, 3, 4), (a * b).sum(-1)[0] * 0.5) < 1e-5
+    assert _rel(gbuf.buf, 1 + 0.25 * v.view(2, 1, 1, 1, 6).expand(2, 2, 3, 4, 6)) < 1e-6
+    assert _rel(o.buf, 1 + 2 * a) < 1e-6
