@@ -1,0 +1,365 @@
+// attn_bwd.hip — backward of the flash SpatialAttention (recompute form, fp32 MFMA, gfx950).
+//
+// Forward (attn_flash.hip):  S = q k^T,  P = softmax_j(S),  O = P v,  z = gamma * O + x.
+// Given dz = dL/dz:  dO = gamma * dz,  D_i = <dO_i, O_i>,  and with P recomputed from the saved
+// log-sum-exp  P_ij = 2^(S'_ij - LSE'_i)  (S' = S * log2 e):
+//     dV_j = sum_i P_ij dO_i          dP_ij = <dO_i, v_j>          dS_ij = P_ij (dP_ij - D_i)
+//     dQ_i = sum_j dS_ij k_j          dK_j  = sum_i dS_ij q_i
+// Two kernels, no atomics (bit-reproducible):
+//   attn_bwd_dq_kernel  : one wavefront per 32 QUERIES sweeping all keys   (3 products per tile)
+//   attn_bwd_dkv_kernel : one wavefront per 32 KEYS sweeping all queries   (4 products per tile)
+// Both reuse the forward's register layouts: the "owned" index (query resp. key) sits on the lane, the
+// swept index arrives in the accumulator's 16 registers in the order kappa(r,h) = (r&3)+8(r>>2)+4h, so
+// every transposed product takes the recomputed P / dS registers directly as its B operand and reads
+// its A operand from the LDS tile with conflict-free ds_read_b32; row-fragment operands are ds_read_b128.
+#include "common.h"
+
+namespace {
+
+struct BwdArgs {
+  const float* q; const float* k; const float* v;   // [B, N, *] views
+  const float* dz;                                   // dL/dz [B, N, C]
+  const float* lse;                                  // [B, N]  (exp2 domain)
+  const float* dvec;                                 // [B, N]  <dz_i, O_i>  (gamma applied in-kernel)
+  const float* gamma;
+  float* dq; float* dk; float* dv;                   // outputs [B, N, *] views
+  int q_cs, k_cs, v_cs, dz_cs, dq_cs, dk_cs, dv_cs;
+  int B, C, N, nt;
+};
+
+constexpr float NEG_BIG = -3.0e38f;
+constexpr float POS_BIG = 3.0e38f;
+constexpr float LOG2E = 1.4426950408889634f;
+
+__device__ __forceinline__ int kappa(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+// ---------------------------------------------------------------------------------------------- dQ
+template <int CP>
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const BwdArgs p) {
+  constexpr int KT = (CP >= 128) ? 32 : 64;
+  constexpr int NSUB = KT / 32;
+  constexpr int PS = CP + 4;
+  constexpr int CT = (CP + 31) / 32;
+  constexpr int QS = CP / 8;
+  constexpr int F4 = CP / 4;
+  constexpr int NF = (KT * F4 + 255) / 256;
+  __shared__ __attribute__((aligned(16))) float smem[2 * 2 * KT * PS];
+  float* const Ks = smem;
+  float* const Vs = smem + 2 * KT * PS;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int b = blockIdx.x / p.nt;
+  const int q0 = (blockIdx.x - b * p.nt) * 128 + wave * 32;
+  const int N = p.N, C = p.C;
+  const long brow = (long)b * N;
+  const float gamma = p.gamma[0];
+
+  float qf[QS * 4], df[QS * 4];
+  const int qrow = q0 + li;
+  const bool qok = qrow < N;
+  {
+    const float* qp = p.q + (brow + (qok ? qrow : 0)) * p.q_cs;
+    const float* dp = p.dz + (brow + (qok ? qrow : 0)) * p.dz_cs;
+#pragma unroll
+    for (int s = 0; s < QS; ++s)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int c = s * 8 + lh * 4 + e;
+        const bool ok = qok && c < C;
+        qf[s * 4 + e] = ok ? qp[c] * LOG2E : 0.f;
+        df[s * 4 + e] = ok ? dp[c] * gamma : 0.f;
+      }
+  }
+  const float lse = qok ? p.lse[brow + qrow] : 0.f;
+  const float dsum = qok ? p.dvec[brow + qrow] * gamma : 0.f;
+
+  f32x16 acc[CT];
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[ct][r] = 0.f;
+
+  f32x4 rk[NF], rv[NF];
+  auto load_tile = [&](int j0) {
+#pragma unroll
+    for (int u = 0; u < NF; ++u) {
+      const int f = tid + u * 256;
+      const int row = f / F4;
+      const int c = (f - row * F4) * 4;
+      const int j = j0 + row;
+      f32x4 tk = {0.f, 0.f, 0.f, 0.f}, tv = {0.f, 0.f, 0.f, 0.f};
+      if (f < KT * F4 && j < N) {
+        const float* kp = p.k + (brow + j) * p.k_cs + c;
+        const float* vp = p.v + (brow + j) * p.v_cs + c;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if ((c + e) < C) {
+            tk[e] = kp[e];
+            tv[e] = vp[e];
+          }
+      }
+      rk[u] = tk;
+      rv[u] = tv;
+    }
+  };
+  auto store_tile = [&](int buf) {
+#pragma unroll
+    for (int u = 0; u < NF; ++u) {
+      const int f = tid + u * 256;
+      if (f < KT * F4) {
+        const int row = f / F4;
+        const int c = (f - row * F4) * 4;
+        *reinterpret_cast<f32x4*>(Ks + (buf * KT + row) * PS + c) = rk[u];
+        *reinterpret_cast<f32x4*>(Vs + (buf * KT + row) * PS + c) = rv[u];
+      }
+    }
+  };
+
+  const int ntiles = (N + KT - 1) / KT;
+  load_tile(0);
+  store_tile(0);
+  __syncthreads();
+  for (int t = 0; t < ntiles; ++t) {
+    const int buf = t & 1;
+    const bool more = (t + 1) < ntiles;
+    if (more) load_tile((t + 1) * KT);
+#pragma unroll
+    for (int sub = 0; sub < NSUB; ++sub) {
+      const int jbase = t * KT + sub * 32;
+      if (jbase >= N) break;
+      f32x16 s, dp;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+      const float* krow = Ks + (buf * KT + sub * 32 + li) * PS + lh * 4;
+      const float* vrow = Vs + (buf * KT + sub * 32 + li) * PS + lh * 4;
+#pragma unroll
+      for (int g = 0; g < QS; ++g) {
+        const f32x4 kf = *reinterpret_cast<const f32x4*>(krow + g * 8);
+        const f32x4 vf = *reinterpret_cast<const f32x4*>(vrow + g * 8);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[e], qf[g * 4 + e], s, 0, 0, 0);     // S'^T = K Q^T
+          dp = __builtin_amdgcn_mfma_f32_32x32x2f32(vf[e], df[g * 4 + e], dp, 0, 0, 0);   // dP^T = V dO^T
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const bool jok = (jbase + kappa(r, lh)) < N;
+        const float pr = jok ? __builtin_amdgcn_exp2f(s[r] - lse) : 0.f;
+        s[r] = pr * (dp[r] - dsum);  // dS^T
+      }
+      const float* kcol = Ks + (buf * KT + sub * 32 + 4 * lh) * PS + (CP >= 32 ? li : (li & (CP - 1)));
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          acc[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(kcol[((r & 3) + 8 * (r >> 2)) * PS + ct * 32], s[r],
+                                                         acc[ct], 0, 0, 0);  // dQ^T += K^T dS^T
+    }
+    if (more) store_tile(buf ^ 1);
+    __syncthreads();
+  }
+  if (!qok) return;
+  float* op = p.dq + (brow + qrow) * p.dq_cs;
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int c = ct * 32 + 8 * (r >> 2) + 4 * lh + (r & 3);
+      if (c < C) op[c] = acc[ct][r];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- dK, dV
+template <int CP>
+__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const BwdArgs p) {
+  constexpr int QT = (CP >= 128) ? 32 : 64;   // queries per LDS tile
+  constexpr int NSUB = QT / 32;
+  constexpr int PS = CP + 4;
+  constexpr int CT = (CP + 31) / 32;
+  constexpr int QS = CP / 8;
+  constexpr int F4 = CP / 4;
+  constexpr int NF = (QT * F4 + 255) / 256;
+  constexpr int TILE = 2 * QT * PS + 2 * QT;  // Q tile, dO tile, lse, D
+  __shared__ __attribute__((aligned(16))) float smem[2 * TILE];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int b = blockIdx.x / p.nt;
+  const int j0 = (blockIdx.x - b * p.nt) * 128 + wave * 32;
+  const int N = p.N, C = p.C;
+  const long brow = (long)b * N;
+  const float gamma = p.gamma[0];
+
+  float kf[QS * 4], vf[QS * 4];
+  const int jrow = j0 + li;
+  const bool jok = jrow < N;
+  {
+    const float* kp = p.k + (brow + (jok ? jrow : 0)) * p.k_cs;
+    const float* vp = p.v + (brow + (jok ? jrow : 0)) * p.v_cs;
+#pragma unroll
+    for (int s = 0; s < QS; ++s)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int c = s * 8 + lh * 4 + e;
+        const bool ok = jok && c < C;
+        kf[s * 4 + e] = ok ? kp[c] * LOG2E : 0.f;
+        vf[s * 4 + e] = ok ? vp[c] : 0.f;
+      }
+  }
+  f32x16 dk[CT], dv[CT];
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { dk[ct][r] = 0.f; dv[ct][r] = 0.f; }
+
+  f32x4 rq[NF], rd[NF];
+  float rl = 0.f, rD = 0.f;
+  auto load_tile = [&](int i0) {
+#pragma unroll
+    for (int u = 0; u < NF; ++u) {
+      const int f = tid + u * 256;
+      const int row = f / F4;
+      const int c = (f - row * F4) * 4;
+      const int i = i0 + row;
+      f32x4 tq = {0.f, 0.f, 0.f, 0.f}, td = {0.f, 0.f, 0.f, 0.f};
+      if (f < QT * F4 && i < N) {
+        const float* qp = p.q + (brow + i) * p.q_cs + c;
+        const float* dp = p.dz + (brow + i) * p.dz_cs + c;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if ((c + e) < C) {
+            tq[e] = qp[e];
+            td[e] = dp[e] * gamma;
+          }
+      }
+      rq[u] = tq;
+      rd[u] = td;
+    }
+    if (tid < QT) {
+      const int i = i0 + tid;
+      rl = (i < N) ? p.lse[brow + i] : POS_BIG;  // P = 2^(s - BIG) = 0 for padded queries
+      rD = (i < N) ? p.dvec[brow + i] * gamma : 0.f;
+    }
+  };
+  auto store_tile = [&](int buf) {
+    float* Qs = smem + buf * TILE;
+    float* Ds = Qs + QT * PS;
+#pragma unroll
+    for (int u = 0; u < NF; ++u) {
+      const int f = tid + u * 256;
+      if (f < QT * F4) {
+        const int row = f / F4;
+        const int c = (f - row * F4) * 4;
+        *reinterpret_cast<f32x4*>(Qs + row * PS + c) = rq[u];
+        *reinterpret_cast<f32x4*>(Ds + row * PS + c) = rd[u];
+      }
+    }
+    if (tid < QT) {
+      Qs[2 * QT * PS + tid] = rl;
+      Qs[2 * QT * PS + QT + tid] = rD;
+    }
+  };
+
+  const int ntiles = (N + QT - 1) / QT;
+  load_tile(0);
+  store_tile(0);
+  __syncthreads();
+  for (int t = 0; t < ntiles; ++t) {
+    const int buf = t & 1;
+    const bool more = (t + 1) < ntiles;
+    if (more) load_tile((t + 1) * QT);
+    const float* Qs = smem + buf * TILE;
+    const float* Ds = Qs + QT * PS;
+    const float* Ls = Qs + 2 * QT * PS;
+    const float* Dv = Ls + QT;
+#pragma unroll
+    for (int sub = 0; sub < NSUB; ++sub) {
+      if (t * QT + sub * 32 >= N) break;
+      f32x16 s, dp;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+      const float* qrow = Qs + (sub * 32 + li) * PS + lh * 4;
+      const float* drow = Ds + (sub * 32 + li) * PS + lh * 4;
+#pragma unroll
+      for (int g = 0; g < QS; ++g) {
+        const f32x4 qa = *reinterpret_cast<const f32x4*>(qrow + g * 8);
+        const f32x4 da = *reinterpret_cast<const f32x4*>(drow + g * 8);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          s = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[e], kf[g * 4 + e], s, 0, 0, 0);    // S' = Q K^T (rows i)
+          dp = __builtin_amdgcn_mfma_f32_32x32x2f32(da[e], vf[g * 4 + e], dp, 0, 0, 0);  // dP = dO V^T
+        }
+      }
+      // rows of the accumulators are queries i = sub*32 + kappa(r, lh): fetch their LSE / D (LDS broadcast)
+      f32x16 pr;
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const f32x4 l4 = *reinterpret_cast<const f32x4*>(Ls + sub * 32 + 8 * g4 + 4 * lh);
+        const f32x4 d4 = *reinterpret_cast<const f32x4*>(Dv + sub * 32 + 8 * g4 + 4 * lh);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int r = 4 * g4 + e;
+          pr[r] = __builtin_amdgcn_exp2f(s[r] - l4[e]);
+          s[r] = pr[r] * (dp[r] - d4[e]);  // dS
+        }
+      }
+      const float* qcol = Qs + (sub * 32 + 4 * lh) * PS + (CP >= 32 ? li : (li & (CP - 1)));
+      const float* dcol = Ds + (sub * 32 + 4 * lh) * PS + (CP >= 32 ? li : (li & (CP - 1)));
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int off = ((r & 3) + 8 * (r >> 2)) * PS + ct * 32;
+          dv[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(dcol[off], pr[r], dv[ct], 0, 0, 0);  // dV^T += dO^T P
+          dk[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(qcol[off], s[r], dk[ct], 0, 0, 0);   // dK^T += Q^T dS
+        }
+    }
+    if (more) store_tile(buf ^ 1);
+    __syncthreads();
+  }
+  if (!jok) return;
+  float* okp = p.dk + (brow + jrow) * p.dk_cs;
+  float* ovp = p.dv + (brow + jrow) * p.dv_cs;
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int c = ct * 32 + 8 * (r >> 2) + 4 * lh + (r & 3);
+      if (c < C) {
+        okp[c] = dk[ct][r];
+        ovp[c] = dv[ct][r];
+      }
+    }
+}
+
+template <int CP>
+int launch(const BwdArgs& a, hipStream_t s) {
+  const int grid = a.B * a.nt;
+  hipLaunchKernelGGL((attn_bwd_dq_kernel<CP>), dim3(grid), dim3(256), 0, s, a);
+  hipLaunchKernelGGL((attn_bwd_dkv_kernel<CP>), dim3(grid), dim3(256), 0, s, a);
+  SF_CHECK_LAUNCH();
+  return SF_OK;
+}
+
+}  // namespace
+
+extern "C" int sf_attn_bwd(const float* q, int q_cs, const float* k, int k_cs, const float* v, int v_cs,
+                           const float* dz, int dz_cs, const float* lse, const float* dvec, const float* gamma,
+                           float* dq, int dq_cs, float* dk, int dk_cs, float* dv, int dv_cs, int B, int N, int C,
+                           void* stream) {
+  if (!q || !k || !v || !dz || !lse || !dvec || !gamma || !dq || !dk || !dv) return SF_EINVAL;
+  if (B <= 0 || N <= 0 || C <= 0 || C > 128) return SF_EINVAL;
+  BwdArgs a;
+  a.q = q; a.k = k; a.v = v; a.dz = dz; a.lse = lse; a.dvec = dvec; a.gamma = gamma;
+  a.dq = dq; a.dk = dk; a.dv = dv;
+  a.q_cs = q_cs; a.k_cs = k_cs; a.v_cs = v_cs; a.dz_cs = dz_cs; a.dq_cs = dq_cs; a.dk_cs = dk_cs; a.dv_cs = dv_cs;
+  a.B = B; a.C = C; a.N = N; a.nt = sf_cdiv(N, 128);
+  hipStream_t s = (hipStream_t)stream;
+  if (C <= 8) return launch<8>(a, s);
+  if (C <= 16) return launch<16>(a, s);
+  if (C <= 32) return launch<32>(a, s);
+  if (C <= 64) return launch<64>(a, s);
+  return launch<128>(a, s);
+}

@@ -31,6 +31,8 @@ struct AttnArgs {
   const float* q; const float* k; const float* v; const float* x;
   const float* gamma; const float* scale; const float* bias;
   float* out;
+  float* o_save;    // optional [B, N, C] dense: O = P v (pre-gamma), saved for the backward pass
+  float* lse_save;  // optional [B, N]: log2-domain log-sum-exp of each query row
   int q_cs, k_cs, v_cs, x_cs, out_cs, out_coff;
   int B, T, H, W, C, N, alpha, act, nqt;
 };
@@ -213,6 +215,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
   const int hw = qrow - tq * HW;
   const float* xp = p.x + (brow + qrow) * p.x_cs;
   const long orow0 = ((long)b * p.T * p.alpha + (long)tq * p.alpha) * HW + hw;
+  if (p.lse_save && lh == 0) p.lse_save[brow + qrow] = m_run + __log2f(l_tot);
 #pragma unroll
   for (int ct = 0; ct < CT; ++ct) {
 #pragma unroll
@@ -224,6 +227,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
       for (int e = 0; e < 4; ++e) {
         const int c = c0 + e;
         const bool okc = c < C;
+        if (p.o_save && okc) p.o_save[(brow + qrow) * C + c] = o[ct][4 * g + e] * inv_l;
         float v = gamma * (o[ct][4 * g + e] * inv_l) + (okc ? xp[c] : 0.f);
         if (p.scale && okc) v = v * p.scale[c] + p.bias[c];
         if (p.act == SF_ACT_RELU) v = fmaxf(v, 0.f);
@@ -259,12 +263,12 @@ int launch(const AttnArgs& a, bool vec4, hipStream_t s) {
 int sf_attn_small_dispatch(const float* q, int q_cs, const float* k, int k_cs, const float* v, int v_cs,
                            const float* x, int x_cs, const float* gamma, const float* scale, const float* bias,
                            int act, float* out, int out_cs, int out_coff, int B, int T, int H, int W, int C,
-                           int alpha, bool vec4, hipStream_t stream);  // attn_small.hip
+                           int alpha, float* o_save, float* lse_save, bool vec4, hipStream_t stream);  // attn_small.hip
 
 extern "C" int sf_attn_fwd(const float* q, int q_cs, const float* k, int k_cs, const float* v, int v_cs,
                            const float* x, int x_cs, const float* gamma, const float* scale, const float* bias,
                            int act, float* out, int out_cs, int out_coff, int B, int T, int H, int W, int C,
-                           int alpha, void* stream) {
+                           int alpha, float* o_save, float* lse_save, void* stream) {
   if (!q || !k || !v || !x || !out) return SF_EINVAL;
   if (B <= 0 || T <= 0 || H <= 0 || W <= 0 || C <= 0 || C > 128 || alpha <= 0) return SF_EINVAL;
   if ((scale == nullptr) != (bias == nullptr)) return SF_EINVAL;
@@ -273,6 +277,7 @@ extern "C" int sf_attn_fwd(const float* q, int q_cs, const float* k, int k_cs, c
   if (N * B > 0x7fffffffL) return SF_EINVAL;
   AttnArgs a;
   a.q = q; a.k = k; a.v = v; a.x = x; a.gamma = gamma; a.scale = scale; a.bias = bias; a.out = out;
+  a.o_save = o_save; a.lse_save = lse_save;
   a.q_cs = q_cs; a.k_cs = k_cs; a.v_cs = v_cs; a.x_cs = x_cs; a.out_cs = out_cs; a.out_coff = out_coff;
   a.B = B; a.T = T; a.H = H; a.W = W; a.C = C; a.N = (int)N; a.alpha = alpha; a.act = act;
   a.nqt = sf_cdiv(N, 128);
@@ -282,7 +287,7 @@ extern "C" int sf_attn_fwd(const float* q, int q_cs, const float* k, int k_cs, c
   hipStream_t s = (hipStream_t)stream;
   if (C <= 16)  // 16-query wavefronts on 16x16x4 tiles: no padded rows in the second product
     return sf_attn_small_dispatch(q, q_cs, k, k_cs, v, v_cs, x, x_cs, gamma, scale, bias, act, out, out_cs,
-                                  out_coff, B, T, H, W, C, alpha, vec4, s);
+                                  out_coff, B, T, H, W, C, alpha, o_save, lse_save, vec4, s);
   if (C <= 32) return launch<32>(a, vec4, s);
   if (C <= 64) return launch<64>(a, vec4, s);
   return launch<128>(a, vec4, s);

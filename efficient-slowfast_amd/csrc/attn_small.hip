@@ -19,6 +19,8 @@ struct AttnArgs {
   const float* q; const float* k; const float* v; const float* x;
   const float* gamma; const float* scale; const float* bias;
   float* out;
+  float* o_save;    // optional [B, N, C] dense: O = P v (pre-gamma), saved for the backward pass
+  float* lse_save;  // optional [B, N]: log2-domain log-sum-exp of each query row
   int q_cs, k_cs, v_cs, x_cs, out_cs, out_coff;
   int B, T, H, W, C, N, alpha, act, nqt;
 };
@@ -187,6 +189,7 @@ __global__ __launch_bounds__(256) void attn_small_kernel(const AttnArgs p) {
   const int c0 = 4 * lg;
   if (qrow >= N || c0 >= C) return;
   const float inv_l = 1.0f / l_tot;
+  if (p.lse_save && lg == 0) p.lse_save[brow + qrow] = m_run + __log2f(l_tot);
   const float gamma = p.gamma ? p.gamma[0] : 1.0f;
   const int HW = p.H * p.W;
   const int tq = qrow / HW;
@@ -198,6 +201,7 @@ __global__ __launch_bounds__(256) void attn_small_kernel(const AttnArgs p) {
   for (int e = 0; e < 4; ++e) {
     const int c = c0 + e;
     const bool okc = c < C;
+    if (p.o_save && okc) p.o_save[(brow + qrow) * C + c] = o[e] * inv_l;
     float v = gamma * (o[e] * inv_l) + (okc ? xp[c] : 0.f);
     if (p.scale && okc) v = v * p.scale[c] + p.bias[c];
     if (p.act == SF_ACT_RELU) v = fmaxf(v, 0.f);
@@ -232,9 +236,10 @@ int launch(const AttnArgs& a, bool vec4, hipStream_t s) {
 int sf_attn_small_dispatch(const float* q, int q_cs, const float* k, int k_cs, const float* v, int v_cs,
                            const float* x, int x_cs, const float* gamma, const float* scale, const float* bias,
                            int act, float* out, int out_cs, int out_coff, int B, int T, int H, int W, int C,
-                           int alpha, bool vec4, hipStream_t stream) {
+                           int alpha, float* o_save, float* lse_save, bool vec4, hipStream_t stream) {
   AttnArgs a;
   a.q = q; a.k = k; a.v = v; a.x = x; a.gamma = gamma; a.scale = scale; a.bias = bias; a.out = out;
+  a.o_save = o_save; a.lse_save = lse_save;
   a.q_cs = q_cs; a.k_cs = k_cs; a.v_cs = v_cs; a.x_cs = x_cs; a.out_cs = out_cs; a.out_coff = out_coff;
   a.B = B; a.T = T; a.H = H; a.W = W; a.C = C; a.N = T * H * W; a.alpha = alpha; a.act = act;
   a.nqt = sf_cdiv(a.N, 64);

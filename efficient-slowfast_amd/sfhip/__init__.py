@@ -42,7 +42,7 @@ EXPORTS = [
     "sf_pool_fwd", "sf_tmax_mean_ws_floats", "sf_tmax_mean", "sf_gate_apply", "sf_attn_fwd", "sf_head_act_mean",
     "sf_copy_channels", "sf_channel_stats_ws_floats", "sf_channel_stats", "sf_affine_fwd",
     "sf_conv_wgrad_splits", "sf_conv_wgrad", "sf_bn_bwd_ws_floats", "sf_bn_bwd_reduce", "sf_bn_bwd_apply",
-    "sf_maxpool_bwd", "sf_tmax_dot", "sf_eca_bwd_apply", "sf_bcast_add", "sf_rowdot", "sf_axpy",
+    "sf_attn_bwd", "sf_maxpool_bwd", "sf_tmax_dot", "sf_eca_bwd_apply", "sf_bcast_add", "sf_rowdot", "sf_axpy",
 ]
 _LONG_RET = ("sf_tmax_mean_ws_floats", "sf_channel_stats_ws_floats", "sf_bn_bwd_ws_floats")
 
@@ -72,7 +72,8 @@ def lib():
         L.sf_tmax_mean_ws_floats.restype = cl
         L.sf_tmax_mean.argtypes = [vp, ci, ci] + [ci] * 6 + [vp, vp, vp]
         L.sf_gate_apply.argtypes = [vp, ci, ci] + [ci] * 6 + [vp, vp, vp, vp, ci, vp, ci, ci, vp]
-        L.sf_attn_fwd.argtypes = [vp, ci, vp, ci, vp, ci, vp, ci, vp, vp, vp, ci, vp, ci, ci] + [ci] * 6 + [vp]
+        L.sf_attn_fwd.argtypes = [vp, ci, vp, ci, vp, ci, vp, ci, vp, vp, vp, ci, vp, ci, ci] + [ci] * 6 + [vp, vp, vp]
+        L.sf_attn_bwd.argtypes = [vp, ci, vp, ci, vp, ci, vp, ci, vp, vp, vp, vp, ci, vp, ci, vp, ci, ci, ci, ci, vp]
         L.sf_head_act_mean.argtypes = [vp, ci, ci, ci, ci, vp, vp]
         L.sf_copy_channels.argtypes = [vp, ci, ci, vp, ci, ci, ci, cl, ci, vp]
         L.sf_channel_stats_ws_floats.argtypes = [ci]
@@ -311,8 +312,9 @@ def _traced(tag, fn):
     return rc
 
 
-def attention(q, k, v, x, gamma, scale=None, bias=None, relu=False, alpha=1, out=None):
-    """Flash SpatialAttention + gamma-residual + (BN affine, ReLU) + nearest T-upsample x alpha."""
+def attention(q, k, v, x, gamma, scale=None, bias=None, relu=False, alpha=1, out=None, save=None):
+    """Flash SpatialAttention + gamma-residual + (BN affine, ReLU) + nearest T-upsample x alpha.
+    save: optional dict that receives 'o' ([B,N,C] tensor, O = P v) and 'lse' ([B,N]) for the backward pass."""
     _require_gpu(x.buf, "attention")
     if out is None:
         out = new_act(x, x.N, x.T * alpha, x.H, x.W, x.C)
@@ -322,10 +324,15 @@ def attention(q, k, v, x, gamma, scale=None, bias=None, relu=False, alpha=1, out
     def base(a):  # slice base pointer: buffer pointer + channel offset
         return ctypes.c_void_p(a.buf.data_ptr() + 4 * a.coff)
 
+    o_save = lse_save = None
+    if save is not None:
+        n = x.T * x.H * x.W
+        o_save = save["o"] = torch.empty((x.N, n, x.C), dtype=torch.float32, device=x.buf.device)
+        lse_save = save["lse"] = torch.empty((x.N, n), dtype=torch.float32, device=x.buf.device)
     _check(_traced(("attn", x.N, x.T * x.H * x.W, x.C), lambda: lib().sf_attn_fwd(
         base(q), q.cs, base(k), k.cs, base(v), v.cs, base(x), x.cs, _ptr(gamma), _ptr(scale),
         _ptr(bias), ACT_RELU if relu else ACT_NONE, out.ptr(), out.cs, out.coff,
-        x.N, x.T, x.H, x.W, x.C, alpha, _stream())), "sf_attn_fwd")
+        x.N, x.T, x.H, x.W, x.C, alpha, _ptr(o_save), _ptr(lse_save), _stream())), "sf_attn_fwd")
     return out
 
 
@@ -477,3 +484,19 @@ def axpy(a, out, alpha=1.0, accumulate=True):
     _check(lib().sf_axpy(a.ptr(), a.cs, a.coff, float(alpha), out.ptr(), out.cs, out.coff, a.rows, a.C,
                          1 if accumulate else 0, _stream()), "sf_axpy")
     return out
+
+
+def attention_bwd(q, k, v, dz, o, lse, gamma, dq, dk, dv):
+    """dq/dk/dv (Act slices, overwritten) of the flash SpatialAttention; returns dvec[i] = <dz_i, O_i>
+    (its sum is dL/dgamma)."""
+    B, n, C = o.shape
+    o_act = Act(o.view(B, 1, 1, n, C))
+    dvec = rowdot(Act(dz.buf.view(B, 1, 1, n, dz.cs), dz.coff, C), o_act)
+
+    def base(a):
+        return ctypes.c_void_p(a.buf.data_ptr() + 4 * a.coff)
+
+    _check(lib().sf_attn_bwd(base(q), q.cs, base(k), k.cs, base(v), v.cs, base(dz), dz.cs, _ptr(lse), _ptr(dvec),
+                             _ptr(gamma), base(dq), dq.cs, base(dk), dk.cs, base(dv), dv.cs, B, n, C, _stream()),
+           "sf_attn_bwd")
+    return dvec

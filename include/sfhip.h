@@ -109,11 +109,20 @@ int sf_gate_apply(const float* x, int cs, int coff, int N, int T, int H, int W, 
  *   z = relu(scale*y + bias)  (bn_s2f eval affine; skipped when scale == NULL),
  *   written `alpha` times along T (nn.Upsample nearest) into out (pitch out_cs, offset out_coff).
  * q,k,v,x: [B, N=T*H*W, C] views with pitches q_cs.. (q,k,v normally slices of one [B,N,3C] buffer).
- * gamma is read from device memory (it is an nn.Parameter).                                       */
+ * gamma is read from device memory (it is an nn.Parameter).
+ * o_save / lse_save (optional, training): O = P v [B, N, C] dense and the log2-domain log-sum-exp [B, N]
+ * of every query row, which sf_attn_bwd recomputes P from.                                           */
 int sf_attn_fwd(const float* q, int q_cs, const float* k, int k_cs, const float* v, int v_cs,
                 const float* x, int x_cs, const float* gamma, const float* scale, const float* bias,
                 int act, float* out, int out_cs, int out_coff, int B, int T, int H, int W, int C,
-                int alpha, void* stream);
+                int alpha, float* o_save, float* lse_save, void* stream);
+
+/* SpatialAttention backward (recompute form): dz = dL/d(gamma*O + x) [B, N, C]; dvec[i] = <dz_i, O_i>
+ * (sf_rowdot); writes dq, dk, dv (overwrite).  dx = dz and dgamma = sum(dvec) are the caller's.        */
+int sf_attn_bwd(const float* q, int q_cs, const float* k, int k_cs, const float* v, int v_cs,
+                const float* dz, int dz_cs, const float* lse, const float* dvec, const float* gamma,
+                float* dq, int dq_cs, float* dk, int dk_cs, float* dv, int dv_cs, int B, int N, int C,
+                void* stream);
 
 /* ---- training-mode BatchNorm3d forward pieces (batchnorm_helper.py:15-34 -> nn.BatchNorm3d, training=True)
  * sf_channel_stats: per-channel mean and BIASED variance over all rows of an NDHWC slice, reduced through

@@ -194,3 +194,41 @@ def test_small_helpers():
     assert _rel(d.view(2, 3, 4), (a * b).sum(-1)[0] * 0.5) < 1e-5
     assert _rel(gbuf.buf, 1 + 0.25 * v.view(2, 1, 1, 1, 6).expand(2, 2, 3, 4, 6)) < 1e-6
     assert _rel(o.buf, 1 + 2 * a) < 1e-6
+
+
+ATTN_BWD = [(8, (2, 12, 12)), (32, (2, 14, 14)), (64, (4, 7, 7)), (128, (2, 7, 7)), (3, (4, 8, 8)), (28, (2, 9, 9)),
+            (32, (1, 3, 3))]
+
+
+@pytest.mark.parametrize("c,thw", ATTN_BWD, ids=["c%d_n%d" % (c, t * h * w) for c, (t, h, w) in ATTN_BWD])
+def test_attention_backward(c, thw):
+    """dq, dk, dv, dgamma of the flash attention vs autograd through the oracle's dense softmax attention."""
+    import sfhip
+    dev = _dev()
+    g = torch.Generator().manual_seed(c * 7 + thw[1])
+    t, h, w = thw
+    B, n = 2, t * h * w
+    q = (torch.randn(B, n, c, generator=g) * 0.7).requires_grad_(True)
+    k = (torch.randn(B, n, c, generator=g) * 0.7).requires_grad_(True)
+    v = torch.randn(B, n, c, generator=g).requires_grad_(True)
+    x = torch.randn(B, n, c, generator=g)
+    gamma = torch.tensor([0.6], requires_grad=True)
+    z = gamma * (torch.softmax(q @ k.transpose(1, 2), -1) @ v) + x
+    dz = torch.randn(z.shape, generator=g)
+    dq_r, dk_r, dv_r, dg_r = torch.autograd.grad(z, (q, k, v, gamma), dz)
+    qkv = sfhip.Act(torch.cat([q, k, v], -1).detach().view(B, t, h, w, 3 * c).contiguous().to(dev))
+    xa = sfhip.Act(x.view(B, t, h, w, c).contiguous().to(dev))
+    gam = gamma.detach().to(dev)
+    save = {}
+    out = sfhip.attention(qkv.slice(0, c), qkv.slice(c, c), qkv.slice(2 * c, c), xa, gam, save=save)
+    dqkv = sfhip.Act(torch.zeros(B, t, h, w, 3 * c, device=dev))
+    dza = sfhip.Act(dz.view(B, t, h, w, c).contiguous().to(dev))
+    dvec = sfhip.attention_bwd(qkv.slice(0, c), qkv.slice(c, c), qkv.slice(2 * c, c), dza, save["o"], save["lse"],
+                               gam, dqkv.slice(0, c), dqkv.slice(c, c), dqkv.slice(2 * c, c))
+    torch.cuda.synchronize()
+    assert _rel(out.buf.view(B, n, c), z) < TOL
+    got = dqkv.buf.view(B, n, 3 * c)
+    errs = [_rel(got[..., :c], dq_r), _rel(got[..., c:2 * c], dk_r), _rel(got[..., 2 * c:], dv_r),
+            _rel(dvec.sum().view(1), dg_r)]
+    _report("attn_bwd c%d n%d" % (c, n), max(errs))
+    assert max(errs) < TOL, errs
