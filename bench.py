@@ -5,8 +5,10 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-A "step" is one eval-mode forward pass of the model over one batch of synthetic clips that are already
-resident in HBM (fp32 NCTHW, as the reference's loaders hand them over).  Default workload =
+--mode train (default): a "step" is one training iteration of the reference's loop (tools/train_net.py:78-96)
+over one batch of synthetic clips already resident in HBM (fp32 NCTHW): train-mode forward (batch-statistics
+BN, dropout), cross-entropy, backward through every kernel, ONE all-reduce of the flat gradient buffer across
+ranks (RCCL) and an SGD(momentum, weight-decay) update.  --mode eval: one eval-mode forward pass (inference).  Default workload =
 BASELINE.json's metric config: SlowFastDualAttention 8x8 R50 + CMDA, 224^2, 8 clips per GPU (configs[2];
 at N GPUs configs[3]: global batch 8N).  Parameters are the de-degenerated seeded fill of
 tests/golden/paramgen.py (gamma != 0, non-zero final BNs) so no part of the network is a no-op.
@@ -110,7 +112,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="dual", choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=0, help="clips per GPU (default: the workload's)")
-    ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
+    ap.add_argument("--mode", default="train", choices=["train", "eval"])
+    ap.add_argument("--no-graph", action="store_true", help="(eval) launch eagerly instead of replaying a hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -128,22 +131,41 @@ def main():
         dist.init_process_group(backend="nccl")  # RCCL over xGMI
 
     import sfhip
+    from slowfast.utils.distributed import FlatGradients, max_over_ranks
     cfg, model, batch, desc = build(args.workload, device)
     batch = args.batch or batch
     clips = synthetic_clips(cfg, batch, device, 100 + rank)  # a different shard of clips per rank
-
-    def step():
-        with torch.no_grad():
-            return model([clips[0], clips[1]])
-
-    # ---- warm-up (also builds the packed-weight / folded-BN caches), optional hipGraph capture
+    labels = torch.randint(0, cfg.MODEL.NUM_CLASSES, (batch,), device=device,
+                           generator=torch.Generator(device=device).manual_seed(7 + rank))
+    train = args.mode == "train"
     side = torch.cuda.Stream()
+
+    if train:
+        model.train()
+        flat = FlatGradients(model.parameters())
+        opt = torch.optim.SGD(model.parameters(), lr=1e-3, momentum=0.9, weight_decay=1e-4)
+
+        def step():
+            flat.zero()
+            logits = model([clips[0], clips[1]])
+            loss = torch.nn.functional.cross_entropy(logits, labels)
+            loss.backward()
+            flat.all_reduce_mean()      # ONE collective per step over RCCL / xGMI (no-op at world 1)
+            opt.step()
+            flat.rebind()
+            return loss
+    else:
+        def step():
+            with torch.no_grad():
+                return model([clips[0], clips[1]])
+
+    # ---- warm-up (also builds the packed-weight / folded-BN caches), optional hipGraph capture (eval)
     with torch.cuda.stream(side):
         for _ in range(max(args.warmup, 1)):
             out = step()
     torch.cuda.synchronize()
     graph = None
-    if not args.no_graph:
+    if not train and not args.no_graph:
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph, stream=side):
             out = step()
@@ -168,18 +190,15 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     barrier()
-    if world > 1:
-        tmax = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+    elapsed = max_over_ranks(elapsed, device)
 
-    # ---- dominant-kernel trace: HIP events around every flash-attention launch over K eager steps on the
-    #      stream the kernels run on (event pairs cannot be recorded inside a replayed graph)
+    # ---- dominant-kernel trace: HIP events around every attention launch (forward and backward) over a few
+    #      eager steps on the stream the kernels run on
     roofline = None
     if rank == 0 and args.workload in ("dual", "ghostnet", "shufflenetv2"):
         sfhip.EVENT_TRACE = []
         with torch.cuda.stream(side):
-            for _ in range(min(args.steps, 5)):
+            for _ in range(min(args.steps, 3)):
                 step()
         torch.cuda.synchronize()
         per = {}
@@ -188,11 +207,16 @@ def main():
         sfhip.EVENT_TRACE = None
         tot = {tag: sum(v) for tag, v in per.items()}
         tag = max(tot, key=tot.get)
-        _, b, n, c = tag
+        kind, b, n, c = tag
         dur = float(np.mean(per[tag]))
-        flops = 4.0 * b * n * n * c  # QK^T + PV, 2 FLOP per MAC (2*N^2*C MAC per clip)
+        # algorithmic FLOPs: forward = QK^T + PV = 2 products, backward = 5 products
+        # (S recompute, dP, dV, dQ, dK); each product 2*N^2*C FLOP per clip
+        nprod = 2 if kind == "attn" else 5
+        flops = nprod * 2.0 * b * n * n * c
         ach = flops / dur / 1e12
-        roofline = {"bound": "mfma", "kernel": "attn_fwd_kernel (flash SpatialAttention) C=%d N=%d B=%d" % (c, n, b),
+        kname = "attn_fwd_kernel (flash SpatialAttention forward)" if kind == "attn" else \
+            "attn_bwd_dq_kernel + attn_bwd_dkv_kernel (flash SpatialAttention backward, one sf_attn_bwd call)"
+        roofline = {"bound": "mfma", "kernel": "%s C=%d N=%d B=%d" % (kname, c, n, b),
                     "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "avg_launch_ms": round(dur * 1e3, 4),
                     "launches_timed": len(per[tag]), "traffic": None}
@@ -200,15 +224,20 @@ def main():
     if rank == 0:
         clips_total = batch * world * args.steps
         res = {
-            "metric": "clips/sec (8x8 224^2 SlowFast-R50+CMDA eval forward)" if args.workload == "dual"
-            else "clips/sec (%s eval forward)" % args.workload,
+            "metric": "clips/sec (8x8 224^2 SlowFast-R50+CMDA, %s)" % ("train step fwd+bwd+allreduce+SGD" if train
+                                                                          else "eval forward")
+            if args.workload == "dual" else "clips/sec (%s, %s)" % (args.workload, args.mode),
             "value": round(clips_total / elapsed, 3), "unit": "clips/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": desc, "mode": "eval forward (inference); train-mode/backward not built yet",
+            "config": {"workload": desc,
+                       "mode": "train step: train-mode forward + CE + backward + 1 flat-gradient all-reduce + SGD"
+                       if train else "eval forward (inference)",
                        "clips_per_gpu": batch, "global_batch": batch * world, "layout": "NCTHW in, NDHWC inside",
                        "launch": "eager" if graph is None else "hipGraph replay",
-                       "parallelism": "dp%d (clip-sharded replicas, no data-path collective in forward)" % world},
+                       "parallelism": "dp%d (clip-sharded replicas; %s)" % (
+                           world, "one RCCL all-reduce of the flat fp32 gradient per step" if train
+                           else "no data-path collective in forward")},
         }
         if roofline is not None:
             res["roofline"] = roofline

@@ -496,7 +496,7 @@ def attention_bwd(q, k, v, dz, o, lse, gamma, dq, dk, dv):
     def base(a):
         return ctypes.c_void_p(a.buf.data_ptr() + 4 * a.coff)
 
-    _check(lib().sf_attn_bwd(base(q), q.cs, base(k), k.cs, base(v), v.cs, base(dz), dz.cs, _ptr(lse), _ptr(dvec),
-                             _ptr(gamma), base(dq), dq.cs, base(dk), dk.cs, base(dv), dv.cs, B, n, C, _stream()),
-           "sf_attn_bwd")
+    _check(_traced(("attn_bwd", B, n, C), lambda: lib().sf_attn_bwd(
+        base(q), q.cs, base(k), k.cs, base(v), v.cs, base(dz), dz.cs, _ptr(lse), _ptr(dvec),
+        _ptr(gamma), base(dq), dq.cs, base(dk), dk.cs, base(dv), dv.cs, B, n, C, _stream())), "sf_attn_bwd")
     return dvec

@@ -52,6 +52,8 @@ class FuseFastAndSlow(nn.Module):
         if x_s.coff == 0 and x_s.cs == x_s.C + self._c_f2s:
             s_wide = sfhip.Act(x_s.buf)
         else:
+            if engine.tape() is not None:
+                raise NotImplementedError("taped CMDA needs the producer-reserved concat slices")
             s_wide = sfhip.new_act(x_s, x_s.N, x_s.T, x_s.H, x_s.W, x_s.C + self._c_f2s)
             sfhip.copy_channels(x_s, s_wide.slice(0, x_s.C))
         if x_f.coff == self._c_s2f and x_f.cs == x_f.C + self._c_s2f:
@@ -102,6 +104,10 @@ class _EfficientTwoPathway(nn.Module):
     """forward = registered children in order: [stems], (stage, fuse)*, [last stage], head."""
 
     def forward(self, x, bboxes=None):
+        return engine.run_model(self, x)
+
+    def _forward_impl(self, x):
+        x = list(x)
         with engine.internal():
             names = [n for n, _ in self.named_children()]
             for i, n in enumerate(names):

@@ -41,6 +41,104 @@ def leave(acts):
     return [sfhip.to_ncthw(a) for a in acts]
 
 
+# ------------------------------------------------------------------------------------------------ tape
+class Tape(object):
+    """Reverse-mode tape of ONE training forward.  Activation gradients live in zero-initialised NDHWC
+    buffers shaped like their forward buffers (keyed by address), and every backward op ACCUMULATES into
+    them — that is autograd's fan-in sum for residual branches and for the two consumers each pathway tensor
+    has in the lateral fusions.  Parameter gradients are collected per nn.Parameter."""
+
+    def __init__(self):
+        self.ops = []
+        self.gbuf = {}
+        self.pgrads = {}
+        self.out_act = None
+
+    def grad_of(self, act):
+        key = act.buf.data_ptr()
+        g = self.gbuf.get(key)
+        if g is None:
+            g = torch.zeros(act.buf.numel(), dtype=torch.float32, device=act.buf.device)
+            self.gbuf[key] = g
+        return Act(g.view(act.buf.shape), act.coff, act.C)
+
+    def has_grad(self, act):
+        return act.buf.data_ptr() in self.gbuf
+
+    def record(self, fn):
+        self.ops.append(fn)
+
+    def add_pgrad(self, param, g):
+        g = g.reshape(param.shape)
+        cur = self.pgrads.get(param)
+        self.pgrads[param] = g if cur is None else cur + g
+
+    def backward(self):
+        for fn in reversed(self.ops):
+            fn()
+        self.ops = []
+        self.gbuf = {}
+
+
+def tape():
+    return getattr(_tls, "tape", None)
+
+
+class taping(object):
+    def __init__(self, t):
+        self.t = t
+
+    def __enter__(self):
+        self.prev = getattr(_tls, "tape", None)
+        _tls.tape = self.t
+
+    def __exit__(self, *a):
+        _tls.tape = self.prev
+
+
+def _colsum(act):
+    """per-channel sum over all rows (bias gradients)."""
+    mean, _ = sfhip.channel_stats(act)
+    return mean * float(act.rows)
+
+
+def _record_conv(x, conv_weight, conv_bias, wp_shape, gsrc, kernel, stride, padding, dilation, x_needs_grad=True,
+                 cin=None, unpack=None):
+    """Backward of a dense conv whose output gradient will be found in `gsrc` (an Act)."""
+    t = tape()
+    if t is None:
+        return
+    cout = conv_weight.shape[0]
+
+    def bwd():
+        g = gsrc() if callable(gsrc) else gsrc
+        dwp = sfhip.conv_wgrad(x, g, cout, kernel, stride, padding, dilation, cin=cin, cin_pad=wp_shape[2])
+        t.add_pgrad(conv_weight, unpack(dwp) if unpack else sfhip.unpack_conv_weight_grad(dwp, conv_weight.shape))
+        if conv_bias is not None:
+            t.add_pgrad(conv_bias, _colsum(g))
+        if x_needs_grad:
+            wtp = _cached_t(conv_weight, "_sf_wtp", _key(conv_weight),
+                            lambda: sfhip.pack_conv_weight(conv_weight.detach().reshape(
+                                conv_weight.shape[0], conv_weight.shape[1], *kernel).transpose(0, 1).contiguous()))
+            sfhip.conv_dgrad(g, wtp, x, kernel, stride, padding, dilation, out=t.grad_of(x), accumulate=True)
+
+    t.record(bwd)
+
+
+_PCACHE = {}
+
+
+def _cached_t(tensor, slot, key, make):
+    """cache keyed on a tensor (parameters are not nn.Modules)."""
+    k = (id(tensor), slot)
+    c = _PCACHE.get(k)
+    if c is None or c[0] != key:
+        with torch.no_grad():
+            c = (key, make())
+        _PCACHE[k] = c
+    return c[1]
+
+
 def _key(*tensors):
     return tuple((t.data_ptr(), t._version) for t in tensors if t is not None)
 
@@ -77,8 +175,22 @@ def bn_train_apply(bn, z, res=None, relu=False, rep=1, out=None, out_reserve=(0,
     zz = z if keep is None else z.slice(0, keep)
     if keep is not None:
         scale, shift = scale[:keep].contiguous(), shift[:keep].contiguous()
-    return sfhip.affine(zz, scale.contiguous(), shift.contiguous(), res=res, relu=relu, rep=rep, out=out,
-                        out_reserve=out_reserve, out_cmul=out_cmul)
+    y = sfhip.affine(zz, scale.contiguous(), shift.contiguous(), res=res, relu=relu, rep=rep, out=out,
+                     out_reserve=out_reserve, out_cmul=out_cmul)
+    t = tape()
+    if t is not None:
+        if keep is not None or out_cmul != 1:
+            raise NotImplementedError("backward through GhostModule slices / channel-shuffled stores is not built "
+                                      "yet (SlowFast / SlowFastDualAttention train end-to-end)")
+
+        def bwd():
+            dres = t.grad_of(res) if res is not None else None
+            _, dgamma, dbeta = sfhip.bn_bwd(t.grad_of(y), y, z, mean, invstd, bn.weight, relu, rep=rep, dres=dres)
+            t.add_pgrad(bn.weight, dgamma)
+            t.add_pgrad(bn.bias, dbeta)
+
+        t.record(bwd)  # afterwards z's buffer holds dL/dz for the producer's backward
+    return y
 
 
 def bn_affine(bn, conv_bias=None):
@@ -111,7 +223,10 @@ def conv_bn_act(x, conv, bn=None, relu=False, res=None, out=None, out_reserve=(0
         k, s, p, d = conv.kernel_size, conv.stride, conv.padding, conv.dilation
         if conv.groups == 1:
             z = sfhip.conv(x, wp, k, s, p, d, bias=conv.bias)
+            _record_conv(x, conv.weight, conv.bias, wp.shape, z, k, s, p, d)
         else:
+            if tape() is not None:
+                raise NotImplementedError("depthwise-conv backward is not built yet")
             ones = _cached(conv, "_sf_ones", (conv.out_channels, str(x.buf.device)),
                            lambda: torch.ones(conv.out_channels, dtype=torch.float32, device=x.buf.device))
             z = sfhip.dwconv(x, wp, k, s, p, scale=ones if conv.bias is not None else None, bias=conv.bias)
@@ -123,8 +238,14 @@ def conv_bn_act(x, conv, bn=None, relu=False, res=None, out=None, out_reserve=(0
         scale, bias = None, conv.bias
     k, s, p, d = conv.kernel_size, conv.stride, conv.padding, conv.dilation
     if conv.groups == 1:
-        return sfhip.conv(x, wp, k, s, p, d, scale=scale, bias=bias, relu=relu, res=res, out=out,
-                          out_reserve=out_reserve, out_cmul=out_cmul)
+        y = sfhip.conv(x, wp, k, s, p, d, scale=scale, bias=bias, relu=relu, res=res, out=out,
+                       out_reserve=out_reserve, out_cmul=out_cmul)
+        t = tape()
+        if t is not None:
+            if bn is not None or relu or res is not None or out_cmul != 1:
+                raise NotImplementedError("taped conv with a folded (eval-mode) BN / activation epilogue")
+            _record_conv(x, conv.weight, conv.bias, wp.shape, lambda: t.grad_of(y), k, s, p, d)
+        return y
     assert d == (1, 1, 1)
     if scale is None and bias is not None:
         scale = torch.ones_like(bias)
@@ -165,7 +286,59 @@ def stem_conv_bn_relu(x, conv, bn, relu=True):
     thw = (T + 2 * pT - kT + 1, Ho, Wo)
     if bn.training:
         z = sfhip.conv(view, wp, (kT, kH, 1), (1, sH, 1), (pT, 0, 0), bias=conv.bias, cin=4 * kW, out_thw=thw)
+
+        def unpack(dwp):  # [Cout][kT*kH][kW*4 + c] -> [Cout, C, kT, kH, kW]
+            co = dwp.shape[0]
+            return dwp[:, :, :4 * kW].reshape(co, kT, kH, kW, 4)[..., :C].permute(0, 4, 1, 2, 3).contiguous()
+
+        _record_conv(view, conv.weight, conv.bias, wp.shape, z, (kT, kH, 1), (1, sH, 1), (pT, 0, 0), (1, 1, 1),
+                     x_needs_grad=False, cin=4 * kW, unpack=unpack)
         return bn_train_apply(bn, z, relu=relu)
     scale, bias = bn_affine(bn, conv.bias)
     return sfhip.conv(view, wp, (kT, kH, 1), (1, sH, 1), (pT, 0, 0), scale=scale, bias=bias, relu=relu,
                       cin=4 * kW, out_thw=thw)
+
+
+def maxpool(x, kernel, stride, padding=(0, 0, 0), out_reserve=(0, 0)):
+    """MaxPool3d (+ its backward on the tape)."""
+    y = sfhip.pool(x, kernel, stride, padding, out_reserve=out_reserve)
+    t = tape()
+    if t is not None:
+        t.record(lambda: sfhip.maxpool_bwd(x, y, t.grad_of(y), t.grad_of(x), kernel, stride, padding))
+    return y
+
+
+class TapedForward(torch.autograd.Function):
+    """The whole HIP forward as ONE autograd node: forward records the tape, backward replays it and hands
+    the parameter gradients back to autograd (so .grad accumulation and DDP's all-reduce hooks work as for
+    any module).  Activations never become autograd tensors."""
+
+    @staticmethod
+    def forward(ctx, model, slow, fast, *params):
+        t = Tape()
+        with taping(t):
+            out = model._forward_impl([slow, fast])
+        if t.out_act is None:
+            raise RuntimeError("the head did not register its logits on the tape")
+        ctx.tape = t
+        ctx.params = params
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        t = ctx.tape
+        with torch.no_grad(), taping(None):
+            g = t.grad_of(t.out_act)
+            g.buf.copy_(dout.reshape(g.buf.shape))
+            t.backward()
+        grads = tuple(t.pgrads.get(p) for p in ctx.params)
+        ctx.tape = None
+        return (None, None, None) + grads
+
+
+def run_model(model, x):
+    """model.forward body shared by all model classes: taped when training with grad enabled."""
+    if model.training and torch.is_grad_enabled():
+        params = [p for p in model.parameters()]
+        return TapedForward.apply(model, x[0], x[1], *params)
+    return model._forward_impl(x)

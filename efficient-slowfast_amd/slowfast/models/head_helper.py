@@ -14,11 +14,25 @@ def _act_code(name):
 
 def _project(pooled, linear, dropout, training):
     """[N,T,H,W,C] -> logits Act [N,T,H,W,K] through nn.Linear's parameters (1x1x1 GEMM)."""
+    t = engine.tape()
     if dropout is not None and training and dropout.p > 0.0:
-        pooled = sfhip.Act(F.dropout(pooled.buf, dropout.p, True))
+        # nn.Dropout on the pooled [N, C] features: a parameter-sized mask (torch RNG, as the reference)
+        keep = 1.0 - dropout.p
+        mask = (torch.rand_like(pooled.buf) < keep).to(torch.float32) / keep
+        src = pooled
+        pooled = sfhip.Act(src.buf * mask)
+        if t is not None:
+            dropped = pooled
+            t.record(lambda: t.grad_of(src).buf.add_(t.grad_of(dropped).buf * mask))
     wp = engine._cached(linear, "_sf_wp", engine._key(linear.weight),
                         lambda: sfhip.pack_conv_weight(linear.weight.reshape(linear.out_features, -1, 1, 1, 1)))
-    return sfhip.conv(pooled, wp, (1, 1, 1), bias=linear.bias)
+    logits = sfhip.conv(pooled, wp, (1, 1, 1), bias=linear.bias)
+    if t is not None:
+        engine._record_conv(pooled, linear.weight, linear.bias, wp.shape, lambda: t.grad_of(logits), (1, 1, 1),
+                            (1, 1, 1), (0, 0, 0), (1, 1, 1),
+                            unpack=lambda dwp: dwp[:, 0, :linear.in_features].contiguous())
+        t.out_act = logits
+    return logits
 
 
 LOGITS_TAP = None  # tests set this to a callable(logits_tensor [N,T,H,W,K]) to observe the pre-activation logits
@@ -74,6 +88,8 @@ class ResNetBasicHead(nn.Module):
             if (to, ho, wo) == (1, 1, 1):  # window == extent: a global mean (parallel tree reduction)
                 _global_mean(x, cat.slice(off, x.C))
             else:
+                if engine.tape() is not None:
+                    raise NotImplementedError("training through a fully-convolutional head (pooled extent > 1)")
                 sfhip.pool(x, k, (1, 1, 1), avg=True, out=cat.slice(off, x.C))
             off += x.C
         logits = _project(cat, self.projection, getattr(self, "dropout", None), self.training)
@@ -97,9 +113,15 @@ def _global_mean(x, out=None):
     """[N,T,H,W,C] -> [N,1,1,1,C] mean (F.avg_pool3d(x, x.size()[-3:]))."""
     pooled = sfhip.tmax_mean(x, 1)
     a = sfhip.Act(pooled.view(x.N, 1, 1, 1, x.C))
-    if out is not None:
-        return sfhip.copy_channels(a, out)
-    return a
+    res = sfhip.copy_channels(a, out) if out is not None else a
+    t = engine.tape()
+    if t is not None:
+        def bwd():  # d mean: broadcast dL/d(pooled) / count over the pooled extent
+            g = t.grad_of(res)
+            v = g.buf.view(g.N, g.cs)[:, g.coff:g.coff + g.C].contiguous()
+            sfhip.bcast_add(t.grad_of(x), v, 1.0 / float(x.T * x.H * x.W))
+        t.record(bwd)
+    return res
 
 
 class ShuffleNetV2BasicHead(nn.Module):

@@ -21,7 +21,7 @@ class ResNetBasicStem(nn.Module):
 
     def forward(self, x, reserve=(0, 0)):
         y = engine.stem_conv_bn_relu(x, self.conv, self.bn, relu=True)
-        return sfhip.pool(y, (1, 3, 3), (1, 2, 2), (0, 1, 1), out_reserve=reserve)
+        return engine.maxpool(y, (1, 3, 3), (1, 2, 2), (0, 1, 1), out_reserve=reserve)
 
 
 class VideoModelStem(nn.Module):
@@ -76,7 +76,7 @@ class SimpleStem(nn.Module):
                 return sfhip.copy_channels(y, wide)
             return y
         y = engine.stem_conv_bn_relu(x, conv, bn, relu=True)
-        return sfhip.pool(y, (3, 3, 3), (1, 2, 2), (1, 1, 1), out_reserve=reserve)
+        return engine.maxpool(y, (3, 3, 3), (1, 2, 2), (1, 1, 1), out_reserve=reserve)
 
 
 class _EfficientStem(nn.Module):

@@ -41,6 +41,8 @@ class FuseFastToSlow(nn.Module):
         if x_s.coff == 0 and x_s.cs == x_s.C + cf:
             wide = sfhip.Act(x_s.buf)
         else:  # producer left no room (stand-alone call): allocate the concat buffer and copy the slow half
+            if engine.tape() is not None:
+                raise NotImplementedError("taped lateral fusion needs the producer-reserved concat slice")
             wide = sfhip.new_act(x_s, x_s.N, x_s.T, x_s.H, x_s.W, x_s.C + cf)
             sfhip.copy_channels(x_s, wide.slice(0, x_s.C))
         engine.conv_bn_act(x_f, self.conv_f2s, self.bn, relu=True, out=wide.slice(x_s.C, cf))
@@ -124,6 +126,10 @@ class _TwoPathwayResNet(nn.Module):
         )
 
     def forward(self, x, bboxes=None):
+        return engine.run_model(self, x)
+
+    def _forward_impl(self, x):
+        x = list(x)
         with engine.internal():
             x = self.s1(x, reserve=self.s1_fuse.reserve(None))
             x = self.s1_fuse(x)

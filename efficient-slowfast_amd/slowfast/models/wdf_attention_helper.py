@@ -34,13 +34,47 @@ class SpatialAttention(nn.Module):
             return sfhip.pack_conv_weight(w), b.contiguous()
 
         wp, b = engine._cached(self, "_sf_qkv", engine._key(*[t for c in convs for t in (c.weight, c.bias)]), make)
-        return sfhip.conv(x, wp, (1, 1, 1), bias=b)
+        qkv = sfhip.conv(x, wp, (1, 1, 1), bias=b)
+        t = engine.tape()
+        if t is not None:
+            c = self.input_channel
+
+            def bwd():  # merged q|k|v projection: one wgrad / dgrad, then split per conv
+                g = t.grad_of(qkv)
+                dwp = sfhip.conv_wgrad(x, g, 3 * c, (1, 1, 1), cin_pad=wp.shape[2])
+                dw = sfhip.unpack_conv_weight_grad(dwp, (3 * c, c, 1, 1, 1))
+                db = engine._colsum(g)
+                for i, cv in enumerate(convs):
+                    t.add_pgrad(cv.weight, dw[i * c:(i + 1) * c])
+                    t.add_pgrad(cv.bias, db[i * c:(i + 1) * c])
+                w_all = torch.cat([cv.weight for cv in convs], 0).detach()
+                wtp = sfhip.pack_conv_weight(w_all.transpose(0, 1).contiguous())
+                sfhip.conv_dgrad(g, wtp, x, (1, 1, 1), out=t.grad_of(x), accumulate=True)
+
+            t.record(bwd)
+        return qkv
 
     def run(self, x, scale=None, bias=None, relu=False, alpha=1, out=None):
         c = self.input_channel
         qkv = self.qkv(x)
-        return sfhip.attention(qkv.slice(0, c), qkv.slice(c, c), qkv.slice(2 * c, c), x, self.gamma,
-                               scale=scale, bias=bias, relu=relu, alpha=alpha, out=out)
+        t = engine.tape()
+        save = {} if t is not None else None
+        q, k, v = qkv.slice(0, c), qkv.slice(c, c), qkv.slice(2 * c, c)
+        z = sfhip.attention(q, k, v, x, self.gamma, scale=scale, bias=bias, relu=relu, alpha=alpha, out=out,
+                            save=save)
+        if t is not None:
+            assert scale is None and not relu and alpha == 1, "taped attention runs un-fused (training-mode BN)"
+
+            def bwd():  # z's grad buffer = the BN backward's in-place dz when z fed a BN, else grad_of(z)
+                gz = z if getattr(bwd, "grad_in_place", True) else t.grad_of(z)
+                dq = t.grad_of(qkv)
+                dvec = sfhip.attention_bwd(q, k, v, gz, save["o"], save["lse"], self.gamma, dq.slice(0, c),
+                                           dq.slice(c, c), dq.slice(2 * c, c))
+                t.add_pgrad(self.gamma, dvec.sum().reshape(1))
+                sfhip.axpy(gz, t.grad_of(x), 1.0, accumulate=True)  # residual: z = gamma*O + x
+
+            t.record(bwd)
+        return z
 
     def forward(self, x):
         plain = not isinstance(x, engine.Act)
@@ -64,7 +98,28 @@ class ECA(nn.Module):
     def run(self, x, alpha=1, scale=None, bias=None, relu=False, out=None):
         """gate(max-pool_alpha(x)) [* BN affine, ReLU], written into `out`."""
         pooled = sfhip.tmax_mean(x, alpha)
-        return sfhip.gate_apply(x, alpha, pooled, w3=self.conv.weight, scale=scale, bias=bias, relu=relu, out=out)
+        z = sfhip.gate_apply(x, alpha, pooled, w3=self.conv.weight, scale=scale, bias=bias, relu=relu, out=out)
+        t = engine.tape()
+        if t is not None:
+            assert scale is None and not relu, "taped ECA runs un-fused (training-mode BN follows)"
+            w3 = self.conv.weight
+
+            def bwd():  # z's buffer holds dL/dz (BN backward wrote it in place)
+                import torch.nn.functional as F
+                dg = sfhip.tmax_dot(x, alpha, z)                       # [N, C] = sum dz * max_r x
+                w = w3.detach()
+                a = F.conv1d(pooled.unsqueeze(1), w, None, 1, 1).squeeze(1)
+                gate = torch.sigmoid(a)
+                da = dg * gate * (1.0 - gate)
+                dpool = F.conv_transpose1d(da.unsqueeze(1), w, None, 1, 1).squeeze(1)
+                pp = F.pad(pooled, (1, 1))
+                C = pooled.shape[1]
+                t.add_pgrad(w3, torch.stack([(da * pp[:, kk:kk + C]).sum() for kk in range(3)]))
+                count = float((x.T // alpha) * x.H * x.W)
+                sfhip.eca_bwd_apply(x, alpha, z, gate.contiguous(), (dpool / count).contiguous(), t.grad_of(x))
+
+            t.record(bwd)
+        return z
 
     def forward(self, x):
         plain = not isinstance(x, engine.Act)

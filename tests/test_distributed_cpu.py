@@ -1,0 +1,89 @@
+"""world_size-2 gloo tests (CPU) of the data-parallel path: flat-buffer gradient all-reduce == the mean of the
+per-rank gradients == single-process gradient of the concatenated batch; clip sharding; max-over-ranks."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _make_model():
+    torch.manual_seed(0)
+    return torch.nn.Sequential(torch.nn.Conv3d(3, 4, 1), torch.nn.BatchNorm3d(4), torch.nn.ReLU(),
+                               torch.nn.AdaptiveAvgPool3d(1), torch.nn.Flatten(), torch.nn.Linear(4, 5))
+
+
+def _worker(rank, world, port, out):
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                    "efficient-slowfast_amd"))
+    from slowfast.utils.distributed import FlatGradients, max_over_ranks, shard_sizes
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        model = _make_model()
+        flat = FlatGradients(model.parameters())
+        g = torch.Generator().manual_seed(5)
+        x = torch.randn(4, 3, 2, 4, 4, generator=g)
+        y = torch.randint(0, 5, (4,), generator=g)
+        per = shard_sizes(4, world)[rank]
+        xs, ys = x[rank * per:(rank + 1) * per], y[rank * per:(rank + 1) * per]
+        flat.zero()
+        torch.nn.functional.cross_entropy(model(xs), ys).backward()
+        local = flat.flat.clone()
+        flat.all_reduce_mean()
+        gathered = [torch.zeros_like(local) for _ in range(world)]
+        dist.all_gather(gathered, local)
+        assert torch.allclose(flat.flat, sum(gathered) / world, atol=1e-7)
+        # every parameter's .grad is still a view of the flat buffer (no copies)
+        off = 0
+        for p in flat.params:
+            assert p.grad.data_ptr() == flat.flat.data_ptr() + 4 * off
+            off += p.numel()
+        assert max_over_ranks(float(rank + 1), "cpu") == float(world)
+        if rank == 0:
+            torch.save(flat.flat.clone(), out)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_flat_gradient_allreduce_world2(tmp_path):
+    out = str(tmp_path / "g.pt")
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
+    got = torch.load(out)
+    # per-rank BN statistics (the reference default, BN.NORM_TYPE batchnorm) => compare with the mean of
+    # two independent half-batch gradients computed in this process
+    model = _make_model()
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(4, 3, 2, 4, 4, generator=g)
+    y = torch.randint(0, 5, (4,), generator=g)
+    grads = []
+    for r in range(2):
+        model.zero_grad()
+        torch.nn.functional.cross_entropy(model(x[2 * r:2 * r + 2]), y[2 * r:2 * r + 2]).backward()
+        grads.append(torch.cat([p.grad.reshape(-1) for p in model.parameters()]))
+        # keep the running stats identical to the workers' (each saw ONE half batch)
+        model = _make_model()
+    assert torch.allclose(got, (grads[0] + grads[1]) / 2, atol=1e-6)
+
+
+def test_shard_sizes():
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                    "efficient-slowfast_amd"))
+    from slowfast.utils.distributed import shard_sizes
+    assert shard_sizes(64, 8) == [8] * 8
+    with pytest.raises(ValueError):
+        shard_sizes(10, 4)

@@ -188,3 +188,45 @@ def test_train_mode_forward_matches_reference_golden(name):
     changed = sum(int(not torch.equal(v, model.state_dict()[k])) for k, v in rm_before.items())
     assert changed == len(rm_before)
     assert int(next(v for k, v in model.state_dict().items() if k.endswith("num_batches_tracked"))) == 1
+
+
+@pytest.mark.parametrize("name", ["slowfast_r50_s64", "dual_r50_s64"])
+def test_train_step_gradients_match_reference_golden(name):
+    """train_net.py:78-96: logits = model(x); loss = CE(logits, labels); loss.backward() — loss, sampled
+    parameter gradients and their norms against the reference's autograd (golden 'grad/*')."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    z, meta = load_case(name)
+    model, sd = _build(meta, z)
+    for m in model.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    model.train()
+    logits = model([x.cuda() for x in case_inputs(meta)])
+    labels = torch.from_numpy(z["train/labels"]).cuda()
+    loss = torch.nn.functional.cross_entropy(logits, labels)
+    loss.backward()
+    torch.cuda.synchronize()
+    assert abs(loss.item() - float(z["train/loss"][0])) < 1e-3
+    params = dict(model.named_parameters())
+    keys = [k[5:] for k in z.files if k.startswith("grad/") and not k.endswith("/stats")]
+    assert len(keys) >= 6
+    # Tolerance: gradients of this ReLU / max-pool network are discontinuous in the activations — one
+    # activation whose sign differs by rounding flips a whole column of contributions.  The REFERENCE's own
+    # fp32-vs-fp64 gradients differ by 1.6 % (median) to 5 % (worst) in relative L2 on this fixture (measured
+    # with the oracle), so the end-to-end check is calibrated to that floor; each backward kernel is held to
+    # 2e-4 against autograd in tests/test_backward_ops_gpu.py.
+    worst = 0.0
+    for k in keys:
+        g = params[k].grad
+        assert g is not None, k
+        s, amax, _ = sample_activation(g.cpu().numpy(), 4096)
+        ref = z["grad/" + k].astype(np.float64)
+        e = float(np.linalg.norm(s.astype(np.float64) - ref) / max(np.linalg.norm(ref), 1e-30))
+        norm, rnorm = float(g.norm()), float(z["grad/" + k + "/stats"][1])
+        _report("%-22s grad %-50s L2rel %.3e  |g| %.4e vs %.4e" % (name, k, e, norm, rnorm))
+        worst = max(worst, e)
+        assert e < 8e-2, (k, e)
+        assert abs(norm - rnorm) < 5e-2 * rnorm + 1e-9, (k, norm, rnorm)
+    missing = [k for k, p in params.items() if p.grad is None]
+    assert not missing, missing[:5]
