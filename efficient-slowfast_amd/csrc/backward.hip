@@ -7,7 +7,7 @@
 namespace {
 
 constexpr int TPB = 256;
-constexpr int RED_P = 128;
+
 
 inline int pow2ceil_b(int v) {
   int p = 1;
@@ -15,62 +15,107 @@ inline int pow2ceil_b(int v) {
   return p;
 }
 
-// g(n,t,hw,c) = sum_{q<rep} dy[n, t*rep+q, hw, c] * (relu ? y[n, t*rep, hw, c] > 0 : 1)
-__device__ __forceinline__ float bn_g(const float* __restrict__ dy, int dy_cs, int dy_coff,
-                                      const float* __restrict__ y, int y_cs, int y_coff, long n, long t, long hw,
-                                      long T, int HW, int rep, int relu, int c) {
-  const long r0 = (n * T * rep + t * rep) * HW + hw;
-  if (relu && !(y[r0 * y_cs + y_coff + c] > 0.f)) return 0.f;
-  float g = 0.f;
-  for (int q = 0; q < rep; ++q) g += dy[(r0 + (long)q * HW) * dy_cs + dy_coff + c];
-  return g;
+// g(n,t,hw,c..c+VEC) = sum_{q<rep} dy[n, t*rep+q, hw, c] * (relu ? y[n, t*rep, hw, c] > 0 : 1)
+template <int VEC>
+__device__ __forceinline__ void bn_g(const float* __restrict__ dy, int dy_cs, int dy_coff,
+                                     const float* __restrict__ y, int y_cs, int y_coff, long r, long THW, int HW,
+                                     int rep, int relu, int c, float (&g)[VEC]) {
+  long r0 = r;
+  if (rep > 1) {
+    const long n = r / THW, rem = r - n * THW;
+    const long t = rem / HW, hw = rem - t * HW;
+    r0 = (n * (THW / HW) * rep + t * rep) * HW + hw;
+  }
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) g[e] = 0.f;
+  for (int q = 0; q < rep; ++q) {
+    const float* d = dy + (r0 + (long)q * HW) * dy_cs + dy_coff + c;
+    if (VEC == 4) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(d);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) g[e] += v[e];
+    } else {
+      g[0] += d[0];
+    }
+  }
+  if (relu) {
+    const float* yp = y + r0 * y_cs + y_coff + c;
+    if (VEC == 4) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(yp);
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (!(v[e] > 0.f)) g[e] = 0.f;
+    } else if (!(yp[0] > 0.f)) {
+      g[0] = 0.f;
+    }
+  }
 }
 
+// Row-block layout shared by the per-channel reductions: CB lanes cover the C/VEC channel vectors of a row,
+// TPB/CB rows are processed per iteration, gridDim.x = P row blocks (P partials, combined in fp64).
+template <int VEC>
 __global__ void bn_bwd_partial_kernel(const float* __restrict__ dy, int dy_cs, int dy_coff,
                                       const float* __restrict__ y, int y_cs, int y_coff,
-                                      const float* __restrict__ z, int z_cs, int z_coff, long rows, long T, int HW,
+                                      const float* __restrict__ z, int z_cs, int z_coff, long rows, long THW, int HW,
                                       int C, int rep, int relu, const float* __restrict__ mean,
                                       const float* __restrict__ invstd, int CB, float* __restrict__ partial) {
-  __shared__ float red[2 * TPB];
-  const int blk = blockIdx.x, cb = blockIdx.y;
+  __shared__ float red[2 * TPB * VEC];
+  const int blk = blockIdx.x, cb = blockIdx.y, P = gridDim.x;
   const int cl = threadIdx.x % CB, rl = threadIdx.x / CB, rpi = TPB / CB;
-  const int c = cb * CB + cl;
-  const long per = (rows + RED_P - 1) / RED_P;
+  const int c = (cb * CB + cl) * VEC;
+  const long per = (rows + P - 1) / P;
   const long r0 = (long)blk * per;
   const long r1 = (r0 + per < rows) ? r0 + per : rows;
-  float s1 = 0.f, s2 = 0.f;
+  float s1[VEC], s2[VEC];
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
   if (c < C) {
-    const float mu = mean[c], is = invstd[c];
-    const long THW = T * HW;
+    float mu[VEC], is[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) { mu[e] = mean[c + e]; is[e] = invstd[c + e]; }
     for (long r = r0 + rl; r < r1; r += rpi) {
-      const long n = r / THW, rem = r - n * THW;
-      const long t = rem / HW, hw = rem - t * HW;
-      const float g = bn_g(dy, dy_cs, dy_coff, y, y_cs, y_coff, n, t, hw, T, HW, rep, relu, c);
-      const float xh = (z[r * z_cs + z_coff + c] - mu) * is;
-      s1 += g;
-      s2 = fmaf(g, xh, s2);
+      float g[VEC], zv[VEC];
+      bn_g<VEC>(dy, dy_cs, dy_coff, y, y_cs, y_coff, r, THW, HW, rep, relu, c, g);
+      if (VEC == 4) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(z + r * z_cs + z_coff + c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) zv[e] = v[e];
+      } else {
+        zv[0] = z[r * z_cs + z_coff + c];
+      }
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        s1[e] += g[e];
+        s2[e] = fmaf(g[e], (zv[e] - mu[e]) * is[e], s2[e]);
+      }
     }
   }
-  red[threadIdx.x] = s1;
-  red[TPB + threadIdx.x] = s2;
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) {
+    red[threadIdx.x * VEC + e] = s1[e];
+    red[(TPB + threadIdx.x) * VEC + e] = s2[e];
+  }
   __syncthreads();
   if (rl == 0 && c < C) {
-    float t1 = 0.f, t2 = 0.f;
-    for (int i = 0; i < rpi; ++i) {
-      t1 += red[i * CB + cl];
-      t2 += red[TPB + i * CB + cl];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      float t1 = 0.f, t2 = 0.f;
+      for (int i = 0; i < rpi; ++i) {
+        t1 += red[(i * CB + cl) * VEC + e];
+        t2 += red[(TPB + i * CB + cl) * VEC + e];
+      }
+      partial[((long)blk * 2 + 0) * C + c + e] = t1;
+      partial[((long)blk * 2 + 1) * C + c + e] = t2;
     }
-    partial[((long)blk * 2 + 0) * C + c] = t1;
-    partial[((long)blk * 2 + 1) * C + c] = t2;
   }
 }
 
-__global__ void pair_final_kernel(const float* __restrict__ partial, int C, float* __restrict__ o1,
+__global__ void pair_final_kernel(const float* __restrict__ partial, int C, int P, float* __restrict__ o1,
                                   float* __restrict__ o2) {
   const int c = blockIdx.x * TPB + threadIdx.x;
   if (c >= C) return;
   double s1 = 0.0, s2 = 0.0;
-  for (int i = 0; i < RED_P; ++i) {
+  for (int i = 0; i < P; ++i) {
     s1 += (double)partial[((long)i * 2 + 0) * C + c];
     s2 += (double)partial[((long)i * 2 + 1) * C + c];
   }
@@ -79,25 +124,51 @@ __global__ void pair_final_kernel(const float* __restrict__ partial, int C, floa
 }
 
 // dz = gamma*invstd * (g - dbeta/M - xhat*dgamma/M)   [written to dz, may alias z];   dres += g
+template <int VEC>
 __global__ void bn_bwd_apply_kernel(const float* __restrict__ dy, int dy_cs, int dy_coff,
                                     const float* __restrict__ y, int y_cs, int y_coff, const float* z, int z_cs,
-                                    int z_coff, long rows, long T, int HW, int C, int rep, int relu,
+                                    int z_coff, long rows, long THW, int HW, int C, int rep, int relu,
                                     const float* __restrict__ mean, const float* __restrict__ invstd,
                                     const float* __restrict__ gamma, const float* __restrict__ dbeta,
                                     const float* __restrict__ dgamma, float inv_m, float* dz, int dz_cs, int dz_coff,
                                     float* __restrict__ dres, int dres_cs, int dres_coff, long total) {
   const long idx = (long)blockIdx.x * TPB + threadIdx.x;
   if (idx >= total) return;
-  const int c = (int)(idx % C);
-  const long r = idx / C;
-  const long THW = T * HW;
-  const long n = r / THW, rem = r - n * THW;
-  const long t = rem / HW, hw = rem - t * HW;
-  const float g = bn_g(dy, dy_cs, dy_coff, y, y_cs, y_coff, n, t, hw, T, HW, rep, relu, c);
-  const float is = invstd[c];
-  const float xh = (z[r * z_cs + z_coff + c] - mean[c]) * is;
-  dz[r * dz_cs + dz_coff + c] = gamma[c] * is * (g - dbeta[c] * inv_m - xh * dgamma[c] * inv_m);
-  if (dres) dres[r * dres_cs + dres_coff + c] += g;
+  const int cv = C / VEC;
+  const int c = (int)(idx % cv) * VEC;
+  const long r = idx / cv;
+  float g[VEC], zv[VEC], o[VEC];
+  bn_g<VEC>(dy, dy_cs, dy_coff, y, y_cs, y_coff, r, THW, HW, rep, relu, c, g);
+  if (VEC == 4) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(z + r * z_cs + z_coff + c);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) zv[e] = v[e];
+  } else {
+    zv[0] = z[r * z_cs + z_coff + c];
+  }
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) {
+    const float is = invstd[c + e];
+    const float xh = (zv[e] - mean[c + e]) * is;
+    o[e] = gamma[c + e] * is * (g[e] - dbeta[c + e] * inv_m - xh * dgamma[c + e] * inv_m);
+  }
+  float* dp = dz + r * dz_cs + dz_coff + c;
+  if (VEC == 4) {
+    *reinterpret_cast<f32x4*>(dp) = (f32x4){o[0], o[1], o[2], o[3]};
+  } else {
+    dp[0] = o[0];
+  }
+  if (dres) {
+    float* rp = dres + r * dres_cs + dres_coff + c;
+    if (VEC == 4) {
+      f32x4 v = *reinterpret_cast<f32x4*>(rp);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] += g[e];
+      *reinterpret_cast<f32x4*>(rp) = v;
+    } else {
+      rp[0] += g[0];
+    }
+  }
 }
 
 // max-pool backward by equality gather: dx[p] += sum_{windows w containing p} dy[w] * [x[p] == y[w]]
@@ -228,7 +299,18 @@ __global__ void axpy_kernel(const float* __restrict__ a, int a_cs, int a_coff, f
 
 }  // namespace
 
-extern "C" long sf_bn_bwd_ws_floats(int C) { return (long)RED_P * 2 * C; }
+constexpr int MAX_P = 1024;
+// lanes per row (CB), rows per iteration and number of row blocks for a per-channel reduction
+static inline void red_geometry(long rows, int C, int vec, int* CB, int* P) {
+  const int cv = sf_cdiv(C, vec);
+  *CB = pow2ceil_b(cv) < TPB ? pow2ceil_b(cv) : TPB;
+  const int rpi = TPB / *CB;
+  long p = rows / ((long)rpi * 8);
+  if (p < 1) p = 1;
+  if (p > MAX_P) p = MAX_P;
+  *P = (int)p;
+}
+extern "C" long sf_bn_bwd_ws_floats(int C) { return (long)MAX_P * 2 * C; }
 
 extern "C" int sf_bn_bwd_reduce(const float* dy, int dy_cs, int dy_coff, const float* y, int y_cs, int y_coff,
                                 const float* z, int z_cs, int z_coff, int N, int T, int H, int W, int C, int rep,
@@ -237,11 +319,21 @@ extern "C" int sf_bn_bwd_reduce(const float* dy, int dy_cs, int dy_coff, const f
   if (!dy || !z || !mean || !invstd || !dbeta || !dgamma || !ws || (relu && !y)) return SF_EINVAL;
   if (N <= 0 || T <= 0 || H <= 0 || W <= 0 || C <= 0 || rep <= 0) return SF_EINVAL;
   const long rows = (long)N * T * H * W;
-  const int CB = pow2ceil_b(C) < TPB ? pow2ceil_b(C) : TPB;
-  hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(RED_P, sf_cdiv(C, CB)), dim3(TPB), 0, (hipStream_t)stream, dy, dy_cs,
-                     dy_coff, y, y_cs, y_coff, z, z_cs, z_coff, rows, (long)T, H * W, C, rep, relu, mean, invstd, CB,
-                     ws);
-  hipLaunchKernelGGL(pair_final_kernel, dim3(sf_cdiv(C, TPB)), dim3(TPB), 0, (hipStream_t)stream, ws, C, dbeta,
+  const bool vec4 = (C % 4 == 0) && (dy_cs % 4 == 0) && (dy_coff % 4 == 0) && (z_cs % 4 == 0) && (z_coff % 4 == 0) &&
+                    sf_aligned16(dy) && sf_aligned16(z) &&
+                    (!relu || ((y_cs % 4 == 0) && (y_coff % 4 == 0) && sf_aligned16(y)));
+  int CB, P;
+  red_geometry(rows, C, vec4 ? 4 : 1, &CB, &P);
+  const int ncb = sf_cdiv(sf_cdiv(C, vec4 ? 4 : 1), CB);
+  if (vec4)
+    hipLaunchKernelGGL(bn_bwd_partial_kernel<4>, dim3(P, ncb), dim3(TPB), 0, (hipStream_t)stream, dy, dy_cs, dy_coff,
+                       y, y_cs, y_coff, z, z_cs, z_coff, rows, (long)T * H * W, H * W, C, rep, relu, mean, invstd,
+                       CB, ws);
+  else
+    hipLaunchKernelGGL(bn_bwd_partial_kernel<1>, dim3(P, ncb), dim3(TPB), 0, (hipStream_t)stream, dy, dy_cs, dy_coff,
+                       y, y_cs, y_coff, z, z_cs, z_coff, rows, (long)T * H * W, H * W, C, rep, relu, mean, invstd,
+                       CB, ws);
+  hipLaunchKernelGGL(pair_final_kernel, dim3(sf_cdiv(C, TPB)), dim3(TPB), 0, (hipStream_t)stream, ws, C, P, dbeta,
                      dgamma);
   SF_CHECK_LAUNCH();
   return SF_OK;
@@ -255,10 +347,21 @@ extern "C" int sf_bn_bwd_apply(const float* dy, int dy_cs, int dy_coff, const fl
   if (!dy || !z || !mean || !invstd || !gamma || !dbeta || !dgamma || !dz || (relu && !y)) return SF_EINVAL;
   if (N <= 0 || T <= 0 || H <= 0 || W <= 0 || C <= 0 || rep <= 0) return SF_EINVAL;
   const long rows = (long)N * T * H * W;
-  const long total = rows * C;
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(sf_cdiv(total, TPB)), dim3(TPB), 0, (hipStream_t)stream, dy, dy_cs,
-                     dy_coff, y, y_cs, y_coff, z, z_cs, z_coff, rows, (long)T, H * W, C, rep, relu, mean, invstd,
-                     gamma, dbeta, dgamma, 1.0f / (float)rows, dz, dz_cs, dz_coff, dres, dres_cs, dres_coff, total);
+  const bool vec4 = (C % 4 == 0) && (dy_cs % 4 == 0) && (dy_coff % 4 == 0) && (z_cs % 4 == 0) && (z_coff % 4 == 0) &&
+                    (dz_cs % 4 == 0) && (dz_coff % 4 == 0) && sf_aligned16(dy) && sf_aligned16(z) && sf_aligned16(dz) &&
+                    (!relu || ((y_cs % 4 == 0) && (y_coff % 4 == 0) && sf_aligned16(y))) &&
+                    (!dres || ((dres_cs % 4 == 0) && (dres_coff % 4 == 0) && sf_aligned16(dres)));
+  const long total = rows * (vec4 ? C / 4 : C);
+  if (vec4)
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<4>, dim3(sf_cdiv(total, TPB)), dim3(TPB), 0, (hipStream_t)stream, dy, dy_cs,
+                       dy_coff, y, y_cs, y_coff, z, z_cs, z_coff, rows, (long)T * H * W, H * W, C, rep, relu, mean,
+                       invstd, gamma, dbeta, dgamma, 1.0f / (float)rows, dz, dz_cs, dz_coff, dres, dres_cs, dres_coff,
+                       total);
+  else
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<1>, dim3(sf_cdiv(total, TPB)), dim3(TPB), 0, (hipStream_t)stream, dy, dy_cs,
+                       dy_coff, y, y_cs, y_coff, z, z_cs, z_coff, rows, (long)T * H * W, H * W, C, rep, relu, mean,
+                       invstd, gamma, dbeta, dgamma, 1.0f / (float)rows, dz, dz_cs, dz_coff, dres, dres_cs, dres_coff,
+                       total);
   SF_CHECK_LAUNCH();
   return SF_OK;
 }

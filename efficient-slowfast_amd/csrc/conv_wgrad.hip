@@ -25,15 +25,18 @@ struct WgradArgs {
   long chunk;          // positions per split (multiple of 32)
 };
 
-constexpr int BM = 32;    // positions per stage
-constexpr int BC = 64;    // channels per tile side
-constexpr int LP = 80;    // LDS row pitch (dwords): consecutive rows land 16 banks apart
+constexpr int BM = 16;    // positions per stage
 
-template <int VEC>
+template <int BCO, int BCI, int VEC>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs p) {
-  __shared__ __attribute__((aligned(16))) float smem[2 * 2 * BM * LP];
-  float* const Zs = smem;                 // [2][BM][LP]  dz tile
-  float* const Xs = smem + 2 * BM * LP;   // [2][BM][LP]  x tile (gathered for this tap)
+  constexpr int LPZ = BCO + 16;   // LDS row pitches (dwords): consecutive rows land 16 banks apart
+  constexpr int LPX = BCI + 16;
+  constexpr int TM = BCO / 32, TN = BCI / 32;        // 16x16 MFMA tiles per wave (2 x 2 waves)
+  constexpr int ZF = BCO / 4, XF = BCI / 4;          // float4 per tile row
+  constexpr int ZIT = (BM * ZF + 255) / 256, XIT = (BM * XF + 255) / 256;
+  __shared__ __attribute__((aligned(16))) float smem[2 * BM * (LPZ + LPX)];
+  float* const Zs = smem;                  // [2][BM][LPZ]  dz tile
+  float* const Xs = smem + 2 * BM * LPZ;   // [2][BM][LPX]  x tile (gathered for this tap)
 
   const sf_conv_desc& d = p.d;
   const int tid = threadIdx.x;
@@ -42,7 +45,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs p) {
   tile /= p.ntaps;
   const int tci = tile % p.nb_ci;
   const int tco = tile / p.nb_ci;
-  const int co0 = tco * BC, ci0 = tci * BC;
+  const int co0 = tco * BCO, ci0 = tci * BCI;
   const int split = blockIdx.y;
   const long m_begin = (long)split * p.chunk;
   const long m_end = (m_begin + p.chunk < p.M) ? m_begin + p.chunk : p.M;
@@ -51,17 +54,15 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs p) {
   const int kh = (tap / d.kW) % d.kH;
   const int kt = tap / (d.kW * d.kH);
 
-  // staging role: thread owns float4 column lc of rows lr and lr + 16 (2 x 16 rows x 16 float4)
-  const int lr = tid >> 4;
-  const int lc = (tid & 15) * 4;
-  f32x4 rz[2], rx[2];
+  f32x4 rz[ZIT], rx[XIT];
   auto load_stage = [&](long mb) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const long m = mb + lr + 16 * i;
-      f32x4 vz = {0.f, 0.f, 0.f, 0.f}, vx = {0.f, 0.f, 0.f, 0.f};
-      if (m < m_end) {
-        // dz row
+    for (int i = 0; i < ZIT; ++i) {
+      const int f = tid + i * 256;
+      const int lr = f / ZF, lc = (f - lr * ZF) * 4;
+      const long m = mb + lr;
+      f32x4 vz = {0.f, 0.f, 0.f, 0.f};
+      if (f < BM * ZF && m < m_end) {
         const float* zp = p.dz + m * p.dz_cs + p.dz_coff + co0 + lc;
         if (VEC == 4) {
           if (co0 + lc < d.Cout) vz = *reinterpret_cast<const f32x4*>(zp);
@@ -70,7 +71,16 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs p) {
           for (int e = 0; e < 4; ++e)
             if (co0 + lc + e < d.Cout) vz[e] = zp[e];
         }
-        // x row of this tap
+      }
+      rz[i] = vz;
+    }
+#pragma unroll
+    for (int i = 0; i < XIT; ++i) {
+      const int f = tid + i * 256;
+      const int lr = f / XF, lc = (f - lr * XF) * 4;
+      const long m = mb + lr;
+      f32x4 vx = {0.f, 0.f, 0.f, 0.f};
+      if (f < BM * XF && m < m_end) {
         const int wo = (int)(m % d.Wo);
         const long t1 = m / d.Wo;
         const int ho = (int)(t1 % d.Ho);
@@ -91,27 +101,33 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs p) {
           }
         }
       }
-      rz[i] = vz;
       rx[i] = vx;
     }
   };
   auto store_stage = [&](int buf) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      *reinterpret_cast<f32x4*>(Zs + (buf * BM + lr + 16 * i) * LP + lc) = rz[i];
-      *reinterpret_cast<f32x4*>(Xs + (buf * BM + lr + 16 * i) * LP + lc) = rx[i];
+    for (int i = 0; i < ZIT; ++i) {
+      const int f = tid + i * 256;
+      const int lr = f / ZF, lc = (f - lr * ZF) * 4;
+      if (f < BM * ZF) *reinterpret_cast<f32x4*>(Zs + (buf * BM + lr) * LPZ + lc) = rz[i];
+    }
+#pragma unroll
+    for (int i = 0; i < XIT; ++i) {
+      const int f = tid + i * 256;
+      const int lr = f / XF, lc = (f - lr * XF) * 4;
+      if (f < BM * XF) *reinterpret_cast<f32x4*>(Xs + (buf * BM + lr) * LPX + lc) = rx[i];
     }
   };
 
   const int lane = tid & 63;
   const int wave = tid >> 6;
-  const int wco = (wave >> 1) * 32, wci = (wave & 1) * 32;
+  const int wco = (wave >> 1) * (BCO / 2), wci = (wave & 1) * (BCI / 2);
   const int fr = lane & 15, fg = lane >> 4;
-  f32x4 acc[2][2];
+  f32x4 acc[TM][TN];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   const long nst = (m_end > m_begin) ? (m_end - m_begin + BM - 1) / BM : 0;
   if (nst > 0) {
@@ -123,19 +139,19 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs p) {
     const int buf = (int)(st & 1);
     const bool more = (st + 1) < nst;
     if (more) load_stage(m_begin + (st + 1) * BM);
-    const float* zs = Zs + (buf * BM + fg) * LP + wco + fr;
-    const float* xs = Xs + (buf * BM + fg) * LP + wci + fr;
+    const float* zs = Zs + (buf * BM + fg) * LPZ + wco + fr;
+    const float* xs = Xs + (buf * BM + fg) * LPX + wci + fr;
 #pragma unroll
     for (int s = 0; s < BM / 4; ++s) {
-      float a[2], b[2];
+      float a[TM], b[TN];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) a[i] = zs[(4 * s) * LP + 16 * i];
+      for (int i = 0; i < TM; ++i) a[i] = zs[(4 * s) * LPZ + 16 * i];
 #pragma unroll
-      for (int j = 0; j < 2; ++j) b[j] = xs[(4 * s) * LP + 16 * j];
+      for (int j = 0; j < TN; ++j) b[j] = xs[(4 * s) * LPX + 16 * j];
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < TN; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
     }
     if (more) store_stage(buf ^ 1);
@@ -145,9 +161,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs p) {
   // partial tile: rows co = .. + 4*fg + r, cols ci = .. + fr
   float* const base = p.part + (long)split * d.Cout * p.ntaps * d.cin_pad;
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < TN; ++j) {
       const int ci = ci0 + wci + 16 * j + fr;
       if (ci >= d.cin_pad) continue;
 #pragma unroll
@@ -158,15 +174,36 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs p) {
     }
 }
 
+// tile shape for a problem: 128 on a side only when that side has >= 128 channels
+static inline void wgrad_tile(const sf_conv_desc* d, int* bco, int* bci) {
+  *bco = d->Cout >= 128 ? 128 : 64;
+  *bci = d->Cin >= 128 ? 128 : 64;
+}
+
+template <int BCO, int BCI>
+static int launch_wgrad(WgradArgs a, bool vec4, hipStream_t s) {
+  a.nb_co = sf_cdiv(a.d.Cout, BCO);
+  a.nb_ci = sf_cdiv(a.d.Cin, BCI);
+  dim3 grid(a.nb_co * a.nb_ci * a.ntaps, a.S);
+  if (vec4)
+    hipLaunchKernelGGL((conv_wgrad_kernel<BCO, BCI, 4>), grid, dim3(256), 0, s, a);
+  else
+    hipLaunchKernelGGL((conv_wgrad_kernel<BCO, BCI, 1>), grid, dim3(256), 0, s, a);
+  SF_CHECK_LAUNCH();
+  return SF_OK;
+}
+
 }  // namespace
 
 // Number of position splits the kernel will use for this problem (the caller sizes the workspace with it).
 extern "C" int sf_conv_wgrad_splits(const sf_conv_desc* d) {
   if (!d) return 0;
+  int bco, bci;
+  wgrad_tile(d, &bco, &bci);
   const long M = (long)d->N * d->To * d->Ho * d->Wo;
-  const long tiles = (long)sf_cdiv(d->Cout, BC) * sf_cdiv(d->Cin, BC) * d->kT * d->kH * d->kW;
-  long S = (2048 + tiles - 1) / tiles;            // aim at ~2048 workgroups (8 per CU)
-  const long maxS = (M + 4 * BM - 1) / (4 * BM);  // at least 128 positions per split
+  const long tiles = (long)sf_cdiv(d->Cout, bco) * sf_cdiv(d->Cin, bci) * d->kT * d->kH * d->kW;
+  long S = (1536 + tiles - 1) / tiles;            // aim at ~1536 workgroups (6 per CU)
+  const long maxS = (M + 8 * BM - 1) / (8 * BM);  // at least 128 positions per split
   if (S > maxS) S = maxS;
   if (S < 1) S = 1;
   if (S > 1024) S = 1024;
@@ -185,16 +222,15 @@ extern "C" int sf_conv_wgrad(const sf_conv_desc* d, const float* x, const float*
   a.M = (int)M;
   a.ntaps = d->kT * d->kH * d->kW;
   a.S = sf_conv_wgrad_splits(d);
-  a.nb_co = sf_cdiv(d->Cout, BC);
-  a.nb_ci = sf_cdiv(d->Cin, BC);
+  a.nb_co = a.nb_ci = 0;
   a.chunk = ((M + a.S - 1) / a.S + BM - 1) / BM * BM;
   const bool vec4 = (d->Cin % 4 == 0) && (d->in_cs % 4 == 0) && (d->in_coff % 4 == 0) && sf_aligned16(x) &&
                     (d->Cout % 4 == 0) && (dz_cs % 4 == 0) && (dz_coff % 4 == 0) && sf_aligned16(dz);
-  dim3 grid(a.nb_co * a.nb_ci * a.ntaps, a.S);
-  if (vec4)
-    hipLaunchKernelGGL(conv_wgrad_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, a);
-  else
-    hipLaunchKernelGGL(conv_wgrad_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, a);
-  SF_CHECK_LAUNCH();
-  return SF_OK;
+  int bco, bci;
+  wgrad_tile(d, &bco, &bci);
+  hipStream_t s = (hipStream_t)stream;
+  if (bco == 128 && bci == 128) return launch_wgrad<128, 128>(a, vec4, s);
+  if (bco == 128) return launch_wgrad<128, 64>(a, vec4, s);
+  if (bci == 128) return launch_wgrad<64, 128>(a, vec4, s);
+  return launch_wgrad<64, 64>(a, vec4, s);
 }

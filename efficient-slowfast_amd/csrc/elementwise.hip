@@ -309,45 +309,63 @@ __global__ void copy_channels_kernel(const float* __restrict__ in, int in_cs, in
 
 // ------------------------------------------------------------------------------------------------
 // Training-mode BN statistics: partial[blk][{sum,sumsq}][c] over the block's rows (fp32), combined in fp64.
-constexpr int STAT_P = 128;
+constexpr int STAT_MAX_P = 1024;
 
+template <int VEC>
 __global__ void stats_partial_kernel(const float* __restrict__ x, int cs, int coff, long rows, int C, int CB,
                                      float* __restrict__ partial) {
-  __shared__ float red[2 * TPB];
-  const int blk = blockIdx.x, cb = blockIdx.y;
+  __shared__ float red[2 * TPB * VEC];
+  const int blk = blockIdx.x, cb = blockIdx.y, P = gridDim.x;
   const int cl = threadIdx.x % CB, rl = threadIdx.x / CB, rpi = TPB / CB;
-  const int c = cb * CB + cl;
-  const long per = (rows + STAT_P - 1) / STAT_P;
+  const int c = (cb * CB + cl) * VEC;
+  const long per = (rows + P - 1) / P;
   const long r0 = (long)blk * per;
   const long r1 = (r0 + per < rows) ? r0 + per : rows;
-  float s1 = 0.f, s2 = 0.f;
+  float s1[VEC], s2[VEC];
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
   if (c < C) {
     for (long r = r0 + rl; r < r1; r += rpi) {
-      const float v = x[r * cs + coff + c];
-      s1 += v;
-      s2 = fmaf(v, v, s2);
+      if (VEC == 4) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(x + r * cs + coff + c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          s1[e] += v[e];
+          s2[e] = fmaf(v[e], v[e], s2[e]);
+        }
+      } else {
+        const float v = x[r * cs + coff + c];
+        s1[0] += v;
+        s2[0] = fmaf(v, v, s2[0]);
+      }
     }
   }
-  red[threadIdx.x] = s1;
-  red[TPB + threadIdx.x] = s2;
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) {
+    red[threadIdx.x * VEC + e] = s1[e];
+    red[(TPB + threadIdx.x) * VEC + e] = s2[e];
+  }
   __syncthreads();
   if (rl == 0 && c < C) {
-    float t1 = 0.f, t2 = 0.f;
-    for (int i = 0; i < rpi; ++i) {
-      t1 += red[i * CB + cl];
-      t2 += red[TPB + i * CB + cl];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      float t1 = 0.f, t2 = 0.f;
+      for (int i = 0; i < rpi; ++i) {
+        t1 += red[(i * CB + cl) * VEC + e];
+        t2 += red[(TPB + i * CB + cl) * VEC + e];
+      }
+      partial[((long)blk * 2 + 0) * C + c + e] = t1;
+      partial[((long)blk * 2 + 1) * C + c + e] = t2;
     }
-    partial[((long)blk * 2 + 0) * C + c] = t1;
-    partial[((long)blk * 2 + 1) * C + c] = t2;
   }
 }
 
-__global__ void stats_final_kernel(const float* __restrict__ partial, int C, double inv_rows,
+__global__ void stats_final_kernel(const float* __restrict__ partial, int C, int P, double inv_rows,
                                    float* __restrict__ mean, float* __restrict__ var) {
   const int c = blockIdx.x * TPB + threadIdx.x;
   if (c >= C) return;
   double s1 = 0.0, s2 = 0.0;
-  for (int i = 0; i < STAT_P; ++i) {
+  for (int i = 0; i < P; ++i) {
     s1 += (double)partial[((long)i * 2 + 0) * C + c];
     s2 += (double)partial[((long)i * 2 + 1) * C + c];
   }
@@ -513,15 +531,24 @@ extern "C" int sf_gate_apply(const float* x, int cs, int coff, int N, int T, int
 }
 
 
-extern "C" long sf_channel_stats_ws_floats(int C) { return (long)STAT_P * 2 * C; }
+extern "C" long sf_channel_stats_ws_floats(int C) { return (long)STAT_MAX_P * 2 * C; }
 
 extern "C" int sf_channel_stats(const float* x, int cs, int coff, long rows, int C, float* mean, float* var,
                                 float* ws, void* stream) {
   if (!x || !mean || !var || !ws || rows <= 0 || C <= 0) return SF_EINVAL;
-  const int CB = pow2ceil(C) < TPB ? pow2ceil(C) : TPB;
-  hipLaunchKernelGGL(stats_partial_kernel, dim3(STAT_P, sf_cdiv(C, CB)), dim3(TPB), 0, (hipStream_t)stream, x, cs,
-                     coff, rows, C, CB, ws);
-  hipLaunchKernelGGL(stats_final_kernel, dim3(sf_cdiv(C, TPB)), dim3(TPB), 0, (hipStream_t)stream, ws, C,
+  const bool vec4 = (C % 4 == 0) && (cs % 4 == 0) && (coff % 4 == 0) && sf_aligned16(x);
+  const int cv = sf_cdiv(C, vec4 ? 4 : 1);
+  const int CB = pow2ceil(cv) < TPB ? pow2ceil(cv) : TPB;
+  const int rpi = TPB / CB;
+  long p = rows / ((long)rpi * 8);
+  const int P = (int)(p < 1 ? 1 : (p > STAT_MAX_P ? STAT_MAX_P : p));
+  if (vec4)
+    hipLaunchKernelGGL(stats_partial_kernel<4>, dim3(P, sf_cdiv(cv, CB)), dim3(TPB), 0, (hipStream_t)stream, x, cs,
+                       coff, rows, C, CB, ws);
+  else
+    hipLaunchKernelGGL(stats_partial_kernel<1>, dim3(P, sf_cdiv(cv, CB)), dim3(TPB), 0, (hipStream_t)stream, x, cs,
+                       coff, rows, C, CB, ws);
+  hipLaunchKernelGGL(stats_final_kernel, dim3(sf_cdiv(C, TPB)), dim3(TPB), 0, (hipStream_t)stream, ws, C, P,
                      1.0 / (double)rows, mean, var);
   SF_CHECK_LAUNCH();
   return SF_OK;
