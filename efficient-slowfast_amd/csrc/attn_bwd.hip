@@ -27,7 +27,6 @@ struct BwdArgs {
   int B, C, N, nt;
 };
 
-constexpr float NEG_BIG = -3.0e38f;
 constexpr float POS_BIG = 3.0e38f;
 constexpr float LOG2E = 1.4426950408889634f;
 

@@ -112,15 +112,27 @@ __global__ void bn_bwd_partial_kernel(const float* __restrict__ dy, int dy_cs, i
 
 __global__ void pair_final_kernel(const float* __restrict__ partial, int C, int P, float* __restrict__ o1,
                                   float* __restrict__ o2) {
-  const int c = blockIdx.x * TPB + threadIdx.x;
-  if (c >= C) return;
+  __shared__ double r1[64], r2[64];
+  const int c = blockIdx.x;
   double s1 = 0.0, s2 = 0.0;
-  for (int i = 0; i < P; ++i) {
+  for (int i = threadIdx.x; i < P; i += 64) {
     s1 += (double)partial[((long)i * 2 + 0) * C + c];
     s2 += (double)partial[((long)i * 2 + 1) * C + c];
   }
-  o1[c] = (float)s1;
-  o2[c] = (float)s2;
+  r1[threadIdx.x] = s1;
+  r2[threadIdx.x] = s2;
+  __syncthreads();
+  for (int s = 32; s > 0; s >>= 1) {
+    if (threadIdx.x < s) {
+      r1[threadIdx.x] += r1[threadIdx.x + s];
+      r2[threadIdx.x] += r2[threadIdx.x + s];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    o1[c] = (float)r1[0];
+    o2[c] = (float)r2[0];
+  }
 }
 
 // dz = gamma*invstd * (g - dbeta/M - xhat*dgamma/M)   [written to dz, may alias z];   dres += g
@@ -333,8 +345,7 @@ extern "C" int sf_bn_bwd_reduce(const float* dy, int dy_cs, int dy_coff, const f
     hipLaunchKernelGGL(bn_bwd_partial_kernel<1>, dim3(P, ncb), dim3(TPB), 0, (hipStream_t)stream, dy, dy_cs, dy_coff,
                        y, y_cs, y_coff, z, z_cs, z_coff, rows, (long)T * H * W, H * W, C, rep, relu, mean, invstd,
                        CB, ws);
-  hipLaunchKernelGGL(pair_final_kernel, dim3(sf_cdiv(C, TPB)), dim3(TPB), 0, (hipStream_t)stream, ws, C, P, dbeta,
-                     dgamma);
+  hipLaunchKernelGGL(pair_final_kernel, dim3(C), dim3(64), 0, (hipStream_t)stream, ws, C, P, dbeta, dgamma);
   SF_CHECK_LAUNCH();
   return SF_OK;
 }

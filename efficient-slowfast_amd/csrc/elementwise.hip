@@ -360,19 +360,49 @@ __global__ void stats_partial_kernel(const float* __restrict__ x, int cs, int co
   }
 }
 
-__global__ void stats_final_kernel(const float* __restrict__ partial, int C, int P, double inv_rows,
-                                   float* __restrict__ mean, float* __restrict__ var) {
-  const int c = blockIdx.x * TPB + threadIdx.x;
-  if (c >= C) return;
+// One 64-lane block per channel: lanes stride over the P partials in fp64, tree-reduce through LDS.  With
+// BN parameters given it also emits the normalisation affine and updates the running statistics in place
+// (nn.BatchNorm3d training semantics: biased variance to normalise, unbiased for running_var).
+__global__ void stats_final_kernel(const float* __restrict__ partial, int C, int P, double inv_rows, double unbias,
+                                   float* __restrict__ mean, float* __restrict__ var,
+                                   const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                   float momentum, float* __restrict__ run_mean, float* __restrict__ run_var,
+                                   float* __restrict__ invstd, float* __restrict__ scale, float* __restrict__ shift) {
+  __shared__ double r1[64], r2[64];
+  const int c = blockIdx.x;
   double s1 = 0.0, s2 = 0.0;
-  for (int i = 0; i < P; ++i) {
+  for (int i = threadIdx.x; i < P; i += 64) {
     s1 += (double)partial[((long)i * 2 + 0) * C + c];
     s2 += (double)partial[((long)i * 2 + 1) * C + c];
   }
-  const double m = s1 * inv_rows;
-  double v = s2 * inv_rows - m * m;
-  mean[c] = (float)m;
-  var[c] = (float)(v > 0.0 ? v : 0.0);
+  r1[threadIdx.x] = s1;
+  r2[threadIdx.x] = s2;
+  __syncthreads();
+  for (int s = 32; s > 0; s >>= 1) {
+    if (threadIdx.x < s) {
+      r1[threadIdx.x] += r1[threadIdx.x + s];
+      r2[threadIdx.x] += r2[threadIdx.x + s];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const double m = r1[0] * inv_rows;
+    double v = r2[0] * inv_rows - m * m;
+    if (v < 0.0) v = 0.0;
+    mean[c] = (float)m;
+    var[c] = (float)v;
+    if (gamma) {
+      const float is = (float)(1.0 / sqrt(v + (double)eps));
+      const float sc = gamma[c] * is;
+      invstd[c] = is;
+      scale[c] = sc;
+      shift[c] = beta[c] - (float)m * sc;
+      if (run_mean) {
+        run_mean[c] = (1.f - momentum) * run_mean[c] + momentum * (float)m;
+        run_var[c] = (1.f - momentum) * run_var[c] + momentum * (float)(v * unbias);
+      }
+    }
+  }
 }
 
 // out[n, t*rep + r, hw, c] = act(x[n,t,hw,c] * scale[c] + bias[c] + res[n,t,hw,c])
@@ -533,9 +563,9 @@ extern "C" int sf_gate_apply(const float* x, int cs, int coff, int N, int T, int
 
 extern "C" long sf_channel_stats_ws_floats(int C) { return (long)STAT_MAX_P * 2 * C; }
 
-extern "C" int sf_channel_stats(const float* x, int cs, int coff, long rows, int C, float* mean, float* var,
-                                float* ws, void* stream) {
-  if (!x || !mean || !var || !ws || rows <= 0 || C <= 0) return SF_EINVAL;
+static int stats_launch(const float* x, int cs, int coff, long rows, int C, float* mean, float* var, float* ws,
+                        const float* gamma, const float* beta, float eps, float momentum, float* run_mean,
+                        float* run_var, float* invstd, float* scale, float* shift, hipStream_t s) {
   const bool vec4 = (C % 4 == 0) && (cs % 4 == 0) && (coff % 4 == 0) && sf_aligned16(x);
   const int cv = sf_cdiv(C, vec4 ? 4 : 1);
   const int CB = pow2ceil(cv) < TPB ? pow2ceil(cv) : TPB;
@@ -543,15 +573,34 @@ extern "C" int sf_channel_stats(const float* x, int cs, int coff, long rows, int
   long p = rows / ((long)rpi * 8);
   const int P = (int)(p < 1 ? 1 : (p > STAT_MAX_P ? STAT_MAX_P : p));
   if (vec4)
-    hipLaunchKernelGGL(stats_partial_kernel<4>, dim3(P, sf_cdiv(cv, CB)), dim3(TPB), 0, (hipStream_t)stream, x, cs,
-                       coff, rows, C, CB, ws);
+    hipLaunchKernelGGL(stats_partial_kernel<4>, dim3(P, sf_cdiv(cv, CB)), dim3(TPB), 0, s, x, cs, coff, rows, C, CB,
+                       ws);
   else
-    hipLaunchKernelGGL(stats_partial_kernel<1>, dim3(P, sf_cdiv(cv, CB)), dim3(TPB), 0, (hipStream_t)stream, x, cs,
-                       coff, rows, C, CB, ws);
-  hipLaunchKernelGGL(stats_final_kernel, dim3(sf_cdiv(C, TPB)), dim3(TPB), 0, (hipStream_t)stream, ws, C, P,
-                     1.0 / (double)rows, mean, var);
+    hipLaunchKernelGGL(stats_partial_kernel<1>, dim3(P, sf_cdiv(cv, CB)), dim3(TPB), 0, s, x, cs, coff, rows, C, CB,
+                       ws);
+  hipLaunchKernelGGL(stats_final_kernel, dim3(C), dim3(64), 0, s, ws, C, P, 1.0 / (double)rows,
+                     rows > 1 ? (double)rows / (double)(rows - 1) : 1.0, mean, var, gamma, beta, eps, momentum,
+                     run_mean, run_var, invstd, scale, shift);
   SF_CHECK_LAUNCH();
   return SF_OK;
+}
+
+extern "C" int sf_channel_stats(const float* x, int cs, int coff, long rows, int C, float* mean, float* var,
+                                float* ws, void* stream) {
+  if (!x || !mean || !var || !ws || rows <= 0 || C <= 0) return SF_EINVAL;
+  return stats_launch(x, cs, coff, rows, C, mean, var, ws, nullptr, nullptr, 0.f, 0.f, nullptr, nullptr, nullptr,
+                      nullptr, nullptr, (hipStream_t)stream);
+}
+
+extern "C" int sf_bn_train_stats(const float* x, int cs, int coff, long rows, int C, const float* gamma,
+                                 const float* beta, float eps, float momentum, float* run_mean, float* run_var,
+                                 float* mean, float* var, float* invstd, float* scale, float* shift, float* ws,
+                                 void* stream) {
+  if (!x || !gamma || !beta || !mean || !var || !invstd || !scale || !shift || !ws || rows <= 0 || C <= 0)
+    return SF_EINVAL;
+  if ((run_mean == nullptr) != (run_var == nullptr)) return SF_EINVAL;
+  return stats_launch(x, cs, coff, rows, C, mean, var, ws, gamma, beta, eps, momentum, run_mean, run_var, invstd,
+                      scale, shift, (hipStream_t)stream);
 }
 
 extern "C" int sf_affine_fwd(const float* x, int cs, int coff, int N, int T, int H, int W, int C,

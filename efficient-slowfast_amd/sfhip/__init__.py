@@ -40,7 +40,7 @@ class PoolDesc(ctypes.Structure):
 EXPORTS = [
     "sf_abi_version", "sf_build_arch", "sf_ncthw_to_ndhwc", "sf_ndhwc_to_ncthw", "sf_conv_fwd", "sf_dwconv_fwd",
     "sf_pool_fwd", "sf_tmax_mean_ws_floats", "sf_tmax_mean", "sf_gate_apply", "sf_attn_fwd", "sf_head_act_mean",
-    "sf_copy_channels", "sf_channel_stats_ws_floats", "sf_channel_stats", "sf_affine_fwd",
+    "sf_copy_channels", "sf_channel_stats_ws_floats", "sf_channel_stats", "sf_affine_fwd", "sf_bn_train_stats",
     "sf_conv_wgrad_splits", "sf_conv_wgrad", "sf_bn_bwd_ws_floats", "sf_bn_bwd_reduce", "sf_bn_bwd_apply",
     "sf_attn_bwd", "sf_maxpool_bwd", "sf_tmax_dot", "sf_eca_bwd_apply", "sf_bcast_add", "sf_rowdot", "sf_axpy",
 ]
@@ -79,6 +79,7 @@ def lib():
         L.sf_channel_stats_ws_floats.argtypes = [ci]
         L.sf_channel_stats_ws_floats.restype = cl
         L.sf_channel_stats.argtypes = [vp, ci, ci, cl, ci, vp, vp, vp, vp]
+        L.sf_bn_train_stats.argtypes = [vp, ci, ci, cl, ci, vp, vp, ctypes.c_float, ctypes.c_float] + [vp] * 9
         L.sf_affine_fwd.argtypes = [vp, ci, ci] + [ci] * 5 + [vp, vp, vp, ci, ci, ci, ci, vp, ci, ci, ci, vp]
         cf = ctypes.c_float
         L.sf_conv_wgrad_splits.argtypes = [ctypes.POINTER(ConvDesc)]
@@ -500,3 +501,16 @@ def attention_bwd(q, k, v, dz, o, lse, gamma, dq, dk, dv):
         base(q), q.cs, base(k), k.cs, base(v), v.cs, base(dz), dz.cs, _ptr(lse), _ptr(dvec),
         _ptr(gamma), base(dq), dq.cs, base(dk), dk.cs, base(dv), dv.cs, B, n, C, _stream())), "sf_attn_bwd")
     return dvec
+
+
+def bn_train_stats(x, gamma, beta, eps, momentum, run_mean, run_var):
+    """Training BN statistics of the view + scale/shift + in-place running-stat update in two launches.
+    Returns (mean, invstd, scale, shift)."""
+    _require_gpu(x.buf, "bn_train_stats")
+    dev = x.buf.device
+    o = torch.empty((5, x.C), dtype=torch.float32, device=dev)
+    ws = torch.empty((lib().sf_channel_stats_ws_floats(x.C),), dtype=torch.float32, device=dev)
+    _check(lib().sf_bn_train_stats(x.ptr(), x.cs, x.coff, x.rows, x.C, _ptr(gamma), _ptr(beta), float(eps),
+                                   float(momentum), _ptr(run_mean), _ptr(run_var), _ptr(o[0]), _ptr(o[1]),
+                                   _ptr(o[2]), _ptr(o[3]), _ptr(o[4]), _ptr(ws), _stream()), "sf_bn_train_stats")
+    return o[0], o[2], o[3], o[4]

@@ -161,16 +161,13 @@ def bn_train_apply(bn, z, res=None, relu=False, rep=1, out=None, out_reserve=(0,
     """Training-mode BatchNorm3d on the raw tensor z: batch statistics (sf_channel_stats), running-stat update
     (momentum, unbiased variance — torch semantics), then ONE normalise(+residual)(+ReLU)(+T-repeat) pass."""
     check_bn(bn)
-    mean, var = sfhip.channel_stats(z)
+    track = bn.track_running_stats and bn.running_mean is not None
+    m = bn.momentum if bn.momentum is not None else 1.0 / float(int(bn.num_batches_tracked) + 1)
     with torch.no_grad():
-        invstd = torch.rsqrt(var + bn.eps)
-        scale = bn.weight * invstd
-        shift = bn.bias - mean * scale
-        if bn.track_running_stats and bn.running_mean is not None:
-            n = z.rows
-            m = bn.momentum if bn.momentum is not None else 1.0 / float(int(bn.num_batches_tracked) + 1)
-            bn.running_mean.mul_(1.0 - m).add_(mean, alpha=m)
-            bn.running_var.mul_(1.0 - m).add_(var, alpha=m * n / max(n - 1, 1))
+        mean, invstd, scale, shift = sfhip.bn_train_stats(
+            z, bn.weight, bn.bias, bn.eps, m, bn.running_mean if track else None, bn.running_var if track else None)
+        if track:  # the kernel wrote the running buffers in place: drop the folded eval-mode affine cache
+            bn.__dict__.pop("_sf_affine", None)
             bn.num_batches_tracked.add_(1)
     zz = z if keep is None else z.slice(0, keep)
     if keep is not None:

@@ -132,6 +132,11 @@ int sf_attn_bwd(const float* q, int q_cs, const float* k, int k_cs, const float*
 long sf_channel_stats_ws_floats(int C);
 int sf_channel_stats(const float* x, int cs, int coff, long rows, int C, float* mean, float* var, float* ws,
                      void* stream);
+/* Statistics + everything parameter-sized in one call: mean/var/invstd, scale = gamma*invstd,
+ * shift = beta - mean*scale, and the in-place running_mean / running_var update (momentum, unbiased var). */
+int sf_bn_train_stats(const float* x, int cs, int coff, long rows, int C, const float* gamma, const float* beta,
+                      float eps, float momentum, float* run_mean, float* run_var, float* mean, float* var,
+                      float* invstd, float* scale, float* shift, float* ws, void* stream);
 int sf_affine_fwd(const float* x, int cs, int coff, int N, int T, int H, int W, int C, const float* scale,
                   const float* bias, const float* res, int res_cs, int res_coff, int act, int rep, float* out,
                   int out_cs, int out_coff, int out_cmul, void* stream);
