@@ -174,10 +174,182 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs p) {
     }
 }
 
+
+// Small-channel variant (Cout <= 32 or Cin <= 32: the Fast pathway, lateral / q|k|v projections, the stems):
+// a 128-wide tile would be > 90 % padding there.  Tile BCO x BCI in {16, 32}^2; the four wavefronts split
+// the POSITIONS of each 64-row stage (16 each) and their accumulators are summed through LDS at the end.
+constexpr int BMS = 64;
+template <int BCO, int BCI, int VEC>
+__global__ __launch_bounds__(256) void conv_wgrad_small_kernel(const WgradArgs p) {
+  constexpr int LPZ = (BCO == 16) ? 16 : 48;   // pitches = 16 (mod 32): rows g, g+1 hit disjoint bank halves
+  constexpr int LPX = (BCI == 16) ? 16 : 48;
+  constexpr int TM = BCO / 16, TN = BCI / 16;
+  constexpr int ZF = BCO / 4, XF = BCI / 4;
+  constexpr int ZIT = (BMS * ZF + 255) / 256, XIT = (BMS * XF + 255) / 256;
+  constexpr int STAGE = BMS * (LPZ + LPX);
+  constexpr int SMEM = (2 * STAGE > 4 * BCO * BCI) ? 2 * STAGE : 4 * BCO * BCI;
+  __shared__ __attribute__((aligned(16))) float smem[SMEM];
+  float* const Zs = smem;
+  float* const Xs = smem + 2 * BMS * LPZ;
+
+  const sf_conv_desc& d = p.d;
+  const int tid = threadIdx.x;
+  int tile = blockIdx.x;
+  const int tap = tile % p.ntaps;
+  tile /= p.ntaps;
+  const int tci = tile % p.nb_ci;
+  const int tco = tile / p.nb_ci;
+  const int co0 = tco * BCO, ci0 = tci * BCI;
+  const int split = blockIdx.y;
+  const long m_begin = (long)split * p.chunk;
+  const long m_end = (m_begin + p.chunk < p.M) ? m_begin + p.chunk : p.M;
+  const int kw = tap % d.kW;
+  const int kh = (tap / d.kW) % d.kH;
+  const int kt = tap / (d.kW * d.kH);
+
+  f32x4 rz[ZIT], rx[XIT];
+  auto load_stage = [&](long mb) {
+#pragma unroll
+    for (int i = 0; i < ZIT; ++i) {
+      const int f = tid + i * 256;
+      const int lr = f / ZF, lc = (f - lr * ZF) * 4;
+      const long m = mb + lr;
+      f32x4 vz = {0.f, 0.f, 0.f, 0.f};
+      if (f < BMS * ZF && m < m_end) {
+        const float* zp = p.dz + m * p.dz_cs + p.dz_coff + co0 + lc;
+        if (VEC == 4) {
+          if (co0 + lc < d.Cout) vz = *reinterpret_cast<const f32x4*>(zp);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (co0 + lc + e < d.Cout) vz[e] = zp[e];
+        }
+      }
+      rz[i] = vz;
+    }
+#pragma unroll
+    for (int i = 0; i < XIT; ++i) {
+      const int f = tid + i * 256;
+      const int lr = f / XF, lc = (f - lr * XF) * 4;
+      const long m = mb + lr;
+      f32x4 vx = {0.f, 0.f, 0.f, 0.f};
+      if (f < BMS * XF && m < m_end) {
+        const int wo = (int)(m % d.Wo);
+        const long t1 = m / d.Wo;
+        const int ho = (int)(t1 % d.Ho);
+        const long t2 = t1 / d.Ho;
+        const int to = (int)(t2 % d.To);
+        const int n = (int)(t2 / d.To);
+        const int ti = to * d.sT - d.pT + kt * d.dT;
+        const int hi = ho * d.sH - d.pH + kh * d.dH;
+        const int wi = wo * d.sW - d.pW + kw * d.dW;
+        if ((unsigned)ti < (unsigned)d.Ti && (unsigned)hi < (unsigned)d.Hi && (unsigned)wi < (unsigned)d.Wi) {
+          const float* xp = p.x + ((((long)n * d.Ti + ti) * d.Hi + hi) * d.Wi + wi) * d.in_cs + d.in_coff + ci0 + lc;
+          if (VEC == 4) {
+            if (ci0 + lc < d.Cin) vx = *reinterpret_cast<const f32x4*>(xp);
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (ci0 + lc + e < d.Cin) vx[e] = xp[e];
+          }
+        }
+      }
+      rx[i] = vx;
+    }
+  };
+  auto store_stage = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < ZIT; ++i) {
+      const int f = tid + i * 256;
+      const int lr = f / ZF, lc = (f - lr * ZF) * 4;
+      if (f < BMS * ZF) *reinterpret_cast<f32x4*>(Zs + (buf * BMS + lr) * LPZ + lc) = rz[i];
+    }
+#pragma unroll
+    for (int i = 0; i < XIT; ++i) {
+      const int f = tid + i * 256;
+      const int lr = f / XF, lc = (f - lr * XF) * 4;
+      if (f < BMS * XF) *reinterpret_cast<f32x4*>(Xs + (buf * BMS + lr) * LPX + lc) = rx[i];
+    }
+  };
+
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int fr = lane & 15, fg = lane >> 4;
+  f32x4 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const long nst = (m_end > m_begin) ? (m_end - m_begin + BMS - 1) / BMS : 0;
+  if (nst > 0) {
+    load_stage(m_begin);
+    store_stage(0);
+  }
+  __syncthreads();
+  for (long st = 0; st < nst; ++st) {
+    const int buf = (int)(st & 1);
+    const bool more = (st + 1) < nst;
+    if (more) load_stage(m_begin + (st + 1) * BMS);
+    const float* zs = Zs + (buf * BMS + wave * 16 + fg) * LPZ + fr;
+    const float* xs = Xs + (buf * BMS + wave * 16 + fg) * LPX + fr;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      float a[TM], b[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) a[i] = zs[(4 * s) * LPZ + 16 * i];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) b[j] = xs[(4 * s) * LPX + 16 * j];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    if (more) store_stage(buf ^ 1);
+    __syncthreads();
+  }
+  // cross-wave sum through LDS (the staging buffers are free after the last barrier)
+  float* const red = smem;  // [4][BCO][BCI]
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) red[(wave * BCO + 16 * i + 4 * fg + r) * BCI + 16 * j + fr] = acc[i][j][r];
+  __syncthreads();
+  float* const base = p.part + (long)split * d.Cout * p.ntaps * d.cin_pad;
+  for (int e = tid; e < BCO * BCI; e += 256) {
+    const int co = co0 + e / BCI, ci = ci0 + e % BCI;
+    if (co < d.Cout && ci < d.cin_pad) {
+      const float v = red[e] + red[BCO * BCI + e] + red[2 * BCO * BCI + e] + red[3 * BCO * BCI + e];
+      base[((long)co * p.ntaps + tap) * d.cin_pad + ci] = (ci < d.Cin) ? v : 0.f;
+    }
+  }
+}
+
 // tile shape for a problem: 128 on a side only when that side has >= 128 channels
 static inline void wgrad_tile(const sf_conv_desc* d, int* bco, int* bci) {
+  if (d->Cout <= 32 || d->Cin <= 32) {  // small-channel kernel
+    *bco = d->Cout <= 16 ? 16 : 32;
+    *bci = d->Cin <= 16 ? 16 : 32;
+    return;
+  }
   *bco = d->Cout >= 128 ? 128 : 64;
   *bci = d->Cin >= 128 ? 128 : 64;
+}
+
+template <int BCO, int BCI>
+static int launch_wgrad_small(WgradArgs a, bool vec4, hipStream_t s) {
+  a.nb_co = sf_cdiv(a.d.Cout, BCO);
+  a.nb_ci = sf_cdiv(a.d.cin_pad, BCI);   // cover the zero-padded packed width too
+  dim3 grid(a.nb_co * a.nb_ci * a.ntaps, a.S);
+  if (vec4)
+    hipLaunchKernelGGL((conv_wgrad_small_kernel<BCO, BCI, 4>), grid, dim3(256), 0, s, a);
+  else
+    hipLaunchKernelGGL((conv_wgrad_small_kernel<BCO, BCI, 1>), grid, dim3(256), 0, s, a);
+  SF_CHECK_LAUNCH();
+  return SF_OK;
 }
 
 template <int BCO, int BCI>
@@ -201,9 +373,10 @@ extern "C" int sf_conv_wgrad_splits(const sf_conv_desc* d) {
   int bco, bci;
   wgrad_tile(d, &bco, &bci);
   const long M = (long)d->N * d->To * d->Ho * d->Wo;
-  const long tiles = (long)sf_cdiv(d->Cout, bco) * sf_cdiv(d->Cin, bci) * d->kT * d->kH * d->kW;
+  const long tiles = (long)sf_cdiv(d->Cout, bco) * sf_cdiv(bco <= 32 ? d->cin_pad : d->Cin, bci) * d->kT * d->kH *
+                     d->kW;
   long S = (1536 + tiles - 1) / tiles;            // aim at ~1536 workgroups (6 per CU)
-  const long maxS = (M + 8 * BM - 1) / (8 * BM);  // at least 128 positions per split
+  const long maxS = (M + 255) / 256;              // at least 256 positions per split
   if (S > maxS) S = maxS;
   if (S < 1) S = 1;
   if (S > 1024) S = 1024;
@@ -223,12 +396,18 @@ extern "C" int sf_conv_wgrad(const sf_conv_desc* d, const float* x, const float*
   a.ntaps = d->kT * d->kH * d->kW;
   a.S = sf_conv_wgrad_splits(d);
   a.nb_co = a.nb_ci = 0;
-  a.chunk = ((M + a.S - 1) / a.S + BM - 1) / BM * BM;
+  a.chunk = ((M + a.S - 1) / a.S + BMS - 1) / BMS * BMS;
   const bool vec4 = (d->Cin % 4 == 0) && (d->in_cs % 4 == 0) && (d->in_coff % 4 == 0) && sf_aligned16(x) &&
                     (d->Cout % 4 == 0) && (dz_cs % 4 == 0) && (dz_coff % 4 == 0) && sf_aligned16(dz);
   int bco, bci;
   wgrad_tile(d, &bco, &bci);
   hipStream_t s = (hipStream_t)stream;
+  if (bco <= 32) {
+    if (bco == 16 && bci == 16) return launch_wgrad_small<16, 16>(a, vec4, s);
+    if (bco == 16) return launch_wgrad_small<16, 32>(a, vec4, s);
+    if (bci == 16) return launch_wgrad_small<32, 16>(a, vec4, s);
+    return launch_wgrad_small<32, 32>(a, vec4, s);
+  }
   if (bco == 128 && bci == 128) return launch_wgrad<128, 128>(a, vec4, s);
   if (bco == 128) return launch_wgrad<128, 64>(a, vec4, s);
   if (bci == 128) return launch_wgrad<64, 128>(a, vec4, s);
