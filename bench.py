@@ -71,10 +71,9 @@ def synthetic_clips(cfg, batch, device, seed):
     return [slow.to(device), fast.to(device)]
 
 
-def cpu_baseline(workload, cfg, model):
-    """The oracle on the host cores, batch 1 (dense attention needs ~6 GB per clip)."""
+def cpu_baseline(workload, cfg, model, train):
+    """The oracle on the host cores, batch 1 (dense attention needs ~6 GB per clip, ~3x that with autograd)."""
     from oracle import slowfast_oracle as oracle
-    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
     hp = oracle.default_hparams(
         alpha=cfg.SLOWFAST.ALPHA, beta_inv=cfg.SLOWFAST.BETA_INV, depth=cfg.RESNET.DEPTH,
         width_per_group=cfg.RESNET.WIDTH_PER_GROUP, num_groups=cfg.RESNET.NUM_GROUPS,
@@ -100,9 +99,20 @@ def cpu_baseline(workload, cfg, model):
         if best is None or dt < best[0]:
             best = (dt, threads)
     dt, threads = best
+    sample = "eval forward, batch 1; best of 16/32/64 threads, 1 warm-up + 1 timed each"
+    if train:  # one training iteration through torch autograd on the oracle's functional graph
+        torch.set_num_threads(threads)
+        sdr = {k: (v.clone().requires_grad_(True) if v.dtype == torch.float32 and "running" not in k else v)
+               for k, v in sd.items()}
+        label = torch.zeros(1, dtype=torch.long)
+        t0 = time.time()
+        acts = oracle.FORWARDS[name](sdr, [x.clone() for x in xs], hp, training=True)
+        torch.nn.functional.cross_entropy(acts["out"], label).backward()
+        dt = time.time() - t0
+        sample = "train-mode forward + CE + autograd backward, batch 1, %d threads (best of 16/32/64 on the " \
+                 "eval forward), 1 timed iteration" % threads
     return {"value": round(1.0 / dt, 4), "unit": "clips/s", "cores": threads, "kind": "port",
-            "sample": "oracle (torch CPU restatement of the reference) eval forward, batch 1, same model/"
-                      "clip shape; best of 16/32/64 threads, 1 warm-up + 1 timed each"}
+            "sample": "oracle (torch CPU restatement of the reference), same model / clip shape: " + sample}
 
 
 def main():
@@ -192,6 +202,34 @@ def main():
     barrier()
     elapsed = max_over_ranks(elapsed, device)
 
+    # ---- secondary: eval-mode forward (inference) clips/s of the same model, hipGraph replay
+    eval_fwd = None
+    if train:
+        model.eval()
+
+        def estep():
+            with torch.no_grad():
+                return model([clips[0], clips[1]])
+
+        with torch.cuda.stream(side):
+            estep()
+        torch.cuda.synchronize()
+        eg = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(eg, stream=side):
+            estep()
+        eg.replay()
+        barrier()
+        t1 = time.perf_counter()
+        with torch.cuda.stream(side):
+            for _ in range(args.steps):
+                eg.replay()
+        torch.cuda.synchronize()
+        et = max_over_ranks(time.perf_counter() - t1, device)
+        barrier()
+        eval_fwd = {"value": round(batch * world * args.steps / et, 3), "unit": "clips/s",
+                    "ms_per_step": round(et / args.steps * 1e3, 3), "launch": "hipGraph replay"}
+        model.train()
+
     # ---- dominant-kernel trace: HIP events around every attention launch (forward and backward) over a few
     #      eager steps on the stream the kernels run on
     roofline = None
@@ -209,17 +247,31 @@ def main():
         tag = max(tot, key=tot.get)
         kind, b, n, c = tag
         dur = float(np.mean(per[tag]))
-        # algorithmic FLOPs: forward = QK^T + PV = 2 products, backward = 5 products
-        # (S recompute, dP, dV, dQ, dK); each product 2*N^2*C FLOP per clip
-        nprod = 2 if kind == "attn" else 5
+        # algorithmic FLOPs, one product = 2*N^2*C FLOP per clip.  Forward: QK^T + PV = 2.
+        # Backward: 5 products in total (S recompute, dP, dV, dK, dQ); the two-kernel, atomic-free split
+        # re-derives S and dP in both kernels (7 executed), so each kernel is credited only its share of the 5:
+        # dK/dV kernel = dV + dK + half of (S, dP) = 3, dQ kernel = dQ + the other half = 2.
+        nprod = {"attn": 2, "attn_bwd_dkv": 3, "attn_bwd_dq": 2}[kind]
+        executed = {"attn": 2, "attn_bwd_dkv": 4, "attn_bwd_dq": 3}[kind]
         flops = nprod * 2.0 * b * n * n * c
         ach = flops / dur / 1e12
-        kname = "attn_fwd_kernel (flash SpatialAttention forward)" if kind == "attn" else \
-            "attn_bwd_dq_kernel + attn_bwd_dkv_kernel (flash SpatialAttention backward, one sf_attn_bwd call)"
+        kname = {"attn": "attn_fwd_kernel (flash SpatialAttention forward)",
+                 "attn_bwd_dkv": "attn_bwd_dkv_kernel (flash SpatialAttention backward, dK/dV)",
+                 "attn_bwd_dq": "attn_bwd_dq_kernel (flash SpatialAttention backward, dQ)"}[kind]
+        traffic = None  # HBM bytes per launch from the committed PMC passes (rocprofv3 cannot run inside bench.py)
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_attention_hbm_traffic.json")))["kernels"]
+            kkey = {"attn": "attn_fwd_kernel<32, 4>", "attn_bwd_dkv": "attn_bwd_dkv_kernel<32>",
+                    "attn_bwd_dq": "attn_bwd_dq_kernel<32>"}[kind]
+            if c == 32 and n == 25088 and b == 8:
+                traffic = tj[kkey]["hbm_bytes_per_launch"]
+        except (OSError, KeyError, ValueError):
+            traffic = None
         roofline = {"bound": "mfma", "kernel": "%s C=%d N=%d B=%d" % (kname, c, n, b),
                     "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "avg_launch_ms": round(dur * 1e3, 4),
-                    "launches_timed": len(per[tag]), "traffic": None}
+                    "launches_timed": len(per[tag]), "traffic": traffic,
+                    "executed_mfma_tflops": round(ach * executed / nprod, 2)}
 
     if rank == 0:
         clips_total = batch * world * args.steps
@@ -239,10 +291,12 @@ def main():
                            world, "one RCCL all-reduce of the flat fp32 gradient per step" if train
                            else "no data-path collective in forward")},
         }
+        if eval_fwd is not None:
+            res["eval_forward"] = eval_fwd
         if roofline is not None:
             res["roofline"] = roofline
         if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(args.workload, cfg, model)
+            res["cpu_baseline"] = cpu_baseline(args.workload, cfg, model, train)
         print(json.dumps(res))
     if world > 1:
         dist.destroy_process_group()

@@ -334,31 +334,32 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const BwdArgs p) {
 }
 
 template <int CP>
-int launch(const BwdArgs& a, hipStream_t s) {
+int launch(const BwdArgs& a, int which, hipStream_t s) {
   const int grid = a.B * a.nt;
-  hipLaunchKernelGGL((attn_bwd_dq_kernel<CP>), dim3(grid), dim3(256), 0, s, a);
-  hipLaunchKernelGGL((attn_bwd_dkv_kernel<CP>), dim3(grid), dim3(256), 0, s, a);
+  if (which & 1) hipLaunchKernelGGL((attn_bwd_dq_kernel<CP>), dim3(grid), dim3(256), 0, s, a);
+  if (which & 2) hipLaunchKernelGGL((attn_bwd_dkv_kernel<CP>), dim3(grid), dim3(256), 0, s, a);
   SF_CHECK_LAUNCH();
   return SF_OK;
 }
 
 }  // namespace
 
+// which: bit 0 = dQ kernel, bit 1 = dK/dV kernel (3 = both; separate launches let callers time them).
 extern "C" int sf_attn_bwd(const float* q, int q_cs, const float* k, int k_cs, const float* v, int v_cs,
                            const float* dz, int dz_cs, const float* lse, const float* dvec, const float* gamma,
                            float* dq, int dq_cs, float* dk, int dk_cs, float* dv, int dv_cs, int B, int N, int C,
-                           void* stream) {
+                           int which, void* stream) {
   if (!q || !k || !v || !dz || !lse || !dvec || !gamma || !dq || !dk || !dv) return SF_EINVAL;
-  if (B <= 0 || N <= 0 || C <= 0 || C > 128) return SF_EINVAL;
+  if (B <= 0 || N <= 0 || C <= 0 || C > 128 || (which & 3) == 0) return SF_EINVAL;
   BwdArgs a;
   a.q = q; a.k = k; a.v = v; a.dz = dz; a.lse = lse; a.dvec = dvec; a.gamma = gamma;
   a.dq = dq; a.dk = dk; a.dv = dv;
   a.q_cs = q_cs; a.k_cs = k_cs; a.v_cs = v_cs; a.dz_cs = dz_cs; a.dq_cs = dq_cs; a.dk_cs = dk_cs; a.dv_cs = dv_cs;
   a.B = B; a.C = C; a.N = N; a.nt = sf_cdiv(N, 128);
   hipStream_t s = (hipStream_t)stream;
-  if (C <= 8) return launch<8>(a, s);
-  if (C <= 16) return launch<16>(a, s);
-  if (C <= 32) return launch<32>(a, s);
-  if (C <= 64) return launch<64>(a, s);
-  return launch<128>(a, s);
+  if (C <= 8) return launch<8>(a, which, s);
+  if (C <= 16) return launch<16>(a, which, s);
+  if (C <= 32) return launch<32>(a, which, s);
+  if (C <= 64) return launch<64>(a, which, s);
+  return launch<128>(a, which, s);
 }

@@ -73,7 +73,7 @@ def lib():
         L.sf_tmax_mean.argtypes = [vp, ci, ci] + [ci] * 6 + [vp, vp, vp]
         L.sf_gate_apply.argtypes = [vp, ci, ci] + [ci] * 6 + [vp, vp, vp, vp, ci, vp, ci, ci, vp]
         L.sf_attn_fwd.argtypes = [vp, ci, vp, ci, vp, ci, vp, ci, vp, vp, vp, ci, vp, ci, ci] + [ci] * 6 + [vp, vp, vp]
-        L.sf_attn_bwd.argtypes = [vp, ci, vp, ci, vp, ci, vp, ci, vp, vp, vp, vp, ci, vp, ci, vp, ci, ci, ci, ci, vp]
+        L.sf_attn_bwd.argtypes = [vp, ci, vp, ci, vp, ci, vp, ci, vp, vp, vp, vp, ci, vp, ci, vp, ci, ci, ci, ci, ci, vp]
         L.sf_head_act_mean.argtypes = [vp, ci, ci, ci, ci, vp, vp]
         L.sf_copy_channels.argtypes = [vp, ci, ci, vp, ci, ci, ci, cl, ci, vp]
         L.sf_channel_stats_ws_floats.argtypes = [ci]
@@ -497,9 +497,11 @@ def attention_bwd(q, k, v, dz, o, lse, gamma, dq, dk, dv):
     def base(a):
         return ctypes.c_void_p(a.buf.data_ptr() + 4 * a.coff)
 
-    _check(_traced(("attn_bwd", B, n, C), lambda: lib().sf_attn_bwd(
-        base(q), q.cs, base(k), k.cs, base(v), v.cs, base(dz), dz.cs, _ptr(lse), _ptr(dvec),
-        _ptr(gamma), base(dq), dq.cs, base(dk), dk.cs, base(dv), dv.cs, B, n, C, _stream())), "sf_attn_bwd")
+    for which, tag in ((1, "attn_bwd_dq"), (2, "attn_bwd_dkv")):
+        _check(_traced((tag, B, n, C), lambda: lib().sf_attn_bwd(
+            base(q), q.cs, base(k), k.cs, base(v), v.cs, base(dz), dz.cs, _ptr(lse), _ptr(dvec),
+            _ptr(gamma), base(dq), dq.cs, base(dk), dk.cs, base(dv), dv.cs, B, n, C, which, _stream())),
+            "sf_attn_bwd")
     return dvec
 
 

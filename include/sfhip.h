@@ -122,7 +122,7 @@ int sf_attn_fwd(const float* q, int q_cs, const float* k, int k_cs, const float*
 int sf_attn_bwd(const float* q, int q_cs, const float* k, int k_cs, const float* v, int v_cs,
                 const float* dz, int dz_cs, const float* lse, const float* dvec, const float* gamma,
                 float* dq, int dq_cs, float* dk, int dk_cs, float* dv, int dv_cs, int B, int N, int C,
-                void* stream);
+                int which /* 1 = dQ kernel, 2 = dK/dV kernel, 3 = both */, void* stream);
 
 /* ---- training-mode BatchNorm3d forward pieces (batchnorm_helper.py:15-34 -> nn.BatchNorm3d, training=True)
  * sf_channel_stats: per-channel mean and BIASED variance over all rows of an NDHWC slice, reduced through
