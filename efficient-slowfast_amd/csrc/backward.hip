@@ -437,3 +437,146 @@ extern "C" int sf_axpy(const float* a, int a_cs, int a_coff, float alpha, float*
   SF_CHECK_LAUNCH();
   return SF_OK;
 }
+
+// ================================================================================================
+// Depthwise convolution backward (GhostNet / ShuffleNetV2) and strided channel gathers.
+namespace {
+
+// dx[p, c] += sum_taps dz[q(p, tap), c] * w[tap, c]   (transposed gather, one thread per (position, channel))
+__global__ void dwconv_dgrad_kernel(const sf_conv_desc d, const float* __restrict__ dz, int dz_cs, int dz_coff,
+                                    const float* __restrict__ w, float* __restrict__ dx, int dx_cs, int dx_coff,
+                                    int C, long total) {
+  const long idx = (long)blockIdx.x * TPB + threadIdx.x;
+  if (idx >= total) return;
+  const int c = (int)(idx % C);
+  long r = idx / C;
+  const long rin = r;
+  const int wi = (int)(r % d.Wi);
+  r /= d.Wi;
+  const int hi = (int)(r % d.Hi);
+  r /= d.Hi;
+  const int ti = (int)(r % d.Ti);
+  const int n = (int)(r / d.Ti);
+  float acc = 0.f;
+  int tap = 0;
+  for (int kt = 0; kt < d.kT; ++kt) {
+    const int nt = ti + d.pT - kt * d.dT;
+    for (int kh = 0; kh < d.kH; ++kh) {
+      const int nh = hi + d.pH - kh * d.dH;
+      for (int kw = 0; kw < d.kW; ++kw, ++tap) {
+        const int nw = wi + d.pW - kw * d.dW;
+        if (nt < 0 || nh < 0 || nw < 0 || (nt % d.sT) || (nh % d.sH) || (nw % d.sW)) continue;
+        const int to = nt / d.sT, ho = nh / d.sH, wo = nw / d.sW;
+        if (to >= d.To || ho >= d.Ho || wo >= d.Wo) continue;
+        const long ro = (((long)n * d.To + to) * d.Ho + ho) * d.Wo + wo;
+        acc = fmaf(dz[ro * dz_cs + dz_coff + c], w[(long)tap * d.cin_pad + c], acc);
+      }
+    }
+  }
+  dx[rin * dx_cs + dx_coff + c] += acc;
+}
+
+// dw[tap, c] = sum_m dz[m, c] * x[row(m, tap), c]: partial[blk][tap][c] over the block's output rows
+constexpr int DW_P = 256;
+__global__ void dwconv_wgrad_partial_kernel(const sf_conv_desc d, const float* __restrict__ x,
+                                            const float* __restrict__ dz, int dz_cs, int dz_coff, int C, int CB,
+                                            long rows, float* __restrict__ partial) {
+  __shared__ float red[TPB];
+  const int blk = blockIdx.x, cb = blockIdx.y;
+  const int cl = threadIdx.x % CB, rl = threadIdx.x / CB, rpi = TPB / CB;
+  const int c = cb * CB + cl;
+  const long per = (rows + DW_P - 1) / DW_P;
+  const long r0 = (long)blk * per;
+  const long r1 = (r0 + per < rows) ? r0 + per : rows;
+  const int ntaps = d.kT * d.kH * d.kW;
+  for (int tap = 0; tap < ntaps; ++tap) {
+    const int kw = tap % d.kW, kh = (tap / d.kW) % d.kH, kt = tap / (d.kW * d.kH);
+    float s = 0.f;
+    if (c < C) {
+      for (long m = r0 + rl; m < r1; m += rpi) {
+        const int wo = (int)(m % d.Wo);
+        const long t1 = m / d.Wo;
+        const int ho = (int)(t1 % d.Ho);
+        const long t2 = t1 / d.Ho;
+        const int to = (int)(t2 % d.To);
+        const int n = (int)(t2 / d.To);
+        const int ti = to * d.sT - d.pT + kt * d.dT;
+        const int hi = ho * d.sH - d.pH + kh * d.dH;
+        const int wi = wo * d.sW - d.pW + kw * d.dW;
+        if ((unsigned)ti >= (unsigned)d.Ti || (unsigned)hi >= (unsigned)d.Hi || (unsigned)wi >= (unsigned)d.Wi)
+          continue;
+        s = fmaf(dz[m * dz_cs + dz_coff + c],
+                 x[((((long)n * d.Ti + ti) * d.Hi + hi) * d.Wi + wi) * d.in_cs + d.in_coff + c], s);
+      }
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (rl == 0 && c < C) {
+      float tot = 0.f;
+      for (int i = 0; i < rpi; ++i) tot += red[i * CB + cl];
+      partial[((long)blk * ntaps + tap) * C + c] = tot;
+    }
+    __syncthreads();
+  }
+}
+
+__global__ void dwconv_wgrad_final_kernel(const float* __restrict__ partial, int n, float* __restrict__ out) {
+  const int i = blockIdx.x * TPB + threadIdx.x;  // i over ntaps*C
+  if (i >= n) return;
+  double s = 0.0;
+  for (int b = 0; b < DW_P; ++b) s += (double)partial[(long)b * n + i];
+  out[i] = (float)s;
+}
+
+// out[r, c] (+)= in[r, in_coff + c * in_cmul]   (backward of a channel-strided store / shuffle)
+__global__ void gather_add_kernel(const float* __restrict__ in, int in_cs, int in_coff, int in_cmul,
+                                  float* __restrict__ out, int out_cs, int out_coff, int C, int accumulate,
+                                  long total) {
+  const long idx = (long)blockIdx.x * TPB + threadIdx.x;
+  if (idx >= total) return;
+  const int c = (int)(idx % C);
+  const long r = idx / C;
+  const float v = in[r * in_cs + in_coff + (long)c * in_cmul];
+  float* o = out + r * out_cs + out_coff + c;
+  *o = accumulate ? *o + v : v;
+}
+
+}  // namespace
+
+extern "C" int sf_dwconv_dgrad(const sf_conv_desc* d, const float* dz, int dz_cs, int dz_coff, const float* w_packed,
+                               float* dx, int dx_cs, int dx_coff, int C, void* stream) {
+  if (!d || !dz || !w_packed || !dx || C <= 0) return SF_EINVAL;
+  const long total = (long)d->N * d->Ti * d->Hi * d->Wi * C;
+  hipLaunchKernelGGL(dwconv_dgrad_kernel, dim3(sf_cdiv(total, TPB)), dim3(TPB), 0, (hipStream_t)stream, *d, dz, dz_cs,
+                     dz_coff, w_packed, dx, dx_cs, dx_coff, C, total);
+  SF_CHECK_LAUNCH();
+  return SF_OK;
+}
+
+extern "C" long sf_dwconv_wgrad_ws_floats(const sf_conv_desc* d, int C) {
+  return d ? (long)DW_P * d->kT * d->kH * d->kW * C : 0;
+}
+
+extern "C" int sf_dwconv_wgrad(const sf_conv_desc* d, const float* x, const float* dz, int dz_cs, int dz_coff, int C,
+                               float* dw /* [taps][C] */, float* ws, void* stream) {
+  if (!d || !x || !dz || !dw || !ws || C <= 0) return SF_EINVAL;
+  const long rows = (long)d->N * d->To * d->Ho * d->Wo;
+  const int CB = pow2ceil_b(C) < TPB ? pow2ceil_b(C) : TPB;
+  const int ntaps = d->kT * d->kH * d->kW;
+  hipLaunchKernelGGL(dwconv_wgrad_partial_kernel, dim3(DW_P, sf_cdiv(C, CB)), dim3(TPB), 0, (hipStream_t)stream, *d, x,
+                     dz, dz_cs, dz_coff, C, CB, rows, ws);
+  hipLaunchKernelGGL(dwconv_wgrad_final_kernel, dim3(sf_cdiv(ntaps * C, TPB)), dim3(TPB), 0, (hipStream_t)stream, ws,
+                     ntaps * C, dw);
+  SF_CHECK_LAUNCH();
+  return SF_OK;
+}
+
+extern "C" int sf_gather_add(const float* in, int in_cs, int in_coff, int in_cmul, float* out, int out_cs,
+                             int out_coff, long rows, int C, int accumulate, void* stream) {
+  if (!in || !out || rows <= 0 || C <= 0 || in_cmul <= 0) return SF_EINVAL;
+  const long total = rows * C;
+  hipLaunchKernelGGL(gather_add_kernel, dim3(sf_cdiv(total, TPB)), dim3(TPB), 0, (hipStream_t)stream, in, in_cs, in_coff,
+                     in_cmul, out, out_cs, out_coff, C, accumulate, total);
+  SF_CHECK_LAUNCH();
+  return SF_OK;
+}

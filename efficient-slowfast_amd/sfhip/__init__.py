@@ -43,8 +43,10 @@ EXPORTS = [
     "sf_copy_channels", "sf_channel_stats_ws_floats", "sf_channel_stats", "sf_affine_fwd", "sf_bn_train_stats",
     "sf_conv_wgrad_splits", "sf_conv_wgrad", "sf_bn_bwd_ws_floats", "sf_bn_bwd_reduce", "sf_bn_bwd_apply",
     "sf_attn_bwd", "sf_maxpool_bwd", "sf_tmax_dot", "sf_eca_bwd_apply", "sf_bcast_add", "sf_rowdot", "sf_axpy",
+    "sf_dwconv_dgrad", "sf_dwconv_wgrad_ws_floats", "sf_dwconv_wgrad", "sf_gather_add",
 ]
-_LONG_RET = ("sf_tmax_mean_ws_floats", "sf_channel_stats_ws_floats", "sf_bn_bwd_ws_floats")
+_LONG_RET = ("sf_tmax_mean_ws_floats", "sf_channel_stats_ws_floats", "sf_bn_bwd_ws_floats",
+             "sf_dwconv_wgrad_ws_floats")
 
 
 def lib_path():
@@ -95,6 +97,11 @@ def lib():
         L.sf_bcast_add.argtypes = [vp, ci, ci, ci, cl, ci, vp, cf, vp]
         L.sf_rowdot.argtypes = [vp, ci, ci, vp, ci, ci, cl, ci, cf, vp, vp]
         L.sf_axpy.argtypes = [vp, ci, ci, cf, vp, ci, ci, cl, ci, ci, vp]
+        L.sf_dwconv_dgrad.argtypes = [ctypes.POINTER(ConvDesc), vp, ci, ci, vp, vp, ci, ci, ci, vp]
+        L.sf_dwconv_wgrad_ws_floats.argtypes = [ctypes.POINTER(ConvDesc), ci]
+        L.sf_dwconv_wgrad_ws_floats.restype = cl
+        L.sf_dwconv_wgrad.argtypes = [ctypes.POINTER(ConvDesc), vp, vp, ci, ci, ci, vp, vp, vp]
+        L.sf_gather_add.argtypes = [vp, ci, ci, ci, vp, ci, ci, cl, ci, ci, vp]
         for name in EXPORTS:
             fn = getattr(L, name)
             if name != "sf_build_arch" and name not in _LONG_RET:
@@ -425,11 +432,12 @@ def unpack_conv_weight_grad(dwp, shape):
     return dwp[:, :, :cin].permute(0, 2, 1).reshape(cout, cin, kT, kH, kW).contiguous()
 
 
-def bn_bwd(dy, y, z, mean, invstd, gamma, relu, rep=1, dres=None, dz_out=None):
+def bn_bwd(dy, y, z, mean, invstd, gamma, relu, rep=1, dres=None, dz_out=None, dgamma_out=None):
     """Training BN backward (+ReLU mask, + residual fan-out, + upsample-copy sum).  Returns (dz, dgamma, dbeta);
     dz is written over z unless dz_out is given."""
     C = z.C
     dev = z.buf.device
+    mean, invstd, gamma = mean.contiguous(), invstd.contiguous(), gamma.detach().contiguous()
     dbeta = torch.empty((C,), dtype=torch.float32, device=dev)
     dgamma = torch.empty((C,), dtype=torch.float32, device=dev)
     ws = torch.empty((lib().sf_bn_bwd_ws_floats(C),), dtype=torch.float32, device=dev)
@@ -441,6 +449,9 @@ def bn_bwd(dy, y, z, mean, invstd, gamma, relu, rep=1, dres=None, dz_out=None):
     _check(lib().sf_bn_bwd_apply(*args, _ptr(gamma), _ptr(dbeta), _ptr(dgamma), out.ptr(), out.cs, out.coff,
                                  dres.ptr() if dres is not None else None, dres.cs if dres is not None else 0,
                                  dres.coff if dres is not None else 0, _stream()), "sf_bn_bwd_apply")
+    if dgamma_out is not None:  # scatter into full-width parameter gradients (sliced BN, GhostModule)
+        dgamma_out[0][:C] = dgamma
+        dgamma_out[1][:C] = dbeta
     return out, dgamma, dbeta
 
 
@@ -516,3 +527,31 @@ def bn_train_stats(x, gamma, beta, eps, momentum, run_mean, run_var):
                                    float(momentum), _ptr(run_mean), _ptr(run_var), _ptr(o[0]), _ptr(o[1]),
                                    _ptr(o[2]), _ptr(o[3]), _ptr(o[4]), _ptr(ws), _stream()), "sf_bn_train_stats")
     return o[0], o[2], o[3], o[4]
+
+
+def _dw_desc(x, dz, kernel, stride, padding):
+    return ConvDesc(x.N, x.T, x.H, x.W, x.C, x.cs, x.coff, dz.T, dz.H, dz.W, x.C, 0, 0, 1,
+                    kernel[0], kernel[1], kernel[2], stride[0], stride[1], stride[2], padding[0], padding[1],
+                    padding[2], 1, 1, 1, x.C, ACT_NONE, 0, 0, 0)
+
+
+def dwconv_bwd(x, dz, wp, kernel, stride, padding, dx=None):
+    """Depthwise conv backward: returns dw [taps, C]; accumulates the data gradient into dx (if given)."""
+    d = _dw_desc(x, dz, kernel, stride, padding)
+    C = x.C
+    dw = torch.empty((kernel[0] * kernel[1] * kernel[2], C), dtype=torch.float32, device=x.buf.device)
+    ws = torch.empty((lib().sf_dwconv_wgrad_ws_floats(ctypes.byref(d), C),), dtype=torch.float32,
+                     device=x.buf.device)
+    _check(lib().sf_dwconv_wgrad(ctypes.byref(d), x.ptr(), dz.ptr(), dz.cs, dz.coff, C, _ptr(dw), _ptr(ws),
+                                 _stream()), "sf_dwconv_wgrad")
+    if dx is not None:
+        _check(lib().sf_dwconv_dgrad(ctypes.byref(d), dz.ptr(), dz.cs, dz.coff, _ptr(wp), dx.ptr(), dx.cs, dx.coff,
+                                     C, _stream()), "sf_dwconv_dgrad")
+    return dw
+
+
+def gather_add(src, src_cmul, out, accumulate=True):
+    """out[r, c] (+)= src[r, src.coff + c*src_cmul]."""
+    _check(lib().sf_gather_add(src.ptr(), src.cs, src.coff, src_cmul, out.ptr(), out.cs, out.coff, out.rows, out.C,
+                               1 if accumulate else 0, _stream()), "sf_gather_add")
+    return out

@@ -170,23 +170,34 @@ def bn_train_apply(bn, z, res=None, relu=False, rep=1, out=None, out_reserve=(0,
             bn.__dict__.pop("_sf_affine", None)
             bn.num_batches_tracked.add_(1)
     zz = z if keep is None else z.slice(0, keep)
+    nk = z.C if keep is None else keep
     if keep is not None:
         scale, shift = scale[:keep].contiguous(), shift[:keep].contiguous()
-    y = sfhip.affine(zz, scale.contiguous(), shift.contiguous(), res=res, relu=relu, rep=rep, out=out,
-                     out_reserve=out_reserve, out_cmul=out_cmul)
     t = tape()
+    shuffled = t is not None and out_cmul != 1
+    if shuffled:
+        # training: a channel-shuffled store is an explicit (taped) strided copy of the dense result
+        y = sfhip.affine(zz, scale.contiguous(), shift.contiguous(), res=res, relu=relu, rep=rep)
+    else:
+        y = sfhip.affine(zz, scale.contiguous(), shift.contiguous(), res=res, relu=relu, rep=rep, out=out,
+                         out_reserve=out_reserve, out_cmul=out_cmul)
     if t is not None:
-        if keep is not None or out_cmul != 1:
-            raise NotImplementedError("backward through GhostModule slices / channel-shuffled stores is not built "
-                                      "yet (SlowFast / SlowFastDualAttention train end-to-end)")
+        dg = torch.zeros_like(bn.weight)
+        db = torch.zeros_like(bn.bias)
 
         def bwd():
             dres = t.grad_of(res) if res is not None else None
-            _, dgamma, dbeta = sfhip.bn_bwd(t.grad_of(y), y, z, mean, invstd, bn.weight, relu, rep=rep, dres=dres)
-            t.add_pgrad(bn.weight, dgamma)
-            t.add_pgrad(bn.bias, dbeta)
+            sfhip.bn_bwd(t.grad_of(y), y, zz, mean[:nk], invstd[:nk], bn.weight[:nk], relu, rep=rep, dres=dres,
+                         dz_out=zz, dgamma_out=(dg, db))
+            if keep is not None and keep < z.C:  # sliced-away channels (GhostModule [:oup]) get no gradient
+                rest = z.slice(keep, z.C - keep)
+                sfhip.axpy(rest, rest, alpha=0.0, accumulate=False)
+            t.add_pgrad(bn.weight, dg)
+            t.add_pgrad(bn.bias, db)
 
         t.record(bwd)  # afterwards z's buffer holds dL/dz for the producer's backward
+    if shuffled:  # recorded AFTER the BN op so that its backward (the gather) runs first
+        return copy_channels(y, out, out_cmul=out_cmul)
     return y
 
 
@@ -222,11 +233,18 @@ def conv_bn_act(x, conv, bn=None, relu=False, res=None, out=None, out_reserve=(0
             z = sfhip.conv(x, wp, k, s, p, d, bias=conv.bias)
             _record_conv(x, conv.weight, conv.bias, wp.shape, z, k, s, p, d)
         else:
-            if tape() is not None:
-                raise NotImplementedError("depthwise-conv backward is not built yet")
             ones = _cached(conv, "_sf_ones", (conv.out_channels, str(x.buf.device)),
                            lambda: torch.ones(conv.out_channels, dtype=torch.float32, device=x.buf.device))
             z = sfhip.dwconv(x, wp, k, s, p, scale=ones if conv.bias is not None else None, bias=conv.bias)
+            t = tape()
+            if t is not None:
+                def bwd_dw():  # z's buffer holds dL/dz after the BN backward
+                    dw = sfhip.dwconv_bwd(x, z, wp, k, s, p, dx=t.grad_of(x))
+                    t.add_pgrad(conv.weight, dw.t().contiguous())
+                    if conv.bias is not None:
+                        t.add_pgrad(conv.bias, _colsum(z))
+
+                t.record(bwd_dw)
         return bn_train_apply(bn, z, res=res, relu=relu, out=out, out_reserve=out_reserve, keep=cout,
                               out_cmul=out_cmul)
     if bn is not None:
@@ -339,3 +357,71 @@ def run_model(model, x):
         params = [p for p in model.parameters()]
         return TapedForward.apply(model, x[0], x[1], *params)
     return model._forward_impl(x)
+
+
+def copy_channels(x, out, out_cmul=1):
+    """out[.., out.coff + c*out_cmul] = x[.., c] (+ the gather on the tape)."""
+    sfhip.copy_channels(x, out, out_cmul=out_cmul)
+    t = tape()
+    if t is not None:
+        t.record(lambda: sfhip.gather_add(t.grad_of(out), out_cmul, t.grad_of(x), accumulate=True))
+    return out
+
+
+def add_into(a, res, out):
+    """out = a + res (elementwise, channel slices), taped: both inputs receive dL/dout."""
+    sfhip.affine(a, res=res, out=out)
+    t = tape()
+    if t is not None:
+        def bwd():
+            g = t.grad_of(out)
+            sfhip.axpy(g, t.grad_of(a), 1.0, accumulate=True)
+            sfhip.axpy(g, t.grad_of(res), 1.0, accumulate=True)
+        t.record(bwd)
+    return out
+
+
+def global_mean(x, out=None):
+    """[N,T,H,W,C] -> [N,1,1,1,C] mean over T,H,W (taped)."""
+    pooled = sfhip.tmax_mean(x, 1)
+    a = Act(pooled.view(x.N, 1, 1, 1, x.C))
+    res = sfhip.copy_channels(a, out) if out is not None else a
+    t = tape()
+    if t is not None:
+        def bwd():
+            g = t.grad_of(res)
+            v = g.buf.view(g.N, g.cs)[:, g.coff:g.coff + g.C].contiguous()
+            sfhip.bcast_add(t.grad_of(x), v, 1.0 / float(x.T * x.H * x.W))
+        t.record(bwd)
+    return res
+
+
+def small_torch_op(inputs, params, fn):
+    """A parameter-sized sub-graph ([N, C] tensors: SE excitation, GhostNet's conv_head on pooled features)
+    evaluated with torch ops; on the tape its backward is torch.autograd.grad over the tiny graph.
+    inputs: list of Acts whose views are [N,1,1,1,C]; fn(list of [N,C] tensors) -> [N,K] tensor.
+    Returns an Act [N,1,1,1,K]."""
+    t = tape()
+    flat = [a.buf.view(a.N, a.cs)[:, a.coff:a.coff + a.C] for a in inputs]
+    if t is None:
+        with torch.no_grad():
+            y = fn([f for f in flat])
+        return Act(y.contiguous().view(y.shape[0], 1, 1, 1, y.shape[1]))
+    with torch.enable_grad():
+        leaves = [f.detach().clone().requires_grad_(True) for f in flat]
+        y = fn(leaves)
+    out = Act(y.detach().contiguous().view(y.shape[0], 1, 1, 1, y.shape[1]))
+
+    def bwd():
+        g = t.grad_of(out).buf.view(y.shape)
+        grads = torch.autograd.grad(y, leaves + list(params), g, allow_unused=True)
+        for a, ga in zip(inputs, grads[:len(leaves)]):
+            if ga is not None:
+                ga_act = Act(ga.contiguous().view(a.N, 1, 1, 1, a.C))
+                sfhip.axpy(ga_act, t.grad_of(a), 1.0, accumulate=True)
+        for p, gp in zip(params, grads[len(leaves):]):
+            if gp is not None:
+                t.add_pgrad(p, gp)
+
+    t.record(bwd)
+    return out

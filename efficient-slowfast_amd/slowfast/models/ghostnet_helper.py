@@ -34,11 +34,28 @@ class SqueezeExcite(nn.Module):
         self.conv_expand = nn.Conv3d(reduced_chs, in_chs, 1, bias=True)
 
     def forward(self, x):
-        pooled = sfhip.tmax_mean(x, 1)                                  # [N, C]
-        s = sfhip.Act(pooled.view(x.N, 1, 1, 1, x.C))
-        s = engine.conv_bn_act(s, self.conv_reduce, None, relu=True)
-        s = engine.conv_bn_act(s, self.conv_expand, None, relu=False)   # pre-gate, hard-sigmoid in gate_apply
-        return sfhip.gate_apply(x, 1, s.buf.view(x.N, x.C), w3=None)
+        import torch.nn.functional as F
+        pooled = engine.global_mean(x)                                   # [N,1,1,1,C] (HIP reduction, taped)
+        cr, ce = self.conv_reduce, self.conv_expand
+        # the two FCs act on [N, C] vectors: parameter-sized algebra (torch), gate applied by the HIP kernel
+        e = engine.small_torch_op(
+            [pooled], [cr.weight, cr.bias, ce.weight, ce.bias],
+            lambda f: F.linear(F.relu(F.linear(f[0], cr.weight.view(cr.out_channels, -1), cr.bias)),
+                               ce.weight.view(ce.out_channels, -1), ce.bias))
+        y = sfhip.gate_apply(x, 1, e.buf.view(x.N, x.C), w3=None)       # x * hard_sigmoid(e)
+        t = engine.tape()
+        if t is not None:
+            def bwd():
+                ev = e.buf.view(x.N, x.C)
+                gate = (torch.clamp(ev + 3.0, 0.0, 6.0) / 6.0).contiguous()
+                dy = t.grad_of(y)
+                dgate = sfhip.tmax_dot(x, 1, dy)                         # sum_pos dy * x
+                de = dgate * ((ev > -3.0) & (ev < 3.0)).to(torch.float32) / 6.0
+                sfhip.axpy(sfhip.Act(de.contiguous().view(x.N, 1, 1, 1, x.C)), t.grad_of(e), 1.0, accumulate=True)
+                zero = torch.zeros_like(gate)
+                sfhip.eca_bwd_apply(x, 1, dy, gate, zero, t.grad_of(x))  # dx += dy * gate
+            t.record(bwd)
+        return y
 
 
 class GhostModule(nn.Module):
@@ -69,9 +86,16 @@ class GhostModule(nn.Module):
         init = pc[0].out_channels
         keep = self.oup - init  # channels of the cheap half that survive the [:oup] slice
         out = sfhip.new_act(x, x.N, x.T, x.H, x.W, self.oup, reserve[0], reserve[1])
+        training = pc[1].training
         if res is None:
             x1 = engine.conv_bn_act(x, pc[0], pc[1], relu=self.relu, out=out.slice(0, init))
             engine.conv_bn_act(x1, co[0], co[1], relu=self.relu, out=out.slice(init, keep), cout=keep)
+        elif training:
+            # x += shortcut(residual): the cheap half must see x1 BEFORE the add
+            x1 = engine.conv_bn_act(x, pc[0], pc[1], relu=self.relu)
+            engine.conv_bn_act(x1, co[0], co[1], relu=self.relu, res=res.slice(init, keep),
+                               out=out.slice(init, keep), cout=keep)
+            engine.add_into(x1, res.slice(0, init), out.slice(0, init))
         else:
             # x += shortcut(residual) (ghostnet_helper.py:162) folded in: the cheap half must see x1 BEFORE
             # the add, so x1 goes to scratch, the depthwise epilogue adds its residual slice, and a 1-tap

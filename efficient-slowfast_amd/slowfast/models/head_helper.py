@@ -110,18 +110,8 @@ class _ConvBnAct(nn.Module):
 
 
 def _global_mean(x, out=None):
-    """[N,T,H,W,C] -> [N,1,1,1,C] mean (F.avg_pool3d(x, x.size()[-3:]))."""
-    pooled = sfhip.tmax_mean(x, 1)
-    a = sfhip.Act(pooled.view(x.N, 1, 1, 1, x.C))
-    res = sfhip.copy_channels(a, out) if out is not None else a
-    t = engine.tape()
-    if t is not None:
-        def bwd():  # d mean: broadcast dL/d(pooled) / count over the pooled extent
-            g = t.grad_of(res)
-            v = g.buf.view(g.N, g.cs)[:, g.coff:g.coff + g.C].contiguous()
-            sfhip.bcast_add(t.grad_of(x), v, 1.0 / float(x.T * x.H * x.W))
-        t.record(bwd)
-    return res
+    """[N,T,H,W,C] -> [N,1,1,1,C] mean (F.avg_pool3d(x, x.size()[-3:])); taped."""
+    return engine.global_mean(x, out)
 
 
 class ShuffleNetV2BasicHead(nn.Module):
@@ -181,7 +171,11 @@ class GhostNetBasicHead(nn.Module):
         for x, stage5, conv_head in ((xs[0], self.stage5_conv_slow, self.conv_head_slow),
                                      (xs[1], self.stage5_conv_fast, self.conv_head_fast)):
             y = _global_mean(stage5(x))
-            engine.conv_bn_act(y, conv_head, None, relu=True, out=cat.slice(off, conv_head.out_channels))
+            # conv_head (+bias) + ReLU on the pooled [N, C] features: parameter-sized
+            z = engine.small_torch_op(
+                [y], [conv_head.weight, conv_head.bias],
+                lambda f, cv=conv_head: F.relu(F.linear(f[0], cv.weight.view(cv.out_channels, -1), cv.bias)))
+            engine.copy_channels(z, cat.slice(off, conv_head.out_channels))
             off += conv_head.out_channels
         logits = _project(cat, self.classifier[1], self.classifier[0], self.training)
         return _finish(logits, self.training, "relu")

@@ -56,7 +56,7 @@ class InvertedResidual(nn.Module):
         odd = sfhip.Act(out.buf, out.coff + 1, out.C - 1)
         engine.conv_bn_act(y, b2[5], b2[6], relu=True, out=odd, out_cmul=2)
         if self.stride == 1:
-            sfhip.copy_channels(x1, even, out_cmul=2)
+            engine.copy_channels(x1, even, out_cmul=2)
         else:
             b1 = self.banch1
             z = engine.conv_bn_act(x, b1[0], b1[1], relu=False)

@@ -73,7 +73,7 @@ class SimpleStem(nn.Module):
             y = engine.stem_conv_bn_relu(x, conv, bn, relu=True)
             if reserve != (0, 0):
                 wide = sfhip.new_act(y, y.N, y.T, y.H, y.W, y.C, reserve[0], reserve[1])
-                return sfhip.copy_channels(y, wide)
+                return engine.copy_channels(y, wide)
             return y
         y = engine.stem_conv_bn_relu(x, conv, bn, relu=True)
         return engine.maxpool(y, (3, 3, 3), (1, 2, 2), (1, 1, 1), out_reserve=reserve)

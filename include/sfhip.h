@@ -189,6 +189,17 @@ int sf_eca_bwd_apply(const float* x, int cs, int coff, int N, int T, int H, int 
                      const float* dz, int dz_cs, int dz_coff, const float* gate, const float* dpool, float* dx,
                      int dx_cs, int dx_coff, void* stream);
 
+/* Depthwise conv backward (`d` = forward descriptor, weights [taps][C]): dx accumulates; dw [taps][C] through
+ * a fixed-count partial workspace (sf_dwconv_wgrad_ws_floats).                                           */
+int sf_dwconv_dgrad(const sf_conv_desc* d, const float* dz, int dz_cs, int dz_coff, const float* w_packed,
+                    float* dx, int dx_cs, int dx_coff, int C, void* stream);
+long sf_dwconv_wgrad_ws_floats(const sf_conv_desc* d, int C);
+int sf_dwconv_wgrad(const sf_conv_desc* d, const float* x, const float* dz, int dz_cs, int dz_coff, int C,
+                    float* dw, float* ws, void* stream);
+/* out[r, c] (+)= in[r, in_coff + c*in_cmul]: backward of a channel-multiplier (shuffled) store.           */
+int sf_gather_add(const float* in, int in_cs, int in_coff, int in_cmul, float* out, int out_cs, int out_coff,
+                  long rows, int C, int accumulate, void* stream);
+
 /* g[n, r, c] += v[n, c] * scale (global-mean backward);  out[r] = scale * <a[r,:], b[r,:]>;
  * out[r, c] (+)= alpha * a[r, c].                                                                       */
 int sf_bcast_add(float* g, int cs, int coff, int N, long rows_per_n, int C, const float* v, float scale,

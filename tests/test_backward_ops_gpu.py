@@ -232,3 +232,35 @@ def test_attention_backward(c, thw):
             _rel(dvec.sum().view(1), dg_r)]
     _report("attn_bwd c%d n%d" % (c, n), max(errs))
     assert max(errs) < TOL, errs
+
+
+@pytest.mark.parametrize("c,k,s", [(32, (3, 3, 3), (1, 1, 1)), (12, (1, 5, 5), (1, 2, 2)), (27, (3, 3, 3), (1, 2, 2))])
+def test_dwconv_backward(c, k, s):
+    import sfhip
+    dev = _dev()
+    g = torch.Generator().manual_seed(c)
+    x = torch.randn(2, c, 4, 10, 10, generator=g).requires_grad_(True)
+    wt = (torch.randn(c, 1, *k, generator=g) / np.sqrt(k[0] * k[1] * k[2])).requires_grad_(True)
+    p = tuple(kk // 2 for kk in k)
+    y = F.conv3d(x, wt, None, s, p, 1, c)
+    dy = torch.randn(y.shape, generator=g)
+    dx_ref, dw_ref = torch.autograd.grad(y, (x, wt), dy)
+    dx = sfhip.Act(torch.zeros(2, 4, 10, 10, c, device=dev))
+    dw = sfhip.dwconv_bwd(_act(x), _act(dy), sfhip.pack_dw_weight(wt.detach().to(dev)), k, s, p, dx=dx)
+    torch.cuda.synchronize()
+    e1 = _rel(_back(dx), dx_ref)
+    e2 = _rel(dw.t().reshape(wt.shape), dw_ref)
+    _report("dwconv_bwd c%d" % c, max(e1, e2))
+    assert e1 < TOL and e2 < TOL, (e1, e2)
+
+
+def test_gather_add_is_the_adjoint_of_the_shuffled_store():
+    import sfhip
+    dev = _dev()
+    x = torch.randn(1, 2, 3, 3, 10)
+    wide = sfhip.Act(torch.zeros(1, 2, 3, 3, 24, device=dev))
+    sfhip.copy_channels(sfhip.Act(x.to(dev)), sfhip.Act(wide.buf, 3, 21), out_cmul=2)
+    back = sfhip.Act(torch.ones(1, 2, 3, 3, 10, device=dev))
+    sfhip.gather_add(sfhip.Act(wide.buf, 3, 21), 2, back, accumulate=True)
+    torch.cuda.synchronize()
+    assert torch.equal(back.buf.cpu(), x + 1)

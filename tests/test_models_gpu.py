@@ -190,7 +190,7 @@ def test_train_mode_forward_matches_reference_golden(name):
     assert int(next(v for k, v in model.state_dict().items() if k.endswith("num_batches_tracked"))) == 1
 
 
-@pytest.mark.parametrize("name", ["slowfast_r50_s64", "dual_r50_s64"])
+@pytest.mark.parametrize("name", MODEL_CASES)
 def test_train_step_gradients_match_reference_golden(name):
     """train_net.py:78-96: logits = model(x); loss = CE(logits, labels); loss.backward() — loss, sampled
     parameter gradients and their norms against the reference's autograd (golden 'grad/*')."""
@@ -210,7 +210,7 @@ def test_train_step_gradients_match_reference_golden(name):
     assert abs(loss.item() - float(z["train/loss"][0])) < 1e-3
     params = dict(model.named_parameters())
     keys = [k[5:] for k in z.files if k.startswith("grad/") and not k.endswith("/stats")]
-    assert len(keys) >= 6
+    assert len(keys) >= 4
     # Tolerance: gradients of this ReLU / max-pool network are discontinuous in the activations — one
     # activation whose sign differs by rounding flips a whole column of contributions.  The REFERENCE's own
     # fp32-vs-fp64 gradients differ by 1.6 % (median) to 5 % (worst) in relative L2 on this fixture (measured

@@ -35,3 +35,12 @@ for k,p in params.items():
 worst.sort(reverse=True)
 for e,k,a,b in worst[:25]: print('%.3e %-60s %.5e %.5e'%(e,k,a,b))
 print('median', worst[len(worst)//2][0])
+import collections
+agg = collections.OrderedDict()
+for k, p in params.items():
+    top = ".".join(k.split(".")[:2])
+    a = agg.setdefault(top, [0.0, 0.0])
+    a[0] += float(p.grad.norm()) ** 2
+    a[1] += float(sdr[k].grad.norm()) ** 2 if sdr[k].grad is not None else 0.0
+for k, (a, b) in agg.items():
+    print("%-40s mine %.4e  ref %.4e" % (k, a ** 0.5, b ** 0.5))
