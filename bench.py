@@ -135,10 +135,11 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback for the hot path)"
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
-    if world > 1:
-        import torch.distributed as dist
+    import torch.distributed as dist
+    if world > 1 or "RANK" in os.environ:  # launched by torch.distributed.run: one process per GPU
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl")  # RCCL over xGMI
+        os.environ.setdefault("MASTER_PORT", "29500")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world)  # RCCL over xGMI
 
     import sfhip
     from slowfast.utils.distributed import FlatGradients, max_over_ranks
@@ -184,7 +185,7 @@ def main():
     assert bool(torch.isfinite(out).all()), "non-finite model output"
 
     def barrier():
-        if world > 1:
+        if dist.is_initialized():
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -298,7 +299,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(args.workload, cfg, model, train)
         print(json.dumps(res))
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

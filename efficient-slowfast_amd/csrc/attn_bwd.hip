@@ -344,6 +344,11 @@ int launch(const BwdArgs& a, int which, hipStream_t s) {
 
 }  // namespace
 
+int sf_attn_small_bwd_dispatch(const float* q, int q_cs, const float* k, int k_cs, const float* v, int v_cs,
+                               const float* dz, int dz_cs, const float* lse, const float* dvec, const float* gamma,
+                               float* dq, int dq_cs, float* dk, int dk_cs, float* dv, int dv_cs, int B, int N, int C,
+                               int which, hipStream_t stream);  // attn_small_bwd.hip
+
 // which: bit 0 = dQ kernel, bit 1 = dK/dV kernel (3 = both; separate launches let callers time them).
 extern "C" int sf_attn_bwd(const float* q, int q_cs, const float* k, int k_cs, const float* v, int v_cs,
                            const float* dz, int dz_cs, const float* lse, const float* dvec, const float* gamma,
@@ -357,8 +362,9 @@ extern "C" int sf_attn_bwd(const float* q, int q_cs, const float* k, int k_cs, c
   a.q_cs = q_cs; a.k_cs = k_cs; a.v_cs = v_cs; a.dz_cs = dz_cs; a.dq_cs = dq_cs; a.dk_cs = dk_cs; a.dv_cs = dv_cs;
   a.B = B; a.C = C; a.N = N; a.nt = sf_cdiv(N, 128);
   hipStream_t s = (hipStream_t)stream;
-  if (C <= 8) return launch<8>(a, which, s);
-  if (C <= 16) return launch<16>(a, which, s);
+  if (C <= 16)  // 16x16x4 tiles: no padded rows
+    return sf_attn_small_bwd_dispatch(q, q_cs, k, k_cs, v, v_cs, dz, dz_cs, lse, dvec, gamma, dq, dq_cs, dk, dk_cs,
+                                      dv, dv_cs, B, N, C, which, s);
   if (C <= 32) return launch<32>(a, which, s);
   if (C <= 64) return launch<64>(a, which, s);
   return launch<128>(a, which, s);

@@ -1,0 +1,316 @@
+// attn_small_bwd.hip — flash SpatialAttention backward for SMALL head dims (C = d <= 16) on
+// v_mfma_f32_16x16x4_f32 tiles (the backward counterpart of attn_small.hip; math as in attn_bwd.hip).
+//
+// One wavefront owns 16 queries (dQ kernel) resp. 16 keys (dK/dV kernel) on its lanes (lane&15) and sweeps
+// the other index in stages of 64 (4 tiles of 16).  Products whose contraction runs over the channels take
+// their A operand from a TRANSPOSED LDS tile [channel][item] (lane (item, g) reads channel 4u+g), products
+// whose contraction runs over the swept index take it from the row-major tile [item][channel]
+// (lane (channel, g) reads item 4g+r) and use the recomputed P / dS registers directly as B operand.
+#include "common.h"
+
+namespace {
+
+struct BwdArgs {
+  const float* q; const float* k; const float* v;
+  const float* dz; const float* lse; const float* dvec; const float* gamma;
+  float* dq; float* dk; float* dv;
+  int q_cs, k_cs, v_cs, dz_cs, dq_cs, dk_cs, dv_cs;
+  int B, C, N, nt;
+};
+
+constexpr float POS_BIG = 3.0e38f;
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr int ST = 64;        // swept items per stage
+constexpr int TP = ST + 16;   // transposed-tile row pitch (quarter g lands 16 banks further)
+
+template <int CP>
+struct Geo {
+  static constexpr int QS = CP / 4;
+  static constexpr int RP = (CP == 16) ? 20 : 12;  // row-major tile pitch (rows 4 apart land 16 banks apart)
+  static constexpr int F4 = CP / 4;
+  static constexpr int NLD = ST * F4;              // float4 per tile (<= 256)
+};
+
+// ---------------------------------------------------------------------------------------------- dQ
+template <int CP>
+__global__ __launch_bounds__(256) void attn_small_dq_kernel(const BwdArgs p) {
+  using G = Geo<CP>;
+  constexpr int QS = G::QS, RP = G::RP, F4 = G::F4, NLD = G::NLD;
+  constexpr int STAGE = 2 * CP * TP + ST * RP;  // Kt, Vt, Ks
+  __shared__ __attribute__((aligned(16))) float smem[2 * STAGE];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, lg = lane >> 4;
+  const int b = blockIdx.x / p.nt;
+  const int q0 = (blockIdx.x - b * p.nt) * 64 + wave * 16;
+  const int N = p.N, C = p.C;
+  const long brow = (long)b * N;
+  const float gamma = p.gamma[0];
+
+  const int qrow = q0 + li;
+  const bool qok = qrow < N;
+  float qf[QS], df[QS];
+  {
+    const float* qp = p.q + (brow + (qok ? qrow : 0)) * p.q_cs;
+    const float* dp = p.dz + (brow + (qok ? qrow : 0)) * p.dz_cs;
+#pragma unroll
+    for (int u = 0; u < QS; ++u) {
+      const int c = 4 * u + lg;
+      const bool ok = qok && c < C;
+      qf[u] = ok ? qp[c] * LOG2E : 0.f;
+      df[u] = ok ? dp[c] * gamma : 0.f;
+    }
+  }
+  const float lse = qok ? p.lse[brow + qrow] : 0.f;
+  const float dsum = qok ? p.dvec[brow + qrow] * gamma : 0.f;
+  f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+
+  const int srow = tid / F4;
+  const int sc4 = (tid - srow * F4) * 4;
+  f32x4 rk = {0.f, 0.f, 0.f, 0.f}, rv = {0.f, 0.f, 0.f, 0.f};
+  auto load_stage = [&](int j0) {
+    rk = (f32x4){0.f, 0.f, 0.f, 0.f};
+    rv = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int j = j0 + srow;
+    if (tid < NLD && j < N) {
+      const float* kp = p.k + (brow + j) * p.k_cs + sc4;
+      const float* vp = p.v + (brow + j) * p.v_cs + sc4;
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if ((sc4 + e) < C) {
+          rk[e] = kp[e];
+          rv[e] = vp[e];
+        }
+    }
+  };
+  auto store_stage = [&](int buf) {
+    if (tid < NLD) {
+      float* Kt = smem + buf * STAGE;
+      float* Vt = Kt + CP * TP;
+      float* Ks = Vt + CP * TP;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        Kt[(sc4 + e) * TP + srow] = rk[e];
+        Vt[(sc4 + e) * TP + srow] = rv[e];
+      }
+      *reinterpret_cast<f32x4*>(Ks + srow * RP + sc4) = rk;
+    }
+  };
+
+  const int nst = (N + ST - 1) / ST;
+  load_stage(0);
+  store_stage(0);
+  __syncthreads();
+  for (int t = 0; t < nst; ++t) {
+    const int buf = t & 1;
+    const bool more = (t + 1) < nst;
+    if (more) load_stage((t + 1) * ST);
+    const float* Kt = smem + buf * STAGE;
+    const float* Vt = Kt + CP * TP;
+    const float* Ks = Vt + CP * TP;
+    f32x4 s[4], dp[4];
+    const float* kb = Kt + lg * TP + li;
+    const float* vb = Vt + lg * TP + li;
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+      s[kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      dp[kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int u = 0; u < QS; ++u) {
+        s[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(kb[(4 * u) * TP + kt * 16], qf[u], s[kt], 0, 0, 0);
+        dp[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(vb[(4 * u) * TP + kt * 16], df[u], dp[kt], 0, 0, 0);
+      }
+    }
+    const int jbase = t * ST;
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const bool jok = (jbase + kt * 16 + 4 * lg + r) < N;
+        const float pr = jok ? __builtin_amdgcn_exp2f(s[kt][r] - lse) : 0.f;
+        s[kt][r] = pr * (dp[kt][r] - dsum);  // dS^T
+      }
+    const float* kc = Ks + (4 * lg) * RP + (li & (CP - 1));
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; r += 2) {
+        a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(kc[(kt * 16 + r) * RP], s[kt][r], a0, 0, 0, 0);
+        a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(kc[(kt * 16 + r + 1) * RP], s[kt][r + 1], a1, 0, 0, 0);
+      }
+    if (more) store_stage(buf ^ 1);
+    __syncthreads();
+  }
+  const int c0 = 4 * lg;
+  if (!qok || c0 >= C) return;
+  float* op = p.dq + (brow + qrow) * p.dq_cs + c0;
+#pragma unroll
+  for (int e = 0; e < 4; ++e)
+    if (c0 + e < C) op[e] = a0[e] + a1[e];
+}
+
+// ---------------------------------------------------------------------------------------------- dK, dV
+template <int CP>
+__global__ __launch_bounds__(256) void attn_small_dkv_kernel(const BwdArgs p) {
+  using G = Geo<CP>;
+  constexpr int QS = G::QS, RP = G::RP, F4 = G::F4, NLD = G::NLD;
+  constexpr int STAGE = 2 * CP * TP + 2 * ST * RP + 2 * ST;  // Qt, dOt, Qs, dOs, lse, D
+  __shared__ __attribute__((aligned(16))) float smem[2 * STAGE];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, lg = lane >> 4;
+  const int b = blockIdx.x / p.nt;
+  const int j0 = (blockIdx.x - b * p.nt) * 64 + wave * 16;
+  const int N = p.N, C = p.C;
+  const long brow = (long)b * N;
+  const float gamma = p.gamma[0];
+
+  const int jrow = j0 + li;
+  const bool jok = jrow < N;
+  float kf[QS], vf[QS];
+  {
+    const float* kp = p.k + (brow + (jok ? jrow : 0)) * p.k_cs;
+    const float* vp = p.v + (brow + (jok ? jrow : 0)) * p.v_cs;
+#pragma unroll
+    for (int u = 0; u < QS; ++u) {
+      const int c = 4 * u + lg;
+      const bool ok = jok && c < C;
+      kf[u] = ok ? kp[c] * LOG2E : 0.f;
+      vf[u] = ok ? vp[c] : 0.f;
+    }
+  }
+  f32x4 dk0 = {0.f, 0.f, 0.f, 0.f}, dk1 = dk0, dv0 = dk0, dv1 = dk0;
+
+  const int srow = tid / F4;
+  const int sc4 = (tid - srow * F4) * 4;
+  f32x4 rq = {0.f, 0.f, 0.f, 0.f}, rd = {0.f, 0.f, 0.f, 0.f};
+  float rl = 0.f, rD = 0.f;
+  auto load_stage = [&](int i0) {
+    rq = (f32x4){0.f, 0.f, 0.f, 0.f};
+    rd = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int i = i0 + srow;
+    if (tid < NLD && i < N) {
+      const float* qp = p.q + (brow + i) * p.q_cs + sc4;
+      const float* dp = p.dz + (brow + i) * p.dz_cs + sc4;
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if ((sc4 + e) < C) {
+          rq[e] = qp[e];
+          rd[e] = dp[e] * gamma;
+        }
+    }
+    if (tid < ST) {
+      const int ii = i0 + tid;
+      rl = (ii < N) ? p.lse[brow + ii] : POS_BIG;
+      rD = (ii < N) ? p.dvec[brow + ii] * gamma : 0.f;
+    }
+  };
+  auto store_stage = [&](int buf) {
+    float* Qt = smem + buf * STAGE;
+    float* Dt = Qt + CP * TP;
+    float* Qs = Dt + CP * TP;
+    float* Ds = Qs + ST * RP;
+    float* Ls = Ds + ST * RP;
+    if (tid < NLD) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        Qt[(sc4 + e) * TP + srow] = rq[e];
+        Dt[(sc4 + e) * TP + srow] = rd[e];
+      }
+      *reinterpret_cast<f32x4*>(Qs + srow * RP + sc4) = rq;
+      *reinterpret_cast<f32x4*>(Ds + srow * RP + sc4) = rd;
+    }
+    if (tid < ST) {
+      Ls[tid] = rl;
+      Ls[ST + tid] = rD;
+    }
+  };
+
+  const int nst = (N + ST - 1) / ST;
+  load_stage(0);
+  store_stage(0);
+  __syncthreads();
+  for (int t = 0; t < nst; ++t) {
+    const int buf = t & 1;
+    const bool more = (t + 1) < nst;
+    if (more) load_stage((t + 1) * ST);
+    const float* Qt = smem + buf * STAGE;
+    const float* Dt = Qt + CP * TP;
+    const float* Qs = Dt + CP * TP;
+    const float* Ds = Qs + ST * RP;
+    const float* Ls = Ds + ST * RP;
+    f32x4 s[4], dp[4];
+    const float* qb = Qt + lg * TP + li;
+    const float* db = Dt + lg * TP + li;
+#pragma unroll
+    for (int qt = 0; qt < 4; ++qt) {
+      s[qt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      dp[qt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int u = 0; u < QS; ++u) {
+        s[qt] = __builtin_amdgcn_mfma_f32_16x16x4f32(qb[(4 * u) * TP + qt * 16], kf[u], s[qt], 0, 0, 0);    // S'
+        dp[qt] = __builtin_amdgcn_mfma_f32_16x16x4f32(db[(4 * u) * TP + qt * 16], vf[u], dp[qt], 0, 0, 0);  // dP
+      }
+    }
+    f32x4 pr[4];
+#pragma unroll
+    for (int qt = 0; qt < 4; ++qt) {
+      const f32x4 l4 = *reinterpret_cast<const f32x4*>(Ls + qt * 16 + 4 * lg);
+      const f32x4 d4 = *reinterpret_cast<const f32x4*>(Ls + ST + qt * 16 + 4 * lg);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        pr[qt][r] = __builtin_amdgcn_exp2f(s[qt][r] - l4[r]);
+        s[qt][r] = pr[qt][r] * (dp[qt][r] - d4[r]);  // dS
+      }
+    }
+    const float* qc = Qs + (4 * lg) * RP + (li & (CP - 1));
+    const float* dc = Ds + (4 * lg) * RP + (li & (CP - 1));
+#pragma unroll
+    for (int qt = 0; qt < 4; ++qt)
+#pragma unroll
+      for (int r = 0; r < 4; r += 2) {
+        dv0 = __builtin_amdgcn_mfma_f32_16x16x4f32(dc[(qt * 16 + r) * RP], pr[qt][r], dv0, 0, 0, 0);
+        dk0 = __builtin_amdgcn_mfma_f32_16x16x4f32(qc[(qt * 16 + r) * RP], s[qt][r], dk0, 0, 0, 0);
+        dv1 = __builtin_amdgcn_mfma_f32_16x16x4f32(dc[(qt * 16 + r + 1) * RP], pr[qt][r + 1], dv1, 0, 0, 0);
+        dk1 = __builtin_amdgcn_mfma_f32_16x16x4f32(qc[(qt * 16 + r + 1) * RP], s[qt][r + 1], dk1, 0, 0, 0);
+      }
+    if (more) store_stage(buf ^ 1);
+    __syncthreads();
+  }
+  const int c0 = 4 * lg;
+  if (!jok || c0 >= C) return;
+  float* okp = p.dk + (brow + jrow) * p.dk_cs + c0;
+  float* ovp = p.dv + (brow + jrow) * p.dv_cs + c0;
+#pragma unroll
+  for (int e = 0; e < 4; ++e)
+    if (c0 + e < C) {
+      okp[e] = dk0[e] + dk1[e];
+      ovp[e] = dv0[e] + dv1[e];
+    }
+}
+
+template <int CP>
+int launch(const BwdArgs& a, int which, hipStream_t s) {
+  const int grid = a.B * a.nt;
+  if (which & 1) hipLaunchKernelGGL((attn_small_dq_kernel<CP>), dim3(grid), dim3(256), 0, s, a);
+  if (which & 2) hipLaunchKernelGGL((attn_small_dkv_kernel<CP>), dim3(grid), dim3(256), 0, s, a);
+  SF_CHECK_LAUNCH();
+  return SF_OK;
+}
+
+}  // namespace
+
+// Called by sf_attn_bwd (attn_bwd.hip) for C <= 16.
+int sf_attn_small_bwd_dispatch(const float* q, int q_cs, const float* k, int k_cs, const float* v, int v_cs,
+                               const float* dz, int dz_cs, const float* lse, const float* dvec, const float* gamma,
+                               float* dq, int dq_cs, float* dk, int dk_cs, float* dv, int dv_cs, int B, int N, int C,
+                               int which, hipStream_t stream) {
+  BwdArgs a;
+  a.q = q; a.k = k; a.v = v; a.dz = dz; a.lse = lse; a.dvec = dvec; a.gamma = gamma;
+  a.dq = dq; a.dk = dk; a.dv = dv;
+  a.q_cs = q_cs; a.k_cs = k_cs; a.v_cs = v_cs; a.dz_cs = dz_cs; a.dq_cs = dq_cs; a.dk_cs = dk_cs; a.dv_cs = dv_cs;
+  a.B = B; a.C = C; a.N = N; a.nt = sf_cdiv(N, 64);
+  if (C <= 4) return launch<4>(a, which, stream);
+  if (C <= 8) return launch<8>(a, which, stream);
+  return launch<16>(a, which, stream);
+}

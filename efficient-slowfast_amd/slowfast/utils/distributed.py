@@ -5,6 +5,8 @@ issued from autograd hooks.  The native design is ONE all-
 parameter's .grad is a view into one flat fp32 buffer (135.9 MB for SlowFastDualAttention R50), so after
 backward a single ncclAllReduce(sum) over the fully connected xGMI mesh plus one scale by 1/world replaces
 DDP's ~6 buckets and needs no gradient copies.  `build_model` still offers the DDP wrap for drop-in use."""
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -43,7 +45,8 @@ class FlatGradients(object):
 
     def all_reduce_mean(self):
         """grad <- mean over ranks: ONE collective on the flat buffer."""
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1:
+        force = os.environ.get("SF_FORCE_ALLREDUCE") == "1"  # exercise the RCCL path on a 1-GPU box
+        if dist.is_available() and dist.is_initialized() and (dist.get_world_size(self.group) > 1 or force):
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
             self.flat.div_(dist.get_world_size(self.group))
         return self.flat
@@ -52,6 +55,6 @@ class FlatGradients(object):
 def max_over_ranks(value, device):
     """Scalar MAX across ranks (bench.py's step time)."""
     t = torch.tensor([float(value)], dtype=torch.float64, device=device)
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_available() and dist.is_initialized():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
