@@ -44,8 +44,8 @@ __device__ __forceinline__ void bn_g(const float* __restrict__ dy, int dy_cs, in
       const f32x4 v = *reinterpret_cast<const f32x4*>(yp);
 #pragma unroll
       for (int e = 0; e < 4; ++e)
-        if (!(v[e] > 0.f)) g[e] = 0.f;
-    } else if (!(yp[0] > 0.f)) {
+        if (!(v[e] > 0.f) || (relu == 2 && !(v[e] < 6.f))) g[e] = 0.f;
+    } else if (!(yp[0] > 0.f) || (relu == 2 && !(yp[0] < 6.f))) {
       g[0] = 0.f;
     }
   }

@@ -22,6 +22,7 @@ __device__ __forceinline__ int xcd_remap(int b, int n) {
 
 __device__ __forceinline__ float sf_act(float v, int act) {
   if (act == SF_ACT_RELU) return v > 0.f ? v : 0.f;
+  if (act == SF_ACT_RELU6) return fminf(fmaxf(v, 0.f), 6.f);
   if (act == SF_ACT_HSIGMOID) return fminf(fmaxf(v + 3.f, 0.f), 6.f) * (1.f / 6.f);
   if (act == SF_ACT_SIGMOID) return 1.f / (1.f + __expf(-v));
   return v;

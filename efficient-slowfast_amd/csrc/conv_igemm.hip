@@ -214,7 +214,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
 
   // ---- epilogue
   const bool has_res = p.res != nullptr;
-  const bool relu = d.act == SF_ACT_RELU;
+  const bool relu = d.act == SF_ACT_RELU || d.act == SF_ACT_RELU6;
+  const float hi = d.act == SF_ACT_RELU6 ? 6.f : 3.0e38f;
   if (p.vec_epi) {
     // The accumulator layout has the channel on the lane (16 lanes = 64 B per row): stored directly, a wave
     // store touches 4 rows x 64 B.  Transpose each 16-row slab through this wave's private LDS region and
@@ -249,7 +250,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
           if (has_res) v += *reinterpret_cast<const f32x4*>(p.res + (long)m * d.res_cs + d.res_coff + n);
           if (relu) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+            for (int e = 0; e < 4; ++e) v[e] = fminf(fmaxf(v[e], 0.f), hi);
           }
           *reinterpret_cast<f32x4*>(p.out + (long)m * d.out_cs + d.out_coff + n) = v;
         }
@@ -273,7 +274,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
         if (m >= p.M) continue;
         float v = acc[i][j][r] * sc + bi;
         if (has_res) v += p.res[(long)m * d.res_cs + d.res_coff + n];
-        v = relu ? fmaxf(v, 0.f) : v;
+        v = relu ? fminf(fmaxf(v, 0.f), hi) : v;
         p.out[(long)m * d.out_cs + d.out_coff + (long)n * d.out_cmul] = v;
       }
     }
@@ -314,7 +315,7 @@ __global__ __launch_bounds__(256) void gemv_rows_kernel(const ConvArgs p) {
     if (lane == 0 && m < p.M) {
       v = v * sc + bi;
       if (p.res) v += p.res[(long)m * d.res_cs + d.res_coff + n];
-      if (d.act == SF_ACT_RELU) v = fmaxf(v, 0.f);
+      v = sf_act(v, d.act);
       p.out[(long)m * d.out_cs + d.out_coff + (long)n * d.out_cmul] = v;
     }
   }
@@ -341,7 +342,7 @@ extern "C" int sf_conv_fwd(const sf_conv_desc* d, const float* in, const float* 
   if (d->Cin <= 0 || d->Cout <= 0 || d->cin_pad < d->Cin || (d->cin_pad % BK) != 0) return SF_EINVAL;
   if (d->kT <= 0 || d->kH <= 0 || d->kW <= 0 || d->sT <= 0 || d->sH <= 0 || d->sW <= 0) return SF_EINVAL;
   if (d->out_cmul <= 0) return SF_EINVAL;
-  if (d->act != SF_ACT_NONE && d->act != SF_ACT_RELU) return SF_EINVAL;
+  if (d->act != SF_ACT_NONE && d->act != SF_ACT_RELU && d->act != SF_ACT_RELU6) return SF_EINVAL;
   if (!sf_aligned16(w_packed)) return SF_EALIGN;
   const long M = (long)d->N * d->To * d->Ho * d->Wo;
   if (M <= 0 || M > 0x7fffffffL) return SF_EINVAL;

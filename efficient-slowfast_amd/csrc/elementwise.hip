@@ -150,7 +150,7 @@ __global__ void dwconv_kernel(const sf_conv_desc d, const float* __restrict__ in
     float v = acc[e];
     if (scale) v = v * scale[c + e] + bias[c + e];
     if (res) v += res[m * d.res_cs + d.res_coff + c + e];
-    if (d.act == SF_ACT_RELU) v = fmaxf(v, 0.f);
+    v = sf_act(v, d.act);
     out[m * d.out_cs + d.out_coff + (long)(c + e) * d.out_cmul] = v;
   }
 }
@@ -309,6 +309,9 @@ __global__ void copy_channels_kernel(const float* __restrict__ in, int in_cs, in
 
 // ------------------------------------------------------------------------------------------------
 // Training-mode BN statistics: partial[blk][{sum,sumsq}][c] over the block's rows (fp32), combined in fp64.
+// Sums are taken of (x - K[c]) with K = the channel's first sample (shifted-data variance): E[d^2] - E[d]^2 then
+// cancels at the scale of (mean-K)^2 / var ~ O(1) instead of mean^2 / var, which for a channel with |mean| >> std
+// would cost several digits of the variance in fp32.
 constexpr int STAT_MAX_P = 1024;
 
 template <int VEC>
@@ -321,22 +324,25 @@ __global__ void stats_partial_kernel(const float* __restrict__ x, int cs, int co
   const long per = (rows + P - 1) / P;
   const long r0 = (long)blk * per;
   const long r1 = (r0 + per < rows) ? r0 + per : rows;
-  float s1[VEC], s2[VEC];
+  float s1[VEC], s2[VEC], k[VEC];
 #pragma unroll
-  for (int e = 0; e < VEC; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
+  for (int e = 0; e < VEC; ++e) { s1[e] = 0.f; s2[e] = 0.f; k[e] = 0.f; }
   if (c < C) {
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) k[e] = x[coff + c + e];
     for (long r = r0 + rl; r < r1; r += rpi) {
       if (VEC == 4) {
         const f32x4 v = *reinterpret_cast<const f32x4*>(x + r * cs + coff + c);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          s1[e] += v[e];
-          s2[e] = fmaf(v[e], v[e], s2[e]);
+          const float d = v[e] - k[e];
+          s1[e] += d;
+          s2[e] = fmaf(d, d, s2[e]);
         }
       } else {
-        const float v = x[r * cs + coff + c];
-        s1[0] += v;
-        s2[0] = fmaf(v, v, s2[0]);
+        const float d = x[r * cs + coff + c] - k[0];
+        s1[0] += d;
+        s2[0] = fmaf(d, d, s2[0]);
       }
     }
   }
@@ -363,7 +369,8 @@ __global__ void stats_partial_kernel(const float* __restrict__ x, int cs, int co
 // One 64-lane block per channel: lanes stride over the P partials in fp64, tree-reduce through LDS.  With
 // BN parameters given it also emits the normalisation affine and updates the running statistics in place
 // (nn.BatchNorm3d training semantics: biased variance to normalise, unbiased for running_var).
-__global__ void stats_final_kernel(const float* __restrict__ partial, int C, int P, double inv_rows, double unbias,
+__global__ void stats_final_kernel(const float* __restrict__ x, int coff, const float* __restrict__ partial, int C,
+                                   int P, double inv_rows, double unbias,
                                    float* __restrict__ mean, float* __restrict__ var,
                                    const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
                                    float momentum, float* __restrict__ run_mean, float* __restrict__ run_var,
@@ -386,9 +393,10 @@ __global__ void stats_final_kernel(const float* __restrict__ partial, int C, int
     __syncthreads();
   }
   if (threadIdx.x == 0) {
-    const double m = r1[0] * inv_rows;
-    double v = r2[0] * inv_rows - m * m;
+    const double md = r1[0] * inv_rows;  // mean of (x - K)
+    double v = r2[0] * inv_rows - md * md;
     if (v < 0.0) v = 0.0;
+    const double m = md + (double)x[coff + c];
     mean[c] = (float)m;
     var[c] = (float)v;
     if (gamma) {
@@ -432,7 +440,7 @@ __global__ void affine_kernel(const float* __restrict__ x, int cs, int coff, lon
     float y = v[e];
     if (scale) y = y * scale[c + e] + bias[c + e];
     if (res) y += res[r * res_cs + res_coff + c + e];
-    v[e] = (act == SF_ACT_RELU) ? fmaxf(y, 0.f) : y;
+    v[e] = sf_act(y, act);
   }
   for (int q = 0; q < rep; ++q) {
     float* o = out + ((n * (THW_in / HW) * rep + t * rep + q) * HW + hw) * out_cs + out_coff + (long)c * out_cmul;
@@ -503,7 +511,7 @@ extern "C" int sf_dwconv_fwd(const sf_conv_desc* d, const float* in, const float
                              const float* bias, const float* res, float* out, void* stream) {
   if (!d || !in || !w_packed || !out || d->Cout <= 0 || d->Cout > d->Cin || d->cin_pad < d->Cin) return SF_EINVAL;
   if ((scale == nullptr) != (bias == nullptr)) return SF_EINVAL;
-  if (d->act != SF_ACT_NONE && d->act != SF_ACT_RELU) return SF_EINVAL;
+  if (d->act != SF_ACT_NONE && d->act != SF_ACT_RELU && d->act != SF_ACT_RELU6) return SF_EINVAL;
   const bool vec4 = (d->Cout % 4 == 0) && (d->in_cs % 4 == 0) && (d->in_coff % 4 == 0) && (d->cin_pad % 4 == 0) &&
                     sf_aligned16(in) && sf_aligned16(w_packed);
   const long pos = (long)d->N * d->To * d->Ho * d->Wo;
@@ -578,7 +586,7 @@ static int stats_launch(const float* x, int cs, int coff, long rows, int C, floa
   else
     hipLaunchKernelGGL(stats_partial_kernel<1>, dim3(P, sf_cdiv(cv, CB)), dim3(TPB), 0, s, x, cs, coff, rows, C, CB,
                        ws);
-  hipLaunchKernelGGL(stats_final_kernel, dim3(C), dim3(64), 0, s, ws, C, P, 1.0 / (double)rows,
+  hipLaunchKernelGGL(stats_final_kernel, dim3(C), dim3(64), 0, s, x, coff, ws, C, P, 1.0 / (double)rows,
                      rows > 1 ? (double)rows / (double)(rows - 1) : 1.0, mean, var, gamma, beta, eps, momentum,
                      run_mean, run_var, invstd, scale, shift);
   SF_CHECK_LAUNCH();
@@ -608,7 +616,7 @@ extern "C" int sf_affine_fwd(const float* x, int cs, int coff, int N, int T, int
                              int act, int rep, float* out, int out_cs, int out_coff, int out_cmul, void* stream) {
   if (!x || !out || N <= 0 || T <= 0 || H <= 0 || W <= 0 || C <= 0 || rep <= 0 || out_cmul <= 0) return SF_EINVAL;
   if ((scale == nullptr) != (bias == nullptr)) return SF_EINVAL;
-  if (act != SF_ACT_NONE && act != SF_ACT_RELU) return SF_EINVAL;
+  if (act != SF_ACT_NONE && act != SF_ACT_RELU && act != SF_ACT_RELU6) return SF_EINVAL;
   const bool vec4 = (out_cmul == 1) && (C % 4 == 0) && (cs % 4 == 0) && (coff % 4 == 0) && (out_cs % 4 == 0) &&
                     (out_coff % 4 == 0) && sf_aligned16(x) && sf_aligned16(out) &&
                     (!res || ((res_cs % 4 == 0) && (res_coff % 4 == 0) && sf_aligned16(res)));

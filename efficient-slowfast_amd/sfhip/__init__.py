@@ -16,7 +16,12 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "libsfhip.so")
 _lib = None
 
-ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_SOFTMAX, ACT_HSIGMOID = 0, 1, 2, 3, 4
+ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_SOFTMAX, ACT_HSIGMOID, ACT_RELU6 = 0, 1, 2, 3, 4, 5
+
+
+def _act(relu):
+    """relu: False/True (ReLU) or 6 (ReLU6)."""
+    return ACT_RELU6 if relu == 6 else (ACT_RELU if relu else ACT_NONE)
 _ERR = {-1: "SF_EINVAL (inconsistent descriptor)", -2: "SF_EALIGN", -3: "SF_ELAUNCH (hip launch failed)"}
 
 
@@ -233,7 +238,7 @@ def conv(x, wp, kernel, stride=(1, 1, 1), padding=(0, 0, 0), dilation=(1, 1, 1),
         assert out.coff + (cout - 1) * out_cmul < out.cs and (out_cmul > 1 or out.C == cout), (out, cout)
     d = ConvDesc(x.N, x.T, x.H, x.W, cin, x.cs, x.coff, To, Ho, Wo, cout, out.cs, out.coff, out_cmul,
                  kT, kH, kW, stride[0], stride[1], stride[2], padding[0], padding[1], padding[2],
-                 dilation[0], dilation[1], dilation[2], cin_pad, ACT_RELU if relu else ACT_NONE,
+                 dilation[0], dilation[1], dilation[2], cin_pad, _act(relu),
                  res.cs if res is not None else 0, res.coff if res is not None else 0, 0)
     if res is not None:
         assert res.rows == out.rows and res.C == cout
@@ -259,7 +264,7 @@ def dwconv(x, wp, kernel, stride=(1, 1, 1), padding=(0, 0, 0), scale=None, bias=
         assert (out.N, out.T, out.H, out.W) == (x.N, To, Ho, Wo)
     d = ConvDesc(x.N, x.T, x.H, x.W, c, x.cs, x.coff, To, Ho, Wo, cout, out.cs, out.coff, out_cmul,
                  kT, kH, kW, stride[0], stride[1], stride[2], padding[0], padding[1], padding[2], 1, 1, 1,
-                 c, ACT_RELU if relu else ACT_NONE,
+                 c, _act(relu),
                  res.cs if res is not None else 0, res.coff if res is not None else 0, 0)
     _check(lib().sf_dwconv_fwd(ctypes.byref(d), x.ptr(), _ptr(wp), _ptr(scale), _ptr(bias),
                                res.ptr() if res is not None else None, out.ptr(), _stream()), "sf_dwconv_fwd")
@@ -384,7 +389,7 @@ def affine(x, scale=None, bias=None, res=None, relu=False, rep=1, out=None, out_
         assert res.rows == x.rows and res.C == x.C
     _check(lib().sf_affine_fwd(x.ptr(), x.cs, x.coff, x.N, x.T, x.H, x.W, x.C, _ptr(scale), _ptr(bias),
                                res.ptr() if res is not None else None, res.cs if res is not None else 0,
-                               res.coff if res is not None else 0, ACT_RELU if relu else ACT_NONE, rep,
+                               res.coff if res is not None else 0, _act(relu), rep,
                                out.ptr(), out.cs, out.coff, out_cmul, _stream()), "sf_affine_fwd")
     return out
 
@@ -443,7 +448,7 @@ def bn_bwd(dy, y, z, mean, invstd, gamma, relu, rep=1, dres=None, dz_out=None, d
     ws = torch.empty((lib().sf_bn_bwd_ws_floats(C),), dtype=torch.float32, device=dev)
     yp, ycs, yco = (y.ptr(), y.cs, y.coff) if y is not None else (None, 0, 0)
     args = (dy.ptr(), dy.cs, dy.coff, yp, ycs, yco, z.ptr(), z.cs, z.coff, z.N, z.T, z.H, z.W, C, rep,
-            1 if relu else 0, _ptr(mean), _ptr(invstd))
+            2 if relu == 6 else (1 if relu else 0), _ptr(mean), _ptr(invstd))
     _check(lib().sf_bn_bwd_reduce(*args, _ptr(dbeta), _ptr(dgamma), _ptr(ws), _stream()), "sf_bn_bwd_reduce")
     out = z if dz_out is None else dz_out
     _check(lib().sf_bn_bwd_apply(*args, _ptr(gamma), _ptr(dbeta), _ptr(dgamma), out.ptr(), out.cs, out.coff,

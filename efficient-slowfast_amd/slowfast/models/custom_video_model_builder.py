@@ -9,6 +9,7 @@ from . import engine, head_helper, stem_helper
 from .batchnorm_helper import get_norm
 from .build import MODEL_REGISTRY
 from .ghostnet_helper import GhostNet_Stage, _make_divisible
+from .mobilenetv2_helper import MobileNetV2_Stage
 from .shufflenetv2_helper import ShuffleNetV2_Stage
 from .video_model_builder import _TwoPathwayResNet
 from .wdf_attention_helper import ECA, SpatialAttention
@@ -218,3 +219,66 @@ class SlowFastGhostNet(_EfficientTwoPathway):
             input_channel=[sc[4][-1][2], fc[4][-1][2]], mid_channel=[sc[4][-1][1], fc[4][-1][1]],
             output_channel=out_ch, num_classes=cfg.MODEL.NUM_CLASSES, dropout_rate=cfg.MODEL.DROPOUT_RATE,
             act_func=cfg.MODEL.HEAD_ACT)
+
+
+_MOBILE_NET_V2_CONFIGS = {  # t, c, n, s (custom_video_model_builder.py:1029-1054)
+    "slow_interverted_residual_setting": [
+        [1, 16, 1, (1, 1, 1)], [6, 24, 2, (1, 2, 2)], [6, 32, 3, (1, 2, 2)], [6, 64, 4, (1, 2, 2)],
+        [6, 96, 3, (1, 1, 1)], [6, 160, 3, (1, 2, 2)], [6, 320, 1, (1, 1, 1)]],
+    "fast_interverted_residual_setting": [
+        [1, 16, 1, (1, 1, 1)], [6, 24, 2, (1, 2, 2)], [6, 32, 3, (1, 2, 2)], [6, 64, 4, (1, 2, 2)],
+        [6, 96, 3, (1, 1, 1)], [6, 160, 3, (1, 2, 2)], [6, 320, 1, (1, 1, 1)]],
+}
+
+
+@MODEL_REGISTRY.register()
+class SlowFastMoibleNetV2(_EfficientTwoPathway):
+    """Two-pathway MobileNetV2 + CMDA (reference custom_video_model_builder.py:1057-1285, class name spelled
+    as the reference spells it); children s1, s2, s3_fuse, s4, s4_fuse, s5, s5_fuse, s6, s7, s7_fuse, s8, head."""
+
+    def __init__(self, cfg):
+        super(SlowFastMoibleNetV2, self).__init__()
+        self.norm_module = get_norm(cfg)
+        self.enable_detection = cfg.DETECTION.ENABLE
+        self.num_pathways = 2
+        self._construct_network(cfg)
+        init_helper.init_weights(self, cfg.MODEL.FC_INIT_STD, cfg.RESNET.ZERO_INIT_FINAL_BN)
+
+    def _construct_network(self, cfg):
+        wm, bi = cfg.SLOWFAST.WIDTH_MULTI, cfg.SLOWFAST.BETA_INV
+        width_per_group = 32
+        self.last_channel = int(1280 * wm) if wm > 1.0 else 1280
+        slow = _MOBILE_NET_V2_CONFIGS["slow_interverted_residual_setting"]
+        fast = _MOBILE_NET_V2_CONFIGS["fast_interverted_residual_setting"]
+        self.s1 = stem_helper.MobilenetV2_Model_Stem(
+            input_channels=[width_per_group, width_per_group], sample_size=cfg.DATA.CROP_SIZE,
+            width_mult=[wm, wm / bi], img_dim=len(cfg.DATA.MEAN))
+
+        def stage(inp, a, b):
+            return MobileNetV2_Stage(input_channel=inp, slow_residual_setting=slow[a:b],
+                                     fast_residual_setting=fast[a:b], width_mult=wm, beta_inv=bi)
+
+        def fuse(row):
+            return FuseFastAndSlow(dim_in=[int(slow[row][1] * wm), int(slow[row][1] * wm) // bi],
+                                   alpha=cfg.SLOWFAST.ALPHA, beta_inv=bi, norm_module=self.norm_module)
+
+        def fused_in(row):  # channel counts after the CMDA that follows settings row `row`
+            c = slow[row][1] * wm
+            return [int(c + c // bi), int(c // bi + c // bi)]
+
+        self.s2 = stage([int(width_per_group * wm), int(width_per_group * wm // bi)], 0, 2)
+        self.s3_fuse = fuse(1)
+        self.s4 = stage(fused_in(1), 2, 3)
+        self.s4_fuse = fuse(2)
+        self.s5 = stage(fused_in(2), 3, 4)
+        self.s5_fuse = fuse(3)
+        self.s6 = stage(fused_in(3), 4, 5)
+        self.s7 = stage([int(slow[4][1] * wm), int(slow[4][1] * wm // bi)], 5, 6)
+        self.s7_fuse = fuse(5)
+        self.s8 = stage(fused_in(5), 6, 7)
+        if cfg.DETECTION.ENABLE:
+            raise NotImplementedError("DETECTION.ENABLE is out of scope of the HIP path")
+        self.head = head_helper.MobileNetV2BasicHead(
+            input_channel=[int(slow[6][1] * wm), int(slow[6][1] * wm // bi)],
+            last_channel=[self.last_channel, self.last_channel // bi], num_classes=cfg.MODEL.NUM_CLASSES,
+            dropout_rate=cfg.MODEL.DROPOUT_RATE, act_func=cfg.MODEL.HEAD_ACT)

@@ -114,6 +114,39 @@ def _global_mean(x, out=None):
     return engine.global_mean(x, out)
 
 
+class MobileNetV2BasicHead(nn.Module):
+    """per pathway 1x1x1 conv+BN+ReLU6 -> global avg-pool -> cat -> Dropout+Linear -> eval softmax+mean
+    (head_helper.py:436-486)."""
+
+    def __init__(self, input_channel, last_channel, num_classes, dropout_rate, act_func="softmax"):
+        super(MobileNetV2BasicHead, self).__init__()
+        self.num_pathways = len(input_channel)
+        for pathway in range(self.num_pathways):
+            seq = nn.Sequential(nn.Conv3d(input_channel[pathway], last_channel[pathway], 1, 1, 0, bias=False),
+                                nn.BatchNorm3d(last_channel[pathway]), nn.ReLU6(inplace=True))
+            self.add_module("pathway{}_conv1x1x1".format(pathway), seq)
+        if act_func == "softmax":
+            self.act = nn.Softmax(dim=4)
+        elif act_func == "sigmoid":
+            self.act = nn.Sigmoid()
+        self._act_name = act_func
+        self.classifier = nn.Sequential(nn.Dropout(dropout_rate), nn.Linear(sum(last_channel), num_classes, bias=True))
+
+    def forward(self, inputs):
+        xs = engine.enter(inputs)
+        outs = []
+        for pathway, x in enumerate(xs):
+            seq = getattr(self, "pathway{}_conv1x1x1".format(pathway))
+            outs.append(engine.conv_bn_act(x, seq[0], seq[1], relu=6))
+        cat = sfhip.new_act(outs[0], outs[0].N, 1, 1, 1, sum(o.C for o in outs))
+        off = 0
+        for o in outs:
+            _global_mean(o, cat.slice(off, o.C))
+            off += o.C
+        logits = _project(cat, self.classifier[1], self.classifier[0], self.training)
+        return _finish(logits, self.training, self._act_name)
+
+
 class ShuffleNetV2BasicHead(nn.Module):
     """per pathway 1x1x1 conv+BN+ReLU -> global avg-pool -> cat -> Dropout+Linear -> eval softmax+mean
     (head_helper.py:499-557)."""

@@ -57,12 +57,13 @@ class SimpleStem(nn.Module):
     '2' ReLU (, '3' MaxPool3d(3,(1,2,2),1)) — shufflenetv2_stem (stem_helper.py:237-245) and the GhostNet
     stem (stem_helper.py:318-327) share it."""
 
-    def __init__(self, img_dim, dim_out, with_pool):
+    def __init__(self, img_dim, dim_out, with_pool, relu6=False):
         super(SimpleStem, self).__init__()
+        self.act = 6 if relu6 else True
         self.add_module("0", nn.Conv3d(img_dim, dim_out, kernel_size=3, stride=(1, 2, 2), padding=(1, 1, 1),
                                        bias=False))
         self.add_module("1", nn.BatchNorm3d(dim_out))
-        self.add_module("2", nn.ReLU(inplace=True))
+        self.add_module("2", nn.ReLU6(inplace=True) if relu6 else nn.ReLU(inplace=True))
         if with_pool:
             self.add_module("3", nn.MaxPool3d(kernel_size=3, stride=(1, 2, 2), padding=1))
         self.with_pool = with_pool
@@ -70,12 +71,12 @@ class SimpleStem(nn.Module):
     def forward(self, x, reserve=(0, 0)):
         conv, bn = self._modules["0"], self._modules["1"]
         if not self.with_pool:
-            y = engine.stem_conv_bn_relu(x, conv, bn, relu=True)
+            y = engine.stem_conv_bn_relu(x, conv, bn, relu=self.act)
             if reserve != (0, 0):
                 wide = sfhip.new_act(y, y.N, y.T, y.H, y.W, y.C, reserve[0], reserve[1])
                 return engine.copy_channels(y, wide)
             return y
-        y = engine.stem_conv_bn_relu(x, conv, bn, relu=True)
+        y = engine.stem_conv_bn_relu(x, conv, bn, relu=self.act)
         return engine.maxpool(y, (3, 3, 3), (1, 2, 2), (1, 1, 1), out_reserve=reserve)
 
 
@@ -108,3 +109,31 @@ class GhostNet_Model_Stem(_EfficientStem):
 
     def __init__(self, input_channels=[32, ], sample_size=224, img_dim=3):
         super(GhostNet_Model_Stem, self).__init__(input_channels, img_dim, False)
+
+
+class MobilenetV2_Basic_Stem(nn.Module):
+    """features = conv 3x3x3 /(1,2,2) -> BN -> ReLU6 with int(input_channel * width_mult) filters
+    (stem_helper.py:181-200)."""
+
+    def __init__(self, input_channel=32, sample_size=224, width_mult=1., img_dim=3):
+        super(MobilenetV2_Basic_Stem, self).__init__()
+        assert sample_size % 16 == 0.
+        self.features = SimpleStem(img_dim, int(input_channel * width_mult), False, relu6=True)
+
+    def forward(self, x, reserve=(0, 0)):
+        return self.features(x, reserve)
+
+
+class MobilenetV2_Model_Stem(nn.Module):
+    """stem_helper.py:202-232."""
+
+    def __init__(self, input_channels=[32], sample_size=224, width_mult=[1.], img_dim=3):
+        super(MobilenetV2_Model_Stem, self).__init__()
+        if len(input_channels) != len(width_mult):
+            width_mult = width_mult * len(input_channels)
+        self.num_pathways = len(input_channels)
+        for pathway in range(self.num_pathways):
+            self.add_module("pathway{}_stem".format(pathway),
+                            MobilenetV2_Basic_Stem(input_channels[pathway], sample_size, width_mult[pathway], img_dim))
+
+    forward = _EfficientStem.forward

@@ -29,6 +29,7 @@ extern "C" {
 #define SF_ACT_SIGMOID 2      /* head only */
 #define SF_ACT_SOFTMAX 3      /* head only */
 #define SF_ACT_HSIGMOID 4     /* relu6(x+3)/6, ghostnet_helper.py:27-31 */
+#define SF_ACT_RELU6 5        /* min(max(x,0),6), mobilenetv2_helper.py:15-30 */
 
 int sf_abi_version(void);
 /* Name of the gfx target the library was built for ("gfx950"). */
@@ -60,7 +61,7 @@ typedef struct sf_conv_desc {
                                /* shuffle folded into index math, shufflenetv2_helper.py:32-43)   */
   int kT, kH, kW, sT, sH, sW, pT, pH, pW, dT, dH, dW;
   int cin_pad;                 /* packed weight row length per tap                                */
-  int act;                     /* SF_ACT_NONE | SF_ACT_RELU                                       */
+  int act;                     /* SF_ACT_NONE | SF_ACT_RELU | SF_ACT_RELU6                        */
   int res_cs, res_coff;        /* residual pitch / offset (used when res != NULL)                 */
   int transposed;              /* 1: data-gradient of the conv described by k/s/p/d: "in" is dL/dz with   */
                                /* dims (Ti,Hi,Wi) = the forward OUTPUT dims, "out" is dL/dx with dims     */

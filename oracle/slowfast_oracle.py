@@ -378,11 +378,80 @@ def ghostnet_forward(sd, inputs, hp, training=False):
     return acts
 
 
+# ----------------------------------------------------------------------------- MobileNetV2
+MOBILENETV2_SETTINGS = [  # custom_video_model_builder.py:1028-1047: t, c, n, stride
+    [1, 16, 1, (1, 1, 1)], [6, 24, 2, (1, 2, 2)], [6, 32, 3, (1, 2, 2)], [6, 64, 4, (1, 2, 2)],
+    [6, 96, 3, (1, 1, 1)], [6, 160, 3, (1, 2, 2)], [6, 320, 1, (1, 1, 1)],
+]
+MOBILENETV2_STAGES = [("s2", 0, 2), ("s4", 2, 3), ("s5", 3, 4), ("s6", 4, 5), ("s7", 5, 6), ("s8", 6, 7)]
+MOBILENETV2_FUSE_AFTER = {"s2": "s3_fuse", "s4": "s4_fuse", "s5": "s5_fuse", "s7": "s7_fuse"}
+
+
+def _relu6(x):
+    return F.relu6(x)
+
+
+def mbv2_block(sd, p, x, inp, oup, stride, t, training):
+    """mobilenetv2_helper.py:30-68 InvertedResidual."""
+    hidden = int(round(inp * t))
+    q = p + ".conv"
+    y = x
+    i = 0
+    if t != 1:
+        y = _relu6(_bn(sd, "%s.1" % q, _conv(sd, "%s.0" % q, y), training))
+        i = 3
+    y = _relu6(_bn(sd, "%s.%d" % (q, i + 1), _conv(sd, "%s.%d" % (q, i), y, stride, 1, 1, hidden), training))
+    y = _bn(sd, "%s.%d" % (q, i + 4), _conv(sd, "%s.%d" % (q, i + 3), y), training)
+    if tuple(stride) == (1, 1, 1) and inp == oup:
+        y = x + y
+    return y
+
+
+def mobilenetv2_forward(sd, inputs, hp, training=False):
+    """SlowFastMoibleNetV2, custom_video_model_builder.py:1058-1285."""
+    wm, bi = hp["width_multi"], hp["beta_inv"]
+    acts = {}
+    x = [_relu6(_bn(sd, "s1.pathway%d_stem.features.1" % pw,
+                    _conv(sd, "s1.pathway%d_stem.features.0" % pw, inputs[pw], (1, 2, 2), 1), training))
+         for pw in range(2)]
+    acts["s1"] = x
+    for name, a, b in MOBILENETV2_STAGES:
+        nxt = []
+        for pw in range(2):
+            z = x[pw]
+            inp = z.shape[1]
+            q = "%s.pathway%d_channel_%d.features" % (name, pw, MOBILENETV2_SETTINGS[a][1])
+            idx = 0
+            for t, c, n, s in MOBILENETV2_SETTINGS[a:b]:
+                oup = int(c * wm) if pw == 0 else int(c * wm // bi)
+                for i in range(n):
+                    z = mbv2_block(sd, "%s.%d" % (q, idx), z, inp, oup, s if i == 0 else (1, 1, 1), t, training)
+                    inp = oup
+                    idx += 1
+            nxt.append(z)
+        x = nxt
+        acts[name] = x
+        if name in MOBILENETV2_FUSE_AFTER:
+            f = MOBILENETV2_FUSE_AFTER[name]
+            x = fuse_fast_and_slow(sd, f, x, hp, training)
+            acts[f] = x
+    pooled = []  # head_helper.py:436-486
+    for pw in range(2):
+        z = _relu6(_bn(sd, "head.pathway%d_conv1x1x1.1" % pw, _conv(sd, "head.pathway%d_conv1x1x1.0" % pw, x[pw]),
+                       training))
+        pooled.append(z.mean((2, 3, 4), keepdim=True))
+    z = torch.cat(pooled, 1).permute(0, 2, 3, 4, 1)
+    logits = F.linear(z, sd["head.classifier.1.weight"], sd["head.classifier.1.bias"])
+    acts["logits"], acts["out"] = logits, _head_tail(logits, training, hp["head_act"])
+    return acts
+
+
 FORWARDS = {
     "SlowFast": lambda sd, x, hp, training=False: slowfast_forward(sd, x, hp, False, training),
     "SlowFastDualAttention": lambda sd, x, hp, training=False: slowfast_forward(sd, x, hp, True, training),
     "SlowFastShuffleNetV2": shufflenetv2_forward,
     "SlowFastGhostNet": ghostnet_forward,
+    "SlowFastMoibleNetV2": mobilenetv2_forward,
 }
 
 

@@ -48,6 +48,10 @@ CASES = [
     dict(name="ghostnet_w2_s64", yaml="SLOWFAST_GHOSTNET_8x8_R50_stepwise_multigrid.yaml",
          model="SlowFastGhostNet", batch=1, t=16, alpha=4, size=64,
          over=["SLOWFAST.WIDTH_MULTI", 2.0, "SLOWFAST.ALPHA", 4] + small(64, 16)),
+    # SlowFastMoibleNetV2 (sic) w1.0 + CMDA at S=64, T=16
+    dict(name="mobilenetv2_w1_s64", yaml="SLOWFAST_MOBILENETV2_8x8_R50_stepwise_multigrid.yaml",
+         model="SlowFastMoibleNetV2", batch=2, t=16, alpha=4, size=64,
+         over=["SLOWFAST.WIDTH_MULTI", 1.0, "SLOWFAST.ALPHA", 4] + small(64, 16)),
 ]
 
 GRAD_KEYS = {
@@ -60,6 +64,9 @@ GRAD_KEYS = {
                               "head.projection.weight"],
     "SlowFastShuffleNetV2": ["s1.pathway0_stem.0.weight", "s2_fuse.attention_spatial_s2f.value_conv.weight",
                              "s3.pathway0_channel_64.features.1.banch2.3.weight", "head.classifier.1.weight"],
+    "SlowFastMoibleNetV2": ["s1.pathway0_stem.features.0.weight", "s4.pathway0_channel_32.features.1.conv.3.weight",
+                            "s5_fuse.attention_spatial_s2f.gamma", "s7.pathway1_channel_160.features.0.conv.0.weight",
+                            "head.classifier.1.weight"],
     "SlowFastGhostNet": ["s0.pathway0_stem.0.weight", "s3.pathway0_channel_80.features.0.se.conv_reduce.weight",
                          "s2_fuse.attention_spatial_s2f.gamma", "head.classifier.1.weight"],
 }

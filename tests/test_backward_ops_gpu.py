@@ -52,6 +52,8 @@ CONV_CASES = [
     ("pw_8_24", 8, 24, (1, 1, 1), (1, 1, 1), (0, 0, 0), (2, 4, 9, 9)),
     ("odd_27_16", 27, 16, (1, 1, 1), (1, 1, 1), (0, 0, 0), (2, 4, 5, 5)),
     ("fc_2304_400", 2304, 400, (1, 1, 1), (1, 1, 1), (0, 0, 0), (8, 1, 1, 1)),
+    ("head_320_1280_m32", 320, 1280, (1, 1, 1), (1, 1, 1), (0, 0, 0), (2, 4, 2, 2)),
+    ("pw_96_16_m32", 96, 16, (1, 1, 1), (1, 1, 1), (0, 0, 0), (2, 4, 2, 2)),
 ]
 
 
@@ -100,20 +102,25 @@ def test_stem_trick_wgrad():
     assert _rel(dw, dw_ref) < TOL
 
 
-@pytest.mark.parametrize("c,relu,use_res,rep", [(64, True, True, 1), (8, True, False, 1), (27, False, False, 1),
-                                                (32, True, False, 4), (300, True, True, 1)])
-def test_bn_backward(c, relu, use_res, rep):
+@pytest.mark.parametrize("c,relu,use_res,rep,hw", [
+    (64, True, True, 1, (6, 5)), (8, True, False, 1, (6, 5)), (27, False, False, 1, (6, 5)),
+    (32, True, False, 4, (6, 5)), (300, True, True, 1, (6, 5)), (48, 6, False, 1, (6, 5)), (1280, 6, False, 1, (2, 2)),
+    (18, 6, True, 1, (3, 3))])
+def test_bn_backward(c, relu, use_res, rep, hw):
     import sfhip
     dev = _dev()
     g = torch.Generator().manual_seed(c + rep)
-    z = (torch.randn(2, c, 4, 6, 5, generator=g) * 1.5 + 0.3).requires_grad_(True)
-    gamma = (torch.rand(c, generator=g) + 0.5).requires_grad_(True)
-    beta = (torch.randn(c, generator=g) * 0.1).requires_grad_(True)
-    res = torch.randn(2, c, 4, 6, 5, generator=g).requires_grad_(True) if use_res else None
+    shp = (2, c, 4) + hw
+    z = (torch.randn(shp, generator=g) * 1.5 + 0.3).requires_grad_(True)
+    gamma = (torch.rand(c, generator=g) + (2.5 if relu == 6 else 0.5)).requires_grad_(True)  # relu6: saturate some
+    beta = (torch.randn(c, generator=g) * 0.1 + (2.0 if relu == 6 else 0.0)).requires_grad_(True)
+    res = torch.randn(shp, generator=g).requires_grad_(True) if use_res else None
     y = F.batch_norm(z, None, None, gamma, beta, True, 0.0, 1e-5)
     if use_res:
         y = y + res
-    if relu:
+    if relu == 6:
+        y = F.relu6(y)
+    elif relu:
         y = F.relu(y)
     y = y.repeat_interleave(rep, dim=2)
     dy = torch.randn(y.shape, generator=g)
@@ -121,14 +128,14 @@ def test_bn_backward(c, relu, use_res, rep):
     za = _act(z)
     mean, var = sfhip.channel_stats(za)
     invstd = torch.rsqrt(var + 1e-5)
-    dres = sfhip.Act(torch.zeros(2, 4, 6, 5, c, device=dev)) if use_res else None
+    dres = sfhip.Act(torch.zeros((2, 4) + hw + (c,), device=dev)) if use_res else None
     dz, dgamma, dbeta = sfhip.bn_bwd(_act(dy), _act(y), za, mean, invstd, gamma.detach().to(dev), relu, rep=rep,
                                      dres=dres)
     torch.cuda.synchronize()
     errs = [_rel(_back(dz), outs[0]), _rel(dgamma, outs[1]), _rel(dbeta, outs[2])]
     if use_res:
         errs.append(_rel(_back(dres), outs[3]))
-    _report("bn_bwd c%d relu%d res%d rep%d" % (c, relu, use_res, rep), max(errs))
+    _report("bn_bwd c%d relu%d res%d rep%d hw%s" % (c, relu, use_res, rep, hw), max(errs))
     assert max(errs) < TOL, errs
 
 

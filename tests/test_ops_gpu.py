@@ -286,6 +286,25 @@ def test_head_act_mean():
         assert _rel(out, ref) < 1e-5
 
 
+@pytest.mark.parametrize("c,shape", [(16, (2, 4, 6, 6)), (7, (2, 4, 5, 3)), (320, (2, 4, 2, 2)), (64, (4, 8, 28, 28))])
+def test_channel_stats_are_robust_to_large_mean(c, shape):
+    """Train-mode BN statistics on channels with |mean| >> std: the variance must not lose digits to
+    E[x^2] - E[x]^2 cancellation (torch's CPU kernel is two-pass)."""
+    import sfhip
+    g = torch.Generator().manual_seed(c)
+    n, t, h, w = shape
+    mu = torch.randn(c, generator=g) * 30.0
+    sd = torch.rand(c, generator=g) * 0.05 + 0.005
+    x = (torch.randn(n, t, h, w, c, generator=g) * sd + mu).float()
+    mean, var = sfhip.channel_stats(sfhip.Act(x.to(_dev())))
+    torch.cuda.synchronize()
+    xd = x.double().reshape(-1, c)
+    e1 = float(((mean.double().cpu() - xd.mean(0)).abs() / xd.std(0, unbiased=False)).max())
+    e2 = float(((var.double().cpu() - xd.var(0, unbiased=False)).abs() / xd.var(0, unbiased=False)).max())
+    _report("channel_stats large-mean c%d rows%d" % (c, n * t * h * w), max(e1, e2))
+    assert e1 < 1e-3 and e2 < 1e-4, (e1, e2)
+
+
 def test_copy_channels_shuffle():
     import sfhip
     dev = _dev()

@@ -44,3 +44,12 @@ for k, p in params.items():
     a[1] += float(sdr[k].grad.norm()) ** 2 if sdr[k].grad is not None else 0.0
 for k, (a, b) in agg.items():
     print("%-40s mine %.4e  ref %.4e" % (k, a ** 0.5, b ** 0.5))
+if len(sys.argv) > 2 and sys.argv[2] == "all":
+    byk = {k: (e, a, b) for e, k, a, b in worst}
+    for k in params:
+        if k in byk and not k.endswith(".bias"):
+            print("%.3e %-62s %.5e %.5e" % ((byk[k][0], k) + byk[k][1:]))
+if len(sys.argv) > 3:
+    keys = sys.argv[3].split(",")
+    os.makedirs(ROOT + "/gpurun_out", exist_ok=True)
+    np.savez(ROOT + "/gpurun_out/dbg_grads.npz", **{k: params[k].grad.cpu().numpy() for k in keys})
