@@ -309,6 +309,21 @@ __global__ void axpy_kernel(const float* __restrict__ a, int a_cs, int a_coff, f
   *o = accumulate ? *o + v : v;
 }
 
+// dx[r, c] (+)= dy[r, c] * [0 < y[r, c] (< 6)]   (backward of a bare ReLU / ReLU6, mask taken from its output)
+__global__ void act_bwd_kernel(const float* __restrict__ dy, int dy_cs, int dy_coff, const float* __restrict__ y,
+                               int y_cs, int y_coff, int act, float* __restrict__ dx, int dx_cs, int dx_coff, int C,
+                               int accumulate, long total) {
+  const long idx = (long)blockIdx.x * TPB + threadIdx.x;
+  if (idx >= total) return;
+  const int c = (int)(idx % C);
+  const long r = idx / C;
+  const float yv = y[r * y_cs + y_coff + c];
+  const bool pass = (yv > 0.f) && (act != SF_ACT_RELU6 || yv < 6.f);
+  const float v = pass ? dy[r * dy_cs + dy_coff + c] : 0.f;
+  float* o = dx + r * dx_cs + dx_coff + c;
+  *o = accumulate ? *o + v : v;
+}
+
 }  // namespace
 
 constexpr int MAX_P = 1024;
@@ -434,6 +449,17 @@ extern "C" int sf_axpy(const float* a, int a_cs, int a_coff, float alpha, float*
   const long total = rows * C;
   hipLaunchKernelGGL(axpy_kernel, dim3(sf_cdiv(total, TPB)), dim3(TPB), 0, (hipStream_t)stream, a, a_cs, a_coff, alpha,
                      out, out_cs, out_coff, C, accumulate, total);
+  SF_CHECK_LAUNCH();
+  return SF_OK;
+}
+
+extern "C" int sf_act_bwd(const float* dy, int dy_cs, int dy_coff, const float* y, int y_cs, int y_coff, int act,
+                          float* dx, int dx_cs, int dx_coff, long rows, int C, int accumulate, void* stream) {
+  if (!dy || !y || !dx || rows <= 0 || C <= 0) return SF_EINVAL;
+  if (act != SF_ACT_RELU && act != SF_ACT_RELU6) return SF_EINVAL;
+  const long total = rows * C;
+  hipLaunchKernelGGL(act_bwd_kernel, dim3(sf_cdiv(total, TPB)), dim3(TPB), 0, (hipStream_t)stream, dy, dy_cs, dy_coff,
+                     y, y_cs, y_coff, act, dx, dx_cs, dx_coff, C, accumulate, total);
   SF_CHECK_LAUNCH();
   return SF_OK;
 }

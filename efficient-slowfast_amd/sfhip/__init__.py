@@ -47,7 +47,7 @@ EXPORTS = [
     "sf_pool_fwd", "sf_tmax_mean_ws_floats", "sf_tmax_mean", "sf_gate_apply", "sf_attn_fwd", "sf_head_act_mean",
     "sf_copy_channels", "sf_channel_stats_ws_floats", "sf_channel_stats", "sf_affine_fwd", "sf_bn_train_stats",
     "sf_conv_wgrad_splits", "sf_conv_wgrad", "sf_bn_bwd_ws_floats", "sf_bn_bwd_reduce", "sf_bn_bwd_apply",
-    "sf_attn_bwd", "sf_maxpool_bwd", "sf_tmax_dot", "sf_eca_bwd_apply", "sf_bcast_add", "sf_rowdot", "sf_axpy",
+    "sf_attn_bwd", "sf_maxpool_bwd", "sf_tmax_dot", "sf_eca_bwd_apply", "sf_bcast_add", "sf_rowdot", "sf_axpy", "sf_act_bwd",
     "sf_dwconv_dgrad", "sf_dwconv_wgrad_ws_floats", "sf_dwconv_wgrad", "sf_gather_add",
 ]
 _LONG_RET = ("sf_tmax_mean_ws_floats", "sf_channel_stats_ws_floats", "sf_bn_bwd_ws_floats",
@@ -102,6 +102,7 @@ def lib():
         L.sf_bcast_add.argtypes = [vp, ci, ci, ci, cl, ci, vp, cf, vp]
         L.sf_rowdot.argtypes = [vp, ci, ci, vp, ci, ci, cl, ci, cf, vp, vp]
         L.sf_axpy.argtypes = [vp, ci, ci, cf, vp, ci, ci, cl, ci, ci, vp]
+        L.sf_act_bwd.argtypes = [vp, ci, ci, vp, ci, ci, ci, vp, ci, ci, cl, ci, ci, vp]
         L.sf_dwconv_dgrad.argtypes = [ctypes.POINTER(ConvDesc), vp, ci, ci, vp, vp, ci, ci, ci, vp]
         L.sf_dwconv_wgrad_ws_floats.argtypes = [ctypes.POINTER(ConvDesc), ci]
         L.sf_dwconv_wgrad_ws_floats.restype = cl
@@ -503,6 +504,14 @@ def axpy(a, out, alpha=1.0, accumulate=True):
     return out
 
 
+def act_bwd(dy, y, relu, dx, accumulate=True):
+    """dx (+)= dy * [0 < y (< 6)] — backward of a bare ReLU (relu=True) / ReLU6 (relu=6)."""
+    assert dy.rows == y.rows == dx.rows and dy.C == y.C == dx.C
+    _check(lib().sf_act_bwd(dy.ptr(), dy.cs, dy.coff, y.ptr(), y.cs, y.coff, _act(relu), dx.ptr(), dx.cs, dx.coff,
+                            dy.rows, dy.C, 1 if accumulate else 0, _stream()), "sf_act_bwd")
+    return dx
+
+
 def attention_bwd(q, k, v, dz, o, lse, gamma, dq, dk, dv):
     """dq/dk/dv (Act slices, overwritten) of the flash SpatialAttention; returns dvec[i] = <dz_i, O_i>
     (its sum is dL/dgamma)."""
@@ -553,6 +562,14 @@ def dwconv_bwd(x, dz, wp, kernel, stride, padding, dx=None):
         _check(lib().sf_dwconv_dgrad(ctypes.byref(d), dz.ptr(), dz.cs, dz.coff, _ptr(wp), dx.ptr(), dx.cs, dx.coff,
                                      C, _stream()), "sf_dwconv_dgrad")
     return dw
+
+
+def dwconv_dgrad(x, dz, wp, kernel, stride, padding, dx):
+    """dx += transposed depthwise conv of dz (data gradient only: constant-weight pooling)."""
+    d = _dw_desc(x, dz, kernel, stride, padding)
+    _check(lib().sf_dwconv_dgrad(ctypes.byref(d), dz.ptr(), dz.cs, dz.coff, _ptr(wp), dx.ptr(), dx.cs, dx.coff,
+                                 x.C, _stream()), "sf_dwconv_dgrad")
+    return dx
 
 
 def gather_add(src, src_cmul, out, accumulate=True):

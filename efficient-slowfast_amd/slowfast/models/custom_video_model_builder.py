@@ -10,6 +10,7 @@ from .batchnorm_helper import get_norm
 from .build import MODEL_REGISTRY
 from .ghostnet_helper import GhostNet_Stage, _make_divisible
 from .mobilenetv2_helper import MobileNetV2_Stage
+from .shufflenet_helper import ShuffleNet_Stage
 from .shufflenetv2_helper import ShuffleNetV2_Stage
 from .video_model_builder import _TwoPathwayResNet
 from .wdf_attention_helper import ECA, SpatialAttention
@@ -281,4 +282,50 @@ class SlowFastMoibleNetV2(_EfficientTwoPathway):
         self.head = head_helper.MobileNetV2BasicHead(
             input_channel=[int(slow[6][1] * wm), int(slow[6][1] * wm // bi)],
             last_channel=[self.last_channel, self.last_channel // bi], num_classes=cfg.MODEL.NUM_CLASSES,
+            dropout_rate=cfg.MODEL.DROPOUT_RATE, act_func=cfg.MODEL.HEAD_ACT)
+
+
+@MODEL_REGISTRY.register()
+class SlowFastShuffleNet(_EfficientTwoPathway):
+    """Two-pathway ShuffleNet v1 + CMDA (reference custom_video_model_builder.py:620-789); children s1, s1_fuse,
+    s2, s2_fuse, s3, s3_fuse, s4, s4_fuse, head."""
+
+    _OUT_PLANES = {1: [24, 144, 288, 567], 2: [24, 200, 400, 800], 3: [24, 240, 480, 960],
+                   4: [24, 272, 544, 1088], 8: [24, 384, 768, 1536]}
+
+    def __init__(self, cfg):
+        super(SlowFastShuffleNet, self).__init__()
+        self.norm_module = get_norm(cfg)
+        self.enable_detection = cfg.DETECTION.ENABLE
+        self.num_pathways = 2
+        width_mult = cfg.SLOWFAST.WIDTH_MULTI
+        groups = cfg.SLOWFAST.GROUPS
+        self.num_blocks = [4, 8, 4]
+        self.groups = groups
+        if groups not in self._OUT_PLANES:
+            raise ValueError("{} groups is not supported for 1x1 Grouped Convolutions".format(groups))
+        out_planes = self._OUT_PLANES[groups]
+        self.stage_out_channels = [int(i * width_mult) for i in out_planes]
+        self.fast_stage_out_channels = [c // cfg.SLOWFAST.BETA_INV for c in self.stage_out_channels]
+        self.in_planes = out_planes[0]
+        self._construct_network(cfg)
+        init_helper.init_weights(self, cfg.MODEL.FC_INIT_STD, cfg.RESNET.ZERO_INIT_FINAL_BN)
+
+    def _construct_network(self, cfg):
+        so, fo, bi = self.stage_out_channels, self.fast_stage_out_channels, cfg.SLOWFAST.BETA_INV
+        self.s1 = stem_helper.ShuffleNet_Model_Stem(input_channels=[so[0], fo[0]], sample_size=cfg.DATA.CROP_SIZE,
+                                                    img_dim=len(cfg.DATA.MEAN))
+        for i in range(4):
+            fuse = FuseFastAndSlow(dim_in=[so[i], fo[i]], alpha=cfg.SLOWFAST.ALPHA, beta_inv=bi,
+                                   norm_module=self.norm_module)
+            setattr(self, "s{}_fuse".format(i + 1), fuse)
+            if i < 3:
+                stage = ShuffleNet_Stage(input_channel=[so[i] + fo[i], fo[i] + so[i] // bi],
+                                         slow_stage_out_channels=so[i + 1], fast_stage_out_channels=fo[i + 1],
+                                         num_block=self.num_blocks[i], group=cfg.SLOWFAST.GROUPS)
+                setattr(self, "s{}".format(i + 2), stage)
+        if cfg.DETECTION.ENABLE:
+            raise NotImplementedError("DETECTION.ENABLE is out of scope of the HIP path")
+        self.head = head_helper.ShuffleNetBasicHead(
+            input_channel=[so[3] + fo[3], fo[3] + so[3] // bi], num_classes=cfg.MODEL.NUM_CLASSES,
             dropout_rate=cfg.MODEL.DROPOUT_RATE, act_func=cfg.MODEL.HEAD_ACT)

@@ -257,9 +257,15 @@ def conv_bn_act(x, conv, bn=None, relu=False, res=None, out=None, out_reserve=(0
                        out_reserve=out_reserve, out_cmul=out_cmul)
         t = tape()
         if t is not None:
-            if bn is not None or relu or res is not None or out_cmul != 1:
-                raise NotImplementedError("taped conv with a folded (eval-mode) BN / activation epilogue")
-            _record_conv(x, conv.weight, conv.bias, wp.shape, lambda: t.grad_of(y), k, s, p, d)
+            if bn is not None or res is not None or out_cmul != 1:
+                raise NotImplementedError("taped conv with a folded (eval-mode) BN / residual epilogue")
+            if relu:  # bare conv + ReLU (no BN): dL/dz = dL/dy masked by the activation's output
+                def masked():
+                    dz = sfhip.new_act(y, y.N, y.T, y.H, y.W, y.C)
+                    return sfhip.act_bwd(t.grad_of(y), y, relu, dz, accumulate=False)
+                _record_conv(x, conv.weight, conv.bias, wp.shape, masked, k, s, p, d)
+            else:
+                _record_conv(x, conv.weight, conv.bias, wp.shape, lambda: t.grad_of(y), k, s, p, d)
         return y
     assert d == (1, 1, 1)
     if scale is None and bias is not None:
@@ -379,6 +385,21 @@ def add_into(a, res, out):
             sfhip.axpy(g, t.grad_of(res), 1.0, accumulate=True)
         t.record(bwd)
     return out
+
+
+def avgpool(x, kernel, stride, padding):
+    """nn.AvgPool3d(kernel, stride, padding) with count_include_pad=True: a depthwise conv whose taps are all
+    1/|kernel| (zero padding == counting the pad).  Taped: the data gradient is the transposed gather."""
+    taps = kernel[0] * kernel[1] * kernel[2]
+    w = _PCACHE.get(("avgpool", taps, x.C, str(x.buf.device)))
+    if w is None:
+        w = torch.full((taps, x.C), 1.0 / taps, dtype=torch.float32, device=x.buf.device)
+        _PCACHE[("avgpool", taps, x.C, str(x.buf.device))] = w
+    y = sfhip.dwconv(x, w, kernel, stride, padding)
+    t = tape()
+    if t is not None:
+        t.record(lambda: sfhip.dwconv_dgrad(x, t.grad_of(y), w, kernel, stride, padding, t.grad_of(x)))
+    return y
 
 
 def global_mean(x, out=None):

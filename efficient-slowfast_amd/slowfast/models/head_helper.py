@@ -147,6 +147,30 @@ class MobileNetV2BasicHead(nn.Module):
         return _finish(logits, self.training, self._act_name)
 
 
+class ShuffleNetBasicHead(nn.Module):
+    """global avg-pool per pathway -> cat -> Dropout+Linear -> eval softmax+mean (head_helper.py:562-609)."""
+
+    def __init__(self, input_channel, num_classes, dropout_rate, act_func="softmax"):
+        super(ShuffleNetBasicHead, self).__init__()
+        self.num_pathways = len(input_channel)
+        if act_func == "softmax":
+            self.act = nn.Softmax(dim=4)
+        elif act_func == "sigmoid":
+            self.act = nn.Sigmoid()
+        self._act_name = act_func
+        self.classifier = nn.Sequential(nn.Dropout(dropout_rate), nn.Linear(sum(input_channel), num_classes, bias=True))
+
+    def forward(self, inputs):
+        xs = engine.enter(inputs)
+        cat = sfhip.new_act(xs[0], xs[0].N, 1, 1, 1, sum(x.C for x in xs))
+        off = 0
+        for x in xs:
+            _global_mean(x, cat.slice(off, x.C))
+            off += x.C
+        logits = _project(cat, self.classifier[1], self.classifier[0], self.training)
+        return _finish(logits, self.training, self._act_name)
+
+
 class ShuffleNetV2BasicHead(nn.Module):
     """per pathway 1x1x1 conv+BN+ReLU -> global avg-pool -> cat -> Dropout+Linear -> eval softmax+mean
     (head_helper.py:499-557)."""

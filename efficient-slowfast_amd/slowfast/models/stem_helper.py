@@ -104,6 +104,16 @@ class ShuffleNetV2_Model_Stem(_EfficientStem):
         super(ShuffleNetV2_Model_Stem, self).__init__(input_channels, img_dim, True)
 
 
+class ShuffleNet_Model_Stem(_EfficientStem):
+    """stem_helper.py:274-306 (conv 3x3x3 /(1,2,2) + BN + ReLU + MaxPool3d 3 /(1,2,2); prints its arguments as the
+    reference does)."""
+
+    def __init__(self, input_channels=[32], sample_size=224, img_dim=3):
+        for c in input_channels:
+            print(img_dim, c, (1, 2, 2))
+        super(ShuffleNet_Model_Stem, self).__init__(input_channels, img_dim, True)
+
+
 class GhostNet_Model_Stem(_EfficientStem):
     """stem_helper.py:310-336 (no max-pool: s1_fuse sees S/2)."""
 

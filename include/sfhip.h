@@ -209,6 +209,11 @@ int sf_rowdot(const float* a, int a_cs, int a_coff, const float* b, int b_cs, in
               float scale, float* out, void* stream);
 int sf_axpy(const float* a, int a_cs, int a_coff, float alpha, float* out, int out_cs, int out_coff, long rows,
             int C, int accumulate, void* stream);
+/* dx[r, c] (+)= dy[r, c] * [0 < y[r, c] (< 6)]: backward of a bare nn.ReLU / nn.ReLU6 (act = SF_ACT_RELU |
+ * SF_ACT_RELU6) that has no BN in front of it, e.g. relu(cat([out, shortcut(x)])) in the ShuffleNet v1
+ * Bottleneck (shufflenet_helper.py:76-77); the mask is taken from the activation's OUTPUT y.            */
+int sf_act_bwd(const float* dy, int dy_cs, int dy_coff, const float* y, int y_cs, int y_coff, int act, float* dx,
+               int dx_cs, int dx_coff, long rows, int C, int accumulate, void* stream);
 
 #ifdef __cplusplus
 }

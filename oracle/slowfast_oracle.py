@@ -446,12 +446,72 @@ def mobilenetv2_forward(sd, inputs, hp, training=False):
     return acts
 
 
+# ----------------------------------------------------------------------------- ShuffleNet v1
+SHUFFLENET_OUT_PLANES = {1: [24, 144, 288, 567], 2: [24, 200, 400, 800], 3: [24, 240, 480, 960],
+                         4: [24, 272, 544, 1088], 8: [24, 384, 768, 1536]}  # custom_video_model_builder.py:646-659
+
+
+def _channel_shuffle(x, groups):
+    """shufflenet_helper.py:22-29."""
+    b, c, t, h, w = x.shape
+    return x.view(b, groups, c // groups, t, h, w).permute(0, 2, 1, 3, 4, 5).reshape(b, c, t, h, w)
+
+
+def shufflenet_bottleneck(sd, p, x, stride, groups, training):
+    """shufflenet_helper.py:32-79: grouped 1x1 -> shuffle -> dw 3x3x3 -> grouped 1x1; stride 2 concatenates a
+    1x1-conv + AvgPool3d((1,3,3),(1,2,2),(0,1,1)) shortcut, stride 1 adds the identity; ReLU last."""
+    g1 = 1 if x.shape[1] == 24 else groups
+    mid = sd[p + ".conv1.weight"].shape[0]
+    out = F.relu(_bn(sd, p + ".bn1", _conv(sd, p + ".conv1", x, groups=g1), training))
+    out = _channel_shuffle(out, groups)
+    out = _bn(sd, p + ".bn2", _conv(sd, p + ".conv2", out, (1, stride, stride), 1, 1, mid), training)
+    out = _bn(sd, p + ".bn3", _conv(sd, p + ".conv3", out, groups=groups), training)
+    if stride == 2:
+        sc = F.avg_pool3d(_conv(sd, p + ".shortcut.0", x), (1, 3, 3), (1, 2, 2), (0, 1, 1))
+        return F.relu(torch.cat([out, sc], 1))
+    return F.relu(out + x)
+
+
+def shufflenet_forward(sd, inputs, hp, training=False):
+    """SlowFastShuffleNet, custom_video_model_builder.py:620-789."""
+    groups = hp.get("groups", 1)
+    planes = [int(c * hp["width_multi"]) for c in SHUFFLENET_OUT_PLANES[groups]]
+    fast = [c // hp["beta_inv"] for c in planes]
+    acts = {}
+    x = []
+    for pw in range(2):  # stem_helper.py:274-306
+        q = "s1.pathway%d_stem" % pw
+        z = F.relu(_bn(sd, q + ".1", _conv(sd, q + ".0", inputs[pw], (1, 2, 2), 1), training))
+        x.append(F.max_pool3d(z, 3, (1, 2, 2), 1))
+    acts["s1"] = x
+    x = fuse_fast_and_slow(sd, "s1_fuse", x, hp, training)
+    acts["s1_fuse"] = x
+    for si, nb in enumerate((4, 8, 4)):
+        name = "s%d" % (si + 2)
+        nxt = []
+        for pw in range(2):
+            z = x[pw]
+            q = "%s.pathway%d_channel_%d.features" % (name, pw, (planes if pw == 0 else fast)[si + 1])
+            for i in range(nb):
+                z = shufflenet_bottleneck(sd, "%s.%d" % (q, i), z, 2 if i == 0 else 1, groups, training)
+            nxt.append(z)
+        x = nxt
+        acts[name] = x
+        x = fuse_fast_and_slow(sd, name + "_fuse", x, hp, training)
+        acts[name + "_fuse"] = x
+    z = torch.cat([t.mean((2, 3, 4), keepdim=True) for t in x], 1).permute(0, 2, 3, 4, 1)  # head_helper.py:562-609
+    logits = F.linear(z, sd["head.classifier.1.weight"], sd["head.classifier.1.bias"])
+    acts["logits"], acts["out"] = logits, _head_tail(logits, training, hp["head_act"])
+    return acts
+
+
 FORWARDS = {
     "SlowFast": lambda sd, x, hp, training=False: slowfast_forward(sd, x, hp, False, training),
     "SlowFastDualAttention": lambda sd, x, hp, training=False: slowfast_forward(sd, x, hp, True, training),
     "SlowFastShuffleNetV2": shufflenetv2_forward,
     "SlowFastGhostNet": ghostnet_forward,
     "SlowFastMoibleNetV2": mobilenetv2_forward,
+    "SlowFastShuffleNet": shufflenet_forward,
 }
 
 

@@ -52,6 +52,10 @@ CASES = [
     dict(name="mobilenetv2_w1_s64", yaml="SLOWFAST_MOBILENETV2_8x8_R50_stepwise_multigrid.yaml",
          model="SlowFastMoibleNetV2", batch=2, t=16, alpha=4, size=64,
          over=["SLOWFAST.WIDTH_MULTI", 1.0, "SLOWFAST.ALPHA", 4] + small(64, 16)),
+    # SlowFastShuffleNet (v1, GROUPS 1 as its YAML) + CMDA at S=64, T=16
+    dict(name="shufflenet_g1_s64", yaml="SLOWFAST_SHUFFLENET_8x8_R50_stepwise_multigrid.yaml",
+         model="SlowFastShuffleNet", batch=2, t=16, alpha=4, size=64,
+         over=["SLOWFAST.ALPHA", 4] + small(64, 16)),
 ]
 
 GRAD_KEYS = {
@@ -67,6 +71,9 @@ GRAD_KEYS = {
     "SlowFastMoibleNetV2": ["s1.pathway0_stem.features.0.weight", "s4.pathway0_channel_32.features.1.conv.3.weight",
                             "s5_fuse.attention_spatial_s2f.gamma", "s7.pathway1_channel_160.features.0.conv.0.weight",
                             "head.classifier.1.weight"],
+    "SlowFastShuffleNet": ["s1.pathway0_stem.0.weight", "s2.pathway0_channel_144.features.0.shortcut.0.weight",
+                           "s3.pathway1_channel_36.features.2.conv2.weight", "s3_fuse.bn_s2f.weight",
+                           "s4.pathway0_channel_567.features.1.conv3.weight", "head.classifier.1.weight"],
     "SlowFastGhostNet": ["s0.pathway0_stem.0.weight", "s3.pathway0_channel_80.features.0.se.conv_reduce.weight",
                          "s2_fuse.attention_spatial_s2f.gamma", "head.classifier.1.weight"],
 }
@@ -90,7 +97,7 @@ def hparams_from_cfg(cfg):
         num_block_temp_kernel=[list(x) for x in cfg.RESNET.NUM_BLOCK_TEMP_KERNEL],
         num_frames=cfg.DATA.NUM_FRAMES, crop_size=cfg.DATA.CROP_SIZE, num_classes=cfg.MODEL.NUM_CLASSES,
         short_cycle=bool(cfg.MULTIGRID.SHORT_CYCLE), head_act=cfg.MODEL.HEAD_ACT,
-        width_multi=cfg.SLOWFAST.WIDTH_MULTI, eps=1e-5,
+        width_multi=cfg.SLOWFAST.WIDTH_MULTI, eps=1e-5, groups=cfg.SLOWFAST.get("GROUPS", 1),
     )
 
 

@@ -261,6 +261,53 @@ def test_dwconv_backward(c, k, s):
     assert e1 < TOL and e2 < TOL, (e1, e2)
 
 
+@pytest.mark.parametrize("relu", [True, 6])
+def test_bare_activation_backward(relu):
+    import sfhip
+    dev = _dev()
+    g = torch.Generator().manual_seed(11)
+    y = torch.randn(2, 10, 3, 5, 4, generator=g) * 4.0
+    y = F.relu6(y) if relu == 6 else F.relu(y)
+    dy = torch.randn(y.shape, generator=g)
+    base = torch.randn(2, 3, 5, 4, 10, generator=g)
+    ref = dy * ((y > 0) & ((y < 6) if relu == 6 else (y == y))).float()
+    dx = sfhip.Act(base.clone().to(dev))
+    sfhip.act_bwd(_act(dy), _act(y), relu, dx, accumulate=True)
+    dx2 = sfhip.Act(torch.full((2, 3, 5, 4, 10), 7.0, device=dev))
+    sfhip.act_bwd(_act(dy), _act(y), relu, dx2, accumulate=False)
+    torch.cuda.synchronize()
+    assert torch.equal(_back(dx2), ref)
+    assert _rel(_back(dx) - base.permute(0, 4, 1, 2, 3), ref) < 1e-6
+
+
+def test_avgpool_shortcut_forward_backward():
+    """ShuffleNet v1 shortcut: conv1x1 -> AvgPool3d((1,3,3),(1,2,2),(0,1,1)) -> ReLU evaluated as pool -> conv
+    -> ReLU through the taped engine ops (shufflenet_helper.py:61-68)."""
+    import sfhip
+    from slowfast.models import engine
+    dev = _dev()
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 27, 3, 9, 7, generator=g, requires_grad=True)
+    conv = torch.nn.Conv3d(27, 20, 1, bias=False)
+    ref = F.relu(F.avg_pool3d(conv(x), (1, 3, 3), (1, 2, 2), (0, 1, 1)))
+    dy = torch.randn(ref.shape, generator=g)
+    dx_ref, dw_ref = torch.autograd.grad(ref, (x, conv.weight), dy)
+    conv_d = torch.nn.Conv3d(27, 20, 1, bias=False).to(dev)
+    conv_d.weight.data.copy_(conv.weight.data)
+    t = engine.Tape()
+    xa = _act(x)
+    with torch.no_grad(), engine.taping(t):
+        pooled = engine.avgpool(xa, (1, 3, 3), (1, 2, 2), (0, 1, 1))
+        y = engine.conv_bn_act(pooled, conv_d, None, relu=True)
+        t.grad_of(y).buf.copy_(dy.permute(0, 2, 3, 4, 1).to(dev))
+        dxa = t.grad_of(xa)
+        t.backward()
+    torch.cuda.synchronize()
+    e = [_rel(_back(y), ref), _rel(_back(dxa), dx_ref), _rel(t.pgrads[conv_d.weight], dw_ref)]
+    _report("avgpool shortcut fwd/dx/dw", max(e))
+    assert max(e) < TOL, e
+
+
 def test_gather_add_is_the_adjoint_of_the_shuffled_store():
     import sfhip
     dev = _dev()
