@@ -56,23 +56,28 @@ __device__ __forceinline__ void bn_g(const float* __restrict__ dy, int dy_cs, in
 template <int VEC>
 __global__ void bn_bwd_partial_kernel(const float* __restrict__ dy, int dy_cs, int dy_coff,
                                       const float* __restrict__ y, int y_cs, int y_coff,
-                                      const float* __restrict__ z, int z_cs, int z_coff, long rows, long THW, int HW,
-                                      int C, int rep, int relu, const float* __restrict__ mean,
-                                      const float* __restrict__ invstd, int CB, float* __restrict__ partial) {
+                                      const float* __restrict__ z, int z_cs, int z_coff, long group_rows, int chunks,
+                                      int S, long THW, int HW, int C, int rep, int relu,
+                                      const float* __restrict__ mean, const float* __restrict__ invstd, int CB,
+                                      float* __restrict__ partial) {
+  // block -> (row group n, chunk); group = whole tensor (S == 1) or one sample of split n % S (Sub-BN)
   __shared__ float red[2 * TPB * VEC];
-  const int blk = blockIdx.x, cb = blockIdx.y, P = gridDim.x;
+  const int blk = blockIdx.x, cb = blockIdx.y;
   const int cl = threadIdx.x % CB, rl = threadIdx.x / CB, rpi = TPB / CB;
   const int c = (cb * CB + cl) * VEC;
-  const long per = (rows + P - 1) / P;
-  const long r0 = (long)blk * per;
-  const long r1 = (r0 + per < rows) ? r0 + per : rows;
+  const int n = blk / chunks, ck = blk - n * chunks;
+  const long per = (group_rows + chunks - 1) / chunks;
+  const long gend = (long)(n + 1) * group_rows;
+  const long r0 = (long)n * group_rows + (long)ck * per;
+  const long r1 = (r0 + per < gend) ? r0 + per : gend;
+  const int so = (n % S) * C;
   float s1[VEC], s2[VEC];
 #pragma unroll
   for (int e = 0; e < VEC; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
   if (c < C) {
     float mu[VEC], is[VEC];
 #pragma unroll
-    for (int e = 0; e < VEC; ++e) { mu[e] = mean[c + e]; is[e] = invstd[c + e]; }
+    for (int e = 0; e < VEC; ++e) { mu[e] = mean[so + c + e]; is[e] = invstd[so + c + e]; }
     for (long r = r0 + rl; r < r1; r += rpi) {
       float g[VEC], zv[VEC];
       bn_g<VEC>(dy, dy_cs, dy_coff, y, y_cs, y_coff, r, THW, HW, rep, relu, c, g);
@@ -110,12 +115,14 @@ __global__ void bn_bwd_partial_kernel(const float* __restrict__ dy, int dy_cs, i
   }
 }
 
-__global__ void pair_final_kernel(const float* __restrict__ partial, int C, int P, float* __restrict__ o1,
-                                  float* __restrict__ o2) {
+__global__ void pair_final_kernel(const float* __restrict__ partial, int C, int P, int chunks, int S,
+                                  float* __restrict__ o1, float* __restrict__ o2) {
   __shared__ double r1[64], r2[64];
-  const int c = blockIdx.x;
+  const int o = blockIdx.x;  // split * C + channel
+  const int sp = o / C, c = o - sp * C;
   double s1 = 0.0, s2 = 0.0;
   for (int i = threadIdx.x; i < P; i += 64) {
+    if ((i / chunks) % S != sp) continue;
     s1 += (double)partial[((long)i * 2 + 0) * C + c];
     s2 += (double)partial[((long)i * 2 + 1) * C + c];
   }
@@ -130,8 +137,8 @@ __global__ void pair_final_kernel(const float* __restrict__ partial, int C, int 
     __syncthreads();
   }
   if (threadIdx.x == 0) {
-    o1[c] = (float)r1[0];
-    o2[c] = (float)r2[0];
+    o1[o] = (float)r1[0];
+    o2[o] = (float)r2[0];
   }
 }
 
@@ -139,7 +146,7 @@ __global__ void pair_final_kernel(const float* __restrict__ partial, int C, int 
 template <int VEC>
 __global__ void bn_bwd_apply_kernel(const float* __restrict__ dy, int dy_cs, int dy_coff,
                                     const float* __restrict__ y, int y_cs, int y_coff, const float* z, int z_cs,
-                                    int z_coff, long rows, long THW, int HW, int C, int rep, int relu,
+                                    int z_coff, long rows, long THW, int HW, int C, int S, int rep, int relu,
                                     const float* __restrict__ mean, const float* __restrict__ invstd,
                                     const float* __restrict__ gamma, const float* __restrict__ dbeta,
                                     const float* __restrict__ dgamma, float inv_m, float* dz, int dz_cs, int dz_coff,
@@ -150,6 +157,7 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ dy, int dy_cs, int
   const int c = (int)(idx % cv) * VEC;
   const long r = idx / cv;
   float g[VEC], zv[VEC], o[VEC];
+  const int so = (int)((r / THW) % S) * C + c;
   bn_g<VEC>(dy, dy_cs, dy_coff, y, y_cs, y_coff, r, THW, HW, rep, relu, c, g);
   if (VEC == 4) {
     const f32x4 v = *reinterpret_cast<const f32x4*>(z + r * z_cs + z_coff + c);
@@ -160,9 +168,9 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ dy, int dy_cs, int
   }
 #pragma unroll
   for (int e = 0; e < VEC; ++e) {
-    const float is = invstd[c + e];
-    const float xh = (zv[e] - mean[c + e]) * is;
-    o[e] = gamma[c + e] * is * (g[e] - dbeta[c + e] * inv_m - xh * dgamma[c + e] * inv_m);
+    const float is = invstd[so + e];
+    const float xh = (zv[e] - mean[so + e]) * is;
+    o[e] = gamma[so + e] * is * (g[e] - dbeta[so + e] * inv_m - xh * dgamma[so + e] * inv_m);
   }
   float* dp = dz + r * dz_cs + dz_coff + c;
   if (VEC == 4) {
@@ -339,28 +347,78 @@ static inline void red_geometry(long rows, int C, int vec, int* CB, int* P) {
 }
 extern "C" long sf_bn_bwd_ws_floats(int C) { return (long)MAX_P * 2 * C; }
 
-extern "C" int sf_bn_bwd_reduce(const float* dy, int dy_cs, int dy_coff, const float* y, int y_cs, int y_coff,
-                                const float* z, int z_cs, int z_coff, int N, int T, int H, int W, int C, int rep,
-                                int relu, const float* mean, const float* invstd, float* dbeta, float* dgamma,
-                                float* ws, void* stream) {
+static int bn_bwd_reduce_launch(const float* dy, int dy_cs, int dy_coff, const float* y, int y_cs, int y_coff,
+                                const float* z, int z_cs, int z_coff, int N, int T, int H, int W, int C, int S,
+                                int rep, int relu, const float* mean, const float* invstd, float* dbeta,
+                                float* dgamma, float* ws, void* stream) {
   if (!dy || !z || !mean || !invstd || !dbeta || !dgamma || !ws || (relu && !y)) return SF_EINVAL;
-  if (N <= 0 || T <= 0 || H <= 0 || W <= 0 || C <= 0 || rep <= 0) return SF_EINVAL;
+  if (N <= 0 || T <= 0 || H <= 0 || W <= 0 || C <= 0 || rep <= 0 || S <= 0 || N % S != 0) return SF_EINVAL;
+  if (S > 1 && N > MAX_P) return SF_EINVAL;
   const long rows = (long)N * T * H * W;
   const bool vec4 = (C % 4 == 0) && (dy_cs % 4 == 0) && (dy_coff % 4 == 0) && (z_cs % 4 == 0) && (z_coff % 4 == 0) &&
                     sf_aligned16(dy) && sf_aligned16(z) &&
                     (!relu || ((y_cs % 4 == 0) && (y_coff % 4 == 0) && sf_aligned16(y)));
+  const int groups = S > 1 ? N : 1;
+  const long group_rows = rows / groups;
   int CB, P;
-  red_geometry(rows, C, vec4 ? 4 : 1, &CB, &P);
+  red_geometry(group_rows, C, vec4 ? 4 : 1, &CB, &P);
+  if ((long)P * groups > MAX_P) P = MAX_P / groups;
+  const int chunks = P;
+  P = chunks * groups;
   const int ncb = sf_cdiv(sf_cdiv(C, vec4 ? 4 : 1), CB);
   if (vec4)
     hipLaunchKernelGGL(bn_bwd_partial_kernel<4>, dim3(P, ncb), dim3(TPB), 0, (hipStream_t)stream, dy, dy_cs, dy_coff,
-                       y, y_cs, y_coff, z, z_cs, z_coff, rows, (long)T * H * W, H * W, C, rep, relu, mean, invstd,
-                       CB, ws);
+                       y, y_cs, y_coff, z, z_cs, z_coff, group_rows, chunks, S, (long)T * H * W, H * W, C, rep, relu,
+                       mean, invstd, CB, ws);
   else
     hipLaunchKernelGGL(bn_bwd_partial_kernel<1>, dim3(P, ncb), dim3(TPB), 0, (hipStream_t)stream, dy, dy_cs, dy_coff,
-                       y, y_cs, y_coff, z, z_cs, z_coff, rows, (long)T * H * W, H * W, C, rep, relu, mean, invstd,
-                       CB, ws);
-  hipLaunchKernelGGL(pair_final_kernel, dim3(C), dim3(64), 0, (hipStream_t)stream, ws, C, P, dbeta, dgamma);
+                       y, y_cs, y_coff, z, z_cs, z_coff, group_rows, chunks, S, (long)T * H * W, H * W, C, rep, relu,
+                       mean, invstd, CB, ws);
+  hipLaunchKernelGGL(pair_final_kernel, dim3(S * C), dim3(64), 0, (hipStream_t)stream, ws, C, P, chunks, S, dbeta,
+                     dgamma);
+  SF_CHECK_LAUNCH();
+  return SF_OK;
+}
+
+extern "C" int sf_bn_bwd_reduce(const float* dy, int dy_cs, int dy_coff, const float* y, int y_cs, int y_coff,
+                                const float* z, int z_cs, int z_coff, int N, int T, int H, int W, int C, int rep,
+                                int relu, const float* mean, const float* invstd, float* dbeta, float* dgamma,
+                                float* ws, void* stream) {
+  return bn_bwd_reduce_launch(dy, dy_cs, dy_coff, y, y_cs, y_coff, z, z_cs, z_coff, N, T, H, W, C, 1, rep, relu, mean,
+                              invstd, dbeta, dgamma, ws, stream);
+}
+
+extern "C" int sf_bn_bwd_reduce_split(const float* dy, int dy_cs, int dy_coff, const float* y, int y_cs, int y_coff,
+                                      const float* z, int z_cs, int z_coff, int N, int T, int H, int W, int C,
+                                      int nsplit, int rep, int relu, const float* mean, const float* invstd,
+                                      float* dbeta, float* dgamma, float* ws, void* stream) {
+  return bn_bwd_reduce_launch(dy, dy_cs, dy_coff, y, y_cs, y_coff, z, z_cs, z_coff, N, T, H, W, C, nsplit, rep, relu,
+                              mean, invstd, dbeta, dgamma, ws, stream);
+}
+
+static int bn_bwd_apply_launch(const float* dy, int dy_cs, int dy_coff, const float* y, int y_cs, int y_coff,
+                               const float* z, int z_cs, int z_coff, int N, int T, int H, int W, int C, int S, int rep,
+                               int relu, const float* mean, const float* invstd, const float* gamma,
+                               const float* dbeta, const float* dgamma, float* dz, int dz_cs, int dz_coff,
+                               float* dres, int dres_cs, int dres_coff, void* stream) {
+  if (!dy || !z || !mean || !invstd || !gamma || !dbeta || !dgamma || !dz || (relu && !y)) return SF_EINVAL;
+  if (N <= 0 || T <= 0 || H <= 0 || W <= 0 || C <= 0 || rep <= 0 || S <= 0 || N % S != 0) return SF_EINVAL;
+  const long rows = (long)N * T * H * W;
+  const bool vec4 = (C % 4 == 0) && (dy_cs % 4 == 0) && (dy_coff % 4 == 0) && (z_cs % 4 == 0) && (z_coff % 4 == 0) &&
+                    (dz_cs % 4 == 0) && (dz_coff % 4 == 0) && sf_aligned16(dy) && sf_aligned16(z) && sf_aligned16(dz) &&
+                    (!relu || ((y_cs % 4 == 0) && (y_coff % 4 == 0) && sf_aligned16(y))) &&
+                    (!dres || ((dres_cs % 4 == 0) && (dres_coff % 4 == 0) && sf_aligned16(dres)));
+  const long total = rows * (vec4 ? C / 4 : C);
+  if (vec4)
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<4>, dim3(sf_cdiv(total, TPB)), dim3(TPB), 0, (hipStream_t)stream, dy, dy_cs,
+                       dy_coff, y, y_cs, y_coff, z, z_cs, z_coff, rows, (long)T * H * W, H * W, C, S, rep, relu, mean,
+                       invstd, gamma, dbeta, dgamma, (float)S / (float)rows, dz, dz_cs, dz_coff, dres, dres_cs,
+                       dres_coff, total);
+  else
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<1>, dim3(sf_cdiv(total, TPB)), dim3(TPB), 0, (hipStream_t)stream, dy, dy_cs,
+                       dy_coff, y, y_cs, y_coff, z, z_cs, z_coff, rows, (long)T * H * W, H * W, C, S, rep, relu, mean,
+                       invstd, gamma, dbeta, dgamma, (float)S / (float)rows, dz, dz_cs, dz_coff, dres, dres_cs,
+                       dres_coff, total);
   SF_CHECK_LAUNCH();
   return SF_OK;
 }
@@ -370,26 +428,17 @@ extern "C" int sf_bn_bwd_apply(const float* dy, int dy_cs, int dy_coff, const fl
                                int relu, const float* mean, const float* invstd, const float* gamma,
                                const float* dbeta, const float* dgamma, float* dz, int dz_cs, int dz_coff,
                                float* dres, int dres_cs, int dres_coff, void* stream) {
-  if (!dy || !z || !mean || !invstd || !gamma || !dbeta || !dgamma || !dz || (relu && !y)) return SF_EINVAL;
-  if (N <= 0 || T <= 0 || H <= 0 || W <= 0 || C <= 0 || rep <= 0) return SF_EINVAL;
-  const long rows = (long)N * T * H * W;
-  const bool vec4 = (C % 4 == 0) && (dy_cs % 4 == 0) && (dy_coff % 4 == 0) && (z_cs % 4 == 0) && (z_coff % 4 == 0) &&
-                    (dz_cs % 4 == 0) && (dz_coff % 4 == 0) && sf_aligned16(dy) && sf_aligned16(z) && sf_aligned16(dz) &&
-                    (!relu || ((y_cs % 4 == 0) && (y_coff % 4 == 0) && sf_aligned16(y))) &&
-                    (!dres || ((dres_cs % 4 == 0) && (dres_coff % 4 == 0) && sf_aligned16(dres)));
-  const long total = rows * (vec4 ? C / 4 : C);
-  if (vec4)
-    hipLaunchKernelGGL(bn_bwd_apply_kernel<4>, dim3(sf_cdiv(total, TPB)), dim3(TPB), 0, (hipStream_t)stream, dy, dy_cs,
-                       dy_coff, y, y_cs, y_coff, z, z_cs, z_coff, rows, (long)T * H * W, H * W, C, rep, relu, mean,
-                       invstd, gamma, dbeta, dgamma, 1.0f / (float)rows, dz, dz_cs, dz_coff, dres, dres_cs, dres_coff,
-                       total);
-  else
-    hipLaunchKernelGGL(bn_bwd_apply_kernel<1>, dim3(sf_cdiv(total, TPB)), dim3(TPB), 0, (hipStream_t)stream, dy, dy_cs,
-                       dy_coff, y, y_cs, y_coff, z, z_cs, z_coff, rows, (long)T * H * W, H * W, C, rep, relu, mean,
-                       invstd, gamma, dbeta, dgamma, 1.0f / (float)rows, dz, dz_cs, dz_coff, dres, dres_cs, dres_coff,
-                       total);
-  SF_CHECK_LAUNCH();
-  return SF_OK;
+  return bn_bwd_apply_launch(dy, dy_cs, dy_coff, y, y_cs, y_coff, z, z_cs, z_coff, N, T, H, W, C, 1, rep, relu, mean,
+                             invstd, gamma, dbeta, dgamma, dz, dz_cs, dz_coff, dres, dres_cs, dres_coff, stream);
+}
+
+extern "C" int sf_bn_bwd_apply_split(const float* dy, int dy_cs, int dy_coff, const float* y, int y_cs, int y_coff,
+                                     const float* z, int z_cs, int z_coff, int N, int T, int H, int W, int C,
+                                     int nsplit, int rep, int relu, const float* mean, const float* invstd,
+                                     const float* gamma, const float* dbeta, const float* dgamma, float* dz,
+                                     int dz_cs, int dz_coff, float* dres, int dres_cs, int dres_coff, void* stream) {
+  return bn_bwd_apply_launch(dy, dy_cs, dy_coff, y, y_cs, y_coff, z, z_cs, z_coff, N, T, H, W, C, nsplit, rep, relu,
+                             mean, invstd, gamma, dbeta, dgamma, dz, dz_cs, dz_coff, dres, dres_cs, dres_coff, stream);
 }
 
 extern "C" int sf_maxpool_bwd(const sf_pool_desc* d, const float* x, const float* y, const float* dy, int dy_cs,

@@ -315,21 +315,25 @@ __global__ void copy_channels_kernel(const float* __restrict__ in, int in_cs, in
 constexpr int STAT_MAX_P = 1024;
 
 template <int VEC>
-__global__ void stats_partial_kernel(const float* __restrict__ x, int cs, int coff, long rows, int C, int CB,
-                                     float* __restrict__ partial) {
+__global__ void stats_partial_kernel(const float* __restrict__ x, int cs, int coff, long group_rows, int chunks,
+                                     int S, int C, int CB, float* __restrict__ partial) {
+  // block -> (row group n, chunk): a group is the whole tensor (S == 1) or one sample (Sub-BN, split = n % S)
   __shared__ float red[2 * TPB * VEC];
-  const int blk = blockIdx.x, cb = blockIdx.y, P = gridDim.x;
+  const int blk = blockIdx.x, cb = blockIdx.y;
   const int cl = threadIdx.x % CB, rl = threadIdx.x / CB, rpi = TPB / CB;
   const int c = (cb * CB + cl) * VEC;
-  const long per = (rows + P - 1) / P;
-  const long r0 = (long)blk * per;
-  const long r1 = (r0 + per < rows) ? r0 + per : rows;
+  const int n = blk / chunks, ck = blk - n * chunks;
+  const long per = (group_rows + chunks - 1) / chunks;
+  const long gend = (long)(n + 1) * group_rows;
+  const long r0 = (long)n * group_rows + (long)ck * per;
+  const long r1 = (r0 + per < gend) ? r0 + per : gend;
+  const long krow = (long)(n % S) * group_rows;  // first row of this split
   float s1[VEC], s2[VEC], k[VEC];
 #pragma unroll
   for (int e = 0; e < VEC; ++e) { s1[e] = 0.f; s2[e] = 0.f; k[e] = 0.f; }
   if (c < C) {
 #pragma unroll
-    for (int e = 0; e < VEC; ++e) k[e] = x[coff + c + e];
+    for (int e = 0; e < VEC; ++e) k[e] = x[krow * cs + coff + c + e];
     for (long r = r0 + rl; r < r1; r += rpi) {
       if (VEC == 4) {
         const f32x4 v = *reinterpret_cast<const f32x4*>(x + r * cs + coff + c);
@@ -369,16 +373,18 @@ __global__ void stats_partial_kernel(const float* __restrict__ x, int cs, int co
 // One 64-lane block per channel: lanes stride over the P partials in fp64, tree-reduce through LDS.  With
 // BN parameters given it also emits the normalisation affine and updates the running statistics in place
 // (nn.BatchNorm3d training semantics: biased variance to normalise, unbiased for running_var).
-__global__ void stats_final_kernel(const float* __restrict__ x, int coff, const float* __restrict__ partial, int C,
-                                   int P, double inv_rows, double unbias,
+__global__ void stats_final_kernel(const float* __restrict__ x, int cs, int coff, long group_rows, int chunks, int S,
+                                   const float* __restrict__ partial, int C, int P, double inv_rows, double unbias,
                                    float* __restrict__ mean, float* __restrict__ var,
                                    const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
                                    float momentum, float* __restrict__ run_mean, float* __restrict__ run_var,
                                    float* __restrict__ invstd, float* __restrict__ scale, float* __restrict__ shift) {
   __shared__ double r1[64], r2[64];
-  const int c = blockIdx.x;
+  const int o = blockIdx.x;            // output index = split * C + channel
+  const int sp = o / C, c = o - sp * C;
   double s1 = 0.0, s2 = 0.0;
   for (int i = threadIdx.x; i < P; i += 64) {
+    if ((i / chunks) % S != sp) continue;
     s1 += (double)partial[((long)i * 2 + 0) * C + c];
     s2 += (double)partial[((long)i * 2 + 1) * C + c];
   }
@@ -396,26 +402,26 @@ __global__ void stats_final_kernel(const float* __restrict__ x, int coff, const 
     const double md = r1[0] * inv_rows;  // mean of (x - K)
     double v = r2[0] * inv_rows - md * md;
     if (v < 0.0) v = 0.0;
-    const double m = md + (double)x[coff + c];
-    mean[c] = (float)m;
-    var[c] = (float)v;
+    const double m = md + (double)x[(long)sp * group_rows * cs + coff + c];
+    mean[o] = (float)m;
+    var[o] = (float)v;
     if (gamma) {
       const float is = (float)(1.0 / sqrt(v + (double)eps));
-      const float sc = gamma[c] * is;
-      invstd[c] = is;
-      scale[c] = sc;
-      shift[c] = beta[c] - (float)m * sc;
+      const float sc = gamma[o] * is;
+      invstd[o] = is;
+      scale[o] = sc;
+      shift[o] = beta[o] - (float)m * sc;
       if (run_mean) {
-        run_mean[c] = (1.f - momentum) * run_mean[c] + momentum * (float)m;
-        run_var[c] = (1.f - momentum) * run_var[c] + momentum * (float)(v * unbias);
+        run_mean[o] = (1.f - momentum) * run_mean[o] + momentum * (float)m;
+        run_var[o] = (1.f - momentum) * run_var[o] + momentum * (float)(v * unbias);
       }
     }
   }
 }
 
-// out[n, t*rep + r, hw, c] = act(x[n,t,hw,c] * scale[c] + bias[c] + res[n,t,hw,c])
+// out[n, t*rep + r, hw, c] = act(x[n,t,hw,c] * scale[(n%S)*C + c] + bias[(n%S)*C + c] + res[n,t,hw,c])
 template <int VEC>
-__global__ void affine_kernel(const float* __restrict__ x, int cs, int coff, long THW_in, int HW, int C,
+__global__ void affine_kernel(const float* __restrict__ x, int cs, int coff, long THW_in, int HW, int C, int S,
                               const float* __restrict__ scale, const float* __restrict__ bias,
                               const float* __restrict__ res, int res_cs, int res_coff, int act, int rep,
                               float* __restrict__ out, int out_cs, int out_coff, int out_cmul, long total) {
@@ -427,6 +433,7 @@ __global__ void affine_kernel(const float* __restrict__ x, int cs, int coff, lon
   const long n = r / THW_in;
   const long thw = r - n * THW_in;
   const long t = thw / HW, hw = thw - t * HW;
+  const int so = (int)(n % S) * C;
   float v[VEC];
   if (VEC == 4) {
     const f32x4 a = *reinterpret_cast<const f32x4*>(x + r * cs + coff + c);
@@ -438,7 +445,7 @@ __global__ void affine_kernel(const float* __restrict__ x, int cs, int coff, lon
 #pragma unroll
   for (int e = 0; e < VEC; ++e) {
     float y = v[e];
-    if (scale) y = y * scale[c + e] + bias[c + e];
+    if (scale) y = y * scale[so + c + e] + bias[so + c + e];
     if (res) y += res[r * res_cs + res_coff + c + e];
     v[e] = sf_act(y, act);
   }
@@ -571,24 +578,30 @@ extern "C" int sf_gate_apply(const float* x, int cs, int coff, int N, int T, int
 
 extern "C" long sf_channel_stats_ws_floats(int C) { return (long)STAT_MAX_P * 2 * C; }
 
-static int stats_launch(const float* x, int cs, int coff, long rows, int C, float* mean, float* var, float* ws,
-                        const float* gamma, const float* beta, float eps, float momentum, float* run_mean,
-                        float* run_var, float* invstd, float* scale, float* shift, hipStream_t s) {
+// Statistics over `groups` row groups of `group_rows` rows each; group n belongs to split n % S and every
+// per-channel output has S*C entries.  Plain BN: groups = 1, S = 1.  Sub-BN: groups = N samples, S = NUM_SPLITS.
+static int stats_launch(const float* x, int cs, int coff, int groups, long group_rows, int S, int C, float* mean,
+                        float* var, float* ws, const float* gamma, const float* beta, float eps, float momentum,
+                        float* run_mean, float* run_var, float* invstd, float* scale, float* shift, hipStream_t s) {
+  if (groups > STAT_MAX_P || S <= 0 || groups % S != 0) return SF_EINVAL;
   const bool vec4 = (C % 4 == 0) && (cs % 4 == 0) && (coff % 4 == 0) && sf_aligned16(x);
   const int cv = sf_cdiv(C, vec4 ? 4 : 1);
   const int CB = pow2ceil(cv) < TPB ? pow2ceil(cv) : TPB;
   const int rpi = TPB / CB;
-  long p = rows / ((long)rpi * 8);
-  const int P = (int)(p < 1 ? 1 : (p > STAT_MAX_P ? STAT_MAX_P : p));
+  long ch = group_rows / ((long)rpi * 8);
+  if (ch < 1) ch = 1;
+  if (ch * groups > STAT_MAX_P) ch = STAT_MAX_P / groups;
+  const int chunks = (int)ch, P = chunks * groups;
+  const long srows = group_rows * (groups / S);  // rows per split
   if (vec4)
-    hipLaunchKernelGGL(stats_partial_kernel<4>, dim3(P, sf_cdiv(cv, CB)), dim3(TPB), 0, s, x, cs, coff, rows, C, CB,
-                       ws);
+    hipLaunchKernelGGL(stats_partial_kernel<4>, dim3(P, sf_cdiv(cv, CB)), dim3(TPB), 0, s, x, cs, coff, group_rows,
+                       chunks, S, C, CB, ws);
   else
-    hipLaunchKernelGGL(stats_partial_kernel<1>, dim3(P, sf_cdiv(cv, CB)), dim3(TPB), 0, s, x, cs, coff, rows, C, CB,
-                       ws);
-  hipLaunchKernelGGL(stats_final_kernel, dim3(C), dim3(64), 0, s, x, coff, ws, C, P, 1.0 / (double)rows,
-                     rows > 1 ? (double)rows / (double)(rows - 1) : 1.0, mean, var, gamma, beta, eps, momentum,
-                     run_mean, run_var, invstd, scale, shift);
+    hipLaunchKernelGGL(stats_partial_kernel<1>, dim3(P, sf_cdiv(cv, CB)), dim3(TPB), 0, s, x, cs, coff, group_rows,
+                       chunks, S, C, CB, ws);
+  hipLaunchKernelGGL(stats_final_kernel, dim3(S * C), dim3(64), 0, s, x, cs, coff, group_rows, chunks, S, ws, C, P,
+                     1.0 / (double)srows, srows > 1 ? (double)srows / (double)(srows - 1) : 1.0, mean, var, gamma,
+                     beta, eps, momentum, run_mean, run_var, invstd, scale, shift);
   SF_CHECK_LAUNCH();
   return SF_OK;
 }
@@ -596,7 +609,7 @@ static int stats_launch(const float* x, int cs, int coff, long rows, int C, floa
 extern "C" int sf_channel_stats(const float* x, int cs, int coff, long rows, int C, float* mean, float* var,
                                 float* ws, void* stream) {
   if (!x || !mean || !var || !ws || rows <= 0 || C <= 0) return SF_EINVAL;
-  return stats_launch(x, cs, coff, rows, C, mean, var, ws, nullptr, nullptr, 0.f, 0.f, nullptr, nullptr, nullptr,
+  return stats_launch(x, cs, coff, 1, rows, 1, C, mean, var, ws, nullptr, nullptr, 0.f, 0.f, nullptr, nullptr, nullptr,
                       nullptr, nullptr, (hipStream_t)stream);
 }
 
@@ -607,14 +620,27 @@ extern "C" int sf_bn_train_stats(const float* x, int cs, int coff, long rows, in
   if (!x || !gamma || !beta || !mean || !var || !invstd || !scale || !shift || !ws || rows <= 0 || C <= 0)
     return SF_EINVAL;
   if ((run_mean == nullptr) != (run_var == nullptr)) return SF_EINVAL;
-  return stats_launch(x, cs, coff, rows, C, mean, var, ws, gamma, beta, eps, momentum, run_mean, run_var, invstd,
-                      scale, shift, (hipStream_t)stream);
+  return stats_launch(x, cs, coff, 1, rows, 1, C, mean, var, ws, gamma, beta, eps, momentum, run_mean, run_var,
+                      invstd, scale, shift, (hipStream_t)stream);
 }
 
-extern "C" int sf_affine_fwd(const float* x, int cs, int coff, int N, int T, int H, int W, int C,
-                             const float* scale, const float* bias, const float* res, int res_cs, int res_coff,
-                             int act, int rep, float* out, int out_cs, int out_coff, int out_cmul, void* stream) {
-  if (!x || !out || N <= 0 || T <= 0 || H <= 0 || W <= 0 || C <= 0 || rep <= 0 || out_cmul <= 0) return SF_EINVAL;
+extern "C" int sf_bn_train_stats_split(const float* x, int cs, int coff, int N, long rows_per_sample, int C,
+                                       int nsplit, const float* gamma, const float* beta, float eps, float momentum,
+                                       float* run_mean, float* run_var, float* mean, float* var, float* invstd,
+                                       float* scale, float* shift, float* ws, void* stream) {
+  if (!x || !gamma || !beta || !mean || !var || !invstd || !scale || !shift || !ws || N <= 0 ||
+      rows_per_sample <= 0 || C <= 0 || nsplit <= 0 || N % nsplit != 0)
+    return SF_EINVAL;
+  if ((run_mean == nullptr) != (run_var == nullptr)) return SF_EINVAL;
+  return stats_launch(x, cs, coff, N, rows_per_sample, nsplit, C, mean, var, ws, gamma, beta, eps, momentum, run_mean,
+                      run_var, invstd, scale, shift, (hipStream_t)stream);
+}
+
+static int affine_launch(const float* x, int cs, int coff, int N, int T, int H, int W, int C, int S,
+                         const float* scale, const float* bias, const float* res, int res_cs, int res_coff,
+                         int act, int rep, float* out, int out_cs, int out_coff, int out_cmul, void* stream) {
+  if (!x || !out || N <= 0 || T <= 0 || H <= 0 || W <= 0 || C <= 0 || rep <= 0 || out_cmul <= 0 || S <= 0)
+    return SF_EINVAL;
   if ((scale == nullptr) != (bias == nullptr)) return SF_EINVAL;
   if (act != SF_ACT_NONE && act != SF_ACT_RELU && act != SF_ACT_RELU6) return SF_EINVAL;
   const bool vec4 = (out_cmul == 1) && (C % 4 == 0) && (cs % 4 == 0) && (coff % 4 == 0) && (out_cs % 4 == 0) &&
@@ -624,14 +650,29 @@ extern "C" int sf_affine_fwd(const float* x, int cs, int coff, int N, int T, int
   const long total = rows * (vec4 ? C / 4 : C);
   if (vec4)
     hipLaunchKernelGGL(affine_kernel<4>, dim3(sf_cdiv(total, TPB)), dim3(TPB), 0, (hipStream_t)stream, x, cs, coff,
-                       (long)T * H * W, H * W, C, scale, bias, res, res_cs, res_coff, act, rep, out, out_cs,
+                       (long)T * H * W, H * W, C, S, scale, bias, res, res_cs, res_coff, act, rep, out, out_cs,
                        out_coff, out_cmul, total);
   else
     hipLaunchKernelGGL(affine_kernel<1>, dim3(sf_cdiv(total, TPB)), dim3(TPB), 0, (hipStream_t)stream, x, cs, coff,
-                       (long)T * H * W, H * W, C, scale, bias, res, res_cs, res_coff, act, rep, out, out_cs,
+                       (long)T * H * W, H * W, C, S, scale, bias, res, res_cs, res_coff, act, rep, out, out_cs,
                        out_coff, out_cmul, total);
   SF_CHECK_LAUNCH();
   return SF_OK;
+}
+
+extern "C" int sf_affine_fwd(const float* x, int cs, int coff, int N, int T, int H, int W, int C,
+                             const float* scale, const float* bias, const float* res, int res_cs, int res_coff,
+                             int act, int rep, float* out, int out_cs, int out_coff, int out_cmul, void* stream) {
+  return affine_launch(x, cs, coff, N, T, H, W, C, 1, scale, bias, res, res_cs, res_coff, act, rep, out, out_cs,
+                       out_coff, out_cmul, stream);
+}
+
+extern "C" int sf_affine_fwd_split(const float* x, int cs, int coff, int N, int T, int H, int W, int C, int nsplit,
+                                   const float* scale, const float* bias, const float* res, int res_cs,
+                                   int res_coff, int act, int rep, float* out, int out_cs, int out_coff,
+                                   int out_cmul, void* stream) {
+  return affine_launch(x, cs, coff, N, T, H, W, C, nsplit, scale, bias, res, res_cs, res_coff, act, rep, out, out_cs,
+                       out_coff, out_cmul, stream);
 }
 
 extern "C" int sf_head_act_mean(const float* logits, int B, int P, int K, int act, float* out, void* stream) {

@@ -49,6 +49,7 @@ EXPORTS = [
     "sf_conv_wgrad_splits", "sf_conv_wgrad", "sf_bn_bwd_ws_floats", "sf_bn_bwd_reduce", "sf_bn_bwd_apply",
     "sf_attn_bwd", "sf_maxpool_bwd", "sf_tmax_dot", "sf_eca_bwd_apply", "sf_bcast_add", "sf_rowdot", "sf_axpy", "sf_act_bwd",
     "sf_dwconv_dgrad", "sf_dwconv_wgrad_ws_floats", "sf_dwconv_wgrad", "sf_gather_add",
+    "sf_bn_train_stats_split", "sf_affine_fwd_split", "sf_bn_bwd_reduce_split", "sf_bn_bwd_apply_split",
 ]
 _LONG_RET = ("sf_tmax_mean_ws_floats", "sf_channel_stats_ws_floats", "sf_bn_bwd_ws_floats",
              "sf_dwconv_wgrad_ws_floats")
@@ -108,6 +109,11 @@ def lib():
         L.sf_dwconv_wgrad_ws_floats.restype = cl
         L.sf_dwconv_wgrad.argtypes = [ctypes.POINTER(ConvDesc), vp, vp, ci, ci, ci, vp, vp, vp]
         L.sf_gather_add.argtypes = [vp, ci, ci, ci, vp, ci, ci, cl, ci, ci, vp]
+        L.sf_bn_train_stats_split.argtypes = [vp, ci, ci, ci, cl, ci, ci, vp, vp, cf, cf] + [vp] * 9
+        L.sf_affine_fwd_split.argtypes = [vp, ci, ci] + [ci] * 6 + [vp, vp, vp, ci, ci, ci, ci, vp, ci, ci, ci, vp]
+        L.sf_bn_bwd_reduce_split.argtypes = [vp, ci, ci, vp, ci, ci, vp, ci, ci] + [ci] * 8 + [vp] * 5 + [vp]
+        L.sf_bn_bwd_apply_split.argtypes = ([vp, ci, ci, vp, ci, ci, vp, ci, ci] + [ci] * 8 + [vp] * 5 +
+                                            [vp, ci, ci, vp, ci, ci, vp])
         for name in EXPORTS:
             fn = getattr(L, name)
             if name != "sf_build_arch" and name not in _LONG_RET:
@@ -378,8 +384,10 @@ def channel_stats(x):
     return mean, var
 
 
-def affine(x, scale=None, bias=None, res=None, relu=False, rep=1, out=None, out_reserve=(0, 0), out_cmul=1):
-    """out = act(x*scale + bias + res), repeated `rep` times along T (nearest upsample)."""
+def affine(x, scale=None, bias=None, res=None, relu=False, rep=1, out=None, out_reserve=(0, 0), out_cmul=1,
+           nsplit=1):
+    """out = act(x*scale + bias + res), repeated `rep` times along T (nearest upsample).  nsplit > 1: scale/bias
+    hold nsplit*C entries and sample n uses block n % nsplit (SubBatchNorm3d)."""
     _require_gpu(x.buf, "affine")
     if out is None:
         out = new_act(x, x.N, x.T * rep, x.H, x.W, x.C, out_reserve[0], out_reserve[1])
@@ -388,10 +396,13 @@ def affine(x, scale=None, bias=None, res=None, relu=False, rep=1, out=None, out_
         assert out.coff + (x.C - 1) * out_cmul < out.cs and (out_cmul > 1 or out.C == x.C), (out, x)
     if res is not None:
         assert res.rows == x.rows and res.C == x.C
-    _check(lib().sf_affine_fwd(x.ptr(), x.cs, x.coff, x.N, x.T, x.H, x.W, x.C, _ptr(scale), _ptr(bias),
-                               res.ptr() if res is not None else None, res.cs if res is not None else 0,
-                               res.coff if res is not None else 0, _act(relu), rep,
-                               out.ptr(), out.cs, out.coff, out_cmul, _stream()), "sf_affine_fwd")
+    tail = (_ptr(scale), _ptr(bias), res.ptr() if res is not None else None, res.cs if res is not None else 0,
+            res.coff if res is not None else 0, _act(relu), rep, out.ptr(), out.cs, out.coff, out_cmul, _stream())
+    if nsplit == 1:
+        _check(lib().sf_affine_fwd(x.ptr(), x.cs, x.coff, x.N, x.T, x.H, x.W, x.C, *tail), "sf_affine_fwd")
+    else:
+        _check(lib().sf_affine_fwd_split(x.ptr(), x.cs, x.coff, x.N, x.T, x.H, x.W, x.C, nsplit, *tail),
+               "sf_affine_fwd_split")
     return out
 
 
@@ -438,26 +449,39 @@ def unpack_conv_weight_grad(dwp, shape):
     return dwp[:, :, :cin].permute(0, 2, 1).reshape(cout, cin, kT, kH, kW).contiguous()
 
 
-def bn_bwd(dy, y, z, mean, invstd, gamma, relu, rep=1, dres=None, dz_out=None, dgamma_out=None):
+def bn_bwd(dy, y, z, mean, invstd, gamma, relu, rep=1, dres=None, dz_out=None, dgamma_out=None, nsplit=1,
+           sync=None):
     """Training BN backward (+ReLU mask, + residual fan-out, + upsample-copy sum).  Returns (dz, dgamma, dbeta);
-    dz is written over z unless dz_out is given."""
+    dz is written over z unless dz_out is given.
+    nsplit > 1 (SubBatchNorm3d): mean/invstd/gamma and the returned sums hold nsplit*C entries [split*C + c].
+    sync (NaiveSyncBatchNorm3d): callable (dbeta, dgamma) -> (dbeta', dgamma') applied between the reduction and
+    the normalisation pass (the cross-rank sum, already divided by the number of ranks); the LOCAL sums are
+    returned for the parameter gradients."""
     C = z.C
     dev = z.buf.device
     mean, invstd, gamma = mean.contiguous(), invstd.contiguous(), gamma.detach().contiguous()
-    dbeta = torch.empty((C,), dtype=torch.float32, device=dev)
-    dgamma = torch.empty((C,), dtype=torch.float32, device=dev)
+    dbeta = torch.empty((nsplit * C,), dtype=torch.float32, device=dev)
+    dgamma = torch.empty((nsplit * C,), dtype=torch.float32, device=dev)
     ws = torch.empty((lib().sf_bn_bwd_ws_floats(C),), dtype=torch.float32, device=dev)
     yp, ycs, yco = (y.ptr(), y.cs, y.coff) if y is not None else (None, 0, 0)
-    args = (dy.ptr(), dy.cs, dy.coff, yp, ycs, yco, z.ptr(), z.cs, z.coff, z.N, z.T, z.H, z.W, C, rep,
-            2 if relu == 6 else (1 if relu else 0), _ptr(mean), _ptr(invstd))
-    _check(lib().sf_bn_bwd_reduce(*args, _ptr(dbeta), _ptr(dgamma), _ptr(ws), _stream()), "sf_bn_bwd_reduce")
+    head = (dy.ptr(), dy.cs, dy.coff, yp, ycs, yco, z.ptr(), z.cs, z.coff, z.N, z.T, z.H, z.W, C)
+    tail = (rep, 2 if relu == 6 else (1 if relu else 0), _ptr(mean), _ptr(invstd))
+    split = (nsplit,) if nsplit > 1 else ()
+    reduce_fn = lib().sf_bn_bwd_reduce_split if nsplit > 1 else lib().sf_bn_bwd_reduce
+    apply_fn = lib().sf_bn_bwd_apply_split if nsplit > 1 else lib().sf_bn_bwd_apply
+    _check(reduce_fn(*head, *split, *tail, _ptr(dbeta), _ptr(dgamma), _ptr(ws), _stream()), "sf_bn_bwd_reduce")
+    db_apply, dg_apply = (dbeta, dgamma) if sync is None else sync(dbeta, dgamma)
     out = z if dz_out is None else dz_out
-    _check(lib().sf_bn_bwd_apply(*args, _ptr(gamma), _ptr(dbeta), _ptr(dgamma), out.ptr(), out.cs, out.coff,
-                                 dres.ptr() if dres is not None else None, dres.cs if dres is not None else 0,
-                                 dres.coff if dres is not None else 0, _stream()), "sf_bn_bwd_apply")
+    _check(apply_fn(*head, *split, *tail, _ptr(gamma), _ptr(db_apply), _ptr(dg_apply), out.ptr(), out.cs, out.coff,
+                    dres.ptr() if dres is not None else None, dres.cs if dres is not None else 0,
+                    dres.coff if dres is not None else 0, _stream()), "sf_bn_bwd_apply")
     if dgamma_out is not None:  # scatter into full-width parameter gradients (sliced BN, GhostModule)
-        dgamma_out[0][:C] = dgamma
-        dgamma_out[1][:C] = dbeta
+        if nsplit > 1:
+            dgamma_out[0][:C] = dgamma.view(nsplit, C).sum(0)
+            dgamma_out[1][:C] = dbeta.view(nsplit, C).sum(0)
+        else:
+            dgamma_out[0][:C] = dgamma
+            dgamma_out[1][:C] = dbeta
     return out, dgamma, dbeta
 
 
@@ -530,16 +554,23 @@ def attention_bwd(q, k, v, dz, o, lse, gamma, dq, dk, dv):
     return dvec
 
 
-def bn_train_stats(x, gamma, beta, eps, momentum, run_mean, run_var):
+def bn_train_stats(x, gamma, beta, eps, momentum, run_mean, run_var, nsplit=1):
     """Training BN statistics of the view + scale/shift + in-place running-stat update in two launches.
-    Returns (mean, invstd, scale, shift)."""
+    Returns (mean, invstd, scale, shift).  nsplit > 1 (SubBatchNorm3d): sample n belongs to split n % nsplit and
+    every array has nsplit*C entries laid out [split*C + c]."""
     _require_gpu(x.buf, "bn_train_stats")
     dev = x.buf.device
-    o = torch.empty((5, x.C), dtype=torch.float32, device=dev)
+    o = torch.empty((5, nsplit * x.C), dtype=torch.float32, device=dev)
     ws = torch.empty((lib().sf_channel_stats_ws_floats(x.C),), dtype=torch.float32, device=dev)
-    _check(lib().sf_bn_train_stats(x.ptr(), x.cs, x.coff, x.rows, x.C, _ptr(gamma), _ptr(beta), float(eps),
-                                   float(momentum), _ptr(run_mean), _ptr(run_var), _ptr(o[0]), _ptr(o[1]),
-                                   _ptr(o[2]), _ptr(o[3]), _ptr(o[4]), _ptr(ws), _stream()), "sf_bn_train_stats")
+    if nsplit == 1:
+        _check(lib().sf_bn_train_stats(x.ptr(), x.cs, x.coff, x.rows, x.C, _ptr(gamma), _ptr(beta), float(eps),
+                                       float(momentum), _ptr(run_mean), _ptr(run_var), _ptr(o[0]), _ptr(o[1]),
+                                       _ptr(o[2]), _ptr(o[3]), _ptr(o[4]), _ptr(ws), _stream()), "sf_bn_train_stats")
+    else:
+        _check(lib().sf_bn_train_stats_split(
+            x.ptr(), x.cs, x.coff, x.N, x.T * x.H * x.W, x.C, nsplit, _ptr(gamma), _ptr(beta), float(eps),
+            float(momentum), _ptr(run_mean), _ptr(run_var), _ptr(o[0]), _ptr(o[1]), _ptr(o[2]), _ptr(o[3]),
+            _ptr(o[4]), _ptr(ws), _stream()), "sf_bn_train_stats_split")
     return o[0], o[2], o[3], o[4]
 
 

@@ -153,47 +153,105 @@ def _cached(mod, slot, key, make):
 
 
 def check_bn(bn):
-    if not isinstance(bn, nn.BatchNorm3d):
-        raise NotImplementedError("only BN.NORM_TYPE=batchnorm is implemented on the HIP path (got %s)" % type(bn))
+    from .batchnorm_helper import SubBatchNorm3d
+    if not isinstance(bn, (nn.BatchNorm3d, SubBatchNorm3d)):
+        raise NotImplementedError("unsupported normalisation layer on the HIP path: %s" % type(bn))
+
+
+def _sub_bn(bn):
+    from .batchnorm_helper import SubBatchNorm3d
+    return isinstance(bn, SubBatchNorm3d)
+
+
+def _sync_bn(bn):
+    from .batchnorm_helper import NaiveSyncBatchNorm3d
+    from slowfast.utils import distributed as du
+    return isinstance(bn, NaiveSyncBatchNorm3d) and du.get_local_size() > 1
+
+
+def _bn_train_stats(bn, z):
+    """(mean, invstd, scale, shift, nsplit, gamma_for_backward, sync_hook) of a training-mode norm layer; updates
+    the running statistics in place exactly as the reference layer would."""
+    if _sub_bn(bn):
+        S, sb = bn.num_splits, bn.split_bn
+        if z.N % S != 0:
+            raise ValueError("SubBatchNorm3d: batch %d is not divisible by num_splits %d" % (z.N, S))
+        dev = z.buf.device
+        w = bn.weight.detach().repeat(S) if bn.affine else torch.ones(S * z.C, device=dev)
+        b = bn.bias.detach().repeat(S) if bn.affine else torch.zeros(S * z.C, device=dev)
+        track = sb.track_running_stats and sb.running_mean is not None
+        m = sb.momentum if sb.momentum is not None else 1.0 / float(int(sb.num_batches_tracked) + 1)
+        mean, invstd, scale, shift = sfhip.bn_train_stats(
+            z, w, b, sb.eps, m, sb.running_mean if track else None, sb.running_var if track else None, nsplit=S)
+        if track:
+            sb.num_batches_tracked.add_(1)
+        return mean, invstd, scale, shift, S, w, None
+    track = bn.track_running_stats and bn.running_mean is not None
+    m = bn.momentum if bn.momentum is not None else 1.0 / float(int(bn.num_batches_tracked) + 1)
+    if _sync_bn(bn):
+        from .batchnorm_helper import group_gather_sum
+        nd, ng = bn.num_sync_devices, bn.num_groups
+        lmean, lvar = sfhip.channel_stats(z)
+        lm = lmean.double()
+        vec = group_gather_sum(torch.cat([lm, lvar.double() + lm * lm]), nd, ng) / nd  # (mean, E[x^2]) in fp64
+        mean64, meansqr = vec[:z.C], vec[z.C:]
+        var64 = (meansqr - mean64 * mean64).clamp_min(0.0)
+        mean, var = mean64.float(), var64.float()
+        invstd = torch.rsqrt(var64 + bn.eps).float()
+        scale = (bn.weight.detach() * invstd).contiguous()
+        shift = (bn.bias.detach() - mean * scale).contiguous()
+        if track:  # the reference keeps the BIASED variance here (batchnorm_helper.py:207-208)
+            bn.running_mean += m * (mean - bn.running_mean)
+            bn.running_var += m * (var - bn.running_var)
+            bn.__dict__.pop("_sf_affine", None)
+
+        def sync(dbeta, dgamma):  # GroupGather.backward: the same gather-and-sum, then the 1/num_sync factor
+            tot = group_gather_sum(torch.cat([dbeta, dgamma]).double(), nd, ng) / nd
+            return tot[:dbeta.numel()].float().contiguous(), tot[dbeta.numel():].float().contiguous()
+
+        return mean, invstd, scale, shift, 1, bn.weight, sync
+    mean, invstd, scale, shift = sfhip.bn_train_stats(
+        z, bn.weight, bn.bias, bn.eps, m, bn.running_mean if track else None, bn.running_var if track else None)
+    if track:  # the kernel wrote the running buffers in place: drop the folded eval-mode affine cache
+        bn.__dict__.pop("_sf_affine", None)
+        bn.num_batches_tracked.add_(1)
+    return mean, invstd, scale, shift, 1, bn.weight, None
 
 
 def bn_train_apply(bn, z, res=None, relu=False, rep=1, out=None, out_reserve=(0, 0), keep=None, out_cmul=1):
     """Training-mode BatchNorm3d on the raw tensor z: batch statistics (sf_channel_stats), running-stat update
     (momentum, unbiased variance — torch semantics), then ONE normalise(+residual)(+ReLU)(+T-repeat) pass."""
     check_bn(bn)
-    track = bn.track_running_stats and bn.running_mean is not None
-    m = bn.momentum if bn.momentum is not None else 1.0 / float(int(bn.num_batches_tracked) + 1)
     with torch.no_grad():
-        mean, invstd, scale, shift = sfhip.bn_train_stats(
-            z, bn.weight, bn.bias, bn.eps, m, bn.running_mean if track else None, bn.running_var if track else None)
-        if track:  # the kernel wrote the running buffers in place: drop the folded eval-mode affine cache
-            bn.__dict__.pop("_sf_affine", None)
-            bn.num_batches_tracked.add_(1)
+        mean, invstd, scale, shift, nsplit, gamma_b, sync = _bn_train_stats(bn, z)
     zz = z if keep is None else z.slice(0, keep)
     nk = z.C if keep is None else keep
     if keep is not None:
+        assert nsplit == 1, "channel-sliced BN (GhostModule) is only defined for plain BatchNorm3d"
         scale, shift = scale[:keep].contiguous(), shift[:keep].contiguous()
     t = tape()
     shuffled = t is not None and out_cmul != 1
     if shuffled:
         # training: a channel-shuffled store is an explicit (taped) strided copy of the dense result
-        y = sfhip.affine(zz, scale.contiguous(), shift.contiguous(), res=res, relu=relu, rep=rep)
+        y = sfhip.affine(zz, scale.contiguous(), shift.contiguous(), res=res, relu=relu, rep=rep, nsplit=nsplit)
     else:
         y = sfhip.affine(zz, scale.contiguous(), shift.contiguous(), res=res, relu=relu, rep=rep, out=out,
-                         out_reserve=out_reserve, out_cmul=out_cmul)
+                         out_reserve=out_reserve, out_cmul=out_cmul, nsplit=nsplit)
     if t is not None:
-        dg = torch.zeros_like(bn.weight)
-        db = torch.zeros_like(bn.bias)
+        dg = torch.zeros(z.C, dtype=torch.float32, device=z.buf.device)
+        db = torch.zeros(z.C, dtype=torch.float32, device=z.buf.device)
+        sel = slice(None) if nsplit > 1 else slice(0, nk)
 
         def bwd():
             dres = t.grad_of(res) if res is not None else None
-            sfhip.bn_bwd(t.grad_of(y), y, zz, mean[:nk], invstd[:nk], bn.weight[:nk], relu, rep=rep, dres=dres,
-                         dz_out=zz, dgamma_out=(dg, db))
+            sfhip.bn_bwd(t.grad_of(y), y, zz, mean[sel], invstd[sel], gamma_b[sel], relu, rep=rep, dres=dres,
+                         dz_out=zz, dgamma_out=(dg, db), nsplit=nsplit, sync=sync)
             if keep is not None and keep < z.C:  # sliced-away channels (GhostModule [:oup]) get no gradient
                 rest = z.slice(keep, z.C - keep)
                 sfhip.axpy(rest, rest, alpha=0.0, accumulate=False)
-            t.add_pgrad(bn.weight, dg)
-            t.add_pgrad(bn.bias, db)
+            if getattr(bn, "weight", None) is not None:
+                t.add_pgrad(bn.weight, dg)
+                t.add_pgrad(bn.bias, db)
 
         t.record(bwd)  # afterwards z's buffer holds dL/dz for the producer's backward
     if shuffled:  # recorded AFTER the BN op so that its backward (the gather) runs first
@@ -204,15 +262,28 @@ def bn_train_apply(bn, z, res=None, relu=False, rep=1, out=None, out_reserve=(0,
 def bn_affine(bn, conv_bias=None):
     """Eval-mode BatchNorm3d as per-channel (scale, bias); a preceding conv bias is folded in."""
     check_bn(bn)
+    stat = bn.bn if _sub_bn(bn) else bn  # SubBatchNorm3d evaluates with the aggregated `bn` statistics
+    w = getattr(bn, "weight", None)
+    b = getattr(bn, "bias", None)
 
     def make():
-        scale = bn.weight / torch.sqrt(bn.running_var + bn.eps)
-        bias = bn.bias - bn.running_mean * scale
+        inv = 1.0 / torch.sqrt(stat.running_var + stat.eps)
+        scale = w * inv if w is not None else inv
+        bias = -stat.running_mean * scale
+        if b is not None:
+            bias = bias + b
         if conv_bias is not None:
             bias = bias + scale * conv_bias
-        return scale.contiguous(), bias.contiguous()
+        return scale.detach().contiguous(), bias.detach().contiguous()
 
-    return _cached(bn, "_sf_affine", _key(bn.weight, bn.bias, bn.running_mean, bn.running_var, conv_bias), make)
+    return _cached(bn, "_sf_affine", _key(w, b, stat.running_mean, stat.running_var, conv_bias), make)
+
+
+def norm_forward(bn, x):
+    """A norm layer called on its own (NCTHW tensor or Act): the HIP statistics / normalise kernels."""
+    (a,) = enter([x])
+    y = bn_train_apply(bn, a) if bn.training else sfhip.affine(a, *bn_affine(bn))
+    return leave([y])[0]
 
 
 def packed_weight(conv):

@@ -11,6 +11,44 @@ import torch
 import torch.distributed as dist
 
 
+_LOCAL_PROCESS_GROUP = None  # per-node group (reference utils/distributed.py:12, 258-273)
+
+
+def init_distributed_training(cfg):
+    """Create one process group per machine and keep this machine's (utils/distributed.py:258-273)."""
+    global _LOCAL_PROCESS_GROUP
+    if cfg.NUM_GPUS == 1:
+        return
+    per = cfg.NUM_GPUS
+    for i in range(dist.get_world_size() // per):
+        pg = dist.new_group(list(range(i * per, (i + 1) * per)))
+        if i == cfg.SHARD_ID:
+            _LOCAL_PROCESS_GROUP = pg
+
+
+def get_local_size():
+    """Processes per machine (utils/distributed.py:276-286)."""
+    if not dist.is_available() or not dist.is_initialized():
+        return 1
+    return dist.get_world_size(group=_LOCAL_PROCESS_GROUP)
+
+
+def get_local_rank():
+    """Rank within the per-machine group (utils/distributed.py:289-299)."""
+    if not dist.is_available() or not dist.is_initialized():
+        return 0
+    assert _LOCAL_PROCESS_GROUP is not None
+    return dist.get_rank(group=_LOCAL_PROCESS_GROUP)
+
+
+def get_world_size():
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+def get_rank():
+    return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+
+
 def shard_sizes(global_batch, world):
     """Clips per rank (loader.py:67: TRAIN.BATCH_SIZE / NUM_GPUS, must divide)."""
     if global_batch % world != 0:

@@ -209,6 +209,27 @@ int sf_rowdot(const float* a, int a_cs, int a_coff, const float* b, int b_cs, in
               float scale, float* out, void* stream);
 int sf_axpy(const float* a, int a_cs, int a_coff, float alpha, float* out, int out_cs, int out_coff, long rows,
             int C, int accumulate, void* stream);
+/* ---- SubBatchNorm3d (batchnorm_helper.py:37-109): the batch is viewed as [N/S, S*C, T, H, W], i.e. sample n
+ * belongs to split n % S and every split normalises with its own statistics (nn.BatchNorm3d(S*C, affine=False)).
+ * The `_split` variants take nsplit = S and per-channel arrays of S*C entries indexed [split*C + c] (the layout of
+ * split_bn.running_mean / running_var); with nsplit = 1 they are the plain functions above.  Requires N % S == 0
+ * and N <= 1024.  sf_bn_bwd_apply_split divides by the rows of ONE split (M = N/S * T*H*W).                 */
+int sf_bn_train_stats_split(const float* x, int cs, int coff, int N, long rows_per_sample, int C, int nsplit,
+                            const float* gamma, const float* beta, float eps, float momentum, float* run_mean,
+                            float* run_var, float* mean, float* var, float* invstd, float* scale, float* shift,
+                            float* ws, void* stream);
+int sf_affine_fwd_split(const float* x, int cs, int coff, int N, int T, int H, int W, int C, int nsplit,
+                        const float* scale, const float* bias, const float* res, int res_cs, int res_coff, int act,
+                        int rep, float* out, int out_cs, int out_coff, int out_cmul, void* stream);
+int sf_bn_bwd_reduce_split(const float* dy, int dy_cs, int dy_coff, const float* y, int y_cs, int y_coff,
+                           const float* z, int z_cs, int z_coff, int N, int T, int H, int W, int C, int nsplit,
+                           int rep, int relu, const float* mean, const float* invstd, float* dbeta, float* dgamma,
+                           float* ws, void* stream);
+int sf_bn_bwd_apply_split(const float* dy, int dy_cs, int dy_coff, const float* y, int y_cs, int y_coff,
+                          const float* z, int z_cs, int z_coff, int N, int T, int H, int W, int C, int nsplit,
+                          int rep, int relu, const float* mean, const float* invstd, const float* gamma,
+                          const float* dbeta, const float* dgamma, float* dz, int dz_cs, int dz_coff, float* dres,
+                          int dres_cs, int dres_coff, void* stream);
 /* dx[r, c] (+)= dy[r, c] * [0 < y[r, c] (< 6)]: backward of a bare nn.ReLU / nn.ReLU6 (act = SF_ACT_RELU |
  * SF_ACT_RELU6) that has no BN in front of it, e.g. relu(cat([out, shortcut(x)])) in the ShuffleNet v1
  * Bottleneck (shufflenet_helper.py:76-77); the mask is taken from the activation's OUTPUT y.            */

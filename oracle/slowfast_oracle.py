@@ -47,10 +47,36 @@ def default_hparams(**over):
 def _bn(sd, p, x, training, eps=1e-5):
     """nn.BatchNorm3d forward (batchnorm_helper.py:15-34 → torch).  training=True uses biased
     batch statistics (running buffers are left untouched: the oracle is stateless)."""
+    if (p + ".split_bn.running_mean") in sd:
+        return _sub_bn(sd, p, x, training, eps)
     w, b = sd[p + ".weight"], sd[p + ".bias"]
     if training:
         return F.batch_norm(x, None, None, w, b, True, 0.0, eps)
     return F.batch_norm(x, sd[p + ".running_mean"], sd[p + ".running_var"], w, b, False, 0.0, eps)
+
+
+def _sub_bn(sd, p, x, training, eps=1e-5):
+    """SubBatchNorm3d (batchnorm_helper.py:37-109): training = affine-free BN over the batch viewed as
+    [N/S, S*C, T, H, W] (sample n -> split n % S), eval = affine-free BN with the aggregated `bn` running
+    statistics; then the single shared weight / bias."""
+    n, c, t, h, w_ = x.shape
+    if training:
+        S = sd[p + ".split_bn.running_mean"].numel() // c
+        y = F.batch_norm(x.reshape(n // S, c * S, t, h, w_), None, None, None, None, True, 0.0, eps)
+        y = y.reshape(n, c, t, h, w_)
+    else:
+        y = F.batch_norm(x, sd[p + ".bn.running_mean"], sd[p + ".bn.running_var"], None, None, False, 0.0, eps)
+    if (p + ".weight") in sd:
+        y = y * sd[p + ".weight"].view(-1, 1, 1, 1) + sd[p + ".bias"].view(-1, 1, 1, 1)
+    return y
+
+
+def sub_bn_aggregate(means, variances, n):
+    """SubBatchNorm3d._get_aggregated_mean_std (batchnorm_helper.py:66-79): mean of the split means, mean of the
+    split variances plus the variance of the split means."""
+    m = means.view(n, -1)
+    mean = m.sum(0) / n
+    return mean, variances.view(n, -1).sum(0) / n + ((m - mean) ** 2).sum(0) / n
 
 
 def _conv(sd, p, x, stride=1, padding=0, dilation=1, groups=1):

@@ -52,6 +52,10 @@ CASES = [
     dict(name="mobilenetv2_w1_s64", yaml="SLOWFAST_MOBILENETV2_8x8_R50_stepwise_multigrid.yaml",
          model="SlowFastMoibleNetV2", batch=2, t=16, alpha=4, size=64,
          over=["SLOWFAST.WIDTH_MULTI", 1.0, "SLOWFAST.ALPHA", 4] + small(64, 16)),
+    # SubBatchNorm3d (multigrid long cycle), NUM_SPLITS 2 over a batch of 4
+    dict(name="dual_r50_subbn_s64", yaml="SLOWFAST_DUAL_8x8_R50_stepwise_multigrid.yaml",
+         model="SlowFastDualAttention", batch=4, t=16, alpha=4, size=64,
+         over=["BN.NORM_TYPE", "sub_batchnorm", "BN.NUM_SPLITS", 2] + small(64, 16)),
     # SlowFastShuffleNet (v1, GROUPS 1 as its YAML) + CMDA at S=64, T=16
     dict(name="shufflenet_g1_s64", yaml="SLOWFAST_SHUFFLENET_8x8_R50_stepwise_multigrid.yaml",
          model="SlowFastShuffleNet", batch=2, t=16, alpha=4, size=64,
@@ -177,6 +181,11 @@ def run_case(case, get_cfg, build_model):
         s, amax, mean = sample_activation(g.numpy(), 4096)
         out["grad/" + k] = s
         out["grad/" + k + "/stats"] = np.array([amax, float(g.norm())], np.float64)
+    # running statistics after ONE training forward (momentum update; SubBatchNorm3d: per-split buffers)
+    after = model.state_dict()
+    bufs = [k for k in after if k.endswith("running_mean") or k.endswith("running_var")]
+    for k in bufs[:4] + bufs[len(bufs) // 2:len(bufs) // 2 + 4] + bufs[-4:]:
+        out["train_buffers/" + k] = after[k].numpy().copy()
     for i, nm in enumerate(("slow", "fast")):
         s, amax, mean = sample_activation(xs[i].grad.numpy(), 4096)
         out["grad_input/" + nm] = s

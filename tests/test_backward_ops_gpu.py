@@ -139,6 +139,57 @@ def test_bn_backward(c, relu, use_res, rep, hw):
     assert max(errs) < TOL, errs
 
 
+@pytest.mark.parametrize("c,nsplit,n,relu,use_res,rep", [(16, 2, 4, True, True, 1), (7, 4, 8, False, False, 1),
+                                                        (32, 2, 6, True, False, 4)])
+def test_sub_batchnorm_forward_backward(c, nsplit, n, relu, use_res, rep):
+    """SubBatchNorm3d training pass (batchnorm_helper.py:96-109): per-split statistics, shared affine, running
+    statistics of the S*C split_bn, and the backward through the split statistics — vs torch autograd."""
+    import sfhip
+    from slowfast.models import engine
+    from slowfast.models.batchnorm_helper import SubBatchNorm3d
+    dev = _dev()
+    g = torch.Generator().manual_seed(c * 7 + nsplit)
+    x = (torch.randn(n, c, 2, 5, 3, generator=g) * 2.0 + 0.5).requires_grad_(True)
+    res = torch.randn(n, c, 2, 5, 3, generator=g).requires_grad_(True) if use_res else None
+    ref_bn = SubBatchNorm3d(nsplit, num_features=c, eps=1e-5, momentum=0.1)
+    ref_bn.weight.data = torch.rand(c, generator=g) + 0.5
+    ref_bn.bias.data = torch.randn(c, generator=g) * 0.2
+    ref_bn.split_bn.running_mean.copy_(torch.randn(nsplit * c, generator=g))
+    ref_bn.split_bn.running_var.copy_(torch.rand(nsplit * c, generator=g) + 0.5)
+    mine = SubBatchNorm3d(nsplit, num_features=c, eps=1e-5, momentum=0.1).to(dev)
+    mine.load_state_dict(ref_bn.state_dict())
+    # torch reference: exactly the reference module's training forward
+    y = ref_bn.split_bn(x.reshape(n // nsplit, c * nsplit, 2, 5, 3)).reshape(n, c, 2, 5, 3)
+    y = y * ref_bn.weight.view(-1, 1, 1, 1) + ref_bn.bias.view(-1, 1, 1, 1)
+    if use_res:
+        y = y + res
+    if relu:
+        y = F.relu(y)
+    y = y.repeat_interleave(rep, dim=2)
+    dy = torch.randn(y.shape, generator=g)
+    outs = torch.autograd.grad(y, [x, ref_bn.weight, ref_bn.bias] + ([res] if use_res else []), dy)
+    t = engine.Tape()
+    xa = _act(x)
+    ra = _act(res) if use_res else None
+    with torch.no_grad(), engine.taping(t):
+        ya = engine.bn_train_apply(mine, xa, res=ra, relu=relu, rep=rep)
+        yv = _back(ya)
+        t.grad_of(ya).buf.copy_(dy.permute(0, 2, 3, 4, 1).to(dev))
+        if use_res:
+            dra = t.grad_of(ra)
+        t.backward()
+    torch.cuda.synchronize()
+    errs = [_rel(yv, y), _rel(_back(xa), outs[0]), _rel(t.pgrads[mine.weight], outs[1]),
+            _rel(t.pgrads[mine.bias], outs[2]),
+            _rel(mine.split_bn.running_mean, ref_bn.split_bn.running_mean),
+            _rel(mine.split_bn.running_var, ref_bn.split_bn.running_var)]
+    if use_res:
+        errs.append(_rel(_back(dra), outs[3]))
+    _report("sub_bn c%d S%d n%d relu%d res%d rep%d" % (c, nsplit, n, relu, use_res, rep), max(errs))
+    assert max(errs) < TOL, errs
+    assert int(mine.split_bn.num_batches_tracked) == 1 and int(mine.bn.num_batches_tracked) == 0
+
+
 @pytest.mark.parametrize("k,s,p", [((1, 3, 3), (1, 2, 2), (0, 1, 1)), ((3, 3, 3), (1, 2, 2), (1, 1, 1))])
 def test_maxpool_backward(k, s, p):
     import sfhip

@@ -50,3 +50,23 @@ def test_no_cpu_fallback():
     a = sfhip.Act(torch.zeros(1, 2, 4, 4, 8))
     with pytest.raises(sfhip.SfhipError):
         sfhip.conv(a, torch.zeros(8, 1, 16), (1, 1, 1))
+
+
+def test_sub_bn_aggregate_matches_oracle():
+    """SubBatchNorm3d.aggregate_stats / utils.misc.aggregate_sub_bn_stats (host logic) vs the oracle's restatement
+    of batchnorm_helper.py:66-95."""
+    import torch
+    from oracle import slowfast_oracle as oracle
+    from slowfast.models.batchnorm_helper import SubBatchNorm3d
+    from slowfast.utils.misc import aggregate_sub_bn_stats
+    torch.manual_seed(3)
+    holder = torch.nn.Sequential(SubBatchNorm3d(4, num_features=6, eps=1e-5, momentum=0.1), torch.nn.ReLU())
+    sb = holder[0]
+    sb.split_bn.running_mean.copy_(torch.randn(24))
+    sb.split_bn.running_var.copy_(torch.rand(24) + 0.5)
+    assert aggregate_sub_bn_stats(holder) == 1
+    mean, var = oracle.sub_bn_aggregate(sb.split_bn.running_mean, sb.split_bn.running_var, 4)
+    assert torch.allclose(sb.bn.running_mean, mean) and torch.allclose(sb.bn.running_var, var)
+    assert list(sb.state_dict().keys()) == ["weight", "bias", "bn.running_mean", "bn.running_var",
+                                            "bn.num_batches_tracked", "split_bn.running_mean",
+                                            "split_bn.running_var", "split_bn.num_batches_tracked"]
