@@ -88,9 +88,13 @@ def group_gather_sum(vec, num_sync_devices, num_groups):
     rank's sync group, sum.  Used for the statistics and — its autograd backward being the same operation — for
     the gradient sums."""
     import torch.distributed as dist
+    group = du._LOCAL_PROCESS_GROUP
+    dev = vec.device
+    if vec.is_cuda and dist.get_backend(group) == "gloo":
+        vec = vec.cpu()  # gloo has no device all_gather; RCCL ("nccl") gathers in place on the GPU
     parts = [torch.zeros_like(vec) for _ in range(du.get_local_size())]
-    dist.all_gather(parts, vec, async_op=False, group=du._LOCAL_PROCESS_GROUP)
-    stacked = torch.stack(parts, dim=0)
+    dist.all_gather(parts, vec, async_op=False, group=group)
+    stacked = torch.stack(parts, dim=0).to(dev)
     if num_groups > 1:
         g = du.get_local_rank() // num_sync_devices
         stacked = stacked[g * num_sync_devices:(g + 1) * num_sync_devices]

@@ -51,6 +51,9 @@ def _bn(sd, p, x, training, eps=1e-5):
         return _sub_bn(sd, p, x, training, eps)
     w, b = sd[p + ".weight"], sd[p + ".bias"]
     if training:
+        rec = sd.get("__bn_batch_stats__")  # optional recorder: {prefix: (batch mean, UNBIASED batch var)}
+        if rec is not None:
+            rec[p] = (x.mean((0, 2, 3, 4)).detach(), x.transpose(0, 1).reshape(x.shape[1], -1).var(1).detach())
         return F.batch_norm(x, None, None, w, b, True, 0.0, eps)
     return F.batch_norm(x, sd[p + ".running_mean"], sd[p + ".running_var"], w, b, False, 0.0, eps)
 

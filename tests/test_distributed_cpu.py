@@ -87,3 +87,37 @@ def test_shard_sizes():
     assert shard_sizes(64, 8) == [8] * 8
     with pytest.raises(ValueError):
         shard_sizes(10, 4)
+
+
+def _gather_worker(rank, world, port):
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                    "efficient-slowfast_amd"))
+    import slowfast.utils.distributed as du
+    from slowfast.models.batchnorm_helper import NaiveSyncBatchNorm3d, get_norm, group_gather_sum
+    from slowfast.config.defaults import get_cfg
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    try:
+        assert du.get_local_size() == world  # default group until init_distributed_training narrows it
+        cfg = get_cfg()
+        cfg.NUM_GPUS, cfg.SHARD_ID = world, 0
+        du.init_distributed_training(cfg)
+        assert du.get_local_size() == world and du.get_local_rank() == rank
+        vec = torch.arange(6, dtype=torch.float64) + 10.0 * rank
+        tot = group_gather_sum(vec, world, 1)              # one sync group of both ranks
+        assert torch.equal(tot, 2 * torch.arange(6, dtype=torch.float64) + 10.0)
+        own = group_gather_sum(vec, 1, world)              # NUM_SYNC_DEVICES 1 -> every rank its own group
+        assert torch.equal(own, vec)
+        cfg.BN.NORM_TYPE, cfg.BN.NUM_SYNC_DEVICES = "sync_batchnorm", 1
+        bn = get_norm(cfg)(num_features=4)
+        assert isinstance(bn, NaiveSyncBatchNorm3d) and (bn.num_sync_devices, bn.num_groups) == (1, world)
+        cfg.BN.NUM_SYNC_DEVICES = 0                        # <= 0 means "all local ranks"
+        bn = get_norm(cfg)(num_features=4)
+        assert (bn.num_sync_devices, bn.num_groups) == (world, 1)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sync_bn_group_gather_world2():
+    """GroupGather semantics (batchnorm_helper.py:112-171) and the per-node process group on 2 gloo ranks."""
+    mp.spawn(_gather_worker, args=(2, _free_port()), nprocs=2, join=True)

@@ -244,3 +244,44 @@ def test_train_step_gradients_match_reference_golden(name):
             assert abs(norm - rnorm) < 5e-2 * rnorm + 1e-9, (k, norm, rnorm)
     missing = [k for k, p in params.items() if p.grad is None]
     assert not missing, missing[:5]
+
+
+def test_precise_bn_pass_matches_oracle_batch_statistics():
+    """calculate_and_update_precise_bn (train_net.py:277-296 -> fvcore update_bn_stats): after the pass every BN's
+    running statistics are the plain average over the iterations of its per-batch (mean, unbiased var); the
+    oracle's train-mode forward records those per batch."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from oracle import slowfast_oracle as oracle
+    from slowfast.utils.precise_bn import get_bn_modules, update_bn_stats
+    z, meta = load_case("dual_r50_s64")
+    model, sd = _build(meta, z)
+    model.train()
+    base = case_inputs(meta)
+    batches = [[x * s for x in base] for s in (1.0, 0.7, 1.3)]
+    assert len(get_bn_modules(model)) == sum(isinstance(m, torch.nn.BatchNorm3d) for m in model.modules())
+    mom = model.s1.pathway0_stem.bn.momentum
+    update_bn_stats(model, ([x.cuda() for x in b] for b in batches), num_iters=3)
+    torch.cuda.synchronize()
+    assert model.s1.pathway0_stem.bn.momentum == mom
+    sums = {}
+    for b in batches:
+        rec = {}
+        sdr = dict(sd)
+        sdr["__bn_batch_stats__"] = rec
+        with torch.no_grad():
+            oracle.FORWARDS[meta["model"]](sdr, [x.clone() for x in b], meta["hparams"], training=True)
+        for k, (m, v) in rec.items():
+            a = sums.setdefault(k, [torch.zeros_like(m), torch.zeros_like(v)])
+            a[0] += m / 3.0
+            a[1] += v / 3.0
+    after = model.state_dict()
+    assert len(sums) >= 100
+    worst = 0.0
+    for k, (m, v) in sums.items():
+        worst = max(worst, rel_err(after[k + ".running_mean"].cpu().numpy(), m.numpy()),
+                    rel_err(after[k + ".running_var"].cpu().numpy(), v.numpy()))
+    _report("precise-bn: %d layers, worst running-stat error %.3e" % (len(sums), worst))
+    assert worst < 1e-3
+    with pytest.raises(AssertionError):
+        update_bn_stats(model, iter([[x.cuda() for x in base]]), num_iters=2)  # loader shorter than num_iters

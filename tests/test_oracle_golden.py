@@ -87,3 +87,32 @@ def test_pack_pathway_known_answer():
     # datasets/utils.py:93-104 for T=32, alpha=4: NOT a plain stride-4
     assert oracle.pack_pathway_indices(32, 4) == [0, 4, 8, 13, 17, 22, 26, 31]
     assert oracle.pack_pathway_indices(32, 8) == [0, 10, 20, 31]
+
+
+def test_sync_bn_two_rank_reference_equals_full_batch_oracle():
+    """NaiveSyncBatchNorm3d over 2 ranks x 2 clips (reference run with gloo, make_golden_sync.py) is, by
+    batchnorm_helper.py:186-218, plain batch-statistics BN over the union batch: the oracle on the 4-clip batch
+    must reproduce both ranks' logits, and its gradient of sum_r loss_r the SUM of the ranks' local gradients
+    (GroupGather.backward sums the statistic gradients over ranks)."""
+    z, meta = load_case("dual_r50_syncbn_s64")
+    sd = seeded_state_dict(z["sd_keys"], z["sd_shapes"], meta["param_seed"])
+    sdr = {k: (v.clone().requires_grad_(True) if v.dtype == torch.float32 and "running" not in k else v)
+           for k, v in sd.items()}
+    acts = oracle.FORWARDS[meta["model"]](sdr, case_inputs(meta), meta["hparams"], training=True)
+    logits, labels = acts["out"], torch.from_numpy(z["labels"])
+    per = meta["batch"] // meta["world"]
+    total = 0.0
+    for r in range(meta["world"]):
+        sl = slice(r * per, (r + 1) * per)
+        assert rel_err(logits[sl].detach().numpy(), z["r%d/logits" % r]) < TOL
+        loss = torch.nn.functional.cross_entropy(logits[sl], labels[sl])
+        assert abs(loss.item() - float(z["r%d/loss" % r][0])) < 1e-4
+        total = total + loss
+    total.backward()
+    keys = [k[len("r0/grad/"):] for k in z.files if k.startswith("r0/grad/") and not k.endswith("/stats")]
+    assert len(keys) >= 6
+    for k in keys:
+        ref = sum(z["r%d/grad/%s" % (r, k)].astype(np.float64) for r in range(meta["world"]))
+        s, _, _ = sample_activation(sdr[k].grad.numpy(), 4096)
+        e = float(np.linalg.norm(s - ref) / max(np.linalg.norm(ref), 1e-30))
+        assert e < 5e-2, (k, e)  # ReLU / max-pool tie flips between the two runs (see test_models_gpu gradient note)
