@@ -50,6 +50,7 @@ EXPORTS = [
     "sf_attn_bwd", "sf_maxpool_bwd", "sf_tmax_dot", "sf_eca_bwd_apply", "sf_bcast_add", "sf_rowdot", "sf_axpy", "sf_act_bwd",
     "sf_dwconv_dgrad", "sf_dwconv_wgrad_ws_floats", "sf_dwconv_wgrad", "sf_gather_add",
     "sf_bn_train_stats_split", "sf_affine_fwd_split", "sf_bn_bwd_reduce_split", "sf_bn_bwd_apply_split",
+    "sf_clip_prologue",
 ]
 _LONG_RET = ("sf_tmax_mean_ws_floats", "sf_channel_stats_ws_floats", "sf_bn_bwd_ws_floats",
              "sf_dwconv_wgrad_ws_floats")
@@ -109,6 +110,7 @@ def lib():
         L.sf_dwconv_wgrad_ws_floats.restype = cl
         L.sf_dwconv_wgrad.argtypes = [ctypes.POINTER(ConvDesc), vp, vp, ci, ci, ci, vp, vp, vp]
         L.sf_gather_add.argtypes = [vp, ci, ci, ci, vp, ci, ci, cl, ci, ci, vp]
+        L.sf_clip_prologue.argtypes = [vp] + [ci] * 10 + [ctypes.POINTER(ctypes.c_float)] * 2 + [vp, ci, vp, ci, ci, ci, vp]
         L.sf_bn_train_stats_split.argtypes = [vp, ci, ci, ci, cl, ci, ci, vp, vp, cf, cf] + [vp] * 9
         L.sf_affine_fwd_split.argtypes = [vp, ci, ci] + [ci] * 6 + [vp, vp, vp, ci, ci, ci, ci, vp, ci, ci, ci, vp]
         L.sf_bn_bwd_reduce_split.argtypes = [vp, ci, ci, vp, ci, ci, vp, ci, ci] + [ci] * 8 + [vp] * 5 + [vp]
@@ -194,6 +196,46 @@ def from_ncthw(x, cpad=None, ph=0, pw=0, wp=None):
     buf = torch.empty((N, T, H + 2 * ph, wp, cpad), dtype=torch.float32, device=x.device)
     _check(lib().sf_ncthw_to_ndhwc(_ptr(x), _ptr(buf), N, C, T, H, W, cpad, ph, pw, wp, _stream()), "sf_ncthw_to_ndhwc")
     return Act(buf, 0, cpad)
+
+
+class PackedClip(object):
+    """A pathway input already in the stem's layout: buf [N, T, H+2*ph, Wp, 4] fp32 (channels padded to 4, zero
+    H/W borders).  Produced by `clip_prologue`; accepted by the model in place of an NCTHW tensor."""
+
+    def __init__(self, buf, channels, H, W, ph, pw):
+        self.buf, self.C, self.H, self.W, self.ph, self.pw = buf, channels, H, W, ph, pw
+
+    @property
+    def shape(self):  # the logical NCTHW shape the reference's tensor would have
+        return (self.buf.shape[0], self.C, self.buf.shape[1], self.H, self.W)
+
+    @property
+    def Wp(self):
+        return self.buf.shape[3]
+
+    def to_ncthw(self):
+        v = self.buf[:, :, self.ph:self.ph + self.H, self.pw:self.pw + self.W, :self.C]
+        return v.permute(0, 4, 1, 2, 3).contiguous()
+
+
+def clip_prologue(clip_u8, dst, new_hw, yx, crop, flip, mean, std, frame_idx=None, reverse=False, ph=0, pw=0):
+    """One decoded clip (uint8 [T,H,W,3], device) -> dst (float [n_frames, crop+2ph, Wp, 4] view of a PackedClip
+    buffer): normalise, bilinear short-side scale, crop, flip, frame selection in one kernel."""
+    _require_gpu(dst, "clip_prologue")
+    if not clip_u8.is_cuda:
+        raise SfhipError("clip_prologue: the uint8 clip is on %s — copy it to the GPU first" % clip_u8.device)
+    assert clip_u8.dtype == torch.uint8 and clip_u8.dim() == 4 and clip_u8.shape[3] == 3 and clip_u8.is_contiguous()
+    assert dst.dtype == torch.float32 and dst.is_contiguous() and dst.shape[3] == 4
+    T, H, W, _ = clip_u8.shape
+    n = dst.shape[0]
+    assert dst.shape[1] == crop + 2 * ph
+    m3 = (ctypes.c_float * 3)(*[float(v) for v in mean])
+    s3 = (ctypes.c_float * 3)(*[float(v) for v in std])
+    _check(lib().sf_clip_prologue(_ptr(clip_u8), T, H, W, int(new_hw[0]), int(new_hw[1]), int(yx[0]), int(yx[1]),
+                                  int(crop), 1 if flip else 0, 1 if reverse else 0, m3, s3,
+                                  _ptr(frame_idx) if frame_idx is not None else None, n, _ptr(dst), ph, pw,
+                                  dst.shape[2], _stream()), "sf_clip_prologue")
+    return dst
 
 
 def to_ncthw(a):

@@ -345,6 +345,16 @@ def conv_bn_act(x, conv, bn=None, relu=False, res=None, out=None, out_reserve=(0
                         out_cmul=out_cmul)
 
 
+def stem_geometry(conv, H, W):
+    """(ph, pw, Wp) of the border-padded NDHWC4 input the stem convolution `conv` consumes for H x W frames."""
+    kT, kH, kW = conv.kernel_size
+    _, sH, sW = conv.stride
+    pT, pH, pW = conv.padding
+    Wo = (W + 2 * pW - kW) // sW + 1
+    wp_need = max(W + 2 * pW, (Wo - 1) * sW + kW)
+    return pH, pW, (wp_need + sW - 1) // sW * sW
+
+
 def stem_conv_bn_relu(x, conv, bn, relu=True):
     """First convolution of a pathway straight from the caller's NCTHW clip (Cin <= 4).
 
@@ -361,8 +371,14 @@ def stem_conv_bn_relu(x, conv, bn, relu=True):
     Wo = (W + 2 * pW - kW) // sW + 1
     wp_need = max(W + 2 * pW, (Wo - 1) * sW + kW)
     Wp = (wp_need + sW - 1) // sW * sW
-    a = sfhip.from_ncthw(x, cpad=4, ph=pH, pw=pW, wp=Wp)
-    view = Act(a.buf.view(N, T, H + 2 * pH, Wp // sW, 4 * sW))
+    if isinstance(x, sfhip.PackedClip):  # produced by the GPU input step already in this layout
+        if (x.ph, x.pw, x.Wp) != (pH, pW, Wp):
+            raise ValueError("PackedClip geometry (ph, pw, Wp) = %s does not match this stem's %s; pack it with "
+                             "engine.stem_geometry(conv, H, W)" % ((x.ph, x.pw, x.Wp), (pH, pW, Wp)))
+        abuf = x.buf
+    else:
+        abuf = sfhip.from_ncthw(x, cpad=4, ph=pH, pw=pW, wp=Wp).buf
+    view = Act(abuf.view(N, T, H + 2 * pH, Wp // sW, 4 * sW))
 
     def make():
         w = conv.weight

@@ -236,6 +236,17 @@ int sf_bn_bwd_apply_split(const float* dy, int dy_cs, int dy_coff, const float* 
 int sf_act_bwd(const float* dy, int dy_cs, int dy_coff, const float* y, int y_cs, int y_coff, int act, float* dx,
                int dx_cs, int dx_coff, long rows, int C, int accumulate, void* stream);
 
+/* ---- input step (datasets/kinetics.py:230-248 -> datasets/utils.py:298-315 tensor_normalize, :151-203
+ * spatial_sampling, :73-112 pack_pathway_output; transform.py:283-337 / 359-393 / 395-423 / 425-468).
+ * clip: ONE decoded clip, uint8 [T,H,W,3] on the device.  The short side is scaled bilinearly to (new_h, new_w)
+ * (== (H, W): no resampling), a crop x crop window at (y0, x0) of the scaled frame is taken, optionally mirrored,
+ * normalised as (u/255 - mean)/std, channel-reversed if asked, and the frames frame_idx[0..n_frames) (device ints;
+ * NULL = all T frames) are written to dst [n_frames][crop+2ph][Wp][4]: the stems' NDHWC layout with the channel
+ * padded to 4 and zero borders, so the stem convolution consumes it without a layout pass.  mean3/std3: HOST.   */
+int sf_clip_prologue(const unsigned char* clip, int T, int H, int W, int new_h, int new_w, int y0, int x0, int crop,
+                     int flip, int reverse, const float* mean3, const float* std3, const int* frame_idx,
+                     int n_frames, float* dst, int ph, int pw, int Wp, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
