@@ -87,3 +87,20 @@ def input_step(clip_u8, mean, std, spatial_idx, min_scale, max_scale, crop_size,
     frames = tensor_normalize(torch.from_numpy(clip_u8), mean, std).permute(3, 0, 1, 2)
     frames, params = spatial_sampling(frames, spatial_idx, min_scale, max_scale, crop_size, flip, inverse_uniform)
     return pack_pathway_output(frames, alpha, reverse), params
+
+
+def test_meter_ensemble(preds, labels, clip_ids, num_videos, num_clips, method="sum"):
+    """TestMeter.update_stats' per-clip loop (utils/meters.py:277-312) + finalize top-k (:351-366,
+    utils/metrics.py:9-42) restated with numpy.  PARITY UNPINNED: utils/meters.py is not importable in the build
+    container and the reference ships no test for it."""
+    vp = np.zeros((num_videos, preds.shape[1]), np.float32)
+    vl = np.zeros((num_videos,), np.int64)
+    cnt = np.zeros((num_videos,), np.int64)
+    for i in range(preds.shape[0]):
+        v = int(clip_ids[i]) // num_clips
+        vl[v] = labels[i]
+        vp[v] = vp[v] + preds[i] if method == "sum" else np.maximum(vp[v], preds[i])
+        cnt[v] += 1
+    order = np.argsort(-vp, axis=1, kind="stable")
+    top = {k: float((order[:, :k] == vl[:, None]).any(1).sum()) / num_videos * 100.0 for k in (1, 5)}
+    return vp, vl, cnt, top

@@ -148,3 +148,23 @@ def test_models_accept_packed_clips(case):
     wrong = ds.gpu_input_step(clips, params, cfg.DATA.MEAN, cfg.DATA.STD, cfg.SLOWFAST.ALPHA, pad=(ph + 1, pw), wp=wp)
     with pytest.raises(ValueError):
         model(list(wrong))
+
+
+@pytest.mark.parametrize("method", ["sum", "max"])
+def test_test_meter_ensemble_matches_loop_restatement(method):
+    from slowfast.utils.meters import TestMeter
+    rs = np.random.RandomState(3)
+    nv, nc, ncls = 7, 6, 20
+    ids = rs.permutation(nv * nc)
+    labels_v = rs.randint(0, ncls, nv)
+    preds = rs.rand(nv * nc, ncls).astype(np.float32)
+    labels = labels_v[ids // nc]
+    meter = TestMeter(nv, nc, ncls, overall_iters=6, ensemble_method=method)
+    for s in range(0, nv * nc, 7):
+        meter.update_stats(torch.from_numpy(preds[s:s + 7]), torch.from_numpy(labels[s:s + 7]),
+                           torch.from_numpy(ids[s:s + 7]))
+    vp, vl, cnt, top = input_oracle.test_meter_ensemble(preds, labels, ids, nv, nc, method)
+    assert np.allclose(meter.video_preds.numpy(), vp, atol=1e-6) and np.array_equal(meter.video_labels.numpy(), vl)
+    assert np.array_equal(meter.clip_count.numpy(), cnt)
+    stats = meter.finalize_metrics()
+    assert stats["complete"] and stats["top1_acc"] == "%.2f" % top[1] and stats["top5_acc"] == "%.2f" % top[5]
