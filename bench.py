@@ -172,6 +172,9 @@ def main():
     ap.add_argument("--mode", default="train", choices=["train", "eval"])
     ap.add_argument("--no-graph", action="store_true", help="(eval) launch eagerly instead of replaying a hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="profiling aid: skip the secondary eval-forward measurement and the HIP-event roofline trace so "
+                         "that a rocprofv3 --stats run contains exactly warmup+steps identical steps")
     ap.add_argument("--aten-gpu-baseline", action="store_true",
                     help="also time the oracle graph on stock ATen/MIOpen kernels on this GPU (informational)")
     args = ap.parse_args()
@@ -254,7 +257,7 @@ def main():
 
     # ---- secondary: eval-mode forward (inference) clips/s of the same model, hipGraph replay
     eval_fwd = None
-    if train:
+    if train and not args.no_extras:
         model.eval()
 
         def estep():
@@ -283,7 +286,7 @@ def main():
     # ---- dominant-kernel trace: HIP events around every attention launch (forward and backward) over a few
     #      eager steps on the stream the kernels run on
     roofline = None
-    if rank == 0 and args.workload in ("dual", "ghostnet", "shufflenetv2"):
+    if rank == 0 and args.workload in ("dual", "ghostnet", "shufflenetv2") and not args.no_extras:
         sfhip.EVENT_TRACE = []
         with torch.cuda.stream(side):
             for _ in range(min(args.steps, 3)):

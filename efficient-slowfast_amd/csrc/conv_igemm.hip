@@ -213,6 +213,20 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
   }
 
   // ---- epilogue
+  // Scattered stores (strided data-gradient classes): output position (n,t,h,w) of this launch lands at
+  // (t*os_T + oo_T, h*os_H + oo_H, w*os_W + oo_W) of a destination of dims ob_T x ob_H x ob_W.
+  const bool scatter = d.os_T > 1 || d.os_H > 1 || d.os_W > 1;
+  auto out_row = [&](int m) -> long {
+    if (!scatter) return (long)m;
+    const int wo = m % d.Wo;
+    const int t1 = m / d.Wo;
+    const int ho = t1 % d.Ho;
+    const int t2 = t1 / d.Ho;
+    const int to = t2 % d.To;
+    const int n = t2 / d.To;
+    const int st = d.os_T > 1 ? d.os_T : 1, sh = d.os_H > 1 ? d.os_H : 1, sw = d.os_W > 1 ? d.os_W : 1;
+    return (((long)n * d.ob_T + to * st + d.oo_T) * d.ob_H + ho * sh + d.oo_H) * d.ob_W + wo * sw + d.oo_W;
+  };
   const bool has_res = p.res != nullptr;
   const bool relu = d.act == SF_ACT_RELU || d.act == SF_ACT_RELU6;
   const float hi = d.act == SF_ACT_RELU6 ? 6.f : 3.0e38f;
@@ -245,14 +259,15 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
         const int row = lane / LPR + q * RPP;
         const int m = m0 + wm * (BM / WM) + i * 16 + row;
         if (n_ok && m < p.M) {
+          const long orow = out_row(m);
           f32x4 v = *reinterpret_cast<const f32x4*>(slab + row * EP + c4);
           v = v * sc + bi;
-          if (has_res) v += *reinterpret_cast<const f32x4*>(p.res + (long)m * d.res_cs + d.res_coff + n);
+          if (has_res) v += *reinterpret_cast<const f32x4*>(p.res + orow * d.res_cs + d.res_coff + n);
           if (relu) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = fminf(fmaxf(v[e], 0.f), hi);
           }
-          *reinterpret_cast<f32x4*>(p.out + (long)m * d.out_cs + d.out_coff + n) = v;
+          *reinterpret_cast<f32x4*>(p.out + orow * d.out_cs + d.out_coff + n) = v;
         }
       }
       __syncthreads();
@@ -272,10 +287,11 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
       for (int r = 0; r < 4; ++r) {
         const int m = m0 + wm * (BM / WM) + i * 16 + fg * 4 + r;
         if (m >= p.M) continue;
+        const long orow = out_row(m);
         float v = acc[i][j][r] * sc + bi;
-        if (has_res) v += p.res[(long)m * d.res_cs + d.res_coff + n];
+        if (has_res) v += p.res[orow * d.res_cs + d.res_coff + n];
         v = relu ? fminf(fmaxf(v, 0.f), hi) : v;
-        p.out[(long)m * d.out_cs + d.out_coff + (long)n * d.out_cmul] = v;
+        p.out[orow * d.out_cs + d.out_coff + (long)n * d.out_cmul] = v;
       }
     }
   }
@@ -346,6 +362,13 @@ extern "C" int sf_conv_fwd(const sf_conv_desc* d, const float* in, const float* 
   if (!sf_aligned16(w_packed)) return SF_EALIGN;
   const long M = (long)d->N * d->To * d->Ho * d->Wo;
   if (M <= 0 || M > 0x7fffffffL) return SF_EINVAL;
+  const bool scatter = d->os_T > 1 || d->os_H > 1 || d->os_W > 1;
+  if (scatter) {  // every scattered position must lie inside the destination
+    const int st = d->os_T > 1 ? d->os_T : 1, sh = d->os_H > 1 ? d->os_H : 1, sw = d->os_W > 1 ? d->os_W : 1;
+    if (d->oo_T < 0 || d->oo_H < 0 || d->oo_W < 0 || (d->To - 1) * st + d->oo_T >= d->ob_T ||
+        (d->Ho - 1) * sh + d->oo_H >= d->ob_H || (d->Wo - 1) * sw + d->oo_W >= d->ob_W)
+      return SF_EINVAL;
+  }
   ConvArgs a;
   a.d = *d;
   a.in = in; a.w = w_packed; a.scale = scale; a.bias = bias; a.res = res; a.out = out;
@@ -357,7 +380,7 @@ extern "C" int sf_conv_fwd(const sf_conv_desc* d, const float* in, const float* 
               sf_aligned16(out) && (!scale || sf_aligned16(scale)) && (!bias || sf_aligned16(bias)) &&
               (!res || ((d->res_cs % 4 == 0) && (d->res_coff % 4 == 0) && sf_aligned16(res)));
   hipStream_t s = (hipStream_t)stream;
-  if (M <= GEMV_MMAX && a.ntaps == 1 && vec4 && d->sT == 1 && d->sH == 1 && d->sW == 1 && d->pT == 0 &&
+  if (M <= GEMV_MMAX && !scatter && a.ntaps == 1 && vec4 && d->sT == 1 && d->sH == 1 && d->sW == 1 && d->pT == 0 &&
       d->pH == 0 && d->pW == 0) {
     hipLaunchKernelGGL(gemv_rows_kernel, dim3(sf_cdiv(d->Cout, 4)), dim3(256), 0, s, a);
     SF_CHECK_LAUNCH();

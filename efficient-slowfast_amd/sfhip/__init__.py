@@ -33,7 +33,7 @@ class ConvDesc(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int) for n in (
         "N", "Ti", "Hi", "Wi", "Cin", "in_cs", "in_coff", "To", "Ho", "Wo", "Cout", "out_cs", "out_coff",
         "out_cmul", "kT", "kH", "kW", "sT", "sH", "sW", "pT", "pH", "pW", "dT", "dH", "dW", "cin_pad", "act",
-        "res_cs", "res_coff", "transposed")]
+        "res_cs", "res_coff", "transposed", "os_T", "os_H", "os_W", "oo_T", "oo_H", "oo_W", "ob_T", "ob_H", "ob_W")]
 
 
 class PoolDesc(ctypes.Structure):
@@ -458,12 +458,62 @@ def conv_dgrad(dz, wt_packed, x_like, kernel, stride=(1, 1, 1), padding=(0, 0, 0
         out = new_act(dz, x_like.N, x_like.T, x_like.H, x_like.W, cin)
         accumulate = False
     assert (out.N, out.T, out.H, out.W, out.C) == (x_like.N, x_like.T, x_like.H, x_like.W, cin), (out, x_like)
+    if max(stride) > 1 and tuple(dilation) == (1, 1, 1) and (accumulate or (out.coff == 0 and out.cs == out.C)):
+        return _conv_dgrad_strided(dz, wt_packed, out, kernel, stride, padding, accumulate)
     d = ConvDesc(dz.N, dz.T, dz.H, dz.W, dz.C, dz.cs, dz.coff, out.T, out.H, out.W, cin, out.cs, out.coff, 1,
                  kernel[0], kernel[1], kernel[2], stride[0], stride[1], stride[2], padding[0], padding[1],
                  padding[2], dilation[0], dilation[1], dilation[2], cout_pad, ACT_NONE,
                  out.cs if accumulate else 0, out.coff if accumulate else 0, 1)
     _check(lib().sf_conv_fwd(ctypes.byref(d), dz.ptr(), _ptr(wt_packed), None, None,
                              out.ptr() if accumulate else None, out.ptr(), _stream()), "sf_conv_fwd(transposed)")
+    return out
+
+
+_CLASS_W = {}  # (weight ptr, version, class) -> tap-subset packed weights
+
+
+def _residue_taps(k, s, p, a):
+    """Taps kk of a stride-s, pad-p, size-k kernel that reach input positions = a (mod s), as (offsets, taps):
+    input position s*i + a receives dz[i + off] through tap kk, off = (a + p - kk) / s; returned in ascending
+    off order so that they form a dense stride-1 kernel over dz."""
+    pairs = sorted(((a + p - kk) // s, kk) for kk in range(k) if (a + p - kk) % s == 0)
+    return [o for o, _ in pairs], [kk for _, kk in pairs]
+
+
+def _conv_dgrad_strided(dz, wt_packed, out, kernel, stride, padding, accumulate):
+    """Data gradient of a strided conv as one DENSE small conv over dL/dz per residue class of the input position
+    (the transposed-gather formulation evaluates every tap at every input position and predicates s^2-1 of s^2
+    of them away).  Class (a_t, a_h, a_w): dx[s*i + a] = sum_j dz[i - pad' + j] * W[tap_j]; stores are scattered
+    to the class's positions by the conv kernel's epilogue."""
+    cin, _, cout_pad = wt_packed.shape
+    kT, kH, kW = kernel
+    if not accumulate:
+        out.buf.zero_()
+    for at in range(stride[0]):
+        ot, tt = _residue_taps(kT, stride[0], padding[0], at)
+        for ah in range(stride[1]):
+            oh, th = _residue_taps(kH, stride[1], padding[1], ah)
+            for aw in range(stride[2]):
+                ow, tw = _residue_taps(kW, stride[2], padding[2], aw)
+                dims = [(full - a + s - 1) // s for full, a, s in zip((out.T, out.H, out.W), (at, ah, aw), stride)]
+                if not (tt and th and tw) or min(dims) <= 0:
+                    continue  # no tap reaches this class: its gradient is zero
+                key = (wt_packed.data_ptr(), wt_packed._version, at, ah, aw, tuple(kernel), tuple(stride),
+                       tuple(padding))
+                wsub = _CLASS_W.get(key)
+                if wsub is None:
+                    idx = torch.tensor([(a * kH + b) * kW + c for a in tt for b in th for c in tw],
+                                       dtype=torch.long, device=wt_packed.device)
+                    wsub = wt_packed.index_select(1, idx).contiguous()
+                    if len(_CLASS_W) > 4096:
+                        _CLASS_W.clear()
+                    _CLASS_W[key] = wsub
+                d = ConvDesc(dz.N, dz.T, dz.H, dz.W, dz.C, dz.cs, dz.coff, dims[0], dims[1], dims[2], cin, out.cs,
+                             out.coff, 1, len(tt), len(th), len(tw), 1, 1, 1, -ot[0], -oh[0], -ow[0], 1, 1, 1,
+                             cout_pad, ACT_NONE, out.cs, out.coff, 0, stride[0], stride[1], stride[2], at, ah, aw,
+                             out.T, out.H, out.W)
+                _check(lib().sf_conv_fwd(ctypes.byref(d), dz.ptr(), _ptr(wsub), None, None, out.ptr(), out.ptr(),
+                                         _stream()), "sf_conv_fwd(strided dgrad class)")
     return out
 
 

@@ -66,6 +66,11 @@ typedef struct sf_conv_desc {
   int transposed;              /* 1: data-gradient of the conv described by k/s/p/d: "in" is dL/dz with   */
                                /* dims (Ti,Hi,Wi) = the forward OUTPUT dims, "out" is dL/dx with dims     */
                                /* (To,Ho,Wo) = the forward INPUT dims, weights packed [Cin][tap][Cout]    */
+  int os_T, os_H, os_W;        /* scattered store (all <= 1: dense).  Output position (t,h,w) of this launch  */
+  int oo_T, oo_H, oo_W;        /* is written (and its residual read) at (t*os_T+oo_T, h*os_H+oo_H,            */
+  int ob_T, ob_H, ob_W;        /* w*os_W+oo_W) of a destination with dims ob_T x ob_H x ob_W: one residue     */
+                               /* class of the data gradient of a strided conv (resnet_helper.py:179,         */
+                               /* :326-335 stride-2 3x3 / 1x1) is then a DENSE small-kernel conv over dL/dz.   */
 } sf_conv_desc;
 int sf_conv_fwd(const sf_conv_desc* d, const float* in, const float* w_packed, const float* scale,
                 const float* bias, const float* res, float* out, void* stream);

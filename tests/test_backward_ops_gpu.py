@@ -52,6 +52,8 @@ CONV_CASES = [
     ("pw_8_24", 8, 24, (1, 1, 1), (1, 1, 1), (0, 0, 0), (2, 4, 9, 9)),
     ("odd_27_16", 27, 16, (1, 1, 1), (1, 1, 1), (0, 0, 0), (2, 4, 5, 5)),
     ("fc_2304_400", 2304, 400, (1, 1, 1), (1, 1, 1), (0, 0, 0), (8, 1, 1, 1)),
+    ("s5_k5_s2_48_32", 48, 32, (1, 5, 5), (1, 2, 2), (0, 2, 2), (2, 2, 13, 11)),
+    ("t3_s2t_odd_24_40", 24, 40, (3, 3, 1), (2, 2, 1), (1, 1, 0), (1, 7, 9, 5)),
     ("head_320_1280_m32", 320, 1280, (1, 1, 1), (1, 1, 1), (0, 0, 0), (2, 4, 2, 2)),
     ("pw_96_16_m32", 96, 16, (1, 1, 1), (1, 1, 1), (0, 0, 0), (2, 4, 2, 2)),
 ]

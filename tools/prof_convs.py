@@ -1,0 +1,87 @@
+#!/usr/bin/env python3
+"""Per-shape timing of every dense conv launch (forward, dgrad, wgrad) of one training step of a bench workload:
+HIP events around each C-ABI call (synchronised per call: a profiling aid, not a benchmark).
+usage: tools/prof_convs.py [workload] [batch]"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "efficient-slowfast_amd")]
+import torch  # noqa: E402
+import sfhip  # noqa: E402
+import bench  # noqa: E402
+
+workload = sys.argv[1] if len(sys.argv) > 1 else "dual"
+dev = torch.device("cuda:0")
+cfg, model, batch, desc = bench.build(workload, dev)
+batch = int(sys.argv[2]) if len(sys.argv) > 2 else batch
+clips = bench.synthetic_clips(cfg, batch, dev, 100)
+labels = torch.randint(0, cfg.MODEL.NUM_CLASSES, (batch,), device=dev)
+model.train()
+
+
+def step():
+    model.zero_grad(set_to_none=True)
+    loss = torch.nn.functional.cross_entropy(model([clips[0], clips[1]]), labels)
+    loss.backward()
+
+
+for _ in range(2):
+    step()
+torch.cuda.synchronize()
+rec = {}
+orig = {n: getattr(sfhip, n) for n in ("conv", "conv_dgrad", "conv_wgrad")}
+
+
+def timed(kind, fn, describe):
+    def w(*a, **k):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        r = fn(*a, **k)
+        e1.record()
+        e1.synchronize()
+        key = (kind,) + describe(*a, **k)
+        v = rec.setdefault(key, [0, 0.0])
+        v[0] += 1
+        v[1] += e0.elapsed_time(e1)
+        return r
+    return w
+
+
+def d_conv(x, wp, kernel, stride=(1, 1, 1), padding=(0, 0, 0), dilation=(1, 1, 1), **k):
+    cin = k.get("cin") or x.C
+    return (x.N * x.T * x.H * x.W, cin, wp.shape[0], tuple(kernel), tuple(stride), (x.T, x.H, x.W))
+
+
+def d_dgrad(dz, wtp, x_like, kernel, stride=(1, 1, 1), padding=(0, 0, 0), dilation=(1, 1, 1), **k):
+    return (x_like.N * x_like.T * x_like.H * x_like.W, dz.C, x_like.C, tuple(kernel), tuple(stride),
+            (x_like.T, x_like.H, x_like.W))
+
+
+def d_wgrad(x, dz, cout, kernel, stride=(1, 1, 1), padding=(0, 0, 0), dilation=(1, 1, 1), cin=None, cin_pad=None):
+    return (dz.N * dz.T * dz.H * dz.W, cin or x.C, cout, tuple(kernel), tuple(stride), (x.T, x.H, x.W))
+
+
+sfhip.conv = timed("fwd", orig["conv"], d_conv)
+sfhip.conv_dgrad = timed("dgrad", orig["conv_dgrad"], d_dgrad)
+sfhip.conv_wgrad = timed("wgrad", orig["conv_wgrad"], d_wgrad)
+step()
+torch.cuda.synchronize()
+rows = []
+for (kind, m, cin, cout, k, s, thw), (n, ms) in rec.items():
+    taps = k[0] * k[1] * k[2]
+    mm = m if kind != "dgrad" else m // (s[0] * s[1] * s[2])  # dgrad: useful MACs are counted at the OUTPUT positions
+    flops = 2.0 * mm * cin * cout * taps * n
+    rows.append((ms, kind, n, m, cin, cout, k, s, thw, flops / (ms * 1e-3) / 1e12))
+rows.sort(reverse=True)
+tot = sum(r[0] for r in rows)
+print("%-6s %3s %9s %5s %5s %-9s %-9s %-12s %8s %7s" % ("kind", "n", "rows", "cin", "cout", "kernel", "stride", "THW",
+                                                      "ms", "TF/s"))
+for ms, kind, n, m, cin, cout, k, s, thw, tf in rows[:70]:
+    print("%-6s %3d %9d %5d %5d %-9s %-9s %-12s %8.3f %7.1f" % (kind, n, m, cin, cout, "x".join(map(str, k)),
+                                                                "x".join(map(str, s)), "x".join(map(str, thw)), ms, tf))
+for kind in ("fwd", "dgrad", "wgrad"):
+    sel = [r for r in rows if r[1] == kind]
+    print("%-6s total %.2f ms, %.1f TF/s aggregate" % (kind, sum(r[0] for r in sel),
+                                                        sum(r[9] * r[0] for r in sel) / max(sum(r[0] for r in sel), 1e-9)))
+print("all convs: %.2f ms" % tot)
