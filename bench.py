@@ -206,6 +206,8 @@ def main():
     if train:
         model.train()
         flat = FlatGradients(model.parameters())
+        from slowfast.models import engine
+        engine.set_grad_sink(os.environ.get("SF_NO_GRAD_SINK") != "1")  # backward kernels accumulate straight into the flat gradient buffer
         opt = torch.optim.SGD(model.parameters(), lr=1e-3, momentum=0.9, weight_decay=1e-4)
 
         def step():

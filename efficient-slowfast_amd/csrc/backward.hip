@@ -116,7 +116,8 @@ __global__ void bn_bwd_partial_kernel(const float* __restrict__ dy, int dy_cs, i
 }
 
 __global__ void pair_final_kernel(const float* __restrict__ partial, int C, int P, int chunks, int S,
-                                  float* __restrict__ o1, float* __restrict__ o2) {
+                                  float* __restrict__ o1, float* __restrict__ o2, float* __restrict__ acc1,
+                                  float* __restrict__ acc2) {
   __shared__ double r1[64], r2[64];
   const int o = blockIdx.x;  // split * C + channel
   const int sp = o / C, c = o - sp * C;
@@ -139,6 +140,10 @@ __global__ void pair_final_kernel(const float* __restrict__ partial, int C, int 
   if (threadIdx.x == 0) {
     o1[o] = (float)r1[0];
     o2[o] = (float)r2[0];
+    if (acc1) {  // parameter-gradient sink: dL/dbeta, dL/dgamma accumulate straight into .grad
+      acc1[o] += (float)r1[0];
+      acc2[o] += (float)r2[0];
+    }
   }
 }
 
@@ -350,7 +355,9 @@ extern "C" long sf_bn_bwd_ws_floats(int C) { return (long)MAX_P * 2 * C; }
 static int bn_bwd_reduce_launch(const float* dy, int dy_cs, int dy_coff, const float* y, int y_cs, int y_coff,
                                 const float* z, int z_cs, int z_coff, int N, int T, int H, int W, int C, int S,
                                 int rep, int relu, const float* mean, const float* invstd, float* dbeta,
-                                float* dgamma, float* ws, void* stream) {
+                                float* dgamma, float* ws, void* stream, float* dbeta_acc = nullptr,
+                                float* dgamma_acc = nullptr) {
+  if ((dbeta_acc == nullptr) != (dgamma_acc == nullptr)) return SF_EINVAL;
   if (!dy || !z || !mean || !invstd || !dbeta || !dgamma || !ws || (relu && !y)) return SF_EINVAL;
   if (N <= 0 || T <= 0 || H <= 0 || W <= 0 || C <= 0 || rep <= 0 || S <= 0 || N % S != 0) return SF_EINVAL;
   if (S > 1 && N > MAX_P) return SF_EINVAL;
@@ -375,7 +382,7 @@ static int bn_bwd_reduce_launch(const float* dy, int dy_cs, int dy_coff, const f
                        y, y_cs, y_coff, z, z_cs, z_coff, group_rows, chunks, S, (long)T * H * W, H * W, C, rep, relu,
                        mean, invstd, CB, ws);
   hipLaunchKernelGGL(pair_final_kernel, dim3(S * C), dim3(64), 0, (hipStream_t)stream, ws, C, P, chunks, S, dbeta,
-                     dgamma);
+                     dgamma, dbeta_acc, dgamma_acc);
   SF_CHECK_LAUNCH();
   return SF_OK;
 }
@@ -386,6 +393,14 @@ extern "C" int sf_bn_bwd_reduce(const float* dy, int dy_cs, int dy_coff, const f
                                 float* ws, void* stream) {
   return bn_bwd_reduce_launch(dy, dy_cs, dy_coff, y, y_cs, y_coff, z, z_cs, z_coff, N, T, H, W, C, 1, rep, relu, mean,
                               invstd, dbeta, dgamma, ws, stream);
+}
+
+extern "C" int sf_bn_bwd_reduce_acc(const float* dy, int dy_cs, int dy_coff, const float* y, int y_cs, int y_coff,
+                                    const float* z, int z_cs, int z_coff, int N, int T, int H, int W, int C, int rep,
+                                    int relu, const float* mean, const float* invstd, float* dbeta, float* dgamma,
+                                    float* ws, float* dbeta_acc, float* dgamma_acc, void* stream) {
+  return bn_bwd_reduce_launch(dy, dy_cs, dy_coff, y, y_cs, y_coff, z, z_cs, z_coff, N, T, H, W, C, 1, rep, relu, mean,
+                              invstd, dbeta, dgamma, ws, stream, dbeta_acc, dgamma_acc);
 }
 
 extern "C" int sf_bn_bwd_reduce_split(const float* dy, int dy_cs, int dy_coff, const float* y, int y_cs, int y_coff,

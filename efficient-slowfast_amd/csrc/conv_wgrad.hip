@@ -365,7 +365,70 @@ static int launch_wgrad(WgradArgs a, bool vec4, hipStream_t s) {
   return SF_OK;
 }
 
+// dst[co][ci][tap] (+)= sum_s part[s][co][tap'][c']: the split partials summed in a fixed order AND un-packed to the
+// nn.Conv3d weight layout [Cout, Cin, kT, kH, kW] in one pass.  One workgroup per (co, 64-channel tile): partial
+// rows are read coalesced along c, transposed through LDS ([c][tap] — which IS the destination order), and the
+// ptaps*64 contiguous destination floats are written / accumulated coalesced.
+constexpr int FIN_C = 64;
+__global__ __launch_bounds__(256) void wgrad_finish_kernel(const float* __restrict__ part, int S, int Cout, int ptaps,
+                                                           int cin_pad, int Cin, float* __restrict__ dst,
+                                                           int accumulate) {
+  extern __shared__ float tile[];  // [FIN_C][ptaps]
+  const int co = blockIdx.x, c0 = blockIdx.y * FIN_C;
+  const int c = threadIdx.x & (FIN_C - 1), tq = threadIdx.x / FIN_C;
+  const long stride = (long)Cout * ptaps * cin_pad;
+  if (c0 + c < cin_pad) {
+    for (int tap = tq; tap < ptaps; tap += 256 / FIN_C) {
+      const float* src = part + ((long)co * ptaps + tap) * cin_pad + c0 + c;
+      float v = 0.f;
+      for (int s = 0; s < S; ++s) v += src[s * stride];
+      tile[c * ptaps + tap] = v;
+    }
+  }
+  __syncthreads();
+  const int ncols = (Cin - c0) < FIN_C ? (Cin - c0) : FIN_C;  // real channels in this tile
+  if (ncols <= 0) return;
+  float* out = dst + ((long)co * Cin + c0) * ptaps;
+  for (int e = threadIdx.x; e < ncols * ptaps; e += 256) out[e] = accumulate ? out[e] + tile[e] : tile[e];
+}
+
+// stem layout: a packed "channel" c' is (kw, ci) = (c' / 4, c' % 4) and a packed tap is (kt, kh); tiny tensors.
+__global__ void wgrad_finish_stem_kernel(const float* __restrict__ part, int S, int Cout, int ptaps, int cin_pad,
+                                         int Cin, int fold_kw, float* __restrict__ dst, int accumulate, long total) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int c = (int)(idx % cin_pad);
+  const long r = idx / cin_pad;
+  const int tap = (int)(r % ptaps);
+  const int co = (int)(r / ptaps);
+  const int kw = c >> 2, ci = c & 3;
+  if (kw >= fold_kw || ci >= Cin) return;
+  const long o = (((long)co * Cin + ci) * ptaps + tap) * fold_kw + kw;
+  const long stride = (long)Cout * ptaps * cin_pad;
+  float v = 0.f;
+  for (int s = 0; s < S; ++s) v += part[s * stride + idx];
+  dst[o] = accumulate ? dst[o] + v : v;
+}
+
 }  // namespace
+
+extern "C" int sf_conv_wgrad_finish(const float* partial, int S, int Cout, int packed_taps, int cin_pad, int Cin,
+                                    int fold_kw, float* dst, int accumulate, void* stream) {
+  if (!partial || !dst || S <= 0 || Cout <= 0 || packed_taps <= 0 || cin_pad <= 0 || Cin <= 0 || fold_kw < 0)
+    return SF_EINVAL;
+  if (fold_kw > 0 ? (Cin > 4 || fold_kw * 4 > cin_pad) : Cin > cin_pad) return SF_EINVAL;
+  if (fold_kw > 0) {
+    const long total = (long)Cout * packed_taps * cin_pad;
+    hipLaunchKernelGGL(wgrad_finish_stem_kernel, dim3(sf_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, partial,
+                       S, Cout, packed_taps, cin_pad, Cin, fold_kw, dst, accumulate, total);
+  } else {
+    hipLaunchKernelGGL(wgrad_finish_kernel, dim3(Cout, sf_cdiv(cin_pad, FIN_C)), dim3(256),
+                       (size_t)FIN_C * packed_taps * sizeof(float), (hipStream_t)stream, partial, S, Cout, packed_taps,
+                       cin_pad, Cin, dst, accumulate);
+  }
+  SF_CHECK_LAUNCH();
+  return SF_OK;
+}
 
 // Number of position splits the kernel will use for this problem (the caller sizes the workspace with it).
 extern "C" int sf_conv_wgrad_splits(const sf_conv_desc* d) {

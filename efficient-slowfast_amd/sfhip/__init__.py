@@ -50,7 +50,7 @@ EXPORTS = [
     "sf_attn_bwd", "sf_maxpool_bwd", "sf_tmax_dot", "sf_eca_bwd_apply", "sf_bcast_add", "sf_rowdot", "sf_axpy", "sf_act_bwd",
     "sf_dwconv_dgrad", "sf_dwconv_wgrad_ws_floats", "sf_dwconv_wgrad", "sf_gather_add",
     "sf_bn_train_stats_split", "sf_affine_fwd_split", "sf_bn_bwd_reduce_split", "sf_bn_bwd_apply_split",
-    "sf_clip_prologue",
+    "sf_clip_prologue", "sf_conv_wgrad_finish", "sf_bn_bwd_reduce_acc",
 ]
 _LONG_RET = ("sf_tmax_mean_ws_floats", "sf_channel_stats_ws_floats", "sf_bn_bwd_ws_floats",
              "sf_dwconv_wgrad_ws_floats")
@@ -111,6 +111,8 @@ def lib():
         L.sf_dwconv_wgrad.argtypes = [ctypes.POINTER(ConvDesc), vp, vp, ci, ci, ci, vp, vp, vp]
         L.sf_gather_add.argtypes = [vp, ci, ci, ci, vp, ci, ci, cl, ci, ci, vp]
         L.sf_clip_prologue.argtypes = [vp] + [ci] * 10 + [ctypes.POINTER(ctypes.c_float)] * 2 + [vp, ci, vp, ci, ci, ci, vp]
+        L.sf_conv_wgrad_finish.argtypes = [vp, ci, ci, ci, ci, ci, ci, vp, ci, vp]
+        L.sf_bn_bwd_reduce_acc.argtypes = [vp, ci, ci, vp, ci, ci, vp, ci, ci] + [ci] * 7 + [vp] * 5 + [vp, vp, vp]
         L.sf_bn_train_stats_split.argtypes = [vp, ci, ci, ci, cl, ci, ci, vp, vp, cf, cf] + [vp] * 9
         L.sf_affine_fwd_split.argtypes = [vp, ci, ci] + [ci] * 6 + [vp, vp, vp, ci, ci, ci, ci, vp, ci, ci, ci, vp]
         L.sf_bn_bwd_reduce_split.argtypes = [vp, ci, ci, vp, ci, ci, vp, ci, ci] + [ci] * 8 + [vp] * 5 + [vp]
@@ -519,8 +521,10 @@ def _conv_dgrad_strided(dz, wt_packed, out, kernel, stride, padding, accumulate)
 
 # ------------------------------------------------------------------------------------------------ backward
 def conv_wgrad(x, dz, cout, kernel, stride=(1, 1, 1), padding=(0, 0, 0), dilation=(1, 1, 1), cin=None,
-               cin_pad=None):
-    """dW packed [Cout, taps, cin_pad] = sum over positions of dz (x) x (split partials summed in fixed order)."""
+               cin_pad=None, finish_into=None):
+    """dW packed [Cout, taps, cin_pad] = sum over positions of dz (x) x (split partials summed in fixed order).
+    finish_into=(dst, Cin, fold_kw): instead of returning the packed gradient, sum the partials and ACCUMULATE
+    them into dst, a contiguous tensor in nn.Conv3d's [Cout, Cin, kT, kH, kW] layout (e.g. the weight's .grad)."""
     _require_gpu(x.buf, "conv_wgrad")
     cin = x.C if cin is None else cin
     cin_pad = (cin + 15) // 16 * 16 if cin_pad is None else cin_pad
@@ -532,6 +536,15 @@ def conv_wgrad(x, dz, cout, kernel, stride=(1, 1, 1), padding=(0, 0, 0), dilatio
     part = torch.empty((S, cout, kT * kH * kW, cin_pad), dtype=torch.float32, device=x.buf.device)
     _check(lib().sf_conv_wgrad(ctypes.byref(d), x.ptr(), dz.ptr(), dz.cs, dz.coff, _ptr(part), _stream()),
            "sf_conv_wgrad")
+    if finish_into is not None:
+        dst, real_cin, fold_kw = finish_into
+        assert dst.is_contiguous() and dst.dtype == torch.float32
+        if S > 4:  # many position splits (small weights, huge M): a parallel tree sum first, the finish pass is serial in S
+            part, S = part.sum(0, keepdim=True), 1
+        assert dst.numel() == cout * real_cin * kT * kH * kW * max(fold_kw, 1), (dst.shape, cout, real_cin, kernel)
+        _check(lib().sf_conv_wgrad_finish(_ptr(part), S, cout, kT * kH * kW, cin_pad, real_cin, fold_kw, _ptr(dst), 1,
+                                          _stream()), "sf_conv_wgrad_finish")
+        return None
     return part.sum(0) if S > 1 else part[0]
 
 
@@ -542,7 +555,7 @@ def unpack_conv_weight_grad(dwp, shape):
 
 
 def bn_bwd(dy, y, z, mean, invstd, gamma, relu, rep=1, dres=None, dz_out=None, dgamma_out=None, nsplit=1,
-           sync=None):
+           sync=None, grad_sink=None):
     """Training BN backward (+ReLU mask, + residual fan-out, + upsample-copy sum).  Returns (dz, dgamma, dbeta);
     dz is written over z unless dz_out is given.
     nsplit > 1 (SubBatchNorm3d): mean/invstd/gamma and the returned sums hold nsplit*C entries [split*C + c].
@@ -561,7 +574,12 @@ def bn_bwd(dy, y, z, mean, invstd, gamma, relu, rep=1, dres=None, dz_out=None, d
     split = (nsplit,) if nsplit > 1 else ()
     reduce_fn = lib().sf_bn_bwd_reduce_split if nsplit > 1 else lib().sf_bn_bwd_reduce
     apply_fn = lib().sf_bn_bwd_apply_split if nsplit > 1 else lib().sf_bn_bwd_apply
-    _check(reduce_fn(*head, *split, *tail, _ptr(dbeta), _ptr(dgamma), _ptr(ws), _stream()), "sf_bn_bwd_reduce")
+    if grad_sink is not None:  # (weight.grad[:C], bias.grad[:C]) accumulated by the reduction's final kernel
+        assert nsplit == 1 and dgamma_out is None
+        _check(lib().sf_bn_bwd_reduce_acc(*head, *tail, _ptr(dbeta), _ptr(dgamma), _ptr(ws), _ptr(grad_sink[1]),
+                                          _ptr(grad_sink[0]), _stream()), "sf_bn_bwd_reduce_acc")
+    else:
+        _check(reduce_fn(*head, *split, *tail, _ptr(dbeta), _ptr(dgamma), _ptr(ws), _stream()), "sf_bn_bwd_reduce")
     db_apply, dg_apply = (dbeta, dgamma) if sync is None else sync(dbeta, dgamma)
     out = z if dz_out is None else dz_out
     _check(apply_fn(*head, *split, *tail, _ptr(gamma), _ptr(db_apply), _ptr(dg_apply), out.ptr(), out.cs, out.coff,

@@ -53,6 +53,14 @@ class Tape(object):
         self.gbuf = {}
         self.pgrads = {}
         self.out_act = None
+        self.sink = None  # {param: its .grad} when parameter gradients are accumulated in place (set_grad_sink)
+
+    def pgrad_target(self, param):
+        """The tensor kernels may accumulate this parameter's gradient into directly, or None."""
+        if self.sink is None:
+            return None
+        g = self.sink.get(param)
+        return g if g is not None and g.is_contiguous() else None
 
     def grad_of(self, act):
         key = act.buf.data_ptr()
@@ -70,6 +78,10 @@ class Tape(object):
 
     def add_pgrad(self, param, g):
         g = g.reshape(param.shape)
+        tgt = self.sink.get(param) if self.sink is not None else None
+        if tgt is not None:
+            tgt.add_(g)
+            return
         cur = self.pgrads.get(param)
         self.pgrads[param] = g if cur is None else cur + g
 
@@ -103,8 +115,9 @@ def _colsum(act):
 
 
 def _record_conv(x, conv_weight, conv_bias, wp_shape, gsrc, kernel, stride, padding, dilation, x_needs_grad=True,
-                 cin=None, unpack=None):
-    """Backward of a dense conv whose output gradient will be found in `gsrc` (an Act)."""
+                 cin=None, unpack=None, fold_kw=0):
+    """Backward of a dense conv whose output gradient will be found in `gsrc` (an Act).  fold_kw: the stem layout
+    (packed channel = (kw, ci)); `unpack` maps the packed gradient to the parameter's layout on the autograd path."""
     t = tape()
     if t is None:
         return
@@ -112,8 +125,14 @@ def _record_conv(x, conv_weight, conv_bias, wp_shape, gsrc, kernel, stride, padd
 
     def bwd():
         g = gsrc() if callable(gsrc) else gsrc
-        dwp = sfhip.conv_wgrad(x, g, cout, kernel, stride, padding, dilation, cin=cin, cin_pad=wp_shape[2])
-        t.add_pgrad(conv_weight, unpack(dwp) if unpack else sfhip.unpack_conv_weight_grad(dwp, conv_weight.shape))
+        tgt = t.pgrad_target(conv_weight)
+        if tgt is not None:  # partial sum + un-pack + accumulate into .grad in one kernel
+            real_cin = conv_weight.shape[1]
+            sfhip.conv_wgrad(x, g, cout, kernel, stride, padding, dilation, cin=cin, cin_pad=wp_shape[2],
+                             finish_into=(tgt, real_cin, fold_kw))
+        else:
+            dwp = sfhip.conv_wgrad(x, g, cout, kernel, stride, padding, dilation, cin=cin, cin_pad=wp_shape[2])
+            t.add_pgrad(conv_weight, unpack(dwp) if unpack else sfhip.unpack_conv_weight_grad(dwp, conv_weight.shape))
         if conv_bias is not None:
             t.add_pgrad(conv_bias, _colsum(g))
         if x_needs_grad:
@@ -238,20 +257,31 @@ def bn_train_apply(bn, z, res=None, relu=False, rep=1, out=None, out_reserve=(0,
         y = sfhip.affine(zz, scale.contiguous(), shift.contiguous(), res=res, relu=relu, rep=rep, out=out,
                          out_reserve=out_reserve, out_cmul=out_cmul, nsplit=nsplit)
     if t is not None:
-        dg = torch.zeros(z.C, dtype=torch.float32, device=z.buf.device)
-        db = torch.zeros(z.C, dtype=torch.float32, device=z.buf.device)
+        if _GRAD_SINK:
+            dg = db = None  # allocated lazily by the fallback below
+        else:
+            dg = torch.zeros(z.C, dtype=torch.float32, device=z.buf.device)
+            db = torch.zeros(z.C, dtype=torch.float32, device=z.buf.device)
         sel = slice(None) if nsplit > 1 else slice(0, nk)
 
         def bwd():
             dres = t.grad_of(res) if res is not None else None
-            sfhip.bn_bwd(t.grad_of(y), y, zz, mean[sel], invstd[sel], gamma_b[sel], relu, rep=rep, dres=dres,
-                         dz_out=zz, dgamma_out=(dg, db), nsplit=nsplit, sync=sync)
+            wt = t.pgrad_target(bn.weight) if (nsplit == 1 and getattr(bn, "weight", None) is not None) else None
+            bt = t.pgrad_target(bn.bias) if wt is not None else None
+            if wt is not None and bt is not None:  # dgamma / dbeta accumulate into .grad inside the reduction
+                sfhip.bn_bwd(t.grad_of(y), y, zz, mean[sel], invstd[sel], gamma_b[sel], relu, rep=rep, dres=dres,
+                             dz_out=zz, sync=sync, grad_sink=(wt, bt))
+            else:
+                dg_ = dg if dg is not None else torch.zeros(z.C, dtype=torch.float32, device=z.buf.device)
+                db_ = db if db is not None else torch.zeros(z.C, dtype=torch.float32, device=z.buf.device)
+                sfhip.bn_bwd(t.grad_of(y), y, zz, mean[sel], invstd[sel], gamma_b[sel], relu, rep=rep, dres=dres,
+                             dz_out=zz, dgamma_out=(dg_, db_), nsplit=nsplit, sync=sync)
             if keep is not None and keep < z.C:  # sliced-away channels (GhostModule [:oup]) get no gradient
                 rest = z.slice(keep, z.C - keep)
                 sfhip.axpy(rest, rest, alpha=0.0, accumulate=False)
-            if getattr(bn, "weight", None) is not None:
-                t.add_pgrad(bn.weight, dg)
-                t.add_pgrad(bn.bias, db)
+            if (wt is None or bt is None) and getattr(bn, "weight", None) is not None:
+                t.add_pgrad(bn.weight, dg_)
+                t.add_pgrad(bn.bias, db_)
 
         t.record(bwd)  # afterwards z's buffer holds dL/dz for the producer's backward
     if shuffled:  # recorded AFTER the BN op so that its backward (the gather) runs first
@@ -400,7 +430,7 @@ def stem_conv_bn_relu(x, conv, bn, relu=True):
             return dwp[:, :, :4 * kW].reshape(co, kT, kH, kW, 4)[..., :C].permute(0, 4, 1, 2, 3).contiguous()
 
         _record_conv(view, conv.weight, conv.bias, wp.shape, z, (kT, kH, 1), (1, sH, 1), (pT, 0, 0), (1, 1, 1),
-                     x_needs_grad=False, cin=4 * kW, unpack=unpack)
+                     x_needs_grad=False, cin=4 * kW, unpack=unpack, fold_kw=kW)
         return bn_train_apply(bn, z, relu=relu)
     scale, bias = bn_affine(bn, conv.bias)
     return sfhip.conv(view, wp, (kT, kH, 1), (1, sH, 1), (pT, 0, 0), scale=scale, bias=bias, relu=relu,
@@ -414,6 +444,20 @@ def maxpool(x, kernel, stride, padding=(0, 0, 0), out_reserve=(0, 0)):
     if t is not None:
         t.record(lambda: sfhip.maxpool_bwd(x, y, t.grad_of(y), t.grad_of(x), kernel, stride, padding))
     return y
+
+
+_GRAD_SINK = False
+
+
+def set_grad_sink(enabled):
+    """Opt-in fast path for the training step: parameter gradients are ACCUMULATED IN PLACE into the parameters'
+    existing .grad tensors by the backward kernels themselves (conv weight gradients: partial-sum + un-pack +
+    accumulate in one launch; BatchNorm dgamma/dbeta: inside the reduction's final kernel) instead of being handed
+    to autograd, which would add one temporary, one copy and one accumulate launch per parameter.  Use it with
+    pre-allocated gradients (utils.distributed.FlatGradients binds every .grad to one flat buffer).  Autograd
+    hooks on the parameters (DistributedDataParallel) do NOT fire for sunk gradients: leave it off under DDP."""
+    global _GRAD_SINK
+    _GRAD_SINK = bool(enabled)
 
 
 class TapedForward(torch.autograd.Function):
@@ -435,11 +479,14 @@ class TapedForward(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout):
         t = ctx.tape
+        if _GRAD_SINK:  # accumulate into the existing .grad tensors ourselves; autograd gets None for those
+            t.sink = {p: p.grad for p in ctx.params if p.grad is not None and p.grad.dtype == torch.float32}
         with torch.no_grad(), taping(None):
             g = t.grad_of(t.out_act)
             g.buf.copy_(dout.reshape(g.buf.shape))
             t.backward()
-        grads = tuple(t.pgrads.get(p) for p in ctx.params)
+        sink = t.sink or {}
+        grads = tuple(None if p in sink else t.pgrads.get(p) for p in ctx.params)
         ctx.tape = None
         return (None, None, None) + grads
 

@@ -169,6 +169,12 @@ int sf_copy_channels(const float* in, int in_cs, int in_coff, float* out, int ou
 int sf_conv_wgrad_splits(const sf_conv_desc* d);
 int sf_conv_wgrad(const sf_conv_desc* d, const float* x, const float* dz, int dz_cs, int dz_coff,
                   float* partial, void* stream);
+/* Sum the S split partials [S][Cout][packed_taps][cin_pad] in a fixed order and store / accumulate them in
+ * nn.Conv3d's own layout dst[Cout][Cin][kT][kH][kW] (one pass, so the gradient can land directly in the
+ * parameter's .grad).  fold_kw > 0: the stem layout, where a packed tap is (kt,kh) and a packed channel is
+ * (kw, ci) = (c/4, c%4) (sf_conv_fwd over the NDHWC4 border-padded clip), Cin <= 4.                          */
+int sf_conv_wgrad_finish(const float* partial, int S, int Cout, int packed_taps, int cin_pad, int Cin, int fold_kw,
+                         float* dst, int accumulate, void* stream);
 
 /* Training BatchNorm3d backward fused with ReLU mask (y > 0), residual fan-out (dres += g) and the sum over
  * `rep` nearest-upsampled copies:  g = sum_q dy * [y > 0];  dbeta = sum g;  dgamma = sum g * xhat;
@@ -177,6 +183,12 @@ long sf_bn_bwd_ws_floats(int C);
 int sf_bn_bwd_reduce(const float* dy, int dy_cs, int dy_coff, const float* y, int y_cs, int y_coff,
                      const float* z, int z_cs, int z_coff, int N, int T, int H, int W, int C, int rep, int relu,
                      const float* mean, const float* invstd, float* dbeta, float* dgamma, float* ws, void* stream);
+/* As sf_bn_bwd_reduce, additionally accumulating dbeta_acc[c] += dbeta[c], dgamma_acc[c] += dgamma[c] (the
+ * BatchNorm3d bias / weight .grad) in the same launch.                                                        */
+int sf_bn_bwd_reduce_acc(const float* dy, int dy_cs, int dy_coff, const float* y, int y_cs, int y_coff,
+                         const float* z, int z_cs, int z_coff, int N, int T, int H, int W, int C, int rep, int relu,
+                         const float* mean, const float* invstd, float* dbeta, float* dgamma, float* ws,
+                         float* dbeta_acc, float* dgamma_acc, void* stream);
 int sf_bn_bwd_apply(const float* dy, int dy_cs, int dy_coff, const float* y, int y_cs, int y_coff,
                     const float* z, int z_cs, int z_coff, int N, int T, int H, int W, int C, int rep, int relu,
                     const float* mean, const float* invstd, const float* gamma, const float* dbeta,

@@ -285,3 +285,49 @@ def test_precise_bn_pass_matches_oracle_batch_statistics():
     assert worst < 1e-3
     with pytest.raises(AssertionError):
         update_bn_stats(model, iter([[x.cuda() for x in base]]), num_iters=2)  # loader shorter than num_iters
+
+
+@pytest.mark.parametrize("name", ["dual_r50_s64", "ghostnet_w2_s64", "shufflenetv2_cfg1", "dual_r50_subbn_s64"])
+def test_grad_sink_equals_autograd_path(name):
+    """engine.set_grad_sink(True) + FlatGradients (the bench/training fast path: backward kernels accumulate into
+    the flat .grad buffer directly) produces the same gradients as handing them to autograd, and accumulates over
+    two backward passes exactly like autograd does."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from slowfast.models import engine
+    from slowfast.utils.distributed import FlatGradients
+    z, meta = load_case(name)
+    model, sd = _build(meta, z)
+    for m in model.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    model.train()
+    xs = [x.cuda() for x in case_inputs(meta)]
+    labels = torch.from_numpy(z["train/labels"]).cuda()
+
+    def run(times):
+        model.load_state_dict(sd)  # identical running statistics before every pass
+        for _ in range(times):
+            torch.nn.functional.cross_entropy(model([x.clone() for x in xs]), labels).backward()
+            model.load_state_dict(sd)
+        torch.cuda.synchronize()
+
+    run(1)
+    ref = torch.cat([p.grad.reshape(-1) for p in model.parameters()]).clone()
+    model.zero_grad(set_to_none=True)
+    flat = FlatGradients(model.parameters())
+    engine.set_grad_sink(True)
+    try:
+        flat.zero()
+        run(1)
+        one = flat.flat.clone()
+        run(1)  # second backward without zeroing: gradients accumulate
+        two = flat.flat.clone()
+    finally:
+        engine.set_grad_sink(False)
+    assert float((one - ref).abs().max()) <= 1e-5 * float(ref.abs().max())
+    assert float((two - 2 * ref).abs().max()) <= 2e-5 * float(ref.abs().max())
+    off = 0
+    for p in flat.params:  # .grad tensors are still the views of the flat buffer
+        assert p.grad.data_ptr() == flat.flat.data_ptr() + 4 * off
+        off += p.numel()
