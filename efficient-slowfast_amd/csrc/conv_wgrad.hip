@@ -54,6 +54,19 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs p) {
   const int kh = (tap / d.kW) % d.kH;
   const int kt = tap / (d.kW * d.kH);
 
+  // (n, to, ho, wo) of the x rows this thread stages, decoded once and advanced incrementally
+  int pos_n[XIT], pos_t[XIT], pos_h[XIT], pos_w[XIT];
+#pragma unroll
+  for (int i = 0; i < XIT; ++i) {
+    const int f = tid + i * 256;
+    const long m = m_begin + f / XF;
+    pos_w[i] = (int)(m % d.Wo);
+    const long t1 = m / d.Wo;
+    pos_h[i] = (int)(t1 % d.Ho);
+    const long t2 = t1 / d.Ho;
+    pos_t[i] = (int)(t2 % d.To);
+    pos_n[i] = (int)(t2 / d.To);
+  }
   f32x4 rz[ZIT], rx[XIT];
   auto load_stage = [&](long mb) {
 #pragma unroll
@@ -81,15 +94,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs p) {
       const long m = mb + lr;
       f32x4 vx = {0.f, 0.f, 0.f, 0.f};
       if (f < BM * XF && m < m_end) {
-        const int wo = (int)(m % d.Wo);
-        const long t1 = m / d.Wo;
-        const int ho = (int)(t1 % d.Ho);
-        const long t2 = t1 / d.Ho;
-        const int to = (int)(t2 % d.To);
-        const int n = (int)(t2 / d.To);
-        const int ti = to * d.sT - d.pT + kt * d.dT;
-        const int hi = ho * d.sH - d.pH + kh * d.dH;
-        const int wi = wo * d.sW - d.pW + kw * d.dW;
+        const int n = pos_n[i];
+        const int ti = pos_t[i] * d.sT - d.pT + kt * d.dT;
+        const int hi = pos_h[i] * d.sH - d.pH + kh * d.dH;
+        const int wi = pos_w[i] * d.sW - d.pW + kw * d.dW;
         if ((unsigned)ti < (unsigned)d.Ti && (unsigned)hi < (unsigned)d.Hi && (unsigned)wi < (unsigned)d.Wi) {
           const float* xp = p.x + ((((long)n * d.Ti + ti) * d.Hi + hi) * d.Wi + wi) * d.in_cs + d.in_coff + ci0 + lc;
           if (VEC == 4) {
@@ -102,6 +110,18 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs p) {
         }
       }
       rx[i] = vx;
+      // next stage: this row moves BM positions on (stages are visited in order, so no division per load)
+      pos_w[i] += BM;
+      while (pos_w[i] >= d.Wo) {
+        pos_w[i] -= d.Wo;
+        if (++pos_h[i] == d.Ho) {
+          pos_h[i] = 0;
+          if (++pos_t[i] == d.To) {
+            pos_t[i] = 0;
+            ++pos_n[i];
+          }
+        }
+      }
     }
   };
   auto store_stage = [&](int buf) {
@@ -207,6 +227,19 @@ __global__ __launch_bounds__(256) void conv_wgrad_small_kernel(const WgradArgs p
   const int kh = (tap / d.kW) % d.kH;
   const int kt = tap / (d.kW * d.kH);
 
+  // (n, to, ho, wo) of the x rows this thread stages, decoded once and advanced incrementally
+  int pos_n[XIT], pos_t[XIT], pos_h[XIT], pos_w[XIT];
+#pragma unroll
+  for (int i = 0; i < XIT; ++i) {
+    const int f = tid + i * 256;
+    const long m = m_begin + f / XF;
+    pos_w[i] = (int)(m % d.Wo);
+    const long t1 = m / d.Wo;
+    pos_h[i] = (int)(t1 % d.Ho);
+    const long t2 = t1 / d.Ho;
+    pos_t[i] = (int)(t2 % d.To);
+    pos_n[i] = (int)(t2 / d.To);
+  }
   f32x4 rz[ZIT], rx[XIT];
   auto load_stage = [&](long mb) {
 #pragma unroll
@@ -234,15 +267,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_small_kernel(const WgradArgs p
       const long m = mb + lr;
       f32x4 vx = {0.f, 0.f, 0.f, 0.f};
       if (f < BMS * XF && m < m_end) {
-        const int wo = (int)(m % d.Wo);
-        const long t1 = m / d.Wo;
-        const int ho = (int)(t1 % d.Ho);
-        const long t2 = t1 / d.Ho;
-        const int to = (int)(t2 % d.To);
-        const int n = (int)(t2 / d.To);
-        const int ti = to * d.sT - d.pT + kt * d.dT;
-        const int hi = ho * d.sH - d.pH + kh * d.dH;
-        const int wi = wo * d.sW - d.pW + kw * d.dW;
+        const int n = pos_n[i];
+        const int ti = pos_t[i] * d.sT - d.pT + kt * d.dT;
+        const int hi = pos_h[i] * d.sH - d.pH + kh * d.dH;
+        const int wi = pos_w[i] * d.sW - d.pW + kw * d.dW;
         if ((unsigned)ti < (unsigned)d.Ti && (unsigned)hi < (unsigned)d.Hi && (unsigned)wi < (unsigned)d.Wi) {
           const float* xp = p.x + ((((long)n * d.Ti + ti) * d.Hi + hi) * d.Wi + wi) * d.in_cs + d.in_coff + ci0 + lc;
           if (VEC == 4) {
@@ -255,6 +283,18 @@ __global__ __launch_bounds__(256) void conv_wgrad_small_kernel(const WgradArgs p
         }
       }
       rx[i] = vx;
+      // next stage: this row moves BMS positions on (stages are visited in order, so no division per load)
+      pos_w[i] += BMS;
+      while (pos_w[i] >= d.Wo) {
+        pos_w[i] -= d.Wo;
+        if (++pos_h[i] == d.Ho) {
+          pos_h[i] = 0;
+          if (++pos_t[i] == d.To) {
+            pos_t[i] = 0;
+            ++pos_n[i];
+          }
+        }
+      }
     }
   };
   auto store_stage = [&](int buf) {
