@@ -466,14 +466,16 @@ class TapedForward(torch.autograd.Function):
     any module).  Activations never become autograd tensors."""
 
     @staticmethod
-    def forward(ctx, model, slow, fast, *params):
+    def forward(ctx, model, n_in, *args):
+        inputs, params = list(args[:n_in]), args[n_in:]
         t = Tape()
         with taping(t):
-            out = model._forward_impl([slow, fast])
+            out = model._forward_impl(inputs)
         if t.out_act is None:
             raise RuntimeError("the head did not register its logits on the tape")
         ctx.tape = t
         ctx.params = params
+        ctx.n_in = n_in
         return out
 
     @staticmethod
@@ -488,14 +490,14 @@ class TapedForward(torch.autograd.Function):
         sink = t.sink or {}
         grads = tuple(None if p in sink else t.pgrads.get(p) for p in ctx.params)
         ctx.tape = None
-        return (None, None, None) + grads
+        return (None, None) + (None,) * ctx.n_in + grads
 
 
 def run_model(model, x):
     """model.forward body shared by all model classes: taped when training with grad enabled."""
     if model.training and torch.is_grad_enabled():
         params = [p for p in model.parameters()]
-        return TapedForward.apply(model, x[0], x[1], *params)
+        return TapedForward.apply(model, len(x), *x, *params)
     return model._forward_impl(x)
 
 

@@ -14,9 +14,21 @@ _MODEL_STAGE_DEPTH = {50: (3, 4, 6, 3), 101: (3, 4, 23, 3), 18: (2, 2, 2, 2), 34
 # [stage][pathway] temporal kernel basis; the fork's slowfast entry (custom_video_model_builder.py:155-163,
 # identical to video_model_builder.py:62-68)
 _TEMPORAL_KERNEL_BASIS = {
+    "c2d": [[[1]], [[1]], [[1]], [[1]], [[1]]],
+    "c2d_nopool": [[[1]], [[1]], [[1]], [[1]], [[1]]],
+    "i3d": [[[5]], [[3]], [[3, 1]], [[3, 1]], [[1, 3]]],
+    "i3d_nopool": [[[5]], [[3]], [[3, 1]], [[3, 1]], [[1, 3]]],
+    "slow": [[[1]], [[1]], [[1]], [[3]], [[3]]],
     "slowfast": [[[1], [5]], [[1], [3]], [[1], [3]], [[3], [3]], [[3], [3]]],
 }
-_POOL1 = {"slowfast": [[1, 1, 1], [1, 1, 1]]}
+_POOL1 = {
+    "c2d": [[2, 1, 1]],
+    "c2d_nopool": [[1, 1, 1]],
+    "i3d": [[2, 1, 1]],
+    "i3d_nopool": [[1, 1, 1]],
+    "slow": [[1, 1, 1]],
+    "slowfast": [[1, 1, 1], [1, 1, 1]],
+}
 
 
 class FuseFastToSlow(nn.Module):
@@ -139,7 +151,7 @@ class _TwoPathwayResNet(nn.Module):
                 pool = getattr(self, "pathway{}_pool".format(pathway))
                 ks = pool.kernel_size if isinstance(pool.kernel_size, (list, tuple)) else [pool.kernel_size] * 3
                 if list(ks) != [1, 1, 1]:  # _POOL1["slowfast"] is the identity (elided)
-                    x[pathway] = sfhip.pool(x[pathway], tuple(ks), tuple(ks))
+                    x[pathway] = engine.maxpool(x[pathway], tuple(ks), tuple(ks))
             x = self.s3(x, reserve=self.s3_fuse.reserve(None))
             x = self.s3_fuse(x)
             x = self.s4(x, reserve=self.s4_fuse.reserve(None))
@@ -167,3 +179,72 @@ class SlowFast(_TwoPathwayResNet):
     def _make_fuse(self, cfg, dim_in):
         return FuseFastToSlow(dim_in[1], cfg.SLOWFAST.FUSION_CONV_CHANNEL_RATIO, cfg.SLOWFAST.FUSION_KERNEL_SZ,
                               cfg.SLOWFAST.ALPHA, norm_module=self.norm_module)
+
+
+@MODEL_REGISTRY.register()
+class ResNet(nn.Module):
+    """Single-pathway ResNet backbone without lateral connections — C2D, I3D, Slow (reference
+    video_model_builder.py:420-616); children s1, s2, pathway0_pool, s3, s4, s5, head."""
+
+    def __init__(self, cfg):
+        super(ResNet, self).__init__()
+        self.norm_module = get_norm(cfg)
+        self.enable_detection = cfg.DETECTION.ENABLE
+        self.num_pathways = 1
+        self._construct_network(cfg)
+        init_helper.init_weights(self, cfg.MODEL.FC_INIT_STD, cfg.RESNET.ZERO_INIT_FINAL_BN)
+
+    def _construct_network(self, cfg):
+        assert cfg.MODEL.ARCH in _POOL1.keys()
+        pool_size = _POOL1[cfg.MODEL.ARCH]
+        assert len({len(pool_size), self.num_pathways}) == 1
+        assert cfg.RESNET.DEPTH in _MODEL_STAGE_DEPTH.keys()
+        depths = _MODEL_STAGE_DEPTH[cfg.RESNET.DEPTH]
+        num_groups = cfg.RESNET.NUM_GROUPS
+        width_per_group = cfg.RESNET.WIDTH_PER_GROUP
+        dim_inner = num_groups * width_per_group
+        temp_kernel = _TEMPORAL_KERNEL_BASIS[cfg.MODEL.ARCH]
+        self.s1 = stem_helper.VideoModelStem(
+            dim_in=cfg.DATA.INPUT_CHANNEL_NUM, dim_out=[width_per_group], kernel=[temp_kernel[0][0] + [7, 7]],
+            stride=[[1, 2, 2]], padding=[[temp_kernel[0][0][0] // 2, 3, 3]], norm_module=self.norm_module)
+        for i in range(4):  # res2..res5 = s2..s5
+            stage = resnet_helper.ResStage(
+                dim_in=[width_per_group * (1 if i == 0 else 2 ** (i + 1))], dim_out=[width_per_group * 2 ** (i + 2)],
+                dim_inner=[dim_inner * 2 ** i], temp_kernel_sizes=temp_kernel[i + 1],
+                stride=cfg.RESNET.SPATIAL_STRIDES[i], num_blocks=[depths[i]], num_groups=[num_groups],
+                num_block_temp_kernel=cfg.RESNET.NUM_BLOCK_TEMP_KERNEL[i], nonlocal_inds=cfg.NONLOCAL.LOCATION[i],
+                nonlocal_group=cfg.NONLOCAL.GROUP[i], nonlocal_pool=cfg.NONLOCAL.POOL[i],
+                instantiation=cfg.NONLOCAL.INSTANTIATION, trans_func_name=cfg.RESNET.TRANS_FUNC,
+                stride_1x1=cfg.RESNET.STRIDE_1X1, inplace_relu=cfg.RESNET.INPLACE_RELU,
+                dilation=cfg.RESNET.SPATIAL_DILATIONS[i], norm_module=self.norm_module)
+            setattr(self, "s{}".format(i + 2), stage)
+            if i == 0:
+                for pathway in range(self.num_pathways):
+                    pool = nn.MaxPool3d(kernel_size=pool_size[pathway], stride=pool_size[pathway], padding=[0, 0, 0])
+                    self.add_module("pathway{}_pool".format(pathway), pool)
+        if cfg.DETECTION.ENABLE:
+            raise NotImplementedError("DETECTION.ENABLE (ResNetRoIHead / AVA) is out of scope of the HIP path")
+        self.head = head_helper.ResNetBasicHead(
+            dim_in=[width_per_group * 32], num_classes=cfg.MODEL.NUM_CLASSES,
+            pool_size=[None, None] if cfg.MULTIGRID.SHORT_CYCLE else [
+                [cfg.DATA.NUM_FRAMES // pool_size[0][0], cfg.DATA.CROP_SIZE // 32 // pool_size[0][1],
+                 cfg.DATA.CROP_SIZE // 32 // pool_size[0][2]]],
+            dropout_rate=cfg.MODEL.DROPOUT_RATE, act_func=cfg.MODEL.HEAD_ACT)
+
+    def forward(self, x, bboxes=None):
+        return engine.run_model(self, x)
+
+    def _forward_impl(self, x):
+        x = list(x)
+        with engine.internal():
+            x = self.s1(x)
+            x = self.s2(x)
+            ks = self.pathway0_pool.kernel_size
+            ks = tuple(ks) if isinstance(ks, (list, tuple)) else (ks,) * 3
+            if ks != (1, 1, 1):
+                x[0] = engine.maxpool(x[0], ks, ks)
+            x = self.s3(x)
+            x = self.s4(x)
+            x = self.s5(x)
+            x = self.head(x)
+        return x

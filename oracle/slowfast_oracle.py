@@ -27,6 +27,14 @@ import torch.nn.functional as F
 MODEL_STAGE_DEPTH = {50: (3, 4, 6, 3), 101: (3, 4, 23, 3), 18: (2, 2, 2, 2), 34: (3, 4, 6, 3)}
 # custom_video_model_builder.py:155-163 ("slowfast" arch): [stage][pathway] temporal kernel
 TEMPORAL_KERNEL = [[1, 5], [1, 3], [1, 3], [3, 3], [3, 3]]
+# video_model_builder.py:20-75: single-pathway bases, [stage] -> repeating pattern of temporal kernels
+SINGLE_TEMPORAL_KERNEL = {
+    "c2d": [[1], [1], [1], [1], [1]], "c2d_nopool": [[1], [1], [1], [1], [1]],
+    "i3d": [[5], [3], [3, 1], [3, 1], [1, 3]], "i3d_nopool": [[5], [3], [3, 1], [3, 1], [1, 3]],
+    "slow": [[1], [1], [1], [3], [3]],
+}
+SINGLE_POOL1 = {"c2d": (2, 1, 1), "c2d_nopool": (1, 1, 1), "i3d": (2, 1, 1), "i3d_nopool": (1, 1, 1),
+                "slow": (1, 1, 1)}  # video_model_builder.py:77-84
 
 
 def default_hparams(**over):
@@ -122,9 +130,12 @@ def res_stage(sd, p, xs, stage_idx, hp, training):
     depth = MODEL_STAGE_DEPTH[hp["depth"]][stage_idx]
     out = []
     for pw, x in enumerate(xs):
-        k = TEMPORAL_KERNEL[stage_idx + 1][pw]
+        if len(xs) == 1:
+            basis = list(SINGLE_TEMPORAL_KERNEL[hp["arch"]][stage_idx + 1])
+        else:
+            basis = [TEMPORAL_KERNEL[stage_idx + 1][pw]]
         nbtk = hp["num_block_temp_kernel"][stage_idx][pw]
-        kts = ([k] * depth)[:nbtk] + [1] * (depth - nbtk)
+        kts = (basis * depth)[:nbtk] + [1] * (depth - nbtk)
         for i in range(depth):
             x = res_block(sd, "%s.pathway%d_res%d" % (p, pw, i), x, kts[i],
                           hp["spatial_strides"][stage_idx] if i == 0 else 1,
@@ -202,7 +213,10 @@ def resnet_basic_head(sd, p, xs, hp, training):
         if hp["short_cycle"]:
             pooled.append(x.mean((2, 3, 4), keepdim=True))
         else:
-            t = hp["num_frames"] // hp["alpha"] if pw == 0 else hp["num_frames"]
+            if len(xs) == 1:  # ResNet: NUM_FRAMES // pool1_T (video_model_builder.py:587-593)
+                t = hp["num_frames"] // SINGLE_POOL1[hp["arch"]][0]
+            else:
+                t = hp["num_frames"] // hp["alpha"] if pw == 0 else hp["num_frames"]
             s = hp["crop_size"] // 32
             pooled.append(F.avg_pool3d(x, (t, s, s), 1))
     x = torch.cat(pooled, 1).permute(0, 2, 3, 4, 1)
@@ -229,6 +243,22 @@ def slowfast_forward(sd, inputs, hp, dual, training=False):
         # pathway{0,1}_pool = MaxPool3d(k=s=[1,1,1]) → identity (:278-284, :433-435)
     x = res_stage(sd, "s5", x, 3, hp, training)
     acts["s5"] = x
+    acts["logits"], acts["out"] = resnet_basic_head(sd, "head", x, hp, training)
+    return acts
+
+
+def resnet_forward(sd, inputs, hp, training=False):
+    """Single-pathway ResNet — C2D / I3D / Slow (video_model_builder.py:420-616): s1, s2, pathway0_pool
+    (MaxPool3d(k = s = _POOL1[arch]), temporal for c2d / i3d), s3, s4, s5, head."""
+    arch = hp["arch"]
+    acts = {}
+    x = [resnet_basic_stem(sd, "s1.pathway0_stem", inputs[0], SINGLE_TEMPORAL_KERNEL[arch][0][0], training)]
+    acts["s1"] = x
+    for si in range(4):
+        x = res_stage(sd, "s%d" % (si + 2), x, si, hp, training)
+        acts["s%d" % (si + 2)] = x
+        if si == 0 and SINGLE_POOL1[arch] != (1, 1, 1):
+            x = [F.max_pool3d(x[0], SINGLE_POOL1[arch], SINGLE_POOL1[arch])]
     acts["logits"], acts["out"] = resnet_basic_head(sd, "head", x, hp, training)
     return acts
 
@@ -541,6 +571,7 @@ FORWARDS = {
     "SlowFastGhostNet": ghostnet_forward,
     "SlowFastMoibleNetV2": mobilenetv2_forward,
     "SlowFastShuffleNet": shufflenet_forward,
+    "ResNet": resnet_forward,
 }
 
 

@@ -56,6 +56,14 @@ CASES = [
     dict(name="dual_r50_subbn_s64", yaml="SLOWFAST_DUAL_8x8_R50_stepwise_multigrid.yaml",
          model="SlowFastDualAttention", batch=4, t=16, alpha=4, size=64,
          over=["BN.NORM_TYPE", "sub_batchnorm", "BN.NUM_SPLITS", 2] + small(64, 16)),
+    # SURVEY §8(b) registry surface: single-pathway ResNet, I3D (temporal kernels 5/3, MaxPool3d([2,1,1]) after res2)
+    dict(name="i3d_r50_s64", yaml="I3D_8x8_R50.yaml", model="ResNet", batch=2, t=8, alpha=1, size=64,
+         over=small(64, 8), single=True),
+    # ... and Slow at DEPTH 18 = (2,2,2,2) bottleneck blocks (TIRED_SLOW_*_R18 YAMLs).  RESNET.TRANS_FUNC
+    # basic_transform cannot be built by the reference: ResBlock passes `dilation=` to BasicTransform, which does
+    # not take it (resnet_helper.py:338-349 vs :31-42) -> TypeError, so there is nothing to pin for it.
+    dict(name="slow_r18_s64", yaml="SLOW_8x8_R50.yaml", model="ResNet", batch=2, t=8, alpha=1, size=64,
+         over=["RESNET.DEPTH", 18, "RESNET.NUM_BLOCK_TEMP_KERNEL", [[2], [2], [2], [2]]] + small(64, 8), single=True),
     # SlowFastShuffleNet (v1, GROUPS 1 as its YAML) + CMDA at S=64, T=16
     dict(name="shufflenet_g1_s64", yaml="SLOWFAST_SHUFFLENET_8x8_R50_stepwise_multigrid.yaml",
          model="SlowFastShuffleNet", batch=2, t=16, alpha=4, size=64,
@@ -66,6 +74,8 @@ GRAD_KEYS = {
     "SlowFast": ["s1.pathway0_stem.conv.weight", "s1_fuse.conv_f2s.weight", "s3.pathway1_res1.branch2.b.weight",
                  "s4.pathway0_res0.branch2.a.weight", "s5.pathway0_res2.branch2.c_bn.weight",
                  "head.projection.weight"],
+    "ResNet": ["s1.pathway0_stem.conv.weight", "s2.pathway0_res1.branch2.b.weight", "s3.pathway0_res0.branch1.weight",
+               "s4.pathway0_res1.branch2.a.weight", "s5.pathway0_res1.branch2.b_bn.weight", "head.projection.weight"],
     "SlowFastDualAttention": ["s1.pathway1_stem.conv.weight", "s2_fuse.attention_spatial_s2f.query_conv.weight",
                               "s2_fuse.attention_spatial_s2f.gamma", "s3_fuse.attention_channel_f2s.conv.weight",
                               "s4.pathway0_res0.branch2.a.weight", "s3_fuse.bn_s2f.weight",
@@ -101,7 +111,7 @@ def hparams_from_cfg(cfg):
         num_block_temp_kernel=[list(x) for x in cfg.RESNET.NUM_BLOCK_TEMP_KERNEL],
         num_frames=cfg.DATA.NUM_FRAMES, crop_size=cfg.DATA.CROP_SIZE, num_classes=cfg.MODEL.NUM_CLASSES,
         short_cycle=bool(cfg.MULTIGRID.SHORT_CYCLE), head_act=cfg.MODEL.HEAD_ACT,
-        width_multi=cfg.SLOWFAST.WIDTH_MULTI, eps=1e-5, groups=cfg.SLOWFAST.get("GROUPS", 1),
+        width_multi=cfg.SLOWFAST.WIDTH_MULTI, eps=1e-5, groups=cfg.SLOWFAST.get("GROUPS", 1), arch=cfg.MODEL.ARCH,
     )
 
 
@@ -116,12 +126,18 @@ def run_case(case, get_cfg, build_model):
     sd = model.state_dict()
     fill_state_dict(sd, PARAM_SEED)
     slow, fast = make_clip(CLIP_SEED, case["batch"], case["t"], case["alpha"], case["size"])
+    single = bool(case.get("single"))
+
+    def clips(grad=False):
+        arrs = [fast] if single else [slow, fast]
+        return [torch.from_numpy(a.copy()).requires_grad_(grad) for a in arrs]
+
     out = {
         "meta": json.dumps(dict(name=case["name"], model=case["model"], yaml=case["yaml"],
                                 overrides=[str(o) if not isinstance(o, (int, float, bool)) else o for o in over],
                                 cfg_dump=plain_cfg(cfg), hparams=hparams_from_cfg(cfg), param_seed=PARAM_SEED, clip_seed=CLIP_SEED,
                                 batch=case["batch"], t=case["t"], alpha=case["alpha"], size=case["size"],
-                                torch=torch.__version__)),
+                                single=single, torch=torch.__version__)),
         "sd_keys": np.array(list(sd.keys())),
         "sd_shapes": np.array([json.dumps(list(v.shape)) for v in sd.values()]),
         "children": np.array([n for n, _ in model.named_children()]),
@@ -141,7 +157,7 @@ def run_case(case, get_cfg, build_model):
     # ---- eval forward (what perform_test does at test_net.py:92)
     model.eval()
     with torch.no_grad():
-        probs = model([torch.from_numpy(slow.copy()), torch.from_numpy(fast.copy())])
+        probs = model(clips())
     for k, v in acts.items():
         if k == "head":
             continue
@@ -161,8 +177,8 @@ def run_case(case, get_cfg, build_model):
             m.p = 0.0
     model.train()
     acts.clear()
-    xs = [torch.from_numpy(slow.copy()).requires_grad_(True), torch.from_numpy(fast.copy()).requires_grad_(True)]
-    xin = [xs[0], xs[1]]
+    xs = clips(grad=True)
+    xin = list(xs)
     logits = model(xin)
     labels = torch.from_numpy(np.random.RandomState(11).randint(0, cfg.MODEL.NUM_CLASSES, case["batch"]))
     loss = torch.nn.functional.cross_entropy(logits, labels)
@@ -186,7 +202,7 @@ def run_case(case, get_cfg, build_model):
     bufs = [k for k in after if k.endswith("running_mean") or k.endswith("running_var")]
     for k in bufs[:4] + bufs[len(bufs) // 2:len(bufs) // 2 + 4] + bufs[-4:]:
         out["train_buffers/" + k] = after[k].numpy().copy()
-    for i, nm in enumerate(("slow", "fast")):
+    for i, nm in enumerate(("fast",) if single else ("slow", "fast")):
         s, amax, mean = sample_activation(xs[i].grad.numpy(), 4096)
         out["grad_input/" + nm] = s
         out["grad_input/%s/stats" % nm] = np.array([amax, float(xs[i].grad.norm())], np.float64)

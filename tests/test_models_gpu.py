@@ -85,7 +85,7 @@ def test_eval_forward_matches_reference_golden(name):
             worst = max(worst, e)
             assert e < TOL, (tag, e)
             checked += 1
-    assert checked >= 16
+    assert checked >= (5 if meta.get("single") else 16)
     e_log = rel_err(tap["logits"].reshape(meta["batch"], -1), z["eval/logits_full"])
     e_out = rel_err(out.cpu().numpy(), z["eval/out"])
     _report("%-22s logits %.3e  out %.3e  worst-stage %.3e" % (name, e_log, e_out, worst))

@@ -27,7 +27,7 @@ def test_model_forward_matches_reference(name):
             s, amax, mean = sample_activation(a.numpy())
             assert rel_err(s, z[tag]) < TOL, tag
             checked += 1
-    assert checked >= 16
+    assert checked >= (5 if meta.get("single") else 16)
     assert rel_err(acts["logits"].reshape(meta["batch"], -1).numpy(), z["eval/logits_full"]) < TOL
     assert rel_err(acts["out"].numpy(), z["eval/out"]) < TOL
 
