@@ -459,6 +459,42 @@ __global__ void affine_kernel(const float* __restrict__ x, int cs, int coff, lon
   }
 }
 
+// Row softmax over the channel dimension (Nonlocal "softmax" instantiation, nonlocal_helper.py:132-134): one
+// wavefront per row of C = N_k scores; x <- softmax(scale * x) in place.  bwd: dp <- scale * p * (dp - <p, dp>).
+__global__ __launch_bounds__(256) void row_softmax_kernel(float* __restrict__ x, int cs, int coff, long rows, int C,
+                                                          float scale) {
+  const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (r >= rows) return;
+  float* row = x + r * cs + coff;
+  float m = -3.0e38f;
+  for (int c = lane; c < C; c += 64) m = fmaxf(m, row[c] * scale);
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  float sum = 0.f;
+  for (int c = lane; c < C; c += 64) {
+    const float e = __expf(row[c] * scale - m);
+    row[c] = e;
+    sum += e;
+  }
+  for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+  const float inv = 1.f / sum;
+  for (int c = lane; c < C; c += 64) row[c] *= inv;
+}
+
+__global__ __launch_bounds__(256) void row_softmax_bwd_kernel(const float* __restrict__ p, int p_cs, int p_coff,
+                                                              float* __restrict__ dp, int dp_cs, int dp_coff,
+                                                              long rows, int C, float scale) {
+  const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (r >= rows) return;
+  const float* pr = p + r * p_cs + p_coff;
+  float* dr = dp + r * dp_cs + dp_coff;
+  float dot = 0.f;
+  for (int c = lane; c < C; c += 64) dot = fmaf(pr[c], dr[c], dot);
+  for (int o = 32; o > 0; o >>= 1) dot += __shfl_xor(dot, o, 64);
+  for (int c = lane; c < C; c += 64) dr[c] = scale * pr[c] * (dr[c] - dot);
+}
+
 inline int pow2ceil(int v) {
   int p = 1;
   while (p < v) p <<= 1;
@@ -673,6 +709,23 @@ extern "C" int sf_affine_fwd_split(const float* x, int cs, int coff, int N, int 
                                    int out_cmul, void* stream) {
   return affine_launch(x, cs, coff, N, T, H, W, C, nsplit, scale, bias, res, res_cs, res_coff, act, rep, out, out_cs,
                        out_coff, out_cmul, stream);
+}
+
+extern "C" int sf_row_softmax_fwd(float* x, int cs, int coff, long rows, int C, float scale, void* stream) {
+  if (!x || rows <= 0 || C <= 0) return SF_EINVAL;
+  hipLaunchKernelGGL(row_softmax_kernel, dim3(sf_cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, x, cs, coff, rows,
+                     C, scale);
+  SF_CHECK_LAUNCH();
+  return SF_OK;
+}
+
+extern "C" int sf_row_softmax_bwd(const float* p, int p_cs, int p_coff, float* dp, int dp_cs, int dp_coff, long rows,
+                                  int C, float scale, void* stream) {
+  if (!p || !dp || rows <= 0 || C <= 0) return SF_EINVAL;
+  hipLaunchKernelGGL(row_softmax_bwd_kernel, dim3(sf_cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, p, p_cs,
+                     p_coff, dp, dp_cs, dp_coff, rows, C, scale);
+  SF_CHECK_LAUNCH();
+  return SF_OK;
 }
 
 extern "C" int sf_head_act_mean(const float* logits, int B, int P, int K, int act, float* out, void* stream) {

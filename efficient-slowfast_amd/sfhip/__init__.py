@@ -50,7 +50,7 @@ EXPORTS = [
     "sf_attn_bwd", "sf_maxpool_bwd", "sf_tmax_dot", "sf_eca_bwd_apply", "sf_bcast_add", "sf_rowdot", "sf_axpy", "sf_act_bwd",
     "sf_dwconv_dgrad", "sf_dwconv_wgrad_ws_floats", "sf_dwconv_wgrad", "sf_gather_add",
     "sf_bn_train_stats_split", "sf_affine_fwd_split", "sf_bn_bwd_reduce_split", "sf_bn_bwd_apply_split",
-    "sf_clip_prologue", "sf_conv_wgrad_finish", "sf_bn_bwd_reduce_acc",
+    "sf_clip_prologue", "sf_conv_wgrad_finish", "sf_bn_bwd_reduce_acc", "sf_row_softmax_fwd", "sf_row_softmax_bwd",
 ]
 _LONG_RET = ("sf_tmax_mean_ws_floats", "sf_channel_stats_ws_floats", "sf_bn_bwd_ws_floats",
              "sf_dwconv_wgrad_ws_floats")
@@ -111,6 +111,8 @@ def lib():
         L.sf_dwconv_wgrad.argtypes = [ctypes.POINTER(ConvDesc), vp, vp, ci, ci, ci, vp, vp, vp]
         L.sf_gather_add.argtypes = [vp, ci, ci, ci, vp, ci, ci, cl, ci, ci, vp]
         L.sf_clip_prologue.argtypes = [vp] + [ci] * 10 + [ctypes.POINTER(ctypes.c_float)] * 2 + [vp, ci, vp, ci, ci, ci, vp]
+        L.sf_row_softmax_fwd.argtypes = [vp, ci, ci, cl, ci, cf, vp]
+        L.sf_row_softmax_bwd.argtypes = [vp, ci, ci, vp, ci, ci, cl, ci, cf, vp]
         L.sf_conv_wgrad_finish.argtypes = [vp, ci, ci, ci, ci, ci, ci, vp, ci, vp]
         L.sf_bn_bwd_reduce_acc.argtypes = [vp, ci, ci, vp, ci, ci, vp, ci, ci] + [ci] * 7 + [vp] * 5 + [vp, vp, vp]
         L.sf_bn_train_stats_split.argtypes = [vp, ci, ci, ci, cl, ci, ci, vp, vp, cf, cf] + [vp] * 9
@@ -636,6 +638,21 @@ def axpy(a, out, alpha=1.0, accumulate=True):
     _check(lib().sf_axpy(a.ptr(), a.cs, a.coff, float(alpha), out.ptr(), out.cs, out.coff, a.rows, a.C,
                          1 if accumulate else 0, _stream()), "sf_axpy")
     return out
+
+
+def row_softmax(x, scale=1.0):
+    """x <- softmax(scale * x) over the channel dimension, in place (one wavefront per row)."""
+    _require_gpu(x.buf, "row_softmax")
+    _check(lib().sf_row_softmax_fwd(x.ptr(), x.cs, x.coff, x.rows, x.C, float(scale), _stream()), "sf_row_softmax_fwd")
+    return x
+
+
+def row_softmax_bwd(p, dp, scale=1.0):
+    """dp <- scale * p * (dp - <p, dp>) in place."""
+    assert p.rows == dp.rows and p.C == dp.C
+    _check(lib().sf_row_softmax_bwd(p.ptr(), p.cs, p.coff, dp.ptr(), dp.cs, dp.coff, p.rows, p.C, float(scale),
+                                    _stream()), "sf_row_softmax_bwd")
+    return dp
 
 
 def act_bwd(dy, y, relu, dx, accumulate=True):

@@ -2,7 +2,9 @@
 (conv+BN+ReLU, conv+BN+ReLU, conv+BN+residual+ReLU); a projection shortcut adds one more."""
 import torch.nn as nn
 
+import sfhip
 from . import engine
+from .nonlocal_helper import Nonlocal
 
 
 def get_trans_func(name):
@@ -108,8 +110,6 @@ class ResStage(nn.Module):
         self.num_pathways = len(self.num_blocks)
         for pathway in range(self.num_pathways):
             for i in range(self.num_blocks[pathway]):
-                if i in nonlocal_inds[pathway]:
-                    raise NotImplementedError("Nonlocal blocks are out of scope of the HIP path (SURVEY §2 #12)")
                 res_block = ResBlock(
                     dim_in[pathway] if i == 0 else dim_out[pathway], dim_out[pathway],
                     self.temp_kernel_sizes[pathway][i], stride[pathway] if i == 0 else 1,
@@ -117,6 +117,10 @@ class ResStage(nn.Module):
                     stride_1x1=stride_1x1, inplace_relu=inplace_relu, dilation=dilation[pathway],
                     norm_module=norm_module)
                 self.add_module("pathway{}_res{}".format(pathway, i), res_block)
+                if i in nonlocal_inds[pathway]:
+                    nln = Nonlocal(dim_out[pathway], dim_out[pathway] // 2, nonlocal_pool[pathway],
+                                   instantiation=instantiation, norm_module=norm_module)
+                    self.add_module("pathway{}_nonlocal{}".format(pathway, i), nln)
 
     def forward(self, inputs, reserve=None):
         xs = engine.enter(inputs)
@@ -127,6 +131,16 @@ class ResStage(nn.Module):
                 n = self.num_blocks[pathway]
                 for i in range(n):
                     m = getattr(self, "pathway{}_res{}".format(pathway, i))
-                    x = m(x, reserve[pathway] if (reserve and i == n - 1) else (0, 0))
+                    nln = getattr(self, "pathway{}_nonlocal{}".format(pathway, i), None)
+                    room = reserve[pathway] if (reserve and i == n - 1) else (0, 0)
+                    x = m(x, room if nln is None else (0, 0))
+                    if nln is not None:
+                        grp = self.nonlocal_group[pathway]
+                        if grp > 1:  # fold groups of T/grp frames into the batch: a free view in NDHWC
+                            assert x.coff == 0 and x.T % grp == 0
+                            x = sfhip.Act(x.buf.view(x.N * grp, x.T // grp, x.H, x.W, x.cs), 0, x.C)
+                        x = nln.run(x, room)
+                        if grp > 1:
+                            x = sfhip.Act(x.buf.view(x.N // grp, x.T * grp, x.H, x.W, x.cs), x.coff, x.C)
                 output.append(x)
         return engine.leave(output)

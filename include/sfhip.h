@@ -253,6 +253,16 @@ int sf_bn_bwd_apply_split(const float* dy, int dy_cs, int dy_coff, const float* 
 int sf_act_bwd(const float* dy, int dy_cs, int dy_coff, const float* y, int y_cs, int y_coff, int act, float* dx,
                int dx_cs, int dx_coff, long rows, int C, int accumulate, void* stream);
 
+/* ---- Nonlocal block core (nonlocal_helper.py:105-148).  The score matrix theta^T phi of ONE sample is small here
+ * (N_q <= 6272 queries x N_k <= 1568 max-pooled keys, d = 256 / 512), so it is materialised by sf_conv_fwd with the
+ * sample's phi rows as the "weights" ([N_k][d] is already the packed layout), normalised in place by the kernels
+ * below ("softmax": softmax(scale * s) over the keys; "dot_product" needs no kernel: 1/N_k in the GEMM epilogue),
+ * and multiplied by g with a second sf_conv_fwd (weights = g^T).  x / dp: rows of C = N_k scores, pitch cs.       */
+int sf_row_softmax_fwd(float* x, int cs, int coff, long rows, int C, float scale, void* stream);
+/* dp <- scale * p * (dp - <p, dp>)  (gradient w.r.t. the un-scaled scores, in place over dL/dp)                 */
+int sf_row_softmax_bwd(const float* p, int p_cs, int p_coff, float* dp, int dp_cs, int dp_coff, long rows, int C,
+                       float scale, void* stream);
+
 /* ---- input step (datasets/kinetics.py:230-248 -> datasets/utils.py:298-315 tensor_normalize, :151-203
  * spatial_sampling, :73-112 pack_pathway_output; transform.py:283-337 / 359-393 / 395-423 / 425-468).
  * clip: ONE decoded clip, uint8 [T,H,W,3] on the device.  The short side is scaled bilinearly to (new_h, new_w)

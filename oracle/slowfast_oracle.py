@@ -124,6 +124,28 @@ def res_block(sd, p, x, kt, stride, groups, dilation, training):
     return F.relu(sc + f)
 
 
+def nonlocal_block(sd, p, x, pool_size, instantiation, training):
+    """nonlocal_helper.py:105-148: theta from x, phi / g from the (optionally max-pooled) x, softmax(theta^T phi /
+    sqrt(d)) or theta^T phi / N_k ("dot_product"), times g, 1x1x1 conv_out + BN, added to x."""
+    n, c, t, h, w = x.shape
+    theta = _conv(sd, p + ".conv_theta", x)
+    d = theta.shape[1]
+    xp = x
+    if pool_size is not None and any(k > 1 for k in pool_size):
+        xp = F.max_pool3d(x, tuple(pool_size), tuple(pool_size))
+    phi = _conv(sd, p + ".conv_phi", xp).reshape(n, d, -1)
+    g = _conv(sd, p + ".conv_g", xp).reshape(n, d, -1)
+    tp = torch.einsum("nct,ncp->ntp", theta.reshape(n, d, -1), phi)
+    if instantiation == "softmax":
+        tp = torch.softmax(tp * (d ** -0.5), dim=2)
+    elif instantiation == "dot_product":
+        tp = tp / tp.shape[2]
+    else:
+        raise NotImplementedError(instantiation)
+    y = torch.einsum("ntg,ncg->nct", tp, g).reshape(n, d, t, h, w)
+    return x + _bn(sd, p + ".bn", _conv(sd, p + ".conv_out", y), training)
+
+
 def res_stage(sd, p, xs, stage_idx, hp, training):
     """resnet_helper.py:444-448, 530-561: per pathway, block i gets temporal kernel
     (k*n)[:num_block_temp_kernel] + [1]*rest and stride only on block 0."""
@@ -140,6 +162,16 @@ def res_stage(sd, p, xs, stage_idx, hp, training):
             x = res_block(sd, "%s.pathway%d_res%d" % (p, pw, i), x, kts[i],
                           hp["spatial_strides"][stage_idx] if i == 0 else 1,
                           hp["num_groups"], hp["spatial_dilations"][stage_idx], training)
+            nl = "%s.pathway%d_nonlocal%d" % (p, pw, i)
+            if (nl + ".conv_theta.weight") in sd:  # resnet_helper.py:519-528, 541-559
+                grp = hp["nonlocal_group"][stage_idx][pw]
+                b, c, t, h, w = x.shape
+                if grp > 1:  # fold groups of frames into the batch
+                    x = x.permute(0, 2, 1, 3, 4).reshape(b * grp, t // grp, c, h, w).permute(0, 2, 1, 3, 4)
+                x = nonlocal_block(sd, nl, x, hp["nonlocal_pool"][stage_idx][pw], hp["nonlocal_instantiation"],
+                                   training)
+                if grp > 1:
+                    x = x.permute(0, 2, 1, 3, 4).reshape(b, t, c, h, w).permute(0, 2, 1, 3, 4)
         out.append(x)
     return out
 

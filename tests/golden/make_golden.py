@@ -64,6 +64,12 @@ CASES = [
     # not take it (resnet_helper.py:338-349 vs :31-42) -> TypeError, so there is nothing to pin for it.
     dict(name="slow_r18_s64", yaml="SLOW_8x8_R50.yaml", model="ResNet", batch=2, t=8, alpha=1, size=64,
          over=["RESNET.DEPTH", 18, "RESNET.NUM_BLOCK_TEMP_KERNEL", [[2], [2], [2], [2]]] + small(64, 8), single=True),
+    # Nonlocal blocks.  SLOWFAST_NLN (dot_product, slow pathway res3 [1,3] / res4 [1,3,5],
+    # keys max-pooled (1,2,2)) and C2D_NLN (softmax instantiation, single pathway, frame groups folded into the batch)
+    dict(name="slowfast_nln_s64", yaml="SLOWFAST_NLN_8x8_R50.yaml", model="SlowFast", batch=2, t=16, alpha=4, size=64,
+         over=small(64, 16)),
+    dict(name="c2d_nln_s64", yaml="C2D_NLN_8x8_R50.yaml", model="ResNet", batch=2, t=8, alpha=1, size=64,
+         over=["NONLOCAL.GROUP", [[1], [2], [1], [1]]] + small(64, 8), single=True),
     # SlowFastShuffleNet (v1, GROUPS 1 as its YAML) + CMDA at S=64, T=16
     dict(name="shufflenet_g1_s64", yaml="SLOWFAST_SHUFFLENET_8x8_R50_stepwise_multigrid.yaml",
          model="SlowFastShuffleNet", batch=2, t=16, alpha=4, size=64,
@@ -112,6 +118,8 @@ def hparams_from_cfg(cfg):
         num_frames=cfg.DATA.NUM_FRAMES, crop_size=cfg.DATA.CROP_SIZE, num_classes=cfg.MODEL.NUM_CLASSES,
         short_cycle=bool(cfg.MULTIGRID.SHORT_CYCLE), head_act=cfg.MODEL.HEAD_ACT,
         width_multi=cfg.SLOWFAST.WIDTH_MULTI, eps=1e-5, groups=cfg.SLOWFAST.get("GROUPS", 1), arch=cfg.MODEL.ARCH,
+        nonlocal_group=[list(g) for g in cfg.NONLOCAL.GROUP], nonlocal_pool=[[list(q) for q in st] for st in cfg.NONLOCAL.POOL],
+        nonlocal_instantiation=cfg.NONLOCAL.INSTANTIATION,
     )
 
 

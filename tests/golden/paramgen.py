@@ -31,6 +31,8 @@ def fill_array(key, shape, seed):
     if leaf == "gamma":  # SpatialAttention residual gate (wdf_attention_helper.py:30)
         return np.full(shape, 0.5, np.float32)
     if len(shape) == 1:
+        if leaf == "weight" and "_nonlocal" in key:  # Nonlocal's final BN: keep x + BN(...) from growing block by block
+            return rs.uniform(0.1, 0.3, shape).astype(np.float32)
         if leaf == "weight":  # BN affine weight
             return rs.uniform(0.5, 1.0, shape).astype(np.float32)
         return rs.uniform(-0.1, 0.1, shape).astype(np.float32)  # any bias
@@ -40,6 +42,10 @@ def fill_array(key, shape, seed):
     gain = 2.0
     if "query_conv" in key or "key_conv" in key:
         gain = 0.5  # keep the un-scaled logits O(1): softmax must not be one-hot
+    if "conv_theta" in key or "conv_phi" in key:
+        gain = 0.02  # Nonlocal: theta^T phi sums d = 256 / 512 products of post-ReLU (non-zero-mean) features
+    if "_nonlocal" in key and ("conv_g" in key or "conv_out" in key):
+        gain = 0.5
     if leaf == "weight" and len(shape) == 2:  # Linear
         gain = 1.0
     return (rs.standard_normal(shape) * np.sqrt(gain / fan_in)).astype(np.float32)

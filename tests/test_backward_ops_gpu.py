@@ -361,6 +361,49 @@ def test_avgpool_shortcut_forward_backward():
     assert max(e) < TOL, e
 
 
+@pytest.mark.parametrize("inst,pool,dim,thw", [("softmax", (1, 2, 2), 64, (2, 6, 6)), ("dot_product", (1, 2, 2), 32, (3, 4, 4)),
+                                                ("softmax", None, 32, (2, 3, 5)), ("dot_product", (2, 2, 2), 96, (4, 6, 6))])
+def test_nonlocal_block_forward_backward(inst, pool, dim, thw):
+    """Nonlocal (nonlocal_helper.py:105-148), train mode, against the oracle's restatement under fp64 autograd:
+    output, input gradient and every parameter gradient."""
+    from oracle import slowfast_oracle as oracle
+    from slowfast.models import engine
+    from slowfast.models.nonlocal_helper import Nonlocal
+    dev = _dev()
+    torch.manual_seed(dim + len(inst))
+    blk = Nonlocal(dim, dim // 2, pool, instantiation=inst).to(dev).train()
+    with torch.no_grad():
+        for k, v in blk.named_parameters():
+            v.copy_(torch.randn_like(v) * (0.3 if v.dim() > 1 else 0.2) + (1.0 if k == "bn.weight" else 0.0))
+    x = torch.randn((2, dim) + thw)
+    dy = torch.randn((2, dim) + thw)
+    sd = {"m." + k: v.detach().double().cpu().requires_grad_(v.dtype.is_floating_point and "running" not in k)
+          for k, v in blk.state_dict().items() if "num_batches" not in k}
+    xr = x.double().requires_grad_(True)
+    ref = oracle.nonlocal_block(sd, "m", xr, pool, inst, True)
+    ref.backward(dy.double())
+    t = engine.Tape()
+    xa = _act(x)
+    with torch.no_grad(), engine.taping(t):
+        ya = blk.run(xa)
+        out = _back(ya)
+        t.grad_of(ya).buf.copy_(dy.permute(0, 2, 3, 4, 1).to(dev))
+        dxa = t.grad_of(xa)
+        t.backward()
+    torch.cuda.synchronize()
+    errs = {"y": _rel(out, ref), "dx": _rel(_back(dxa), xr.grad)}
+    for k, v in blk.named_parameters():
+        a, b = t.pgrads[v].double().cpu(), sd["m." + k].grad
+        # biases whose true gradient is exactly 0 (a constant shift removed by the train-mode BN / the softmax's
+        # shift invariance) only carry cancellation noise: measure them ...
+        scale = b.abs().max()
+        if k.endswith(".bias"):  # ... relative to the same layer's weight gradient
+            scale = torch.maximum(scale, sd["m." + k[:-4] + "weight"].grad.abs().max())
+        errs[k] = float((a.reshape(b.shape) - b).abs().max() / scale.clamp_min(1e-30))
+    _report("nonlocal %s pool=%s dim=%d" % (inst, pool, dim), max(errs.values()))
+    assert max(errs.values()) < TOL, errs
+
+
 def test_gather_add_is_the_adjoint_of_the_shuffled_store():
     import sfhip
     dev = _dev()
