@@ -306,18 +306,22 @@ def main():
         # Backward: 5 products in total (S recompute, dP, dV, dK, dQ); the two-kernel, atomic-free split
         # re-derives S and dP in both kernels (7 executed), so each kernel is credited only its share of the 5:
         # dK/dV kernel = dV + dK + half of (S, dP) = 3, dQ kernel = dQ + the other half = 2.
-        nprod = {"attn": 2, "attn_bwd_dkv": 3, "attn_bwd_dq": 2}[kind]
-        executed = {"attn": 2, "attn_bwd_dkv": 4, "attn_bwd_dq": 3}[kind]
+        # The single-sweep backward (attn_bwd_fused: dK/dV/dQ kernel + the dQ plane reduction, timed together)
+        # executes exactly the 5 algorithmic products.
+        nprod = {"attn": 2, "attn_bwd_dkv": 3, "attn_bwd_dq": 2, "attn_bwd_fused": 5}[kind]
+        executed = {"attn": 2, "attn_bwd_dkv": 4, "attn_bwd_dq": 3, "attn_bwd_fused": 5}[kind]
         flops = nprod * 2.0 * b * n * n * c
         ach = flops / dur / 1e12
         kname = {"attn": "attn_fwd_kernel (flash SpatialAttention forward)",
                  "attn_bwd_dkv": "attn_bwd_dkv_kernel (flash SpatialAttention backward, dK/dV)",
-                 "attn_bwd_dq": "attn_bwd_dq_kernel (flash SpatialAttention backward, dQ)"}[kind]
+                 "attn_bwd_dq": "attn_bwd_dq_kernel (flash SpatialAttention backward, dQ)",
+                 "attn_bwd_fused": "attn_bwd_fused_kernel + attn_dq_reduce_kernel (flash SpatialAttention backward, "
+                                   "dQ/dK/dV in one sweep)"}[kind]
         traffic = None  # HBM bytes per launch from the committed PMC passes (rocprofv3 cannot run inside bench.py)
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", "r01_attention_hbm_traffic.json")))["kernels"]
             kkey = {"attn": "attn_fwd_kernel<32, 4>", "attn_bwd_dkv": "attn_bwd_dkv_kernel<32>",
-                    "attn_bwd_dq": "attn_bwd_dq_kernel<32>"}[kind]
+                    "attn_bwd_dq": "attn_bwd_dq_kernel<32>", "attn_bwd_fused": "attn_bwd_fused<32>"}[kind]
             if c == 32 and n == 25088 and b == 8:
                 traffic = tj[kkey]["hbm_bytes_per_launch"]
         except (OSError, KeyError, ValueError):

@@ -333,6 +333,256 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const BwdArgs p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------- fused dK, dV, dQ
+// One sweep instead of two: the dK/dV kernel above additionally forms this wavefront's share of dQ for every query
+// tile (dQ_i += sum_{j in my 32 keys} dS_ij k_j), so S and dP are recomputed once — 5 products per tile in total
+// instead of 3 + 4.  dS sits with the KEY on the lane, the dQ product needs the QUERY on the lane: each wavefront
+// transposes its 32x32 dS tile through its own LDS slot (16 ds_write_b32 / 4 ds_read_b128, both conflict-free), K is
+// held in the B-operand layout in registers for the whole sweep.  The four wavefronts' partials of a query tile are
+// summed in a FIXED order through LDS and stored to a workspace plane per 128-key block; a second kernel sums the
+// planes (no float atomics: results stay bit-reproducible; the workspace is 5 GB at N = 25 088, d = 32, B = 8).
+template <int CP>
+__global__ __launch_bounds__(256) void attn_bwd_fused_kernel(const BwdArgs p, float* __restrict__ ws) {
+  constexpr int QT = (CP >= 64) ? 32 : 64;    // queries per LDS tile
+  constexpr int NSUB = QT / 32;
+  constexpr int PS = CP + 4;
+  constexpr int CT = CP / 32;
+  constexpr int QS = CP / 8;
+  constexpr int F4 = CP / 4;
+  constexpr int NF = (QT * F4 + 255) / 256;
+  constexpr int TILE = 2 * QT * PS + 2 * QT;  // Q tile, dO tile, lse, D
+  constexpr int SLOT = QT * CP;               // one wavefront's dQ partial [QT][CP]
+  constexpr int TP = 36;                      // pitch of the 32x32 transposition tile living in the slot
+  static_assert(32 * TP <= SLOT, "transposition tile must fit the slot");
+  static_assert(SLOT % (256 * 4) == 0, "flush covers the slot with float4 per thread");
+  __shared__ __attribute__((aligned(16))) float smem[2 * TILE + 4 * SLOT];
+  float* const slots = smem + 2 * TILE;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int b = blockIdx.x / p.nt;
+  const int kb = blockIdx.x - b * p.nt;
+  const int j0 = kb * 128 + wave * 32;
+  const int N = p.N, C = p.C;
+  const long brow = (long)b * N;
+  const float gamma = p.gamma[0];
+  float* const myslot = slots + wave * SLOT;
+
+  float kf[QS * 4], vf[QS * 4];
+  const int jrow = j0 + li;
+  const bool jok = jrow < N;
+  {
+    const float* kp = p.k + (brow + (jok ? jrow : 0)) * p.k_cs;
+    const float* vp = p.v + (brow + (jok ? jrow : 0)) * p.v_cs;
+#pragma unroll
+    for (int s = 0; s < QS; ++s)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int c = s * 8 + lh * 4 + e;
+        const bool ok = jok && c < C;
+        kf[s * 4 + e] = ok ? kp[c] * LOG2E : 0.f;
+        vf[s * 4 + e] = ok ? vp[c] : 0.f;
+      }
+  }
+  // K as the B operand of dQ = dS K: lane (c = li, half lh) holds k[key j0 + s + 16*lh][ct*32 + li] for step s
+  float kbr[CT][16];
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      const int key = j0 + s + 16 * lh, c = ct * 32 + li;
+      kbr[ct][s] = (key < N && c < C) ? p.k[(brow + key) * p.k_cs + c] : 0.f;
+    }
+  f32x16 dk[CT], dv[CT];
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { dk[ct][r] = 0.f; dv[ct][r] = 0.f; }
+
+  f32x4 rq[NF], rd[NF];
+  float rl = 0.f, rD = 0.f;
+  auto load_tile = [&](int i0) {
+#pragma unroll
+    for (int u = 0; u < NF; ++u) {
+      const int f = tid + u * 256;
+      const int row = f / F4;
+      const int c = (f - row * F4) * 4;
+      const int i = i0 + row;
+      f32x4 tq = {0.f, 0.f, 0.f, 0.f}, td = {0.f, 0.f, 0.f, 0.f};
+      if (f < QT * F4 && i < N) {
+        const float* qp = p.q + (brow + i) * p.q_cs + c;
+        const float* dp = p.dz + (brow + i) * p.dz_cs + c;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if ((c + e) < C) {
+            tq[e] = qp[e];
+            td[e] = dp[e] * gamma;
+          }
+      }
+      rq[u] = tq;
+      rd[u] = td;
+    }
+    if (tid < QT) {
+      const int i = i0 + tid;
+      rl = (i < N) ? p.lse[brow + i] : POS_BIG;  // P = 2^(s - BIG) = 0 for padded queries
+      rD = (i < N) ? p.dvec[brow + i] * gamma : 0.f;
+    }
+  };
+  auto store_tile = [&](int buf) {
+    float* Qs = smem + buf * TILE;
+    float* Ds = Qs + QT * PS;
+#pragma unroll
+    for (int u = 0; u < NF; ++u) {
+      const int f = tid + u * 256;
+      if (f < QT * F4) {
+        const int row = f / F4;
+        const int c = (f - row * F4) * 4;
+        *reinterpret_cast<f32x4*>(Qs + row * PS + c) = rq[u];
+        *reinterpret_cast<f32x4*>(Ds + row * PS + c) = rd[u];
+      }
+    }
+    if (tid < QT) {
+      Qs[2 * QT * PS + tid] = rl;
+      Qs[2 * QT * PS + QT + tid] = rD;
+    }
+  };
+
+  float* const plane = ws + ((long)b * p.nt + kb) * N * CP;  // this key block's dQ plane [N][CP]
+  const int ntiles = (N + QT - 1) / QT;
+  load_tile(0);
+  store_tile(0);
+  __syncthreads();
+  for (int t = 0; t < ntiles; ++t) {
+    const int buf = t & 1;
+    const bool more = (t + 1) < ntiles;
+    if (more) load_tile((t + 1) * QT);
+    const float* Qs = smem + buf * TILE;
+    const float* Ds = Qs + QT * PS;
+    const float* Ls = Qs + 2 * QT * PS;
+    const float* Dv = Ls + QT;
+    f32x16 dqp[NSUB][CT];
+#pragma unroll
+    for (int sub = 0; sub < NSUB; ++sub) {
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dqp[sub][ct][r] = 0.f;
+      if (t * QT + sub * 32 >= N) continue;
+      f32x16 s, dp;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+      const float* qrow = Qs + (sub * 32 + li) * PS + lh * 4;
+      const float* drow = Ds + (sub * 32 + li) * PS + lh * 4;
+#pragma unroll
+      for (int g = 0; g < QS; ++g) {
+        const f32x4 qa = *reinterpret_cast<const f32x4*>(qrow + g * 8);
+        const f32x4 da = *reinterpret_cast<const f32x4*>(drow + g * 8);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          s = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[e], kf[g * 4 + e], s, 0, 0, 0);    // S' = Q K^T (rows i)
+          dp = __builtin_amdgcn_mfma_f32_32x32x2f32(da[e], vf[g * 4 + e], dp, 0, 0, 0);  // dP = dO V^T
+        }
+      }
+      f32x16 pr;
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const f32x4 l4 = *reinterpret_cast<const f32x4*>(Ls + sub * 32 + 8 * g4 + 4 * lh);
+        const f32x4 d4 = *reinterpret_cast<const f32x4*>(Dv + sub * 32 + 8 * g4 + 4 * lh);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int r = 4 * g4 + e;
+          pr[r] = __builtin_amdgcn_exp2f(s[r] - l4[e]);
+          s[r] = pr[r] * (dp[r] - d4[e]);  // dS
+        }
+      }
+      const float* qcol = Qs + (sub * 32 + 4 * lh) * PS + li;
+      const float* dcol = Ds + (sub * 32 + 4 * lh) * PS + li;
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int off = ((r & 3) + 8 * (r >> 2)) * PS + ct * 32;
+          dv[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(dcol[off], pr[r], dv[ct], 0, 0, 0);  // dV^T += dO^T P
+          dk[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(qcol[off], s[r], dk[ct], 0, 0, 0);   // dK^T += Q^T dS
+        }
+      // dS [query kappa(r,lh)][key li]  ->  LDS tile T[query][key]  ->  A fragments with the query on the lane
+#pragma unroll
+      for (int r = 0; r < 16; ++r) myslot[kappa(r, lh) * TP + li] = s[r];
+      f32x4 af[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) af[j] = *reinterpret_cast<const f32x4*>(myslot + li * TP + 16 * lh + 4 * j);
+#pragma unroll
+      for (int st = 0; st < 16; ++st)
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+          dqp[sub][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[st >> 2][st & 3], kbr[ct][st], dqp[sub][ct], 0, 0,
+                                                              0);  // dQ(i, c) += dS(i, j) k(j, c)
+    }
+    // this wavefront's partial [QT][CP] into its slot (rows kappa(r,lh), channel on the lane)
+#pragma unroll
+    for (int sub = 0; sub < NSUB; ++sub)
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) myslot[(sub * 32 + kappa(r, lh)) * CP + ct * 32 + li] = dqp[sub][ct][r];
+    if (more) store_tile(buf ^ 1);
+    __syncthreads();
+    // fixed-order sum of the four wavefronts' partials, one float4 x (SLOT/1024) per thread, to the plane
+#pragma unroll
+    for (int u = 0; u < SLOT / 1024; ++u) {
+      const int e0 = (tid + u * 256) * 4;
+      f32x4 v = *reinterpret_cast<const f32x4*>(slots + e0);
+#pragma unroll
+      for (int w = 1; w < 4; ++w) v += *reinterpret_cast<const f32x4*>(slots + w * SLOT + e0);
+      const int qi = t * QT + e0 / CP;
+      if (qi < N) *reinterpret_cast<f32x4*>(plane + (long)qi * CP + (e0 % CP)) = v;
+    }
+    __syncthreads();  // slots are reused as transposition tiles by the next iteration
+  }
+  if (!jok) return;
+  float* okp = p.dk + (brow + jrow) * p.dk_cs;
+  float* ovp = p.dv + (brow + jrow) * p.dv_cs;
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int c = ct * 32 + 8 * (r >> 2) + 4 * lh + (r & 3);
+      if (c < C) {
+        okp[c] = dk[ct][r];
+        ovp[c] = dv[ct][r];
+      }
+    }
+}
+
+// dq[b, i, c] = sum over the key-block planes, in plane order.
+template <int CP>
+__global__ void attn_dq_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dq, int dq_cs, int B, int N,
+                                      int C, int nkb) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;  // float4 index over [B][N][CP/4]
+  const long total = (long)B * N * (CP / 4);
+  if (idx >= total) return;
+  const int c = (int)(idx % (CP / 4)) * 4;
+  const long row = idx / (CP / 4);  // b*N + i
+  const long b = row / N, i = row - b * N;
+  const float* src = ws + ((b * nkb) * N + i) * CP + c;
+  f32x4 v = {0.f, 0.f, 0.f, 0.f};
+  for (int k = 0; k < nkb; ++k) v += *reinterpret_cast<const f32x4*>(src + (long)k * N * CP);
+  float* o = dq + row * dq_cs + c;
+#pragma unroll
+  for (int e = 0; e < 4; ++e)
+    if (c + e < C) o[e] = v[e];
+}
+
+template <int CP>
+int launch_fused(const BwdArgs& a, float* ws, hipStream_t s) {
+  hipLaunchKernelGGL((attn_bwd_fused_kernel<CP>), dim3(a.B * a.nt), dim3(256), 0, s, a, ws);
+  const long total = (long)a.B * a.N * (CP / 4);
+  hipLaunchKernelGGL((attn_dq_reduce_kernel<CP>), dim3(sf_cdiv(total, 256)), dim3(256), 0, s, ws, a.dq, a.dq_cs, a.B,
+                     a.N, a.C, a.nt);
+  SF_CHECK_LAUNCH();
+  return SF_OK;
+}
+
 template <int CP>
 int launch(const BwdArgs& a, int which, hipStream_t s) {
   const int grid = a.B * a.nt;
@@ -368,4 +618,27 @@ extern "C" int sf_attn_bwd(const float* q, int q_cs, const float* k, int k_cs, c
   if (C <= 32) return launch<32>(a, which, s);
   if (C <= 64) return launch<64>(a, which, s);
   return launch<128>(a, which, s);
+}
+
+// Fused single-sweep backward (dQ, dK, dV) for 16 < C <= 64; ws: sf_attn_bwd_fused_ws_floats(B, N, C) floats
+// (0 = this shape is not served by the fused kernel: call sf_attn_bwd).
+extern "C" long sf_attn_bwd_fused_ws_floats(int B, int N, int C) {
+  if (B <= 0 || N <= 0 || C <= 16 || C > 64) return 0;
+  const long cp = C <= 32 ? 32 : 64;
+  return (long)B * sf_cdiv(N, 128) * N * cp;
+}
+
+extern "C" int sf_attn_bwd_fused(const float* q, int q_cs, const float* k, int k_cs, const float* v, int v_cs,
+                                 const float* dz, int dz_cs, const float* lse, const float* dvec, const float* gamma,
+                                 float* dq, int dq_cs, float* dk, int dk_cs, float* dv, int dv_cs, int B, int N, int C,
+                                 float* ws, void* stream) {
+  if (!q || !k || !v || !dz || !lse || !dvec || !gamma || !dq || !dk || !dv || !ws) return SF_EINVAL;
+  if (sf_attn_bwd_fused_ws_floats(B, N, C) == 0 || !sf_aligned16(ws)) return SF_EINVAL;
+  BwdArgs a;
+  a.q = q; a.k = k; a.v = v; a.dz = dz; a.lse = lse; a.dvec = dvec; a.gamma = gamma;
+  a.dq = dq; a.dk = dk; a.dv = dv;
+  a.q_cs = q_cs; a.k_cs = k_cs; a.v_cs = v_cs; a.dz_cs = dz_cs; a.dq_cs = dq_cs; a.dk_cs = dk_cs; a.dv_cs = dv_cs;
+  a.B = B; a.C = C; a.N = N; a.nt = sf_cdiv(N, 128);
+  if (C <= 32) return launch_fused<32>(a, ws, (hipStream_t)stream);
+  return launch_fused<64>(a, ws, (hipStream_t)stream);
 }

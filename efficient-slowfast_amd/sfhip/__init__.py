@@ -51,9 +51,10 @@ EXPORTS = [
     "sf_dwconv_dgrad", "sf_dwconv_wgrad_ws_floats", "sf_dwconv_wgrad", "sf_gather_add",
     "sf_bn_train_stats_split", "sf_affine_fwd_split", "sf_bn_bwd_reduce_split", "sf_bn_bwd_apply_split",
     "sf_clip_prologue", "sf_conv_wgrad_finish", "sf_bn_bwd_reduce_acc", "sf_row_softmax_fwd", "sf_row_softmax_bwd",
+    "sf_attn_bwd_fused_ws_floats", "sf_attn_bwd_fused",
 ]
 _LONG_RET = ("sf_tmax_mean_ws_floats", "sf_channel_stats_ws_floats", "sf_bn_bwd_ws_floats",
-             "sf_dwconv_wgrad_ws_floats")
+             "sf_dwconv_wgrad_ws_floats", "sf_attn_bwd_fused_ws_floats")
 
 
 def lib_path():
@@ -111,6 +112,10 @@ def lib():
         L.sf_dwconv_wgrad.argtypes = [ctypes.POINTER(ConvDesc), vp, vp, ci, ci, ci, vp, vp, vp]
         L.sf_gather_add.argtypes = [vp, ci, ci, ci, vp, ci, ci, cl, ci, ci, vp]
         L.sf_clip_prologue.argtypes = [vp] + [ci] * 10 + [ctypes.POINTER(ctypes.c_float)] * 2 + [vp, ci, vp, ci, ci, ci, vp]
+        L.sf_attn_bwd_fused_ws_floats.argtypes = [ci, ci, ci]
+        L.sf_attn_bwd_fused_ws_floats.restype = cl
+        L.sf_attn_bwd_fused.argtypes = [vp, ci, vp, ci, vp, ci, vp, ci, vp, vp, vp, vp, ci, vp, ci, vp, ci, ci, ci, ci,
+                                        vp, vp]
         L.sf_row_softmax_fwd.argtypes = [vp, ci, ci, cl, ci, cf, vp]
         L.sf_row_softmax_bwd.argtypes = [vp, ci, ci, vp, ci, ci, cl, ci, cf, vp]
         L.sf_conv_wgrad_finish.argtypes = [vp, ci, ci, ci, ci, ci, ci, vp, ci, vp]
@@ -663,6 +668,10 @@ def act_bwd(dy, y, relu, dx, accumulate=True):
     return dx
 
 
+FUSED_ATTN_BWD = os.environ.get("SF_ATTN_BWD_SPLIT") != "1"  # single-sweep backward for 16 < C <= 64 (5 GB scratch at
+# N = 25088); SF_ATTN_BWD_SPLIT=1 selects the two-kernel form (no scratch)
+
+
 def attention_bwd(q, k, v, dz, o, lse, gamma, dq, dk, dv):
     """dq/dk/dv (Act slices, overwritten) of the flash SpatialAttention; returns dvec[i] = <dz_i, O_i>
     (its sum is dL/dgamma)."""
@@ -673,6 +682,13 @@ def attention_bwd(q, k, v, dz, o, lse, gamma, dq, dk, dv):
     def base(a):
         return ctypes.c_void_p(a.buf.data_ptr() + 4 * a.coff)
 
+    nws = lib().sf_attn_bwd_fused_ws_floats(B, n, C) if FUSED_ATTN_BWD else 0
+    if nws > 0:  # one sweep: S and dP are recomputed once (5 products), dQ summed over key-block planes
+        ws = torch.empty((nws,), dtype=torch.float32, device=o.device)
+        _check(_traced(("attn_bwd_fused", B, n, C), lambda: lib().sf_attn_bwd_fused(
+            base(q), q.cs, base(k), k.cs, base(v), v.cs, base(dz), dz.cs, _ptr(lse), _ptr(dvec), _ptr(gamma),
+            base(dq), dq.cs, base(dk), dk.cs, base(dv), dv.cs, B, n, C, _ptr(ws), _stream())), "sf_attn_bwd_fused")
+        return dvec
     for which, tag in ((1, "attn_bwd_dq"), (2, "attn_bwd_dkv")):
         _check(_traced((tag, B, n, C), lambda: lib().sf_attn_bwd(
             base(q), q.cs, base(k), k.cs, base(v), v.cs, base(dz), dz.cs, _ptr(lse), _ptr(dvec),

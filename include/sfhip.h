@@ -130,6 +130,16 @@ int sf_attn_bwd(const float* q, int q_cs, const float* k, int k_cs, const float*
                 float* dq, int dq_cs, float* dk, int dk_cs, float* dv, int dv_cs, int B, int N, int C,
                 int which /* 1 = dQ kernel, 2 = dK/dV kernel, 3 = both */, void* stream);
 
+/* Single-sweep form of sf_attn_bwd for 16 < C <= 64: dK/dV and dQ in one pass over the (key block, query tile)
+ * pairs — S and dP are recomputed once (5 MFMA products per tile instead of 3 + 4).  Each 128-key workgroup writes
+ * its share of dQ to a plane of the workspace ws [B][ceil(N/128)][N][32|64] (four wavefronts summed in a fixed order
+ * through LDS) and a second kernel sums the planes: no float atomics, bit-reproducible.
+ * sf_attn_bwd_fused_ws_floats returns the workspace size in floats, or 0 when the shape is not served.          */
+long sf_attn_bwd_fused_ws_floats(int B, int N, int C);
+int sf_attn_bwd_fused(const float* q, int q_cs, const float* k, int k_cs, const float* v, int v_cs, const float* dz,
+                      int dz_cs, const float* lse, const float* dvec, const float* gamma, float* dq, int dq_cs,
+                      float* dk, int dk_cs, float* dv, int dv_cs, int B, int N, int C, float* ws, void* stream);
+
 /* ---- training-mode BatchNorm3d forward pieces (batchnorm_helper.py:15-34 -> nn.BatchNorm3d, training=True)
  * sf_channel_stats: per-channel mean and BIASED variance over all rows of an NDHWC slice, reduced through
  *   a fixed number of fp32 partials combined in fp64 (bit-reproducible; ws = sf_channel_stats_ws_floats(C)).
