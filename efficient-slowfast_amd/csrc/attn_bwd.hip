@@ -555,9 +555,8 @@ __global__ __launch_bounds__(256) void attn_bwd_fused_kernel(const BwdArgs p, fl
 }
 
 // dq[b, i, c] = sum over the key-block planes, in plane order.
-template <int CP>
 __global__ void attn_dq_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dq, int dq_cs, int B, int N,
-                                      int C, int nkb) {
+                                      int C, int CP, int nkb) {
   const long idx = (long)blockIdx.x * 256 + threadIdx.x;  // float4 index over [B][N][CP/4]
   const long total = (long)B * N * (CP / 4);
   if (idx >= total) return;
@@ -573,14 +572,23 @@ __global__ void attn_dq_reduce_kernel(const float* __restrict__ ws, float* __res
     if (c + e < C) o[e] = v[e];
 }
 
+}  // namespace
+
+// dq = sum of the nkb key-block planes [B][nkb][N][CP] (shared with attn_small_bwd.hip)
+int sf_attn_dq_reduce(const float* ws, float* dq, int dq_cs, int B, int N, int C, int CP, int nkb, hipStream_t s) {
+  const long total = (long)B * N * (CP / 4);
+  hipLaunchKernelGGL(attn_dq_reduce_kernel, dim3(sf_cdiv(total, 256)), dim3(256), 0, s, ws, dq, dq_cs, B, N, C, CP, nkb);
+  SF_CHECK_LAUNCH();
+  return SF_OK;
+}
+
+namespace {
+
 template <int CP>
 int launch_fused(const BwdArgs& a, float* ws, hipStream_t s) {
   hipLaunchKernelGGL((attn_bwd_fused_kernel<CP>), dim3(a.B * a.nt), dim3(256), 0, s, a, ws);
-  const long total = (long)a.B * a.N * (CP / 4);
-  hipLaunchKernelGGL((attn_dq_reduce_kernel<CP>), dim3(sf_cdiv(total, 256)), dim3(256), 0, s, ws, a.dq, a.dq_cs, a.B,
-                     a.N, a.C, a.nt);
   SF_CHECK_LAUNCH();
-  return SF_OK;
+  return sf_attn_dq_reduce(ws, a.dq, a.dq_cs, a.B, a.N, a.C, CP, a.nt, s);
 }
 
 template <int CP>
@@ -620,12 +628,17 @@ extern "C" int sf_attn_bwd(const float* q, int q_cs, const float* k, int k_cs, c
   return launch<128>(a, which, s);
 }
 
-// Fused single-sweep backward (dQ, dK, dV) for 16 < C <= 64; ws: sf_attn_bwd_fused_ws_floats(B, N, C) floats
+// Fused single-sweep backward (dQ, dK, dV) for C <= 64; ws: sf_attn_bwd_fused_ws_floats(B, N, C) floats
 // (0 = this shape is not served by the fused kernel: call sf_attn_bwd).
+int sf_attn_small_fused_dispatch(const float* q, int q_cs, const float* k, int k_cs, const float* v, int v_cs,
+                                 const float* dz, int dz_cs, const float* lse, const float* dvec, const float* gamma,
+                                 float* dq, int dq_cs, float* dk, int dk_cs, float* dv, int dv_cs, int B, int N, int C,
+                                 float* ws, hipStream_t stream);  // attn_small_bwd.hip
+
 extern "C" long sf_attn_bwd_fused_ws_floats(int B, int N, int C) {
-  if (B <= 0 || N <= 0 || C <= 16 || C > 64) return 0;
-  const long cp = C <= 32 ? 32 : 64;
-  return (long)B * sf_cdiv(N, 128) * N * cp;
+  if (B <= 0 || N <= 0 || C <= 0 || C > 64) return 0;
+  if (C <= 16) return (long)B * sf_cdiv(N, 64) * N * (C <= 4 ? 4 : (C <= 8 ? 8 : 16));  // 64-key blocks
+  return (long)B * sf_cdiv(N, 128) * N * (C <= 32 ? 32 : 64);
 }
 
 extern "C" int sf_attn_bwd_fused(const float* q, int q_cs, const float* k, int k_cs, const float* v, int v_cs,
@@ -634,6 +647,9 @@ extern "C" int sf_attn_bwd_fused(const float* q, int q_cs, const float* k, int k
                                  float* ws, void* stream) {
   if (!q || !k || !v || !dz || !lse || !dvec || !gamma || !dq || !dk || !dv || !ws) return SF_EINVAL;
   if (sf_attn_bwd_fused_ws_floats(B, N, C) == 0 || !sf_aligned16(ws)) return SF_EINVAL;
+  if (C <= 16)
+    return sf_attn_small_fused_dispatch(q, q_cs, k, k_cs, v, v_cs, dz, dz_cs, lse, dvec, gamma, dq, dq_cs, dk, dk_cs,
+                                        dv, dv_cs, B, N, C, ws, (hipStream_t)stream);
   BwdArgs a;
   a.q = q; a.k = k; a.v = v; a.dz = dz; a.lse = lse; a.dvec = dvec; a.gamma = gamma;
   a.dq = dq; a.dk = dk; a.dv = dv;

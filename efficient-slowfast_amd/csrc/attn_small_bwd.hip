@@ -289,6 +289,191 @@ __global__ __launch_bounds__(256) void attn_small_dkv_kernel(const BwdArgs p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------- fused dK, dV, dQ
+// The dK/dV sweep also forms dQ (see attn_bwd_fused_kernel in attn_bwd.hip): per 16x16 dS tile the wavefront
+// transposes dS through its LDS slot (4 ds_write_b32, 1 ds_read_b128) and adds 4 MFMAs  dQ(i,c) += dS(i,j) k(j,c);
+// the four wavefronts' [64 x CP] partials of a stage are summed in a fixed order and stored to this 64-key block's
+// plane of the workspace.
+template <int CP>
+__global__ __launch_bounds__(256) void attn_small_fused_kernel(const BwdArgs p, float* __restrict__ ws) {
+  using G = Geo<CP>;
+  constexpr int QS = G::QS, RP = G::RP, F4 = G::F4, NLD = G::NLD;
+  constexpr int STAGE = 2 * CP * TP + 2 * ST * RP + 2 * ST;  // Qt, dOt, Qs, dOs, lse, D
+  constexpr int SLOT = (ST * CP > 16 * 20) ? ST * CP : 16 * 20;  // dQ partial [64][CP]; also the 16x16 transposition tile
+  constexpr int TT = 20;                                          // its pitch
+  __shared__ __attribute__((aligned(16))) float smem[2 * STAGE + 4 * SLOT];
+  float* const slots = smem + 2 * STAGE;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, lg = lane >> 4;
+  const int b = blockIdx.x / p.nt;
+  const int kb = blockIdx.x - b * p.nt;
+  const int j0 = kb * 64 + wave * 16;
+  const int N = p.N, C = p.C;
+  const long brow = (long)b * N;
+  const float gamma = p.gamma[0];
+  float* const myslot = slots + wave * SLOT;
+
+  const int jrow = j0 + li;
+  const bool jok = jrow < N;
+  float kf[QS], vf[QS];
+  {
+    const float* kp = p.k + (brow + (jok ? jrow : 0)) * p.k_cs;
+    const float* vp = p.v + (brow + (jok ? jrow : 0)) * p.v_cs;
+#pragma unroll
+    for (int u = 0; u < QS; ++u) {
+      const int c = 4 * u + lg;
+      const bool ok = jok && c < C;
+      kf[u] = ok ? kp[c] * LOG2E : 0.f;
+      vf[u] = ok ? vp[c] : 0.f;
+    }
+  }
+  // K as B operand of dQ = dS K: lane (c = li, quarter lg) holds k[key j0 + 4*lg + s][li] for step s
+  float kbr[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const int key = j0 + 4 * lg + s;
+    kbr[s] = (key < N && li < C) ? p.k[(brow + key) * p.k_cs + li] : 0.f;
+  }
+  f32x4 dk0 = {0.f, 0.f, 0.f, 0.f}, dk1 = dk0, dv0 = dk0, dv1 = dk0;
+
+  const int srow = tid / F4;
+  const int sc4 = (tid - srow * F4) * 4;
+  f32x4 rq = {0.f, 0.f, 0.f, 0.f}, rd = {0.f, 0.f, 0.f, 0.f};
+  float rl = 0.f, rD = 0.f;
+  auto load_stage = [&](int i0) {
+    rq = (f32x4){0.f, 0.f, 0.f, 0.f};
+    rd = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int i = i0 + srow;
+    if (tid < NLD && i < N) {
+      const float* qp = p.q + (brow + i) * p.q_cs + sc4;
+      const float* dp = p.dz + (brow + i) * p.dz_cs + sc4;
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if ((sc4 + e) < C) {
+          rq[e] = qp[e];
+          rd[e] = dp[e] * gamma;
+        }
+    }
+    if (tid < ST) {
+      const int ii = i0 + tid;
+      rl = (ii < N) ? p.lse[brow + ii] : POS_BIG;
+      rD = (ii < N) ? p.dvec[brow + ii] * gamma : 0.f;
+    }
+  };
+  auto store_stage = [&](int buf) {
+    float* Qt = smem + buf * STAGE;
+    float* Dt = Qt + CP * TP;
+    float* Qs = Dt + CP * TP;
+    float* Ds = Qs + ST * RP;
+    float* Ls = Ds + ST * RP;
+    if (tid < NLD) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        Qt[(sc4 + e) * TP + srow] = rq[e];
+        Dt[(sc4 + e) * TP + srow] = rd[e];
+      }
+      *reinterpret_cast<f32x4*>(Qs + srow * RP + sc4) = rq;
+      *reinterpret_cast<f32x4*>(Ds + srow * RP + sc4) = rd;
+    }
+    if (tid < ST) {
+      Ls[tid] = rl;
+      Ls[ST + tid] = rD;
+    }
+  };
+
+  float* const plane = ws + ((long)b * p.nt + kb) * N * CP;
+  const int nst = (N + ST - 1) / ST;
+  load_stage(0);
+  store_stage(0);
+  __syncthreads();
+  for (int t = 0; t < nst; ++t) {
+    const int buf = t & 1;
+    const bool more = (t + 1) < nst;
+    if (more) load_stage((t + 1) * ST);
+    const float* Qt = smem + buf * STAGE;
+    const float* Dt = Qt + CP * TP;
+    const float* Qs = Dt + CP * TP;
+    const float* Ds = Qs + ST * RP;
+    const float* Ls = Ds + ST * RP;
+    f32x4 s[4], dp[4];
+    const float* qb = Qt + lg * TP + li;
+    const float* db = Dt + lg * TP + li;
+#pragma unroll
+    for (int qt = 0; qt < 4; ++qt) {
+      s[qt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      dp[qt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int u = 0; u < QS; ++u) {
+        s[qt] = __builtin_amdgcn_mfma_f32_16x16x4f32(qb[(4 * u) * TP + qt * 16], kf[u], s[qt], 0, 0, 0);    // S'
+        dp[qt] = __builtin_amdgcn_mfma_f32_16x16x4f32(db[(4 * u) * TP + qt * 16], vf[u], dp[qt], 0, 0, 0);  // dP
+      }
+    }
+    f32x4 pr[4];
+#pragma unroll
+    for (int qt = 0; qt < 4; ++qt) {
+      const f32x4 l4 = *reinterpret_cast<const f32x4*>(Ls + qt * 16 + 4 * lg);
+      const f32x4 d4 = *reinterpret_cast<const f32x4*>(Ls + ST + qt * 16 + 4 * lg);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        pr[qt][r] = __builtin_amdgcn_exp2f(s[qt][r] - l4[r]);
+        s[qt][r] = pr[qt][r] * (dp[qt][r] - d4[r]);  // dS
+      }
+    }
+    const float* qc = Qs + (4 * lg) * RP + (li & (CP - 1));
+    const float* dc = Ds + (4 * lg) * RP + (li & (CP - 1));
+#pragma unroll
+    for (int qt = 0; qt < 4; ++qt)
+#pragma unroll
+      for (int r = 0; r < 4; r += 2) {
+        dv0 = __builtin_amdgcn_mfma_f32_16x16x4f32(dc[(qt * 16 + r) * RP], pr[qt][r], dv0, 0, 0, 0);
+        dk0 = __builtin_amdgcn_mfma_f32_16x16x4f32(qc[(qt * 16 + r) * RP], s[qt][r], dk0, 0, 0, 0);
+        dv1 = __builtin_amdgcn_mfma_f32_16x16x4f32(dc[(qt * 16 + r + 1) * RP], pr[qt][r + 1], dv1, 0, 0, 0);
+        dk1 = __builtin_amdgcn_mfma_f32_16x16x4f32(qc[(qt * 16 + r + 1) * RP], s[qt][r + 1], dk1, 0, 0, 0);
+      }
+    // dQ: dS tile [query 4*lg + r][key li] -> T[query][key] -> A fragment (query li, keys 4*lg .. 4*lg+3)
+    f32x4 dqp[4];
+#pragma unroll
+    for (int qt = 0; qt < 4; ++qt) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) myslot[(4 * lg + r) * TT + li] = s[qt][r];
+      const f32x4 a = *reinterpret_cast<const f32x4*>(myslot + li * TT + 4 * lg);
+      dqp[qt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int st = 0; st < 4; ++st)
+        dqp[qt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[st], kbr[st], dqp[qt], 0, 0, 0);  // rows query, cols c
+    }
+    // partial [64][CP] (row 16*qt + 4*lg + r, channel li) into the slot
+    if (li < CP) {
+#pragma unroll
+      for (int qt = 0; qt < 4; ++qt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) myslot[(qt * 16 + 4 * lg + r) * CP + li] = dqp[qt][r];
+    }
+    if (more) store_stage(buf ^ 1);
+    __syncthreads();
+    if (tid < ST * CP / 4) {  // fixed-order sum of the four partials, one float4 per thread
+      const int e0 = tid * 4;
+      f32x4 v = *reinterpret_cast<const f32x4*>(slots + e0);
+#pragma unroll
+      for (int w = 1; w < 4; ++w) v += *reinterpret_cast<const f32x4*>(slots + w * SLOT + e0);
+      const int qi = t * ST + e0 / CP;
+      if (qi < N) *reinterpret_cast<f32x4*>(plane + (long)qi * CP + (e0 % CP)) = v;
+    }
+    __syncthreads();
+  }
+  const int c0 = 4 * lg;
+  if (!jok || c0 >= C) return;
+  float* okp = p.dk + (brow + jrow) * p.dk_cs + c0;
+  float* ovp = p.dv + (brow + jrow) * p.dv_cs + c0;
+#pragma unroll
+  for (int e = 0; e < 4; ++e)
+    if (c0 + e < C) {
+      okp[e] = dk0[e] + dk1[e];
+      ovp[e] = dv0[e] + dv1[e];
+    }
+}
+
 template <int CP>
 int launch(const BwdArgs& a, int which, hipStream_t s) {
   const int grid = a.B * a.nt;
@@ -313,4 +498,32 @@ int sf_attn_small_bwd_dispatch(const float* q, int q_cs, const float* k, int k_c
   if (C <= 4) return launch<4>(a, which, stream);
   if (C <= 8) return launch<8>(a, which, stream);
   return launch<16>(a, which, stream);
+}
+
+int sf_attn_dq_reduce(const float* ws, float* dq, int dq_cs, int B, int N, int C, int CP, int nkb, hipStream_t s);
+
+// Called by sf_attn_bwd_fused (attn_bwd.hip) for C <= 16.
+int sf_attn_small_fused_dispatch(const float* q, int q_cs, const float* k, int k_cs, const float* v, int v_cs,
+                                 const float* dz, int dz_cs, const float* lse, const float* dvec, const float* gamma,
+                                 float* dq, int dq_cs, float* dk, int dk_cs, float* dv, int dv_cs, int B, int N, int C,
+                                 float* ws, hipStream_t stream) {
+  BwdArgs a;
+  a.q = q; a.k = k; a.v = v; a.dz = dz; a.lse = lse; a.dvec = dvec; a.gamma = gamma;
+  a.dq = dq; a.dk = dk; a.dv = dv;
+  a.q_cs = q_cs; a.k_cs = k_cs; a.v_cs = v_cs; a.dz_cs = dz_cs; a.dq_cs = dq_cs; a.dk_cs = dk_cs; a.dv_cs = dv_cs;
+  a.B = B; a.C = C; a.N = N; a.nt = sf_cdiv(N, 64);
+  const int grid = B * a.nt;
+  int cp;
+  if (C <= 4) {
+    cp = 4;
+    hipLaunchKernelGGL((attn_small_fused_kernel<4>), dim3(grid), dim3(256), 0, stream, a, ws);
+  } else if (C <= 8) {
+    cp = 8;
+    hipLaunchKernelGGL((attn_small_fused_kernel<8>), dim3(grid), dim3(256), 0, stream, a, ws);
+  } else {
+    cp = 16;
+    hipLaunchKernelGGL((attn_small_fused_kernel<16>), dim3(grid), dim3(256), 0, stream, a, ws);
+  }
+  SF_CHECK_LAUNCH();
+  return sf_attn_dq_reduce(ws, dq, dq_cs, B, N, C, cp, a.nt, stream);
 }
