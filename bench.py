@@ -319,7 +319,7 @@ def main():
                                    "dQ/dK/dV in one sweep)"}[kind]
         traffic = None  # HBM bytes per launch from the committed PMC passes (rocprofv3 cannot run inside bench.py)
         try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_attention_hbm_traffic.json")))["kernels"]
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_attention_hbm_traffic_v2.json")))["kernels"]
             kkey = {"attn": "attn_fwd_kernel<32, 4>", "attn_bwd_dkv": "attn_bwd_dkv_kernel<32>",
                     "attn_bwd_dq": "attn_bwd_dq_kernel<32>", "attn_bwd_fused": "attn_bwd_fused<32>"}[kind]
             if c == 32 and n == 25088 and b == 8:

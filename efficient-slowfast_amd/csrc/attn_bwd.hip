@@ -341,28 +341,29 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const BwdArgs p) {
 // held in the B-operand layout in registers for the whole sweep.  The four wavefronts' partials of a query tile are
 // summed in a FIXED order through LDS and stored to a workspace plane per 128-key block; a second kernel sums the
 // planes (no float atomics: results stay bit-reproducible; the workspace is 5 GB at N = 25 088, d = 32, B = 8).
-template <int CP>
-__global__ __launch_bounds__(256) void attn_bwd_fused_kernel(const BwdArgs p, float* __restrict__ ws) {
+template <int CP, int NW>
+__global__ __launch_bounds__(64 * NW) void attn_bwd_fused_kernel(const BwdArgs p, float* __restrict__ ws) {
+  constexpr int NT = 64 * NW;                  // threads; the workgroup owns 32*NW keys
   constexpr int QT = (CP >= 64) ? 32 : 64;    // queries per LDS tile
   constexpr int NSUB = QT / 32;
   constexpr int PS = CP + 4;
   constexpr int CT = CP / 32;
   constexpr int QS = CP / 8;
   constexpr int F4 = CP / 4;
-  constexpr int NF = (QT * F4 + 255) / 256;
+  constexpr int NF = (QT * F4 + NT - 1) / NT;
   constexpr int TILE = 2 * QT * PS + 2 * QT;  // Q tile, dO tile, lse, D
   constexpr int SLOT = QT * CP;               // one wavefront's dQ partial [QT][CP]
   constexpr int TP = 36;                      // pitch of the 32x32 transposition tile living in the slot
   static_assert(32 * TP <= SLOT, "transposition tile must fit the slot");
-  static_assert(SLOT % (256 * 4) == 0, "flush covers the slot with float4 per thread");
-  __shared__ __attribute__((aligned(16))) float smem[2 * TILE + 4 * SLOT];
+  static_assert(SLOT % 4 == 0, "flush uses float4");
+  __shared__ __attribute__((aligned(16))) float smem[2 * TILE + NW * SLOT];
   float* const slots = smem + 2 * TILE;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, lh = lane >> 5;
   const int b = blockIdx.x / p.nt;
   const int kb = blockIdx.x - b * p.nt;
-  const int j0 = kb * 128 + wave * 32;
+  const int j0 = kb * (32 * NW) + wave * 32;
   const int N = p.N, C = p.C;
   const long brow = (long)b * N;
   const float gamma = p.gamma[0];
@@ -404,7 +405,7 @@ __global__ __launch_bounds__(256) void attn_bwd_fused_kernel(const BwdArgs p, fl
   auto load_tile = [&](int i0) {
 #pragma unroll
     for (int u = 0; u < NF; ++u) {
-      const int f = tid + u * 256;
+      const int f = tid + u * NT;
       const int row = f / F4;
       const int c = (f - row * F4) * 4;
       const int i = i0 + row;
@@ -433,7 +434,7 @@ __global__ __launch_bounds__(256) void attn_bwd_fused_kernel(const BwdArgs p, fl
     float* Ds = Qs + QT * PS;
 #pragma unroll
     for (int u = 0; u < NF; ++u) {
-      const int f = tid + u * 256;
+      const int f = tid + u * NT;
       if (f < QT * F4) {
         const int row = f / F4;
         const int c = (f - row * F4) * 4;
@@ -527,13 +528,11 @@ __global__ __launch_bounds__(256) void attn_bwd_fused_kernel(const BwdArgs p, fl
         for (int r = 0; r < 16; ++r) myslot[(sub * 32 + kappa(r, lh)) * CP + ct * 32 + li] = dqp[sub][ct][r];
     if (more) store_tile(buf ^ 1);
     __syncthreads();
-    // fixed-order sum of the four wavefronts' partials, one float4 x (SLOT/1024) per thread, to the plane
-#pragma unroll
-    for (int u = 0; u < SLOT / 1024; ++u) {
-      const int e0 = (tid + u * 256) * 4;
+    // fixed-order sum of the NW wavefronts' partials to the plane
+    for (int e0 = tid * 4; e0 < SLOT; e0 += NT * 4) {
       f32x4 v = *reinterpret_cast<const f32x4*>(slots + e0);
 #pragma unroll
-      for (int w = 1; w < 4; ++w) v += *reinterpret_cast<const f32x4*>(slots + w * SLOT + e0);
+      for (int w = 1; w < NW; ++w) v += *reinterpret_cast<const f32x4*>(slots + w * SLOT + e0);
       const int qi = t * QT + e0 / CP;
       if (qi < N) *reinterpret_cast<f32x4*>(plane + (long)qi * CP + (e0 % CP)) = v;
     }
@@ -584,9 +583,10 @@ int sf_attn_dq_reduce(const float* ws, float* dq, int dq_cs, int B, int N, int C
 
 namespace {
 
-template <int CP>
-int launch_fused(const BwdArgs& a, float* ws, hipStream_t s) {
-  hipLaunchKernelGGL((attn_bwd_fused_kernel<CP>), dim3(a.B * a.nt), dim3(256), 0, s, a, ws);
+template <int CP, int NW>
+int launch_fused(BwdArgs a, float* ws, hipStream_t s) {
+  a.nt = sf_cdiv(a.N, 32 * NW);  // key blocks (= dQ planes) per clip
+  hipLaunchKernelGGL((attn_bwd_fused_kernel<CP, NW>), dim3(a.B * a.nt), dim3(64 * NW), 0, s, a, ws);
   SF_CHECK_LAUNCH();
   return sf_attn_dq_reduce(ws, a.dq, a.dq_cs, a.B, a.N, a.C, CP, a.nt, s);
 }
@@ -630,6 +630,9 @@ extern "C" int sf_attn_bwd(const float* q, int q_cs, const float* k, int k_cs, c
 
 // Fused single-sweep backward (dQ, dK, dV) for C <= 64; ws: sf_attn_bwd_fused_ws_floats(B, N, C) floats
 // (0 = this shape is not served by the fused kernel: call sf_attn_bwd).
+constexpr int FUSED_KEYS_32 = 128;  // keys per workgroup of the d <= 32 fused kernel.  256 (8 wavefronts, half the
+// planes) measured SLOWER on MI355X: 18.9 vs 16.6 ms per backward at N = 25088 (one workgroup per CU, 8-wave barriers)
+
 int sf_attn_small_fused_dispatch(const float* q, int q_cs, const float* k, int k_cs, const float* v, int v_cs,
                                  const float* dz, int dz_cs, const float* lse, const float* dvec, const float* gamma,
                                  float* dq, int dq_cs, float* dk, int dk_cs, float* dv, int dv_cs, int B, int N, int C,
@@ -638,7 +641,8 @@ int sf_attn_small_fused_dispatch(const float* q, int q_cs, const float* k, int k
 extern "C" long sf_attn_bwd_fused_ws_floats(int B, int N, int C) {
   if (B <= 0 || N <= 0 || C <= 0 || C > 64) return 0;
   if (C <= 16) return (long)B * sf_cdiv(N, 64) * N * (C <= 4 ? 4 : (C <= 8 ? 8 : 16));  // 64-key blocks
-  return (long)B * sf_cdiv(N, 128) * N * (C <= 32 ? 32 : 64);
+  if (C <= 32) return (long)B * sf_cdiv(N, FUSED_KEYS_32) * N * 32;
+  return (long)B * sf_cdiv(N, 128) * N * 64;
 }
 
 extern "C" int sf_attn_bwd_fused(const float* q, int q_cs, const float* k, int k_cs, const float* v, int v_cs,
@@ -655,6 +659,6 @@ extern "C" int sf_attn_bwd_fused(const float* q, int q_cs, const float* k, int k
   a.dq = dq; a.dk = dk; a.dv = dv;
   a.q_cs = q_cs; a.k_cs = k_cs; a.v_cs = v_cs; a.dz_cs = dz_cs; a.dq_cs = dq_cs; a.dk_cs = dk_cs; a.dv_cs = dv_cs;
   a.B = B; a.C = C; a.N = N; a.nt = sf_cdiv(N, 128);
-  if (C <= 32) return launch_fused<32>(a, ws, (hipStream_t)stream);
-  return launch_fused<64>(a, ws, (hipStream_t)stream);
+  if (C <= 32) return launch_fused<32, FUSED_KEYS_32 / 32>(a, ws, (hipStream_t)stream);
+  return launch_fused<64, 4>(a, ws, (hipStream_t)stream);
 }
