@@ -495,6 +495,30 @@ __global__ __launch_bounds__(256) void row_softmax_bwd_kernel(const float* __res
   for (int c = lane; c < C; c += 64) dr[c] = scale * pr[c] * (dr[c] - dot);
 }
 
+// nn.Conv3d weight [Cout][Cin][taps] -> the two layouts the implicit-GEMM kernels consume, in ONE launch:
+//   wp  [Cout][taps][cin_pad]  (forward / weight-gradient order)   and, when asked,
+//   wtp [Cin][taps][cout_pad]  (data-gradient order: the transposed conv's "output channel" is Cin),
+// zero padded.  Runs once per optimizer step per conv (the packed copies are keyed on the parameter's version).
+__global__ void pack_weight_kernel(const float* __restrict__ w, int Cout, int Cin, int taps, float* __restrict__ wp,
+                                   int cin_pad, float* __restrict__ wtp, int cout_pad, long n_wp, long total) {
+  const long idx = (long)blockIdx.x * TPB + threadIdx.x;
+  if (idx >= total) return;
+  if (idx < n_wp) {
+    const int c = (int)(idx % cin_pad);
+    const long r = idx / cin_pad;
+    const int tap = (int)(r % taps);
+    const int co = (int)(r / taps);
+    wp[idx] = c < Cin ? w[((long)co * Cin + c) * taps + tap] : 0.f;
+  } else {
+    const long j = idx - n_wp;
+    const int co = (int)(j % cout_pad);
+    const long r = j / cout_pad;
+    const int tap = (int)(r % taps);
+    const int ci = (int)(r / taps);
+    wtp[j] = co < Cout ? w[((long)co * Cin + ci) * taps + tap] : 0.f;
+  }
+}
+
 inline int pow2ceil(int v) {
   int p = 1;
   while (p < v) p <<= 1;
@@ -709,6 +733,17 @@ extern "C" int sf_affine_fwd_split(const float* x, int cs, int coff, int N, int 
                                    int out_cmul, void* stream) {
   return affine_launch(x, cs, coff, N, T, H, W, C, nsplit, scale, bias, res, res_cs, res_coff, act, rep, out, out_cs,
                        out_coff, out_cmul, stream);
+}
+
+extern "C" int sf_pack_conv_weight(const float* w, int Cout, int Cin, int taps, float* wp, int cin_pad, float* wtp,
+                                   int cout_pad, void* stream) {
+  if (!w || !wp || Cout <= 0 || Cin <= 0 || taps <= 0 || cin_pad < Cin || (wtp && cout_pad < Cout)) return SF_EINVAL;
+  const long n_wp = (long)Cout * taps * cin_pad;
+  const long total = n_wp + (wtp ? (long)Cin * taps * cout_pad : 0);
+  hipLaunchKernelGGL(pack_weight_kernel, dim3(sf_cdiv(total, TPB)), dim3(TPB), 0, (hipStream_t)stream, w, Cout, Cin,
+                     taps, wp, cin_pad, wtp, cout_pad, n_wp, total);
+  SF_CHECK_LAUNCH();
+  return SF_OK;
 }
 
 extern "C" int sf_row_softmax_fwd(float* x, int cs, int coff, long rows, int C, float scale, void* stream) {

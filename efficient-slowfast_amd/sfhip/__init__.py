@@ -51,7 +51,7 @@ EXPORTS = [
     "sf_dwconv_dgrad", "sf_dwconv_wgrad_ws_floats", "sf_dwconv_wgrad", "sf_gather_add",
     "sf_bn_train_stats_split", "sf_affine_fwd_split", "sf_bn_bwd_reduce_split", "sf_bn_bwd_apply_split",
     "sf_clip_prologue", "sf_conv_wgrad_finish", "sf_bn_bwd_reduce_acc", "sf_row_softmax_fwd", "sf_row_softmax_bwd",
-    "sf_attn_bwd_fused_ws_floats", "sf_attn_bwd_fused",
+    "sf_attn_bwd_fused_ws_floats", "sf_attn_bwd_fused", "sf_pack_conv_weight",
 ]
 _LONG_RET = ("sf_tmax_mean_ws_floats", "sf_channel_stats_ws_floats", "sf_bn_bwd_ws_floats",
              "sf_dwconv_wgrad_ws_floats", "sf_attn_bwd_fused_ws_floats")
@@ -116,6 +116,7 @@ def lib():
         L.sf_attn_bwd_fused_ws_floats.restype = cl
         L.sf_attn_bwd_fused.argtypes = [vp, ci, vp, ci, vp, ci, vp, ci, vp, vp, vp, vp, ci, vp, ci, vp, ci, ci, ci, ci,
                                         vp, vp]
+        L.sf_pack_conv_weight.argtypes = [vp, ci, ci, ci, vp, ci, vp, ci, vp]
         L.sf_row_softmax_fwd.argtypes = [vp, ci, ci, cl, ci, cf, vp]
         L.sf_row_softmax_bwd.argtypes = [vp, ci, ci, vp, ci, ci, cl, ci, cf, vp]
         L.sf_conv_wgrad_finish.argtypes = [vp, ci, ci, ci, ci, ci, ci, vp, ci, vp]
@@ -267,6 +268,20 @@ def pack_conv_weight(w, cin_pad=None):
     wp = torch.zeros((cout, taps, cin_pad), dtype=torch.float32, device=w.device)
     wp[:, :, :cin] = w.detach().reshape(cout, cin, taps).permute(0, 2, 1)
     return wp.contiguous()
+
+
+def pack_conv_weight_pair(w):
+    """(wp [Cout][taps][cin_pad], wtp [Cin][taps][cout_pad]) of an nn.Conv3d weight on the GPU in one launch."""
+    _require_gpu(w, "pack_conv_weight_pair")
+    w = w.detach().contiguous()
+    cout, cin = w.shape[0], w.shape[1]
+    taps = w.shape[2] * w.shape[3] * w.shape[4]
+    cin_pad, cout_pad = (cin + 15) // 16 * 16, (cout + 15) // 16 * 16
+    wp = torch.empty((cout, taps, cin_pad), dtype=torch.float32, device=w.device)
+    wtp = torch.empty((cin, taps, cout_pad), dtype=torch.float32, device=w.device)
+    _check(lib().sf_pack_conv_weight(_ptr(w), cout, cin, taps, _ptr(wp), cin_pad, _ptr(wtp), cout_pad, _stream()),
+           "sf_pack_conv_weight")
+    return wp, wtp
 
 
 def pack_dw_weight(w):

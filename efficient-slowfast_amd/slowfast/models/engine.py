@@ -136,9 +136,12 @@ def _record_conv(x, conv_weight, conv_bias, wp_shape, gsrc, kernel, stride, padd
         if conv_bias is not None:
             t.add_pgrad(conv_bias, _colsum(g))
         if x_needs_grad:
-            wtp = _cached_t(conv_weight, "_sf_wtp", _key(conv_weight),
-                            lambda: sfhip.pack_conv_weight(conv_weight.detach().reshape(
-                                conv_weight.shape[0], conv_weight.shape[1], *kernel).transpose(0, 1).contiguous()))
+            if conv_weight.dim() == 5 and tuple(conv_weight.shape[2:]) == tuple(kernel):
+                wtp = _packed_pair(conv_weight)[1]
+            else:  # nn.Linear weights ([K, C]) and other re-shaped uses
+                wtp = _cached_t(conv_weight, "_sf_wtp", _key(conv_weight),
+                                lambda: sfhip.pack_conv_weight(conv_weight.detach().reshape(
+                                    conv_weight.shape[0], conv_weight.shape[1], *kernel).transpose(0, 1).contiguous()))
             sfhip.conv_dgrad(g, wtp, x, kernel, stride, padding, dilation, out=t.grad_of(x), accumulate=True)
 
     t.record(bwd)
@@ -188,6 +191,16 @@ def _sync_bn(bn):
     return isinstance(bn, NaiveSyncBatchNorm3d) and du.get_local_size() > 1
 
 
+_NBT = None  # inside run_model: the num_batches_tracked buffers to bump with ONE foreach add at the end
+
+
+def _bump(counter):
+    if _NBT is not None:
+        _NBT.append(counter)
+    else:
+        counter.add_(1)
+
+
 def _bn_train_stats(bn, z):
     """(mean, invstd, scale, shift, nsplit, gamma_for_backward, sync_hook) of a training-mode norm layer; updates
     the running statistics in place exactly as the reference layer would."""
@@ -203,7 +216,7 @@ def _bn_train_stats(bn, z):
         mean, invstd, scale, shift = sfhip.bn_train_stats(
             z, w, b, sb.eps, m, sb.running_mean if track else None, sb.running_var if track else None, nsplit=S)
         if track:
-            sb.num_batches_tracked.add_(1)
+            _bump(sb.num_batches_tracked)
         return mean, invstd, scale, shift, S, w, None
     track = bn.track_running_stats and bn.running_mean is not None
     m = bn.momentum if bn.momentum is not None else 1.0 / float(int(bn.num_batches_tracked) + 1)
@@ -233,7 +246,7 @@ def _bn_train_stats(bn, z):
         z, bn.weight, bn.bias, bn.eps, m, bn.running_mean if track else None, bn.running_var if track else None)
     if track:  # the kernel wrote the running buffers in place: drop the folded eval-mode affine cache
         bn.__dict__.pop("_sf_affine", None)
-        bn.num_batches_tracked.add_(1)
+        _bump(bn.num_batches_tracked)
     return mean, invstd, scale, shift, 1, bn.weight, None
 
 
@@ -316,9 +329,17 @@ def norm_forward(bn, x):
     return leave([y])[0]
 
 
+def _packed_pair(weight):
+    """(forward, data-gradient) packed copies of a dense conv weight, built together by one kernel and cached per
+    parameter version (training re-packs every conv once per optimizer step)."""
+    if not weight.is_cuda:  # CPU construction / state_dict work: torch fallback for the forward layout only
+        return sfhip.pack_conv_weight(weight), None
+    return _cached_t(weight, "_sf_wpair", _key(weight), lambda: sfhip.pack_conv_weight_pair(weight))
+
+
 def packed_weight(conv):
     if conv.groups == 1:
-        return _cached(conv, "_sf_wp", _key(conv.weight), lambda: sfhip.pack_conv_weight(conv.weight))
+        return _packed_pair(conv.weight)[0]
     if conv.groups == conv.in_channels and conv.out_channels == conv.in_channels:
         return _cached(conv, "_sf_wp", _key(conv.weight), lambda: sfhip.pack_dw_weight(conv.weight))
     raise NotImplementedError("grouped convolution with groups=%d (ResNeXt) is not on the HIP path" % conv.groups)
@@ -495,10 +516,18 @@ class TapedForward(torch.autograd.Function):
 
 def run_model(model, x):
     """model.forward body shared by all model classes: taped when training with grad enabled."""
-    if model.training and torch.is_grad_enabled():
-        params = [p for p in model.parameters()]
-        return TapedForward.apply(model, len(x), *x, *params)
-    return model._forward_impl(x)
+    global _NBT
+    outer, _NBT = _NBT, []
+    try:
+        if model.training and torch.is_grad_enabled():
+            params = [p for p in model.parameters()]
+            return TapedForward.apply(model, len(x), *x, *params)
+        return model._forward_impl(x)
+    finally:
+        counters, _NBT = _NBT, outer
+        if counters:
+            with torch.no_grad():
+                torch._foreach_add_(counters, 1)
 
 
 def copy_channels(x, out, out_cmul=1):

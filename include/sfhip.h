@@ -74,6 +74,10 @@ typedef struct sf_conv_desc {
 } sf_conv_desc;
 int sf_conv_fwd(const sf_conv_desc* d, const float* in, const float* w_packed, const float* scale,
                 const float* bias, const float* res, float* out, void* stream);
+/* Packs an nn.Conv3d weight [Cout][Cin][kT*kH*kW] (device) into wp [Cout][taps][cin_pad] and — when wtp != NULL —
+ * wtp [Cin][taps][cout_pad] (the data-gradient order), zero padded, in one launch.                           */
+int sf_pack_conv_weight(const float* w, int Cout, int Cin, int taps, float* wp, int cin_pad, float* wtp,
+                        int cout_pad, void* stream);
 
 /* ---- depthwise convolution (groups == channels) ----------------------------------------------
  * ghostnet_helper.py:88-90,114-120,137-143; shufflenetv2_helper.py:62-64,74-75,89-91.
