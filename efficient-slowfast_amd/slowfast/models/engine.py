@@ -73,6 +73,17 @@ class Tape(object):
     def has_grad(self, act):
         return act.buf.data_ptr() in self.gbuf
 
+    def grad_of_uninitialised(self, act):
+        """The gradient buffer of a whole-buffer activation that has no gradient yet, NOT zeroed: the caller must
+        overwrite every element (the first — usually only — consumer's data gradient), which saves the zero fill
+        and the read of an accumulate.  Returns None when the buffer already exists or `act` is a channel slice."""
+        key = act.buf.data_ptr()
+        if key in self.gbuf or act.coff != 0 or act.cs != act.C:
+            return None
+        g = torch.empty(act.buf.numel(), dtype=torch.float32, device=act.buf.device)
+        self.gbuf[key] = g
+        return Act(g.view(act.buf.shape), 0, act.C)
+
     def record(self, fn):
         self.ops.append(fn)
 
@@ -142,7 +153,11 @@ def _record_conv(x, conv_weight, conv_bias, wp_shape, gsrc, kernel, stride, padd
                 wtp = _cached_t(conv_weight, "_sf_wtp", _key(conv_weight),
                                 lambda: sfhip.pack_conv_weight(conv_weight.detach().reshape(
                                     conv_weight.shape[0], conv_weight.shape[1], *kernel).transpose(0, 1).contiguous()))
-            sfhip.conv_dgrad(g, wtp, x, kernel, stride, padding, dilation, out=t.grad_of(x), accumulate=True)
+            fresh = t.grad_of_uninitialised(x)
+            if fresh is not None:  # first consumer of x: write, do not accumulate
+                sfhip.conv_dgrad(g, wtp, x, kernel, stride, padding, dilation, out=fresh, accumulate=False)
+            else:
+                sfhip.conv_dgrad(g, wtp, x, kernel, stride, padding, dilation, out=t.grad_of(x), accumulate=True)
 
     t.record(bwd)
 
