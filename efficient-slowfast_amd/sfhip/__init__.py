@@ -493,8 +493,6 @@ def conv_dgrad(dz, wt_packed, x_like, kernel, stride=(1, 1, 1), padding=(0, 0, 0
     return out
 
 
-_CLASS_W = {}  # (weight ptr, version, class) -> tap-subset packed weights
-
 
 def _residue_taps(k, s, p, a):
     """Taps kk of a stride-s, pad-p, size-k kernel that reach input positions = a (mod s), as (offsets, taps):
@@ -522,16 +520,15 @@ def _conv_dgrad_strided(dz, wt_packed, out, kernel, stride, padding, accumulate)
                 dims = [(full - a + s - 1) // s for full, a, s in zip((out.T, out.H, out.W), (at, ah, aw), stride)]
                 if not (tt and th and tw) or min(dims) <= 0:
                     continue  # no tap reaches this class: its gradient is zero
-                key = (wt_packed.data_ptr(), wt_packed._version, at, ah, aw, tuple(kernel), tuple(stride),
-                       tuple(padding))
-                wsub = _CLASS_W.get(key)
+                # tap-subset weights, cached ON the packed tensor (they must die with it: the next optimizer step's
+                # packed copy may land at the same address)
+                store = wt_packed.__dict__.setdefault("_sf_classes", {})
+                key = (at, ah, aw, tuple(kernel), tuple(stride), tuple(padding))
+                wsub = store.get(key)
                 if wsub is None:
                     idx = torch.tensor([(a * kH + b) * kW + c for a in tt for b in th for c in tw],
                                        dtype=torch.long, device=wt_packed.device)
-                    wsub = wt_packed.index_select(1, idx).contiguous()
-                    if len(_CLASS_W) > 4096:
-                        _CLASS_W.clear()
-                    _CLASS_W[key] = wsub
+                    wsub = store[key] = wt_packed.index_select(1, idx).contiguous()
                 d = ConvDesc(dz.N, dz.T, dz.H, dz.W, dz.C, dz.cs, dz.coff, dims[0], dims[1], dims[2], cin, out.cs,
                              out.coff, 1, len(tt), len(th), len(tw), 1, 1, 1, -ot[0], -oh[0], -ow[0], 1, 1, 1,
                              cout_pad, ACT_NONE, out.cs, out.coff, 0, stride[0], stride[1], stride[2], at, ah, aw,

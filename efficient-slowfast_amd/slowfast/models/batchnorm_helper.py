@@ -77,6 +77,10 @@ class NaiveSyncBatchNorm3d(nn.BatchNorm3d):
             self.num_sync_devices = du.get_local_size()
             self.num_groups = 1
         super(NaiveSyncBatchNorm3d, self).__init__(**args)
+        if du.get_local_size() > 1:
+            # its statistics are collectives: keep every rank's collectives on one stream, in program order
+            from slowfast.models import engine
+            engine.OVERLAP_PATHS = False
 
     def forward(self, input):
         from slowfast.models import engine

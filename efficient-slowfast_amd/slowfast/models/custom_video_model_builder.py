@@ -63,23 +63,28 @@ class FuseFastAndSlow(nn.Module):
         else:
             f_wide = sfhip.new_act(x_f, x_f.N, x_f.T, x_f.H, x_f.W, x_f.C + self._c_s2f)
             sfhip.copy_channels(x_f, f_wide.slice(self._c_s2f, x_f.C))
-        # ---- Fast -> Slow
-        if self.bn_f2s.training:  # batch statistics sit between the gate and the ReLU: one extra pass
-            z = self.attention_channel_f2s.run(x_f, alpha=a)
-            engine.bn_train_apply(self.bn_f2s, z, relu=True, out=s_wide.slice(x_s.C, self._c_f2s))
-        else:
-            sc, bi = engine.bn_affine(self.bn_f2s)
-            self.attention_channel_f2s.run(x_f, alpha=a, scale=sc, bias=bi, relu=True,
-                                           out=s_wide.slice(x_s.C, self._c_f2s))
-        # ---- Slow -> Fast
-        y = engine.conv_bn_act(x_s, self.downsample_c_of_slow)
-        if self.bn_s2f.training:
-            z = self.attention_spatial_s2f.run(y)
-            engine.bn_train_apply(self.bn_s2f, z, relu=True, rep=a, out=f_wide.slice(0, self._c_s2f))
-        else:
-            sc, bi = engine.bn_affine(self.bn_s2f)
-            self.attention_spatial_s2f.run(y, scale=sc, bias=bi, relu=True, alpha=a,
-                                           out=f_wide.slice(0, self._c_s2f))
+        def fast_to_slow():
+            if self.bn_f2s.training:  # batch statistics sit between the gate and the ReLU: one extra pass
+                z = self.attention_channel_f2s.run(x_f, alpha=a)
+                engine.bn_train_apply(self.bn_f2s, z, relu=True, out=s_wide.slice(x_s.C, self._c_f2s))
+            else:
+                sc, bi = engine.bn_affine(self.bn_f2s)
+                self.attention_channel_f2s.run(x_f, alpha=a, scale=sc, bias=bi, relu=True,
+                                               out=s_wide.slice(x_s.C, self._c_f2s))
+
+        def slow_to_fast():
+            y = engine.conv_bn_act(x_s, self.downsample_c_of_slow)
+            if self.bn_s2f.training:
+                z = self.attention_spatial_s2f.run(y)
+                engine.bn_train_apply(self.bn_s2f, z, relu=True, rep=a, out=f_wide.slice(0, self._c_s2f))
+            else:
+                sc, bi = engine.bn_affine(self.bn_s2f)
+                self.attention_spatial_s2f.run(y, scale=sc, bias=bi, relu=True, alpha=a,
+                                               out=f_wide.slice(0, self._c_s2f))
+
+        # the two directions touch disjoint channel slices: the MFMA-bound attention runs beside the HBM-bound
+        # pool / gate / BN chain of the other direction
+        engine.run_paths([slow_to_fast, fast_to_slow], x_s.buf.device)
         return engine.leave([s_wide, f_wide])
 
 

@@ -3,6 +3,7 @@ libsfhip kernels: parameter preprocessing caches (packed weights, folded eval-mo
 conv(+BN)(+residual)(+ReLU) unit, the stem trick, and the NCTHW <-> NDHWC boundary handling that lets
 every top-level child be called on its own with the reference's list-of-NCTHW-tensors convention
 (Grad-CAM contract, wdf_visualization/gradcam_video.py:92-105)."""
+import os
 import threading
 
 import torch
@@ -54,6 +55,7 @@ class Tape(object):
         self.pgrads = {}
         self.out_act = None
         self.sink = None  # {param: its .grad} when parameter gradients are accumulated in place (set_grad_sink)
+        self.side = None  # the side stream ops are being recorded for (run_paths), None = the caller's stream
 
     def pgrad_target(self, param):
         """The tensor kernels may accumulate this parameter's gradient into directly, or None."""
@@ -85,7 +87,7 @@ class Tape(object):
         return Act(g.view(act.buf.shape), 0, act.C)
 
     def record(self, fn):
-        self.ops.append(fn)
+        self.ops.append((fn, self.side))
 
     def add_pgrad(self, param, g):
         g = g.reshape(param.shape)
@@ -97,14 +99,70 @@ class Tape(object):
         self.pgrads[param] = g if cur is None else cur + g
 
     def backward(self):
-        for fn in reversed(self.ops):
-            fn()
+        """Replay in reverse.  Ops recorded inside run_paths on the side stream run there again; the region's
+        join / fork markers become the backward pass's fork / join."""
+        for fn, side in reversed(self.ops):
+            if side is None:
+                fn()
+            else:
+                with torch.cuda.stream(side):
+                    fn()
         self.ops = []
         self.gbuf = {}
 
 
 def tape():
     return getattr(_tls, "tape", None)
+
+
+# ------------------------------------------------------------------------------------------------ two streams
+# The Slow and the Fast pathway are independent between lateral fusions, and so are the two directions of a CMDA
+# fusion: the Fast pathway is a string of small-channel, HBM-bound kernels (and tiny grids), the Slow pathway of
+# MFMA-bound ones.  run_paths issues the second callable on a side stream so the two overlap on the GPU; forward and
+# backward regions are delimited by events (fork: side waits for the caller's stream; join: the caller's stream waits
+# for side), which is also all the ordering the caching allocator needs: a block is only ever re-used by the stream
+# that allocated it, and every region starts / ends by ordering that stream against the other.
+OVERLAP_PATHS = os.environ.get("SF_OVERLAP_PATHS", "1") != "0"
+_SIDE = {}
+
+
+def _side_stream(device):
+    s = _SIDE.get(device)
+    if s is None:
+        s = _SIDE[device] = torch.cuda.Stream(device=device)
+    return s
+
+
+def _sync_streams(first, then):
+    ev = torch.cuda.Event()
+    ev.record(first)
+    then.wait_event(ev)
+
+
+def run_paths(fns, device):
+    """[f() for f in fns] with fns[1] issued on the side stream (two callables on a CUDA device; otherwise serial)."""
+    if not OVERLAP_PATHS or len(fns) != 2 or device.type != "cuda":
+        return [f() for f in fns]
+    t = tape()
+    if t is not None and t.side is not None:
+        return [f() for f in fns]  # already inside a region
+    main, side = torch.cuda.current_stream(device), _side_stream(device)
+    if t is not None:
+        t.record(lambda: _sync_streams(side, torch.cuda.current_stream(device)))  # backward: join
+    _sync_streams(main, side)                                                       # forward: fork
+    out0 = fns[0]()
+    with torch.cuda.stream(side):
+        if t is not None:
+            t.side = side
+        try:
+            out1 = fns[1]()
+        finally:
+            if t is not None:
+                t.side = None
+    _sync_streams(side, main)                                                       # forward: join
+    if t is not None:
+        t.record(lambda: _sync_streams(torch.cuda.current_stream(device), side))  # backward: fork
+    return [out0, out1]
 
 
 class taping(object):
@@ -166,13 +224,15 @@ _PCACHE = {}
 
 
 def _cached_t(tensor, slot, key, make):
-    """cache keyed on a tensor (parameters are not nn.Modules)."""
-    k = (id(tensor), slot)
-    c = _PCACHE.get(k)
+    """cache keyed on a tensor (parameters are not nn.Modules).  The entry lives ON the tensor object, so it dies
+    with it: a global table keyed by id() would hand a new parameter that re-uses a freed one's id, address and
+    version the old one's packed weights."""
+    store = tensor.__dict__.setdefault("_sf_cache", {})
+    c = store.get(slot)
     if c is None or c[0] != key:
         with torch.no_grad():
             c = (key, make())
-        _PCACHE[k] = c
+        store[slot] = c
     return c[1]
 
 
@@ -571,10 +631,13 @@ def avgpool(x, kernel, stride, padding):
     """nn.AvgPool3d(kernel, stride, padding) with count_include_pad=True: a depthwise conv whose taps are all
     1/|kernel| (zero padding == counting the pad).  Taped: the data gradient is the transposed gather."""
     taps = kernel[0] * kernel[1] * kernel[2]
-    w = _PCACHE.get(("avgpool", taps, x.C, str(x.buf.device)))
+    # keyed on the issuing stream too: a constant created inside a run_paths region must not be shared with the
+    # other stream before the region's join
+    key = ("avgpool", taps, x.C, str(x.buf.device), torch.cuda.current_stream(x.buf.device).cuda_stream)
+    w = _PCACHE.get(key)
     if w is None:
         w = torch.full((taps, x.C), 1.0 / taps, dtype=torch.float32, device=x.buf.device)
-        _PCACHE[("avgpool", taps, x.C, str(x.buf.device))] = w
+        _PCACHE[key] = w
     y = sfhip.dwconv(x, w, kernel, stride, padding)
     t = tape()
     if t is not None:

@@ -124,9 +124,9 @@ class ResStage(nn.Module):
 
     def forward(self, inputs, reserve=None):
         xs = engine.enter(inputs)
-        output = []
-        with engine.internal():
-            for pathway in range(self.num_pathways):
+
+        def pathway_fn(pathway):
+            def run():
                 x = xs[pathway]
                 n = self.num_blocks[pathway]
                 for i in range(n):
@@ -142,5 +142,9 @@ class ResStage(nn.Module):
                         x = nln.run(x, room)
                         if grp > 1:
                             x = sfhip.Act(x.buf.view(x.N // grp, x.T * grp, x.H, x.W, x.cs), x.coff, x.C)
-                output.append(x)
+                return x
+            return run
+
+        with engine.internal():  # the two pathways are independent inside a stage: Fast on the side stream
+            output = engine.run_paths([pathway_fn(p) for p in range(self.num_pathways)], xs[0].buf.device)
         return engine.leave(output)

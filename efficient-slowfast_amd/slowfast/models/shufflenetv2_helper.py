@@ -124,6 +124,7 @@ class ShuffleNetV2_Stage(nn.Module):
     def forward(self, inputs, reserve=None):
         xs = engine.enter(inputs)
         with engine.internal():
-            out = [getattr(self, self._names[p])(xs[p], reserve[p] if reserve else (0, 0))
-                   for p in range(self.num_pathways)]
+            out = engine.run_paths(
+                [lambda p=p: getattr(self, self._names[p])(xs[p], reserve[p] if reserve else (0, 0))
+                 for p in range(self.num_pathways)], xs[0].buf.device)
         return engine.leave(out)

@@ -42,10 +42,10 @@ class VideoModelStem(nn.Module):
 
     def forward(self, x, reserve=None):
         assert len(x) == self.num_pathways, "Input tensor does not contain {} pathway".format(self.num_pathways)
-        acts = []
-        for pathway in range(len(x)):
-            m = getattr(self, "pathway{}_stem".format(pathway))
-            acts.append(m(x[pathway], reserve[pathway] if reserve else (0, 0)))
+        dev = x[0].buf.device if hasattr(x[0], "buf") else x[0].device
+        acts = engine.run_paths(
+            [lambda p=p: getattr(self, "pathway{}_stem".format(p))(x[p], reserve[p] if reserve else (0, 0))
+             for p in range(len(x))], dev)
         out = engine.leave(acts)
         for pathway in range(len(x)):  # the reference mutates the caller's list in place (:96-98)
             x[pathway] = out[pathway]
@@ -89,8 +89,10 @@ class _EfficientStem(nn.Module):
 
     def forward(self, x, reserve=None):
         assert len(x) == self.num_pathways, "Input tensor does not contain {} pathway".format(self.num_pathways)
-        acts = [getattr(self, "pathway{}_stem".format(p))(x[p], reserve[p] if reserve else (0, 0))
-                for p in range(len(x))]
+        dev = x[0].buf.device if hasattr(x[0], "buf") else x[0].device
+        acts = engine.run_paths(
+            [lambda p=p: getattr(self, "pathway{}_stem".format(p))(x[p], reserve[p] if reserve else (0, 0))
+             for p in range(len(x))], dev)
         out = engine.leave(acts)
         for pathway in range(len(x)):
             x[pathway] = out[pathway]

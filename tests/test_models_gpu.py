@@ -331,3 +331,80 @@ def test_grad_sink_equals_autograd_path(name):
     for p in flat.params:  # .grad tensors are still the views of the flat buffer
         assert p.grad.data_ptr() == flat.flat.data_ptr() + 4 * off
         off += p.numel()
+
+
+@pytest.mark.parametrize("name", ["dual_r50_s64", "ghostnet_w2_s64"])
+def test_two_stream_overlap_is_deterministic_and_equal_to_serial(name):
+    """engine.run_paths issues the Fast pathway / one CMDA direction on a side stream.  Every kernel is
+    deterministic, so any missing fork/join ordering would show up as run-to-run or overlap-vs-serial differences:
+    five training steps with the overlap must be bit-identical to each other and to the serial schedule."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from slowfast.models import engine
+    z, meta = load_case(name)
+    model, sd = _build(meta, z)
+    for m in model.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    model.train()
+    xs = [x.cuda() for x in case_inputs(meta)]
+    labels = torch.from_numpy(z["train/labels"]).cuda()
+
+    def step():
+        model.load_state_dict(sd)
+        model.zero_grad(set_to_none=True)
+        out = model([x.clone() for x in xs])
+        torch.nn.functional.cross_entropy(out, labels).backward()
+        torch.cuda.synchronize()
+        return torch.cat([out.detach().reshape(-1)] + [p.grad.reshape(-1) for p in model.parameters()]).clone()
+
+    saved = engine.OVERLAP_PATHS
+    try:
+        engine.OVERLAP_PATHS = False
+        serial = step()
+        engine.OVERLAP_PATHS = True
+        runs = [step() for _ in range(5)]
+    finally:
+        engine.OVERLAP_PATHS = saved
+    for r in runs:
+        assert torch.equal(r, serial)
+    model.eval()
+    with torch.no_grad():
+        engine.OVERLAP_PATHS = False
+        a = model([x.clone() for x in xs])
+        engine.OVERLAP_PATHS = saved
+        b = model([x.clone() for x in xs])
+    assert torch.equal(a, b)
+
+
+def test_packed_weight_caches_follow_optimizer_steps():
+    """Three SGD steps on the HIP path == three SGD steps with every cache dropped before each forward/backward:
+    packed (forward, data-gradient, strided-class) weight copies must be rebuilt after each update even when the new
+    copy lands at the old one's address."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    z, meta = load_case("slowfast_r50_s64")
+    xs = [x.cuda() for x in case_inputs(meta)]
+    labels = torch.from_numpy(z["train/labels"]).cuda()
+
+    def train(drop_caches):
+        model, sd = _build(meta, z)
+        for m in model.modules():
+            if isinstance(m, torch.nn.Dropout):
+                m.p = 0.0
+        model.train()
+        opt = torch.optim.SGD(model.parameters(), lr=0.05)
+        for _ in range(3):
+            if drop_caches:
+                for p in model.parameters():
+                    p.__dict__.pop("_sf_cache", None)
+                for m in model.modules():
+                    for k in [k for k in m.__dict__ if k.startswith("_sf_")]:
+                        m.__dict__.pop(k)
+            opt.zero_grad(set_to_none=True)
+            torch.nn.functional.cross_entropy(model([x.clone() for x in xs]), labels).backward()
+            opt.step()
+        torch.cuda.synchronize()
+        return torch.cat([p.detach().reshape(-1) for p in model.parameters()])
+
+    assert torch.equal(train(False), train(True))
