@@ -56,6 +56,7 @@ class Tape(object):
         self.out_act = None
         self.sink = None  # {param: its .grad} when parameter gradients are accumulated in place (set_grad_sink)
         self.side = None  # the side stream ops are being recorded for (run_paths), None = the caller's stream
+        self.joins = set()  # companion streams with weight-gradient work in flight (joined at the end of backward)
 
     def pgrad_target(self, param):
         """The tensor kernels may accumulate this parameter's gradient into directly, or None."""
@@ -107,6 +108,9 @@ class Tape(object):
             else:
                 with torch.cuda.stream(side):
                     fn()
+        for wg in self.joins:
+            _sync_streams(wg, torch.cuda.current_stream(wg.device))
+        self.joins = set()
         self.ops = []
         self.gbuf = {}
 
@@ -130,6 +134,18 @@ def _side_stream(device):
     s = _SIDE.get(device)
     if s is None:
         s = _SIDE[device] = torch.cuda.Stream(device=device)
+    return s
+
+
+_COMPANION = {}
+
+
+def _companion_stream(parent):
+    """A stream paired with `parent` (the caller's or the side stream) for work only needed at the end of backward."""
+    key = (parent.device, parent.cuda_stream)
+    s = _COMPANION.get(key)
+    if s is None:
+        s = _COMPANION[key] = torch.cuda.Stream(device=parent.device)
     return s
 
 
@@ -192,8 +208,7 @@ def _record_conv(x, conv_weight, conv_bias, wp_shape, gsrc, kernel, stride, padd
         return
     cout = conv_weight.shape[0]
 
-    def bwd():
-        g = gsrc() if callable(gsrc) else gsrc
+    def wgrad(g):
         tgt = t.pgrad_target(conv_weight)
         if tgt is not None:  # partial sum + un-pack + accumulate into .grad in one kernel
             real_cin = conv_weight.shape[1]
@@ -204,6 +219,24 @@ def _record_conv(x, conv_weight, conv_bias, wp_shape, gsrc, kernel, stride, padd
             t.add_pgrad(conv_weight, unpack(dwp) if unpack else sfhip.unpack_conv_weight_grad(dwp, conv_weight.shape))
         if conv_bias is not None:
             t.add_pgrad(conv_bias, _colsum(g))
+
+    def bwd():
+        g = gsrc() if callable(gsrc) else gsrc
+        dev = x.buf.device
+        if OVERLAP_PATHS and x_needs_grad and dev.type == "cuda":
+            # the weight gradient only feeds the parameter's .grad: issue it on a companion stream so that it
+            # overlaps the data gradient (both are short-grid GEMMs on the res4 / res5 layers); joined by
+            # Tape.backward before the gradients are handed back
+            cur = torch.cuda.current_stream(dev)
+            wg = _companion_stream(cur)
+            _sync_streams(cur, wg)
+            with torch.cuda.stream(wg):
+                wgrad(g)
+            g.buf.record_stream(wg)  # e.g. the masked-gradient temporary of a bare ReLU dies with this closure
+            x.buf.record_stream(wg)
+            t.joins.add(wg)
+        else:
+            wgrad(g)
         if x_needs_grad:
             if conv_weight.dim() == 5 and tuple(conv_weight.shape[2:]) == tuple(kernel):
                 wtp = _packed_pair(conv_weight)[1]
