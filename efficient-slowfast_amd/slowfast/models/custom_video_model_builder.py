@@ -47,7 +47,7 @@ class FuseFastAndSlow(nn.Module):
         """(before, after) channel room per pathway: slow = [x_s | from_fast], fast = [from_slow | x_f]."""
         return [(0, self._c_f2s), (self._c_s2f, 0)]
 
-    def forward(self, x):
+    def forward(self, x, defer_join=False):
         x_s, x_f = engine.enter(x)
         a = self.alpha
         # ---- destination buffers (in place when the producers reserved room)
@@ -84,7 +84,10 @@ class FuseFastAndSlow(nn.Module):
 
         # the two directions touch disjoint channel slices: the MFMA-bound attention runs beside the HBM-bound
         # pool / gate / BN chain of the other direction
-        engine.run_paths([slow_to_fast, fast_to_slow], x_s.buf.device)
+        # (Fast->Slow on the caller's stream, the attention on the side stream: with defer_join the Slow pathway's
+        # next stage starts as soon as its own input is complete)
+        engine.run_paths([fast_to_slow, slow_to_fast], x_s.buf.device,
+                         defer_join=defer_join and engine.is_internal())
         return engine.leave([s_wide, f_wide])
 
 
@@ -122,7 +125,8 @@ class _EfficientTwoPathway(nn.Module):
                 if n == "head":
                     x = m(x)
                 elif n.endswith("_fuse"):
-                    x = m(x)
+                    nxt = names[i + 1] if i + 1 < len(names) else "head"
+                    x = m(x, defer_join=(nxt != "head"))  # followed by a stage: the attention overlaps it
                 else:
                     nxt = getattr(self, names[i + 1]) if i + 1 < len(names) else None
                     x = m(x, reserve=nxt.reserve(None) if isinstance(nxt, FuseFastAndSlow) else None)

@@ -155,8 +155,12 @@ def _sync_streams(first, then):
     then.wait_event(ev)
 
 
-def run_paths(fns, device):
-    """[f() for f in fns] with fns[1] issued on the side stream (two callables on a CUDA device; otherwise serial)."""
+def run_paths(fns, device, defer_join=False):
+    """[f() for f in fns] with fns[1] issued on the side stream (two callables on a CUDA device; otherwise serial).
+    defer_join: do not make the caller's stream wait for the side stream at the end of the FORWARD region — only
+    valid when the next work on the caller's stream does not read what fns[1] produced before the next region's
+    join (a CMDA fusion followed by a stage: the attention keeps running beside the Slow pathway's next stage).
+    The backward pass is unaffected: its fork at this point is always recorded."""
     if not OVERLAP_PATHS or len(fns) != 2 or device.type != "cuda":
         return [f() for f in fns]
     t = tape()
@@ -175,7 +179,8 @@ def run_paths(fns, device):
         finally:
             if t is not None:
                 t.side = None
-    _sync_streams(side, main)                                                       # forward: join
+    if not defer_join:
+        _sync_streams(side, main)                                                   # forward: join
     if t is not None:
         t.record(lambda: _sync_streams(torch.cuda.current_stream(device), side))  # backward: fork
     return [out0, out1]

@@ -47,7 +47,7 @@ class FuseFastToSlow(nn.Module):
         """(before, after) channel room each pathway's producer should leave: slow gets the fuse after it."""
         return [(0, self.conv_f2s.out_channels), (0, 0)]
 
-    def forward(self, x):
+    def forward(self, x, defer_join=False):  # single direction: nothing to defer
         x_s, x_f = engine.enter(x)
         cf = self.conv_f2s.out_channels
         if x_s.coff == 0 and x_s.cs == x_s.C + cf:
@@ -144,21 +144,28 @@ class _TwoPathwayResNet(nn.Module):
         x = list(x)
         with engine.internal():
             x = self.s1(x, reserve=self.s1_fuse.reserve(None))
-            x = self.s1_fuse(x)
+            x = self._fuse(self.s1_fuse, x)
             x = self.s2(x, reserve=self.s2_fuse.reserve(None))
-            x = self.s2_fuse(x)
+            x = self._fuse(self.s2_fuse, x)
             for pathway in range(self.num_pathways):
                 pool = getattr(self, "pathway{}_pool".format(pathway))
                 ks = pool.kernel_size if isinstance(pool.kernel_size, (list, tuple)) else [pool.kernel_size] * 3
                 if list(ks) != [1, 1, 1]:  # _POOL1["slowfast"] is the identity (elided)
                     x[pathway] = engine.maxpool(x[pathway], tuple(ks), tuple(ks))
             x = self.s3(x, reserve=self.s3_fuse.reserve(None))
-            x = self.s3_fuse(x)
+            x = self._fuse(self.s3_fuse, x)
             x = self.s4(x, reserve=self.s4_fuse.reserve(None))
-            x = self.s4_fuse(x)
+            x = self._fuse(self.s4_fuse, x)
             x = self.s5(x)
             x = self.head(x)
         return x
+
+    def _fuse(self, fuse, x):
+        """A lateral fusion that is followed by a ResStage: CMDA may leave its attention running on the side stream
+        (the stage's own two-stream region orders everything again); the identity pools in between touch nothing."""
+        pools_are_identity = all(
+            list(getattr(self, "pathway{}_pool".format(p)).kernel_size) == [1, 1, 1] for p in range(self.num_pathways))
+        return fuse(x, defer_join=pools_are_identity)
 
 
 @MODEL_REGISTRY.register()
