@@ -1,0 +1,50 @@
+#!/usr/bin/env python3
+"""Concurrency picture of the last training step in a rocprofv3 kernel-trace CSV: span, GPU-busy time, how much of
+the span has 1 / 2 / 3+ kernels in flight, and which kernels own the solo (critical-path) time.
+usage: tools/prof_timeline.py <kernel_trace.csv> [marker-kernel-substring]"""
+import csv
+import sys
+from collections import defaultdict
+
+rows = list(csv.DictReader(open(sys.argv[1])))
+marker = sys.argv[2] if len(sys.argv) > 2 else "multi_tensor_apply"
+rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+# steps are delimited by the optimizer's multi-tensor kernels: take the region between the last two bursts
+idx = [i for i, r in enumerate(rows) if marker in r["Kernel_Name"]]
+bursts = []
+for i in idx:
+    if not bursts or i - bursts[-1][-1] > 50:
+        bursts.append([i])
+    else:
+        bursts[-1].append(i)
+a, b = bursts[-2][-1] + 1, bursts[-1][0]
+ev = rows[a:b]
+t0 = int(ev[0]["Start_Timestamp"])
+t1 = max(int(r["End_Timestamp"]) for r in ev)
+points = []
+for r in ev:
+    n = r["Kernel_Name"]
+    short = n.split("::")[1].split("(")[0] if "anonymous" in n else n[:40]
+    points.append((int(r["Start_Timestamp"]), 1, short))
+    points.append((int(r["End_Timestamp"]), -1, short))
+points.sort(key=lambda p: (p[0], p[1]))
+active = defaultdict(int)
+depth_time = defaultdict(float)
+solo = defaultdict(float)
+prev = t0
+for ts, d, name in points:
+    k = sum(active.values())
+    dt = ts - prev
+    if dt > 0:
+        depth_time[min(k, 3)] += dt
+        if k == 1:
+            solo[next(n for n, c in active.items() if c > 0)] += dt
+    active[name] += d
+    prev = ts
+span = (t1 - t0) / 1e6
+print("step span %.2f ms, kernels %d" % (span, len(ev)))
+for k in sorted(depth_time):
+    print("  %s kernels in flight: %7.2f ms (%4.1f%%)" % ("3+" if k == 3 else k, depth_time[k] / 1e6, 100 * depth_time[k] / (t1 - t0)))
+print("solo time by kernel:")
+for n, v in sorted(solo.items(), key=lambda kv: -kv[1])[:18]:
+    print("  %-44s %7.2f ms" % (n, v / 1e6))
