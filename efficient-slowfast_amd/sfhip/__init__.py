@@ -526,9 +526,9 @@ def _conv_dgrad_strided(dz, wt_packed, out, kernel, stride, padding, accumulate)
                 key = (at, ah, aw, tuple(kernel), tuple(stride), tuple(padding))
                 wsub = store.get(key)
                 if wsub is None:
-                    idx = torch.tensor([(a * kH + b) * kW + c for a in tt for b in th for c in tw],
-                                       dtype=torch.long, device=wt_packed.device)
-                    wsub = store[key] = wt_packed.index_select(1, idx).contiguous()
+                    # device-only gather (no host index tensor: this runs inside hipGraph capture too)
+                    taps_sel = [(a * kH + b) * kW + c for a in tt for b in th for c in tw]
+                    wsub = store[key] = torch.stack([wt_packed[:, i, :] for i in taps_sel], dim=1).contiguous()
                 d = ConvDesc(dz.N, dz.T, dz.H, dz.W, dz.C, dz.cs, dz.coff, dims[0], dims[1], dims[2], cin, out.cs,
                              out.coff, 1, len(tt), len(th), len(tw), 1, 1, 1, -ot[0], -oh[0], -ow[0], 1, 1, 1,
                              cout_pad, ACT_NONE, out.cs, out.coff, 0, stride[0], stride[1], stride[2], at, ah, aw,
