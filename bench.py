@@ -363,6 +363,7 @@ def main():
                            world, "one RCCL all-reduce of the flat fp32 gradient per step" if train
                            else "no data-path collective in forward")},
         }
+        res["peak_hbm_gb"] = round(torch.cuda.max_memory_allocated(device) / 1e9, 2)  # of 288 GB
         if eval_fwd is not None:
             res["eval_forward"] = eval_fwd
         if roofline is not None:
