@@ -364,6 +364,15 @@ def main():
                            else "no data-path collective in forward")},
         }
         res["peak_hbm_gb"] = round(torch.cuda.max_memory_allocated(device) / 1e9, 2)  # of 288 GB
+        # whole-step arithmetic roofline (algorithmic FLOPs per clip: convs x3 for fwd + dgrad + wgrad,
+        # flash attention x3.5; fwd only in eval mode) against the dense-f32 MFMA peak of all GPUs in the job
+        per_clip = {"dual": (211.3e9, 690.0e9), "slowfast": (100.6e9, 302.0e9)}.get(args.workload)
+        if per_clip is not None:
+            flop = per_clip[1 if train else 0] * clips_total
+            ach = flop / elapsed / 1e12
+            res["step_roofline"] = {"algorithmic_gflop_per_clip": per_clip[1 if train else 0] / 1e9,
+                                    "achieved_tflops": round(ach, 2), "peak_tflops": PEAK_FP32_MFMA_TFLOPS * world,
+                                    "frac": round(ach / (PEAK_FP32_MFMA_TFLOPS * world), 4)}
         if eval_fwd is not None:
             res["eval_forward"] = eval_fwd
         if roofline is not None:
