@@ -34,6 +34,8 @@ struct ConvArgs {
   int nb_n;     // number of N tiles
   int nblocks;  // total tiles
   int vec_epi;  // 1: outputs/residual are 16-byte addressable -> LDS-transposed float4 epilogue
+  int ksplit;   // > 1: blockIdx.y takes a contiguous share of the K steps and stores a raw partial tile to ws
+  float* ws;    // [ksplit][M][Cout] partials (split-K), finished by conv_splitk_finish_kernel
 };
 
 constexpr int BK = 16;
@@ -93,8 +95,14 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
     b_ptr[j] = p.w + (long)(b_ok[j] ? n : 0) * kpad + lc;
   }
 
-  // ---- K iteration state: tap (kt,kh,kw) outer, 16-channel chunk inner
-  int kt = 0, kh = 0, kw = 0, c0 = 0, tap = 0;
+  // ---- K iteration state: tap (kt,kh,kw) outer, 16-channel chunk inner; a split-K workgroup starts at its share
+  const int nk_all = p.ntaps * (d.cin_pad / BK);
+  const int nk_per = (nk_all + p.ksplit - 1) / p.ksplit;
+  const int it_begin = (int)blockIdx.y * nk_per;
+  const int it_end = (it_begin + nk_per < nk_all) ? it_begin + nk_per : nk_all;
+  int tap = it_begin / (d.cin_pad / BK);
+  int c0 = (it_begin - tap * (d.cin_pad / BK)) * BK;
+  int kw = tap % d.kW, kh = (tap / d.kW) % d.kH, kt = tap / (d.kW * d.kH);
   long a_off[A_IT];
   bool a_v[A_IT];
   auto set_tap = [&]() {
@@ -183,9 +191,11 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
 #pragma unroll
     for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  const int nk = p.ntaps * (d.cin_pad / BK);
-  load_global();
-  store_lds(0);
+  const int nk = it_end - it_begin;  // >= 16 for every split by construction of splitk_factor; 0 is still safe
+  if (nk > 0) {
+    load_global();
+    store_lds(0);
+  }
   __syncthreads();
   for (int it = 0; it < nk; ++it) {
     const int buf = it & 1;
@@ -215,7 +225,14 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
   // ---- epilogue
   // Scattered stores (strided data-gradient classes): output position (n,t,h,w) of this launch lands at
   // (t*os_T + oo_T, h*os_H + oo_H, w*os_W + oo_W) of a destination of dims ob_T x ob_H x ob_W.
-  const bool scatter = d.os_T > 1 || d.os_H > 1 || d.os_W > 1;
+  const bool split = p.ksplit > 1;  // raw partial tile to the workspace; the finish kernel applies the epilogue
+  const float* const e_scale = split ? nullptr : p.scale;
+  const float* const e_bias = split ? nullptr : p.bias;
+  const float* const e_res = split ? nullptr : p.res;
+  float* const e_out = split ? p.ws + (long)blockIdx.y * p.M * d.Cout : p.out;
+  const int e_out_cs = split ? d.Cout : d.out_cs, e_out_coff = split ? 0 : d.out_coff;
+  const int e_out_cmul = split ? 1 : d.out_cmul;
+  const bool scatter = !split && (d.os_T > 1 || d.os_H > 1 || d.os_W > 1);
   auto out_row = [&](int m) -> long {
     if (!scatter) return (long)m;
     const int wo = m % d.Wo;
@@ -227,10 +244,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
     const int st = d.os_T > 1 ? d.os_T : 1, sh = d.os_H > 1 ? d.os_H : 1, sw = d.os_W > 1 ? d.os_W : 1;
     return (((long)n * d.ob_T + to * st + d.oo_T) * d.ob_H + ho * sh + d.oo_H) * d.ob_W + wo * sw + d.oo_W;
   };
-  const bool has_res = p.res != nullptr;
-  const bool relu = d.act == SF_ACT_RELU || d.act == SF_ACT_RELU6;
+  const bool has_res = e_res != nullptr;
+  const bool relu = !split && (d.act == SF_ACT_RELU || d.act == SF_ACT_RELU6);
   const float hi = d.act == SF_ACT_RELU6 ? 6.f : 3.0e38f;
-  if (p.vec_epi) {
+  if (split ? (d.Cout % 4 == 0) : p.vec_epi) {
     // The accumulator layout has the channel on the lane (16 lanes = 64 B per row): stored directly, a wave
     // store touches 4 rows x 64 B.  Transpose each 16-row slab through this wave's private LDS region and
     // emit 16-byte stores (and residual loads) that cover whole WN_COLS*4-byte row segments instead.
@@ -244,8 +261,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
     const bool n_ok = n < d.Cout;              // Cout % 4 == 0 on this path
     f32x4 sc = {1.f, 1.f, 1.f, 1.f}, bi = {0.f, 0.f, 0.f, 0.f};
     if (n_ok) {
-      if (p.scale) sc = *reinterpret_cast<const f32x4*>(p.scale + n);
-      if (p.bias) bi = *reinterpret_cast<const f32x4*>(p.bias + n);
+      if (e_scale) sc = *reinterpret_cast<const f32x4*>(e_scale + n);
+      if (e_bias) bi = *reinterpret_cast<const f32x4*>(e_bias + n);
     }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
@@ -262,12 +279,12 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
           const long orow = out_row(m);
           f32x4 v = *reinterpret_cast<const f32x4*>(slab + row * EP + c4);
           v = v * sc + bi;
-          if (has_res) v += *reinterpret_cast<const f32x4*>(p.res + orow * d.res_cs + d.res_coff + n);
+          if (has_res) v += *reinterpret_cast<const f32x4*>(e_res + orow * d.res_cs + d.res_coff + n);
           if (relu) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = fminf(fmaxf(v[e], 0.f), hi);
           }
-          *reinterpret_cast<f32x4*>(p.out + orow * d.out_cs + d.out_coff + n) = v;
+          *reinterpret_cast<f32x4*>(e_out + orow * e_out_cs + e_out_coff + n) = v;
         }
       }
       __syncthreads();
@@ -279,8 +296,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
   for (int j = 0; j < TN; ++j) {
     const int n = n0 + wn * (BN / WN) + j * 16 + fr;
     if (n >= d.Cout) continue;
-    const float sc = p.scale ? p.scale[n] : 1.f;
-    const float bi = p.bias ? p.bias[n] : 0.f;
+    const float sc = e_scale ? e_scale[n] : 1.f;
+    const float bi = e_bias ? e_bias[n] : 0.f;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -289,9 +306,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
         if (m >= p.M) continue;
         const long orow = out_row(m);
         float v = acc[i][j][r] * sc + bi;
-        if (has_res) v += p.res[orow * d.res_cs + d.res_coff + n];
+        if (has_res) v += e_res[orow * d.res_cs + d.res_coff + n];
         v = relu ? fminf(fmaxf(v, 0.f), hi) : v;
-        p.out[orow * d.out_cs + d.out_coff + (long)n * d.out_cmul] = v;
+        e_out[orow * e_out_cs + e_out_coff + (long)n * e_out_cmul] = v;
       }
     }
   }
@@ -337,23 +354,89 @@ __global__ __launch_bounds__(256) void gemv_rows_kernel(const ConvArgs p) {
   }
 }
 
+// Split-K finish: out[m, n] = act(scale[n] * sum_s ws[s][m][n] + bias[n] + res[m, n]) — the partials summed in split
+// order (no float atomics), then the same epilogue (incl. the scattered-store map) as the single-pass kernel.
+__global__ void conv_splitk_finish_kernel(const ConvArgs p) {
+  const sf_conv_desc& d = p.d;
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  const long total = (long)p.M * d.Cout;
+  if (idx >= total) return;
+  const int n = (int)(idx % d.Cout);
+  const int m = (int)(idx / d.Cout);
+  float v = 0.f;
+  for (int s = 0; s < p.ksplit; ++s) v += p.ws[(long)s * total + idx];
+  long orow = m;
+  if (d.os_T > 1 || d.os_H > 1 || d.os_W > 1) {
+    const int wo = m % d.Wo;
+    const int t1 = m / d.Wo;
+    const int ho = t1 % d.Ho;
+    const int t2 = t1 / d.Ho;
+    const int to = t2 % d.To;
+    const int nn = t2 / d.To;
+    const int st = d.os_T > 1 ? d.os_T : 1, sh = d.os_H > 1 ? d.os_H : 1, sw = d.os_W > 1 ? d.os_W : 1;
+    orow = (((long)nn * d.ob_T + to * st + d.oo_T) * d.ob_H + ho * sh + d.oo_H) * d.ob_W + wo * sw + d.oo_W;
+  }
+  v = v * (p.scale ? p.scale[n] : 1.f) + (p.bias ? p.bias[n] : 0.f);
+  if (p.res) v += p.res[orow * d.res_cs + d.res_coff + n];
+  v = sf_act(v, d.act);
+  p.out[orow * d.out_cs + d.out_coff + (long)n * d.out_cmul] = v;
+}
+
 template <int BM, int BN, int WM, int WN>
 int launch(const ConvArgs& a, bool vec4, hipStream_t s) {
   ConvArgs p = a;
   p.nb_n = sf_cdiv(p.d.Cout, BN);
   p.nblocks = sf_cdiv(p.M, BM) * p.nb_n;
+  const dim3 grid(p.nblocks, p.ksplit);
   if (vec4)
-    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, 4>), dim3(p.nblocks), dim3(256), 0, s, p);
+    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, 4>), grid, dim3(256), 0, s, p);
   else
-    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, 1>), dim3(p.nblocks), dim3(256), 0, s, p);
+    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, 1>), grid, dim3(256), 0, s, p);
+  if (p.ksplit > 1) {
+    const long total = (long)p.M * p.d.Cout;
+    hipLaunchKernelGGL(conv_splitk_finish_kernel, dim3(sf_cdiv(total, 256)), dim3(256), 0, s, p);
+  }
   SF_CHECK_LAUNCH();
   return SF_OK;
 }
 
+// Split-K factor: the M <= 12544 layers of res4 / res5 with long reductions (3x1x1 and 1x3x3 over 256..2048 channels)
+// give 25..200 tiles of 128x128 — less than one per CU — but 144..384 K steps each: share the K steps of a tile between
+// `S` workgroups instead of shrinking the tile (the vendor GEMM reaches 108-123 TFLOP/s on these shapes the same way).
+static int splitk_factor(const sf_conv_desc* d, long M) {
+  if (d->Cout < 64) return 1;
+  const long tiles = (long)sf_cdiv(M, 128) * sf_cdiv(d->Cout, d->Cout <= 64 ? 64 : 128);
+  const int nk = d->kT * d->kH * d->kW * (d->cin_pad / BK);
+  if (tiles >= 384 || nk < 48) return 1;
+  // Equal-sized workgroups run in "rounds" of 256 (one per CU): pick the split whose workgroup count wastes the
+  // least of its last round, with a small penalty per split for the partial-tile traffic.  Measured on MI355X
+  // (tools/microbench/splitk_sweep.py): 196 tiles -> S = 5 (980 = 3.83 rounds) 86 TFLOP/s vs S = 4 (784 = 3.06
+  // rounds) 76; 100 tiles -> S = 5 (500 = 1.95 rounds) 96 vs S = 4 (1.56 rounds) 83.
+  int best = 1;
+  double best_score = (double)tiles / (double)(sf_cdiv(tiles, 256) * 256L);
+  for (int S = 2; S <= 12 && nk / S >= 16; ++S) {
+    const long wg = tiles * S;
+    const double score = (double)wg / (double)(sf_cdiv(wg, 256) * 256L) - 0.01 * S;
+    if (score > best_score + 1e-9) {
+      best_score = score;
+      best = S;
+    }
+  }
+  return best;
+}
+
 }  // namespace
 
-extern "C" int sf_conv_fwd(const sf_conv_desc* d, const float* in, const float* w_packed, const float* scale,
-                           const float* bias, const float* res, float* out, void* stream) {
+extern "C" long sf_conv_fwd_ws_floats(const sf_conv_desc* d) {
+  if (!d) return 0;
+  const long M = (long)d->N * d->To * d->Ho * d->Wo;
+  if (M <= 0 || d->Cout <= 0 || d->cin_pad <= 0) return 0;
+  const int S = splitk_factor(d, M);
+  return S > 1 ? (long)S * M * d->Cout : 0;
+}
+
+static int conv_fwd_impl(const sf_conv_desc* d, const float* in, const float* w_packed, const float* scale,
+                         const float* bias, const float* res, float* out, float* ws, void* stream) {
   if (!d || !in || !w_packed || !out) return SF_EINVAL;
   if (d->Cin <= 0 || d->Cout <= 0 || d->cin_pad < d->Cin || (d->cin_pad % BK) != 0) return SF_EINVAL;
   if (d->kT <= 0 || d->kH <= 0 || d->kW <= 0 || d->sT <= 0 || d->sH <= 0 || d->sW <= 0) return SF_EINVAL;
@@ -375,6 +458,8 @@ extern "C" int sf_conv_fwd(const sf_conv_desc* d, const float* in, const float* 
   a.M = (int)M;
   a.ntaps = d->kT * d->kH * d->kW;
   a.nb_n = 0; a.nblocks = 0; a.vec_epi = 0;
+  a.ksplit = ws ? splitk_factor(d, M) : 1;
+  a.ws = ws;
   const bool vec4 = (d->Cin % 4 == 0) && (d->in_cs % 4 == 0) && (d->in_coff % 4 == 0) && sf_aligned16(in);
   a.vec_epi = (d->out_cmul == 1) && (d->Cout % 4 == 0) && (d->out_cs % 4 == 0) && (d->out_coff % 4 == 0) &&
               sf_aligned16(out) && (!scale || sf_aligned16(scale)) && (!bias || sf_aligned16(bias)) &&
@@ -391,7 +476,21 @@ extern "C" int sf_conv_fwd(const sf_conv_desc* d, const float* in, const float* 
   // Large tiles maximise operand reuse, but the M <= 12544 layers of res4/res5 then give < 1 workgroup per
   // CU (256 CUs): drop to 64x64 tiles when the big tiling cannot fill the chip twice over.
   const long big = (long)sf_cdiv(M, 128) * sf_cdiv(d->Cout, d->Cout <= 64 ? 64 : 128);
+  if (a.ksplit > 1) return d->Cout <= 64 ? launch<128, 64, 2, 2>(a, vec4, s) : launch<128, 128, 2, 2>(a, vec4, s);
   if (big < 512) return launch<64, 64, 2, 2>(a, vec4, s);
   if (d->Cout <= 64) return launch<128, 64, 2, 2>(a, vec4, s);
   return launch<128, 128, 2, 2>(a, vec4, s);
+}
+
+extern "C" int sf_conv_fwd(const sf_conv_desc* d, const float* in, const float* w_packed, const float* scale,
+                           const float* bias, const float* res, float* out, void* stream) {
+  return conv_fwd_impl(d, in, w_packed, scale, bias, res, out, nullptr, stream);
+}
+
+// As sf_conv_fwd with a caller-provided workspace of sf_conv_fwd_ws_floats(d) floats (0: none needed): enables the
+// split-K schedule for short-M / long-K layers.  ws == NULL behaves exactly like sf_conv_fwd.
+extern "C" int sf_conv_fwd_ws(const sf_conv_desc* d, const float* in, const float* w_packed, const float* scale,
+                              const float* bias, const float* res, float* out, float* ws, void* stream) {
+  if (ws && !sf_aligned16(ws)) return SF_EALIGN;
+  return conv_fwd_impl(d, in, w_packed, scale, bias, res, out, ws, stream);
 }

@@ -51,10 +51,11 @@ EXPORTS = [
     "sf_dwconv_dgrad", "sf_dwconv_wgrad_ws_floats", "sf_dwconv_wgrad", "sf_gather_add",
     "sf_bn_train_stats_split", "sf_affine_fwd_split", "sf_bn_bwd_reduce_split", "sf_bn_bwd_apply_split",
     "sf_clip_prologue", "sf_conv_wgrad_finish", "sf_bn_bwd_reduce_acc", "sf_row_softmax_fwd", "sf_row_softmax_bwd",
-    "sf_attn_bwd_fused_ws_floats", "sf_attn_bwd_fused", "sf_pack_conv_weight",
+    "sf_attn_bwd_fused_ws_floats", "sf_attn_bwd_fused", "sf_pack_conv_weight", "sf_conv_fwd_ws_floats",
+    "sf_conv_fwd_ws",
 ]
 _LONG_RET = ("sf_tmax_mean_ws_floats", "sf_channel_stats_ws_floats", "sf_bn_bwd_ws_floats",
-             "sf_dwconv_wgrad_ws_floats", "sf_attn_bwd_fused_ws_floats")
+             "sf_dwconv_wgrad_ws_floats", "sf_attn_bwd_fused_ws_floats", "sf_conv_fwd_ws_floats")
 
 
 def lib_path():
@@ -116,6 +117,9 @@ def lib():
         L.sf_attn_bwd_fused_ws_floats.restype = cl
         L.sf_attn_bwd_fused.argtypes = [vp, ci, vp, ci, vp, ci, vp, ci, vp, vp, vp, vp, ci, vp, ci, vp, ci, ci, ci, ci,
                                         vp, vp]
+        L.sf_conv_fwd_ws_floats.argtypes = [ctypes.POINTER(ConvDesc)]
+        L.sf_conv_fwd_ws_floats.restype = cl
+        L.sf_conv_fwd_ws.argtypes = [ctypes.POINTER(ConvDesc)] + [vp] * 8
         L.sf_pack_conv_weight.argtypes = [vp, ci, ci, ci, vp, ci, vp, ci, vp]
         L.sf_row_softmax_fwd.argtypes = [vp, ci, ci, cl, ci, cf, vp]
         L.sf_row_softmax_bwd.argtypes = [vp, ci, ci, vp, ci, ci, cl, ci, cf, vp]
@@ -270,6 +274,20 @@ def pack_conv_weight(w, cin_pad=None):
     return wp.contiguous()
 
 
+def _conv_launch(d, x_ptr, w_ptr, scale, bias, res_ptr, out_ptr, device, what):
+    """sf_conv_fwd, through the split-K schedule when the shape asks for it (workspace from the caching allocator)."""
+    n = lib().sf_conv_fwd_ws_floats(ctypes.byref(d)) if SPLIT_K else 0
+    if n > 0:
+        ws = torch.empty((n,), dtype=torch.float32, device=device)
+        _check(lib().sf_conv_fwd_ws(ctypes.byref(d), x_ptr, w_ptr, scale, bias, res_ptr, out_ptr, _ptr(ws), _stream()),
+               what)
+    else:
+        _check(lib().sf_conv_fwd(ctypes.byref(d), x_ptr, w_ptr, scale, bias, res_ptr, out_ptr, _stream()), what)
+
+
+SPLIT_K = os.environ.get("SF_SPLIT_K", "1") != "0"
+
+
 def pack_conv_weight_pair(w):
     """(wp [Cout][taps][cin_pad], wtp [Cin][taps][cout_pad]) of an nn.Conv3d weight on the GPU in one launch."""
     _require_gpu(w, "pack_conv_weight_pair")
@@ -315,8 +333,8 @@ def conv(x, wp, kernel, stride=(1, 1, 1), padding=(0, 0, 0), dilation=(1, 1, 1),
                  res.cs if res is not None else 0, res.coff if res is not None else 0, 0)
     if res is not None:
         assert res.rows == out.rows and res.C == cout
-    _check(lib().sf_conv_fwd(ctypes.byref(d), x.ptr(), _ptr(wp), _ptr(scale), _ptr(bias),
-                             res.ptr() if res is not None else None, out.ptr(), _stream()), "sf_conv_fwd")
+    _conv_launch(d, x.ptr(), _ptr(wp), _ptr(scale), _ptr(bias), res.ptr() if res is not None else None, out.ptr(),
+                 x.buf.device, "sf_conv_fwd")
     return out
 
 
@@ -488,8 +506,8 @@ def conv_dgrad(dz, wt_packed, x_like, kernel, stride=(1, 1, 1), padding=(0, 0, 0
                  kernel[0], kernel[1], kernel[2], stride[0], stride[1], stride[2], padding[0], padding[1],
                  padding[2], dilation[0], dilation[1], dilation[2], cout_pad, ACT_NONE,
                  out.cs if accumulate else 0, out.coff if accumulate else 0, 1)
-    _check(lib().sf_conv_fwd(ctypes.byref(d), dz.ptr(), _ptr(wt_packed), None, None,
-                             out.ptr() if accumulate else None, out.ptr(), _stream()), "sf_conv_fwd(transposed)")
+    _conv_launch(d, dz.ptr(), _ptr(wt_packed), None, None, out.ptr() if accumulate else None, out.ptr(),
+                 dz.buf.device, "sf_conv_fwd(transposed)")
     return out
 
 
@@ -533,8 +551,8 @@ def _conv_dgrad_strided(dz, wt_packed, out, kernel, stride, padding, accumulate)
                              out.coff, 1, len(tt), len(th), len(tw), 1, 1, 1, -ot[0], -oh[0], -ow[0], 1, 1, 1,
                              cout_pad, ACT_NONE, out.cs, out.coff, 0, stride[0], stride[1], stride[2], at, ah, aw,
                              out.T, out.H, out.W)
-                _check(lib().sf_conv_fwd(ctypes.byref(d), dz.ptr(), _ptr(wsub), None, None, out.ptr(), out.ptr(),
-                                         _stream()), "sf_conv_fwd(strided dgrad class)")
+                _conv_launch(d, dz.ptr(), _ptr(wsub), None, None, out.ptr(), out.ptr(), dz.buf.device,
+                             "sf_conv_fwd(strided dgrad class)")
     return out
 
 

@@ -74,6 +74,13 @@ typedef struct sf_conv_desc {
 } sf_conv_desc;
 int sf_conv_fwd(const sf_conv_desc* d, const float* in, const float* w_packed, const float* scale,
                 const float* bias, const float* res, float* out, void* stream);
+/* Split-K schedule for short-M / long-K layers (res4 / res5: M <= 12544 positions, K = 2304..6144): the K steps of a
+ * tile are shared by S workgroups that store raw partial tiles to ws [S][M][Cout]; a finish kernel sums them in split
+ * order (no float atomics) and applies the epilogue.  sf_conv_fwd_ws_floats(d) = workspace floats (0: the single-pass
+ * schedule is used); ws == NULL makes sf_conv_fwd_ws identical to sf_conv_fwd.                                   */
+long sf_conv_fwd_ws_floats(const sf_conv_desc* d);
+int sf_conv_fwd_ws(const sf_conv_desc* d, const float* in, const float* w_packed, const float* scale,
+                   const float* bias, const float* res, float* out, float* ws, void* stream);
 /* Packs an nn.Conv3d weight [Cout][Cin][kT*kH*kW] (device) into wp [Cout][taps][cin_pad] and — when wtp != NULL —
  * wtp [Cin][taps][cout_pad] (the data-gradient order), zero padded, in one launch.                           */
 int sf_pack_conv_weight(const float* w, int Cout, int Cin, int taps, float* wp, int cin_pad, float* wtp,

@@ -114,6 +114,47 @@ def test_conv(case):
     assert err < TOL, (name, err)
 
 
+@pytest.mark.parametrize("cin,cout,k,shp,res", [(512, 256, (3, 1, 1), (2, 4, 7, 7), True),
+                                                (256, 128, (1, 3, 3), (2, 4, 14, 14), False),
+                                                (1024, 256, (1, 1, 1), (2, 4, 14, 14), True)])
+def test_conv_split_k_schedule(cin, cout, k, shp, res):
+    """Short-M / long-K layers take the split-K schedule (partials in a workspace + finish kernel with the full
+    epilogue): same result as torch, and within fp32 re-association of the single-pass schedule."""
+    import ctypes
+    import sfhip
+    dev = _dev()
+    g = torch.Generator().manual_seed(cin + cout)
+    n, t, h, w = shp
+    x = torch.randn(n, cin, t, h, w, generator=g)
+    wt = torch.randn(cout, cin, *k, generator=g) / np.sqrt(cin * k[0] * k[1] * k[2])
+    scale = torch.rand(cout, generator=g) + 0.5
+    bias = torch.randn(cout, generator=g) * 0.1
+    pad = tuple(kk // 2 for kk in k)
+    ref = F.conv3d(x, wt, None, 1, pad) * scale.view(-1, 1, 1, 1) + bias.view(-1, 1, 1, 1)
+    r = torch.randn(ref.shape, generator=g) if res else None
+    if res:
+        ref = ref + r
+    ref = F.relu(ref)
+    xa = _ndhwc(x)
+    wp = sfhip.pack_conv_weight(wt.to(dev))
+    kw = dict(scale=scale.to(dev), bias=bias.to(dev), relu=True, res=_ndhwc(r) if res else None)
+    y_split = sfhip.conv(xa, wp, k, (1, 1, 1), pad, **kw)
+    d = sfhip.ConvDesc(n, t, h, w, cin, cin, 0, t, h, w, cout, cout, 0, 1, k[0], k[1], k[2], 1, 1, 1, pad[0], pad[1], pad[2],
+                       1, 1, 1, wp.shape[2], 1, 0, 0, 0)
+    assert sfhip.lib().sf_conv_fwd_ws_floats(ctypes.byref(d)) > 0, "this shape is meant to exercise split-K"
+    saved = sfhip.SPLIT_K
+    sfhip.SPLIT_K = False
+    try:
+        y_single = sfhip.conv(xa, wp, k, (1, 1, 1), pad, **kw)
+    finally:
+        sfhip.SPLIT_K = saved
+    torch.cuda.synchronize()
+    e = _rel(_back(y_split), ref)
+    _report("conv split-K %d->%d k%s M=%d" % (cin, cout, k, n * t * h * w), e)
+    assert e < TOL
+    assert _rel(_back(y_split), _back(y_single)) < 1e-5
+
+
 def test_conv_stem_trick():
     """7x7 stem on a border-padded NDHWC4 input expressed as kW=1 / 'Cin'=28 contiguous floats."""
     import sfhip

@@ -44,4 +44,5 @@ def test_sync_batchnorm_two_ranks_match_reference():
             pass
         assert rep["logits"] < 1e-3 and rep["loss"] < 1e-3, rep
         assert len(rep["grads"]) >= 6 and max(rep["grads"].values()) < 8e-2, rep["grads"]
+        assert all(v < 0.3 for v in rep["scalar_grads"].values()), rep["scalar_grads"]
         assert len(rep["buffers"]) >= 8 and max(rep["buffers"].values()) < 1e-4, rep["buffers"]
