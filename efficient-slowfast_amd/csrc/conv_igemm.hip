@@ -477,6 +477,11 @@ static int conv_fwd_impl(const sf_conv_desc* d, const float* in, const float* w_
   // CU (256 CUs): drop to 64x64 tiles when the big tiling cannot fill the chip twice over.
   const long big = (long)sf_cdiv(M, 128) * sf_cdiv(d->Cout, d->Cout <= 64 ? 64 : 128);
   if (a.ksplit > 1) return d->Cout <= 64 ? launch<128, 64, 2, 2>(a, vec4, s) : launch<128, 128, 2, 2>(a, vec4, s);
+  // Short reductions into wide outputs (the bottleneck "c" convs, K = Cin <= 256 -> Cout >= 128, with the residual in
+  // the epilogue) are prologue / epilogue bound: 64x64 tiles (4x the workgroups) measured 81 vs 67 TFLOP/s on
+  // 256 -> 1024 at M = 12544 and 74 vs 66 on 128 -> 512 at M = 50176 (tools/microbench/tile_sweep.py).
+  const int nk = a.ntaps * (d->cin_pad / BK);
+  if (nk <= 16 && d->Cout >= 128) return launch<64, 64, 2, 2>(a, vec4, s);
   if (big < 512) return launch<64, 64, 2, 2>(a, vec4, s);
   if (d->Cout <= 64) return launch<128, 64, 2, 2>(a, vec4, s);
   return launch<128, 128, 2, 2>(a, vec4, s);
