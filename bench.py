@@ -115,53 +115,6 @@ def cpu_baseline(workload, cfg, model, train):
             "sample": "oracle (torch CPU restatement of the reference), same model / clip shape: " + sample}
 
 
-def aten_gpu_baseline(cfg, model, batch, device, train, steps):
-    """The oracle's functional graph run ON THE GPU through stock ATen (MIOpen / rocBLAS kernels, dense N x N
-    attention) — i.e. what the reference's nn.Modules execute on ROCm.  Informational (--aten-gpu-baseline):
-    it is a measured stand-in for 'the reference on MI355X', never part of `value`."""
-    from oracle import slowfast_oracle as oracle
-    hp = oracle.default_hparams(
-        alpha=cfg.SLOWFAST.ALPHA, beta_inv=cfg.SLOWFAST.BETA_INV, depth=cfg.RESNET.DEPTH,
-        width_per_group=cfg.RESNET.WIDTH_PER_GROUP, num_groups=cfg.RESNET.NUM_GROUPS,
-        fusion_kernel=cfg.SLOWFAST.FUSION_KERNEL_SZ,
-        spatial_strides=[s[0] for s in cfg.RESNET.SPATIAL_STRIDES],
-        spatial_dilations=[s[0] for s in cfg.RESNET.SPATIAL_DILATIONS],
-        num_block_temp_kernel=[list(x) for x in cfg.RESNET.NUM_BLOCK_TEMP_KERNEL],
-        num_frames=cfg.DATA.NUM_FRAMES, crop_size=cfg.DATA.CROP_SIZE, num_classes=cfg.MODEL.NUM_CLASSES,
-        short_cycle=bool(cfg.MULTIGRID.SHORT_CYCLE), head_act=cfg.MODEL.HEAD_ACT,
-        width_multi=cfg.SLOWFAST.WIDTH_MULTI)
-    name = cfg.MODEL.MODEL_NAME
-    xs = synthetic_clips(cfg, batch, device, 1)
-    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
-    if train:
-        sd = {k: (v.requires_grad_(True) if v.dtype == torch.float32 and "running" not in k else v)
-              for k, v in sd.items()}
-        labels = torch.zeros(batch, dtype=torch.long, device=device)
-
-    def step():
-        if train:
-            acts = oracle.FORWARDS[name](sd, [x.clone() for x in xs], hp, training=True)
-            torch.nn.functional.cross_entropy(acts["out"], labels).backward()
-            for v in sd.values():
-                v.grad = None
-        else:
-            with torch.no_grad():
-                oracle.FORWARDS[name](sd, [x.clone() for x in xs], hp, training=False)
-
-    step()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        step()
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / steps
-    return {"value": round(batch / dt, 3), "unit": "clips/s", "ms_per_step": round(dt * 1e3, 2), "batch": batch,
-            "what": "oracle graph on stock ATen ROCm kernels (MIOpen conv, rocBLAS bmm + softmax: dense N x N "
-                    "attention), %s, same GPU" % ("train-mode forward + CE + autograd backward" if train
-                                                  else "eval forward"),
-            "peak_mem_GB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)}
-
-
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -176,8 +129,6 @@ def main():
     ap.add_argument("--no-extras", action="store_true",
                     help="profiling aid: skip the secondary eval-forward measurement and the HIP-event roofline trace so "
                          "that a rocprofv3 --stats run contains exactly warmup+steps identical steps")
-    ap.add_argument("--aten-gpu-baseline", action="store_true",
-                    help="also time the oracle graph on stock ATen/MIOpen kernels on this GPU (informational)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -379,10 +330,6 @@ def main():
             res["roofline"] = roofline
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(args.workload, cfg, model, train)
-        if world == 1 and args.aten_gpu_baseline:
-            torch.cuda.empty_cache()
-            torch.cuda.reset_peak_memory_stats()
-            res["aten_gpu_baseline"] = aten_gpu_baseline(cfg, model, batch, device, train, min(args.steps, 3))
         print(json.dumps(res))
     if dist.is_initialized():
         dist.destroy_process_group()
