@@ -1,0 +1,103 @@
+"""Host-side drop-in surface on the CPU (no kernels run): registry / factory behaviour (models/build.py:9-44), every
+model's state_dict keys, shapes and top-level child order against the lists recorded from the reference, config
+handling, and that a CPU forward refuses to run (no fallback)."""
+import contextlib
+import io
+import json
+import os
+
+import pytest
+import torch
+
+from _util import MODEL_CASES, load_case
+
+
+def _build_cpu(meta):
+    from slowfast.config.defaults import get_cfg
+    from slowfast.models import build_model
+    cfg = get_cfg()
+    cfg.merge_from_other_cfg(meta["cfg_dump"])
+    cfg.NUM_GPUS = 0
+    with contextlib.redirect_stdout(io.StringIO()) as out:
+        model = build_model(cfg)
+    return cfg, model, out.getvalue()
+
+
+@pytest.mark.parametrize("name", MODEL_CASES)
+def test_state_dict_and_children_equal_the_references(name):
+    z, meta = load_case(name)
+    cfg, model, printed = _build_cpu(meta)
+    sd = model.state_dict()
+    assert list(sd.keys()) == [str(k) for k in z["sd_keys"]]
+    assert [list(v.shape) for v in sd.values()] == [json.loads(str(s)) for s in z["sd_shapes"]]
+    assert [n for n, _ in model.named_children()] == [str(c) for c in z["children"]]
+    assert all(v.dtype in (torch.float32, torch.int64) for v in sd.values())
+    if "attention_spatial_s2f.gamma" in " ".join(sd.keys()):
+        assert "fusion layer dim input:" in printed  # FuseFastAndSlow prints at construction, like the reference
+
+
+def test_registry_and_factory_contract():
+    from slowfast.config.defaults import get_cfg
+    from slowfast.models import build_model
+    from slowfast.models.build import MODEL_REGISTRY, Registry
+    for name in ("SlowFast", "SlowFastDualAttention", "SlowFastShuffleNetV2", "SlowFastGhostNet", "SlowFastShuffleNet",
+                 "SlowFastMoibleNetV2", "ResNet"):
+        assert name in MODEL_REGISTRY and MODEL_REGISTRY.get(name).__name__ == name
+    with pytest.raises(KeyError):
+        MODEL_REGISTRY.get("SlowFastMobileNetV2")  # the reference's spelling is the registered one
+    reg = Registry("T")
+
+    @reg.register()
+    class A(object):
+        pass
+
+    with pytest.raises(AssertionError):
+        reg.register(A)
+    cfg = get_cfg()
+    cfg.NUM_GPUS = torch.cuda.device_count() + 1
+    with pytest.raises(AssertionError):
+        build_model(cfg)
+
+
+def test_config_yaml_and_overrides(tmp_path):
+    from slowfast.config.defaults import get_cfg
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for y in sorted(os.listdir(os.path.join(root, "configs"))):
+        cfg = get_cfg()
+        cfg.merge_from_file(os.path.join(root, "configs", y))
+        assert cfg.MODEL.MODEL_NAME and cfg.DATA.NUM_FRAMES % cfg.SLOWFAST.ALPHA == 0
+    cfg = get_cfg()
+    cfg.merge_from_list(["SLOWFAST.ALPHA", 8, "SOLVER.WEIGHT_DECAY", "1e-4", "BN.NORM_TYPE", "sub_batchnorm"])
+    assert cfg.SLOWFAST.ALPHA == 8 and abs(cfg.SOLVER.WEIGHT_DECAY - 1e-4) < 1e-12
+    with pytest.raises(KeyError):
+        cfg.merge_from_list(["SLOWFAST.NOT_A_KEY", 1])
+    bad = tmp_path / "bad.yaml"
+    bad.write_text("MODEL:\\n  NOT_A_KEY: 3\\n")
+    with pytest.raises(KeyError):
+        get_cfg().merge_from_file(str(bad))
+
+
+def test_forward_on_cpu_refuses_to_run():
+    """NUM_GPUS 0 builds the module tree (checkpoint conversion, state_dict work) but there is no CPU arithmetic."""
+    import sfhip
+    z, meta = load_case("shufflenetv2_cfg1")
+    cfg, model, _ = _build_cpu(meta)
+    model.eval()
+    x = [torch.zeros(1, 3, 4, 32, 32), torch.zeros(1, 3, 32, 32, 32)]
+    with pytest.raises(sfhip.SfhipError):
+        model(x)
+
+
+def test_init_weights_semantics():
+    """init_weights (utils/weight_init_helper.py:10-43): final BN of every bottleneck zeroed iff ZERO_INIT_FINAL_BN,
+    SpatialAttention.gamma = 0, conv biases 0, Linear ~ N(0, FC_INIT_STD)."""
+    z, meta = load_case("dual_r50_s64")
+    cfg, model, _ = _build_cpu(meta)
+    sd = model.state_dict()
+    zero_final = bool(cfg.RESNET.ZERO_INIT_FINAL_BN)
+    cbn = [k for k in sd if k.endswith("branch2.c_bn.weight")]
+    assert len(cbn) == 32 and all(float(sd[k].abs().max()) == (0.0 if zero_final else 1.0) for k in cbn)
+    assert all(float(sd[k].abs().max()) == 1.0 for k in sd if k.endswith("a_bn.weight"))
+    assert all(float(sd[k]) == 0.0 for k in sd if k.endswith(".gamma"))
+    assert float(sd["head.projection.bias"].abs().max()) == 0.0
+    assert abs(float(sd["head.projection.weight"].std()) - cfg.MODEL.FC_INIT_STD) < 0.2 * cfg.MODEL.FC_INIT_STD
