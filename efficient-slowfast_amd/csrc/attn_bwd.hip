@@ -13,6 +13,7 @@
 // every transposed product takes the recomputed P / dS registers directly as its B operand and reads
 // its A operand from the LDS tile with conflict-free ds_read_b32; row-fragment operands are ds_read_b128.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -25,6 +26,8 @@ struct BwdArgs {
   float* dq; float* dk; float* dv;                   // outputs [B, N, *] views
   int q_cs, k_cs, v_cs, dz_cs, dq_cs, dk_cs, dv_cs;
   int B, C, N, nt;
+  int zs;                                            // fused kernels: the swept (query) range is cut into zs parts
+  float* dkp; float* dvp;                            // zs > 1: dK / dV partials [B][zs][N][CP], summed afterwards
 };
 
 constexpr float POS_BIG = 3.0e38f;
@@ -361,8 +364,9 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_fused_kernel(const BwdArgs p
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, lh = lane >> 5;
-  const int b = blockIdx.x / p.nt;
-  const int kb = blockIdx.x - b * p.nt;
+  const int bz = blockIdx.x / p.nt;  // workgroup -> (clip b, query part z, key block kb)
+  const int kb = blockIdx.x - bz * p.nt;
+  const int b = bz / p.zs, z = bz - b * p.zs;
   const int j0 = kb * (32 * NW) + wave * 32;
   const int N = p.N, C = p.C;
   const long brow = (long)b * N;
@@ -449,12 +453,14 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_fused_kernel(const BwdArgs p
   };
 
   float* const plane = ws + ((long)b * p.nt + kb) * N * CP;  // this key block's dQ plane [N][CP]
-  const int ntiles = (N + QT - 1) / QT;
-  load_tile(0);
+  const int tz = ((N + QT - 1) / QT + p.zs - 1) / p.zs;  // query tiles per part
+  const int t0 = z * tz;
+  const int ntiles = min((N + QT - 1) / QT, t0 + tz);
+  load_tile(t0 * QT);
   store_tile(0);
   __syncthreads();
-  for (int t = 0; t < ntiles; ++t) {
-    const int buf = t & 1;
+  for (int t = t0; t < ntiles; ++t) {
+    const int buf = (t - t0) & 1;
     const bool more = (t + 1) < ntiles;
     if (more) load_tile((t + 1) * QT);
     const float* Qs = smem + buf * TILE;
@@ -539,6 +545,19 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_fused_kernel(const BwdArgs p
     __syncthreads();  // slots are reused as transposition tiles by the next iteration
   }
   if (!jok) return;
+  if (p.zs > 1) {  // this query part's share of dK / dV; attn_dq_reduce_kernel adds the parts in order
+    float* okp = p.dkp + ((long)bz * N + jrow) * CP;
+    float* ovp = p.dvp + ((long)bz * N + jrow) * CP;
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+      for (int r = 0; r < 16; r += 4) {
+        const int c = ct * 32 + 8 * (r >> 2) + 4 * lh;
+        *reinterpret_cast<f32x4*>(okp + c) = (f32x4){dk[ct][r], dk[ct][r + 1], dk[ct][r + 2], dk[ct][r + 3]};
+        *reinterpret_cast<f32x4*>(ovp + c) = (f32x4){dv[ct][r], dv[ct][r + 1], dv[ct][r + 2], dv[ct][r + 3]};
+      }
+    return;
+  }
   float* okp = p.dk + (brow + jrow) * p.dk_cs;
   float* ovp = p.dv + (brow + jrow) * p.dv_cs;
 #pragma unroll
@@ -581,13 +600,46 @@ int sf_attn_dq_reduce(const float* ws, float* dq, int dq_cs, int B, int N, int C
   return SF_OK;
 }
 
+int sf_sweep_parts(long units, int tiles) {
+  static const int forced = [] {
+    const char* e = getenv("SF_SWEEP_PARTS");
+    return e ? atoi(e) : 0;
+  }();
+  static const int cus = [] {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+      n = 256;
+    return n;
+  }();
+  if (forced >= 1) return forced > SF_SWEEP_PARTS_MAX ? SF_SWEEP_PARTS_MAX : forced;
+  int best = 1;
+  double best_fill = 0.0;
+  for (int z = 1; z <= SF_SWEEP_PARTS_MAX && (z == 1 || tiles / z >= 8); ++z) {
+    const double per_cu = (double)units * z / cus;
+    const double fill = per_cu / (double)((units * z + cus - 1) / cus) - 0.004 * z;  // each part re-loads its K / V
+    if (fill > best_fill) { best_fill = fill; best = z; }
+  }
+  return best;
+}
+
 namespace {
 
 template <int CP, int NW>
 int launch_fused(BwdArgs a, float* ws, hipStream_t s) {
   a.nt = sf_cdiv(a.N, 32 * NW);  // key blocks (= dQ planes) per clip
-  hipLaunchKernelGGL((attn_bwd_fused_kernel<CP, NW>), dim3(a.B * a.nt), dim3(64 * NW), 0, s, a, ws);
+  const int qt = (CP >= 64) ? 32 : 64;
+  a.zs = sf_sweep_parts((long)a.B * a.nt, sf_cdiv(a.N, qt));
+  const long planes = (long)a.B * a.nt * a.N * CP, part = (long)a.B * a.zs * a.N * CP;
+  a.dkp = ws + planes;
+  a.dvp = a.dkp + part;
+  hipLaunchKernelGGL((attn_bwd_fused_kernel<CP, NW>), dim3(a.B * a.zs * a.nt), dim3(64 * NW), 0, s, a, ws);
   SF_CHECK_LAUNCH();
+  if (a.zs > 1) {
+    int rc = sf_attn_dq_reduce(a.dkp, a.dk, a.dk_cs, a.B, a.N, a.C, CP, a.zs, s);
+    if (rc == SF_OK) rc = sf_attn_dq_reduce(a.dvp, a.dv, a.dv_cs, a.B, a.N, a.C, CP, a.zs, s);
+    if (rc != SF_OK) return rc;
+  }
   return sf_attn_dq_reduce(ws, a.dq, a.dq_cs, a.B, a.N, a.C, CP, a.nt, s);
 }
 
@@ -638,11 +690,12 @@ int sf_attn_small_fused_dispatch(const float* q, int q_cs, const float* k, int k
                                  float* dq, int dq_cs, float* dk, int dk_cs, float* dv, int dv_cs, int B, int N, int C,
                                  float* ws, hipStream_t stream);  // attn_small_bwd.hip
 
+// dQ planes (one per key block) + room for the dK / dV partials of up to SF_SWEEP_PARTS_MAX query parts
 extern "C" long sf_attn_bwd_fused_ws_floats(int B, int N, int C) {
   if (B <= 0 || N <= 0 || C <= 0 || C > 64) return 0;
-  if (C <= 16) return (long)B * sf_cdiv(N, 64) * N * (C <= 4 ? 4 : (C <= 8 ? 8 : 16));  // 64-key blocks
-  if (C <= 32) return (long)B * sf_cdiv(N, FUSED_KEYS_32) * N * 32;
-  return (long)B * sf_cdiv(N, 128) * N * 64;
+  const int cp = C <= 4 ? 4 : (C <= 8 ? 8 : (C <= 16 ? 16 : (C <= 32 ? 32 : 64)));
+  const int keys = C <= 16 ? 64 : (C <= 32 ? FUSED_KEYS_32 : 128);
+  return (long)B * (sf_cdiv(N, keys) + 2 * SF_SWEEP_PARTS_MAX) * N * cp;
 }
 
 extern "C" int sf_attn_bwd_fused(const float* q, int q_cs, const float* k, int k_cs, const float* v, int v_cs,

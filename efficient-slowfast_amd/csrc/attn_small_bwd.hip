@@ -16,6 +16,8 @@ struct BwdArgs {
   float* dq; float* dk; float* dv;
   int q_cs, k_cs, v_cs, dz_cs, dq_cs, dk_cs, dv_cs;
   int B, C, N, nt;
+  int zs;                  // fused kernel: the swept (query) range is cut into zs parts
+  float* dkp; float* dvp;  // zs > 1: dK / dV partials [B][zs][N][CP], summed afterwards
 };
 
 constexpr float POS_BIG = 3.0e38f;
@@ -306,8 +308,9 @@ __global__ __launch_bounds__(256) void attn_small_fused_kernel(const BwdArgs p, 
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, lg = lane >> 4;
-  const int b = blockIdx.x / p.nt;
-  const int kb = blockIdx.x - b * p.nt;
+  const int bz = blockIdx.x / p.nt;  // workgroup -> (clip b, query part z, key block kb)
+  const int kb = blockIdx.x - bz * p.nt;
+  const int b = bz / p.zs, z = bz - b * p.zs;
   const int j0 = kb * 64 + wave * 16;
   const int N = p.N, C = p.C;
   const long brow = (long)b * N;
@@ -383,12 +386,14 @@ __global__ __launch_bounds__(256) void attn_small_fused_kernel(const BwdArgs p, 
   };
 
   float* const plane = ws + ((long)b * p.nt + kb) * N * CP;
-  const int nst = (N + ST - 1) / ST;
-  load_stage(0);
+  const int tz = ((N + ST - 1) / ST + p.zs - 1) / p.zs;  // stages per query part
+  const int t0 = z * tz;
+  const int nst = min((N + ST - 1) / ST, t0 + tz);
+  load_stage(t0 * ST);
   store_stage(0);
   __syncthreads();
-  for (int t = 0; t < nst; ++t) {
-    const int buf = t & 1;
+  for (int t = t0; t < nst; ++t) {
+    const int buf = (t - t0) & 1;
     const bool more = (t + 1) < nst;
     if (more) load_stage((t + 1) * ST);
     const float* Qt = smem + buf * STAGE;
@@ -463,6 +468,13 @@ __global__ __launch_bounds__(256) void attn_small_fused_kernel(const BwdArgs p, 
     __syncthreads();
   }
   const int c0 = 4 * lg;
+  if (p.zs > 1) {  // this query part's share; attn_dq_reduce_kernel adds the parts in order
+    if (jok && c0 < CP) {
+      *reinterpret_cast<f32x4*>(p.dkp + ((long)bz * N + jrow) * CP + c0) = dk0 + dk1;
+      *reinterpret_cast<f32x4*>(p.dvp + ((long)bz * N + jrow) * CP + c0) = dv0 + dv1;
+    }
+    return;
+  }
   if (!jok || c0 >= C) return;
   float* okp = p.dk + (brow + jrow) * p.dk_cs + c0;
   float* ovp = p.dv + (brow + jrow) * p.dv_cs + c0;
@@ -512,8 +524,11 @@ int sf_attn_small_fused_dispatch(const float* q, int q_cs, const float* k, int k
   a.dq = dq; a.dk = dk; a.dv = dv;
   a.q_cs = q_cs; a.k_cs = k_cs; a.v_cs = v_cs; a.dz_cs = dz_cs; a.dq_cs = dq_cs; a.dk_cs = dk_cs; a.dv_cs = dv_cs;
   a.B = B; a.C = C; a.N = N; a.nt = sf_cdiv(N, 64);
-  const int grid = B * a.nt;
-  int cp;
+  a.zs = sf_sweep_parts((long)B * a.nt, sf_cdiv(N, ST));
+  const int grid = B * a.zs * a.nt;
+  int cp = C <= 4 ? 4 : (C <= 8 ? 8 : 16);
+  a.dkp = ws + (long)B * a.nt * N * cp;
+  a.dvp = a.dkp + (long)B * a.zs * N * cp;
   if (C <= 4) {
     cp = 4;
     hipLaunchKernelGGL((attn_small_fused_kernel<4>), dim3(grid), dim3(256), 0, stream, a, ws);
@@ -525,5 +540,10 @@ int sf_attn_small_fused_dispatch(const float* q, int q_cs, const float* k, int k
     hipLaunchKernelGGL((attn_small_fused_kernel<16>), dim3(grid), dim3(256), 0, stream, a, ws);
   }
   SF_CHECK_LAUNCH();
+  if (a.zs > 1) {
+    int rc = sf_attn_dq_reduce(a.dkp, dk, dk_cs, B, N, C, cp, a.zs, stream);
+    if (rc == SF_OK) rc = sf_attn_dq_reduce(a.dvp, dv, dv_cs, B, N, C, cp, a.zs, stream);
+    if (rc != SF_OK) return rc;
+  }
   return sf_attn_dq_reduce(ws, dq, dq_cs, B, N, C, cp, a.nt, stream);
 }

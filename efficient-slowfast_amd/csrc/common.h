@@ -30,3 +30,11 @@ __device__ __forceinline__ float sf_act(float v, int act) {
 
 static inline bool sf_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 static inline int sf_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// A sweep kernel (one workgroup per block of owned rows, looping over all swept rows) launched with `units`
+// equal workgroups finishes when the busiest CU does: ceil(units / CUs) workgroup-times for units / CUs of work
+// (1568 workgroups on 256 CUs: 6.125 -> 7, 12.5 % of the chip idle in the tail).  Cutting the swept range into z
+// parts makes z-times more, z-times shorter units; pick the z <= SF_SWEEP_PARTS_MAX with the best fill, each part
+// keeping at least 8 tiles.  SF_SWEEP_PARTS=<z> overrides (1 = off).
+constexpr int SF_SWEEP_PARTS_MAX = 8;
+int sf_sweep_parts(long units, int tiles);  // attn_bwd.hip

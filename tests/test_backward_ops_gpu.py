@@ -294,6 +294,23 @@ def test_attention_backward(c, thw):
     assert max(errs) < TOL, errs
 
 
+@pytest.mark.parametrize("parts", [3, 8])
+def test_attention_backward_query_parts(parts):
+    """The fused backward cuts the query sweep into parts to fill the chip's tail (sf_sweep_parts); the shapes above
+    are too small to be cut, so force the cut (SF_SWEEP_PARTS is read once per process -> child process).  8 parts of
+    a 5..7-tile sweep also leave parts EMPTY, which must contribute zero dK / dV."""
+    import subprocess
+    import sys
+    if os.environ.get("SF_SWEEP_PARTS"):
+        pytest.skip("already inside the forced-parts child")
+    env = dict(os.environ, SF_SWEEP_PARTS=str(parts))
+    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", __file__, "-k",
+                        "test_attention_backward and not query_parts"], env=env, capture_output=True, text=True,
+                       timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert "passed" in r.stdout
+
+
 @pytest.mark.parametrize("c,k,s", [(32, (3, 3, 3), (1, 1, 1)), (12, (1, 5, 5), (1, 2, 2)), (27, (3, 3, 3), (1, 2, 2))])
 def test_dwconv_backward(c, k, s):
     import sfhip
