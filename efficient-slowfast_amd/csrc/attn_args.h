@@ -1,0 +1,28 @@
+// attn_args.h — argument block shared by the forward attention kernels (attn_flash.hip, attn_small.hip).
+#pragma once
+#include "common.h"
+
+struct SfAttnArgs {
+  const float* q; const float* k; const float* v; const float* x;
+  const float* gamma; const float* scale; const float* bias;
+  float* out;
+  float* o_save;    // optional [B, N, C] dense: O = P v (pre-gamma), saved for the backward pass
+  float* lse_save;  // optional [B, N]: log2-domain log-sum-exp of each query row
+  int q_cs, k_cs, v_cs, x_cs, out_cs, out_coff;
+  int B, T, H, W, C, N, alpha, act, nqt;
+  // Key-range parts (sf_sweep_parts): with zs > 1 workgroup (b, z, query tile) sweeps only part z of the keys and
+  // leaves its UNNORMALISED O^T, running max and denominator in the workspace; attn_fwd_merge_kernel combines the
+  // parts (the usual log-sum-exp merge) and applies the epilogue.
+  int zs;
+  float* part_o;   // [B][zs][N][CP]
+  float* part_ml;  // [B][zs][N][2]   (m, l)
+};
+
+// Combine the zs key parts of every query row and run the attention epilogue (attn_flash.hip).
+int sf_attn_fwd_merge(const SfAttnArgs& a, int cp, hipStream_t s);
+
+// Place the part buffers in a workspace of sf_attn_fwd_ws_floats(B, N, C) floats.
+static inline void sf_attn_place_parts(SfAttnArgs& a, int cp, float* ws) {
+  a.part_o = ws;
+  a.part_ml = ws + (long)a.B * a.zs * a.N * cp;
+}

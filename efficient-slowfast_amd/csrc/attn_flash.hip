@@ -23,19 +23,11 @@
 //   * K/V tiles: global -> registers (issued before the tile's MFMAs) -> LDS (after them), double
 //     buffered, one barrier per tile.
 // fp32 throughout (the reference never leaves fp32; gfx950 has no reduced-precision f32 MFMA path).
-#include "common.h"
+#include "attn_args.h"
 
 namespace {
 
-struct AttnArgs {
-  const float* q; const float* k; const float* v; const float* x;
-  const float* gamma; const float* scale; const float* bias;
-  float* out;
-  float* o_save;    // optional [B, N, C] dense: O = P v (pre-gamma), saved for the backward pass
-  float* lse_save;  // optional [B, N]: log2-domain log-sum-exp of each query row
-  int q_cs, k_cs, v_cs, x_cs, out_cs, out_coff;
-  int B, T, H, W, C, N, alpha, act, nqt;
-};
+using AttnArgs = SfAttnArgs;
 
 constexpr float NEG_BIG = -3.0e38f;
 constexpr float LOG2E = 1.4426950408889634f;
@@ -60,8 +52,9 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
   const int wave = tid >> 6;
   const int li = lane & 31;
   const int lh = lane >> 5;
-  const int b = blockIdx.x / p.nqt;
-  const int q0 = (blockIdx.x - b * p.nqt) * 128 + wave * 32;
+  const int bz = blockIdx.x / p.nqt;  // workgroup -> (clip b, key part z, query tile)
+  const int b = bz / p.zs, z = bz - b * p.zs;
+  const int q0 = (blockIdx.x - bz * p.nqt) * 128 + wave * 32;
   const int N = p.N, C = p.C;
   const long brow = (long)b * N;
 
@@ -137,12 +130,14 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
     }
   };
 
-  const int ntiles = (N + KT - 1) / KT;
-  load_tile(0);
+  const int tz = ((N + KT - 1) / KT + p.zs - 1) / p.zs;  // key tiles per part
+  const int t0 = z * tz;
+  const int ntiles = min((N + KT - 1) / KT, t0 + tz);
+  load_tile(t0 * KT);
   store_tile(0);
   __syncthreads();
-  for (int t = 0; t < ntiles; ++t) {
-    const int buf = t & 1;
+  for (int t = t0; t < ntiles; ++t) {
+    const int buf = (t - t0) & 1;
     const bool more = (t + 1) < ntiles;
     if (more) load_tile((t + 1) * KT);
 #pragma unroll
@@ -208,6 +203,21 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
   const int qrow = q0 + li;
   if (qrow >= N) return;
+  if (p.zs > 1) {  // this key part's (O^T, m, l): merged and finished by attn_fwd_merge_kernel
+    const long prow = (long)bz * N + qrow;
+    if (lh == 0) *reinterpret_cast<float2*>(p.part_ml + prow * 2) = make_float2(m_run, l_tot);
+    float* po = p.part_o + prow * CP;
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int c0 = ct * 32 + 8 * g + 4 * lh;
+        if (c0 < CP)
+          *reinterpret_cast<f32x4*>(po + c0) =
+              (f32x4){o[ct][4 * g], o[ct][4 * g + 1], o[ct][4 * g + 2], o[ct][4 * g + 3]};
+      }
+    return;
+  }
   const float inv_l = 1.0f / l_tot;
   const float gamma = p.gamma ? p.gamma[0] : 1.0f;
   const int HW = p.H * p.W;
@@ -247,32 +257,91 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
   }
 }
 
+// One thread per (query row, 4 channels): O = sum_z o_z 2^(m_z - m) / sum_z l_z 2^(m_z - m), m = max_z m_z, then the
+// same epilogue as above.  An empty part carries (m, l, o) = (-BIG, 0, 0) and drops out with weight 0.
+__global__ __launch_bounds__(256) void attn_fwd_merge_kernel(const AttnArgs p, int cp) {
+  const int f4 = cp >> 2;
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  const long total = (long)p.B * p.N * f4;
+  if (idx >= total) return;
+  const int c0 = (int)(idx % f4) * 4;
+  const long row = idx / f4;  // b*N + i
+  const int N = p.N, C = p.C, zs = p.zs;
+  const int b = (int)(row / N), qrow = (int)(row - (long)b * N);
+  if (c0 >= C) return;
+  const float* ml = p.part_ml + ((long)b * zs * N + qrow) * 2;
+  float m = NEG_BIG;
+  for (int z = 0; z < zs; ++z) m = fmaxf(m, ml[(long)z * N * 2]);
+  float l_tot = 0.f;
+  f32x4 o = {0.f, 0.f, 0.f, 0.f};
+  const float* po = p.part_o + ((long)b * zs * N + qrow) * cp + c0;
+  for (int z = 0; z < zs; ++z) {
+    const float w = __builtin_amdgcn_exp2f(ml[(long)z * N * 2] - m);
+    l_tot += ml[(long)z * N * 2 + 1] * w;
+    o += *reinterpret_cast<const f32x4*>(po + (long)z * N * cp) * w;
+  }
+  const float inv_l = 1.0f / l_tot;
+  const float gamma = p.gamma ? p.gamma[0] : 1.0f;
+  const int HW = p.H * p.W;
+  const int tq = qrow / HW;
+  const int hw = qrow - tq * HW;
+  const float* xp = p.x + row * p.x_cs;
+  const long orow0 = ((long)b * p.T * p.alpha + (long)tq * p.alpha) * HW + hw;
+  if (p.lse_save && c0 == 0) p.lse_save[row] = m + __log2f(l_tot);
+  float y[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int c = c0 + e;
+    const bool okc = c < C;
+    if (p.o_save && okc) p.o_save[row * C + c] = o[e] * inv_l;
+    float v = gamma * (o[e] * inv_l) + (okc ? xp[c] : 0.f);
+    if (p.scale && okc) v = v * p.scale[c] + p.bias[c];
+    if (p.act == SF_ACT_RELU) v = fmaxf(v, 0.f);
+    y[e] = v;
+  }
+  for (int r = 0; r < p.alpha; ++r) {
+    float* op = p.out + (orow0 + (long)r * HW) * p.out_cs + p.out_coff + c0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if ((c0 + e) < C) op[e] = y[e];
+  }
+}
+
 template <int CP>
 int launch(const AttnArgs& a, bool vec4, hipStream_t s) {
-  const int grid = a.B * a.nqt;
+  const int grid = a.B * a.zs * a.nqt;
   if (vec4)
     hipLaunchKernelGGL((attn_fwd_kernel<CP, 4>), dim3(grid), dim3(256), 0, s, a);
   else
     hipLaunchKernelGGL((attn_fwd_kernel<CP, 1>), dim3(grid), dim3(256), 0, s, a);
   SF_CHECK_LAUNCH();
-  return SF_OK;
+  return a.zs > 1 ? sf_attn_fwd_merge(a, CP, s) : SF_OK;
 }
 
 }  // namespace
 
+int sf_attn_fwd_merge(const SfAttnArgs& a, int cp, hipStream_t s) {
+  const long total = (long)a.B * a.N * (cp / 4);
+  hipLaunchKernelGGL(attn_fwd_merge_kernel, dim3(sf_cdiv(total, 256)), dim3(256), 0, s, a, cp);
+  SF_CHECK_LAUNCH();
+  return SF_OK;
+}
+
 int sf_attn_small_dispatch(const float* q, int q_cs, const float* k, int k_cs, const float* v, int v_cs,
                            const float* x, int x_cs, const float* gamma, const float* scale, const float* bias,
                            int act, float* out, int out_cs, int out_coff, int B, int T, int H, int W, int C,
-                           int alpha, float* o_save, float* lse_save, bool vec4, hipStream_t stream);  // attn_small.hip
+                           int alpha, float* o_save, float* lse_save, bool vec4, float* ws,
+                           hipStream_t stream);  // attn_small.hip
 
-extern "C" int sf_attn_fwd(const float* q, int q_cs, const float* k, int k_cs, const float* v, int v_cs,
-                           const float* x, int x_cs, const float* gamma, const float* scale, const float* bias,
-                           int act, float* out, int out_cs, int out_coff, int B, int T, int H, int W, int C,
-                           int alpha, float* o_save, float* lse_save, void* stream) {
+static int attn_fwd_impl(const float* q, int q_cs, const float* k, int k_cs, const float* v, int v_cs,
+                         const float* x, int x_cs, const float* gamma, const float* scale, const float* bias,
+                         int act, float* out, int out_cs, int out_coff, int B, int T, int H, int W, int C,
+                         int alpha, float* o_save, float* lse_save, float* ws, void* stream) {
   if (!q || !k || !v || !x || !out) return SF_EINVAL;
   if (B <= 0 || T <= 0 || H <= 0 || W <= 0 || C <= 0 || C > 128 || alpha <= 0) return SF_EINVAL;
   if ((scale == nullptr) != (bias == nullptr)) return SF_EINVAL;
   if (act != SF_ACT_NONE && act != SF_ACT_RELU) return SF_EINVAL;
+  if (ws && !sf_aligned16(ws)) return SF_EINVAL;
   const long N = (long)T * H * W;
   if (N * B > 0x7fffffffL) return SF_EINVAL;
   AttnArgs a;
@@ -281,14 +350,44 @@ extern "C" int sf_attn_fwd(const float* q, int q_cs, const float* k, int k_cs, c
   a.q_cs = q_cs; a.k_cs = k_cs; a.v_cs = v_cs; a.x_cs = x_cs; a.out_cs = out_cs; a.out_coff = out_coff;
   a.B = B; a.T = T; a.H = H; a.W = W; a.C = C; a.N = (int)N; a.alpha = alpha; a.act = act;
   a.nqt = sf_cdiv(N, 128);
+  a.zs = 1; a.part_o = nullptr; a.part_ml = nullptr;
   const bool vec4 = (C % 4 == 0) && (q_cs % 4 == 0) && (k_cs % 4 == 0) && (v_cs % 4 == 0) && (x_cs % 4 == 0) &&
                     (out_cs % 4 == 0) && (out_coff % 4 == 0) && sf_aligned16(q) && sf_aligned16(k) &&
                     sf_aligned16(v) && sf_aligned16(x) && sf_aligned16(out);
   hipStream_t s = (hipStream_t)stream;
   if (C <= 16)  // 16-query wavefronts on 16x16x4 tiles: no padded rows in the second product
     return sf_attn_small_dispatch(q, q_cs, k, k_cs, v, v_cs, x, x_cs, gamma, scale, bias, act, out, out_cs,
-                                  out_coff, B, T, H, W, C, alpha, o_save, lse_save, vec4, s);
+                                  out_coff, B, T, H, W, C, alpha, o_save, lse_save, vec4, ws, s);
+  const int cp = C <= 32 ? 32 : (C <= 64 ? 64 : 128);
+  if (ws) {
+    a.zs = sf_sweep_parts((long)B * a.nqt, sf_cdiv(N, cp >= 128 ? 32 : 64));
+    sf_attn_place_parts(a, cp, ws);
+  }
   if (C <= 32) return launch<32>(a, vec4, s);
   if (C <= 64) return launch<64>(a, vec4, s);
   return launch<128>(a, vec4, s);
+}
+
+extern "C" int sf_attn_fwd(const float* q, int q_cs, const float* k, int k_cs, const float* v, int v_cs,
+                           const float* x, int x_cs, const float* gamma, const float* scale, const float* bias,
+                           int act, float* out, int out_cs, int out_coff, int B, int T, int H, int W, int C,
+                           int alpha, float* o_save, float* lse_save, void* stream) {
+  return attn_fwd_impl(q, q_cs, k, k_cs, v, v_cs, x, x_cs, gamma, scale, bias, act, out, out_cs, out_coff, B, T, H,
+                       W, C, alpha, o_save, lse_save, nullptr, stream);
+}
+
+// Room for the (O^T, m, l) of up to SF_SWEEP_PARTS_MAX key parts per query row.
+extern "C" long sf_attn_fwd_ws_floats(int B, int N, int C) {
+  if (B <= 0 || N <= 0 || C <= 0 || C > 128) return 0;
+  const int cp = C <= 4 ? 4 : (C <= 8 ? 8 : (C <= 16 ? 16 : (C <= 32 ? 32 : (C <= 64 ? 64 : 128))));
+  return (long)B * SF_SWEEP_PARTS_MAX * N * (cp + 2);
+}
+
+extern "C" int sf_attn_fwd_ws(const float* q, int q_cs, const float* k, int k_cs, const float* v, int v_cs,
+                              const float* x, int x_cs, const float* gamma, const float* scale, const float* bias,
+                              int act, float* out, int out_cs, int out_coff, int B, int T, int H, int W, int C,
+                              int alpha, float* o_save, float* lse_save, float* ws, void* stream) {
+  if (!ws) return SF_EINVAL;
+  return attn_fwd_impl(q, q_cs, k, k_cs, v, v_cs, x, x_cs, gamma, scale, bias, act, out, out_cs, out_coff, B, T, H,
+                       W, C, alpha, o_save, lse_save, ws, stream);
 }

@@ -11,19 +11,11 @@
 //                                         A = V[key 4g + r][channel lane&15] (ds_read_b32, conflict free).
 // Four key tiles (64 keys) are scored before each online-softmax update, so the per-row max costs one
 // in-register reduction over 16 values plus two lane-quarter exchanges, as in the 32x32 kernel.
-#include "common.h"
+#include "attn_args.h"
 
 namespace {
 
-struct AttnArgs {
-  const float* q; const float* k; const float* v; const float* x;
-  const float* gamma; const float* scale; const float* bias;
-  float* out;
-  float* o_save;    // optional [B, N, C] dense: O = P v (pre-gamma), saved for the backward pass
-  float* lse_save;  // optional [B, N]: log2-domain log-sum-exp of each query row
-  int q_cs, k_cs, v_cs, x_cs, out_cs, out_coff;
-  int B, T, H, W, C, N, alpha, act, nqt;
-};
+using AttnArgs = SfAttnArgs;
 
 constexpr float NEG_BIG = -3.0e38f;
 constexpr float LOG2E = 1.4426950408889634f;
@@ -46,8 +38,9 @@ __global__ __launch_bounds__(256) void attn_small_kernel(const AttnArgs p) {
   const int wave = tid >> 6;
   const int li = lane & 15;
   const int lg = lane >> 4;
-  const int b = blockIdx.x / p.nqt;
-  const int q0 = (blockIdx.x - b * p.nqt) * 64 + wave * 16;
+  const int bz = blockIdx.x / p.nqt;  // workgroup -> (clip b, key part z, query tile)
+  const int b = bz / p.zs, z = bz - b * p.zs;
+  const int q0 = (blockIdx.x - bz * p.nqt) * 64 + wave * 16;
   const int N = p.N, C = p.C;
   const long brow = (long)b * N;
 
@@ -108,12 +101,14 @@ __global__ __launch_bounds__(256) void attn_small_kernel(const AttnArgs p) {
     }
   };
 
-  const int ntiles = (N + KT - 1) / KT;
-  load_tile(0);
+  const int tz = ((N + KT - 1) / KT + p.zs - 1) / p.zs;  // key tiles per part
+  const int t0 = z * tz;
+  const int ntiles = min((N + KT - 1) / KT, t0 + tz);
+  load_tile(t0 * KT);
   store_tile(0);
   __syncthreads();
-  for (int t = 0; t < ntiles; ++t) {
-    const int buf = t & 1;
+  for (int t = t0; t < ntiles; ++t) {
+    const int buf = (t - t0) & 1;
     const bool more = (t + 1) < ntiles;
     if (more) load_tile((t + 1) * KT);
     // ---- scores for 4 key tiles of 16
@@ -187,6 +182,14 @@ __global__ __launch_bounds__(256) void attn_small_kernel(const AttnArgs p) {
   }
   const int qrow = q0 + li;
   const int c0 = 4 * lg;
+  if (p.zs > 1) {  // this key part's (O^T, m, l): merged and finished by attn_fwd_merge_kernel (attn_flash.hip)
+    if (qrow < N) {
+      const long prow = (long)bz * N + qrow;
+      if (lg == 0) *reinterpret_cast<float2*>(p.part_ml + prow * 2) = make_float2(m_run, l_tot);
+      if (c0 < CP) *reinterpret_cast<f32x4*>(p.part_o + prow * CP + c0) = o;
+    }
+    return;
+  }
   if (qrow >= N || c0 >= C) return;
   const float inv_l = 1.0f / l_tot;
   if (p.lse_save && lg == 0) p.lse_save[brow + qrow] = m_run + __log2f(l_tot);
@@ -221,13 +224,13 @@ __global__ __launch_bounds__(256) void attn_small_kernel(const AttnArgs p) {
 
 template <int CP>
 int launch(const AttnArgs& a, bool vec4, hipStream_t s) {
-  const int grid = a.B * a.nqt;
+  const int grid = a.B * a.zs * a.nqt;
   if (vec4)
     hipLaunchKernelGGL((attn_small_kernel<CP, 4>), dim3(grid), dim3(256), 0, s, a);
   else
     hipLaunchKernelGGL((attn_small_kernel<CP, 1>), dim3(grid), dim3(256), 0, s, a);
   SF_CHECK_LAUNCH();
-  return SF_OK;
+  return a.zs > 1 ? sf_attn_fwd_merge(a, CP, s) : SF_OK;
 }
 
 }  // namespace
@@ -236,13 +239,18 @@ int launch(const AttnArgs& a, bool vec4, hipStream_t s) {
 int sf_attn_small_dispatch(const float* q, int q_cs, const float* k, int k_cs, const float* v, int v_cs,
                            const float* x, int x_cs, const float* gamma, const float* scale, const float* bias,
                            int act, float* out, int out_cs, int out_coff, int B, int T, int H, int W, int C,
-                           int alpha, float* o_save, float* lse_save, bool vec4, hipStream_t stream) {
+                           int alpha, float* o_save, float* lse_save, bool vec4, float* ws, hipStream_t stream) {
   AttnArgs a;
   a.q = q; a.k = k; a.v = v; a.x = x; a.gamma = gamma; a.scale = scale; a.bias = bias; a.out = out;
   a.o_save = o_save; a.lse_save = lse_save;
   a.q_cs = q_cs; a.k_cs = k_cs; a.v_cs = v_cs; a.x_cs = x_cs; a.out_cs = out_cs; a.out_coff = out_coff;
   a.B = B; a.T = T; a.H = H; a.W = W; a.C = C; a.N = T * H * W; a.alpha = alpha; a.act = act;
   a.nqt = sf_cdiv(a.N, 64);
+  a.zs = 1; a.part_o = nullptr; a.part_ml = nullptr;
+  if (ws) {
+    a.zs = sf_sweep_parts((long)B * a.nqt, sf_cdiv(a.N, 64));
+    sf_attn_place_parts(a, C <= 4 ? 4 : (C <= 8 ? 8 : 16), ws);
+  }
   if (C <= 4) return launch<4>(a, vec4, stream);
   if (C <= 8) return launch<8>(a, vec4, stream);
   return launch<16>(a, vec4, stream);

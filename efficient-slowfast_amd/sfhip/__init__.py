@@ -52,10 +52,11 @@ EXPORTS = [
     "sf_bn_train_stats_split", "sf_affine_fwd_split", "sf_bn_bwd_reduce_split", "sf_bn_bwd_apply_split",
     "sf_clip_prologue", "sf_conv_wgrad_finish", "sf_bn_bwd_reduce_acc", "sf_row_softmax_fwd", "sf_row_softmax_bwd",
     "sf_attn_bwd_fused_ws_floats", "sf_attn_bwd_fused", "sf_pack_conv_weight", "sf_conv_fwd_ws_floats",
-    "sf_conv_fwd_ws",
+    "sf_conv_fwd_ws", "sf_attn_fwd_ws_floats", "sf_attn_fwd_ws",
 ]
 _LONG_RET = ("sf_tmax_mean_ws_floats", "sf_channel_stats_ws_floats", "sf_bn_bwd_ws_floats",
-             "sf_dwconv_wgrad_ws_floats", "sf_attn_bwd_fused_ws_floats", "sf_conv_fwd_ws_floats")
+             "sf_dwconv_wgrad_ws_floats", "sf_attn_bwd_fused_ws_floats", "sf_conv_fwd_ws_floats",
+             "sf_attn_fwd_ws_floats")
 
 
 def lib_path():
@@ -84,6 +85,9 @@ def lib():
         L.sf_tmax_mean.argtypes = [vp, ci, ci] + [ci] * 6 + [vp, vp, vp]
         L.sf_gate_apply.argtypes = [vp, ci, ci] + [ci] * 6 + [vp, vp, vp, vp, ci, vp, ci, ci, vp]
         L.sf_attn_fwd.argtypes = [vp, ci, vp, ci, vp, ci, vp, ci, vp, vp, vp, ci, vp, ci, ci] + [ci] * 6 + [vp, vp, vp]
+        L.sf_attn_fwd_ws_floats.argtypes = [ci, ci, ci]
+        L.sf_attn_fwd_ws_floats.restype = cl
+        L.sf_attn_fwd_ws.argtypes = L.sf_attn_fwd.argtypes[:-1] + [vp, vp]
         L.sf_attn_bwd.argtypes = [vp, ci, vp, ci, vp, ci, vp, ci, vp, vp, vp, vp, ci, vp, ci, vp, ci, ci, ci, ci, ci, vp]
         L.sf_head_act_mean.argtypes = [vp, ci, ci, ci, ci, vp, vp]
         L.sf_copy_channels.argtypes = [vp, ci, ci, vp, ci, ci, ci, cl, ci, vp]
@@ -433,10 +437,13 @@ def attention(q, k, v, x, gamma, scale=None, bias=None, relu=False, alpha=1, out
         n = x.T * x.H * x.W
         o_save = save["o"] = torch.empty((x.N, n, x.C), dtype=torch.float32, device=x.buf.device)
         lse_save = save["lse"] = torch.empty((x.N, n), dtype=torch.float32, device=x.buf.device)
-    _check(_traced(("attn", x.N, x.T * x.H * x.W, x.C), lambda: lib().sf_attn_fwd(
+    # workspace for the key-range parts the launcher may cut the sweep into (sf_sweep_parts: fills the last round)
+    ws = torch.empty((lib().sf_attn_fwd_ws_floats(x.N, x.T * x.H * x.W, x.C),), dtype=torch.float32,
+                     device=x.buf.device)
+    _check(_traced(("attn", x.N, x.T * x.H * x.W, x.C), lambda: lib().sf_attn_fwd_ws(
         base(q), q.cs, base(k), k.cs, base(v), v.cs, base(x), x.cs, _ptr(gamma), _ptr(scale),
         _ptr(bias), ACT_RELU if relu else ACT_NONE, out.ptr(), out.cs, out.coff,
-        x.N, x.T, x.H, x.W, x.C, alpha, _ptr(o_save), _ptr(lse_save), _stream())), "sf_attn_fwd")
+        x.N, x.T, x.H, x.W, x.C, alpha, _ptr(o_save), _ptr(lse_save), _ptr(ws), _stream())), "sf_attn_fwd_ws")
     return out
 
 

@@ -134,6 +134,16 @@ int sf_attn_fwd(const float* q, int q_cs, const float* k, int k_cs, const float*
                 int act, float* out, int out_cs, int out_coff, int B, int T, int H, int W, int C,
                 int alpha, float* o_save, float* lse_save, void* stream);
 
+/* Same, with a workspace of sf_attn_fwd_ws_floats(B, N = T*H*W, C) floats (16-byte aligned): the launcher may then
+ * cut the key sweep into up to 8 parts so that the last round of workgroups fills all CUs (B * N/128 query tiles on
+ * 256 CUs otherwise leave up to one workgroup-time of tail), merging the parts' (O, max, denominator) in a second
+ * kernel that also runs the epilogue.  Same results up to fp32 summation order; deterministic.              */
+long sf_attn_fwd_ws_floats(int B, int N, int C);
+int sf_attn_fwd_ws(const float* q, int q_cs, const float* k, int k_cs, const float* v, int v_cs,
+                   const float* x, int x_cs, const float* gamma, const float* scale, const float* bias,
+                   int act, float* out, int out_cs, int out_coff, int B, int T, int H, int W, int C,
+                   int alpha, float* o_save, float* lse_save, float* ws, void* stream);
+
 /* SpatialAttention backward (recompute form): dz = dL/d(gamma*O + x) [B, N, C]; dvec[i] = <dz_i, O_i>
  * (sf_rowdot); writes dq, dk, dv (overwrite).  dx = dz and dgamma = sum(dvec) are the caller's.        */
 int sf_attn_bwd(const float* q, int q_cs, const float* k, int k_cs, const float* v, int v_cs,

@@ -304,9 +304,10 @@ def test_attention_backward_query_parts(parts):
     if os.environ.get("SF_SWEEP_PARTS"):
         pytest.skip("already inside the forced-parts child")
     env = dict(os.environ, SF_SWEEP_PARTS=str(parts))
-    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", __file__, "-k",
-                        "test_attention_backward and not query_parts"], env=env, capture_output=True, text=True,
-                       timeout=900)
+    fwd = os.path.join(os.path.dirname(__file__), "test_ops_gpu.py")  # its forward tests cut the KEY sweep alike
+    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", __file__, fwd, "-k",
+                        "(test_attention_backward and not query_parts) or test_attention"], env=env,
+                       capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert "passed" in r.stdout
 
