@@ -483,7 +483,18 @@ extern "C" int sf_conv_wgrad_splits(const sf_conv_desc* d) {
   if (S > maxS) S = maxS;
   if (S < 1) S = 1;
   if (S > 1024) S = 1024;
-  return (int)S;
+  // Equal workgroups run in rounds of 256 (one per CU) and the launch ends with its busiest CU: 9 tiles x 171 splits
+  // = 1539 workgroups is 6.01 rounds -> 7.  Among the split counts within 25 % of the target take the one that
+  // wastes the least of its last round (ties: the larger, i.e. shorter workgroups).
+  long best = S;
+  double best_fill = 0.0;
+  for (long c = S - S / 4; c <= S + S / 4 && c <= maxS && c <= 1024; ++c) {
+    if (c < 1) continue;
+    const long wg = tiles * c;
+    const double fill = (double)wg / (double)((wg + 255) / 256 * 256);
+    if (fill >= best_fill - 1e-12) { best_fill = fill; best = c; }
+  }
+  return (int)best;
 }
 
 extern "C" int sf_conv_wgrad(const sf_conv_desc* d, const float* x, const float* dz, int dz_cs, int dz_coff,
