@@ -283,12 +283,13 @@ def main():
                                    "dQ/dK/dV in one sweep)"}[kind]
         traffic = None  # HBM bytes per launch from the committed PMC passes (rocprofv3 cannot run inside bench.py)
         try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_attention_hbm_traffic_v2.json")))["kernels"]
-            kkey = {"attn": "attn_fwd_kernel<32, 4>", "attn_bwd_dkv": "attn_bwd_dkv_kernel<32>",
-                    "attn_bwd_dq": "attn_bwd_dq_kernel<32>", "attn_bwd_fused": "attn_bwd_fused<32>"}[kind]
-            if c == 32 and n == 25088 and b == 8:
-                traffic = tj[kkey]["hbm_bytes_per_launch"]
-        except (OSError, KeyError, ValueError):
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_attention_hbm_traffic_v3.json")))["kernels"]
+            if kind == "attn_bwd_fused" and c == 32 and n == 25088 and b == 8:
+                # the sweep kernel + its three reductions (dK parts, dV parts, dQ planes): one thread per (row, 4 ch)
+                sweep = [v for k, v in tj.items() if k.startswith("attn_bwd_fused_kernel<32, 4>")]
+                red = tj["attn_dq_reduce_kernel grid=%d" % (-(-(b * n * 8) // 256) * 256)]
+                traffic = sweep[0]["hbm_bytes_per_launch"] + 3 * red["hbm_bytes_per_launch"]
+        except (OSError, KeyError, ValueError, IndexError):
             traffic = None
         roofline = {"bound": "mfma", "kernel": "%s C=%d N=%d B=%d" % (kname, c, n, b),
                     "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",

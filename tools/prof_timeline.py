@@ -48,3 +48,34 @@ for k in sorted(depth_time):
 print("solo time by kernel:")
 for n, v in sorted(solo.items(), key=lambda kv: -kv[1])[:18]:
     print("  %-44s %7.2f ms" % (n, v / 1e6))
+
+# ---- idle gaps (no kernel in flight): the longest ones with the kernels either side, and totals by the kernel that
+#      FOLLOWS the gap (what the GPU was waiting for: a host-side launch, or a cross-stream event)
+gaps = []
+end = None
+last = None
+for r in sorted(ev, key=lambda r: int(r["Start_Timestamp"])):
+    s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+    n = r["Kernel_Name"]
+    short = n.split("::")[1].split("(")[0] if "anonymous" in n else n[:40]
+    if end is not None and s > end:
+        gaps.append((s - end, last, short, (end - t0) / 1e6))
+    if end is None or e > end:
+        end, last = e, short
+tot = sum(g[0] for g in gaps)
+print("idle gaps: %d, total %.2f ms; > 20 us: %d (%.2f ms)" % (
+    len(gaps), tot / 1e6, sum(1 for g in gaps if g[0] > 20000), sum(g[0] for g in gaps if g[0] > 20000) / 1e6))
+by_next = defaultdict(float)
+for g in gaps:
+    by_next[g[2]] += g[0]
+print("idle time by the kernel that follows the gap:")
+for n, v in sorted(by_next.items(), key=lambda kv: -kv[1])[:14]:
+    print("  %-44s %7.2f ms" % (n, v / 1e6))
+print("longest gaps (us, at ms into the step, before -> after):")
+for g in sorted(gaps, key=lambda g: -g[0])[:16]:
+    print("  %7.1f  @%6.2f  %s -> %s" % (g[0] / 1e3, g[3], g[1], g[2]))
+# idle time per 5-ms slice of the step
+sl = defaultdict(float)
+for g in gaps:
+    sl[int(g[3] // 5)] += g[0]
+print("idle per 5 ms slice:", " ".join("%d:%.1f" % (k * 5, v / 1e6) for k, v in sorted(sl.items())))
