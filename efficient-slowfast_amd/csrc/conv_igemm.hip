@@ -18,6 +18,7 @@
 // Replaces: stem_helper.py:157-164, resnet_helper.py:182-223, :326-335, video_model_builder.py:128-135,
 // custom_video_model_builder.py:102-108, wdf_attention_helper.py:21-29, head_helper.py:181 (as 1x1x1).
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -46,9 +47,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
   static_assert(WM * WN == 4, "4 wavefronts per workgroup");
   constexpr int TM = BM / WM / 16;
   constexpr int TN = BN / WN / 16;
-  constexpr int A_IT = BM / 64;
+  constexpr int A_IT = (BM + 63) / 64;  // BM = 112 (7 x 16 rows): the second pass stages rows 64..111 only
   constexpr int B_IT = (BN + 63) / 64;
   static_assert(TM >= 1 && TN >= 1, "tile too small");
+  static_assert(BM % (WM * 16) == 0 && BN % (WN * 16) == 0, "whole 16x16 MFMA tiles per wavefront");
 
   __shared__ __attribute__((aligned(16))) float smem[2 * (BM + BN) * LDK];
   float* const As = smem;
@@ -70,7 +72,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
 #pragma unroll
   for (int i = 0; i < A_IT; ++i) {
     const int m = m0 + lr + 64 * i;
-    a_ok[i] = m < p.M;
+    a_ok[i] = (BM % 64 == 0 || lr + 64 * i < BM) && m < p.M;
     const int mm = a_ok[i] ? m : 0;
     const int wo = mm % d.Wo;
     const int t1 = mm / d.Wo;
@@ -172,7 +174,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
   auto store_lds = [&](int buf) {
 #pragma unroll
     for (int i = 0; i < A_IT; ++i)
-      *reinterpret_cast<f32x4*>(As + (buf * BM + lr + 64 * i) * LDK + lc) = ra[i];
+      if (BM % 64 == 0 || lr + 64 * i < BM) *reinterpret_cast<f32x4*>(As + (buf * BM + lr + 64 * i) * LDK + lc) = ra[i];
 #pragma unroll
     for (int j = 0; j < B_IT; ++j)
       if (lr + 64 * j < BN) *reinterpret_cast<f32x4*>(Bs + (buf * BN + lr + 64 * j) * LDK + lc) = rb[j];
@@ -425,6 +427,51 @@ static int splitk_factor(const sf_conv_desc* d, long M) {
   return best;
 }
 
+// Tile configuration of a layer.  Every activation of this network has 49 * 2^k rows, so power-of-two tiles give
+// 49 * 2^j workgroups — 392, 784, 1568: 0.77, 0.77, 0.875 of their last round of 256 CUs filled, and the launch ends
+// with its busiest CU (tools/microbench/conv_tail.py: the 3x3 128->128 layer runs at 81 TFLOP/s at M = 50 176 and at
+// 111 at M = 65 536).  Tiles of 112 = 7 x 16 rows give 7 * 2^j workgroups instead (448, 896: 0.875; 1792, 3584: whole
+// rounds), so among the MFMA tilings that fit the layer take the one with the best (last-round fill) x (tile
+// efficiency prior); the priors are the measured TFLOP/s of each tiling divided by its fill on the res3 layers
+// (tools/microbench/tile_sweep.py: 3x3 128->128 at M = 50 176: 112x128 93.9, 224x128 86.1, 128x128 85.0, 112x64
+// 84.3, 64x64 81.3, 128x64 78.3 TFLOP/s).
+enum ConvCfg { CFG_256x16, CFG_256x32, CFG_64x64, CFG_128x64, CFG_128x128, CFG_112x64, CFG_112x128, CFG_224x128,
+               CFG_COUNT };
+static const int CFG_BM[] = {256, 256, 64, 128, 128, 112, 112, 224};
+static const int CFG_BN[] = {16, 32, 64, 64, 128, 64, 128, 128};
+static const double CFG_EFF[] = {0, 0, 0.86, 0.94, 1.00, 0.90, 0.965, 0.97};
+
+static ConvCfg conv_cfg(const sf_conv_desc* d, long M, int ksplit) {
+  static const int forced = [] {
+    const char* e = getenv("SF_CONV_CFG");  // microbenchmark aid: force one tiling for Cout >= 64 layers (-2: no 7x16-row tiles)
+    return e ? atoi(e) : -1;
+  }();
+  if (d->Cout <= 16) return CFG_256x16;
+  if (d->Cout <= 32) return CFG_256x32;
+  if (ksplit > 1) return d->Cout <= 64 ? CFG_128x64 : CFG_128x128;
+  if (forced >= CFG_64x64 && forced < CFG_COUNT) return (ConvCfg)forced;
+  // Short reductions into wide outputs (the bottleneck "c" convs, K = Cin <= 256 -> Cout >= 128, with the residual in
+  // the epilogue) are prologue / epilogue bound: 64x64 tiles (4x the workgroups) measured 81 vs 67 TFLOP/s on
+  // 256 -> 1024 at M = 12544 and 74 vs 66 on 128 -> 512 at M = 50176 (tools/microbench/tile_sweep.py).
+  // (also 256 -> 64 at M = 200704: 78.7 vs 74.5-76.7 for the larger tiles)
+  const int nk = d->kT * d->kH * d->kW * (d->cin_pad / BK);
+  if (nk <= 16) return CFG_64x64;
+  ConvCfg best = CFG_64x64;
+  double best_score = -1.0;
+  for (int c = CFG_64x64; c < CFG_COUNT; ++c) {
+    if (CFG_BN[c] == 128 && d->Cout <= 64) continue;
+    if (forced == -2 && CFG_BM[c] % 112 == 0) continue;  // A/B aid: power-of-two tiles only
+    const long nbm = sf_cdiv(M, CFG_BM[c]), nbn = sf_cdiv(d->Cout, CFG_BN[c]);
+    const long tiles = nbm * nbn;
+    const double fill = (double)tiles / (double)(sf_cdiv(tiles, 256) * 256L);
+    const double used = ((double)M * d->Cout) / ((double)nbm * CFG_BM[c] * nbn * CFG_BN[c]);  // padded rows / columns
+    const double lone = tiles <= 256 ? 0.9 : 1.0;  // one workgroup per CU: nothing covers its barriers
+    const double score = fill * used * CFG_EFF[c] * lone;
+    if (score > best_score + 1e-9) { best_score = score; best = (ConvCfg)c; }
+  }
+  return best;
+}
+
 }  // namespace
 
 extern "C" long sf_conv_fwd_ws_floats(const sf_conv_desc* d) {
@@ -471,20 +518,16 @@ static int conv_fwd_impl(const sf_conv_desc* d, const float* in, const float* w_
     SF_CHECK_LAUNCH();
     return SF_OK;
   }
-  if (d->Cout <= 16) return launch<256, 16, 4, 1>(a, vec4, s);
-  if (d->Cout <= 32) return launch<256, 32, 4, 1>(a, vec4, s);
-  // Large tiles maximise operand reuse, but the M <= 12544 layers of res4/res5 then give < 1 workgroup per
-  // CU (256 CUs): drop to 64x64 tiles when the big tiling cannot fill the chip twice over.
-  const long big = (long)sf_cdiv(M, 128) * sf_cdiv(d->Cout, d->Cout <= 64 ? 64 : 128);
-  if (a.ksplit > 1) return d->Cout <= 64 ? launch<128, 64, 2, 2>(a, vec4, s) : launch<128, 128, 2, 2>(a, vec4, s);
-  // Short reductions into wide outputs (the bottleneck "c" convs, K = Cin <= 256 -> Cout >= 128, with the residual in
-  // the epilogue) are prologue / epilogue bound: 64x64 tiles (4x the workgroups) measured 81 vs 67 TFLOP/s on
-  // 256 -> 1024 at M = 12544 and 74 vs 66 on 128 -> 512 at M = 50176 (tools/microbench/tile_sweep.py).
-  const int nk = a.ntaps * (d->cin_pad / BK);
-  if (nk <= 16 && d->Cout >= 128) return launch<64, 64, 2, 2>(a, vec4, s);
-  if (big < 512) return launch<64, 64, 2, 2>(a, vec4, s);
-  if (d->Cout <= 64) return launch<128, 64, 2, 2>(a, vec4, s);
-  return launch<128, 128, 2, 2>(a, vec4, s);
+  switch (conv_cfg(d, M, a.ksplit)) {
+    case CFG_256x16: return launch<256, 16, 4, 1>(a, vec4, s);
+    case CFG_256x32: return launch<256, 32, 4, 1>(a, vec4, s);
+    case CFG_64x64: return launch<64, 64, 2, 2>(a, vec4, s);
+    case CFG_128x64: return launch<128, 64, 2, 2>(a, vec4, s);
+    case CFG_112x64: return launch<112, 64, 1, 4>(a, vec4, s);
+    case CFG_112x128: return launch<112, 128, 1, 4>(a, vec4, s);
+    case CFG_224x128: return launch<224, 128, 2, 2>(a, vec4, s);
+    default: return launch<128, 128, 2, 2>(a, vec4, s);
+  }
 }
 
 extern "C" int sf_conv_fwd(const sf_conv_desc* d, const float* in, const float* w_packed, const float* scale,
