@@ -12,6 +12,7 @@
 // and each v_mfma_f32_16x16x4_f32 takes A = dz^T (lane (co, g) reads dz[4s+g][co]) and B = x (lane (ci, g)
 // reads x[4s+g][ci]) as conflict-free ds_read_b32.  Block tile 64 co x 64 ci, 4 wavefronts of 32 x 32.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -368,6 +369,195 @@ __global__ __launch_bounds__(256) void conv_wgrad_small_kernel(const WgradArgs p
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------- Fast-pathway stem
+// Weight gradient of the "stem trick" convolution (engine.stem_conv_bn_relu: a 5x7x7 / stride (1,2,2) conv over the
+// border-padded NDHWC4 clip seen as a 5x7x1 conv over pixels of 8 floats that reads 28 contiguous floats per tap;
+// Cout = 8, 3.2 M output positions).  The per-tap kernel above re-reads every input row once per tap — 35 taps x 28
+// floats per position = 12.6 GB through L2, 2.8 ms.  Here a workgroup owns an output row h of a clip and walks t:
+// the 5 frames x 7 input rows the row needs sit in an LDS ring (129 KB), every step of t brings in ONE new slab
+// (7 contiguous rows) and retires the oldest, and all 35 taps x 32 packed channels are accumulated from LDS:
+// input traffic drops from 35x to 3.5x re-reads (an input row serves 3.5 output rows).
+//   A[m = packed channel j][k = position]  = ring[(t + kt) % 5][kh][w * ps + j]        (ds_read_b32, conflict free)
+//   B[k = position][n = co]                = dz row in LDS (lanes n >= Cout hold 0)
+// 70 tiles of 16 packed channels (35 taps x 2) are dealt to the 4 wavefronts (18 accumulators each); the 16
+// positions of a block are assigned to (MFMA s, lane quarter g) as w0 + 2g + (s & 1) + 8 (s >> 1), which puts the
+// quarters 16 banks apart for a pixel stride of 8 floats.  Units (clip, row, t range) are dealt round-robin to a
+// persistent grid of one workgroup per CU; each workgroup writes ONE partial (summed by the usual finish path).
+constexpr int STEM_KT = 5, STEM_KH = 7, STEM_CO = 8;
+constexpr int STEM_NI = (2 * STEM_KT * STEM_KH + 3) / 4;  // accumulator tiles per wavefront
+
+struct StemArgs {
+  WgradArgs w;
+  int rowf;      // floats per input row = Wi * in_cs
+  int ps;        // floats between neighbouring output positions = sW * in_cs
+  int nblk;      // 16-position blocks per output row
+  int tparts;    // the t range of a (clip, row) is cut into this many units
+  int units;     // N * Ho * tparts
+};
+
+__global__ __launch_bounds__(256) void conv_wgrad_stem_kernel(const StemArgs q) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const WgradArgs& p = q.w;
+  const sf_conv_desc& d = p.d;
+  const int slab = STEM_KH * q.rowf;              // one frame's 7 rows (contiguous in HBM and here)
+  float* const ring = lds;                        // [STEM_KT][slab]
+  float* const dzs = lds + STEM_KT * slab;        // [nblk * 16][STEM_CO]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int fr = lane & 15, fg = lane >> 4;
+  const int slab4 = slab >> 2;                    // float4 per slab
+  constexpr int LD4 = 8;                          // float4 per thread per slab (<= 2048 float4 = 32 KB)
+
+  f32x4 acc[STEM_NI];
+#pragma unroll
+  for (int i = 0; i < STEM_NI; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  // this wavefront's tiles: mt = wave + 4 i -> tap = mt >> 1 = (kt, kh), packed channels 16 (mt & 1) ..
+  int t_kt[STEM_NI], t_off[STEM_NI];
+#pragma unroll
+  for (int i = 0; i < STEM_NI; ++i) {
+    const int mt = wave + 4 * i, tap = mt >> 1;
+    t_kt[i] = tap / STEM_KH;
+    t_off[i] = (tap % STEM_KH) * q.rowf + (mt & 1) * 16 + fr;
+  }
+
+  f32x4 rs[LD4];
+  float rz[4];
+  auto load_slab = [&](int n, int ti, int h) {  // frame ti of clip n, input rows h*sH .. +6 (zeros outside the clip)
+    const bool ok = (unsigned)ti < (unsigned)d.Ti;
+    const f32x4* src = reinterpret_cast<const f32x4*>(p.x + (((long)n * d.Ti + (ok ? ti : 0)) * d.Hi + (long)h * d.sH) * q.rowf);
+#pragma unroll
+    for (int u = 0; u < LD4; ++u) {
+      const int f = tid + u * 256;
+      rs[u] = (ok && f < slab4) ? src[f] : (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+  };
+  auto store_slab = [&](int slot) {
+    f32x4* dst = reinterpret_cast<f32x4*>(ring + slot * slab);
+#pragma unroll
+    for (int u = 0; u < LD4; ++u) {
+      const int f = tid + u * 256;
+      if (f < slab4) dst[f] = rs[u];
+    }
+  };
+  auto load_dz = [&](int n, int t, int h) {
+    const long m0 = (((long)n * d.To + t) * d.Ho + h) * d.Wo;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int e = tid + u * 256, w = e >> 3, co = e & 7;
+      rz[u] = (w < d.Wo && co < d.Cout) ? p.dz[(m0 + w) * p.dz_cs + p.dz_coff + co] : 0.f;
+    }
+  };
+  auto store_dz = [&]() {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int e = tid + u * 256;
+      if (e < q.nblk * 16 * STEM_CO) dzs[e] = rz[u];
+    }
+  };
+
+  for (int unit = blockIdx.x; unit < q.units; unit += gridDim.x) {
+    const int tz = unit % q.tparts;
+    const int nh = unit / q.tparts;
+    const int h = nh % d.Ho, n = nh / d.Ho;
+    const int tper = (d.To + q.tparts - 1) / q.tparts;
+    const int t0 = tz * tper, t1 = min(d.To, t0 + tper);
+    if (t0 >= t1) continue;
+    __syncthreads();  // the previous unit's last step may still read the ring
+    // prime the ring with the frames of step t0 except the newest one: input frame of (t, kt) is t - pT + kt
+    for (int kt = 0; kt < STEM_KT - 1; ++kt) {
+      const int ti = t0 - d.pT + kt;
+      load_slab(n, ti, h);
+      store_slab(((ti % STEM_KT) + STEM_KT) % STEM_KT);
+    }
+    load_slab(n, t0 - d.pT + STEM_KT - 1, h);
+    load_dz(n, t0, h);
+    for (int t = t0; t < t1; ++t) {
+      const int tnew = t - d.pT + STEM_KT - 1;
+      store_slab(((tnew % STEM_KT) + STEM_KT) % STEM_KT);
+      store_dz();
+      __syncthreads();
+      if (t + 1 < t1) {  // next step's slab and dz row travel while this step computes
+        load_slab(n, tnew + 1, h);
+        load_dz(n, t + 1, h);
+      }
+      const int base = t - d.pT;  // frame of kt = 0
+      const float* arow[STEM_NI];
+#pragma unroll
+      for (int i = 0; i < STEM_NI; ++i) {
+        const int ti = base + t_kt[i];
+        arow[i] = ring + (((ti % STEM_KT) + STEM_KT) % STEM_KT) * slab + t_off[i];
+      }
+      for (int blk = 0; blk < q.nblk; ++blk) {
+        int wpos[4];
+        float b[4];
+#pragma unroll
+        for (int sidx = 0; sidx < 4; ++sidx) {
+          const int w = blk * 16 + 2 * fg + (sidx & 1) + 8 * (sidx >> 1);
+          b[sidx] = (fr < STEM_CO) ? dzs[w * STEM_CO + fr] : 0.f;          // rows w >= Wo of dzs hold zeros
+          wpos[sidx] = min(w, d.Wo - 1) * q.ps;                               // keep the A read inside the row
+        }
+#pragma unroll
+        for (int i = 0; i < STEM_NI; ++i) {
+          if (wave + 4 * i >= 2 * STEM_KT * STEM_KH) break;  // wave-uniform: the last tile slot of waves 2, 3
+#pragma unroll
+          for (int sidx = 0; sidx < 4; ++sidx)
+            acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(arow[i][wpos[sidx]], b[sidx], acc[i], 0, 0, 0);
+        }
+      }
+      __syncthreads();  // everyone is done with the oldest slab and the dz row before they are overwritten
+    }
+  }
+  // this workgroup's partial: tile mt -> tap, packed channels 16 (mt & 1) + 4 fg + r, co = fr
+  float* const out = p.part + (long)blockIdx.x * d.Cout * p.ntaps * d.cin_pad;
+  if (fr < d.Cout) {
+#pragma unroll
+    for (int i = 0; i < STEM_NI; ++i) {
+      const int mt = wave + 4 * i;
+      if (mt >= 2 * STEM_KT * STEM_KH) break;
+      const int tap = mt >> 1;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int ci = (mt & 1) * 16 + 4 * fg + r;
+        out[((long)fr * p.ntaps + tap) * d.cin_pad + ci] = (ci < d.Cin) ? acc[i][r] : 0.f;
+      }
+    }
+  }
+}
+
+// Does this problem take the stem kernel, and with how many workgroups (= partials)?
+static bool stem_plan(const sf_conv_desc* d, int dz_cs, StemArgs* q) {
+  static const bool off = [] { const char* e = getenv("SF_WGRAD_STEM"); return e && e[0] == '0'; }();
+  if (off) return false;
+  if (d->kT != STEM_KT || d->kH != STEM_KH || d->kW != 1 || d->sT != 1 || d->sW != 1 || d->pH != 0 || d->pW != 0 ||
+      d->dT != 1 || d->dH != 1 || d->dW != 1 || d->cin_pad != 32 || d->Cin > 32 || d->Cout > STEM_CO ||
+      d->in_coff != 0 || (d->in_cs % 4) != 0 || d->To != d->Ti + 2 * d->pT - STEM_KT + 1)
+    return false;
+  const int rowf = d->Wi * d->in_cs, ps = d->sW * d->in_cs;
+  if ((long)(d->Wo - 1) * ps + 32 > rowf) return false;                       // a tap reads 32 floats from its pixel
+  if ((long)(d->Ho - 1) * d->sH + STEM_KH > d->Hi) return false;
+  const int nblk = (d->Wo + 15) / 16;
+  if (nblk * 16 * STEM_CO > 1024 || STEM_KH * rowf > 8 * 256 * 4) return false; // staging capacity per thread
+  const long lds = ((long)STEM_KT * STEM_KH * rowf + (long)nblk * 16 * STEM_CO) * 4;
+  if (lds > 160 * 1024 - 512) return false;
+  if (q) {
+    q->rowf = rowf; q->ps = ps; q->nblk = nblk;
+    // units: (clip, output row) x t parts; cut t so that the units deal evenly onto 256 workgroups
+    int best = 1;
+    double best_fill = 0.0;
+    for (int tp = 1; tp <= 4 && d->To / tp >= 4; ++tp) {
+      const long u = (long)d->N * d->Ho * tp;
+      const double fill = (double)u / (double)((u + 255) / 256 * 256) - 0.03 * (tp - 1);  // each part re-primes 4 slabs
+      if (fill > best_fill) { best_fill = fill; best = tp; }
+    }
+    q->tparts = best;
+    q->units = d->N * d->Ho * best;
+  }
+  (void)dz_cs;
+  return true;
+}
+
+static int stem_workgroups(const StemArgs& q) { return q.units < 256 ? q.units : 256; }
+
 // tile shape for a problem: 128 on a side only when that side has >= 128 channels
 static inline void wgrad_tile(const sf_conv_desc* d, int* bco, int* bci) {
   if (d->Cout <= 32 || d->Cin <= 32) {  // small-channel kernel
@@ -473,6 +663,8 @@ extern "C" int sf_conv_wgrad_finish(const float* partial, int S, int Cout, int p
 // Number of position splits the kernel will use for this problem (the caller sizes the workspace with it).
 extern "C" int sf_conv_wgrad_splits(const sf_conv_desc* d) {
   if (!d) return 0;
+  StemArgs sq;
+  if (stem_plan(d, 0, &sq)) return stem_workgroups(sq);
   int bco, bci;
   wgrad_tile(d, &bco, &bci);
   const long M = (long)d->N * d->To * d->Ho * d->Wo;
@@ -510,6 +702,22 @@ extern "C" int sf_conv_wgrad(const sf_conv_desc* d, const float* x, const float*
   a.ntaps = d->kT * d->kH * d->kW;
   a.S = sf_conv_wgrad_splits(d);
   a.nb_co = a.nb_ci = 0;
+  a.chunk = 0;
+  StemArgs sq;
+  if (sf_aligned16(x) && stem_plan(d, dz_cs, &sq)) {
+    sq.w = a;
+    const size_t lds = ((size_t)STEM_KT * STEM_KH * sq.rowf + (size_t)sq.nblk * 16 * STEM_CO) * sizeof(float);
+    static bool attr_set = false;  // raise the dynamic-LDS cap once (129 KB of the CU's 160 KB)
+    if (!attr_set) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_stem_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512) != hipSuccess)
+        return SF_ELAUNCH;
+      attr_set = true;
+    }
+    hipLaunchKernelGGL(conv_wgrad_stem_kernel, dim3(stem_workgroups(sq)), dim3(256), lds, (hipStream_t)stream, sq);
+    SF_CHECK_LAUNCH();
+    return SF_OK;
+  }
   a.chunk = ((M + a.S - 1) / a.S + BMS - 1) / BMS * BMS;
   const bool vec4 = (d->Cin % 4 == 0) && (d->in_cs % 4 == 0) && (d->in_coff % 4 == 0) && sf_aligned16(x) &&
                     (d->Cout % 4 == 0) && (dz_cs % 4 == 0) && (dz_coff % 4 == 0) && sf_aligned16(dz);
