@@ -482,6 +482,9 @@ extern "C" long sf_conv_fwd_ws_floats(const sf_conv_desc* d) {
   return S > 1 ? (long)S * M * d->Cout : 0;
 }
 
+int sf_conv_stem_fwd_try(const sf_conv_desc* d, const float* in, const float* w, const float* scale,
+                         const float* bias, const float* res, float* out, hipStream_t stream);  // conv_stem.hip
+
 static int conv_fwd_impl(const sf_conv_desc* d, const float* in, const float* w_packed, const float* scale,
                          const float* bias, const float* res, float* out, float* ws, void* stream) {
   if (!d || !in || !w_packed || !out) return SF_EINVAL;
@@ -498,6 +501,10 @@ static int conv_fwd_impl(const sf_conv_desc* d, const float* in, const float* w_
     if (d->oo_T < 0 || d->oo_H < 0 || d->oo_W < 0 || (d->To - 1) * st + d->oo_T >= d->ob_T ||
         (d->Ho - 1) * sh + d->oo_H >= d->ob_H || (d->Wo - 1) * sw + d->oo_W >= d->ob_W)
       return SF_EINVAL;
+  }
+  {  // the Fast pathway's stem: LDS-ring kernel instead of one L2 fetch per tap
+    const int rc = sf_conv_stem_fwd_try(d, in, w_packed, scale, bias, res, out, (hipStream_t)stream);
+    if (rc != 1) return rc;
   }
   ConvArgs a;
   a.d = *d;

@@ -179,6 +179,38 @@ def test_conv_stem_trick():
         assert err < TOL
 
 
+@pytest.mark.parametrize("shape", [(3, 9, 20, 40), (1, 12, 18, 70)])
+def test_conv_stem_ring_forward(shape):
+    """The Fast pathway's 5x7x7 stem through conv_stem_fwd_kernel (LDS ring): zero frames outside the clip in T,
+    ragged last 16-position block, the t range cut into parts, scale / bias / ReLU epilogue, channel-slice store."""
+    import sfhip
+    dev = _dev()
+    g = torch.Generator().manual_seed(11 + shape[0])
+    kt, cout = 5, 8
+    n, t, h, w = shape
+    x = torch.randn(n, 3, t, h, w, generator=g)
+    wt = torch.randn(cout, 3, kt, 7, 7, generator=g) / np.sqrt(147 * kt)
+    scale = torch.rand(cout, generator=g) + 0.5
+    bias = torch.randn(cout, generator=g) * 0.2
+    y = F.relu(F.conv3d(x, wt, None, (1, 2, 2), (kt // 2, 3, 3)) * scale.view(-1, 1, 1, 1) + bias.view(-1, 1, 1, 1))
+    wpx = (w + 6 + 1) // 2 * 2
+    xa = sfhip.from_ncthw(x.to(dev), cpad=4, ph=3, pw=3, wp=wpx)
+    w4 = torch.zeros(cout, 4, kt, 7, 7)
+    w4[:, :3] = wt
+    wp = torch.zeros(cout, kt * 7, 32)
+    wp[:, :, :28] = w4.permute(0, 2, 3, 4, 1).reshape(cout, kt * 7, 28)
+    view = sfhip.Act(xa.buf.view(n, t, h + 6, wpx // 2, 8))
+    ho, wo = y.shape[3], y.shape[4]
+    wide = sfhip.Act(torch.full((n, t, ho, wo, cout + 4), 7.0, device=dev)).slice(4, cout)  # store into a channel slice
+    out = sfhip.conv(view, wp.to(dev).contiguous(), (kt, 7, 1), (1, 2, 1), (kt // 2, 0, 0), cin=28,
+                     out_thw=(t, ho, wo), scale=scale.to(dev), bias=bias.to(dev), relu=True, out=wide)
+    torch.cuda.synchronize()
+    err = _rel(_back(out), y)
+    _report("conv/stem_ring %s" % (shape,), err)
+    assert err < TOL
+    assert float((wide.buf[..., :4] - 7.0).abs().max()) == 0.0, "neighbouring channels untouched"
+
+
 def test_conv_out_cmul():
     import sfhip
     dev = _dev()
