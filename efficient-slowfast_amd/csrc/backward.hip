@@ -16,6 +16,8 @@ inline int pow2ceil_b(int v) {
 }
 
 // g(n,t,hw,c..c+VEC) = sum_{q<rep} dy[n, t*rep+q, hw, c] * (relu ? y[n, t*rep, hw, c] > 0 : 1)
+// relu == 3 (SF_BN_MASK_BYTES): `y` is not the activation but the byte mask sf_affine_fwd_mask left, one byte per
+// 4 channels ([rows][C/4], y_cs = C/4; bit e = channel c+e passes): 1/16 of the activation's bytes per read.
 template <int VEC>
 __device__ __forceinline__ void bn_g(const float* __restrict__ dy, int dy_cs, int dy_coff,
                                      const float* __restrict__ y, int y_cs, int y_coff, long r, long THW, int HW,
@@ -38,7 +40,14 @@ __device__ __forceinline__ void bn_g(const float* __restrict__ dy, int dy_cs, in
       g[0] += d[0];
     }
   }
-  if (relu) {
+  if (relu == 3) {
+    if (VEC == 4) {
+      const unsigned mk = reinterpret_cast<const unsigned char*>(y)[r0 * y_cs + (c >> 2)];
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (!((mk >> e) & 1u)) g[e] = 0.f;
+    }
+  } else if (relu) {
     const float* yp = y + r0 * y_cs + y_coff + c;
     if (VEC == 4) {
       const f32x4 v = *reinterpret_cast<const f32x4*>(yp);
@@ -359,12 +368,14 @@ static int bn_bwd_reduce_launch(const float* dy, int dy_cs, int dy_coff, const f
                                 float* dgamma_acc = nullptr) {
   if ((dbeta_acc == nullptr) != (dgamma_acc == nullptr)) return SF_EINVAL;
   if (!dy || !z || !mean || !invstd || !dbeta || !dgamma || !ws || (relu && !y)) return SF_EINVAL;
+  if (relu == 3 && (rep != 1 || (C % 4) != 0 || y_cs != C / 4 || y_coff != 0)) return SF_EINVAL;
   if (N <= 0 || T <= 0 || H <= 0 || W <= 0 || C <= 0 || rep <= 0 || S <= 0 || N % S != 0) return SF_EINVAL;
   if (S > 1 && N > MAX_P) return SF_EINVAL;
   const long rows = (long)N * T * H * W;
   const bool vec4 = (C % 4 == 0) && (dy_cs % 4 == 0) && (dy_coff % 4 == 0) && (z_cs % 4 == 0) && (z_coff % 4 == 0) &&
                     sf_aligned16(dy) && sf_aligned16(z) &&
-                    (!relu || ((y_cs % 4 == 0) && (y_coff % 4 == 0) && sf_aligned16(y)));
+                    (!relu || relu == 3 || ((y_cs % 4 == 0) && (y_coff % 4 == 0) && sf_aligned16(y)));
+  if (relu == 3 && !vec4) return SF_EINVAL;  // the byte mask only exists on the float4 path
   const int groups = S > 1 ? N : 1;
   const long group_rows = rows / groups;
   int CB, P;
@@ -417,12 +428,14 @@ static int bn_bwd_apply_launch(const float* dy, int dy_cs, int dy_coff, const fl
                                const float* dbeta, const float* dgamma, float* dz, int dz_cs, int dz_coff,
                                float* dres, int dres_cs, int dres_coff, void* stream) {
   if (!dy || !z || !mean || !invstd || !gamma || !dbeta || !dgamma || !dz || (relu && !y)) return SF_EINVAL;
+  if (relu == 3 && (rep != 1 || (C % 4) != 0 || y_cs != C / 4 || y_coff != 0)) return SF_EINVAL;
   if (N <= 0 || T <= 0 || H <= 0 || W <= 0 || C <= 0 || rep <= 0 || S <= 0 || N % S != 0) return SF_EINVAL;
   const long rows = (long)N * T * H * W;
   const bool vec4 = (C % 4 == 0) && (dy_cs % 4 == 0) && (dy_coff % 4 == 0) && (z_cs % 4 == 0) && (z_coff % 4 == 0) &&
                     (dz_cs % 4 == 0) && (dz_coff % 4 == 0) && sf_aligned16(dy) && sf_aligned16(z) && sf_aligned16(dz) &&
-                    (!relu || ((y_cs % 4 == 0) && (y_coff % 4 == 0) && sf_aligned16(y))) &&
+                    (!relu || relu == 3 || ((y_cs % 4 == 0) && (y_coff % 4 == 0) && sf_aligned16(y))) &&
                     (!dres || ((dres_cs % 4 == 0) && (dres_coff % 4 == 0) && sf_aligned16(dres)));
+  if (relu == 3 && !vec4) return SF_EINVAL;  // the byte mask only exists on the float4 path
   const long total = rows * (vec4 ? C / 4 : C);
   if (vec4)
     hipLaunchKernelGGL(bn_bwd_apply_kernel<4>, dim3(sf_cdiv(total, TPB)), dim3(TPB), 0, (hipStream_t)stream, dy, dy_cs,

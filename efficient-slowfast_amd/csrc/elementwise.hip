@@ -467,7 +467,7 @@ __global__ __launch_bounds__(256) void affine_flat_kernel(const float* __restric
                                                           const float* __restrict__ bias,
                                                           const float* __restrict__ res, int res_cs, int res_coff,
                                                           int act, float* __restrict__ out, int out_cs, int out_coff,
-                                                          unsigned total) {
+                                                          unsigned char* __restrict__ mask, unsigned total) {
   constexpr int U = 4;
   const unsigned base = blockIdx.x * (TPB * U) + threadIdx.x;
   unsigned r[U], c[U];
@@ -486,7 +486,16 @@ __global__ __launch_bounds__(256) void affine_flat_kernel(const float* __restric
     if (res) v[u] += q[u];
 #pragma unroll
     for (int e = 0; e < 4; ++e) v[u][e] = sf_act(v[u][e], act);
-    if (base + u * TPB < total) *reinterpret_cast<f32x4*>(out + (long)r[u] * out_cs + out_coff + c[u]) = v[u];
+    if (base + u * TPB < total) {
+      *reinterpret_cast<f32x4*>(out + (long)r[u] * out_cs + out_coff + c[u]) = v[u];
+      if (mask) {  // which of the 4 channels pass a gradient through the activation (bn_bwd's relu == 3 mode)
+        unsigned mk = 0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          mk |= ((v[u][e] > 0.f && !(act == SF_ACT_RELU6 && !(v[u][e] < 6.f))) ? 1u : 0u) << e;
+        mask[base + u * TPB] = (unsigned char)mk;
+      }
+    }
   }
 }
 
@@ -729,7 +738,8 @@ extern "C" int sf_bn_train_stats_split(const float* x, int cs, int coff, int N, 
 
 static int affine_launch(const float* x, int cs, int coff, int N, int T, int H, int W, int C, int S,
                          const float* scale, const float* bias, const float* res, int res_cs, int res_coff,
-                         int act, int rep, float* out, int out_cs, int out_coff, int out_cmul, void* stream) {
+                         int act, int rep, float* out, int out_cs, int out_coff, int out_cmul, void* stream,
+                         unsigned char* mask = nullptr) {
   if (!x || !out || N <= 0 || T <= 0 || H <= 0 || W <= 0 || C <= 0 || rep <= 0 || out_cmul <= 0 || S <= 0)
     return SF_EINVAL;
   if ((scale == nullptr) != (bias == nullptr)) return SF_EINVAL;
@@ -745,8 +755,10 @@ static int affine_launch(const float* x, int cs, int coff, int N, int T, int H, 
     if ((cv & (cv - 1)) == 0)
       for (shift = 0; (1 << shift) < cv; ++shift) {}
     hipLaunchKernelGGL(affine_flat_kernel, dim3(sf_cdiv(total, TPB * 4)), dim3(TPB), 0, (hipStream_t)stream, x, cs,
-                       coff, cv, shift, scale, bias, res, res_cs, res_coff, act, out, out_cs, out_coff,
+                       coff, cv, shift, scale, bias, res, res_cs, res_coff, act, out, out_cs, out_coff, mask,
                        (unsigned)total);
+  } else if (mask) {
+    return SF_EINVAL;  // the byte mask is a product of the flat float4 kernel only
   } else if (vec4)
     hipLaunchKernelGGL(affine_kernel<4>, dim3(sf_cdiv(total, TPB)), dim3(TPB), 0, (hipStream_t)stream, x, cs, coff,
                        (long)T * H * W, H * W, C, S, scale, bias, res, res_cs, res_coff, act, rep, out, out_cs,
@@ -764,6 +776,18 @@ extern "C" int sf_affine_fwd(const float* x, int cs, int coff, int N, int T, int
                              int act, int rep, float* out, int out_cs, int out_coff, int out_cmul, void* stream) {
   return affine_launch(x, cs, coff, N, T, H, W, C, 1, scale, bias, res, res_cs, res_coff, act, rep, out, out_cs,
                        out_coff, out_cmul, stream);
+}
+
+// sf_affine_fwd that also leaves a byte per 4 channels saying which of them pass a gradient through the activation
+// (ReLU: y > 0; ReLU6: 0 < y < 6): mask[rows][C/4], read by sf_bn_bwd_reduce / sf_bn_bwd_apply with relu = 3 in place
+// of the activation itself (1/16 of its bytes, twice per backward).  Needs the flat float4 case: C % 4 == 0,
+// 16-byte addressable views, rep = 1, no channel multiplier; SF_EINVAL otherwise.
+extern "C" int sf_affine_fwd_mask(const float* x, int cs, int coff, int N, int T, int H, int W, int C,
+                                  const float* scale, const float* bias, const float* res, int res_cs, int res_coff,
+                                  int act, float* out, int out_cs, int out_coff, unsigned char* mask, void* stream) {
+  if (!mask || (act != SF_ACT_RELU && act != SF_ACT_RELU6)) return SF_EINVAL;
+  return affine_launch(x, cs, coff, N, T, H, W, C, 1, scale, bias, res, res_cs, res_coff, act, 1, out, out_cs,
+                       out_coff, 1, stream, mask);
 }
 
 extern "C" int sf_affine_fwd_split(const float* x, int cs, int coff, int N, int T, int H, int W, int C, int nsplit,

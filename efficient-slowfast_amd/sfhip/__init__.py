@@ -52,7 +52,7 @@ EXPORTS = [
     "sf_bn_train_stats_split", "sf_affine_fwd_split", "sf_bn_bwd_reduce_split", "sf_bn_bwd_apply_split",
     "sf_clip_prologue", "sf_conv_wgrad_finish", "sf_bn_bwd_reduce_acc", "sf_row_softmax_fwd", "sf_row_softmax_bwd",
     "sf_attn_bwd_fused_ws_floats", "sf_attn_bwd_fused", "sf_pack_conv_weight", "sf_conv_fwd_ws_floats",
-    "sf_conv_fwd_ws", "sf_attn_fwd_ws_floats", "sf_attn_fwd_ws",
+    "sf_conv_fwd_ws", "sf_attn_fwd_ws_floats", "sf_attn_fwd_ws", "sf_affine_fwd_mask",
 ]
 _LONG_RET = ("sf_tmax_mean_ws_floats", "sf_channel_stats_ws_floats", "sf_bn_bwd_ws_floats",
              "sf_dwconv_wgrad_ws_floats", "sf_attn_bwd_fused_ws_floats", "sf_conv_fwd_ws_floats",
@@ -85,6 +85,7 @@ def lib():
         L.sf_tmax_mean.argtypes = [vp, ci, ci] + [ci] * 6 + [vp, vp, vp]
         L.sf_gate_apply.argtypes = [vp, ci, ci] + [ci] * 6 + [vp, vp, vp, vp, ci, vp, ci, ci, vp]
         L.sf_attn_fwd.argtypes = [vp, ci, vp, ci, vp, ci, vp, ci, vp, vp, vp, ci, vp, ci, ci] + [ci] * 6 + [vp, vp, vp]
+        L.sf_affine_fwd_mask.argtypes = [vp, ci, ci] + [ci] * 5 + [vp, vp, vp, ci, ci, ci, vp, ci, ci, vp, vp]
         L.sf_attn_fwd_ws_floats.argtypes = [ci, ci, ci]
         L.sf_attn_fwd_ws_floats.restype = cl
         L.sf_attn_fwd_ws.argtypes = L.sf_attn_fwd.argtypes[:-1] + [vp, vp]
@@ -475,10 +476,16 @@ def channel_stats(x):
     return mean, var
 
 
+BN_MASK = os.environ.get("SF_BN_MASK", "1") != "0"  # byte masks instead of re-reading activations in BN backward
+
+
 def affine(x, scale=None, bias=None, res=None, relu=False, rep=1, out=None, out_reserve=(0, 0), out_cmul=1,
-           nsplit=1):
+           nsplit=1, mask=None):
     """out = act(x*scale + bias + res), repeated `rep` times along T (nearest upsample).  nsplit > 1: scale/bias
-    hold nsplit*C entries and sample n uses block n % nsplit (SubBatchNorm3d)."""
+    hold nsplit*C entries and sample n uses block n % nsplit (SubBatchNorm3d).
+    mask: optional dict (training, ReLU / ReLU6 layers): when the layer qualifies for the flat float4 kernel it
+    receives 'bytes', a uint8 tensor [rows * C/4] with one pass-through bit per channel, which bn_bwd(mask=...)
+    reads instead of the activation."""
     _require_gpu(x.buf, "affine")
     if out is None:
         out = new_act(x, x.N, x.T * rep, x.H, x.W, x.C, out_reserve[0], out_reserve[1])
@@ -487,6 +494,18 @@ def affine(x, scale=None, bias=None, res=None, relu=False, rep=1, out=None, out_
         assert out.coff + (x.C - 1) * out_cmul < out.cs and (out_cmul > 1 or out.C == x.C), (out, x)
     if res is not None:
         assert res.rows == x.rows and res.C == x.C
+    if (mask is not None and BN_MASK and relu and rep == 1 and nsplit == 1 and out_cmul == 1 and x.C % 4 == 0 and
+            x.cs % 4 == 0 and x.coff % 4 == 0 and out.cs % 4 == 0 and out.coff % 4 == 0 and
+            x.rows * (x.C // 4) < 2 ** 31 - 1 and scale is not None and
+            (res is None or (res.cs % 4 == 0 and res.coff % 4 == 0))):
+        mk = torch.empty((x.rows * (x.C // 4),), dtype=torch.uint8, device=x.buf.device)
+        _check(lib().sf_affine_fwd_mask(
+            x.ptr(), x.cs, x.coff, x.N, x.T, x.H, x.W, x.C, _ptr(scale), _ptr(bias),
+            res.ptr() if res is not None else None, res.cs if res is not None else 0,
+            res.coff if res is not None else 0, _act(relu), out.ptr(), out.cs, out.coff, _ptr(mk), _stream()),
+            "sf_affine_fwd_mask")
+        mask["bytes"] = mk
+        return out
     tail = (_ptr(scale), _ptr(bias), res.ptr() if res is not None else None, res.cs if res is not None else 0,
             res.coff if res is not None else 0, _act(relu), rep, out.ptr(), out.cs, out.coff, out_cmul, _stream())
     if nsplit == 1:
@@ -599,7 +618,7 @@ def unpack_conv_weight_grad(dwp, shape):
 
 
 def bn_bwd(dy, y, z, mean, invstd, gamma, relu, rep=1, dres=None, dz_out=None, dgamma_out=None, nsplit=1,
-           sync=None, grad_sink=None):
+           sync=None, grad_sink=None, mask=None):
     """Training BN backward (+ReLU mask, + residual fan-out, + upsample-copy sum).  Returns (dz, dgamma, dbeta);
     dz is written over z unless dz_out is given.
     nsplit > 1 (SubBatchNorm3d): mean/invstd/gamma and the returned sums hold nsplit*C entries [split*C + c].
@@ -613,8 +632,12 @@ def bn_bwd(dy, y, z, mean, invstd, gamma, relu, rep=1, dres=None, dz_out=None, d
     dgamma = torch.empty((nsplit * C,), dtype=torch.float32, device=dev)
     ws = torch.empty((lib().sf_bn_bwd_ws_floats(C),), dtype=torch.float32, device=dev)
     yp, ycs, yco = (y.ptr(), y.cs, y.coff) if y is not None else (None, 0, 0)
+    code = 2 if relu == 6 else (1 if relu else 0)
+    if mask is not None and relu:  # the byte mask affine(mask=...) left: read instead of the activation
+        assert rep == 1 and nsplit == 1 and mask.numel() == z.rows * (C // 4)
+        yp, ycs, yco, code = _ptr(mask), C // 4, 0, 3
     head = (dy.ptr(), dy.cs, dy.coff, yp, ycs, yco, z.ptr(), z.cs, z.coff, z.N, z.T, z.H, z.W, C)
-    tail = (rep, 2 if relu == 6 else (1 if relu else 0), _ptr(mean), _ptr(invstd))
+    tail = (rep, code, _ptr(mean), _ptr(invstd))
     split = (nsplit,) if nsplit > 1 else ()
     reduce_fn = lib().sf_bn_bwd_reduce_split if nsplit > 1 else lib().sf_bn_bwd_reduce
     apply_fn = lib().sf_bn_bwd_apply_split if nsplit > 1 else lib().sf_bn_bwd_apply

@@ -376,12 +376,17 @@ def bn_train_apply(bn, z, res=None, relu=False, rep=1, out=None, out_reserve=(0,
         scale, shift = scale[:keep].contiguous(), shift[:keep].contiguous()
     t = tape()
     shuffled = t is not None and out_cmul != 1
+    # taped ReLU / ReLU6 layers: the normalise pass also leaves a byte per 4 channels for the backward's mask, which
+    # then reads that instead of the activation (1/16 of the bytes, twice per backward)
+    mk = {} if (t is not None and relu) else None
     if shuffled:
         # training: a channel-shuffled store is an explicit (taped) strided copy of the dense result
-        y = sfhip.affine(zz, scale.contiguous(), shift.contiguous(), res=res, relu=relu, rep=rep, nsplit=nsplit)
+        y = sfhip.affine(zz, scale.contiguous(), shift.contiguous(), res=res, relu=relu, rep=rep, nsplit=nsplit,
+                         mask=mk)
     else:
         y = sfhip.affine(zz, scale.contiguous(), shift.contiguous(), res=res, relu=relu, rep=rep, out=out,
-                         out_reserve=out_reserve, out_cmul=out_cmul, nsplit=nsplit)
+                         out_reserve=out_reserve, out_cmul=out_cmul, nsplit=nsplit, mask=mk)
+    mask = mk.get("bytes") if mk else None
     if t is not None:
         if _GRAD_SINK:
             dg = db = None  # allocated lazily by the fallback below
@@ -396,12 +401,12 @@ def bn_train_apply(bn, z, res=None, relu=False, rep=1, out=None, out_reserve=(0,
             bt = t.pgrad_target(bn.bias) if wt is not None else None
             if wt is not None and bt is not None:  # dgamma / dbeta accumulate into .grad inside the reduction
                 sfhip.bn_bwd(t.grad_of(y), y, zz, mean[sel], invstd[sel], gamma_b[sel], relu, rep=rep, dres=dres,
-                             dz_out=zz, sync=sync, grad_sink=(wt, bt))
+                             dz_out=zz, sync=sync, grad_sink=(wt, bt), mask=mask)
             else:
                 dg_ = dg if dg is not None else torch.zeros(z.C, dtype=torch.float32, device=z.buf.device)
                 db_ = db if db is not None else torch.zeros(z.C, dtype=torch.float32, device=z.buf.device)
                 sfhip.bn_bwd(t.grad_of(y), y, zz, mean[sel], invstd[sel], gamma_b[sel], relu, rep=rep, dres=dres,
-                             dz_out=zz, dgamma_out=(dg_, db_), nsplit=nsplit, sync=sync)
+                             dz_out=zz, dgamma_out=(dg_, db_), nsplit=nsplit, sync=sync, mask=mask)
             if keep is not None and keep < z.C:  # sliced-away channels (GhostModule [:oup]) get no gradient
                 rest = z.slice(keep, z.C - keep)
                 sfhip.axpy(rest, rest, alpha=0.0, accumulate=False)

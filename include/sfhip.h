@@ -209,8 +209,18 @@ int sf_conv_wgrad_finish(const float* partial, int S, int Cout, int packed_taps,
 
 /* Training BatchNorm3d backward fused with ReLU mask (y > 0), residual fan-out (dres += g) and the sum over
  * `rep` nearest-upsampled copies:  g = sum_q dy * [y > 0];  dbeta = sum g;  dgamma = sum g * xhat;
- * dz = gamma * invstd * (g - dbeta/M - xhat * dgamma/M)  (dz may alias z).  ws: sf_bn_bwd_ws_floats(C). */
+ * dz = gamma * invstd * (g - dbeta/M - xhat * dgamma/M)  (dz may alias z).  ws: sf_bn_bwd_ws_floats(C).
+ * relu: 0 none, 1 ReLU (y > 0), 2 ReLU6 (0 < y < 6), 3 = SF_BN_MASK_BYTES: `y` is the byte mask sf_affine_fwd_mask
+ * left in the forward pass (cast to const float*; y_cs = C/4, y_coff = 0, rep = 1, float4-addressable views) — the
+ * backward then reads 1/16 of the activation's bytes for the mask, twice.                                       */
+#define SF_BN_MASK_BYTES 3
 long sf_bn_bwd_ws_floats(int C);
+/* sf_affine_fwd (below) for a ReLU / ReLU6 layer that also leaves mask[rows][C/4]: bit e of a byte says channel
+ * 4i+e passes a gradient through the activation.  Flat float4 case only (C % 4 == 0, 16-byte addressable views, no
+ * T repeat, no channel multiplier): SF_EINVAL otherwise.                                                        */
+int sf_affine_fwd_mask(const float* x, int cs, int coff, int N, int T, int H, int W, int C, const float* scale,
+                       const float* bias, const float* res, int res_cs, int res_coff, int act, float* out,
+                       int out_cs, int out_coff, unsigned char* mask, void* stream);
 int sf_bn_bwd_reduce(const float* dy, int dy_cs, int dy_coff, const float* y, int y_cs, int y_coff,
                      const float* z, int z_cs, int z_coff, int N, int T, int H, int W, int C, int rep, int relu,
                      const float* mean, const float* invstd, float* dbeta, float* dgamma, float* ws, void* stream);

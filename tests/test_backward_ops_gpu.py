@@ -321,6 +321,47 @@ def test_attention_backward_query_parts(parts):
     assert "passed" in r.stdout
 
 
+@pytest.mark.parametrize("c,relu,use_res,wide", [(64, True, True, False), (8, True, False, True), (48, 6, False, False),
+                                                 (256, 6, True, True)])
+def test_bn_backward_byte_mask(c, relu, use_res, wide):
+    """The normalise pass can leave a byte per 4 channels (which of them pass a gradient through ReLU / ReLU6) and
+    the BN backward reads that instead of the activation: bit-identical dz / dres / dgamma / dbeta to the
+    activation-reading form, for dense and channel-slice views."""
+    import sfhip
+    dev = _dev()
+    g = torch.Generator().manual_seed(c + (7 if use_res else 0))
+    shp = (2, 3, 5, 6, c)
+    z = torch.randn(shp, generator=g) * 1.5 + 0.3
+    gamma = (torch.rand(c, generator=g) + (2.5 if relu == 6 else 0.5)).to(dev)
+    beta = (torch.randn(c, generator=g) * 0.1 + (2.0 if relu == 6 else 0.0)).to(dev)
+    res = sfhip.Act(torch.randn(shp, generator=g).to(dev)) if use_res else None
+    dy = sfhip.Act(torch.randn(shp, generator=g).to(dev))
+
+    def run(with_mask):
+        za = sfhip.Act(z.to(dev).clone())
+        mean, invstd, scale, shift = sfhip.bn_train_stats(za, gamma, beta, 1e-5, 0.1, None, None)
+        if wide:  # the activation lives in a channel slice of a wider buffer
+            out = sfhip.Act(torch.zeros(shp[:4] + (c + 8,), device=dev)).slice(4, c)
+        else:
+            out = None
+        mk = {} if with_mask else None
+        y = sfhip.affine(za, scale, shift, res=res, relu=relu, out=out, mask=mk)
+        if with_mask:
+            assert "bytes" in mk and mk["bytes"].dtype == torch.uint8 and mk["bytes"].numel() == za.rows * (c // 4)
+        dres = sfhip.Act(torch.ones(shp, device=dev)) if use_res else None
+        dz, dg, db = sfhip.bn_bwd(dy, y, za, mean, invstd, gamma, relu, dres=dres,
+                                  mask=mk["bytes"] if with_mask else None)
+        torch.cuda.synchronize()
+        return y.buf.clone(), dz.buf.clone(), dg.clone(), db.clone(), (dres.buf.clone() if use_res else None)
+
+    a, b = run(True), run(False)
+    for u, v in zip(a, b):
+        if u is not None:
+            assert torch.equal(u, v)
+    passed = float((a[0][..., -c:] > 0).float().mean())
+    assert 0.05 < passed < 0.98, passed  # the mask is neither all ones nor all zeros
+
+
 @pytest.mark.parametrize("c,k,s", [(32, (3, 3, 3), (1, 1, 1)), (12, (1, 5, 5), (1, 2, 2)), (27, (3, 3, 3), (1, 2, 2))])
 def test_dwconv_backward(c, k, s):
     import sfhip
