@@ -5,6 +5,7 @@ usage: tools/prof_convs.py [workload] [batch]"""
 import os
 import sys
 
+os.environ["SF_OVERLAP_PATHS"] = "0"  # one stream: an event pair around a call then times that call, not a join wait
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "efficient-slowfast_amd")]
 import torch  # noqa: E402
