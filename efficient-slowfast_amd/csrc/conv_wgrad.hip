@@ -670,7 +670,13 @@ extern "C" int sf_conv_wgrad_splits(const sf_conv_desc* d) {
   const long M = (long)d->N * d->To * d->Ho * d->Wo;
   const long tiles = (long)sf_cdiv(d->Cout, bco) * sf_cdiv(bco <= 32 ? d->cin_pad : d->Cin, bci) * d->kT * d->kH *
                      d->kW;
-  long S = (1536 + tiles - 1) / tiles;            // aim at ~1536 workgroups (6 per CU)
+  static const long target = [] {
+    const char* e = getenv("SF_WGRAD_WGS");  // tuning aid
+    return e ? atol(e) : 768L;
+  }();
+  // aim at ~768 workgroups (3 per CU): every workgroup writes its whole partial tile, so the partial traffic (and
+  // the sum over S afterwards) grows with the split count — 1536 measured 75.5 ms per train step, 768 75.1, 256 76.0
+  long S = (target + tiles - 1) / tiles;
   const long maxS = (M + 255) / 256;              // at least 256 positions per split
   if (S > maxS) S = maxS;
   if (S < 1) S = 1;
