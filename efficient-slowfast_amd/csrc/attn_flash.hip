@@ -24,6 +24,7 @@
 //     buffered, one barrier per tile.
 // fp32 throughout (the reference never leaves fp32; gfx950 has no reduced-precision f32 MFMA path).
 #include "attn_args.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -355,7 +356,16 @@ static int attn_fwd_impl(const float* q, int q_cs, const float* k, int k_cs, con
                     (out_cs % 4 == 0) && (out_coff % 4 == 0) && sf_aligned16(q) && sf_aligned16(k) &&
                     sf_aligned16(v) && sf_aligned16(x) && sf_aligned16(out);
   hipStream_t s = (hipStream_t)stream;
-  if (C <= 16)  // 16-query wavefronts on 16x16x4 tiles: no padded rows in the second product
+  // C <= 16: 16-query wavefronts on 16x16x4 tiles (no padded rows in the second product).  The same kernel also
+  // instantiates for 16 < C <= 32 (SF_ATTN_FWD32=small) — a probe of whether the 16x16x4 shape, which sustains a
+  // higher clock than 32x32x2 in a bare MFMA loop on this part, pays at d = 32: it does not in this form (one
+  // ds_read_b32 per MFMA for K^T and V, twice the softmax rows per FLOP): 5.6 -> 6.1 ms at N = 25 088, eval forward
+  // 19.31 -> 19.78 ms.  The 32x32x2 kernel stays the default.
+  static const bool small32 = [] {
+    const char* e = getenv("SF_ATTN_FWD32");
+    return e && e[0] == 's';
+  }();
+  if (C <= 16 || (C <= 32 && small32))
     return sf_attn_small_dispatch(q, q_cs, k, k_cs, v, v_cs, x, x_cs, gamma, scale, bias, act, out, out_cs,
                                   out_coff, B, T, H, W, C, alpha, o_save, lse_save, vec4, ws, s);
   const int cp = C <= 32 ? 32 : (C <= 64 ? 64 : 128);

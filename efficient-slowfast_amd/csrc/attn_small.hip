@@ -25,9 +25,11 @@ __global__ __launch_bounds__(256) void attn_small_kernel(const AttnArgs p) {
   constexpr int KT = 64;                        // keys per LDS tile = one softmax step
   constexpr int QS = CP / 4;                    // MFMA k-steps of the first product
   constexpr int KP = KT + 16;                   // K^T row pitch: quarter g lands 16 banks further
-  constexpr int VP = (CP == 16) ? 20 : 12;      // V row pitch: rows 4 apart land 16 banks apart
+  constexpr int VP = (CP == 32) ? 36 : ((CP == 16) ? 20 : 12);  // V row pitch: rows 4 apart land 16 banks apart
   constexpr int F4 = CP / 4;
-  constexpr int NLD = KT * F4;                  // float4 per tile (K and V each), <= 256
+  constexpr int NLD = KT * F4;                  // float4 per tile (K and V each)
+  constexpr int LIT = (NLD + 255) / 256;        // staging passes (2 for CP = 32)
+  constexpr int CTN = (CP + 15) / 16;           // 16-channel output tiles (2 for CP = 32)
 
   __shared__ __attribute__((aligned(16))) float smem[2 * (CP * KP + KT * VP)];
   float* const Kt = smem;
@@ -62,42 +64,55 @@ __global__ __launch_bounds__(256) void attn_small_kernel(const AttnArgs p) {
   // into the V tile's pad column), so O^T row CP accumulates the softmax denominator on the matrix core
   // with exactly the same rescaling as O — no per-element VALU adds.
   constexpr bool ONES_ROW = CP < 16;
-  f32x4 o0 = {0.f, 0.f, 0.f, 0.f}, o1 = {0.f, 0.f, 0.f, 0.f};
+  f32x4 o0[CTN], o1[CTN];
+#pragma unroll
+  for (int ct = 0; ct < CTN; ++ct) {
+    o0[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    o1[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
   float m_run = NEG_BIG;
   float l_run = 0.f;
 
-  // ---- staging: thread tid < NLD owns float4 (row = tid / F4, channels 4*(tid % F4) ..)
-  const int srow = tid / F4;
-  const int sc4 = (tid - srow * F4) * 4;
-  f32x4 rk = {0.f, 0.f, 0.f, 0.f}, rv = {0.f, 0.f, 0.f, 0.f};
+  // ---- staging: float4 f = tid + 256 i (< NLD) is (row = f / F4, channels 4*(f % F4) ..)
+  f32x4 rk[LIT], rv[LIT];
   auto load_tile = [&](int j0) {
-    rk = (f32x4){0.f, 0.f, 0.f, 0.f};
-    rv = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const int j = j0 + srow;
-    if (tid < NLD && j < N) {
-      const float* kp = p.k + (brow + j) * p.k_cs + sc4;
-      const float* vp = p.v + (brow + j) * p.v_cs + sc4;
-      if (VEC == 4) {
-        if (sc4 < C) {
-          rk = *reinterpret_cast<const f32x4*>(kp);
-          rv = *reinterpret_cast<const f32x4*>(vp);
-        }
-      } else {
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
-          if ((sc4 + e) < C) {
-            rk[e] = kp[e];
-            rv[e] = vp[e];
+    for (int i = 0; i < LIT; ++i) {
+      const int f = tid + i * 256;
+      const int srow = f / F4, sc4 = (f - srow * F4) * 4;
+      rk[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      rv[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      const int j = j0 + srow;
+      if (f < NLD && j < N) {
+        const float* kp = p.k + (brow + j) * p.k_cs + sc4;
+        const float* vp = p.v + (brow + j) * p.v_cs + sc4;
+        if (VEC == 4) {
+          if (sc4 < C) {
+            rk[i] = *reinterpret_cast<const f32x4*>(kp);
+            rv[i] = *reinterpret_cast<const f32x4*>(vp);
           }
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if ((sc4 + e) < C) {
+              rk[i][e] = kp[e];
+              rv[i][e] = vp[e];
+            }
+        }
       }
     }
   };
   auto store_tile = [&](int buf) {
-    if (tid < NLD) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) Kt[(buf * CP + sc4 + e) * KP + srow] = rk[e];
-      *reinterpret_cast<f32x4*>(Vs + (buf * KT + srow) * VP + sc4) = rv;
-      if (ONES_ROW && sc4 == 0) Vs[(buf * KT + srow) * VP + CP] = 1.0f;
+    for (int i = 0; i < LIT; ++i) {
+      const int f = tid + i * 256;
+      const int srow = f / F4, sc4 = (f - srow * F4) * 4;
+      if (f < NLD) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) Kt[(buf * CP + sc4 + e) * KP + srow] = rk[i][e];
+        *reinterpret_cast<f32x4*>(Vs + (buf * KT + srow) * VP + sc4) = rv[i];
+        if (ONES_ROW && sc4 == 0) Vs[(buf * KT + srow) * VP + CP] = 1.0f;
+      }
     }
   };
 
@@ -151,10 +166,12 @@ __global__ __launch_bounds__(256) void attn_small_kernel(const AttnArgs p) {
     m_run = mnew;
     if (__any(alpha != 1.0f)) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        o0[r] *= alpha;
-        o1[r] *= alpha;
-      }
+      for (int ct = 0; ct < CTN; ++ct)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          o0[ct][r] *= alpha;
+          o1[ct][r] *= alpha;
+        }
     }
     // ---- O^T += V^T P^T (lanes li > CP re-read column 0: their output rows are never stored)
     const float* vbase = Vs + (buf * KT + 4 * lg) * VP + (ONES_ROW ? (li <= CP ? li : 0) : li);
@@ -162,35 +179,42 @@ __global__ __launch_bounds__(256) void attn_small_kernel(const AttnArgs p) {
     for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
       for (int r = 0; r < 4; r += 2) {
-        o0 = __builtin_amdgcn_mfma_f32_16x16x4f32(vbase[(kt * 16 + r) * VP], s[kt][r], o0, 0, 0, 0);
-        o1 = __builtin_amdgcn_mfma_f32_16x16x4f32(vbase[(kt * 16 + r + 1) * VP], s[kt][r + 1], o1, 0, 0, 0);
+#pragma unroll
+        for (int ct = 0; ct < CTN; ++ct) {
+          o0[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(vbase[(kt * 16 + r) * VP + 16 * ct], s[kt][r], o0[ct], 0, 0, 0);
+          o1[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(vbase[(kt * 16 + r + 1) * VP + 16 * ct], s[kt][r + 1], o1[ct],
+                                                        0, 0, 0);
+        }
       }
     if (more) store_tile(buf ^ 1);
     __syncthreads();
   }
 
-  // ---- epilogue: lane (i, g) holds channels 4g..4g+3 of query i
-  f32x4 o;
+  // ---- epilogue: lane (i, g) holds channels 16 ct + 4g .. +3 of query i
+  f32x4 o[CTN];
 #pragma unroll
-  for (int r = 0; r < 4; ++r) o[r] = o0[r] + o1[r];
+  for (int ct = 0; ct < CTN; ++ct)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) o[ct][r] = o0[ct][r] + o1[ct][r];
   float l_tot;
   if (ONES_ROW) {  // denominator = O^T row CP: lane (i, g = CP/4), register 0
-    l_tot = __shfl(o[0], li + 16 * (CP / 4), 64);
+    l_tot = __shfl(o[0][0], li + 16 * (CP / 4), 64);
   } else {
     l_tot = l_run + __shfl_xor(l_run, 16, 64);
     l_tot += __shfl_xor(l_tot, 32, 64);
   }
   const int qrow = q0 + li;
-  const int c0 = 4 * lg;
   if (p.zs > 1) {  // this key part's (O^T, m, l): merged and finished by attn_fwd_merge_kernel (attn_flash.hip)
     if (qrow < N) {
       const long prow = (long)bz * N + qrow;
       if (lg == 0) *reinterpret_cast<float2*>(p.part_ml + prow * 2) = make_float2(m_run, l_tot);
-      if (c0 < CP) *reinterpret_cast<f32x4*>(p.part_o + prow * CP + c0) = o;
+#pragma unroll
+      for (int ct = 0; ct < CTN; ++ct)
+        if (16 * ct + 4 * lg < CP) *reinterpret_cast<f32x4*>(p.part_o + prow * CP + 16 * ct + 4 * lg) = o[ct];
     }
     return;
   }
-  if (qrow >= N || c0 >= C) return;
+  if (qrow >= N) return;
   const float inv_l = 1.0f / l_tot;
   if (p.lse_save && lg == 0) p.lse_save[brow + qrow] = m_run + __log2f(l_tot);
   const float gamma = p.gamma ? p.gamma[0] : 1.0f;
@@ -199,25 +223,30 @@ __global__ __launch_bounds__(256) void attn_small_kernel(const AttnArgs p) {
   const int hw = qrow - tq * HW;
   const float* xp = p.x + (brow + qrow) * p.x_cs;
   const long orow0 = ((long)b * p.T * p.alpha + (long)tq * p.alpha) * HW + hw;
-  float y[4];
 #pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    const int c = c0 + e;
-    const bool okc = c < C;
-    if (p.o_save && okc) p.o_save[(brow + qrow) * C + c] = o[e] * inv_l;
-    float v = gamma * (o[e] * inv_l) + (okc ? xp[c] : 0.f);
-    if (p.scale && okc) v = v * p.scale[c] + p.bias[c];
-    if (p.act == SF_ACT_RELU) v = fmaxf(v, 0.f);
-    y[e] = v;
-  }
-  for (int r = 0; r < p.alpha; ++r) {
-    float* op = p.out + (orow0 + (long)r * HW) * p.out_cs + p.out_coff + c0;
-    if (VEC == 4) {
-      *reinterpret_cast<f32x4*>(op) = (f32x4){y[0], y[1], y[2], y[3]};
-    } else {
+  for (int ct = 0; ct < CTN; ++ct) {
+    const int c0 = 16 * ct + 4 * lg;
+    if (c0 >= C) continue;
+    float y[4];
 #pragma unroll
-      for (int e = 0; e < 4; ++e)
-        if ((c0 + e) < C) op[e] = y[e];
+    for (int e = 0; e < 4; ++e) {
+      const int c = c0 + e;
+      const bool okc = c < C;
+      if (p.o_save && okc) p.o_save[(brow + qrow) * C + c] = o[ct][e] * inv_l;
+      float v = gamma * (o[ct][e] * inv_l) + (okc ? xp[c] : 0.f);
+      if (p.scale && okc) v = v * p.scale[c] + p.bias[c];
+      if (p.act == SF_ACT_RELU) v = fmaxf(v, 0.f);
+      y[e] = v;
+    }
+    for (int r = 0; r < p.alpha; ++r) {
+      float* op = p.out + (orow0 + (long)r * HW) * p.out_cs + p.out_coff + c0;
+      if (VEC == 4) {
+        *reinterpret_cast<f32x4*>(op) = (f32x4){y[0], y[1], y[2], y[3]};
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if ((c0 + e) < C) op[e] = y[e];
+      }
     }
   }
 }
@@ -249,9 +278,10 @@ int sf_attn_small_dispatch(const float* q, int q_cs, const float* k, int k_cs, c
   a.zs = 1; a.part_o = nullptr; a.part_ml = nullptr;
   if (ws) {
     a.zs = sf_sweep_parts((long)B * a.nqt, sf_cdiv(a.N, 64));
-    sf_attn_place_parts(a, C <= 4 ? 4 : (C <= 8 ? 8 : 16), ws);
+    sf_attn_place_parts(a, C <= 4 ? 4 : (C <= 8 ? 8 : (C <= 16 ? 16 : 32)), ws);
   }
   if (C <= 4) return launch<4>(a, vec4, stream);
   if (C <= 8) return launch<8>(a, vec4, stream);
-  return launch<16>(a, vec4, stream);
+  if (C <= 16) return launch<16>(a, vec4, stream);
+  return launch<32>(a, vec4, stream);
 }

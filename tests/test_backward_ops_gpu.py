@@ -313,6 +313,8 @@ def test_attention_backward_query_parts(parts):
     if os.environ.get("SF_SWEEP_PARTS"):
         pytest.skip("already inside the forced-parts child")
     env = dict(os.environ, SF_SWEEP_PARTS=str(parts))
+    if parts == 3:  # also take the 16x16x4 forward kernel's d = 32 instantiation (off by default) through the suite
+        env["SF_ATTN_FWD32"] = "small"
     fwd = os.path.join(os.path.dirname(__file__), "test_ops_gpu.py")  # its forward tests cut the KEY sweep alike
     r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", __file__, fwd, "-k",
                         "(test_attention_backward and not query_parts) or test_attention"], env=env,
