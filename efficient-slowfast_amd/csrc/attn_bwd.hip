@@ -345,7 +345,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const BwdArgs p) {
 // summed in a FIXED order through LDS and stored to a workspace plane per 128-key block; a second kernel sums the
 // planes (no float atomics: results stay bit-reproducible; the workspace is 5 GB at N = 25 088, d = 32, B = 8).
 template <int CP, int NW>
-__global__ __launch_bounds__(64 * NW) void attn_bwd_fused_kernel(const BwdArgs p, float* __restrict__ ws) {
+__global__ __launch_bounds__(64 * NW, (CP >= 64) ? 2 : 1) void attn_bwd_fused_kernel(const BwdArgs p, float* __restrict__ ws) {
   constexpr int NT = 64 * NW;                  // threads; the workgroup owns 32*NW keys
   constexpr int QT = (CP >= 64) ? 32 : 64;    // queries per LDS tile
   constexpr int NSUB = QT / 32;
