@@ -70,3 +70,44 @@ def test_sub_bn_aggregate_matches_oracle():
     assert list(sb.state_dict().keys()) == ["weight", "bias", "bn.running_mean", "bn.running_var",
                                             "bn.num_batches_tracked", "split_bn.running_mean",
                                             "split_bn.running_var", "split_bn.num_batches_tracked"]
+
+
+def _conv_desc(n, t, h, w, cin, cout, k, stride=(1, 1, 1), cin_pad=None, in_cs=None, pad=None):
+    import sfhip
+    pad = tuple(kk // 2 for kk in k) if pad is None else pad
+    od = [(i + 2 * p - kk) // s + 1 for i, p, kk, s in zip((t, h, w), pad, k, stride)]
+    cin_pad = (cin + 15) // 16 * 16 if cin_pad is None else cin_pad
+    return sfhip.ConvDesc(n, t, h, w, cin, in_cs or cin, 0, od[0], od[1], od[2], cout, cout, 0, 1, k[0], k[1], k[2],
+                          stride[0], stride[1], stride[2], pad[0], pad[1], pad[2], 1, 1, 1, cin_pad, 0, 0, 0, 0)
+
+
+def test_launch_planning_queries_are_host_only_and_fill_the_chip():
+    """The workspace / split queries of the C ABI are pure host logic (callable without a GPU): the weight-gradient
+    position splits land near the 768-workgroup target on whole rounds of 256, split-K workspaces appear exactly for
+    the short-M / long-K layers, the Fast stem takes the one-workgroup-per-CU ring kernel, and the attention
+    workspaces hold their planes / parts."""
+    import ctypes
+    import sfhip
+    L = sfhip.lib()
+    # res2 3x3 64->64 at 8x8x56x56: 9 tiles of 64x64 per tap set -> S chosen so that 9*S workgroups fill whole rounds
+    d = _conv_desc(8, 8, 56, 56, 64, 64, (1, 3, 3))
+    S = L.sf_conv_wgrad_splits(ctypes.byref(d))
+    wg = 9 * S
+    assert 512 <= wg <= 1024 and wg / (-(-wg // 256) * 256) >= 0.94, (S, wg)
+    assert L.sf_conv_fwd_ws_floats(ctypes.byref(d)) == 0                       # 1568 tiles: no split-K
+    # res4 3x1x1 1024->256 at M = 12544: 196 tiles, 192 K steps -> split-K with a [S][M][Cout] workspace
+    d4 = _conv_desc(8, 8, 14, 14, 1024, 256, (3, 1, 1))
+    n = L.sf_conv_fwd_ws_floats(ctypes.byref(d4))
+    assert n > 0 and n % (12544 * 256) == 0 and 2 <= n // (12544 * 256) <= 12
+    # Fast stem in the stem-trick layout (5x7x1 over pixels of 8 floats, 28 packed channels): persistent ring kernel
+    ds = _conv_desc(8, 32, 230, 115, 28, 8, (5, 7, 1), stride=(1, 2, 1), cin_pad=32, in_cs=8, pad=(2, 0, 0))
+    ds.Wo = 112
+    assert (ds.To, ds.Ho) == (32, 112)
+    assert L.sf_conv_wgrad_splits(ctypes.byref(ds)) == 256
+    # attention workspaces: dQ planes (one per 128 / 64 keys) + room for 8 dK / dV parts; forward: 8 key parts
+    B, N = 8, 25088
+    assert L.sf_attn_bwd_fused_ws_floats(B, N, 32) == B * (N // 128 + 16) * N * 32
+    assert L.sf_attn_bwd_fused_ws_floats(B, N, 8) == B * (N // 64 + 16) * N * 8
+    assert L.sf_attn_bwd_fused_ws_floats(B, N, 128) == 0                       # d = 128 keeps the two-kernel form
+    assert L.sf_attn_fwd_ws_floats(B, N, 32) == B * 8 * N * 34
+    assert L.sf_attn_fwd_ws_floats(0, N, 32) == 0 and L.sf_attn_fwd_ws_floats(B, N, 129) == 0
