@@ -469,12 +469,59 @@ extern "C" int sf_bn_bwd_apply_split(const float* dy, int dy_cs, int dy_coff, co
                              mean, invstd, gamma, dbeta, dgamma, dz, dz_cs, dz_coff, dres, dres_cs, dres_coff, stream);
 }
 
+// Four channels per thread, 32-bit index arithmetic (the scalar kernel above pays four 64-bit divisions per element
+// and runs at a third of the HBM rate): taken when every view is float4-addressable and the element count fits.
+__global__ __launch_bounds__(256) void maxpool_bwd_vec4_kernel(const sf_pool_desc d, const float* __restrict__ x,
+                                                               const float* __restrict__ y,
+                                                               const float* __restrict__ dy, int dy_cs, int dy_coff,
+                                                               float* __restrict__ dx, int dx_cs, int dx_coff,
+                                                               unsigned total) {
+  const unsigned idx = blockIdx.x * TPB + threadIdx.x;
+  if (idx >= total) return;
+  const unsigned cv = d.C >> 2;
+  const unsigned rin = idx / cv;
+  const int c = (int)(idx - rin * cv) * 4;
+  unsigned r = rin;
+  const int wi = (int)(r % (unsigned)d.Wi);
+  r /= (unsigned)d.Wi;
+  const int hi = (int)(r % (unsigned)d.Hi);
+  r /= (unsigned)d.Hi;
+  const int ti = (int)(r % (unsigned)d.Ti);
+  const int n = (int)(r / (unsigned)d.Ti);
+  const f32x4 xv = *reinterpret_cast<const f32x4*>(x + (long)rin * d.in_cs + d.in_coff + c);
+  auto lo = [](int i, int p, int k, int s) { const int a = i + p - k + 1; return a <= 0 ? 0 : (a + s - 1) / s; };
+  const int t0 = lo(ti, d.pT, d.kT, d.sT), t1 = min((ti + d.pT) / d.sT, d.To - 1);
+  const int h0 = lo(hi, d.pH, d.kH, d.sH), h1 = min((hi + d.pH) / d.sH, d.Ho - 1);
+  const int w0 = lo(wi, d.pW, d.kW, d.sW), w1 = min((wi + d.pW) / d.sW, d.Wo - 1);
+  f32x4 g = {0.f, 0.f, 0.f, 0.f};
+  for (int to = t0; to <= t1; ++to)
+    for (int ho = h0; ho <= h1; ++ho)
+      for (int wo = w0; wo <= w1; ++wo) {
+        const long ro = (((long)n * d.To + to) * d.Ho + ho) * d.Wo + wo;
+        const f32x4 yv = *reinterpret_cast<const f32x4*>(y + ro * d.out_cs + d.out_coff + c);
+        const f32x4 gv = *reinterpret_cast<const f32x4*>(dy + ro * dy_cs + dy_coff + c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (yv[e] == xv[e]) g[e] += gv[e];
+      }
+  f32x4* o = reinterpret_cast<f32x4*>(dx + (long)rin * dx_cs + dx_coff + c);
+  *o = *o + g;
+}
+
 extern "C" int sf_maxpool_bwd(const sf_pool_desc* d, const float* x, const float* y, const float* dy, int dy_cs,
                               int dy_coff, float* dx, int dx_cs, int dx_coff, void* stream) {
   if (!d || !x || !y || !dy || !dx || d->is_avg) return SF_EINVAL;
   const long total = (long)d->N * d->Ti * d->Hi * d->Wi * d->C;
-  hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(sf_cdiv(total, TPB)), dim3(TPB), 0, (hipStream_t)stream, *d, x, y, dy,
-                     dy_cs, dy_coff, dx, dx_cs, dx_coff, total);
+  const bool vec4 = (d->C % 4 == 0) && (d->in_cs % 4 == 0) && (d->in_coff % 4 == 0) && (d->out_cs % 4 == 0) &&
+                    (d->out_coff % 4 == 0) && (dy_cs % 4 == 0) && (dy_coff % 4 == 0) && (dx_cs % 4 == 0) &&
+                    (dx_coff % 4 == 0) && sf_aligned16(x) && sf_aligned16(y) && sf_aligned16(dy) && sf_aligned16(dx) &&
+                    total / 4 < 0x7fffffffL;
+  if (vec4)
+    hipLaunchKernelGGL(maxpool_bwd_vec4_kernel, dim3(sf_cdiv(total / 4, TPB)), dim3(TPB), 0, (hipStream_t)stream, *d, x,
+                       y, dy, dy_cs, dy_coff, dx, dx_cs, dx_coff, (unsigned)(total / 4));
+  else
+    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(sf_cdiv(total, TPB)), dim3(TPB), 0, (hipStream_t)stream, *d, x, y, dy,
+                       dy_cs, dy_coff, dx, dx_cs, dx_coff, total);
   SF_CHECK_LAUNCH();
   return SF_OK;
 }

@@ -201,16 +201,17 @@ def test_sub_batchnorm_forward_backward(c, nsplit, n, relu, use_res, rep):
     assert int(mine.split_bn.num_batches_tracked) == 1 and int(mine.bn.num_batches_tracked) == 0
 
 
+@pytest.mark.parametrize("c", [12, 7])  # float4 kernel / scalar kernel
 @pytest.mark.parametrize("k,s,p", [((1, 3, 3), (1, 2, 2), (0, 1, 1)), ((3, 3, 3), (1, 2, 2), (1, 1, 1))])
-def test_maxpool_backward(k, s, p):
+def test_maxpool_backward(k, s, p, c):
     import sfhip
     dev = _dev()
     g = torch.Generator().manual_seed(3)
-    x = torch.randn(2, 12, 4, 13, 12, generator=g).requires_grad_(True)
+    x = torch.randn(2, c, 4, 13, 12, generator=g).requires_grad_(True)
     y = F.max_pool3d(x, k, s, p)
     dy = torch.randn(y.shape, generator=g)
     (dx_ref,) = torch.autograd.grad(y, (x,), dy)
-    dx = sfhip.Act(torch.zeros(2, 4, 13, 12, 12, device=dev))
+    dx = sfhip.Act(torch.zeros(2, 4, 13, 12, c, device=dev))
     sfhip.maxpool_bwd(_act(x), _act(y), _act(dy), dx, k, s, p)
     torch.cuda.synchronize()
     assert _rel(_back(dx), dx_ref) < 1e-6
