@@ -319,6 +319,24 @@ __global__ void rowdot_kernel(const float* __restrict__ a, int a_cs, int a_coff,
   out[r] = s * scale;
 }
 
+// C/4 = 1..64 (a power of two) lanes per row, one float4 each, shuffle reduction inside the lane group: coalesced
+// 16-byte loads instead of one thread walking a row (row-strided scalar loads).
+__global__ __launch_bounds__(256) void rowdot_vec4_kernel(const float* __restrict__ a, int a_cs, int a_coff,
+                                                          const float* __restrict__ b, int b_cs, int b_coff, long rows,
+                                                          int cv_shift, float scale, float* __restrict__ out) {
+  const long idx = (long)blockIdx.x * TPB + threadIdx.x;
+  const long r = idx >> cv_shift;
+  const int c = (int)(idx - (r << cv_shift)) * 4;
+  float s = 0.f;
+  if (r < rows) {
+    const f32x4 x = *reinterpret_cast<const f32x4*>(a + r * a_cs + a_coff + c);
+    const f32x4 y = *reinterpret_cast<const f32x4*>(b + r * b_cs + b_coff + c);
+    s = x[0] * y[0] + x[1] * y[1] + x[2] * y[2] + x[3] * y[3];
+  }
+  for (int o = (1 << cv_shift) >> 1; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  if (r < rows && c == 0) out[r] = s * scale;
+}
+
 // out[r, c] (+)= alpha * a[r, c]   (gradient fan-in / scaled copies between channel slices)
 __global__ void axpy_kernel(const float* __restrict__ a, int a_cs, int a_coff, float alpha, float* __restrict__ out,
                             int out_cs, int out_coff, int C, int accumulate, long total) {
@@ -561,6 +579,16 @@ extern "C" int sf_bcast_add(float* g, int cs, int coff, int N, long rows_per_n, 
 extern "C" int sf_rowdot(const float* a, int a_cs, int a_coff, const float* b, int b_cs, int b_coff, long rows, int C,
                          float scale, float* out, void* stream) {
   if (!a || !b || !out || rows <= 0 || C <= 0) return SF_EINVAL;
+  const int cv = C / 4;
+  if (C % 4 == 0 && cv <= 64 && (cv & (cv - 1)) == 0 && a_cs % 4 == 0 && a_coff % 4 == 0 && b_cs % 4 == 0 &&
+      b_coff % 4 == 0 && sf_aligned16(a) && sf_aligned16(b)) {
+    int shift = 0;
+    while ((1 << shift) < cv) ++shift;
+    hipLaunchKernelGGL(rowdot_vec4_kernel, dim3(sf_cdiv(rows * cv, TPB)), dim3(TPB), 0, (hipStream_t)stream, a, a_cs,
+                       a_coff, b, b_cs, b_coff, rows, shift, scale, out);
+    SF_CHECK_LAUNCH();
+    return SF_OK;
+  }
   hipLaunchKernelGGL(rowdot_kernel, dim3(sf_cdiv(rows, TPB)), dim3(TPB), 0, (hipStream_t)stream, a, a_cs, a_coff, b,
                      b_cs, b_coff, rows, C, scale, out);
   SF_CHECK_LAUNCH();
