@@ -28,6 +28,7 @@ struct BwdArgs {
   int B, C, N, nt;
   int zs;                                            // fused kernels: the swept (query) range is cut into zs parts
   float* dkp; float* dvp;                            // zs > 1: dK / dV partials [B][zs][N][CP], summed afterwards
+  float* dqp;                                        // two-kernel form with zs > 1: dQ partials [B][zs][N][CP]
 };
 
 constexpr float POS_BIG = 3.0e38f;
@@ -51,8 +52,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const BwdArgs p) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, lh = lane >> 5;
-  const int b = blockIdx.x / p.nt;
-  const int q0 = (blockIdx.x - b * p.nt) * 128 + wave * 32;
+  const int bz = blockIdx.x / p.nt;  // workgroup -> (clip b, key part z, query tile); zs = 1 outside the parts mode
+  const int b = bz / p.zs, z = bz - b * p.zs;
+  const int q0 = (blockIdx.x - bz * p.nt) * 128 + wave * 32;
   const int N = p.N, C = p.C;
   const long brow = (long)b * N;
   const float gamma = p.gamma[0];
@@ -118,12 +120,14 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const BwdArgs p) {
     }
   };
 
-  const int ntiles = (N + KT - 1) / KT;
-  load_tile(0);
+  const int tz = ((N + KT - 1) / KT + p.zs - 1) / p.zs;  // key tiles per part
+  const int t0 = z * tz;
+  const int ntiles = min((N + KT - 1) / KT, t0 + tz);
+  load_tile(t0 * KT);
   store_tile(0);
   __syncthreads();
-  for (int t = 0; t < ntiles; ++t) {
-    const int buf = t & 1;
+  for (int t = t0; t < ntiles; ++t) {
+    const int buf = (t - t0) & 1;
     const bool more = (t + 1) < ntiles;
     if (more) load_tile((t + 1) * KT);
 #pragma unroll
@@ -163,6 +167,16 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const BwdArgs p) {
     __syncthreads();
   }
   if (!qok) return;
+  if (p.zs > 1) {  // this key part's share of dQ: [B][zs][N][CP], summed in part order by attn_dq_reduce_kernel
+    float* pp = p.dqp + ((long)bz * N + qrow) * CP;
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+      for (int r = 0; r < 16; r += 4)
+        *reinterpret_cast<f32x4*>(pp + ct * 32 + 8 * (r >> 2) + 4 * lh) =
+            (f32x4){acc[ct][r], acc[ct][r + 1], acc[ct][r + 2], acc[ct][r + 3]};
+    return;
+  }
   float* op = p.dq + (brow + qrow) * p.dq_cs;
 #pragma unroll
   for (int ct = 0; ct < CT; ++ct)
@@ -188,8 +202,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const BwdArgs p) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, lh = lane >> 5;
-  const int b = blockIdx.x / p.nt;
-  const int j0 = (blockIdx.x - b * p.nt) * 128 + wave * 32;
+  const int bz = blockIdx.x / p.nt;  // workgroup -> (clip b, query part z, key block)
+  const int b = bz / p.zs, z = bz - b * p.zs;
+  const int j0 = (blockIdx.x - bz * p.nt) * 128 + wave * 32;
   const int N = p.N, C = p.C;
   const long brow = (long)b * N;
   const float gamma = p.gamma[0];
@@ -264,12 +279,14 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const BwdArgs p) {
     }
   };
 
-  const int ntiles = (N + QT - 1) / QT;
-  load_tile(0);
+  const int tz = ((N + QT - 1) / QT + p.zs - 1) / p.zs;  // query tiles per part
+  const int t0 = z * tz;
+  const int ntiles = min((N + QT - 1) / QT, t0 + tz);
+  load_tile(t0 * QT);
   store_tile(0);
   __syncthreads();
-  for (int t = 0; t < ntiles; ++t) {
-    const int buf = t & 1;
+  for (int t = t0; t < ntiles; ++t) {
+    const int buf = (t - t0) & 1;
     const bool more = (t + 1) < ntiles;
     if (more) load_tile((t + 1) * QT);
     const float* Qs = smem + buf * TILE;
@@ -322,6 +339,19 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const BwdArgs p) {
     __syncthreads();
   }
   if (!jok) return;
+  if (p.zs > 1) {
+    float* okp = p.dkp + ((long)bz * N + jrow) * CP;
+    float* ovp = p.dvp + ((long)bz * N + jrow) * CP;
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+      for (int r = 0; r < 16; r += 4) {
+        const int c = ct * 32 + 8 * (r >> 2) + 4 * lh;
+        *reinterpret_cast<f32x4*>(okp + c) = (f32x4){dk[ct][r], dk[ct][r + 1], dk[ct][r + 2], dk[ct][r + 3]};
+        *reinterpret_cast<f32x4*>(ovp + c) = (f32x4){dv[ct][r], dv[ct][r + 1], dv[ct][r + 2], dv[ct][r + 3]};
+      }
+    return;
+  }
   float* okp = p.dk + (brow + jrow) * p.dk_cs;
   float* ovp = p.dv + (brow + jrow) * p.dv_cs;
 #pragma unroll
@@ -645,7 +675,7 @@ int launch_fused(BwdArgs a, float* ws, hipStream_t s) {
 
 template <int CP>
 int launch(const BwdArgs& a, int which, hipStream_t s) {
-  const int grid = a.B * a.nt;
+  const int grid = a.B * a.zs * a.nt;
   if (which & 1) hipLaunchKernelGGL((attn_bwd_dq_kernel<CP>), dim3(grid), dim3(256), 0, s, a);
   if (which & 2) hipLaunchKernelGGL((attn_bwd_dkv_kernel<CP>), dim3(grid), dim3(256), 0, s, a);
   SF_CHECK_LAUNCH();
@@ -671,6 +701,7 @@ extern "C" int sf_attn_bwd(const float* q, int q_cs, const float* k, int k_cs, c
   a.dq = dq; a.dk = dk; a.dv = dv;
   a.q_cs = q_cs; a.k_cs = k_cs; a.v_cs = v_cs; a.dz_cs = dz_cs; a.dq_cs = dq_cs; a.dk_cs = dk_cs; a.dv_cs = dv_cs;
   a.B = B; a.C = C; a.N = N; a.nt = sf_cdiv(N, 128);
+  a.zs = 1; a.dkp = a.dvp = a.dqp = nullptr;
   hipStream_t s = (hipStream_t)stream;
   if (C <= 16)  // 16x16x4 tiles: no padded rows
     return sf_attn_small_bwd_dispatch(q, q_cs, k, k_cs, v, v_cs, dz, dz_cs, lse, dvec, gamma, dq, dq_cs, dk, dk_cs,
@@ -692,7 +723,11 @@ int sf_attn_small_fused_dispatch(const float* q, int q_cs, const float* k, int k
 
 // dQ planes (one per key block) + room for the dK / dV partials of up to SF_SWEEP_PARTS_MAX query parts
 extern "C" long sf_attn_bwd_fused_ws_floats(int B, int N, int C) {
-  if (B <= 0 || N <= 0 || C <= 0 || C > 64) return 0;
+  if (B <= 0 || N <= 0 || C <= 0 || C > 128) return 0;
+  if (C > 64) {  // two-kernel form with sweep parts (dQ, dK, dV parts, no planes) — only when it needs them to fill the chip
+    const long units = (long)B * sf_cdiv(N, 128);
+    return units < 2 * 256 ? 3L * B * SF_SWEEP_PARTS_MAX * N * 128 : 0;
+  }
   const int cp = C <= 4 ? 4 : (C <= 8 ? 8 : (C <= 16 ? 16 : (C <= 32 ? 32 : 64)));
   const int keys = C <= 16 ? 64 : (C <= 32 ? FUSED_KEYS_32 : 128);
   return (long)B * (sf_cdiv(N, keys) + 2 * SF_SWEEP_PARTS_MAX) * N * cp;
@@ -712,6 +747,22 @@ extern "C" int sf_attn_bwd_fused(const float* q, int q_cs, const float* k, int k
   a.dq = dq; a.dk = dk; a.dv = dv;
   a.q_cs = q_cs; a.k_cs = k_cs; a.v_cs = v_cs; a.dz_cs = dz_cs; a.dq_cs = dq_cs; a.dk_cs = dk_cs; a.dv_cs = dv_cs;
   a.B = B; a.C = C; a.N = N; a.nt = sf_cdiv(N, 128);
+  a.dqp = nullptr;
+  if (C > 64) {  // d = 128: both kernels of the two-kernel form, their sweeps cut into parts so that B * N/128 < 2 x 256
+    hipStream_t st = (hipStream_t)stream;  // workgroups become B * N/128 * z; the parts are summed in part order
+    a.zs = sf_sweep_parts((long)B * a.nt, sf_cdiv(N, 32));
+    if (a.zs <= 1) {
+      a.zs = 1;
+      return launch<128>(a, 3, st);
+    }
+    const long part = (long)B * a.zs * N * 128;
+    a.dqp = ws; a.dkp = ws + part; a.dvp = ws + 2 * part;
+    int rc = launch<128>(a, 3, st);
+    if (rc == SF_OK) rc = sf_attn_dq_reduce(a.dqp, dq, dq_cs, B, N, C, 128, a.zs, st);
+    if (rc == SF_OK) rc = sf_attn_dq_reduce(a.dkp, dk, dk_cs, B, N, C, 128, a.zs, st);
+    if (rc == SF_OK) rc = sf_attn_dq_reduce(a.dvp, dv, dv_cs, B, N, C, 128, a.zs, st);
+    return rc;
+  }
   if (C <= 32) return launch_fused<32, FUSED_KEYS_32 / 32>(a, ws, (hipStream_t)stream);
   return launch_fused<64, 4>(a, ws, (hipStream_t)stream);
 }
