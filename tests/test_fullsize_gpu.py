@@ -52,6 +52,46 @@ def _chunked_attention_fp64(q, k, v, dz, gamma, chunk=3136):
     return o, dq, dk, dv, dgamma
 
 
+def test_fast_stem_ring_kernels_at_full_size():
+    """The Fast pathway's stem at its real size (T = 32, 224^2 -> 8 x 32 x 112 x 112, 3.2 M positions per 8 clips;
+    2 clips here): conv_stem_fwd_kernel and conv_wgrad_stem_kernel (LDS rings, persistent one-workgroup-per-CU grid,
+    t range cut in parts) against an fp64 GPU restatement by exact identities — the forward as a dense fp64 conv3d of
+    the same clip, the weight gradient through linearity: <dW, V> = <dy, conv(x, V)> for random directions V."""
+    import sfhip
+    dev = _dev()
+    g = torch.Generator().manual_seed(21)
+    n, t, h, w, cout, kt = 2, 32, 224, 224, 8, 5
+    x = torch.randn(n, 3, t, h, w, generator=g)
+    wt = torch.randn(cout, 3, kt, 7, 7, generator=g) / np.sqrt(147 * kt)
+    xa = sfhip.from_ncthw(x.to(dev), cpad=4, ph=3, pw=3, wp=230)
+    view = sfhip.Act(xa.buf.view(n, t, 230, 115, 8))
+    w4 = torch.zeros(cout, 4, kt, 7, 7)
+    w4[:, :3] = wt
+    wp = torch.zeros(cout, kt * 7, 32)
+    wp[:, :, :28] = w4.permute(0, 2, 3, 4, 1).reshape(cout, kt * 7, 28)
+    z = sfhip.conv(view, wp.to(dev).contiguous(), (kt, 7, 1), (1, 2, 1), (kt // 2, 0, 0), cin=28, out_thw=(t, 112, 112))
+    xd, wd = x.to(dev).double(), wt.to(dev).double()
+    ref = torch.nn.functional.conv3d(xd, wd, None, (1, 2, 2), (kt // 2, 3, 3))          # fp64, NCTHW
+    got = z.buf.permute(0, 4, 1, 2, 3).double()
+    e_f = float((got - ref).abs().max() / ref.abs().max())
+    dy = torch.randn(n, t, 112, 112, cout, generator=g).to(dev)
+    dwp = sfhip.conv_wgrad(view, sfhip.Act(dy), cout, (kt, 7, 1), (1, 2, 1), (kt // 2, 0, 0), cin=28, cin_pad=32)
+    again = sfhip.conv_wgrad(view, sfhip.Act(dy), cout, (kt, 7, 1), (1, 2, 1), (kt // 2, 0, 0), cin=28, cin_pad=32)
+    torch.cuda.synchronize()
+    dw = dwp[:, :, :28].reshape(cout, kt, 7, 7, 4)[..., :3].permute(0, 4, 1, 2, 3).double()
+    errs = []
+    dyd = dy.permute(0, 4, 1, 2, 3).double()
+    for _ in range(3):
+        v = torch.randn(wt.shape, generator=g).to(dev).double()
+        lhs = float((dw * v).sum())
+        rhs = float((dyd * torch.nn.functional.conv3d(xd, v, None, (1, 2, 2), (kt // 2, 3, 3))).sum())
+        errs.append(abs(lhs - rhs) / max(abs(rhs), 1e-30))
+    _report("fast stem at full size: forward max rel err %.2e, wgrad <dW,V> rel err %.2e" % (e_f, max(errs)))
+    assert e_f < 1e-5, e_f
+    assert max(errs) < 1e-4, errs
+    assert torch.equal(dwp, again), "bit-reproducible"
+
+
 @pytest.mark.parametrize("c,thw", [(32, (8, 56, 56)), (8, (8, 56, 56))], ids=["d32_n25088", "d8_n25088"])
 def test_attention_at_production_size_against_exact_fp64(c, thw):
     import sfhip
