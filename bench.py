@@ -118,8 +118,11 @@ def cpu_baseline(workload, cfg, model, train):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=20)
+    # 8 warm-up steps by default: on a box whose GPU has been idle the first few steps run 3-4 ms slow (clock ramp,
+    # stream-pool growth in the caching allocator) — measured 77.7 vs 73.4 ms / step with 3 warm-up steps as the first
+    # GPU process on a fresh box, 73.3 with 10
+    ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--workload", default="dual", choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=0, help="clips per GPU (default: the workload's)")
     ap.add_argument("--mode", default="train", choices=["train", "eval"])

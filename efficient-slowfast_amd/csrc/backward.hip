@@ -164,7 +164,7 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ dy, int dy_cs, int
                                     const float* __restrict__ mean, const float* __restrict__ invstd,
                                     const float* __restrict__ gamma, const float* __restrict__ dbeta,
                                     const float* __restrict__ dgamma, float inv_m, float* dz, int dz_cs, int dz_coff,
-                                    float* __restrict__ dres, int dres_cs, int dres_coff, long total) {
+                                    float* __restrict__ dres, int dres_cs, int dres_coff, int dres_acc, long total) {
   const long idx = (long)blockIdx.x * TPB + threadIdx.x;
   if (idx >= total) return;
   const int cv = C / VEC;
@@ -194,13 +194,14 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ dy, int dy_cs, int
   }
   if (dres) {
     float* rp = dres + r * dres_cs + dres_coff + c;
-    if (VEC == 4) {
-      f32x4 v = *reinterpret_cast<f32x4*>(rp);
+    if (VEC == 4) {  // dres_acc == 0: first writer of the residual branch's gradient (no zero fill, no read)
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (dres_acc) v = *reinterpret_cast<f32x4*>(rp);
 #pragma unroll
       for (int e = 0; e < 4; ++e) v[e] += g[e];
       *reinterpret_cast<f32x4*>(rp) = v;
     } else {
-      rp[0] += g[0];
+      rp[0] = dres_acc ? rp[0] + g[0] : g[0];
     }
   }
 }
@@ -444,7 +445,7 @@ static int bn_bwd_apply_launch(const float* dy, int dy_cs, int dy_coff, const fl
                                const float* z, int z_cs, int z_coff, int N, int T, int H, int W, int C, int S, int rep,
                                int relu, const float* mean, const float* invstd, const float* gamma,
                                const float* dbeta, const float* dgamma, float* dz, int dz_cs, int dz_coff,
-                               float* dres, int dres_cs, int dres_coff, void* stream) {
+                               float* dres, int dres_cs, int dres_coff, int dres_acc, void* stream) {
   if (!dy || !z || !mean || !invstd || !gamma || !dbeta || !dgamma || !dz || (relu && !y)) return SF_EINVAL;
   if (relu == 3 && (rep != 1 || (C % 4) != 0 || y_cs != C / 4 || y_coff != 0)) return SF_EINVAL;
   if (N <= 0 || T <= 0 || H <= 0 || W <= 0 || C <= 0 || rep <= 0 || S <= 0 || N % S != 0) return SF_EINVAL;
@@ -459,12 +460,12 @@ static int bn_bwd_apply_launch(const float* dy, int dy_cs, int dy_coff, const fl
     hipLaunchKernelGGL(bn_bwd_apply_kernel<4>, dim3(sf_cdiv(total, TPB)), dim3(TPB), 0, (hipStream_t)stream, dy, dy_cs,
                        dy_coff, y, y_cs, y_coff, z, z_cs, z_coff, rows, (long)T * H * W, H * W, C, S, rep, relu, mean,
                        invstd, gamma, dbeta, dgamma, (float)S / (float)rows, dz, dz_cs, dz_coff, dres, dres_cs,
-                       dres_coff, total);
+                       dres_coff, dres_acc, total);
   else
     hipLaunchKernelGGL(bn_bwd_apply_kernel<1>, dim3(sf_cdiv(total, TPB)), dim3(TPB), 0, (hipStream_t)stream, dy, dy_cs,
                        dy_coff, y, y_cs, y_coff, z, z_cs, z_coff, rows, (long)T * H * W, H * W, C, S, rep, relu, mean,
                        invstd, gamma, dbeta, dgamma, (float)S / (float)rows, dz, dz_cs, dz_coff, dres, dres_cs,
-                       dres_coff, total);
+                       dres_coff, dres_acc, total);
   SF_CHECK_LAUNCH();
   return SF_OK;
 }
@@ -475,7 +476,19 @@ extern "C" int sf_bn_bwd_apply(const float* dy, int dy_cs, int dy_coff, const fl
                                const float* dbeta, const float* dgamma, float* dz, int dz_cs, int dz_coff,
                                float* dres, int dres_cs, int dres_coff, void* stream) {
   return bn_bwd_apply_launch(dy, dy_cs, dy_coff, y, y_cs, y_coff, z, z_cs, z_coff, N, T, H, W, C, 1, rep, relu, mean,
-                             invstd, gamma, dbeta, dgamma, dz, dz_cs, dz_coff, dres, dres_cs, dres_coff, stream);
+                             invstd, gamma, dbeta, dgamma, dz, dz_cs, dz_coff, dres, dres_cs, dres_coff, 1, stream);
+}
+
+// As sf_bn_bwd_apply, but the residual branch's gradient is WRITTEN (dres = g), not accumulated: for the first
+// writer of that buffer, which then needs neither a zero fill nor a read.
+extern "C" int sf_bn_bwd_apply_first(const float* dy, int dy_cs, int dy_coff, const float* y, int y_cs, int y_coff,
+                                     const float* z, int z_cs, int z_coff, int N, int T, int H, int W, int C, int rep,
+                                     int relu, const float* mean, const float* invstd, const float* gamma,
+                                     const float* dbeta, const float* dgamma, float* dz, int dz_cs, int dz_coff,
+                                     float* dres, int dres_cs, int dres_coff, void* stream) {
+  if (!dres) return SF_EINVAL;
+  return bn_bwd_apply_launch(dy, dy_cs, dy_coff, y, y_cs, y_coff, z, z_cs, z_coff, N, T, H, W, C, 1, rep, relu, mean,
+                             invstd, gamma, dbeta, dgamma, dz, dz_cs, dz_coff, dres, dres_cs, dres_coff, 0, stream);
 }
 
 extern "C" int sf_bn_bwd_apply_split(const float* dy, int dy_cs, int dy_coff, const float* y, int y_cs, int y_coff,
@@ -484,7 +497,8 @@ extern "C" int sf_bn_bwd_apply_split(const float* dy, int dy_cs, int dy_coff, co
                                      const float* gamma, const float* dbeta, const float* dgamma, float* dz,
                                      int dz_cs, int dz_coff, float* dres, int dres_cs, int dres_coff, void* stream) {
   return bn_bwd_apply_launch(dy, dy_cs, dy_coff, y, y_cs, y_coff, z, z_cs, z_coff, N, T, H, W, C, nsplit, rep, relu,
-                             mean, invstd, gamma, dbeta, dgamma, dz, dz_cs, dz_coff, dres, dres_cs, dres_coff, stream);
+                             mean, invstd, gamma, dbeta, dgamma, dz, dz_cs, dz_coff, dres, dres_cs, dres_coff, 1,
+                             stream);
 }
 
 // Four channels per thread, 32-bit index arithmetic (the scalar kernel above pays four 64-bit divisions per element

@@ -52,7 +52,7 @@ EXPORTS = [
     "sf_bn_train_stats_split", "sf_affine_fwd_split", "sf_bn_bwd_reduce_split", "sf_bn_bwd_apply_split",
     "sf_clip_prologue", "sf_conv_wgrad_finish", "sf_bn_bwd_reduce_acc", "sf_row_softmax_fwd", "sf_row_softmax_bwd",
     "sf_attn_bwd_fused_ws_floats", "sf_attn_bwd_fused", "sf_pack_conv_weight", "sf_conv_fwd_ws_floats",
-    "sf_conv_fwd_ws", "sf_attn_fwd_ws_floats", "sf_attn_fwd_ws", "sf_affine_fwd_mask",
+    "sf_conv_fwd_ws", "sf_attn_fwd_ws_floats", "sf_attn_fwd_ws", "sf_affine_fwd_mask", "sf_bn_bwd_apply_first",
 ]
 _LONG_RET = ("sf_tmax_mean_ws_floats", "sf_channel_stats_ws_floats", "sf_bn_bwd_ws_floats",
              "sf_dwconv_wgrad_ws_floats", "sf_attn_bwd_fused_ws_floats", "sf_conv_fwd_ws_floats",
@@ -105,6 +105,7 @@ def lib():
         L.sf_bn_bwd_reduce.argtypes = [vp, ci, ci, vp, ci, ci, vp, ci, ci] + [ci] * 7 + [vp] * 5 + [vp]
         L.sf_bn_bwd_apply.argtypes = ([vp, ci, ci, vp, ci, ci, vp, ci, ci] + [ci] * 7 + [vp] * 5 +
                                       [vp, ci, ci, vp, ci, ci, vp])
+        L.sf_bn_bwd_apply_first.argtypes = L.sf_bn_bwd_apply.argtypes
         L.sf_maxpool_bwd.argtypes = [ctypes.POINTER(PoolDesc), vp, vp, vp, ci, ci, vp, ci, ci, vp]
         L.sf_tmax_dot.argtypes = [vp, ci, ci] + [ci] * 6 + [vp, ci, ci, vp, vp, vp]
         L.sf_eca_bwd_apply.argtypes = [vp, ci, ci] + [ci] * 6 + [vp, ci, ci, vp, vp, vp, ci, ci, vp]
@@ -618,7 +619,7 @@ def unpack_conv_weight_grad(dwp, shape):
 
 
 def bn_bwd(dy, y, z, mean, invstd, gamma, relu, rep=1, dres=None, dz_out=None, dgamma_out=None, nsplit=1,
-           sync=None, grad_sink=None, mask=None):
+           sync=None, grad_sink=None, mask=None, dres_overwrite=False):
     """Training BN backward (+ReLU mask, + residual fan-out, + upsample-copy sum).  Returns (dz, dgamma, dbeta);
     dz is written over z unless dz_out is given.
     nsplit > 1 (SubBatchNorm3d): mean/invstd/gamma and the returned sums hold nsplit*C entries [split*C + c].
@@ -641,6 +642,9 @@ def bn_bwd(dy, y, z, mean, invstd, gamma, relu, rep=1, dres=None, dz_out=None, d
     split = (nsplit,) if nsplit > 1 else ()
     reduce_fn = lib().sf_bn_bwd_reduce_split if nsplit > 1 else lib().sf_bn_bwd_reduce
     apply_fn = lib().sf_bn_bwd_apply_split if nsplit > 1 else lib().sf_bn_bwd_apply
+    if dres_overwrite:  # dres is an uninitialised buffer this call is the first writer of (dres = g, not +=)
+        assert dres is not None and nsplit == 1
+        apply_fn = lib().sf_bn_bwd_apply_first
     if grad_sink is not None:  # (weight.grad[:C], bias.grad[:C]) accumulated by the reduction's final kernel
         assert nsplit == 1 and dgamma_out is None
         _check(lib().sf_bn_bwd_reduce_acc(*head, *tail, _ptr(dbeta), _ptr(dgamma), _ptr(ws), _ptr(grad_sink[1]),

@@ -396,17 +396,21 @@ def bn_train_apply(bn, z, res=None, relu=False, rep=1, out=None, out_reserve=(0,
         sel = slice(None) if nsplit > 1 else slice(0, nk)
 
         def bwd():
-            dres = t.grad_of(res) if res is not None else None
+            dres, first = None, False
+            if res is not None:  # first writer of the residual branch's gradient: write it, no zero fill / read
+                fresh = t.grad_of_uninitialised(res) if (nsplit == 1 and res.C == zz.C and rep == 1) else None
+                dres, first = (fresh, True) if fresh is not None else (t.grad_of(res), False)
             wt = t.pgrad_target(bn.weight) if (nsplit == 1 and getattr(bn, "weight", None) is not None) else None
             bt = t.pgrad_target(bn.bias) if wt is not None else None
             if wt is not None and bt is not None:  # dgamma / dbeta accumulate into .grad inside the reduction
                 sfhip.bn_bwd(t.grad_of(y), y, zz, mean[sel], invstd[sel], gamma_b[sel], relu, rep=rep, dres=dres,
-                             dz_out=zz, sync=sync, grad_sink=(wt, bt), mask=mask)
+                             dz_out=zz, sync=sync, grad_sink=(wt, bt), mask=mask, dres_overwrite=first)
             else:
                 dg_ = dg if dg is not None else torch.zeros(z.C, dtype=torch.float32, device=z.buf.device)
                 db_ = db if db is not None else torch.zeros(z.C, dtype=torch.float32, device=z.buf.device)
                 sfhip.bn_bwd(t.grad_of(y), y, zz, mean[sel], invstd[sel], gamma_b[sel], relu, rep=rep, dres=dres,
-                             dz_out=zz, dgamma_out=(dg_, db_), nsplit=nsplit, sync=sync, mask=mask)
+                             dz_out=zz, dgamma_out=(dg_, db_), nsplit=nsplit, sync=sync, mask=mask,
+                             dres_overwrite=first)
             if keep is not None and keep < z.C:  # sliced-away channels (GhostModule [:oup]) get no gradient
                 rest = z.slice(keep, z.C - keep)
                 sfhip.axpy(rest, rest, alpha=0.0, accumulate=False)

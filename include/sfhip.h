@@ -235,6 +235,13 @@ int sf_bn_bwd_apply(const float* dy, int dy_cs, int dy_coff, const float* y, int
                     const float* mean, const float* invstd, const float* gamma, const float* dbeta,
                     const float* dgamma, float* dz, int dz_cs, int dz_coff, float* dres, int dres_cs,
                     int dres_coff, void* stream);
+/* As sf_bn_bwd_apply with dres != NULL, but dres is WRITTEN (dres = g) instead of accumulated: the first writer of
+ * the residual branch's gradient buffer needs neither a zero fill nor a read of it.                         */
+int sf_bn_bwd_apply_first(const float* dy, int dy_cs, int dy_coff, const float* y, int y_cs, int y_coff,
+                          const float* z, int z_cs, int z_coff, int N, int T, int H, int W, int C, int rep, int relu,
+                          const float* mean, const float* invstd, const float* gamma, const float* dbeta,
+                          const float* dgamma, float* dz, int dz_cs, int dz_coff, float* dres, int dres_cs,
+                          int dres_coff, void* stream);
 
 /* MaxPool3d backward (equality gather; dx accumulates).  `d` is the forward descriptor.                 */
 int sf_maxpool_bwd(const sf_pool_desc* d, const float* x, const float* y, const float* dy, int dy_cs,

@@ -365,6 +365,32 @@ def test_bn_backward_byte_mask(c, relu, use_res, wide):
     assert 0.05 < passed < 0.98, passed  # the mask is neither all ones nor all zeros
 
 
+@pytest.mark.parametrize("c", [64, 7])
+def test_bn_backward_first_writer_of_residual_gradient(c):
+    """sf_bn_bwd_apply_first writes the residual branch's gradient (dres = g) where sf_bn_bwd_apply accumulates: an
+    uninitialised (here NaN-filled) buffer comes back equal to the accumulate-into-zeros result, bit for bit."""
+    import sfhip
+    dev = _dev()
+    g = torch.Generator().manual_seed(c)
+    shp = (2, 3, 5, 6, c)
+    z = torch.randn(shp, generator=g) * 1.5 + 0.3
+    gamma, beta = (torch.rand(c, generator=g) + 0.5).to(dev), torch.randn(c, generator=g).to(dev)
+    res = sfhip.Act(torch.randn(shp, generator=g).to(dev))
+    dy = sfhip.Act(torch.randn(shp, generator=g).to(dev))
+    outs = []
+    for first in (False, True):
+        za = sfhip.Act(z.to(dev).clone())
+        mean, invstd, scale, shift = sfhip.bn_train_stats(za, gamma, beta, 1e-5, 0.1, None, None)
+        y = sfhip.affine(za, scale, shift, res=res, relu=True)
+        dres = sfhip.Act(torch.full(shp, float("nan"), device=dev) if first else torch.zeros(shp, device=dev))
+        dz, dg, db = sfhip.bn_bwd(dy, y, za, mean, invstd, gamma, True, dres=dres, dres_overwrite=first)
+        torch.cuda.synchronize()
+        outs.append((dz.buf.clone(), dres.buf.clone(), dg.clone(), db.clone()))
+    for u, v in zip(*outs):
+        assert torch.equal(u, v)
+    assert bool(torch.isfinite(outs[1][1]).all())
+
+
 @pytest.mark.parametrize("c,k,s", [(32, (3, 3, 3), (1, 1, 1)), (12, (1, 5, 5), (1, 2, 2)), (27, (3, 3, 3), (1, 2, 2))])
 def test_dwconv_backward(c, k, s):
     import sfhip
