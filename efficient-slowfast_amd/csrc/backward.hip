@@ -209,7 +209,7 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ dy, int dy_cs, int
 // max-pool backward by equality gather: dx[p] += sum_{windows w containing p} dy[w] * [x[p] == y[w]]
 __global__ void maxpool_bwd_kernel(const sf_pool_desc d, const float* __restrict__ x, const float* __restrict__ y,
                                    const float* __restrict__ dy, int dy_cs, int dy_coff, float* __restrict__ dx,
-                                   int dx_cs, int dx_coff, long total) {
+                                   int dx_cs, int dx_coff, int acc, long total) {
   const long idx = (long)blockIdx.x * TPB + threadIdx.x;
   if (idx >= total) return;
   const int c = (int)(idx % d.C);
@@ -233,7 +233,8 @@ __global__ void maxpool_bwd_kernel(const sf_pool_desc d, const float* __restrict
         const long ro = (((long)n * d.To + to) * d.Ho + ho) * d.Wo + wo;
         if (y[ro * d.out_cs + d.out_coff + c] == xv) g += dy[ro * dy_cs + dy_coff + c];
       }
-  dx[rin * dx_cs + dx_coff + c] += g;
+  float* o = dx + rin * dx_cs + dx_coff + c;
+  *o = acc ? *o + g : g;
 }
 
 // ECA backward, reduction: partial[b][blk][c] = sum_{t',hw} dz[b,t',hw,c] * max_r x[b,t'*alpha+r,hw,c]
@@ -507,7 +508,7 @@ __global__ __launch_bounds__(256) void maxpool_bwd_vec4_kernel(const sf_pool_des
                                                                const float* __restrict__ y,
                                                                const float* __restrict__ dy, int dy_cs, int dy_coff,
                                                                float* __restrict__ dx, int dx_cs, int dx_coff,
-                                                               unsigned total) {
+                                                               int acc, unsigned total) {
   const unsigned idx = blockIdx.x * TPB + threadIdx.x;
   if (idx >= total) return;
   const unsigned cv = d.C >> 2;
@@ -537,11 +538,11 @@ __global__ __launch_bounds__(256) void maxpool_bwd_vec4_kernel(const sf_pool_des
           if (yv[e] == xv[e]) g[e] += gv[e];
       }
   f32x4* o = reinterpret_cast<f32x4*>(dx + (long)rin * dx_cs + dx_coff + c);
-  *o = *o + g;
+  *o = acc ? *o + g : g;
 }
 
-extern "C" int sf_maxpool_bwd(const sf_pool_desc* d, const float* x, const float* y, const float* dy, int dy_cs,
-                              int dy_coff, float* dx, int dx_cs, int dx_coff, void* stream) {
+static int maxpool_bwd_launch(const sf_pool_desc* d, const float* x, const float* y, const float* dy, int dy_cs,
+                              int dy_coff, float* dx, int dx_cs, int dx_coff, int acc, void* stream) {
   if (!d || !x || !y || !dy || !dx || d->is_avg) return SF_EINVAL;
   const long total = (long)d->N * d->Ti * d->Hi * d->Wi * d->C;
   const bool vec4 = (d->C % 4 == 0) && (d->in_cs % 4 == 0) && (d->in_coff % 4 == 0) && (d->out_cs % 4 == 0) &&
@@ -550,12 +551,24 @@ extern "C" int sf_maxpool_bwd(const sf_pool_desc* d, const float* x, const float
                     total / 4 < 0x7fffffffL;
   if (vec4)
     hipLaunchKernelGGL(maxpool_bwd_vec4_kernel, dim3(sf_cdiv(total / 4, TPB)), dim3(TPB), 0, (hipStream_t)stream, *d, x,
-                       y, dy, dy_cs, dy_coff, dx, dx_cs, dx_coff, (unsigned)(total / 4));
+                       y, dy, dy_cs, dy_coff, dx, dx_cs, dx_coff, acc, (unsigned)(total / 4));
   else
     hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(sf_cdiv(total, TPB)), dim3(TPB), 0, (hipStream_t)stream, *d, x, y, dy,
-                       dy_cs, dy_coff, dx, dx_cs, dx_coff, total);
+                       dy_cs, dy_coff, dx, dx_cs, dx_coff, acc, total);
   SF_CHECK_LAUNCH();
   return SF_OK;
+}
+
+extern "C" int sf_maxpool_bwd(const sf_pool_desc* d, const float* x, const float* y, const float* dy, int dy_cs,
+                              int dy_coff, float* dx, int dx_cs, int dx_coff, void* stream) {
+  return maxpool_bwd_launch(d, x, y, dy, dy_cs, dy_coff, dx, dx_cs, dx_coff, 1, stream);
+}
+
+// dx is WRITTEN (every input position gets its gathered gradient, zero where it won no window), not accumulated: for
+// the first writer of that buffer.
+extern "C" int sf_maxpool_bwd_first(const sf_pool_desc* d, const float* x, const float* y, const float* dy, int dy_cs,
+                                    int dy_coff, float* dx, int dx_cs, int dx_coff, void* stream) {
+  return maxpool_bwd_launch(d, x, y, dy, dy_cs, dy_coff, dx, dx_cs, dx_coff, 0, stream);
 }
 
 extern "C" int sf_tmax_dot(const float* x, int cs, int coff, int N, int T, int H, int W, int C, int alpha,

@@ -52,7 +52,7 @@ EXPORTS = [
     "sf_bn_train_stats_split", "sf_affine_fwd_split", "sf_bn_bwd_reduce_split", "sf_bn_bwd_apply_split",
     "sf_clip_prologue", "sf_conv_wgrad_finish", "sf_bn_bwd_reduce_acc", "sf_row_softmax_fwd", "sf_row_softmax_bwd",
     "sf_attn_bwd_fused_ws_floats", "sf_attn_bwd_fused", "sf_pack_conv_weight", "sf_conv_fwd_ws_floats",
-    "sf_conv_fwd_ws", "sf_attn_fwd_ws_floats", "sf_attn_fwd_ws", "sf_affine_fwd_mask", "sf_bn_bwd_apply_first",
+    "sf_conv_fwd_ws", "sf_attn_fwd_ws_floats", "sf_attn_fwd_ws", "sf_affine_fwd_mask", "sf_bn_bwd_apply_first", "sf_maxpool_bwd_first",
 ]
 _LONG_RET = ("sf_tmax_mean_ws_floats", "sf_channel_stats_ws_floats", "sf_bn_bwd_ws_floats",
              "sf_dwconv_wgrad_ws_floats", "sf_attn_bwd_fused_ws_floats", "sf_conv_fwd_ws_floats",
@@ -106,6 +106,7 @@ def lib():
         L.sf_bn_bwd_apply.argtypes = ([vp, ci, ci, vp, ci, ci, vp, ci, ci] + [ci] * 7 + [vp] * 5 +
                                       [vp, ci, ci, vp, ci, ci, vp])
         L.sf_bn_bwd_apply_first.argtypes = L.sf_bn_bwd_apply.argtypes
+        L.sf_maxpool_bwd_first.argtypes = [ctypes.POINTER(PoolDesc), vp, vp, vp, ci, ci, vp, ci, ci, vp]
         L.sf_maxpool_bwd.argtypes = [ctypes.POINTER(PoolDesc), vp, vp, vp, ci, ci, vp, ci, ci, vp]
         L.sf_tmax_dot.argtypes = [vp, ci, ci] + [ci] * 6 + [vp, ci, ci, vp, vp, vp]
         L.sf_eca_bwd_apply.argtypes = [vp, ci, ci] + [ci] * 6 + [vp, ci, ci, vp, vp, vp, ci, ci, vp]
@@ -666,12 +667,14 @@ def bn_bwd(dy, y, z, mean, invstd, gamma, relu, rep=1, dres=None, dz_out=None, d
     return out, dgamma, dbeta
 
 
-def maxpool_bwd(x, y, dy, dx, kernel, stride, padding=(0, 0, 0)):
+def maxpool_bwd(x, y, dy, dx, kernel, stride, padding=(0, 0, 0), overwrite=False):
+    """dx (+)= gathered dy; overwrite: dx is an uninitialised buffer this call is the first writer of."""
     d = PoolDesc(x.N, x.T, x.H, x.W, x.C, x.cs, x.coff, y.T, y.H, y.W, y.cs, y.coff,
                  kernel[0], kernel[1], kernel[2], stride[0], stride[1], stride[2],
                  padding[0], padding[1], padding[2], 0)
-    _check(lib().sf_maxpool_bwd(ctypes.byref(d), x.ptr(), y.ptr(), dy.ptr(), dy.cs, dy.coff, dx.ptr(), dx.cs,
-                                dx.coff, _stream()), "sf_maxpool_bwd")
+    fn = lib().sf_maxpool_bwd_first if overwrite else lib().sf_maxpool_bwd
+    _check(fn(ctypes.byref(d), x.ptr(), y.ptr(), dy.ptr(), dy.cs, dy.coff, dx.ptr(), dx.cs, dx.coff, _stream()),
+           "sf_maxpool_bwd")
     return dx
 
 

@@ -585,7 +585,12 @@ def maxpool(x, kernel, stride, padding=(0, 0, 0), out_reserve=(0, 0)):
     y = sfhip.pool(x, kernel, stride, padding, out_reserve=out_reserve)
     t = tape()
     if t is not None:
-        t.record(lambda: sfhip.maxpool_bwd(x, y, t.grad_of(y), t.grad_of(x), kernel, stride, padding))
+        def bwd():
+            fresh = t.grad_of_uninitialised(x)  # first writer of x's gradient: write, no zero fill / read
+            sfhip.maxpool_bwd(x, y, t.grad_of(y), fresh if fresh is not None else t.grad_of(x), kernel, stride,
+                              padding, overwrite=fresh is not None)
+
+        t.record(bwd)
     return y
 
 

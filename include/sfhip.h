@@ -246,6 +246,10 @@ int sf_bn_bwd_apply_first(const float* dy, int dy_cs, int dy_coff, const float* 
 /* MaxPool3d backward (equality gather; dx accumulates).  `d` is the forward descriptor.                 */
 int sf_maxpool_bwd(const sf_pool_desc* d, const float* x, const float* y, const float* dy, int dy_cs,
                    int dy_coff, float* dx, int dx_cs, int dx_coff, void* stream);
+/* As sf_maxpool_bwd, but dx is WRITTEN (zero where a position won no window) instead of accumulated: the first
+ * writer of the gradient buffer needs neither a zero fill nor a read of it.                                 */
+int sf_maxpool_bwd_first(const sf_pool_desc* d, const float* x, const float* y, const float* dy, int dy_cs,
+                         int dy_coff, float* dx, int dx_cs, int dx_coff, void* stream);
 
 /* ECA backward: out[b,c] = sum_{t',hw} dz * max_r x (sf_tmax_dot), then
  * dx[frames holding the max] += dz * gate[b,c] + dpool[b,c]  (sf_eca_bwd_apply).  ws as sf_tmax_mean.   */

@@ -213,8 +213,11 @@ def test_maxpool_backward(k, s, p, c):
     (dx_ref,) = torch.autograd.grad(y, (x,), dy)
     dx = sfhip.Act(torch.zeros(2, 4, 13, 12, c, device=dev))
     sfhip.maxpool_bwd(_act(x), _act(y), _act(dy), dx, k, s, p)
+    first = sfhip.Act(torch.full((2, 4, 13, 12, c), float("nan"), device=dev))  # first-writer form: no zero fill
+    sfhip.maxpool_bwd(_act(x), _act(y), _act(dy), first, k, s, p, overwrite=True)
     torch.cuda.synchronize()
     assert _rel(_back(dx), dx_ref) < 1e-6
+    assert torch.equal(dx.buf, first.buf)
 
 
 @pytest.mark.parametrize("c,alpha", [(8, 4), (32, 4), (3, 8)])
