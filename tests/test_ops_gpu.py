@@ -325,6 +325,37 @@ def test_attention_online_softmax_rescale_branch():
     assert err < TOL
 
 
+@pytest.mark.parametrize("c", [8, 32, 64])
+def test_attention_workspace_free_entry_point(c):
+    """sf_attn_fwd (no workspace: one launch, never cut into key parts) — the entry the Python binding no longer
+    takes — called straight through the C ABI, against the fp64 softmax attention and against sf_attn_fwd_ws."""
+    import ctypes
+    import sfhip
+    dev = _dev()
+    g = torch.Generator().manual_seed(40 + c)
+    n = 700
+    q, k, v, x = [torch.randn(2, n, c, generator=g) * (0.6 if i < 2 else 1.0) for i in range(4)]
+    gamma = torch.tensor([0.7])
+    ref = gamma.double() * (torch.softmax(q.double() @ k.double().transpose(1, 2), -1) @ v.double()) + x.double()
+    qa, ka, va, xa = [sfhip.Act(z.view(2, 1, 1, n, c).contiguous().to(dev)) for z in (q, k, v, x)]
+    gam = gamma.to(dev)
+    via_ws = sfhip.attention(qa, ka, va, xa, gam)
+    out = sfhip.Act(torch.empty(2, 1, 1, n, c, device=dev))
+    o_save = torch.empty(2, n, c, device=dev)
+    lse = torch.empty(2, n, device=dev)
+    vp = ctypes.c_void_p
+    rc = sfhip.lib().sf_attn_fwd(vp(qa.buf.data_ptr()), c, vp(ka.buf.data_ptr()), c, vp(va.buf.data_ptr()), c,
+                                 vp(xa.buf.data_ptr()), c, vp(gam.data_ptr()), None, None, 0, vp(out.buf.data_ptr()),
+                                 c, 0, 2, 1, 1, n, c, 1, vp(o_save.data_ptr()), vp(lse.data_ptr()),
+                                 vp(torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    assert rc == 0
+    assert _rel(out.buf.view(2, n, c), ref) < TOL
+    assert _rel(out.buf, via_ws.buf) < 1e-5
+    lse_ref = torch.logsumexp(q.double() @ k.double().transpose(1, 2), -1) * 1.4426950408889634
+    assert float((lse.double().cpu() - lse_ref).abs().max()) < 1e-3
+
+
 @pytest.mark.parametrize("c,k,s,cout", [(32, (3, 3, 3), (1, 1, 1), 32), (12, (1, 5, 5), (1, 2, 2), 12),
                                         (27, (3, 3, 3), (1, 2, 2), 27), (16, (3, 3, 3), (1, 1, 1), 13)])
 def test_dwconv(c, k, s, cout):
