@@ -555,7 +555,12 @@ def _conv_dgrad_strided(dz, wt_packed, out, kernel, stride, padding, accumulate)
     to the class's positions by the conv kernel's epilogue."""
     cin, _, cout_pad = wt_packed.shape
     kT, kH, kW = kernel
-    if not accumulate:
+    # without accumulation every class WRITES its own positions; only when some class gets no tap at all (1x1x1
+    # stride-2 shortcuts: 3 of 4) does the buffer need zeros underneath
+    every = all(_residue_taps(k, s, p, a)[1] and (full - a + s - 1) // s > 0
+                for k, s, p, full in zip(kernel, stride, padding, (out.T, out.H, out.W)) for a in range(s))
+    add = accumulate or not every
+    if not accumulate and not every:
         out.buf.zero_()
     for at in range(stride[0]):
         ot, tt = _residue_taps(kT, stride[0], padding[0], at)
@@ -579,8 +584,8 @@ def _conv_dgrad_strided(dz, wt_packed, out, kernel, stride, padding, accumulate)
                              out.coff, 1, len(tt), len(th), len(tw), 1, 1, 1, -ot[0], -oh[0], -ow[0], 1, 1, 1,
                              cout_pad, ACT_NONE, out.cs, out.coff, 0, stride[0], stride[1], stride[2], at, ah, aw,
                              out.T, out.H, out.W)
-                _conv_launch(d, dz.ptr(), _ptr(wsub), None, None, out.ptr(), out.ptr(), dz.buf.device,
-                             "sf_conv_fwd(strided dgrad class)")
+                _conv_launch(d, dz.ptr(), _ptr(wsub), None, None, out.ptr() if add else None, out.ptr(),
+                             dz.buf.device, "sf_conv_fwd(strided dgrad class)")
     return out
 
 
