@@ -76,8 +76,13 @@ def test_conv_dgrad_wgrad(case):
     base = torch.randn(n, t, h, w, cin, generator=g)
     dxa = sfhip.Act(base.clone().to(dev))
     sfhip.conv_dgrad(dza, wtp, xa, k, s, p, out=dxa, accumulate=True)
+    # first-writer form into an uninitialised (NaN-filled) buffer: strided layers write every residue class (or zero
+    # the buffer first when a class gets no tap at all), dense layers overwrite
+    fresh = sfhip.Act(torch.full((n, t, h, w, cin), float("nan"), device=dev))
+    sfhip.conv_dgrad(dza, wtp, xa, k, s, p, out=fresh, accumulate=False)
     dwp = sfhip.conv_wgrad(xa, dza, cout, k, s, p)
     torch.cuda.synchronize()
+    assert _rel(_back(fresh), dx_ref) < TOL, name
     e1 = _rel(_back(dxa) - base.permute(0, 4, 1, 2, 3), dx_ref)
     e2 = _rel(sfhip.unpack_conv_weight_grad(dwp, wt.shape), dw_ref)
     _report("conv/%s dgrad" % name, e1)
