@@ -474,10 +474,15 @@ static ConvCfg conv_cfg(const sf_conv_desc* d, long M, int ksplit) {
 
 }  // namespace
 
+int sf_conv_wave_try(const sf_conv_desc* d, const float* in, const float* w, const float* scale,
+                     const float* bias, const float* res, float* out, hipStream_t stream);  // conv_wave.hip
+int sf_conv_wave_takes(const sf_conv_desc* d);                                                // conv_wave.hip
+
 extern "C" long sf_conv_fwd_ws_floats(const sf_conv_desc* d) {
   if (!d) return 0;
   const long M = (long)d->N * d->To * d->Ho * d->Wo;
   if (M <= 0 || d->Cout <= 0 || d->cin_pad <= 0) return 0;
+  if (sf_conv_wave_takes(d)) return 0;  // conv_wave.hip splits long reductions inside the workgroup
   const int S = splitk_factor(d, M);
   return S > 1 ? (long)S * M * d->Cout : 0;
 }
@@ -504,6 +509,10 @@ static int conv_fwd_impl(const sf_conv_desc* d, const float* in, const float* w_
   }
   {  // the Fast pathway's stem: LDS-ring kernel instead of one L2 fetch per tap
     const int rc = sf_conv_stem_fwd_try(d, in, w_packed, scale, bias, res, out, (hipStream_t)stream);
+    if (rc != 1) return rc;
+  }
+  {  // the per-wavefront implicit GEMM (no LDS staging, no barrier in the main loop) for every 16-byte aligned shape
+    const int rc = sf_conv_wave_try(d, in, w_packed, scale, bias, res, out, (hipStream_t)stream);
     if (rc != 1) return rc;
   }
   ConvArgs a;

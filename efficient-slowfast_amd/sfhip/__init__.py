@@ -53,6 +53,7 @@ EXPORTS = [
     "sf_clip_prologue", "sf_conv_wgrad_finish", "sf_bn_bwd_reduce_acc", "sf_row_softmax_fwd", "sf_row_softmax_bwd",
     "sf_attn_bwd_fused_ws_floats", "sf_attn_bwd_fused", "sf_pack_conv_weight", "sf_conv_fwd_ws_floats",
     "sf_conv_fwd_ws", "sf_attn_fwd_ws_floats", "sf_attn_fwd_ws", "sf_affine_fwd_mask", "sf_bn_bwd_apply_first", "sf_maxpool_bwd_first",
+    "sf_conv_tune",
 ]
 _LONG_RET = ("sf_tmax_mean_ws_floats", "sf_channel_stats_ws_floats", "sf_bn_bwd_ws_floats",
              "sf_dwconv_wgrad_ws_floats", "sf_attn_bwd_fused_ws_floats", "sf_conv_fwd_ws_floats",
@@ -128,6 +129,7 @@ def lib():
         L.sf_conv_fwd_ws_floats.restype = cl
         L.sf_conv_fwd_ws.argtypes = [ctypes.POINTER(ConvDesc)] + [vp] * 8
         L.sf_pack_conv_weight.argtypes = [vp, ci, ci, ci, vp, ci, vp, ci, vp]
+        L.sf_conv_tune.argtypes = [ci, ci]
         L.sf_row_softmax_fwd.argtypes = [vp, ci, ci, cl, ci, cf, vp]
         L.sf_row_softmax_bwd.argtypes = [vp, ci, ci, vp, ci, ci, cl, ci, cf, vp]
         L.sf_conv_wgrad_finish.argtypes = [vp, ci, ci, ci, ci, ci, ci, vp, ci, vp]

@@ -81,6 +81,11 @@ int sf_conv_fwd(const sf_conv_desc* d, const float* in, const float* w_packed, c
 long sf_conv_fwd_ws_floats(const sf_conv_desc* d);
 int sf_conv_fwd_ws(const sf_conv_desc* d, const float* in, const float* w_packed, const float* scale,
                    const float* bias, const float* res, float* out, float* ws, void* stream);
+/* Tuning knobs of the dense-conv launcher for microbenchmarks and A/B runs (process-wide, not used by the model code):
+ * knob 0: value 0 routes every conv to the LDS-tiled kernels of conv_igemm.hip instead of the per-wavefront kernels of
+ * conv_wave.hip; knob 1: force tile configuration `value` of conv_wave.hip (-1: planner); knob 2: force the rows per
+ * M tile (0: planner).  Returns SF_EINVAL for an unknown knob.                                                  */
+int sf_conv_tune(int knob, int value);
 /* Packs an nn.Conv3d weight [Cout][Cin][kT*kH*kW] (device) into wp [Cout][taps][cin_pad] and — when wtp != NULL —
  * wtp [Cin][taps][cout_pad] (the data-gradient order), zero padded, in one launch.                           */
 int sf_pack_conv_weight(const float* w, int Cout, int Cin, int taps, float* wp, int cin_pad, float* wtp,

@@ -118,11 +118,23 @@ def test_conv(case):
                                                 (256, 128, (1, 3, 3), (2, 4, 14, 14), False),
                                                 (1024, 256, (1, 1, 1), (2, 4, 14, 14), True)])
 def test_conv_split_k_schedule(cin, cout, k, shp, res):
-    """Short-M / long-K layers take the split-K schedule (partials in a workspace + finish kernel with the full
-    epilogue): same result as torch, and within fp32 re-association of the single-pass schedule."""
+    """Short-M / long-K layers on the LDS-tiled kernels (conv_igemm.hip, the fallback of conv_wave.hip: selected here
+    with sf_conv_tune(0, 0)) take the split-K schedule (partials in a workspace + finish kernel with the full
+    epilogue): same result as torch, and within fp32 re-association of the single-pass schedule and of the
+    per-wavefront kernel's in-workgroup K split."""
     import ctypes
     import sfhip
     dev = _dev()
+    sfhip.lib().sf_conv_tune(0, 0)
+    try:
+        _split_k_case(cin, cout, k, shp, res, dev)
+    finally:
+        sfhip.lib().sf_conv_tune(0, 1)
+
+
+def _split_k_case(cin, cout, k, shp, res, dev):
+    import ctypes
+    import sfhip
     g = torch.Generator().manual_seed(cin + cout)
     n, t, h, w = shp
     x = torch.randn(n, cin, t, h, w, generator=g)
@@ -153,6 +165,13 @@ def test_conv_split_k_schedule(cin, cout, k, shp, res):
     _report("conv split-K %d->%d k%s M=%d" % (cin, cout, k, n * t * h * w), e)
     assert e < TOL
     assert _rel(_back(y_split), _back(y_single)) < 1e-5
+    sfhip.lib().sf_conv_tune(0, 1)  # the default path: per-wavefront kernel, K split across the workgroup's wavefronts
+    assert sfhip.lib().sf_conv_fwd_ws_floats(ctypes.byref(d)) == 0
+    y_wave = sfhip.conv(xa, wp, k, (1, 1, 1), pad, **kw)
+    torch.cuda.synchronize()
+    sfhip.lib().sf_conv_tune(0, 0)
+    assert _rel(_back(y_wave), ref) < TOL
+    assert _rel(_back(y_wave), _back(y_single)) < 1e-5
 
 
 def test_conv_stem_trick():

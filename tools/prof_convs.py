@@ -49,13 +49,21 @@ def timed(kind, fn, describe):
     return w
 
 
+def _odim(i, k, s, p, d):
+    return (i + 2 * p - d * (k - 1) - 1) // s + 1
+
+
 def d_conv(x, wp, kernel, stride=(1, 1, 1), padding=(0, 0, 0), dilation=(1, 1, 1), **k):
     cin = k.get("cin") or x.C
-    return (x.N * x.T * x.H * x.W, cin, wp.shape[0], tuple(kernel), tuple(stride), (x.T, x.H, x.W))
+    othw = k.get("out_thw") or tuple(_odim(i, kk, s, p, d) for i, kk, s, p, d in
+                                     zip((x.T, x.H, x.W), kernel, stride, padding, dilation))
+    # rows = OUTPUT positions (the algorithmic MAC count of a strided conv), not input positions
+    return (x.N * othw[0] * othw[1] * othw[2], cin, wp.shape[0], tuple(kernel), tuple(stride), (x.T, x.H, x.W))
 
 
 def d_dgrad(dz, wtp, x_like, kernel, stride=(1, 1, 1), padding=(0, 0, 0), dilation=(1, 1, 1), **k):
-    return (x_like.N * x_like.T * x_like.H * x_like.W, dz.C, x_like.C, tuple(kernel), tuple(stride),
+    # rows = positions of dL/dz = the forward conv's OUTPUT positions: the useful MACs of the data gradient
+    return (dz.N * dz.T * dz.H * dz.W, dz.C, x_like.C, tuple(kernel), tuple(stride),
             (x_like.T, x_like.H, x_like.W))
 
 
@@ -71,8 +79,7 @@ torch.cuda.synchronize()
 rows = []
 for (kind, m, cin, cout, k, s, thw), (n, ms) in rec.items():
     taps = k[0] * k[1] * k[2]
-    mm = m if kind != "dgrad" else m // (s[0] * s[1] * s[2])  # dgrad: useful MACs are counted at the OUTPUT positions
-    flops = 2.0 * mm * cin * cout * taps * n
+    flops = 2.0 * m * cin * cout * taps * n  # m = forward-output positions for every kind
     rows.append((ms, kind, n, m, cin, cout, k, s, thw, flops / (ms * 1e-3) / 1e12))
 rows.sort(reverse=True)
 tot = sum(r[0] for r in rows)
