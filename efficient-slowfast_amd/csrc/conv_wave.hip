@@ -343,8 +343,11 @@ static double plan_score(const sf_conv_desc* d, long M, int nk, bool has_res, co
 
 }  // namespace
 
+int sf_wgrad_wave_tune(int knob, int value);  // conv_wgrad_wave.hip (knobs 10..)
+
 // Runtime knobs for microbenchmarks / A-B runs (not used by the model code).
 extern "C" int sf_conv_tune(int knob, int value) {
+  if (knob >= 10) return sf_wgrad_wave_tune(knob, value);
   if (knob == 0) g_enable = value;
   else if (knob == 1) g_force_cfg = value;
   else if (knob == 2) g_force_rows = value;

@@ -660,11 +660,19 @@ extern "C" int sf_conv_wgrad_finish(const float* partial, int S, int Cout, int p
   return SF_OK;
 }
 
+int sf_wgrad_wave_splits(const sf_conv_desc* d);  // conv_wgrad_wave.hip
+int sf_wgrad_wave_try(const sf_conv_desc* d, const float* x, const float* dz, int dz_cs, int dz_coff, float* partial,
+                      hipStream_t stream);
+
 // Number of position splits the kernel will use for this problem (the caller sizes the workspace with it).
 extern "C" int sf_conv_wgrad_splits(const sf_conv_desc* d) {
   if (!d) return 0;
   StemArgs sq;
   if (stem_plan(d, 0, &sq)) return stem_workgroups(sq);
+  {
+    const int s = sf_wgrad_wave_splits(d);  // >= 64 channels on both sides: the per-wavefront kernel's own plan
+    if (s > 0) return s;
+  }
   int bco, bci;
   wgrad_tile(d, &bco, &bci);
   const long M = (long)d->N * d->To * d->Ho * d->Wo;
@@ -723,6 +731,10 @@ extern "C" int sf_conv_wgrad(const sf_conv_desc* d, const float* x, const float*
     hipLaunchKernelGGL(conv_wgrad_stem_kernel, dim3(stem_workgroups(sq)), dim3(256), lds, (hipStream_t)stream, sq);
     SF_CHECK_LAUNCH();
     return SF_OK;
+  }
+  {
+    const int rc = sf_wgrad_wave_try(d, x, dz, dz_cs, dz_coff, partial, (hipStream_t)stream);
+    if (rc != 1) return rc;
   }
   a.chunk = ((M + a.S - 1) / a.S + BMS - 1) / BMS * BMS;
   const bool vec4 = (d->Cin % 4 == 0) && (d->in_cs % 4 == 0) && (d->in_coff % 4 == 0) && sf_aligned16(x) &&

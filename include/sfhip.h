@@ -84,7 +84,9 @@ int sf_conv_fwd_ws(const sf_conv_desc* d, const float* in, const float* w_packed
 /* Tuning knobs of the dense-conv launcher for microbenchmarks and A/B runs (process-wide, not used by the model code):
  * knob 0: value 0 routes every conv to the LDS-tiled kernels of conv_igemm.hip instead of the per-wavefront kernels of
  * conv_wave.hip; knob 1: force tile configuration `value` of conv_wave.hip (-1: planner); knob 2: force the rows per
- * M tile (0: planner).  Returns SF_EINVAL for an unknown knob.                                                  */
+ * M tile (0: planner); knob 3: value 1 selects 32-channel K steps; knobs 10 / 11 / 12: the weight-gradient kernels of
+ * conv_wgrad_wave.hip — 10: value 0 routes every weight gradient to conv_wgrad.hip, 11: force the blocks per
+ * wavefront (-1: planner), 12: workgroups to aim at (0: default).  Returns SF_EINVAL for an unknown knob.      */
 int sf_conv_tune(int knob, int value);
 /* Packs an nn.Conv3d weight [Cout][Cin][kT*kH*kW] (device) into wp [Cout][taps][cin_pad] and — when wtp != NULL —
  * wtp [Cin][taps][cout_pad] (the data-gradient order), zero padded, in one launch.                           */
