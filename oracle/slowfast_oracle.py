@@ -102,6 +102,15 @@ def resnet_basic_stem(sd, p, x, kt, training):
     return F.max_pool3d(x, (1, 3, 3), (1, 2, 2), (0, 1, 1))
 
 
+def basic_transform(sd, p, x, kt, stride, training):
+    """resnet_helper.py:25-107 (BasicTransform._construct :71-96, forward :98-106): [kt,3,3] conv / s(1,s,s) /
+    p(kt//2,1,1) -> BN -> ReLU -> [1,3,3] conv / p(0,1,1) -> BN (no final ReLU: ResBlock adds the shortcut first)."""
+    x = _conv(sd, p + ".a", x, (1, stride, stride), (kt // 2, 1, 1))
+    x = F.relu(_bn(sd, p + ".a_bn", x, training))
+    x = _conv(sd, p + ".b", x, 1, (0, 1, 1))
+    return _bn(sd, p + ".b_bn", x, training)
+
+
 def bottleneck(sd, p, x, kt, stride, groups, dilation, training):
     """resnet_helper.py:169-240.  SlowFast* never pass stride_1x1 → stride sits on the 3x3."""
     x = _conv(sd, p + ".a", x, 1, (kt // 2, 0, 0))

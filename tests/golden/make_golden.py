@@ -20,7 +20,7 @@ import torch
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
 from _refimport import import_reference, ref_yaml  # noqa: E402
-from paramgen import fill_state_dict, make_clip, sample_activation  # noqa: E402
+from paramgen import fill_state_dict, make_clip, make_upstream, sample_activation, upstream_seed  # noqa: E402
 
 PARAM_SEED = 7
 CLIP_SEED = 3
@@ -185,6 +185,15 @@ def run_case(case, get_cfg, build_model):
             m.p = 0.0
     model.train()
     acts.clear()
+    child_in = {}
+
+    def pre_hook(name):
+        def f(m, args):
+            a = args[0]
+            child_in[name] = [t.detach().clone() for t in a] if isinstance(a, (list, tuple)) else a.detach().clone()
+        return f
+
+    handles += [m.register_forward_pre_hook(pre_hook(n)) for n, m in model.named_children()]
     xs = clips(grad=True)
     xin = list(xs)
     logits = model(xin)
@@ -216,17 +225,54 @@ def run_case(case, get_cfg, build_model):
         out["grad_input/%s/stats" % nm] = np.array([amax, float(xs[i].grad.norm())], np.float64)
     for h in handles:
         h.remove()
+    stage_gradients(model, child_in, out)
     path = os.path.join(HERE, case["name"] + ".npz")
     np.savez_compressed(path, **out)
     print("%-20s %5.1fs  %6.1f KB  loss=%.5f  max-prob=%.4f" % (
         case["name"], time.time() - t0, os.path.getsize(path) / 1024, loss.item(), float(probs.max())))
 
 
+def stage_gradients(model, child_in, out):
+    """Stage-wise gradient vectors: every top-level child is run on ITS OWN train-mode input of
+    the full forward above with a SEEDED upstream gradient G (paramgen.make_upstream), L = sum_j <G_j, out_j>, and
+    the reference's dL/d(input) and dL/d(parameter) of that child alone are recorded (strided samples + norms).  The
+    end-to-end gradients of these ReLU / max-pool networks amplify fp32 noise to 1-5 % (fp32 vs fp64 of the
+    reference itself); one child at a time does not, so the HIP tape's wiring can be held to a tight tolerance."""
+    names = []
+    for k, (name, child) in enumerate(model.named_children()):
+        if name not in child_in or isinstance(child, torch.nn.MaxPool3d):
+            continue
+        a = child_in[name]
+        ins = [t.clone().requires_grad_(True) for t in a] if isinstance(a, list) else a.clone().requires_grad_(True)
+        model.zero_grad(set_to_none=True)
+        o = child(list(ins) if isinstance(ins, list) else ins)  # a fresh list: several children overwrite x[pathway]
+        outs = list(o) if isinstance(o, (list, tuple)) else [o]
+        loss = 0.0
+        for j, t in enumerate(outs):
+            loss = loss + (t * torch.from_numpy(make_upstream(upstream_seed(k, j), t.shape))).sum()
+        loss.backward()
+        names.append(name)
+        out["stage/%s/index" % name] = np.array([k, len(outs)])
+        for j, t in enumerate(outs):
+            out["stage/%s/out_shape/%d" % (name, j)] = np.array(t.shape)
+        for i, t in enumerate(ins if isinstance(ins, list) else [ins]):
+            g = t.grad if t.grad is not None else torch.zeros_like(t)
+            s_, amax, _ = sample_activation(g.numpy(), 4096)
+            out["stage/%s/gin/%d" % (name, i)] = s_
+            out["stage/%s/gin/%d/stats" % (name, i)] = np.array([amax, float(g.norm())], np.float64)
+        for pn, p in child.named_parameters():
+            g = p.grad if p.grad is not None else torch.zeros_like(p)
+            s_, amax, _ = sample_activation(g.numpy(), 512)
+            out["stage/%s/p/%s" % (name, pn)] = s_
+            out["stage/%s/p/%s/stats" % (name, pn)] = np.array([amax, float(g.norm())], np.float64)
+    out["stage_children"] = np.array(names)
+
+
 def op_vectors(get_cfg, build_model):
     """Per-op vectors at production channel widths from the reference's own modules."""
     from slowfast.models.wdf_attention_helper import ECA, SpatialAttention
     from slowfast.models.custom_video_model_builder import FuseFastAndSlow
-    from slowfast.models.resnet_helper import ResBlock, BottleneckTransform
+    from slowfast.models.resnet_helper import ResBlock, BottleneckTransform, BasicTransform
     from slowfast.models.video_model_builder import FuseFastToSlow
     from slowfast.models.stem_helper import ResNetBasicStem
 
@@ -256,6 +302,10 @@ def op_vectors(get_cfg, build_model):
     run("bottleneck_s3", BottleneckTransform(288, 512, 1, 2, 128, 1), [(1, 288, 2, 28, 28)], 150)
     run("resblock_s5_fast", ResBlock(256, 256, 3, 1, BottleneckTransform, 64), [(1, 256, 8, 7, 7)], 151)
     run("resblock_s4_slow", ResBlock(1152, 1024, 3, 2, BottleneckTransform, 256), [(1, 1152, 2, 14, 14)], 152)
+    # BasicTransform (resnet_helper.py:25-107) instantiated on its own: ResBlock cannot build it (it passes dilation=),
+    # but the class itself is constructible — Tx3x3 -> BN -> ReLU -> 1x3x3 -> BN, stride 2 and stride 1
+    run("basic_transform_s2", BasicTransform(64, 128, 3, 2), [(2, 64, 4, 16, 16)], 157)
+    run("basic_transform_s1", BasicTransform(32, 32, 1, 1), [(2, 32, 4, 14, 14)], 158)
     run("stem_slow", ResNetBasicStem(3, 64, [1, 7, 7], [1, 2, 2], [0, 3, 3]), [(1, 3, 2, 64, 64)], 153)
     run("stem_fast", ResNetBasicStem(3, 8, [5, 7, 7], [1, 2, 2], [2, 3, 3]), [(1, 3, 8, 64, 64)], 154)
     run("f2s_k7", FuseFastToSlow(32, 2, 7, 4), [(1, 256, 2, 14, 14), (1, 32, 8, 14, 14)], 155)

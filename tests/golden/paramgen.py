@@ -78,3 +78,13 @@ def sample_activation(a, n=2048):
     flat = np.asarray(a, dtype=np.float32).reshape(-1)
     step = max(1, flat.size // n)
     return flat[::step][:n].copy(), float(np.abs(flat).max()), float(flat.mean())
+
+
+def make_upstream(seed, shape):
+    """Seeded upstream gradient dL/d(output) of a top-level child (stage-wise gradient fixtures): both the
+    reference side (make_golden.py) and the HIP side regenerate it instead of shipping activation-sized tensors."""
+    return np.random.RandomState(int(seed) & 0x7FFFFFFF).standard_normal(tuple(int(s) for s in shape)).astype(np.float32)
+
+
+def upstream_seed(child_index, out_index):
+    return 90001 + 131 * int(child_index) + int(out_index)

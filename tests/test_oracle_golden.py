@@ -63,6 +63,10 @@ def test_op_vectors():
                 ys = [oracle.spatial_attention(sd, "m", xs[0])]
             elif name.startswith("eca_"):
                 ys = [oracle.eca(sd, "m", xs[0])]
+            elif name == "basic_transform_s2":
+                ys = [oracle.basic_transform(sd, "m", xs[0], 3, 2, False)]
+            elif name == "basic_transform_s1":
+                ys = [oracle.basic_transform(sd, "m", xs[0], 1, 1, False)]
             elif name == "bottleneck_s3":
                 ys = [oracle.bottleneck(sd, "m", xs[0], 1, 2, 1, 1, False)]
             elif name == "resblock_s5_fast":
