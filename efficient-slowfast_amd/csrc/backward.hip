@@ -206,7 +206,7 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ dy, int dy_cs, int
   }
 }
 
-// max-pool backward by equality gather: dx[p] += sum_{windows w containing p} dy[w] * [x[p] == y[w]]
+// max-pool backward by equality gather: dx[p] += sum_{windows w containing p} dy[w] * [p is w's first maximum]
 __global__ void maxpool_bwd_kernel(const sf_pool_desc d, const float* __restrict__ x, const float* __restrict__ y,
                                    const float* __restrict__ dy, int dy_cs, int dy_coff, float* __restrict__ dx,
                                    int dx_cs, int dx_coff, int acc, long total) {
@@ -231,7 +231,24 @@ __global__ void maxpool_bwd_kernel(const sf_pool_desc d, const float* __restrict
     for (int ho = h0; ho <= h1; ++ho)
       for (int wo = w0; wo <= w1; ++wo) {
         const long ro = (((long)n * d.To + to) * d.Ho + ho) * d.Wo + wo;
-        if (y[ro * d.out_cs + d.out_coff + c] == xv) g += dy[ro * dy_cs + dy_coff + c];
+        const float yv = y[ro * d.out_cs + d.out_coff + c];
+        if (yv != xv) continue;
+        // nn.MaxPool3d credits a window's gradient to its FIRST maximum in (t, h, w) scan order only: this element
+        // takes it unless an earlier element of the window holds the same value (ties: exact zeros after a ReLU)
+        bool first = true;
+        const int ts = to * d.sT - d.pT, hs = ho * d.sH - d.pH, ws = wo * d.sW - d.pW;
+        for (int tt = max(ts, 0); tt <= ti && first; ++tt)
+          for (int hh = max(hs, 0); hh < min(hs + d.kH, d.Hi) && first; ++hh) {
+            if (tt == ti && hh > hi) break;
+            for (int ww = max(ws, 0); ww < min(ws + d.kW, d.Wi); ++ww) {
+              if (tt == ti && hh == hi && ww >= wi) break;
+              if (x[((((long)n * d.Ti + tt) * d.Hi + hh) * d.Wi + ww) * d.in_cs + d.in_coff + c] == yv) {
+                first = false;
+                break;
+              }
+            }
+          }
+        if (first) g += dy[ro * dy_cs + dy_coff + c];
       }
   float* o = dx + rin * dx_cs + dx_coff + c;
   *o = acc ? *o + g : g;
@@ -279,7 +296,8 @@ __global__ void pool_final_kernel(const float* __restrict__ partial, int C, floa
   out[(long)b * C + c] = tot;
 }
 
-// ECA backward, apply: dm = dz * gate[b,c] + dpool[b,c]; routed to the frame(s) holding the temporal max
+// ECA backward, apply: dm = dz * gate[b,c] + dpool[b,c]; routed to the FIRST frame holding the temporal max
+// (nn.MaxPool3d((alpha,1,1)) keeps the first maximum's index, custom_video_model_builder.py:131)
 __global__ void eca_bwd_apply_kernel(const float* __restrict__ x, int cs, int coff, int T, int HW, int C, int alpha,
                                      const float* __restrict__ dz, int dz_cs, int dz_coff,
                                      const float* __restrict__ gate, const float* __restrict__ dpool,
@@ -297,7 +315,10 @@ __global__ void eca_bwd_apply_kernel(const float* __restrict__ x, int cs, int co
   for (int a = 1; a < alpha; ++a) mx = fmaxf(mx, s[(long)a * HW * cs]);
   const float dm = dz[((long)b * rows + r) * dz_cs + dz_coff + c] * gate[(long)b * C + c] + dpool[(long)b * C + c];
   for (int a = 0; a < alpha; ++a)
-    if (s[(long)a * HW * cs] == mx) dx[(base + (long)a * HW) * dx_cs + dx_coff + c] += dm;
+    if (s[(long)a * HW * cs] == mx) {
+      dx[(base + (long)a * HW) * dx_cs + dx_coff + c] += dm;
+      break;
+    }
 }
 
 __global__ void bcast_add_kernel(float* __restrict__ g, int cs, int coff, long rows_per_n, int C,
@@ -533,9 +554,26 @@ __global__ __launch_bounds__(256) void maxpool_bwd_vec4_kernel(const sf_pool_des
         const long ro = (((long)n * d.To + to) * d.Ho + ho) * d.Wo + wo;
         const f32x4 yv = *reinterpret_cast<const f32x4*>(y + ro * d.out_cs + d.out_coff + c);
         const f32x4 gv = *reinterpret_cast<const f32x4*>(dy + ro * dy_cs + dy_coff + c);
+        unsigned m = (yv[0] == xv[0] ? 1u : 0u) | (yv[1] == xv[1] ? 2u : 0u) | (yv[2] == xv[2] ? 4u : 0u) |
+                     (yv[3] == xv[3] ? 8u : 0u);
+        if (m) {  // first-maximum rule of nn.MaxPool3d (see the scalar kernel): drop the channels an earlier element ties
+          const int ts = to * d.sT - d.pT, hs = ho * d.sH - d.pH, ws = wo * d.sW - d.pW;
+          for (int tt = max(ts, 0); tt <= ti && m; ++tt)
+            for (int hh = max(hs, 0); hh < min(hs + d.kH, d.Hi) && m; ++hh) {
+              if (tt == ti && hh > hi) break;
+              for (int ww = max(ws, 0); ww < min(ws + d.kW, d.Wi) && m; ++ww) {
+                if (tt == ti && hh == hi && ww >= wi) break;
+                const f32x4 xe = *reinterpret_cast<const f32x4*>(
+                    x + ((((long)n * d.Ti + tt) * d.Hi + hh) * d.Wi + ww) * d.in_cs + d.in_coff + c);
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
-          if (yv[e] == xv[e]) g[e] += gv[e];
+                for (int e = 0; e < 4; ++e)
+                  if (xe[e] == yv[e]) m &= ~(1u << e);
+              }
+            }
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if ((m >> e) & 1u) g[e] += gv[e];
+        }
       }
   f32x4* o = reinterpret_cast<f32x4*>(dx + (long)rin * dx_cs + dx_coff + c);
   *o = acc ? *o + g : g;

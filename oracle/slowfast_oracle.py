@@ -265,6 +265,23 @@ def resnet_basic_head(sd, p, xs, hp, training):
     return logits, _head_tail(logits, training, hp["head_act"])
 
 
+class StopForward(Exception):
+    """Raised by _mark when sd["__stop__"] names the boundary just recorded (test aid: child-level evaluation)."""
+
+
+def _mark(sd, acts, name, x):
+    """Record the output of top-level child `name`.  Test aids (tests/test_stage_grads*.py): sd["__override__"] =
+    {name: tensors} substitutes the child's output — the NEXT child is then evaluated on exactly those tensors (e.g.
+    the HIP path's own activations, as autograd leaves); sd["__stop__"] = name ends the forward here."""
+    ov = sd.get("__override__")
+    if ov is not None and name in ov:
+        x = list(ov[name])
+    acts[name] = x
+    if sd.get("__stop__") == name:
+        raise StopForward(acts)
+    return x
+
+
 # ----------------------------------------------------------------------------- R50 models
 def slowfast_forward(sd, inputs, hp, dual, training=False):
     """SlowFast (video_model_builder.py:399-416) when dual=False,
@@ -274,16 +291,16 @@ def slowfast_forward(sd, inputs, hp, dual, training=False):
     acts = {}
     x = [resnet_basic_stem(sd, "s1.pathway%d_stem" % i, inputs[i], TEMPORAL_KERNEL[0][i], training)
          for i in range(2)]
-    acts["s1"] = x
+    x = _mark(sd, acts, "s1", x)
     for si in range(4):
         if si > 0:
             x = res_stage(sd, "s%d" % (si + 1), x, si - 1, hp, training)
-            acts["s%d" % (si + 1)] = x
+            x = _mark(sd, acts, "s%d" % (si + 1), x)
         x = fuse(sd, "s%d_fuse" % (si + 1), x, hp, training)
-        acts["s%d_fuse" % (si + 1)] = x
+        x = _mark(sd, acts, "s%d_fuse" % (si + 1), x)
         # pathway{0,1}_pool = MaxPool3d(k=s=[1,1,1]) → identity (:278-284, :433-435)
     x = res_stage(sd, "s5", x, 3, hp, training)
-    acts["s5"] = x
+    x = _mark(sd, acts, "s5", x)
     acts["logits"], acts["out"] = resnet_basic_head(sd, "head", x, hp, training)
     return acts
 
@@ -294,12 +311,12 @@ def resnet_forward(sd, inputs, hp, training=False):
     arch = hp["arch"]
     acts = {}
     x = [resnet_basic_stem(sd, "s1.pathway0_stem", inputs[0], SINGLE_TEMPORAL_KERNEL[arch][0][0], training)]
-    acts["s1"] = x
+    x = _mark(sd, acts, "s1", x)
     for si in range(4):
         x = res_stage(sd, "s%d" % (si + 2), x, si, hp, training)
-        acts["s%d" % (si + 2)] = x
+        x = _mark(sd, acts, "s%d" % (si + 2), x)
         if si == 0 and SINGLE_POOL1[arch] != (1, 1, 1):
-            x = [F.max_pool3d(x[0], SINGLE_POOL1[arch], SINGLE_POOL1[arch])]
+            x = _mark(sd, acts, "pathway0_pool", [F.max_pool3d(x[0], SINGLE_POOL1[arch], SINGLE_POOL1[arch])])
     acts["logits"], acts["out"] = resnet_basic_head(sd, "head", x, hp, training)
     return acts
 
@@ -353,9 +370,9 @@ def shufflenetv2_forward(sd, inputs, hp, training=False):
     for pw in range(2):  # stem_helper.py:237-270: conv3x3x3/s(1,2,2) BN ReLU MaxPool3d(3,(1,2,2),1)
         z = _seq_conv_bn(sd, "s1.pathway%d_stem" % pw, 0, inputs[pw], training, True, (1, 2, 2), 1)
         x.append(F.max_pool3d(z, 3, (1, 2, 2), 1))
-    acts["s1"] = x
+    x = _mark(sd, acts, "s1", x)
     x = fuse_fast_and_slow(sd, "s1_fuse", x, hp, training)
-    acts["s1_fuse"] = x
+    x = _mark(sd, acts, "s1_fuse", x)
     for st in range(3):
         nxt = []
         for pw in range(2):
@@ -366,9 +383,9 @@ def shufflenetv2_forward(sd, inputs, hp, training=False):
                 z = shufflev2_block(sd, "%s.%d" % (p, i), z, 2 if i == 0 else 1, training)
             nxt.append(z)
         x = nxt
-        acts["s%d" % (st + 2)] = x
+        x = _mark(sd, acts, "s%d" % (st + 2), x)
         x = fuse_fast_and_slow(sd, "s%d_fuse" % (st + 2), x, hp, training)
-        acts["s%d_fuse" % (st + 2)] = x
+        x = _mark(sd, acts, "s%d_fuse" % (st + 2), x)
     pooled = []  # head_helper.py:499-557
     for pw in range(2):
         z = _seq_conv_bn(sd, "head.pathway%d_conv1x1x1.0" % pw, 0, x[pw], training, True)
@@ -448,7 +465,7 @@ def ghostnet_forward(sd, inputs, hp, training=False):
     acts = {}
     # stem_helper.py:310-336: conv3x3x3/s(1,2,2)/p1 BN ReLU, NO max-pool
     x = [_seq_conv_bn(sd, "s0.pathway%d_stem" % pw, 0, inputs[pw], training, True, (1, 2, 2), 1) for pw in range(2)]
-    acts["s0"] = x
+    x = _mark(sd, acts, "s0", x)
     for st in range(5):
         nxt = []
         for pw in range(2):
@@ -461,10 +478,10 @@ def ghostnet_forward(sd, inputs, hp, training=False):
                                      se, s, training)
             nxt.append(z)
         x = nxt
-        acts["s%d" % (st + 1)] = x
+        x = _mark(sd, acts, "s%d" % (st + 1), x)
         if st < 4:
             x = fuse_fast_and_slow(sd, "s%d_fuse" % (st + 1), x, hp, training)
-            acts["s%d_fuse" % (st + 1)] = x
+            x = _mark(sd, acts, "s%d_fuse" % (st + 1), x)
     pooled = []  # head_helper.py:630-700
     for pw, nm in enumerate(("slow", "fast")):
         z = F.relu(_bn(sd, "head.stage5_conv_%s.bn1" % nm, _conv(sd, "head.stage5_conv_%s.conv" % nm, x[pw]), training))
@@ -514,7 +531,7 @@ def mobilenetv2_forward(sd, inputs, hp, training=False):
     x = [_relu6(_bn(sd, "s1.pathway%d_stem.features.1" % pw,
                     _conv(sd, "s1.pathway%d_stem.features.0" % pw, inputs[pw], (1, 2, 2), 1), training))
          for pw in range(2)]
-    acts["s1"] = x
+    x = _mark(sd, acts, "s1", x)
     for name, a, b in MOBILENETV2_STAGES:
         nxt = []
         for pw in range(2):
@@ -530,11 +547,11 @@ def mobilenetv2_forward(sd, inputs, hp, training=False):
                     idx += 1
             nxt.append(z)
         x = nxt
-        acts[name] = x
+        x = _mark(sd, acts, name, x)
         if name in MOBILENETV2_FUSE_AFTER:
             f = MOBILENETV2_FUSE_AFTER[name]
             x = fuse_fast_and_slow(sd, f, x, hp, training)
-            acts[f] = x
+            x = _mark(sd, acts, f, x)
     pooled = []  # head_helper.py:436-486
     for pw in range(2):
         z = _relu6(_bn(sd, "head.pathway%d_conv1x1x1.1" % pw, _conv(sd, "head.pathway%d_conv1x1x1.0" % pw, x[pw]),
@@ -583,9 +600,9 @@ def shufflenet_forward(sd, inputs, hp, training=False):
         q = "s1.pathway%d_stem" % pw
         z = F.relu(_bn(sd, q + ".1", _conv(sd, q + ".0", inputs[pw], (1, 2, 2), 1), training))
         x.append(F.max_pool3d(z, 3, (1, 2, 2), 1))
-    acts["s1"] = x
+    x = _mark(sd, acts, "s1", x)
     x = fuse_fast_and_slow(sd, "s1_fuse", x, hp, training)
-    acts["s1_fuse"] = x
+    x = _mark(sd, acts, "s1_fuse", x)
     for si, nb in enumerate((4, 8, 4)):
         name = "s%d" % (si + 2)
         nxt = []
@@ -596,9 +613,9 @@ def shufflenet_forward(sd, inputs, hp, training=False):
                 z = shufflenet_bottleneck(sd, "%s.%d" % (q, i), z, 2 if i == 0 else 1, groups, training)
             nxt.append(z)
         x = nxt
-        acts[name] = x
+        x = _mark(sd, acts, name, x)
         x = fuse_fast_and_slow(sd, name + "_fuse", x, hp, training)
-        acts[name + "_fuse"] = x
+        x = _mark(sd, acts, name + "_fuse", x)
     z = torch.cat([t.mean((2, 3, 4), keepdim=True) for t in x], 1).permute(0, 2, 3, 4, 1)  # head_helper.py:562-609
     logits = F.linear(z, sd["head.classifier.1.weight"], sd["head.classifier.1.bias"])
     acts["logits"], acts["out"] = logits, _head_tail(logits, training, hp["head_act"])

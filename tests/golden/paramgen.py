@@ -74,9 +74,11 @@ def make_clip(seed, batch, t_fast, alpha, size, channels=3):
 
 
 def sample_activation(a, n=2048):
-    """Strided digest of a big activation: (flat strided sample, absmax, mean, shape)."""
+    """Strided digest of a big activation: (flat strided sample, absmax, mean).  The stride is made ODD: every
+    tensor dimension here is a power of two times 7 or 3, and an even stride would only ever visit w = 0 and a few h
+    (a [2,64,8,16,16] tensor sampled at stride 64 sees one column) — an odd stride walks through all of them."""
     flat = np.asarray(a, dtype=np.float32).reshape(-1)
-    step = max(1, flat.size // n)
+    step = max(1, flat.size // n) | 1
     return flat[::step][:n].copy(), float(np.abs(flat).max()), float(flat.mean())
 
 

@@ -89,9 +89,18 @@ def test_launch_planning_queries_are_host_only_and_fill_the_chip():
     import ctypes
     import sfhip
     L = sfhip.lib()
-    # res2 3x3 64->64 at 8x8x56x56: 9 tiles of 64x64 per tap set -> S chosen so that 9*S workgroups fill whole rounds
+    # res2 3x3 64->64 at 8x8x56x56.  Per-wavefront kernel (conv_wgrad_wave.hip): 9 (tap, 64-channel) column blocks,
+    # two per wavefront -> 5 tiles, S chosen so that 5*S workgroups fill whole rounds of 256; LDS-tiled fallback
+    # (sf_conv_tune(10, 0)): 9 tiles of 64x64, 9*S workgroups
     d = _conv_desc(8, 8, 56, 56, 64, 64, (1, 3, 3))
     S = L.sf_conv_wgrad_splits(ctypes.byref(d))
+    wg = 5 * S
+    assert 256 <= wg <= 1024 and wg / (-(-wg // 256) * 256) >= 0.94, (S, wg)
+    L.sf_conv_tune(10, 0)
+    try:
+        S = L.sf_conv_wgrad_splits(ctypes.byref(d))
+    finally:
+        L.sf_conv_tune(10, 1)
     wg = 9 * S
     assert 512 <= wg <= 1024 and wg / (-(-wg // 256) * 256) >= 0.94, (S, wg)
     assert L.sf_conv_fwd_ws_floats(ctypes.byref(d)) == 0                       # 1568 tiles: no split-K

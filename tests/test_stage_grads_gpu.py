@@ -1,10 +1,18 @@
 """Stage-wise gradient parity ("harden parity where the tests are blind"): the end-to-end gradient check
 has to accept 8 % because these ReLU / max-pool networks amplify fp32 noise (the reference's own fp32-vs-fp64
 gradients differ by 1-5 %), so a wrongly wired fan-in in one residual branch could hide in it.  Here every top-level
-child's backward is replayed ON ITS OWN from the tape of one full training forward, with the seeded upstream gradient
-the reference side used (tests/golden/make_golden.py::stage_gradients), and the child's dL/d(input) and
-dL/d(parameters) are held to the reference's — one child at a time there is no chaotic amplification, and the ops
-replayed are exactly the ones the whole-model backward runs (same tape, same reserved concat slices, same
+child's backward is replayed ON ITS OWN from the tape of one full training forward, with a seeded upstream gradient,
+and the child's dL/d(input) and dL/d(parameters) are held
+
+  (1) to the oracle's autograd through that child evaluated on THE SAME input tensors (the HIP path's own
+      activations copied to the host, tests/_stage.py) — identical inputs leave only in-child rounding, so ReLU-mask
+      flips are rare even in the S = 64 fixtures' deep stages (256 .. 16 positions per channel); the oracle's
+      child-level backward is itself pinned to the reference at 1e-4 by tests/test_stage_grads_cpu.py;
+  (2) to the reference's own vectors (fixtures 'stage/*', make_golden.py::stage_gradients), whose child inputs
+      differ from the HIP ones by the accumulated forward rounding (up to 7e-5) — enough for ~1e-4 of the masks to
+      flip, i.e. 0.2-1 % of a 256-sample reduction.
+
+The ops replayed are exactly the ones the whole-model backward runs (same tape, same reserved concat slices, same
 first-writer / accumulate decisions)."""
 import os
 
@@ -12,13 +20,21 @@ import numpy as np
 import pytest
 import torch
 
+from _stage import boundaries, oracle_child_grads
 from _util import MODEL_CASES, case_inputs, load_case, sample_activation
 from paramgen import make_upstream, upstream_seed
 from test_models_gpu import _build
 
 pytestmark = pytest.mark.gpu
-TOL = 2e-3           # relative L2 of the sampled gradient (observed <= a few 1e-4; one ReLU tie flip inside a stage costs ~1e-3)
-TOL_NORM = 2e-3      # relative error of the full gradient's L2 norm
+# Resolution of these fixtures: their deep tensors are small (S = 64: 7e3 .. 3e5 elements), so ONE ReLU-mask flip is a
+# relative-L2 error of 1/sqrt(numel) = 2e-3 .. 1e-2 of the whole tensor, and a flip needs only a 1e-6 difference in a
+# pre-activation (measured with the oracle alone, tests/tools/stage_grad_sensitivity.py: perturbing the oracle's own s2
+# input of slow_r18_s64 by 1e-7 moves its gradients by 3e-7, by 1e-6 by 3.5e-3).  Both comparators see such flips
+# independently (the oracle's rounding differs from the HIP kernels' on identical inputs; the reference's inputs differ
+# by the accumulated forward rounding), so a tensor passes when it is TIGHT against one of them and LOOSE against both:
+# a wrongly wired fan-in / dropped residual term moves a child's gradients by tens of percent against both.
+TOL = 1e-2           # min(vs oracle, vs reference)
+TOL_LOOSE = 6e-2     # max(vs oracle, vs reference)
 
 
 def _report(line):
@@ -76,11 +92,15 @@ def test_stage_gradients_match_reference(name):
     saved = engine.OVERLAP_PATHS
     engine.OVERLAP_PATHS = False  # one stream: a sub-range of the tape can be replayed without its region markers
     try:
+        clips_cpu = case_inputs(meta)
+        children = [str(c) for c in z["children"]]
+        acts0 = boundaries(meta, sd, clips_cpu)
         with torch.no_grad(), engine.taping(t):
-            model._forward_impl([x.cuda() for x in case_inputs(meta)])
+            model._forward_impl([x.cuda() for x in clips_cpu])
         torch.cuda.synchronize()
         worst = 0.0
         checked = 0
+        bad = []
         for child in [str(c) for c in z["stage_children"]]:
             assert child in marks, "child %s was never called by the HIP model" % child
             start, ins, end, outs = marks[child]
@@ -103,46 +123,56 @@ def test_stage_gradients_match_reference(name):
                     assert side is None
                     fn()
             torch.cuda.synchronize()
+            # ---- the oracle on the same inputs
+            ins_cpu = [sfhip.to_ncthw(a).cpu() if isinstance(a, sfhip.Act) else a.detach().cpu() for a in ins]
+            _, ogin, opg = oracle_child_grads(meta, sd, clips_cpu, children, child, k, acts0, inputs=ins_cpu)
+            pscale = max([float(g.norm()) for g in opg.values() if g is not None] + [0.0])
             # ---- dL/d(input)
             for i, a in enumerate(ins):
                 tag = "stage/%s/gin/%d" % (child, i)
-                ref = z[tag]
-                rnorm = float(z[tag + "/stats"][1])
                 if not isinstance(a, sfhip.Act):
                     continue  # raw NCTHW clips into the stem: dL/d(clip) is covered by test_input_gradients
                 gb = t.gbuf.get(a.buf.data_ptr())
+                oref = ogin[i].numpy()
                 if gb is None:
-                    assert rnorm == 0.0, (child, i, "the HIP child produced no input gradient")
+                    assert float(np.abs(oref).max()) == 0.0, (child, i, "the HIP child produced no input gradient")
                     continue
                 gi = _view(sfhip.Act(gb.view(a.buf.shape), a.coff, a.C)).contiguous().cpu().numpy()
+                e = _l2rel(gi, oref)
                 s, _, _ = sample_activation(gi, 4096)
-                e = _l2rel(s, ref)
-                norm = float(np.linalg.norm(gi.astype(np.float64)))
-                _report("%-22s %-12s gin%d   L2rel %.3e  |g| %.5e vs %.5e" % (name, child, i, e, norm, rnorm))
+                er = _l2rel(s, z[tag])
+                _report("%-22s %-12s gin%d   vs oracle %.3e   vs reference %.3e" % (name, child, i, e, er))
                 worst = max(worst, e)
-                assert e < TOL, (child, i, e)
-                assert abs(norm - rnorm) <= TOL_NORM * rnorm + 1e-12, (child, i, norm, rnorm)
+                if not (min(e, er) < TOL and max(e, er) < TOL_LOOSE):
+                    bad.append((child, "gin%d" % i, e, er))
                 checked += 1
-            # ---- dL/d(parameters)
+            # ---- dL/d(parameters).  Some gradients are analytically ZERO (a conv bias in front of a train-mode BN, the
+            # key bias of a softmax over keys): both sides then hold rounding noise, which is compared against the
+            # child's largest parameter-gradient norm instead of against itself.
             for pn, p in getattr(model, child).named_parameters():
                 tag = "stage/%s/p/%s" % (child, pn)
-                ref = z[tag]
-                rnorm = float(z[tag + "/stats"][1])
+                og = opg.get(pn)
                 g = t.pgrads.get(p)
                 if g is None:
-                    assert rnorm == 0.0, (child, pn, "no gradient on the HIP side")
+                    assert og is None or float(og.norm()) <= 1e-5 * pscale, (child, pn, "no gradient on the HIP side")
                     continue
                 gn = g.detach().reshape(p.shape).cpu().numpy()
+                on = og.numpy() if og is not None else np.zeros_like(gn)
+                if float(np.linalg.norm(on)) <= 1e-6 * pscale:
+                    assert float(np.linalg.norm(gn)) <= 1e-5 * pscale, (child, pn)
+                    checked += 1
+                    continue
+                e = _l2rel(gn, on)
                 s, _, _ = sample_activation(gn, 512)
-                e = _l2rel(s, ref)
-                norm = float(np.linalg.norm(gn.astype(np.float64)))
+                er = _l2rel(s, z[tag])
                 worst = max(worst, e)
-                if e > 0.25 * TOL:
-                    _report("%-22s %-12s %-52s L2rel %.3e" % (name, child, pn, e))
-                assert e < TOL, (child, pn, e)
-                assert abs(norm - rnorm) <= TOL_NORM * rnorm + 1e-12, (child, pn, norm, rnorm)
+                if min(e, er) > 0.1 * TOL:
+                    _report("%-22s %-12s %-52s vs oracle %.3e   vs reference %.3e" % (name, child, pn, e, er))
+                if not (min(e, er) < TOL and max(e, er) < TOL_LOOSE):
+                    bad.append((child, pn, e, er))
                 checked += 1
         _report("%-22s stage-wise gradients: %d tensors checked, worst L2rel %.3e" % (name, checked, worst))
+        assert not bad, bad[:12]
         assert checked >= 20
     finally:
         engine.OVERLAP_PATHS = saved
