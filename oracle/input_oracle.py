@@ -91,8 +91,9 @@ def input_step(clip_u8, mean, std, spatial_idx, min_scale, max_scale, crop_size,
 
 def test_meter_ensemble(preds, labels, clip_ids, num_videos, num_clips, method="sum"):
     """TestMeter.update_stats' per-clip loop (utils/meters.py:277-312) + finalize top-k (:351-366,
-    utils/metrics.py:9-42) restated with numpy.  PARITY UNPINNED: utils/meters.py is not importable in the build
-    container and the reference ships no test for it."""
+    utils/metrics.py:9-42) restated with numpy.  Pinned by tests/test_meter_cpu.py against the reference's own TestMeter
+    run in the build container behind import stand-ins (tests/golden/make_golden_meter.py -> test_meter.npz):
+    ensembles, labels, counts and top-1; the reference's own top-5 raises on torch >= 1.8 (metrics.py:40 .view(-1))."""
     vp = np.zeros((num_videos, preds.shape[1]), np.float32)
     vl = np.zeros((num_videos,), np.int64)
     cnt = np.zeros((num_videos,), np.int64)

@@ -316,6 +316,31 @@ def op_vectors(get_cfg, build_model):
     print("op_vectors           %6.1f KB" % (os.path.getsize(path) / 1024))
 
 
+def init_digests(get_cfg, build_model):
+    """SHA-256 of every tensor of the reference's FRESH state_dict under torch.manual_seed(0) (no paramgen fill): pins
+    init_weights AND the order in which module construction consumes the RNG (a15 'parameter identity
+    under a seed')."""
+    import hashlib
+    out = {}
+    for case in CASES:
+        if case["name"] not in ("shufflenetv2_cfg1", "slowfast_r50_s64", "dual_r50_s64", "ghostnet_w2_s64",
+                                "mobilenetv2_w1_s64", "shufflenet_g1_s64", "i3d_r50_s64"):
+            continue
+        cfg = get_cfg()
+        cfg.merge_from_file(ref_yaml(case["yaml"]))
+        cfg.merge_from_list(COMMON + ["MODEL.MODEL_NAME", case["model"]] + case["over"])
+        torch.manual_seed(0)
+        sd = build_model(cfg).state_dict()
+        out[case["name"]] = {k: hashlib.sha256(v.detach().cpu().contiguous().numpy().tobytes()).hexdigest()[:16]
+                             for k, v in sd.items()}
+        # what the generator state looks like afterwards: the same number of draws must have been consumed
+        out[case["name"]]["__next_rand__"] = "%.9f" % float(torch.rand(1))
+    path = os.path.join(HERE, "init_digests.json")
+    with open(path, "w") as f:
+        json.dump(out, f, indent=0, sort_keys=True)
+    print("init_digests         %6.1f KB" % (os.path.getsize(path) / 1024))
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
     get_cfg, build_model = import_reference()
@@ -325,3 +350,5 @@ if __name__ == "__main__":
             run_case(c, get_cfg, build_model)
     if not which or "ops" in which:
         op_vectors(get_cfg, build_model)
+    if not which or "init" in which:
+        init_digests(get_cfg, build_model)

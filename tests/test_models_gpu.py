@@ -199,6 +199,7 @@ def test_train_mode_forward_matches_reference_golden(name):
             assert e < 1e-4, (tag, e)  # 0.1 x batch statistics at the end of a train-mode chain
             nbuf += 1
     _report("%-22s train running-stat buffers checked: %d" % (name, nbuf))
+    assert nbuf >= 8, "fixture %s carries no train_buffers/*: regenerate it with tests/golden/make_golden.py" % name
 
 
 @pytest.mark.parametrize("name", MODEL_CASES)
