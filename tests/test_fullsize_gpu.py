@@ -199,3 +199,57 @@ def test_model_properties_at_baseline_size(workload):
     _report("%s 224^2 T=32 B=3: eval row-sum err %.1e, batch independence %.1e, graph == eager, train step deterministic "
             "and == serial schedule (|grad| %.3e)" % (workload, float((p_all.sum(1) - 1.0).abs().max()),
                                                    float((p_all[1:2] - p_one).abs().max()), float(a.norm())))
+
+
+@pytest.mark.parametrize("workload", ["dual", "slowfast"])
+def test_fullsize_eval_forward_matches_oracle(workload):
+    """cfg #3 / #2 of BASELINE.json at their real size (224^2, T = 32, alpha = 4), ONE clip: every top-level child's
+    output, the pre-activation logits and the output probabilities of the HIP eval forward against the oracle's on
+    the same seeded parameters and clip (north_star: within 1e-3 rel fp32, max-norm).  The oracle needs ~6 GB and a
+    few seconds per clip for the dense N = 25 088 attention."""
+    import sfhip
+    from oracle import slowfast_oracle as oracle
+    from slowfast.models import head_helper
+    dev = _dev()
+    bench, cfg, model = _model(workload)
+    xs = bench.synthetic_clips(cfg, 1, "cpu", 1)
+    model.eval()
+    acts, tap = {}, {}
+
+    def hook(child):
+        def f(m, i, o):
+            if isinstance(o, (list, tuple)):
+                acts[child] = [sfhip.to_ncthw(a).cpu() if isinstance(a, sfhip.Act) else a.cpu() for a in o]
+        return f
+
+    handles = [m.register_forward_hook(hook(n)) for n, m in model.named_children()]
+    head_helper.LOGITS_TAP = lambda t: tap.__setitem__("logits", t.detach().cpu())
+    try:
+        with torch.no_grad():
+            out = model([x.to(dev) for x in xs]).cpu()
+        torch.cuda.synchronize()
+    finally:
+        head_helper.LOGITS_TAP = None
+        for h in handles:
+            h.remove()
+    torch.set_num_threads(min(os.cpu_count() or 1, 32))
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    ref = oracle.forward(cfg.MODEL.MODEL_NAME, sd, xs, bench.oracle_hparams(cfg))
+
+    def rel(a, b):
+        return float((a.double() - b.double()).abs().max() / b.double().abs().max())
+
+    worst, checked = 0.0, 0
+    for child, outs in acts.items():
+        if child not in ref:
+            continue
+        for i, a in enumerate(outs):
+            e = rel(a, ref[child][i])
+            worst = max(worst, e)
+            checked += 1
+            assert e < 1e-3, (child, i, e)
+    e_log = rel(tap["logits"].reshape(1, -1), ref["logits"].reshape(1, -1))
+    e_out = rel(out, ref["out"])
+    _report("%s 224^2 T=32 B=1 vs oracle: %d child outputs, worst %.2e; logits %.2e; output %.2e" % (
+        workload, checked, worst, e_log, e_out))
+    assert checked >= 16 and e_log < 1e-3 and e_out < 1e-3
