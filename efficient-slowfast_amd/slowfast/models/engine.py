@@ -56,6 +56,8 @@ class Tape(object):
         self.out_act = None
         self.sink = None  # {param: its .grad} when parameter gradients are accumulated in place (set_grad_sink)
         self.side = None  # the side stream ops are being recorded for (run_paths), None = the caller's stream
+        self.input_ids = {}    # id(clip tensor) -> input index, for the inputs whose gradient autograd asked for
+        self.input_grads = {}  # input index -> dL/d(clip), NCTHW (written by the stems' backward)
         self.joins = set()  # companion streams with weight-gradient work in flight (joined at the end of backward)
 
     def pgrad_target(self, param):
@@ -574,10 +576,47 @@ def stem_conv_bn_relu(x, conv, bn, relu=True):
 
         _record_conv(view, conv.weight, conv.bias, wp.shape, z, (kT, kH, 1), (1, sH, 1), (pT, 0, 0), (1, 1, 1),
                      x_needs_grad=False, cin=4 * kW, unpack=unpack, fold_kw=kW)
+        _record_stem_input_grad(x, conv, z, view, (N, C, T, H, W), (pH, pW, Wp), Wo)
         return bn_train_apply(bn, z, relu=relu)
     scale, bias = bn_affine(bn, conv.bias)
     return sfhip.conv(view, wp, (kT, kH, 1), (1, sH, 1), (pT, 0, 0), scale=scale, bias=bias, relu=relu,
                       cin=4 * kW, out_thw=thw)
+
+
+def _record_stem_input_grad(x, conv, z, view, ncthw, geom, Wo):
+    """dL/d(clip) when the caller asked for it (x.requires_grad: saliency / adversarial uses; train_net.py never
+    does).  In the stem-trick layout a tap reads kW*4 contiguous floats = ceil(kW*4 / (4*sW)) whole pixels of 4*sW
+    floats, so the stem IS an ordinary conv with kernel (kT, kH, KP) over pixels with 4*sW channels (weights
+    re-arranged, zero where a tap's float index runs past kW*4) and its data gradient is the generic one; the clip's
+    gradient is the interior (borders and the pad channel dropped) of that buffer."""
+    t = tape()
+    if t is None or not isinstance(x, torch.Tensor) or id(x) not in t.input_ids:
+        return
+    N, C, T, H, W = ncthw
+    pH, pW, Wp = geom
+    kT, kH, kW = conv.kernel_size
+    _, sH, sW = conv.stride
+    pT = conv.padding[0]
+    pix = 4 * sW
+    KP = (kW * 4 + pix - 1) // pix
+    if view.W - KP + 1 != Wo:
+        raise NotImplementedError("input gradient of a stem whose packed row is wider than its outputs need")
+    idx = t.input_ids[id(x)]
+
+    def make():  # [Cout, 3, kT, kH, kW] -> pixel-conv weight [Cout, pix, kT, kH, KP] -> data-gradient packing
+        w = conv.weight
+        w4 = torch.zeros((w.shape[0], kT, kH, KP * pix), dtype=torch.float32, device=w.device)
+        w4[..., :kW * 4].view(w.shape[0], kT, kH, kW, 4)[..., :C] = w.permute(0, 2, 3, 4, 1)
+        wpix = w4.view(w.shape[0], kT, kH, KP, pix).permute(0, 4, 1, 2, 3).contiguous()
+        return sfhip.pack_conv_weight(wpix.transpose(0, 1).contiguous())
+
+    def bwd():  # z's buffer holds dL/dz after the BN backward
+        wtp = _cached_t(conv.weight, "_sf_wtp_stem", _key(conv.weight), make)
+        dxp = sfhip.conv_dgrad(z, wtp, view, (kT, kH, KP), (1, sH, 1), (pT, 0, 0))
+        full = dxp.buf.view(N, T, H + 2 * pH, Wp, 4)
+        t.input_grads[idx] = full[:, :, pH:pH + H, pW:pW + W, :C].permute(0, 4, 1, 2, 3).contiguous()
+
+    t.record(bwd)
 
 
 def maxpool(x, kernel, stride, padding=(0, 0, 0), out_reserve=(0, 0)):
@@ -617,6 +656,8 @@ class TapedForward(torch.autograd.Function):
     def forward(ctx, model, n_in, *args):
         inputs, params = list(args[:n_in]), args[n_in:]
         t = Tape()
+        t.input_ids = {id(x): i for i, x in enumerate(inputs)
+                       if isinstance(x, torch.Tensor) and ctx.needs_input_grad[2 + i]}
         with taping(t):
             out = model._forward_impl(inputs)
         if t.out_act is None:
@@ -637,8 +678,12 @@ class TapedForward(torch.autograd.Function):
             t.backward()
         sink = t.sink or {}
         grads = tuple(None if p in sink else t.pgrads.get(p) for p in ctx.params)
+        gin = tuple(t.input_grads.get(i) for i in range(ctx.n_in))
+        if any(ctx.needs_input_grad[2 + i] and gin[i] is None for i in range(ctx.n_in)):
+            raise NotImplementedError("dL/d(input) was requested for an input this model's stem does not "
+                                      "differentiate (PackedClip inputs / non-stem consumers)")
         ctx.tape = None
-        return (None, None) + (None,) * ctx.n_in + grads
+        return (None, None) + gin + grads
 
 
 def run_model(model, x):

@@ -249,6 +249,37 @@ def test_train_step_gradients_match_reference_golden(name):
     assert not missing, missing[:5]
 
 
+@pytest.mark.parametrize("name", ["dual_r50_s64", "slowfast_r50_s64", "shufflenetv2_cfg1", "ghostnet_w2_s64",
+                                  "i3d_r50_s64"])
+def test_input_gradients_match_reference_golden(name):
+    """dL/d(clip) of the training step (the fixtures' 'grad_input/*') through the stems' data gradient:
+    clips passed with requires_grad=True receive .grad like any autograd input.  End-to-end tolerance as for the
+    parameter gradients (the chaotic 1-5 % floor of these fixtures); the stems' own data gradient is held tightly by
+    tests/test_stage_grads_gpu.py (child s1 / s0)."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    z, meta = load_case(name)
+    model, sd = _build(meta, z)
+    for m in model.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    model.train()
+    xs = [x.cuda().requires_grad_(True) for x in case_inputs(meta)]
+    logits = model(xs)
+    labels = torch.from_numpy(z["train/labels"]).cuda()
+    torch.nn.functional.cross_entropy(logits, labels).backward()
+    torch.cuda.synchronize()
+    for x, nm in zip(xs, ("fast",) if meta.get("single") else ("slow", "fast")):
+        assert x.grad is not None and tuple(x.grad.shape) == tuple(x.shape), nm
+        g = x.grad.cpu().numpy()
+        s, _, _ = sample_activation(g, 4096)
+        ref = z["grad_input/" + nm].astype(np.float64)
+        e = float(np.linalg.norm(s.astype(np.float64) - ref) / max(np.linalg.norm(ref), 1e-30))
+        norm, rnorm = float(np.linalg.norm(g.astype(np.float64))), float(z["grad_input/%s/stats" % nm][1])
+        _report("%-22s grad_input/%s L2rel %.3e  |g| %.4e vs %.4e" % (name, nm, e, norm, rnorm))
+        assert e < 8e-2 and abs(norm - rnorm) < 5e-2 * rnorm, (nm, e, norm, rnorm)
+
+
 def test_precise_bn_pass_matches_oracle_batch_statistics():
     """calculate_and_update_precise_bn (train_net.py:277-296 -> fvcore update_bn_stats): after the pass every BN's
     running statistics are the plain average over the iterations of its per-batch (mean, unbiased var); the

@@ -95,8 +95,10 @@ def test_stage_gradients_match_reference(name):
         clips_cpu = case_inputs(meta)
         children = [str(c) for c in z["children"]]
         acts0 = boundaries(meta, sd, clips_cpu)
+        clips_gpu = [x.cuda() for x in clips_cpu]
+        t.input_ids = {id(x): i for i, x in enumerate(clips_gpu)}  # ask the stems for dL/d(clip) too
         with torch.no_grad(), engine.taping(t):
-            model._forward_impl([x.cuda() for x in clips_cpu])
+            model._forward_impl(clips_gpu)
         torch.cuda.synchronize()
         worst = 0.0
         checked = 0
@@ -108,7 +110,7 @@ def test_stage_gradients_match_reference(name):
             if child == "head":
                 outs = [t.out_act]
             assert len(outs) == nouts, (child, len(outs), nouts)
-            t.gbuf, t.pgrads, t.sink = {}, {}, None
+            t.gbuf, t.pgrads, t.sink, t.input_grads = {}, {}, None, {}
             with torch.no_grad():
                 for j, o in enumerate(outs):
                     shape = tuple(int(v) for v in z["stage/%s/out_shape/%d" % (child, j)])
@@ -130,14 +132,16 @@ def test_stage_gradients_match_reference(name):
             # ---- dL/d(input)
             for i, a in enumerate(ins):
                 tag = "stage/%s/gin/%d" % (child, i)
-                if not isinstance(a, sfhip.Act):
-                    continue  # raw NCTHW clips into the stem: dL/d(clip) is covered by test_input_gradients
-                gb = t.gbuf.get(a.buf.data_ptr())
                 oref = ogin[i].numpy()
-                if gb is None:
-                    assert float(np.abs(oref).max()) == 0.0, (child, i, "the HIP child produced no input gradient")
-                    continue
-                gi = _view(sfhip.Act(gb.view(a.buf.shape), a.coff, a.C)).contiguous().cpu().numpy()
+                if not isinstance(a, sfhip.Act):  # a raw NCTHW clip into a stem: the stem's own data gradient
+                    assert i in t.input_grads, (child, i, "the stem produced no dL/d(clip)")
+                    gi = t.input_grads[i].cpu().numpy()
+                else:
+                    gb = t.gbuf.get(a.buf.data_ptr())
+                    if gb is None:
+                        assert float(np.abs(oref).max()) == 0.0, (child, i, "the HIP child produced no input gradient")
+                        continue
+                    gi = _view(sfhip.Act(gb.view(a.buf.shape), a.coff, a.C)).contiguous().cpu().numpy()
                 e = _l2rel(gi, oref)
                 s, _, _ = sample_activation(gi, 4096)
                 er = _l2rel(s, z[tag])
