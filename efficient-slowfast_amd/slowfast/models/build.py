@@ -46,6 +46,7 @@ def build_model(cfg):
         cur_device = torch.cuda.current_device()
         model = model.cuda(device=cur_device)
     if cfg.NUM_GPUS > 1:
+        model._sf_ddp_wrapped = True  # engine.set_grad_sink refuses models whose gradients must pass DDP's hooks
         model = torch.nn.parallel.DistributedDataParallel(
             module=model, device_ids=[cur_device], output_device=cur_device)
     return model

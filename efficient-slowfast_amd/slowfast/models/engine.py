@@ -642,7 +642,8 @@ def set_grad_sink(enabled):
     accumulate in one launch; BatchNorm dgamma/dbeta: inside the reduction's final kernel) instead of being handed
     to autograd, which would add one temporary, one copy and one accumulate launch per parameter.  Use it with
     pre-allocated gradients (utils.distributed.FlatGradients binds every .grad to one flat buffer).  Autograd
-    hooks on the parameters (DistributedDataParallel) do NOT fire for sunk gradients: leave it off under DDP."""
+    hooks on the parameters (DistributedDataParallel) do NOT fire for sunk gradients: leave it off under DDP —
+    run_model raises for a model that build_model wrapped in DistributedDataParallel while the sink is on."""
     global _GRAD_SINK
     _GRAD_SINK = bool(enabled)
 
@@ -692,6 +693,10 @@ def run_model(model, x):
     outer, _NBT = _NBT, []
     try:
         if model.training and torch.is_grad_enabled():
+            if _GRAD_SINK and getattr(model, "_sf_ddp_wrapped", False):
+                raise RuntimeError("engine.set_grad_sink(True) bypasses autograd's gradient hooks, which "
+                                   "DistributedDataParallel's all-reduce depends on: switch the sink off, or use "
+                                   "utils.distributed.FlatGradients on the unwrapped model")
             params = [p for p in model.parameters()]
             return TapedForward.apply(model, len(x), *x, *params)
         return model._forward_impl(x)

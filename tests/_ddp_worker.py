@@ -1,0 +1,134 @@
+"""Multi-GPU readiness workers (launched by tests/test_multigpu_gpu.py), all on the box's single GPU.
+
+mode ddp   : ONE process, a world-1 `nccl` (RCCL) group; the HIP dual_r50_s64 model wrapped by build_model exactly as
+             the reference does for NUM_GPUS > 1 (models/build.py:39-43; torch.cuda.device_count is patched to 2 so the
+             drop-in's own assertion lets NUM_GPUS = 2 through).  DistributedDataParallel's gradient hooks must fire
+             through TapedForward (a comm hook counts the buckets) and the gradients must equal the unwrapped model's;
+             with the gradient sink on, the wrapped model must refuse to run.
+mode flat  : TWO processes over gloo (RCCL refuses two ranks on one device), each with half of the fixture batch:
+             FlatGradients + the in-kernel gradient sink + ONE flat all-reduce == the mean of the two ranks' gradients
+             (each rank also computes the other rank's gradient locally as the checker)."""
+import contextlib
+import io
+import json
+import os
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+for p in (ROOT, os.path.join(ROOT, "efficient-slowfast_amd"), HERE, os.path.join(HERE, "golden")):
+    sys.path.insert(0, p)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+
+def build(meta, z, num_gpus):
+    from _util import seeded_state_dict
+    from slowfast.config.defaults import get_cfg
+    from slowfast.models import build_model
+    cfg = get_cfg()
+    cfg.merge_from_other_cfg(meta["cfg_dump"])
+    cfg.NUM_GPUS = num_gpus
+    with contextlib.redirect_stdout(io.StringIO()):
+        model = build_model(cfg)
+    inner = model.module if hasattr(model, "module") else model
+    inner.load_state_dict(seeded_state_dict(z["sd_keys"], z["sd_shapes"], meta["param_seed"]))
+    for m in inner.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    return model.train()
+
+
+def grads_of(model, xs, labels):
+    inner = model.module if hasattr(model, "module") else model
+    inner.zero_grad(set_to_none=True)
+    torch.nn.functional.cross_entropy(model([x.clone() for x in xs]), labels).backward()
+    torch.cuda.synchronize()
+    return torch.cat([p.grad.reshape(-1) for p in inner.parameters()]).clone()
+
+
+def main():
+    mode, out_dir = sys.argv[1], sys.argv[2]
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    from _util import case_inputs, load_case
+    from slowfast.models import engine
+    z, meta = load_case("dual_r50_s64")
+    labels_all = torch.from_numpy(z["train/labels"])
+    rep = {"rank": rank}
+    if mode == "ddp":
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%s" % os.environ["MASTER_PORT"], rank=0,
+                                world_size=1)
+        xs = [x.cuda() for x in case_inputs(meta)]
+        labels = labels_all.cuda()
+        sd0 = None
+        plain = build(meta, z, 1)
+        sd0 = {k: v.clone() for k, v in plain.state_dict().items()}
+        ref = grads_of(plain, xs, labels)
+        torch.cuda.device_count = lambda: 2  # the drop-in asserts NUM_GPUS <= device_count (build.py:31)
+        wrapped = build(meta, z, 2)
+        assert isinstance(wrapped, torch.nn.parallel.DistributedDataParallel)
+        wrapped.module.load_state_dict(sd0)
+        fired = []
+
+        def hook(state, bucket):
+            fired.append(int(bucket.buffer().numel()))
+            fut = dist.all_reduce(bucket.buffer(), async_op=True).get_future()
+            return fut.then(lambda f: f.value()[0])
+
+        wrapped.register_comm_hook(None, hook)
+        got = grads_of(wrapped, xs, labels)
+        rep["ddp_buckets"] = len(fired)
+        rep["ddp_bucket_floats"] = sum(fired)
+        rep["ddp_params"] = int(ref.numel())
+        rep["ddp_err"] = float((got - ref).abs().max() / ref.abs().max())
+        engine.set_grad_sink(True)
+        try:
+            grads_of(wrapped, xs, labels)
+            rep["sink_guard"] = "did not raise"
+        except RuntimeError as e:
+            rep["sink_guard"] = "raised" if "DistributedDataParallel" in str(e) else "wrong error: %s" % e
+        finally:
+            engine.set_grad_sink(False)
+    else:
+        dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%s" % os.environ["MASTER_PORT"], rank=rank,
+                                world_size=world)
+        from slowfast.utils.distributed import FlatGradients, shard_sizes
+        per = shard_sizes(meta["batch"], world)[rank]
+        clips = case_inputs(meta)
+        model = build(meta, z, 1)
+        sd0 = {k: v.clone() for k, v in model.state_dict().items()}
+        flat = FlatGradients(model.parameters())
+        engine.set_grad_sink(True)
+
+        def shard_grad(r):
+            model.load_state_dict(sd0)  # identical running statistics before every pass
+            flat.zero()
+            sl = slice(r * per, (r + 1) * per)
+            xs = [x[sl].cuda() for x in clips]
+            torch.nn.functional.cross_entropy(model(xs), labels_all[sl].cuda()).backward()
+            torch.cuda.synchronize()
+            return flat.flat.clone()
+
+        other = shard_grad(1 - rank)       # checker: the other rank's gradient, computed here
+        mine = shard_grad(rank)            # leaves this rank's gradient in the flat buffer
+        assert all(p.grad.data_ptr() == flat.flat.data_ptr() + 4 * off for p, off in zip(
+            flat.params, __import__("itertools").accumulate([0] + [p.numel() for p in flat.params[:-1]])))
+        host = flat.flat.cpu()
+        dist.all_reduce(host, op=dist.ReduceOp.SUM)          # what all_reduce_mean does, on the host copy for gloo
+        # the product call itself (gloo accepts CUDA tensors by staging): ONE collective on the flat buffer
+        flat.all_reduce_mean()
+        torch.cuda.synchronize()
+        want = (mine + other) / 2
+        rep["flat_err"] = float((flat.flat - want).abs().max() / want.abs().max())
+        rep["flat_err_host"] = float((host.cuda() / world - want).abs().max() / want.abs().max())
+        rep["grad_norm"] = float(want.norm())
+        rep["differs_from_local"] = float((want - mine).abs().max() / want.abs().max())
+        engine.set_grad_sink(False)
+    with open(os.path.join(out_dir, "%s_rank%d.json" % (mode, rank)), "w") as f:
+        json.dump(rep, f)
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

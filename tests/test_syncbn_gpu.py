@@ -16,10 +16,15 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 def test_sync_batchnorm_two_ranks_match_reference():
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
+    import socket
     out = tempfile.mkdtemp()
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))  # a free port per run: a lingering worker of an earlier run cannot block the rendezvous
+    port = str(sock.getsockname()[1])
+    sock.close()
     procs = []
     for r in range(2):
-        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT="29713")
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
         procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "_syncbn_worker.py"), out], env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
     logs = []
