@@ -282,53 +282,100 @@ def main():
                     "ms_per_step": round(et / args.steps * 1e3, 3), "launch": "hipGraph replay"}
         model.train()
 
-    # ---- dominant-kernel trace: HIP events around every attention launch (forward and backward) over a few
-    #      eager steps on the stream the kernels run on
+    # ---- dominant-kernel trace: HIP events around every attention / dense-conv / depthwise-conv C-ABI call over a few
+    #      eager steps on ONE stream (the two-stream schedule is switched off for these steps, so an event pair times its
+    #      kernel(s) and not a neighbour running beside them).  The (kernel, shape) with the largest total time per step
+    #      is the roofline object: algorithmic FLOPs or bytes of one launch / its average duration.
     roofline = None
-    if rank == 0 and args.workload in ("dual", "ghostnet", "shufflenetv2") and not args.no_extras:
+    family_ms = None
+    if rank == 0 and not args.no_extras:
+        from slowfast.models import engine as _engine
         sfhip.EVENT_TRACE = []
-        with torch.cuda.stream(side):
-            for _ in range(min(args.steps, 3)):
-                step()
-        torch.cuda.synchronize()
+        nsteps = min(args.steps, 3)
+        saved_overlap, _engine.OVERLAP_PATHS = _engine.OVERLAP_PATHS, False
+        try:
+            with torch.cuda.stream(side):
+                step()  # one un-traced step in the serial schedule first (allocator pools of the single stream)
+                sfhip.EVENT_TRACE = []
+                for _ in range(nsteps):
+                    step()
+            torch.cuda.synchronize()
+        finally:
+            _engine.OVERLAP_PATHS = saved_overlap
         per = {}
         for tag, e0, e1 in sfhip.EVENT_TRACE:
             per.setdefault(tag, []).append(e0.elapsed_time(e1) * 1e-3)
         sfhip.EVENT_TRACE = None
         tot = {tag: sum(v) for tag, v in per.items()}
+        fam = {}
+        for tag, v in tot.items():
+            f = "attention" if tag[0].startswith("attn") else tag[0]
+            fam[f] = fam.get(f, 0.0) + v
+        family_ms = {f: round(v / nsteps * 1e3, 3) for f, v in sorted(fam.items(), key=lambda kv: -kv[1])}
         tag = max(tot, key=tot.get)
-        kind, b, n, c = tag
+        top_family = "attention" if tag[0].startswith("attn") else tag[0]
         dur = float(np.mean(per[tag]))
-        # algorithmic FLOPs, one product = 2*N^2*C FLOP per clip.  Forward: QK^T + PV = 2.
-        # Backward: 5 products in total (S recompute, dP, dV, dK, dQ); the two-kernel, atomic-free split
-        # re-derives S and dP in both kernels (7 executed), so each kernel is credited only its share of the 5:
-        # dK/dV kernel = dV + dK + half of (S, dP) = 3, dQ kernel = dQ + the other half = 2.
-        # The single-sweep backward (attn_bwd_fused: dK/dV/dQ kernel + the dQ plane reduction, timed together)
-        # executes exactly the 5 algorithmic products.
-        nprod = {"attn": 2, "attn_bwd_dkv": 3, "attn_bwd_dq": 2, "attn_bwd_fused": 5}[kind]
-        executed = {"attn": 2, "attn_bwd_dkv": 4, "attn_bwd_dq": 3, "attn_bwd_fused": 5}[kind]
-        flops = nprod * 2.0 * b * n * n * c
-        ach = flops / dur / 1e12
-        kname = {"attn": "attn_fwd_kernel (flash SpatialAttention forward)",
-                 "attn_bwd_dkv": "attn_bwd_dkv_kernel (flash SpatialAttention backward, dK/dV)",
-                 "attn_bwd_dq": "attn_bwd_dq_kernel (flash SpatialAttention backward, dQ)",
-                 "attn_bwd_fused": "attn_bwd_fused_kernel + attn_dq_reduce_kernel (flash SpatialAttention backward, "
-                                   "dQ/dK/dV in one sweep)"}[kind]
-        traffic = None  # HBM bytes per launch from the committed PMC passes (rocprofv3 cannot run inside bench.py)
-        try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_attention_hbm_traffic_v3.json")))["kernels"]
-            if kind == "attn_bwd_fused" and c == 32 and n == 25088 and b == 8:
-                # the sweep kernel + its three reductions (dK parts, dV parts, dQ planes): one thread per (row, 4 ch)
-                sweep = [v for k, v in tj.items() if k.startswith("attn_bwd_fused_kernel<32, 4>")]
-                red = tj["attn_dq_reduce_kernel grid=%d" % (-(-(b * n * 8) // 256) * 256)]
-                traffic = sweep[0]["hbm_bytes_per_launch"] + 3 * red["hbm_bytes_per_launch"]
-        except (OSError, KeyError, ValueError, IndexError):
-            traffic = None
-        roofline = {"bound": "mfma", "kernel": "%s C=%d N=%d B=%d" % (kname, c, n, b),
-                    "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "avg_launch_ms": round(dur * 1e3, 4),
-                    "launches_timed": len(per[tag]), "traffic": traffic,
-                    "executed_mfma_tflops": round(ach * executed / nprod, 2)}
+        if top_family == "attention":
+            kind, b, n, c = tag
+            # algorithmic FLOPs, one product = 2*N^2*C FLOP per clip.  Forward: QK^T + PV = 2.
+            # Backward: 5 products in total (S recompute, dP, dV, dK, dQ); the two-kernel, atomic-free split
+            # re-derives S and dP in both kernels (7 executed), so each kernel is credited only its share of the 5:
+            # dK/dV kernel = dV + dK + half of (S, dP) = 3, dQ kernel = dQ + the other half = 2.
+            # The single-sweep backward (attn_bwd_fused: dK/dV/dQ kernel + the dQ plane reduction, timed together)
+            # executes exactly the 5 algorithmic products.
+            nprod = {"attn": 2, "attn_bwd_dkv": 3, "attn_bwd_dq": 2, "attn_bwd_fused": 5}[kind]
+            executed = {"attn": 2, "attn_bwd_dkv": 4, "attn_bwd_dq": 3, "attn_bwd_fused": 5}[kind]
+            flops = nprod * 2.0 * b * n * n * c
+            ach = flops / dur / 1e12
+            kname = {"attn": "attn_fwd_kernel (flash SpatialAttention forward)",
+                     "attn_bwd_dkv": "attn_bwd_dkv_kernel (flash SpatialAttention backward, dK/dV)",
+                     "attn_bwd_dq": "attn_bwd_dq_kernel (flash SpatialAttention backward, dQ)",
+                     "attn_bwd_fused": "attn_bwd_fused_kernel + attn_dq_reduce_kernel (flash SpatialAttention "
+                                       "backward, dQ/dK/dV in one sweep)"}[kind]
+            traffic, traffic_src = None, None  # HBM bytes per launch: rocprofv3 PMC passes cannot run inside bench.py
+            try:
+                tj = json.load(open(os.path.join(ROOT, "profiles", "r01_attention_hbm_traffic_v3.json")))["kernels"]
+                if kind == "attn_bwd_fused" and c == 32 and n == 25088 and b == 8:
+                    # the sweep kernel + its three reductions (dK parts, dV parts, dQ planes)
+                    sweep = [v for k, v in tj.items() if k.startswith("attn_bwd_fused_kernel<32, 4>")]
+                    red = tj["attn_dq_reduce_kernel grid=%d" % (-(-(b * n * 8) // 256) * 256)]
+                    traffic = sweep[0]["hbm_bytes_per_launch"] + 3 * red["hbm_bytes_per_launch"]
+                    traffic_src = "profiles/r01_attention_hbm_traffic_v3.json (PMC passes of the same kernel; not " \
+                                  "measured in this run)"
+            except (OSError, KeyError, ValueError, IndexError):
+                traffic = None
+            roofline = {"bound": "mfma", "kernel": "%s C=%d N=%d B=%d" % (kname, c, n, b),
+                        "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                        "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "avg_launch_ms": round(dur * 1e3, 4),
+                        "launches_timed": len(per[tag]), "traffic": traffic, "traffic_source": traffic_src,
+                        "executed_mfma_tflops": round(ach * executed / nprod, 2)}
+        elif top_family == "conv":
+            _, m, k, n = tag
+            ach = 2.0 * m * k * n / dur / 1e12
+            # the conv family as a whole: algorithmic FLOPs of every traced launch / their summed durations
+            fl = sum(2.0 * t[1] * t[2] * t[3] * len(v) for t, v in per.items() if t[0] == "conv")
+            agg = fl / fam["conv"] / 1e12
+            roofline = {"bound": "mfma", "kernel": "conv_wave_kernel / conv_wgrad_wave_kernel (dense 3-D conv as "
+                        "implicit GEMM; forward, data- and weight-gradient launches of the shape positions=%d, "
+                        "taps*Cin=%d, Cout=%d)" % (m, k, n),
+                        "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                        "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "avg_launch_ms": round(dur * 1e3, 4),
+                        "launches_timed": len(per[tag]), "traffic": None,
+                        "conv_family": {"achieved": round(agg, 2), "frac": round(agg / PEAK_FP32_MFMA_TFLOPS, 4),
+                                        "note": "algorithmic FLOPs of ALL dense-conv launches of a step / the sum of "
+                                                "their HIP-event durations (conv-arithmetic roofline, SURVEY 8d)"}}
+        else:  # depthwise convs: HBM-bound
+            by = sum(t[1] * len(v) for t, v in per.items() if t[0] == "dwconv")
+            ach = by / fam["dwconv"] / 1e9
+            roofline = {"bound": "hbm", "kernel": "dwconv_kernel (depthwise 3-D conv, GhostNet / ShuffleNetV2 paths)",
+                        "achieved": round(ach, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 4),
+                        "launches_timed": sum(len(v) for t, v in per.items() if t[0] == "dwconv"), "traffic": None}
+        # the HBM-bound depthwise family beside the dominant one (cfg #5's "bandwidth-bound stress")
+        if "dwconv" in fam and roofline is not None and top_family != "dwconv":
+            by = sum(t[1] * len(v) for t, v in per.items() if t[0] == "dwconv")
+            roofline["dwconv_hbm"] = {"achieved": round(by / fam["dwconv"] / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
+                                      "frac": round(by / fam["dwconv"] / 1e9 / 8000.0, 4),
+                                      "ms_per_step": family_ms["dwconv"]}
 
     if rank == 0:
         clips_total = batch * world * args.steps
@@ -361,7 +408,9 @@ def main():
         if eval_fwd is not None:
             res["eval_forward"] = eval_fwd
         if roofline is not None:
+            roofline["trace_schedule"] = "one stream (two-stream overlap off for the traced steps)"
             res["roofline"] = roofline
+            res["kernel_family_ms_per_step"] = family_ms
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"], fwd_err = cpu_baseline(args.workload, cfg, model, train, device)
             # second half of BASELINE.json's metric: the HIP eval forward against the oracle's on the same full-size

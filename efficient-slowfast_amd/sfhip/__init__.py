@@ -160,6 +160,22 @@ def _ptr(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else None
 
 
+EVENT_TRACE = None  # bench.py sets this to a list: (tag, start_event, end_event) per traced launch
+
+
+def _traced(tag, fn):
+    """Run `fn` (the launches of one C-ABI call on the current stream) between two HIP events when tracing is on."""
+    if EVENT_TRACE is None:
+        return fn()
+    e0 = torch.cuda.Event(enable_timing=True)
+    e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    rc = fn()
+    e1.record()
+    EVENT_TRACE.append((tag, e0, e1))
+    return rc
+
+
 def _require_gpu(t, what):
     if not t.is_cuda:
         raise SfhipError("%s: tensor is on %s — the SlowFast hot path only runs on an MI355X GPU "
@@ -284,14 +300,17 @@ def pack_conv_weight(w, cin_pad=None):
 
 
 def _conv_launch(d, x_ptr, w_ptr, scale, bias, res_ptr, out_ptr, device, what):
-    """sf_conv_fwd, through the split-K schedule when the shape asks for it (workspace from the caching allocator)."""
+    """sf_conv_fwd, through the split-K schedule when the shape asks for it (workspace from the caching allocator).
+    Trace tag: ("conv", output positions, taps * Cin, Cout) — 2 * product = the launch's algorithmic FLOPs."""
+    tag = ("conv", d.N * d.To * d.Ho * d.Wo, d.kT * d.kH * d.kW * d.Cin, d.Cout)
     n = lib().sf_conv_fwd_ws_floats(ctypes.byref(d)) if SPLIT_K else 0
     if n > 0:
         ws = torch.empty((n,), dtype=torch.float32, device=device)
-        _check(lib().sf_conv_fwd_ws(ctypes.byref(d), x_ptr, w_ptr, scale, bias, res_ptr, out_ptr, _ptr(ws), _stream()),
-               what)
+        _check(_traced(tag, lambda: lib().sf_conv_fwd_ws(ctypes.byref(d), x_ptr, w_ptr, scale, bias, res_ptr, out_ptr,
+                                                         _ptr(ws), _stream())), what)
     else:
-        _check(lib().sf_conv_fwd(ctypes.byref(d), x_ptr, w_ptr, scale, bias, res_ptr, out_ptr, _stream()), what)
+        _check(_traced(tag, lambda: lib().sf_conv_fwd(ctypes.byref(d), x_ptr, w_ptr, scale, bias, res_ptr, out_ptr,
+                                                      _stream())), what)
 
 
 SPLIT_K = os.environ.get("SF_SPLIT_K", "1") != "0"
@@ -366,8 +385,11 @@ def dwconv(x, wp, kernel, stride=(1, 1, 1), padding=(0, 0, 0), scale=None, bias=
                  kT, kH, kW, stride[0], stride[1], stride[2], padding[0], padding[1], padding[2], 1, 1, 1,
                  c, _act(relu),
                  res.cs if res is not None else 0, res.coff if res is not None else 0, 0)
-    _check(lib().sf_dwconv_fwd(ctypes.byref(d), x.ptr(), _ptr(wp), _ptr(scale), _ptr(bias),
-                               res.ptr() if res is not None else None, out.ptr(), _stream()), "sf_dwconv_fwd")
+    # trace tag: ("dwconv", algorithmic HBM bytes = input + output (+ residual) rows once)
+    nbytes = 4 * (x.rows * c + out.rows * cout * (2 if res is not None else 1))
+    _check(_traced(("dwconv", nbytes, taps, c), lambda: lib().sf_dwconv_fwd(
+        ctypes.byref(d), x.ptr(), _ptr(wp), _ptr(scale), _ptr(bias), res.ptr() if res is not None else None,
+        out.ptr(), _stream())), "sf_dwconv_fwd")
     return out
 
 
@@ -407,22 +429,6 @@ def gate_apply(x, alpha, pooled, w3=None, scale=None, bias=None, relu=False, out
                                _ptr(scale), _ptr(bias), ACT_RELU if relu else ACT_NONE, out.ptr(), out.cs,
                                out.coff, _stream()), "sf_gate_apply")
     return out
-
-
-EVENT_TRACE = None  # bench.py sets this to a list: (tag, start_event, end_event) per traced launch
-
-
-def _traced(tag, fn):
-    """Run `fn` (one kernel launch on the current stream) between two HIP events when tracing is on."""
-    if EVENT_TRACE is None:
-        return fn()
-    e0 = torch.cuda.Event(enable_timing=True)
-    e1 = torch.cuda.Event(enable_timing=True)
-    e0.record()
-    rc = fn()
-    e1.record()
-    EVENT_TRACE.append((tag, e0, e1))
-    return rc
 
 
 def attention(q, k, v, x, gamma, scale=None, bias=None, relu=False, alpha=1, out=None, save=None):
@@ -606,8 +612,8 @@ def conv_wgrad(x, dz, cout, kernel, stride=(1, 1, 1), padding=(0, 0, 0), dilatio
                  dilation[0], dilation[1], dilation[2], cin_pad, ACT_NONE, 0, 0, 0)
     S = lib().sf_conv_wgrad_splits(ctypes.byref(d))
     part = torch.empty((S, cout, kT * kH * kW, cin_pad), dtype=torch.float32, device=x.buf.device)
-    _check(lib().sf_conv_wgrad(ctypes.byref(d), x.ptr(), dz.ptr(), dz.cs, dz.coff, _ptr(part), _stream()),
-           "sf_conv_wgrad")
+    _check(_traced(("conv", dz.rows, kT * kH * kW * cin, cout), lambda: lib().sf_conv_wgrad(
+        ctypes.byref(d), x.ptr(), dz.ptr(), dz.cs, dz.coff, _ptr(part), _stream())), "sf_conv_wgrad")
     if finish_into is not None:
         dst, real_cin, fold_kw = finish_into
         assert dst.is_contiguous() and dst.dtype == torch.float32
