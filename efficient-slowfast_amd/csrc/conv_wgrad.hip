@@ -603,19 +603,24 @@ constexpr int FIN_C = 64;
 __global__ __launch_bounds__(256) void wgrad_finish_kernel(const float* __restrict__ part, int S, int Cout, int ptaps,
                                                            int cin_pad, int Cin, float* __restrict__ dst,
                                                            int accumulate) {
-  extern __shared__ float tile[];  // [FIN_C][ptaps]
+  extern __shared__ float tile[];  // [FIN_C][ptaps] + [4][FIN_C] partial sums
+  float* const red = tile + FIN_C * ptaps;
   const int co = blockIdx.x, c0 = blockIdx.y * FIN_C;
-  const int c = threadIdx.x & (FIN_C - 1), tq = threadIdx.x / FIN_C;
+  const int c = threadIdx.x & (FIN_C - 1), q = threadIdx.x / FIN_C;
   const long stride = (long)Cout * ptaps * cin_pad;
-  if (c0 + c < cin_pad) {
-    for (int tap = tq; tap < ptaps; tap += 256 / FIN_C) {
+  // the four thread groups take the splits s = q, q + 4, ... of every tap (the splits number up to ~100 for small
+  // weights over many positions); the four sub-sums are combined in group order — a fixed summation order
+  for (int tap = 0; tap < ptaps; ++tap) {
+    float v = 0.f;
+    if (c0 + c < cin_pad) {
       const float* src = part + ((long)co * ptaps + tap) * cin_pad + c0 + c;
-      float v = 0.f;
-      for (int s = 0; s < S; ++s) v += src[s * stride];
-      tile[c * ptaps + tap] = v;
+      for (int s = q; s < S; s += 256 / FIN_C) v += src[s * stride];
     }
+    red[q * FIN_C + c] = v;
+    __syncthreads();
+    if (q == 0) tile[c * ptaps + tap] = (red[c] + red[FIN_C + c]) + (red[2 * FIN_C + c] + red[3 * FIN_C + c]);
+    __syncthreads();
   }
-  __syncthreads();
   const int ncols = (Cin - c0) < FIN_C ? (Cin - c0) : FIN_C;  // real channels in this tile
   if (ncols <= 0) return;
   float* out = dst + ((long)co * Cin + c0) * ptaps;
@@ -653,7 +658,7 @@ extern "C" int sf_conv_wgrad_finish(const float* partial, int S, int Cout, int p
                        S, Cout, packed_taps, cin_pad, Cin, fold_kw, dst, accumulate, total);
   } else {
     hipLaunchKernelGGL(wgrad_finish_kernel, dim3(Cout, sf_cdiv(cin_pad, FIN_C)), dim3(256),
-                       (size_t)FIN_C * packed_taps * sizeof(float), (hipStream_t)stream, partial, S, Cout, packed_taps,
+                       (size_t)FIN_C * (packed_taps + 4) * sizeof(float), (hipStream_t)stream, partial, S, Cout, packed_taps,
                        cin_pad, Cin, dst, accumulate);
   }
   SF_CHECK_LAUNCH();

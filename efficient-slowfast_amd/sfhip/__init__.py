@@ -556,6 +556,9 @@ def _residue_taps(k, s, p, a):
     return [o for o, _ in pairs], [kk for _, kk in pairs]
 
 
+_TAP_INDEX = {}
+
+
 def _conv_dgrad_strided(dz, wt_packed, out, kernel, stride, padding, accumulate):
     """Data gradient of a strided conv as one DENSE small conv over dL/dz per residue class of the input position
     (the transposed-gather formulation evaluates every tap at every input position and predicates s^2-1 of s^2
@@ -585,9 +588,15 @@ def _conv_dgrad_strided(dz, wt_packed, out, kernel, stride, padding, accumulate)
                 key = (at, ah, aw, tuple(kernel), tuple(stride), tuple(padding))
                 wsub = store.get(key)
                 if wsub is None:
-                    # device-only gather (no host index tensor: this runs inside hipGraph capture too)
-                    taps_sel = [(a * kH + b) * kW + c for a in tt for b in th for c in tw]
-                    wsub = store[key] = torch.stack([wt_packed[:, i, :] for i in taps_sel], dim=1).contiguous()
+                    # ONE gather launch per class and optimizer step (a torch.stack of the tap slices was a burst of
+                    # ~190 small copy kernels per step); the index tensor is built once per (taps, device) — during
+                    # warm-up, so nothing is copied from the host inside a hipGraph capture
+                    taps_sel = tuple((a * kH + b) * kW + c for a in tt for b in th for c in tw)
+                    ikey = (taps_sel, str(wt_packed.device))
+                    idx = _TAP_INDEX.get(ikey)
+                    if idx is None:
+                        idx = _TAP_INDEX[ikey] = torch.tensor(taps_sel, dtype=torch.long, device=wt_packed.device)
+                    wsub = store[key] = wt_packed.index_select(1, idx)
                 d = ConvDesc(dz.N, dz.T, dz.H, dz.W, dz.C, dz.cs, dz.coff, dims[0], dims[1], dims[2], cin, out.cs,
                              out.coff, 1, len(tt), len(th), len(tw), 1, 1, 1, -ot[0], -oh[0], -ow[0], 1, 1, 1,
                              cout_pad, ACT_NONE, out.cs, out.coff, 0, stride[0], stride[1], stride[2], at, ah, aw,
@@ -617,8 +626,8 @@ def conv_wgrad(x, dz, cout, kernel, stride=(1, 1, 1), padding=(0, 0, 0), dilatio
     if finish_into is not None:
         dst, real_cin, fold_kw = finish_into
         assert dst.is_contiguous() and dst.dtype == torch.float32
-        if S > 4:  # many position splits (small weights, huge M): a parallel tree sum first, the finish pass is serial in S
-            part, S = part.sum(0, keepdim=True), 1
+        if S > 128:  # tiny weights over millions of positions (Fast pathway): few finish workgroups, each would walk
+            part, S = part.sum(0, keepdim=True), 1  # S / 4 partials per thread — a parallel tree sum first
         assert dst.numel() == cout * real_cin * kT * kH * kW * max(fold_kw, 1), (dst.shape, cout, real_cin, kernel)
         _check(lib().sf_conv_wgrad_finish(_ptr(part), S, cout, kT * kH * kW, cin_pad, real_cin, fold_kw, _ptr(dst), 1,
                                           _stream()), "sf_conv_wgrad_finish")
