@@ -92,7 +92,8 @@ def test_fast_stem_ring_kernels_at_full_size():
     assert torch.equal(dwp, again), "bit-reproducible"
 
 
-@pytest.mark.parametrize("c,thw", [(32, (8, 56, 56)), (8, (8, 56, 56))], ids=["d32_n25088", "d8_n25088"])
+@pytest.mark.parametrize("c,thw", [(32, (8, 56, 56)), (8, (8, 56, 56)), (4, (8, 112, 112))],
+                         ids=["d32_n25088", "d8_n25088", "d4_n100352_cfg5"])
 def test_attention_at_production_size_against_exact_fp64(c, thw):
     import sfhip
     dev = _dev()
@@ -146,9 +147,10 @@ def _model(workload):
     return bench, cfg, model
 
 
-@pytest.mark.parametrize("workload", ["dual", "slowfast"])
+@pytest.mark.parametrize("workload", ["dual", "slowfast", "ghostnet"])
 def test_model_properties_at_baseline_size(workload):
-    """cfg #3 / #2 of BASELINE.json at 224^2, T = 32 (3 clips to keep the test short)."""
+    """cfg #3 / #2 / #5 of BASELINE.json at 224^2, T = 32 (3 clips to keep the test short; cfg #5 = SlowFastGhostNet
+    w2.0 + CMDA, whose s1_fuse attention runs at N = 100 352, d = 4: custom_video_model_builder.py:872-1005)."""
     from slowfast.models import engine
     dev = _dev()
     bench, cfg, model = _model(workload)
@@ -168,8 +170,10 @@ def test_model_properties_at_baseline_size(workload):
         graph.replay()
         torch.cuda.synchronize()
     assert tuple(p_all.shape) == (3, cfg.MODEL.NUM_CLASSES) and bool(torch.isfinite(p_all).all())
-    assert float((p_all.sum(1) - 1.0).abs().max()) < 1e-5          # softmax-mean probabilities
-    assert float((p_all[1:2] - p_one).abs().max()) < 1e-6           # clips do not interact in eval mode
+    if workload != "ghostnet":  # GhostNet's head ends in ReLU, not softmax (head_helper.py:640-653, bug-compatible)
+        assert float((p_all.sum(1) - 1.0).abs().max()) < 1e-5      # softmax-mean probabilities
+    # clips do not interact in eval mode (a different batch size may pick other conv tilings: fp32 re-association only)
+    assert float((p_all[1:2] - p_one).abs().max()) < 1e-5 * max(1.0, float(p_one.abs().max()))
     assert torch.equal(p_graph, p_all)                              # hipGraph replay == eager launches
     # training step: deterministic, and the two-stream schedule equals the serial one bit for bit
     model.train()
