@@ -48,7 +48,7 @@ SHAPES = [
 ]
 if "quick" in sys.argv[1:]:
     SHAPES = SHAPES[::4]
-L.sf_conv_tune(3, 1 if "k16" in sys.argv[1:] else 0)
+L.sf_conv_tune(3, 1 if "k32" in sys.argv[1:] else 0)
 
 
 def run(x, wp, k, s, p, tr, res, relu):

@@ -34,17 +34,18 @@ rec = {}
 orig = {n: getattr(sfhip, n) for n in ("conv", "conv_dgrad", "conv_wgrad")}
 
 
+pending = []
+
+
 def timed(kind, fn, describe):
     def w(*a, **k):
+        # events only, no host synchronisation per call (a sync would add the host's launch latency of the NEXT call to
+        # every small kernel): the pairs are read after the step
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         r = fn(*a, **k)
         e1.record()
-        e1.synchronize()
-        key = (kind,) + describe(*a, **k)
-        v = rec.setdefault(key, [0, 0.0])
-        v[0] += 1
-        v[1] += e0.elapsed_time(e1)
+        pending.append(((kind,) + describe(*a, **k), e0, e1))
         return r
     return w
 
@@ -76,6 +77,10 @@ sfhip.conv_dgrad = timed("dgrad", orig["conv_dgrad"], d_dgrad)
 sfhip.conv_wgrad = timed("wgrad", orig["conv_wgrad"], d_wgrad)
 step()
 torch.cuda.synchronize()
+for key, e0, e1 in pending:
+    v = rec.setdefault(key, [0, 0.0])
+    v[0] += 1
+    v[1] += e0.elapsed_time(e1)
 rows = []
 for (kind, m, cin, cout, k, s, thw), (n, ms) in rec.items():
     taps = k[0] * k[1] * k[2]
