@@ -68,7 +68,8 @@ __global__ void bn_bwd_partial_kernel(const float* __restrict__ dy, int dy_cs, i
                                       const float* __restrict__ z, int z_cs, int z_coff, long group_rows, int chunks,
                                       int S, long THW, int HW, int C, int rep, int relu,
                                       const float* __restrict__ mean, const float* __restrict__ invstd, int CB,
-                                      float* __restrict__ partial) {
+                                      float* __restrict__ partial, unsigned* tickets, float* __restrict__ o1,
+                                      float* __restrict__ o2, float* __restrict__ acc1, float* __restrict__ acc2) {
   // block -> (row group n, chunk); group = whole tensor (S == 1) or one sample of split n % S (Sub-BN)
   __shared__ float red[2 * TPB * VEC];
   const int blk = blockIdx.x, cb = blockIdx.y;
@@ -118,8 +119,43 @@ __global__ void bn_bwd_partial_kernel(const float* __restrict__ dy, int dy_cs, i
         t1 += red[(i * CB + cl) * VEC + e];
         t2 += red[(TPB + i * CB + cl) * VEC + e];
       }
-      partial[((long)blk * 2 + 0) * C + c + e] = t1;
-      partial[((long)blk * 2 + 1) * C + c + e] = t2;
+      if (tickets) {
+        sf_store_sc1(partial + ((long)blk * 2 + 0) * C + c + e, t1);
+        sf_store_sc1(partial + ((long)blk * 2 + 1) * C + c + e, t2);
+      } else {
+        partial[((long)blk * 2 + 0) * C + c + e] = t1;
+        partial[((long)blk * 2 + 1) * C + c + e] = t2;
+      }
+    }
+  }
+  if (!tickets) return;
+  // fused final step (common.h): the last workgroup of this channel group sums the P partials of its channels in
+  // fp64, four lanes per output in a fixed order, and accumulates into the parameter gradients when asked to
+  if (!sf_ticket_last(tickets + cb, gridDim.x)) return;
+  const int P = gridDim.x;
+  const int cbase = cb * CB * VEC;
+  const int ncg = (C - cbase) < CB * VEC ? (C - cbase) : CB * VEC;
+  const int q = threadIdx.x & 3;
+  for (int item = threadIdx.x >> 2; item < S * ncg; item += TPB / 4) {
+    const int sp = item / ncg, cc = cbase + (item - sp * ncg);
+    double a1 = 0.0, a2 = 0.0;
+    for (int i = q; i < P; i += 4) {
+      if ((i / chunks) % S != sp) continue;
+      a1 += (double)partial[((long)i * 2 + 0) * C + cc];
+      a2 += (double)partial[((long)i * 2 + 1) * C + cc];
+    }
+    a1 += __shfl_xor(a1, 1, 64);
+    a2 += __shfl_xor(a2, 1, 64);
+    a1 += __shfl_xor(a1, 2, 64);
+    a2 += __shfl_xor(a2, 2, 64);
+    if (q == 0) {
+      const int o = sp * C + cc;
+      o1[o] = (float)a1;
+      o2[o] = (float)a2;
+      if (acc1) {
+        acc1[o] += (float)a1;
+        acc2[o] += (float)a2;
+      }
     }
   }
 }
@@ -420,21 +456,33 @@ static int bn_bwd_reduce_launch(const float* dy, int dy_cs, int dy_coff, const f
   const int groups = S > 1 ? N : 1;
   const long group_rows = rows / groups;
   int CB, P;
+  const bool fused = sf_tickets_enabled();
   red_geometry(group_rows, C, vec4 ? 4 : 1, &CB, &P);
-  if ((long)P * groups > MAX_P) P = MAX_P / groups;
+  const int max_p = fused ? 512 : MAX_P;
+  if (fused && CB > 16) {  // <= 64 channels per channel group: the groups' last workgroups finish in parallel
+    CB = 16;
+    long pp = group_rows / ((long)(TPB / CB) * 8);
+    P = (int)(pp < 1 ? 1 : (pp > max_p ? max_p : pp));
+  }
+  if (P > max_p) P = max_p;
+  if ((long)P * groups > max_p) P = max_p / groups;
+  if (P < 1) return SF_EINVAL;
   const int chunks = P;
   P = chunks * groups;
   const int ncb = sf_cdiv(sf_cdiv(C, vec4 ? 4 : 1), CB);
+  unsigned* tickets = fused ? sf_ticket_slots(ncb) : nullptr;
+  if (fused && !tickets) return SF_ELAUNCH;
   if (vec4)
     hipLaunchKernelGGL(bn_bwd_partial_kernel<4>, dim3(P, ncb), dim3(TPB), 0, (hipStream_t)stream, dy, dy_cs, dy_coff,
                        y, y_cs, y_coff, z, z_cs, z_coff, group_rows, chunks, S, (long)T * H * W, H * W, C, rep, relu,
-                       mean, invstd, CB, ws);
+                       mean, invstd, CB, ws, tickets, dbeta, dgamma, dbeta_acc, dgamma_acc);
   else
     hipLaunchKernelGGL(bn_bwd_partial_kernel<1>, dim3(P, ncb), dim3(TPB), 0, (hipStream_t)stream, dy, dy_cs, dy_coff,
                        y, y_cs, y_coff, z, z_cs, z_coff, group_rows, chunks, S, (long)T * H * W, H * W, C, rep, relu,
-                       mean, invstd, CB, ws);
-  hipLaunchKernelGGL(pair_final_kernel, dim3(S * C), dim3(64), 0, (hipStream_t)stream, ws, C, P, chunks, S, dbeta,
-                     dgamma, dbeta_acc, dgamma_acc);
+                       mean, invstd, CB, ws, tickets, dbeta, dgamma, dbeta_acc, dgamma_acc);
+  if (!fused)
+    hipLaunchKernelGGL(pair_final_kernel, dim3(S * C), dim3(64), 0, (hipStream_t)stream, ws, C, P, chunks, S, dbeta,
+                       dgamma, dbeta_acc, dgamma_acc);
   SF_CHECK_LAUNCH();
   return SF_OK;
 }

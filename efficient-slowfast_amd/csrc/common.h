@@ -38,3 +38,36 @@ static inline int sf_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 // keeping at least 8 tiles.  SF_SWEEP_PARTS=<z> overrides (1 = off).
 constexpr int SF_SWEEP_PARTS_MAX = 8;
 int sf_sweep_parts(long units, int tiles);  // attn_bwd.hip
+
+// ---- last-workgroup tickets (a reduction's partial sums and its final step in ONE launch) ----------------------
+// Every workgroup of a reduction stores its partial sums write-through (sc1), drains, and takes a ticket; the workgroup
+// that draws the last ticket of its group reads all partials and finishes (MI355X_MICROARCH.md "Workgroup dispatch,
+// XCD placement & inter-workgroup visibility": sc1 payload + every storing wave's vmcnt(0) + workgroup barrier + one
+// agent-scope atomic add; the last arriver runs ONE agent-scope acquire before plain loads).  No workgroup ever waits
+// for another, so nothing depends on residency or dispatch order.  Counters live in a library-owned, zero-initialised
+// ring; the last arriver resets its counter, so a slot is clean again when the launch ends.
+unsigned* sf_ticket_slots(int n);  // elementwise.hip: n consecutive zeroed counters (host side, no launch)
+bool sf_tickets_enabled();         // SF_BN_TICKET=1 selects the fused reductions (default: two launches, measured faster)
+
+__device__ __forceinline__ void sf_store_sc1(float* p, float v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Call with ALL threads of the workgroup after the sc1 stores; true (in every thread) for the last of `total` arrivals.
+__device__ __forceinline__ bool sf_ticket_last(unsigned* cnt, unsigned total) {
+  __shared__ int s_last;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains its write-through stores
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned old = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const bool last = old == total - 1u;
+    if (last) {
+      __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // clean for the slot's next user
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    s_last = last ? 1 : 0;
+  }
+  __syncthreads();
+  return s_last != 0;
+}

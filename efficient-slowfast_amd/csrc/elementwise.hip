@@ -314,9 +314,41 @@ __global__ void copy_channels_kernel(const float* __restrict__ in, int in_cs, in
 // would cost several digits of the variance in fp32.
 constexpr int STAT_MAX_P = 1024;
 
+// Final step of the statistics for output o = split * C + channel from the fp64 sums of (x - K), (x - K)^2
+// (nn.BatchNorm3d training semantics: biased variance to normalise, unbiased for running_var).
+struct StatsFinal {
+  double inv_rows, unbias;
+  float* mean; float* var;
+  const float* gamma; const float* beta;
+  float eps, momentum;
+  float* run_mean; float* run_var;
+  float* invstd; float* scale; float* shift;
+  unsigned* tickets;   // != NULL: fused launch — one counter per channel group
+};
+
+__device__ __forceinline__ void stats_finish(const StatsFinal& f, int o, double s1, double s2, float k) {
+  const double md = s1 * f.inv_rows;  // mean of (x - K)
+  double v = s2 * f.inv_rows - md * md;
+  if (v < 0.0) v = 0.0;
+  const double m = md + (double)k;
+  f.mean[o] = (float)m;
+  f.var[o] = (float)v;
+  if (f.gamma) {
+    const float is = (float)(1.0 / sqrt(v + (double)f.eps));
+    const float sc = f.gamma[o] * is;
+    f.invstd[o] = is;
+    f.scale[o] = sc;
+    f.shift[o] = f.beta[o] - (float)m * sc;
+    if (f.run_mean) {
+      f.run_mean[o] = (1.f - f.momentum) * f.run_mean[o] + f.momentum * (float)m;
+      f.run_var[o] = (1.f - f.momentum) * f.run_var[o] + f.momentum * (float)(v * f.unbias);
+    }
+  }
+}
+
 template <int VEC>
 __global__ void stats_partial_kernel(const float* __restrict__ x, int cs, int coff, long group_rows, int chunks,
-                                     int S, int C, int CB, float* __restrict__ partial) {
+                                     int S, int C, int CB, float* __restrict__ partial, const StatsFinal fin) {
   // block -> (row group n, chunk): a group is the whole tensor (S == 1) or one sample (Sub-BN, split = n % S)
   __shared__ float red[2 * TPB * VEC];
   const int blk = blockIdx.x, cb = blockIdx.y;
@@ -364,15 +396,43 @@ __global__ void stats_partial_kernel(const float* __restrict__ x, int cs, int co
         t1 += red[(i * CB + cl) * VEC + e];
         t2 += red[(TPB + i * CB + cl) * VEC + e];
       }
-      partial[((long)blk * 2 + 0) * C + c + e] = t1;
-      partial[((long)blk * 2 + 1) * C + c + e] = t2;
+      if (fin.tickets) {
+        sf_store_sc1(partial + ((long)blk * 2 + 0) * C + c + e, t1);
+        sf_store_sc1(partial + ((long)blk * 2 + 1) * C + c + e, t2);
+      } else {
+        partial[((long)blk * 2 + 0) * C + c + e] = t1;
+        partial[((long)blk * 2 + 1) * C + c + e] = t2;
+      }
     }
+  }
+  if (!fin.tickets) return;
+  // ---- fused final step: the last workgroup of this channel group sums the P partials of its channels in fp64.
+  // Four lanes per output (split, channel) take the partials i = q, q + 4, ..; the four sub-sums are combined in lane
+  // order — a fixed summation order, as bit-reproducible as the two-launch form.
+  if (!sf_ticket_last(fin.tickets + cb, gridDim.x)) return;
+  const int P = gridDim.x;
+  const int cbase = cb * CB * VEC;
+  const int ncg = (C - cbase) < CB * VEC ? (C - cbase) : CB * VEC;
+  const int q = threadIdx.x & 3;
+  for (int item = threadIdx.x >> 2; item < S * ncg; item += TPB / 4) {
+    const int sp = item / ncg, cc = cbase + (item - sp * ncg);
+    double s1 = 0.0, s2 = 0.0;
+    for (int i = q; i < P; i += 4) {
+      if ((i / chunks) % S != sp) continue;
+      s1 += (double)partial[((long)i * 2 + 0) * C + cc];
+      s2 += (double)partial[((long)i * 2 + 1) * C + cc];
+    }
+    s1 += __shfl_xor(s1, 1, 64);
+    s2 += __shfl_xor(s2, 1, 64);
+    s1 += __shfl_xor(s1, 2, 64);
+    s2 += __shfl_xor(s2, 2, 64);
+    if (q == 0) stats_finish(fin, sp * C + cc, s1, s2, x[(long)sp * group_rows * cs + coff + cc]);
   }
 }
 
 // One 64-lane block per channel: lanes stride over the P partials in fp64, tree-reduce through LDS.  With
 // BN parameters given it also emits the normalisation affine and updates the running statistics in place
-// (nn.BatchNorm3d training semantics: biased variance to normalise, unbiased for running_var).
+// (the two-launch form: SF_BN_TICKET=0).
 __global__ void stats_final_kernel(const float* __restrict__ x, int cs, int coff, long group_rows, int chunks, int S,
                                    const float* __restrict__ partial, int C, int P, double inv_rows, double unbias,
                                    float* __restrict__ mean, float* __restrict__ var,
@@ -568,6 +628,35 @@ inline int pow2ceil(int v) {
 }  // namespace
 
 // =================================================================================================
+// Ticket ring (common.h): 64 Ki zero-initialised counters per device, handed out in consecutive runs; a run is reused
+// only after 64 Ki counters' worth of later launches, and every last arriver leaves its counter at zero.
+#include <atomic>
+// OFF by default (SF_BN_TICKET=1 switches it on): measured on MI355X (profiles/README.md, round 2) the fused launches
+// are SLOWER than partial + final kernels — stats 2.5 -> 5.8 ms and BN-backward reductions 4.1 -> 7.2 ms per train
+// step (serial profile), 71.1 -> 73.8 ms per step: the last workgroup's walk over <= 512 write-through partials per
+// output is latency-bound on one CU, where the separate final kernel spreads it over S*C workgroups.
+bool sf_tickets_enabled() {
+  static const bool on = [] { const char* e = getenv("SF_BN_TICKET"); return e && e[0] == '1'; }();
+  return on;
+}
+unsigned* sf_ticket_slots(int n) {
+  constexpr int RING = 1 << 16, MAXDEV = 16;
+  static unsigned* ring[MAXDEV] = {};
+  static std::atomic<unsigned> next[MAXDEV];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAXDEV || n <= 0 || n > 4096) return nullptr;
+  if (!ring[dev]) {  // first use on this device (warm-up, never inside a graph capture): allocate and zero once
+    unsigned* p = nullptr;
+    if (hipMalloc(&p, RING * sizeof(unsigned)) != hipSuccess) return nullptr;
+    if (hipMemset(p, 0, RING * sizeof(unsigned)) != hipSuccess) return nullptr;
+    ring[dev] = p;
+  }
+  const unsigned take = ((unsigned)n + 63u) & ~63u;
+  unsigned off = next[dev].fetch_add(take) % RING;
+  if (off + take > RING) off = next[dev].fetch_add(take) % RING, off = (off + take > RING) ? 0 : off;
+  return ring[dev] + off;
+}
+
 extern "C" int sf_abi_version(void) { return 1; }
 extern "C" const char* sf_build_arch(void) { return "gfx950"; }
 
@@ -686,22 +775,37 @@ static int stats_launch(const float* x, int cs, int coff, int groups, long group
   if (groups > STAT_MAX_P || S <= 0 || groups % S != 0) return SF_EINVAL;
   const bool vec4 = (C % 4 == 0) && (cs % 4 == 0) && (coff % 4 == 0) && sf_aligned16(x);
   const int cv = sf_cdiv(C, vec4 ? 4 : 1);
-  const int CB = pow2ceil(cv) < TPB ? pow2ceil(cv) : TPB;
+  const bool fused = sf_tickets_enabled();
+  // fused launch: <= 16 lanes (64 channels) per channel group, so that the group's last workgroup finishes few outputs
+  // while the groups finish in parallel, and <= 512 partials per output
+  const int cb_max = fused ? 16 : TPB;
+  const int CB = pow2ceil(cv) < cb_max ? pow2ceil(cv) : cb_max;
   const int rpi = TPB / CB;
+  const int max_p = fused ? 512 : STAT_MAX_P;
+  if (groups > max_p) return SF_EINVAL;
   long ch = group_rows / ((long)rpi * 8);
   if (ch < 1) ch = 1;
-  if (ch * groups > STAT_MAX_P) ch = STAT_MAX_P / groups;
+  if (ch * groups > max_p) ch = max_p / groups;
   const int chunks = (int)ch, P = chunks * groups;
   const long srows = group_rows * (groups / S);  // rows per split
+  const int ncb = sf_cdiv(cv, CB);
+  StatsFinal fin;
+  fin.inv_rows = 1.0 / (double)srows;
+  fin.unbias = srows > 1 ? (double)srows / (double)(srows - 1) : 1.0;
+  fin.mean = mean; fin.var = var; fin.gamma = gamma; fin.beta = beta; fin.eps = eps; fin.momentum = momentum;
+  fin.run_mean = run_mean; fin.run_var = run_var; fin.invstd = invstd; fin.scale = scale; fin.shift = shift;
+  fin.tickets = fused ? sf_ticket_slots(ncb) : nullptr;
+  if (fused && !fin.tickets) return SF_ELAUNCH;
   if (vec4)
-    hipLaunchKernelGGL(stats_partial_kernel<4>, dim3(P, sf_cdiv(cv, CB)), dim3(TPB), 0, s, x, cs, coff, group_rows,
-                       chunks, S, C, CB, ws);
+    hipLaunchKernelGGL(stats_partial_kernel<4>, dim3(P, ncb), dim3(TPB), 0, s, x, cs, coff, group_rows, chunks, S, C, CB,
+                       ws, fin);
   else
-    hipLaunchKernelGGL(stats_partial_kernel<1>, dim3(P, sf_cdiv(cv, CB)), dim3(TPB), 0, s, x, cs, coff, group_rows,
-                       chunks, S, C, CB, ws);
-  hipLaunchKernelGGL(stats_final_kernel, dim3(S * C), dim3(64), 0, s, x, cs, coff, group_rows, chunks, S, ws, C, P,
-                     1.0 / (double)srows, srows > 1 ? (double)srows / (double)(srows - 1) : 1.0, mean, var, gamma,
-                     beta, eps, momentum, run_mean, run_var, invstd, scale, shift);
+    hipLaunchKernelGGL(stats_partial_kernel<1>, dim3(P, ncb), dim3(TPB), 0, s, x, cs, coff, group_rows, chunks, S, C, CB,
+                       ws, fin);
+  if (!fused)
+    hipLaunchKernelGGL(stats_final_kernel, dim3(S * C), dim3(64), 0, s, x, cs, coff, group_rows, chunks, S, ws, C, P,
+                       fin.inv_rows, fin.unbias, mean, var, gamma, beta, eps, momentum, run_mean, run_var, invstd, scale,
+                       shift);
   SF_CHECK_LAUNCH();
   return SF_OK;
 }
