@@ -1,0 +1,14 @@
+cd /tmp && export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/final; mkdir -p $O
+timeout 400 rocprofv3 --kernel-trace --stats -d $O/default --output-format csv -- python3 $R/bench.py --no-cpu-baseline > $O/default.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats -d $O/train --output-format csv -- python3 $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-extras > $O/train.log 2>&1
+SF_OVERLAP_PATHS=0 timeout 300 rocprofv3 --kernel-trace --stats -d $O/serial --output-format csv -- python3 $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-extras > $O/serial.log 2>&1
+for p in "GRBM_GUI_ACTIVE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES" "SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY"; do n=$(echo $p | cut -c1-12 | tr " " _); PMC_CFGS=0,2,3 timeout 250 rocprofv3 --kernel-trace --pmc $p -d $O/pmcw_$n --output-format csv -- python3 $R/tools/microbench/conv_wave_pmc.py > $O/pmcw_$n.log 2>&1; done
+cd $R
+python3 tools/pmc_short.py $(find gpurun_out/final/pmcw_* -name "*counter_collection.csv") > gpurun_out/final/pmc_conv_wave.txt
+timeout 300 python tools/prof_convs.py dual > gpurun_out/final/conv_per_shape.txt 2>&1
+timeout 400 python tools/microbench/conv_wave_bench.py > gpurun_out/final/conv_wave_ab.txt 2>&1
+timeout 400 python tools/microbench/wgrad_wave_bench.py > gpurun_out/final/wgrad_wave_ab.txt 2>&1
+for w in dual slowfast ghostnet shufflenetv2; do timeout 600 python bench.py --workload $w > gpurun_out/final/bench_$w.json 2> gpurun_out/final/bench_$w.err; done
+for d in default train serial; do cp $(find gpurun_out/final/$d -name "*kernel_stats.csv") gpurun_out/final/${d}_kernel_stats.csv; done
+python3 tools/prof_stats.py gpurun_out/final/serial_kernel_stats.csv 8 50 > gpurun_out/final/serial_per_step.txt
+tail -3 gpurun_out/final/serial_per_step.txt; cat gpurun_out/final/pmc_conv_wave.txt | head -20; tail -4 gpurun_out/final/conv_per_shape.txt
