@@ -182,6 +182,10 @@ def _require_gpu(t, what):
                          "(no CPU fallback)" % (what, t.device))
     if t.dtype != torch.float32:
         raise SfhipError("%s: expected float32, got %s" % (what, t.dtype))
+    if t.device.index != torch.cuda.current_device():
+        # kernels are enqueued on the CURRENT device's stream: a tensor of another GPU would be launched on the wrong one
+        raise SfhipError("%s: tensor is on %s but the current device is cuda:%d — call torch.cuda.set_device(%d) (one "
+                         "process per GPU)" % (what, t.device, torch.cuda.current_device(), t.device.index))
 
 
 # ------------------------------------------------------------------------------------------------ Act

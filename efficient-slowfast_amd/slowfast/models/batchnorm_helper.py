@@ -77,10 +77,10 @@ class NaiveSyncBatchNorm3d(nn.BatchNorm3d):
             self.num_sync_devices = du.get_local_size()
             self.num_groups = 1
         super(NaiveSyncBatchNorm3d, self).__init__(**args)
-        if du.get_local_size() > 1:
-            # its statistics are collectives: keep every rank's collectives on one stream, in program order
-            from slowfast.models import engine
-            engine.OVERLAP_PATHS = False
+        # its statistics are collectives: engine.run_model keeps a model that contains such a layer (and runs on more
+        # than one local rank) on ONE stream, so that every rank issues its collectives in program order — decided per
+        # model, not process-wide
+        self._sf_collective = True
 
     def forward(self, input):
         from slowfast.models import engine

@@ -56,6 +56,7 @@ class Tape(object):
         self.out_act = None
         self.sink = None  # {param: its .grad} when parameter gradients are accumulated in place (set_grad_sink)
         self.side = None  # the side stream ops are being recorded for (run_paths), None = the caller's stream
+        self.serial = getattr(_tls, "serial", False)  # the model keeps one stream (collective-carrying layers)
         self.input_ids = {}    # id(clip tensor) -> input index, for the inputs whose gradient autograd asked for
         self.input_grads = {}  # input index -> dL/d(clip), NCTHW (written by the stems' backward)
         self.joins = set()  # companion streams with weight-gradient work in flight (joined at the end of backward)
@@ -163,7 +164,7 @@ def run_paths(fns, device, defer_join=False):
     valid when the next work on the caller's stream does not read what fns[1] produced before the next region's
     join (a CMDA fusion followed by a stage: the attention keeps running beside the Slow pathway's next stage).
     The backward pass is unaffected: its fork at this point is always recorded."""
-    if not OVERLAP_PATHS or len(fns) != 2 or device.type != "cuda":
+    if not OVERLAP_PATHS or getattr(_tls, "serial", False) or len(fns) != 2 or device.type != "cuda":
         return [f() for f in fns]
     t = tape()
     if t is not None and t.side is not None:
@@ -230,7 +231,7 @@ def _record_conv(x, conv_weight, conv_bias, wp_shape, gsrc, kernel, stride, padd
     def bwd():
         g = gsrc() if callable(gsrc) else gsrc
         dev = x.buf.device
-        if OVERLAP_PATHS and x_needs_grad and dev.type == "cuda":
+        if OVERLAP_PATHS and not t.serial and x_needs_grad and dev.type == "cuda":
             # the weight gradient only feeds the parameter's .grad: issue it on a companion stream so that it
             # overlaps the data gradient (both are short-grid GEMMs on the res4 / res5 layers); joined by
             # Tape.backward before the gradients are handed back
@@ -691,6 +692,15 @@ def run_model(model, x):
     """model.forward body shared by all model classes: taped when training with grad enabled."""
     global _NBT
     outer, _NBT = _NBT, []
+    serial = model.__dict__.get("_sf_serial_streams")
+    if serial is None:  # collective-carrying layers (Sync-BN over > 1 local rank): one stream for this model only
+        from slowfast.utils import distributed as du
+        serial = du.get_local_size() > 1 and any(getattr(m, "_sf_collective", False) for m in model.modules())
+        model.__dict__["_sf_serial_streams"] = serial
+        if serial and OVERLAP_PATHS:
+            print("[sfhip] %s holds Sync-BN layers over %d local ranks: its pathways run on one stream (collectives "
+                  "stay in program order)" % (type(model).__name__, du.get_local_size()))
+    outer_serial, _tls.serial = getattr(_tls, "serial", False), serial
     try:
         if model.training and torch.is_grad_enabled():
             if _GRAD_SINK and getattr(model, "_sf_ddp_wrapped", False):
@@ -701,6 +711,7 @@ def run_model(model, x):
             return TapedForward.apply(model, len(x), *x, *params)
         return model._forward_impl(x)
     finally:
+        _tls.serial = outer_serial
         counters, _NBT = _NBT, outer
         if counters:
             with torch.no_grad():

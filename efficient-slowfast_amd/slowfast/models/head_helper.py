@@ -16,14 +16,15 @@ def _project(pooled, linear, dropout, training):
     """[N,T,H,W,C] -> logits Act [N,T,H,W,K] through nn.Linear's parameters (1x1x1 GEMM)."""
     t = engine.tape()
     if dropout is not None and training and dropout.p > 0.0:
-        # nn.Dropout on the pooled [N, C] features: a parameter-sized mask (torch RNG, as the reference)
+        # nn.Dropout on the pooled [N, C] features through the same ATen kernel nn.Dropout dispatches to, so the mask
+        # and the generator's consumption equal the reference's under a seed (head_helper.py:207-208)
         keep = 1.0 - dropout.p
-        mask = (torch.rand_like(pooled.buf) < keep).to(torch.float32) / keep
         src = pooled
-        pooled = sfhip.Act(src.buf * mask)
+        out, keep_mask = torch.native_dropout(src.buf, dropout.p, True)
+        pooled = sfhip.Act(out)
         if t is not None:
             dropped = pooled
-            t.record(lambda: t.grad_of(src).buf.add_(t.grad_of(dropped).buf * mask))
+            t.record(lambda: t.grad_of(src).buf.add_(t.grad_of(dropped).buf * keep_mask.to(torch.float32) / keep))
     wp = engine._cached(linear, "_sf_wp", engine._key(linear.weight),
                         lambda: sfhip.pack_conv_weight(linear.weight.reshape(linear.out_features, -1, 1, 1, 1)))
     logits = sfhip.conv(pooled, wp, (1, 1, 1), bias=linear.bias)

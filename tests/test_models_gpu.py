@@ -280,6 +280,29 @@ def test_input_gradients_match_reference_golden(name):
         assert e < 8e-2 and abs(norm - rnorm) < 5e-2 * rnorm, (nm, e, norm, rnorm)
 
 
+def test_head_dropout_draws_like_nn_dropout():
+    """The head's training dropout goes through the ATen kernel nn.Dropout dispatches to (head_helper.py:207-208 in
+    the reference): same mask and same generator consumption under a seed, so a seeded training run stays comparable
+    with the reference's."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import sfhip
+    from slowfast.models import head_helper
+    x = torch.randn(8, 1, 1, 1, 2304, device="cuda")
+    lin = torch.nn.Linear(2304, 400).cuda()
+    drop = torch.nn.Dropout(0.5)
+    torch.manual_seed(123)
+    ref = torch.nn.functional.linear(drop(x), lin.weight, lin.bias)
+    after_ref = torch.rand(1, device="cuda")
+    torch.manual_seed(123)
+    with torch.no_grad():
+        got = head_helper._project(sfhip.Act(x.clone()), lin, drop, True).buf
+    after_got = torch.rand(1, device="cuda")
+    torch.cuda.synchronize()
+    assert rel_err(got.cpu().numpy(), ref.detach().cpu().numpy()) < 1e-5
+    assert torch.equal(after_ref, after_got)
+
+
 def test_precise_bn_pass_matches_oracle_batch_statistics():
     """calculate_and_update_precise_bn (train_net.py:277-296 -> fvcore update_bn_stats): after the pass every BN's
     running statistics are the plain average over the iterations of its per-batch (mean, unbiased var); the
