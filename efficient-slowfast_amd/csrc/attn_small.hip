@@ -264,6 +264,8 @@ int launch(const AttnArgs& a, bool vec4, hipStream_t s) {
 
 }  // namespace
 
+int sf_attn_lane_try(SfAttnArgs a, bool vec4, float* ws, hipStream_t stream);  // attn_lane.hip
+
 // Called by sf_attn_fwd (attn_flash.hip) for C <= 16.
 int sf_attn_small_dispatch(const float* q, int q_cs, const float* k, int k_cs, const float* v, int v_cs,
                            const float* x, int x_cs, const float* gamma, const float* scale, const float* bias,
@@ -274,6 +276,10 @@ int sf_attn_small_dispatch(const float* q, int q_cs, const float* k, int k_cs, c
   a.o_save = o_save; a.lse_save = lse_save;
   a.q_cs = q_cs; a.k_cs = k_cs; a.v_cs = v_cs; a.x_cs = x_cs; a.out_cs = out_cs; a.out_coff = out_coff;
   a.B = B; a.T = T; a.H = H; a.W = W; a.C = C; a.N = T * H * W; a.alpha = alpha; a.act = act;
+  {  // d = 4 / d = 8: one query per lane on 4x4x1 MFMA blocks (attn_lane.hip) — no padded rows in either product
+    const int rc = sf_attn_lane_try(a, vec4, ws, stream);
+    if (rc != 1) return rc;
+  }
   a.nqt = sf_cdiv(a.N, 64);
   a.zs = 1; a.part_o = nullptr; a.part_ml = nullptr;
   if (ws) {
