@@ -475,8 +475,10 @@ static ConvCfg conv_cfg(const sf_conv_desc* d, long M, int ksplit) {
 }  // namespace
 
 int sf_conv_wave_try(const sf_conv_desc* d, const float* in, const float* w, const float* scale,
-                     const float* bias, const float* res, float* out, hipStream_t stream);  // conv_wave.hip
+                     const float* bias, const float* res, float* out, hipStream_t stream, float* stats,
+                     int* stat_parts);                                                       // conv_wave.hip
 int sf_conv_wave_takes(const sf_conv_desc* d);                                                // conv_wave.hip
+long sf_conv_wave_max_parts(long M);                                                          // conv_wave.hip
 
 extern "C" long sf_conv_fwd_ws_floats(const sf_conv_desc* d) {
   if (!d) return 0;
@@ -491,7 +493,9 @@ int sf_conv_stem_fwd_try(const sf_conv_desc* d, const float* in, const float* w,
                          const float* bias, const float* res, float* out, hipStream_t stream);  // conv_stem.hip
 
 static int conv_fwd_impl(const sf_conv_desc* d, const float* in, const float* w_packed, const float* scale,
-                         const float* bias, const float* res, float* out, float* ws, void* stream) {
+                         const float* bias, const float* res, float* out, float* ws, void* stream,
+                         float* stats = nullptr, int* stat_parts = nullptr) {
+  if (stat_parts) *stat_parts = 0;
   if (!d || !in || !w_packed || !out) return SF_EINVAL;
   if (d->Cin <= 0 || d->Cout <= 0 || d->cin_pad < d->Cin || (d->cin_pad % BK) != 0) return SF_EINVAL;
   if (d->kT <= 0 || d->kH <= 0 || d->kW <= 0 || d->sT <= 0 || d->sH <= 0 || d->sW <= 0) return SF_EINVAL;
@@ -512,7 +516,7 @@ static int conv_fwd_impl(const sf_conv_desc* d, const float* in, const float* w_
     if (rc != 1) return rc;
   }
   {  // the per-wavefront implicit GEMM (no LDS staging, no barrier in the main loop) for every 16-byte aligned shape
-    const int rc = sf_conv_wave_try(d, in, w_packed, scale, bias, res, out, (hipStream_t)stream);
+    const int rc = sf_conv_wave_try(d, in, w_packed, scale, bias, res, out, (hipStream_t)stream, stats, stat_parts);
     if (rc != 1) return rc;
   }
   ConvArgs a;
@@ -557,4 +561,20 @@ extern "C" int sf_conv_fwd_ws(const sf_conv_desc* d, const float* in, const floa
                               const float* bias, const float* res, float* out, float* ws, void* stream) {
   if (ws && !sf_aligned16(ws)) return SF_EALIGN;
   return conv_fwd_impl(d, in, w_packed, scale, bias, res, out, ws, stream);
+}
+
+// Training-mode BN statistics out of the conv's epilogue (conv_wave.hip): sf_conv_stats_ws_floats(d) floats of scratch
+// (0: this shape never produces them); sf_conv_fwd_stats runs the conv and sets *parts to the number of [count, K, S1,
+// S2] rows per channel it left in stats_ws (0: none were produced — run sf_bn_train_stats on the output instead).
+extern "C" long sf_conv_stats_ws_floats(const sf_conv_desc* d) {
+  if (!d || !sf_conv_wave_takes(d) || d->transposed) return 0;
+  const long M = (long)d->N * d->To * d->Ho * d->Wo;
+  return sf_conv_wave_max_parts(M) * 4 * d->Cout;
+}
+
+extern "C" int sf_conv_fwd_stats(const sf_conv_desc* d, const float* in, const float* w_packed, const float* scale,
+                                 const float* bias, const float* res, float* out, float* stats_ws, int* parts,
+                                 void* stream) {
+  if (!parts) return SF_EINVAL;
+  return conv_fwd_impl(d, in, w_packed, scale, bias, res, out, nullptr, stream, stats_ws, parts);
 }

@@ -44,6 +44,7 @@ struct WaveArgs {
   int nk;              // K steps of 16 = ntaps * cin_pad / 16
   int cpk;             // K steps per tap = cin_pad / 16
   unsigned in_bytes, w_bytes;
+  float* stats;        // != NULL: per (M tile, channel) [count, K, sum(v - K), sum((v - K)^2)] of the stored outputs
   // n / d for 0 <= n < 2^31 as (mulhi(n, mul) >> sh); d == 1 has mul == 0 (identity)
   unsigned wo_mul, wo_sh, ho_mul, ho_sh, to_mul, to_sh;
 };
@@ -231,6 +232,13 @@ __global__ __launch_bounds__(256) void conv_wave_kernel(const WaveArgs p) {
   constexpr int PER = (NV + KS * 64 - 1) / (KS * 64);
   float* const slab = smem + wave * (R * 16 * EP);
   const float* const slab0 = smem + (tslot * KS) * (R * 16 * EP);
+  // Training-mode BN statistics of the outputs, taken where they are stored (removes the statistics kernel's read
+  // pass over z): a lane always handles the same 4 channels (c4 = 4 * (lane % LPR)), so it keeps shifted sums
+  // sum(v - K), sum((v - K)^2) with K = the tile's first row; lanes, then the tile's KS wavefronts, are combined at
+  // the end and ONE row [count, K, S1, S2] per (M tile, channel) goes to p.stats (merged in fp64 by
+  // stats_merge_kernel with Chan's formula, so the shift may differ from tile to tile).
+  const bool want_stats = p.stats != nullptr;
+  f32x4 st_k = {0.f, 0.f, 0.f, 0.f}, st_1 = {0.f, 0.f, 0.f, 0.f}, st_2 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int i0 = 0; i0 < TM; i0 += R) {
 #pragma unroll
@@ -243,6 +251,13 @@ __global__ __launch_bounds__(256) void conv_wave_kernel(const WaveArgs p) {
       }
     }
     __syncthreads();
+    if (want_stats && i0 == 0) {  // the tile's first output row (always a valid row of a live tile)
+      const int c4 = (lane % LPR) * 4;
+      st_k = *reinterpret_cast<const f32x4*>(slab0 + c4);
+#pragma unroll
+      for (int s = 1; s < KS; ++s) st_k += *reinterpret_cast<const f32x4*>(slab0 + s * (R * 16 * EP) + c4);
+      if (p.bias && n0 + c4 < d.Cout) st_k += *reinterpret_cast<const f32x4*>(p.bias + n0 + c4);
+    }
 #pragma unroll
     for (int q = 0; q < PER; ++q) {
       const int idx = (q * KS + ksub) * 64 + lane;
@@ -274,9 +289,47 @@ __global__ __launch_bounds__(256) void conv_wave_kernel(const WaveArgs p) {
           for (int e = 0; e < 4; ++e) v[e] = fminf(fmaxf(v[e], 0.f), hi);
         }
         *reinterpret_cast<f32x4*>(p.out + orow * d.out_cs + d.out_coff + n) = v;
+        if (want_stats) {
+          const f32x4 dv = v - st_k;
+          st_1 += dv;
+          st_2 += dv * dv;
+        }
       }
     }
     if (i0 + R < TM) __syncthreads();
+  }
+  if (want_stats) {
+#pragma unroll
+    for (int off = LPR; off < 64; off <<= 1)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        st_1[e] += __shfl_xor(st_1[e], off, 64);
+        st_2[e] += __shfl_xor(st_2[e], off, 64);
+      }
+    __syncthreads();  // the slabs are free now: [wave][LPR][8] partial sums
+    float* const red = smem;
+    if (lane < LPR) {
+      *reinterpret_cast<f32x4*>(red + (wave * LPR + lane) * 8) = st_1;
+      *reinterpret_cast<f32x4*>(red + (wave * LPR + lane) * 8 + 4) = st_2;
+    }
+    __syncthreads();
+    const int n = n0 + lane * 4;
+    if (ksub == 0 && lane < LPR && live && n < d.Cout) {
+      f32x4 a1 = *reinterpret_cast<const f32x4*>(red + (wave * LPR + lane) * 8);
+      f32x4 a2 = *reinterpret_cast<const f32x4*>(red + (wave * LPR + lane) * 8 + 4);
+#pragma unroll
+      for (int s = 1; s < KS; ++s) {  // the tile's other wavefronts, in wavefront order
+        a1 += *reinterpret_cast<const f32x4*>(red + ((wave + s) * LPR + lane) * 8);
+        a2 += *reinterpret_cast<const f32x4*>(red + ((wave + s) * LPR + lane) * 8 + 4);
+      }
+      const int left = p.M - m0;
+      const float cnt = (float)(left < p.rows ? left : p.rows);
+      float* const o = p.stats + ((long)tile_m * 4) * d.Cout + n;
+      *reinterpret_cast<f32x4*>(o) = (f32x4){cnt, cnt, cnt, cnt};
+      *reinterpret_cast<f32x4*>(o + d.Cout) = st_k;
+      *reinterpret_cast<f32x4*>(o + 2 * d.Cout) = a1;
+      *reinterpret_cast<f32x4*>(o + 3 * d.Cout) = a2;
+    }
   }
 }
 
@@ -378,9 +431,14 @@ int sf_conv_wave_takes(const sf_conv_desc* d) {
   return 1;
 }
 
+// Upper bound of the M tiles any configuration makes of M rows (rows per tile >= M / (ceil(M / 112) + 47)).
+long sf_conv_wave_max_parts(long M) { return (M + 111) / 112 + 48; }
+
 // Returns 1 when the shape is not taken (the caller falls through to conv_igemm), else SF_OK / an error code.
 int sf_conv_wave_try(const sf_conv_desc* d, const float* in, const float* w_packed, const float* scale,
-                     const float* bias, const float* res, float* out, hipStream_t stream) {
+                     const float* bias, const float* res, float* out, hipStream_t stream, float* stats,
+                     int* stat_parts) {
+  if (stat_parts) *stat_parts = 0;
   if (!sf_conv_wave_takes(d)) return 1;
   const long M = (long)d->N * d->To * d->Ho * d->Wo;
   const int ntaps = d->kT * d->kH * d->kW;
@@ -425,6 +483,11 @@ int sf_conv_wave_try(const sf_conv_desc* d, const float* in, const float* w_pack
   a.nb_n = sf_cdiv(d->Cout, c.tn * 16);
   a.ntiles = sf_cdiv(M, a.rows) * a.nb_n;
   a.nwg = sf_cdiv(a.ntiles, 4 / c.ks);
+  // statistics of the stored outputs: only for the plain epilogue (raw conv output + bias), dense stores
+  const bool scatter = d->os_T > 1 || d->os_H > 1 || d->os_W > 1;
+  a.stats = (stats && stat_parts && !scale && !res && d->act == SF_ACT_NONE && !scatter && sf_aligned16(stats))
+                ? stats : nullptr;
+  if (a.stats) *stat_parts = sf_cdiv(M, a.rows);
   switch (best) {
     case 0: return launch_wave<13, 2, 4>(a, kv, stream);
     case 1: return launch_wave<13, 2, 1>(a, kv, stream);

@@ -810,6 +810,69 @@ static int stats_launch(const float* x, int cs, int coff, int groups, long group
   return SF_OK;
 }
 
+// Merge of the per-tile rows [count, K, S1 = sum(v - K), S2 = sum((v - K)^2)] a conv epilogue left per channel
+// (conv_wave.hip) — Chan's parallel mean / M2 update in fp64, one 64-lane block per channel, fixed order.
+__global__ void stats_merge_kernel(const float* __restrict__ parts, int P, int C, const StatsFinal f) {
+  __shared__ double r1[64], r2[64];
+  const int c = blockIdx.x;
+  double n = 0.0, t = 0.0;
+  for (int i = threadIdx.x; i < P; i += 64) {
+    const float* q = parts + (long)i * 4 * C + c;
+    const double ni = (double)q[0];
+    n += ni;
+    t += ni * (double)q[C] + (double)q[2 * C];
+  }
+  r1[threadIdx.x] = n;
+  r2[threadIdx.x] = t;
+  __syncthreads();
+  for (int s = 32; s > 0; s >>= 1) {
+    if (threadIdx.x < s) {
+      r1[threadIdx.x] += r1[threadIdx.x + s];
+      r2[threadIdx.x] += r2[threadIdx.x + s];
+    }
+    __syncthreads();
+  }
+  const double N = r1[0], mean = r2[0] / r1[0];
+  __syncthreads();
+  double m2 = 0.0;
+  for (int i = threadIdx.x; i < P; i += 64) {
+    const float* q = parts + (long)i * 4 * C + c;
+    const double ni = (double)q[0], s1 = (double)q[2 * C], s2 = (double)q[3 * C];
+    const double dm = (double)q[C] + s1 / ni - mean;
+    m2 += (s2 - s1 * s1 / ni) + ni * dm * dm;
+  }
+  r1[threadIdx.x] = m2;
+  __syncthreads();
+  for (int s = 32; s > 0; s >>= 1) {
+    if (threadIdx.x < s) r1[threadIdx.x] += r1[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    double v = r1[0] / N;
+    if (v < 0.0) v = 0.0;
+    StatsFinal g = f;
+    g.unbias = N > 1.0 ? N / (N - 1.0) : 1.0;
+    // stats_finish takes sums of (x - K) with one K: hand it the merged moments with K = 0
+    g.inv_rows = 1.0;
+    stats_finish(g, c, mean, v + mean * mean, 0.f);
+  }
+}
+
+extern "C" int sf_bn_train_stats_merge(const float* parts, int P, int C, const float* gamma, const float* beta, float eps,
+                                       float momentum, float* run_mean, float* run_var, float* mean, float* var,
+                                       float* invstd, float* scale, float* shift, void* stream) {
+  if (!parts || P <= 0 || C <= 0 || !gamma || !beta || !mean || !var || !invstd || !scale || !shift) return SF_EINVAL;
+  if ((run_mean == nullptr) != (run_var == nullptr)) return SF_EINVAL;
+  StatsFinal fin;
+  fin.inv_rows = 1.0; fin.unbias = 1.0;
+  fin.mean = mean; fin.var = var; fin.gamma = gamma; fin.beta = beta; fin.eps = eps; fin.momentum = momentum;
+  fin.run_mean = run_mean; fin.run_var = run_var; fin.invstd = invstd; fin.scale = scale; fin.shift = shift;
+  fin.tickets = nullptr;
+  hipLaunchKernelGGL(stats_merge_kernel, dim3(C), dim3(64), 0, (hipStream_t)stream, parts, P, C, fin);
+  SF_CHECK_LAUNCH();
+  return SF_OK;
+}
+
 extern "C" int sf_channel_stats(const float* x, int cs, int coff, long rows, int C, float* mean, float* var,
                                 float* ws, void* stream) {
   if (!x || !mean || !var || !ws || rows <= 0 || C <= 0) return SF_EINVAL;

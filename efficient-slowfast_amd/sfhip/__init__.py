@@ -53,11 +53,11 @@ EXPORTS = [
     "sf_clip_prologue", "sf_conv_wgrad_finish", "sf_bn_bwd_reduce_acc", "sf_row_softmax_fwd", "sf_row_softmax_bwd",
     "sf_attn_bwd_fused_ws_floats", "sf_attn_bwd_fused", "sf_pack_conv_weight", "sf_conv_fwd_ws_floats",
     "sf_conv_fwd_ws", "sf_attn_fwd_ws_floats", "sf_attn_fwd_ws", "sf_affine_fwd_mask", "sf_bn_bwd_apply_first", "sf_maxpool_bwd_first",
-    "sf_conv_tune",
+    "sf_conv_tune", "sf_conv_stats_ws_floats", "sf_conv_fwd_stats", "sf_bn_train_stats_merge",
 ]
 _LONG_RET = ("sf_tmax_mean_ws_floats", "sf_channel_stats_ws_floats", "sf_bn_bwd_ws_floats",
              "sf_dwconv_wgrad_ws_floats", "sf_attn_bwd_fused_ws_floats", "sf_conv_fwd_ws_floats",
-             "sf_attn_fwd_ws_floats")
+             "sf_attn_fwd_ws_floats", "sf_conv_stats_ws_floats")
 
 
 def lib_path():
@@ -127,6 +127,10 @@ def lib():
                                         vp, vp]
         L.sf_conv_fwd_ws_floats.argtypes = [ctypes.POINTER(ConvDesc)]
         L.sf_conv_fwd_ws_floats.restype = cl
+        L.sf_conv_stats_ws_floats.argtypes = [ctypes.POINTER(ConvDesc)]
+        L.sf_conv_stats_ws_floats.restype = cl
+        L.sf_conv_fwd_stats.argtypes = [ctypes.POINTER(ConvDesc)] + [vp] * 7 + [ctypes.POINTER(ctypes.c_int), vp]
+        L.sf_bn_train_stats_merge.argtypes = [vp, ci, ci, vp, vp, ctypes.c_float, ctypes.c_float] + [vp] * 8
         L.sf_conv_fwd_ws.argtypes = [ctypes.POINTER(ConvDesc)] + [vp] * 8
         L.sf_pack_conv_weight.argtypes = [vp, ci, ci, ci, vp, ci, vp, ci, vp]
         L.sf_conv_tune.argtypes = [ci, ci]
@@ -340,10 +344,15 @@ def pack_dw_weight(w):
     return w.detach().reshape(c, -1).t().contiguous()
 
 
+CONV_STATS = os.environ.get("SF_CONV_STATS", "1") != "0"
+
+
 def conv(x, wp, kernel, stride=(1, 1, 1), padding=(0, 0, 0), dilation=(1, 1, 1), scale=None, bias=None,
-         relu=False, res=None, out=None, cin=None, out_cmul=1, out_reserve=(0, 0), out_thw=None):
+         relu=False, res=None, out=None, cin=None, out_cmul=1, out_reserve=(0, 0), out_thw=None, stats=False):
     """Dense conv (implicit GEMM, sf_conv_fwd).  `wp` = pack_conv_weight(...).  `out`: Act to write into
-    (a slice of a wider buffer) or None to allocate [.., before + Cout + after]."""
+    (a slice of a wider buffer) or None to allocate [.., before + Cout + after].
+    stats=True returns (out, parts) with parts = (workspace, rows) of per-tile channel statistics of the output taken
+    in the conv's epilogue (sf_conv_fwd_stats) for bn_train_stats_merge, or None when this shape produces none."""
     _require_gpu(x.buf, "conv")
     cout, taps, cin_pad = wp.shape
     cin = x.C if cin is None else cin
@@ -365,9 +374,20 @@ def conv(x, wp, kernel, stride=(1, 1, 1), padding=(0, 0, 0), dilation=(1, 1, 1),
                  res.cs if res is not None else 0, res.coff if res is not None else 0, 0)
     if res is not None:
         assert res.rows == out.rows and res.C == cout
+    if stats:
+        n = lib().sf_conv_stats_ws_floats(ctypes.byref(d)) if (CONV_STATS and scale is None and res is None
+                                                              and not relu and out_cmul == 1) else 0
+        if n > 0:
+            ws = torch.empty((n,), dtype=torch.float32, device=x.buf.device)
+            parts = ctypes.c_int(0)
+            tag = ("conv", d.N * d.To * d.Ho * d.Wo, d.kT * d.kH * d.kW * d.Cin, d.Cout)
+            _check(_traced(tag, lambda: lib().sf_conv_fwd_stats(ctypes.byref(d), x.ptr(), _ptr(wp), None, _ptr(bias),
+                                                                None, out.ptr(), _ptr(ws), ctypes.byref(parts),
+                                                                _stream())), "sf_conv_fwd_stats")
+            return out, ((ws, parts.value) if parts.value > 0 else None)
     _conv_launch(d, x.ptr(), _ptr(wp), _ptr(scale), _ptr(bias), res.ptr() if res is not None else None, out.ptr(),
                  x.buf.device, "sf_conv_fwd")
-    return out
+    return (out, None) if stats else out
 
 
 def dwconv(x, wp, kernel, stride=(1, 1, 1), padding=(0, 0, 0), scale=None, bias=None, relu=False, res=None,
@@ -807,6 +827,17 @@ def bn_train_stats(x, gamma, beta, eps, momentum, run_mean, run_var, nsplit=1):
             x.ptr(), x.cs, x.coff, x.N, x.T * x.H * x.W, x.C, nsplit, _ptr(gamma), _ptr(beta), float(eps),
             float(momentum), _ptr(run_mean), _ptr(run_var), _ptr(o[0]), _ptr(o[1]), _ptr(o[2]), _ptr(o[3]),
             _ptr(o[4]), _ptr(ws), _stream()), "sf_bn_train_stats_split")
+    return o[0], o[2], o[3], o[4]
+
+
+def bn_train_stats_merge(parts, C, gamma, beta, eps, momentum, run_mean, run_var):
+    """bn_train_stats from the per-tile rows a conv epilogue left (conv(..., stats=True)): one small launch, no pass
+    over the activation.  Returns (mean, invstd, scale, shift)."""
+    ws, rows = parts
+    o = torch.empty((5, C), dtype=torch.float32, device=ws.device)
+    _check(lib().sf_bn_train_stats_merge(_ptr(ws), rows, C, _ptr(gamma), _ptr(beta), float(eps), float(momentum),
+                                         _ptr(run_mean), _ptr(run_var), _ptr(o[0]), _ptr(o[1]), _ptr(o[2]),
+                                         _ptr(o[3]), _ptr(o[4]), _stream()), "sf_bn_train_stats_merge")
     return o[0], o[2], o[3], o[4]
 
 

@@ -317,9 +317,15 @@ def _bump(counter):
         counter.add_(1)
 
 
-def _bn_train_stats(bn, z):
+def _plain_bn(bn):
+    return not _sub_bn(bn) and not _sync_bn(bn)
+
+
+def _bn_train_stats(bn, z, conv_stats=None):
     """(mean, invstd, scale, shift, nsplit, gamma_for_backward, sync_hook) of a training-mode norm layer; updates
-    the running statistics in place exactly as the reference layer would."""
+    the running statistics in place exactly as the reference layer would.  conv_stats: per-tile statistics the
+    producing conv's epilogue left (sfhip.conv(..., stats=True)) — plain BatchNorm3d then merges those instead of
+    reading z again."""
     if _sub_bn(bn):
         S, sb = bn.num_splits, bn.split_bn
         if z.N % S != 0:
@@ -358,20 +364,26 @@ def _bn_train_stats(bn, z):
             return tot[:dbeta.numel()].float().contiguous(), tot[dbeta.numel():].float().contiguous()
 
         return mean, invstd, scale, shift, 1, bn.weight, sync
-    mean, invstd, scale, shift = sfhip.bn_train_stats(
-        z, bn.weight, bn.bias, bn.eps, m, bn.running_mean if track else None, bn.running_var if track else None)
+    if conv_stats is not None:
+        mean, invstd, scale, shift = sfhip.bn_train_stats_merge(
+            conv_stats, z.C, bn.weight, bn.bias, bn.eps, m, bn.running_mean if track else None,
+            bn.running_var if track else None)
+    else:
+        mean, invstd, scale, shift = sfhip.bn_train_stats(
+            z, bn.weight, bn.bias, bn.eps, m, bn.running_mean if track else None, bn.running_var if track else None)
     if track:  # the kernel wrote the running buffers in place: drop the folded eval-mode affine cache
         bn.__dict__.pop("_sf_affine", None)
         _bump(bn.num_batches_tracked)
     return mean, invstd, scale, shift, 1, bn.weight, None
 
 
-def bn_train_apply(bn, z, res=None, relu=False, rep=1, out=None, out_reserve=(0, 0), keep=None, out_cmul=1):
+def bn_train_apply(bn, z, res=None, relu=False, rep=1, out=None, out_reserve=(0, 0), keep=None, out_cmul=1,
+                   conv_stats=None):
     """Training-mode BatchNorm3d on the raw tensor z: batch statistics (sf_channel_stats), running-stat update
     (momentum, unbiased variance — torch semantics), then ONE normalise(+residual)(+ReLU)(+T-repeat) pass."""
     check_bn(bn)
     with torch.no_grad():
-        mean, invstd, scale, shift, nsplit, gamma_b, sync = _bn_train_stats(bn, z)
+        mean, invstd, scale, shift, nsplit, gamma_b, sync = _bn_train_stats(bn, z, conv_stats)
     zz = z if keep is None else z.slice(0, keep)
     nk = z.C if keep is None else keep
     if keep is not None:
@@ -476,8 +488,12 @@ def conv_bn_act(x, conv, bn=None, relu=False, res=None, out=None, out_reserve=(0
     wp = packed_weight(conv)
     if bn is not None and bn.training:
         k, s, p, d = conv.kernel_size, conv.stride, conv.padding, conv.dilation
+        st = None
         if conv.groups == 1:
-            z = sfhip.conv(x, wp, k, s, p, d, bias=conv.bias)
+            # plain BatchNorm3d: its batch statistics come out of the conv's epilogue (no extra pass over z)
+            want = _plain_bn(bn) and bn.affine
+            z = sfhip.conv(x, wp, k, s, p, d, bias=conv.bias, stats=want)
+            z, st = z if want else (z, None)
             _record_conv(x, conv.weight, conv.bias, wp.shape, z, k, s, p, d)
         else:
             ones = _cached(conv, "_sf_ones", (conv.out_channels, str(x.buf.device)),
@@ -493,7 +509,7 @@ def conv_bn_act(x, conv, bn=None, relu=False, res=None, out=None, out_reserve=(0
 
                 t.record(bwd_dw)
         return bn_train_apply(bn, z, res=res, relu=relu, out=out, out_reserve=out_reserve, keep=cout,
-                              out_cmul=out_cmul)
+                              out_cmul=out_cmul, conv_stats=st)
     if bn is not None:
         scale, bias = bn_affine(bn, conv.bias)
     else:
@@ -569,7 +585,10 @@ def stem_conv_bn_relu(x, conv, bn, relu=True):
     wp = _cached(conv, "_sf_wp_stem", _key(conv.weight), make)
     thw = (T + 2 * pT - kT + 1, Ho, Wo)
     if bn.training:
-        z = sfhip.conv(view, wp, (kT, kH, 1), (1, sH, 1), (pT, 0, 0), bias=conv.bias, cin=4 * kW, out_thw=thw)
+        want = _plain_bn(bn) and bn.affine
+        z = sfhip.conv(view, wp, (kT, kH, 1), (1, sH, 1), (pT, 0, 0), bias=conv.bias, cin=4 * kW, out_thw=thw,
+                       stats=want)
+        z, st = z if want else (z, None)
 
         def unpack(dwp):  # [Cout][kT*kH][kW*4 + c] -> [Cout, C, kT, kH, kW]
             co = dwp.shape[0]
@@ -578,7 +597,7 @@ def stem_conv_bn_relu(x, conv, bn, relu=True):
         _record_conv(view, conv.weight, conv.bias, wp.shape, z, (kT, kH, 1), (1, sH, 1), (pT, 0, 0), (1, 1, 1),
                      x_needs_grad=False, cin=4 * kW, unpack=unpack, fold_kw=kW)
         _record_stem_input_grad(x, conv, z, view, (N, C, T, H, W), (pH, pW, Wp), Wo)
-        return bn_train_apply(bn, z, relu=relu)
+        return bn_train_apply(bn, z, relu=relu, conv_stats=st)
     scale, bias = bn_affine(bn, conv.bias)
     return sfhip.conv(view, wp, (kT, kH, 1), (1, sH, 1), (pT, 0, 0), scale=scale, bias=bias, relu=relu,
                       cin=4 * kW, out_thw=thw)

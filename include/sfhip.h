@@ -81,6 +81,16 @@ int sf_conv_fwd(const sf_conv_desc* d, const float* in, const float* w_packed, c
 long sf_conv_fwd_ws_floats(const sf_conv_desc* d);
 int sf_conv_fwd_ws(const sf_conv_desc* d, const float* in, const float* w_packed, const float* scale,
                    const float* bias, const float* res, float* out, float* ws, void* stream);
+/* Training-mode BN statistics out of the conv's epilogue (Conv3d -> BatchNorm3d of stem_helper.py:239-254,
+ * resnet_helper.py:150-215 in train mode): the per-wavefront conv kernels keep shifted sums of the outputs they store
+ * and leave ONE row [count, K, sum(v - K), sum((v - K)^2)] per (M tile, channel) in stats_ws
+ * [parts][4][Cout]; sf_bn_train_stats_merge below turns those into what sf_bn_train_stats returns without a pass over
+ * the activation.  sf_conv_stats_ws_floats(d) = floats of stats_ws (0: this shape never produces statistics).
+ * sf_conv_fwd_stats sets *parts to the rows written, or to 0 when none were (epilogue with scale / res / act, or the
+ * LDS-tiled kernels took the launch): the caller then runs sf_bn_train_stats on the output.                      */
+long sf_conv_stats_ws_floats(const sf_conv_desc* d);
+int sf_conv_fwd_stats(const sf_conv_desc* d, const float* in, const float* w_packed, const float* scale,
+                      const float* bias, const float* res, float* out, float* stats_ws, int* parts, void* stream);
 /* Tuning knobs of the dense-conv launcher for microbenchmarks and A/B runs (process-wide, not used by the model code):
  * knob 0: value 0 routes every conv to the LDS-tiled kernels of conv_igemm.hip instead of the per-wavefront kernels of
  * conv_wave.hip; knob 1: force tile configuration `value` of conv_wave.hip (-1: planner); knob 2: force the rows per
@@ -181,6 +191,11 @@ int sf_channel_stats(const float* x, int cs, int coff, long rows, int C, float* 
 int sf_bn_train_stats(const float* x, int cs, int coff, long rows, int C, const float* gamma, const float* beta,
                       float eps, float momentum, float* run_mean, float* run_var, float* mean, float* var,
                       float* invstd, float* scale, float* shift, float* ws, void* stream);
+/* The same outputs from the per-tile rows of sf_conv_fwd_stats (Chan's parallel mean / M2 merge in fp64, fixed
+ * order); parts rows of [count, K, S1, S2] x C.                                                              */
+int sf_bn_train_stats_merge(const float* parts_ws, int parts, int C, const float* gamma, const float* beta, float eps,
+                            float momentum, float* run_mean, float* run_var, float* mean, float* var, float* invstd,
+                            float* scale, float* shift, void* stream);
 int sf_affine_fwd(const float* x, int cs, int coff, int N, int T, int H, int W, int C, const float* scale,
                   const float* bias, const float* res, int res_cs, int res_coff, int act, int rep, float* out,
                   int out_cs, int out_coff, int out_cmul, void* stream);

@@ -428,6 +428,59 @@ def test_channel_stats_are_robust_to_large_mean(c, shape):
     assert e1 < 1e-3 and e2 < 1e-4, (e1, e2)
 
 
+STAT_CASES = [
+    # cin, cout, kernel, stride, pad, (N,T,H,W), conv bias (large: |mean| >> std per channel)
+    (64, 64, (1, 3, 3), (1, 1, 1), (0, 1, 1), (2, 4, 28, 28), False),
+    (72, 24, (1, 1, 1), (1, 1, 1), (0, 0, 0), (1, 3, 13, 11), True),
+    (256, 512, (1, 1, 1), (1, 2, 2), (0, 0, 0), (2, 4, 14, 14), False),
+    (512, 128, (3, 1, 1), (1, 1, 1), (1, 0, 0), (2, 4, 7, 7), True),
+    (16, 8, (3, 1, 1), (1, 1, 1), (1, 0, 0), (2, 8, 9, 9), False),
+    (32, 64, (7, 1, 1), (4, 1, 1), (3, 0, 0), (1, 16, 6, 6), True),
+]
+
+
+@pytest.mark.parametrize("case", STAT_CASES, ids=["%dx%d_k%d%d%d" % (c[0], c[1], *c[2]) for c in STAT_CASES])
+def test_conv_epilogue_statistics(case):
+    """sf_conv_fwd_stats + sf_bn_train_stats_merge (batch statistics taken where the conv stores its outputs) against
+    fp64 statistics of the conv's own output and against sf_bn_train_stats on it: same mean / var / scale / shift and
+    the same running-stat update, also with a conv bias that puts |mean| at 30x the standard deviation."""
+    import sfhip
+    cin, cout, k, s, p, shp, big_bias = case
+    dev = _dev()
+    g = torch.Generator().manual_seed(cin * 7 + cout)
+    n, t, h, w = shp
+    x = torch.randn(n, cin, t, h, w, generator=g)
+    wt = torch.randn(cout, cin, *k, generator=g) / np.sqrt(cin * k[0] * k[1] * k[2])
+    bias = (torch.randn(cout, generator=g) * 30.0) if big_bias else None
+    wp = sfhip.pack_conv_weight(wt.to(dev))
+    xa = _ndhwc(x)
+    z, parts = sfhip.conv(xa, wp, k, s, p, bias=bias.to(dev) if big_bias else None, stats=True, out_reserve=(4, 4))
+    assert parts is not None, "the per-wavefront conv kernels take this shape and must produce statistics"
+    z0 = sfhip.conv(xa, wp, k, s, p, bias=bias.to(dev) if big_bias else None, out_reserve=(4, 4))
+    torch.cuda.synchronize()
+    assert torch.equal(_back(z), _back(z0)), "the statistics must not change what the conv stores"
+    gamma = (torch.rand(cout, generator=g) + 0.5).to(dev)
+    beta = torch.randn(cout, generator=g).to(dev)
+    rm0, rv0 = torch.randn(cout, generator=g).to(dev), (torch.rand(cout, generator=g) + 0.5).to(dev)
+    rm1, rv1 = rm0.clone(), rv0.clone()
+    m1, i1, sc1, sh1 = sfhip.bn_train_stats_merge(parts, cout, gamma, beta, 1e-5, 0.1, rm1, rv1)
+    rm2, rv2 = rm0.clone(), rv0.clone()
+    m2, i2, sc2, sh2 = sfhip.bn_train_stats(z, gamma, beta, 1e-5, 0.1, rm2, rv2)
+    torch.cuda.synchronize()
+    zd = _back(z).double().permute(0, 2, 3, 4, 1).reshape(-1, cout)
+    mean, var = zd.mean(0), zd.var(0, unbiased=False)
+    e_mean = float(((m1.double().cpu() - mean).abs() / var.sqrt()).max())
+    e_is = _rel(i1, torch.rsqrt(var + 1e-5))
+    _report("conv epilogue stats %s" % (case[:3],), max(e_mean, e_is))
+    assert e_mean < 1e-4 and e_is < 1e-4, (e_mean, e_is)
+    # the two kernels sum in different orders: means agree to 1e-5 of a standard deviation, the rest to 5e-5
+    assert float(((m1 - m2).double().cpu().abs() / var.sqrt()).max()) < 1e-5
+    for a, b in ((i1, i2), (sc1, sc2), (sh1, sh2), (rm1, rm2), (rv1, rv2)):
+        assert _rel(a, b) < 5e-5
+    nrows = zd.shape[0]
+    assert _rel(rv1, 0.9 * rv0.cpu().double() + 0.1 * var * nrows / (nrows - 1)) < 1e-5
+
+
 def test_copy_channels_shuffle():
     import sfhip
     dev = _dev()
