@@ -88,7 +88,32 @@ __global__ void bn_bwd_partial_kernel(const float* __restrict__ dy, int dy_cs, i
     float mu[VEC], is[VEC];
 #pragma unroll
     for (int e = 0; e < VEC; ++e) { mu[e] = mean[so + c + e]; is[e] = invstd[so + c + e]; }
-    for (long r = r0 + rl; r < r1; r += rpi) {
+    long r = r0 + rl;
+    if constexpr (VEC == 4) if (rep == 1 && (relu == 0 || relu == 3)) {
+      // four rows per trip, every load issued before the first use: a thread keeps 8 x 16 bytes (+ 4 mask bytes) in
+      // flight instead of 2 x 16 (<= 1024 workgroups = 16 wavefronts per CU cannot hide HBM latency with less)
+      const unsigned char* const mk = reinterpret_cast<const unsigned char*>(y);
+      for (; r + 3 * (long)rpi < r1; r += 4 * (long)rpi) {
+        f32x4 gv[4], zq[4];
+        unsigned mb[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const long ru = r + (long)u * rpi;
+          gv[u] = *reinterpret_cast<const f32x4*>(dy + ru * dy_cs + dy_coff + c);
+          zq[u] = *reinterpret_cast<const f32x4*>(z + ru * z_cs + z_coff + c);
+          mb[u] = relu == 3 ? mk[ru * y_cs + (c >> 2)] : 0xFu;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float ge = ((mb[u] >> e) & 1u) ? gv[u][e] : 0.f;
+            s1[e] += ge;
+            s2[e] = fmaf(ge, (zq[u][e] - mu[e]) * is[e], s2[e]);
+          }
+      }
+    }
+    for (; r < r1; r += rpi) {
       float g[VEC], zv[VEC];
       bn_g<VEC>(dy, dy_cs, dy_coff, y, y_cs, y_coff, r, THW, HW, rep, relu, c, g);
       if (VEC == 4) {

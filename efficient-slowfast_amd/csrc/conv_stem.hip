@@ -11,6 +11,12 @@
 //   B[k][n = co]: the weights of this wavefront's taps, in registers for the whole launch (the 35 taps are dealt to
 //       the 4 wavefronts: 9 taps x 2 chunks x 4 = 72 values per lane); packed channels 28..31 carry zero weights.
 // The wavefronts' partial rows are summed through LDS in wavefront order, then scale / bias / ReLU and the store.
+//
+// PAIR form (Cout <= 8, pixel stride 8 floats — the Fast stem itself): Cout = 8 fills half of the 16 MFMA columns, so
+// a row of the tile is a PAIR of neighbouring output positions and the columns are (h, co) = position 2p + h, channel
+// co.  The pair reads ONE window of 28 + 8 = 36 floats; position h sees it shifted by 8, i.e. the weights of column
+// (h, co) are w[co][tap][j - 8 h] (zero outside 0..27).  K per tap = 36 = two 16-float chunks + one 4-float chunk
+// (a ds_read_b32 feeding one MFMA): 9 MFMAs per tap per 32 positions instead of 16.
 #include "common.h"
 #include <stdlib.h>
 
@@ -26,6 +32,7 @@ struct StemFwdArgs {
   int rowf, ps, nblk, tparts, units;
 };
 
+template <bool PAIR>
 __global__ __launch_bounds__(256) void conv_stem_fwd_kernel(const StemFwdArgs q) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const sf_conv_desc& d = q.d;
@@ -38,17 +45,22 @@ __global__ __launch_bounds__(256) void conv_stem_fwd_kernel(const StemFwdArgs q)
   constexpr int LD4 = 8;
 
   // this wavefront's weights: tap = wave + 4 u; chunk c; MFMA s  ->  w[co = fr][tap][16 c + 4 fg + s]
-  float wreg[TPW][2][4];
+  // PAIR: column fr = (h, co) = (fr >> 3, fr & 7) holds w[co][tap][j - ps h]; wx = the 4-float chunk j = 32 + fg
+  float wreg[TPW][2][4], wx[TPW];
+  const int wco = PAIR ? (fr & 7) : fr, wsh = PAIR ? (fr >> 3) * q.ps : 0;
 #pragma unroll
   for (int u = 0; u < TPW; ++u) {
     const int tap = wave + 4 * u;
+    const bool okw = tap < NTAP && wco < d.Cout;
 #pragma unroll
     for (int c = 0; c < 2; ++c)
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
-        const int j = 16 * c + 4 * fg + s;
-        wreg[u][c][s] = (tap < NTAP && fr < d.Cout && j < d.Cin) ? q.w[((long)fr * NTAP + tap) * d.cin_pad + j] : 0.f;
+        const int j = 16 * c + 4 * fg + s - wsh;
+        wreg[u][c][s] = (okw && j >= 0 && j < d.Cin) ? q.w[((long)wco * NTAP + tap) * d.cin_pad + j] : 0.f;
       }
+    const int jx = 32 + fg - wsh;
+    wx[u] = (PAIR && okw && jx >= 0 && jx < d.Cin) ? q.w[((long)wco * NTAP + tap) * d.cin_pad + jx] : 0.f;
   }
   int t_kt[TPW], t_off[TPW];
 #pragma unroll
@@ -108,7 +120,11 @@ __global__ __launch_bounds__(256) void conv_stem_fwd_kernel(const StemFwdArgs q)
       for (int u = 0; u < TPW; ++u) aoff[u] = slot_of(base + t_kt[u]) * slab + t_off[u];
       for (int blk = 0; blk < q.nblk; ++blk) {
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        const int pos = min(blk * 16 + fr, d.Wo - 1) * q.ps;  // rows past Wo recompute the last position, never stored
+        // rows past the last position (pair) recompute the last one and are never stored
+        const int pos = PAIR ? min(blk * 16 + fr, ((d.Wo + 1) >> 1) - 1) * 2 * q.ps : min(blk * 16 + fr, d.Wo - 1) * q.ps;
+        // the pair's 4-float chunk: j = 32 + fg; past the row's end only for the unstored half of an odd last pair,
+        // whose weights are not zero-padded there -> read a zero instead of the neighbouring row
+        const bool xin = PAIR && pos + 32 + fg < q.rowf;
 #pragma unroll
         for (int u = 0; u < TPW; ++u) {
           if (wave + 4 * u >= NTAP) break;  // wave-uniform
@@ -117,6 +133,10 @@ __global__ __launch_bounds__(256) void conv_stem_fwd_kernel(const StemFwdArgs q)
             const f32x4 a = *reinterpret_cast<const f32x4*>(ring + aoff[u] + pos + 16 * c);
 #pragma unroll
             for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], wreg[u][c][s], acc, 0, 0, 0);
+          }
+          if (PAIR) {
+            const float ax = xin ? ring[aoff[u] + pos + 32 - 3 * fg] : 0.f;  // aoff carries 4 fg; this chunk wants fg
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ax, wx[u], acc, 0, 0, 0);
           }
         }
         // C layout: col n = fr (co), rows 4 fg + r (position within the block)
@@ -127,13 +147,153 @@ __global__ __launch_bounds__(256) void conv_stem_fwd_kernel(const StemFwdArgs q)
       const long orow0 = (((long)n * d.To + t) * d.Ho + h) * d.Wo;
       for (int e = tid; e < d.Wo * d.Cout; e += 256) {
         const int w = e / d.Cout, co = e - w * d.Cout;
-        const int idx = w * 16 + co;
+        const int idx = PAIR ? w * 8 + co : w * 16 + co;  // PAIR: row w >> 1, column 8 (w & 1) + co
         float v = red[idx] + red[nrow * 16 + idx] + red[2 * nrow * 16 + idx] + red[3 * nrow * 16 + idx];
         v = v * (q.scale ? q.scale[co] : 1.f) + (q.bias ? q.bias[co] : 0.f);
         if (relu) v = fminf(fmaxf(v, 0.f), hi);
         q.out[(orow0 + w) * d.out_cs + d.out_coff + co] = v;
       }
       // the next step's partial rows are written only after its own barrier, which also orders these reads
+    }
+  }
+}
+
+
+// PAIR form with the taps NOT dealt to the wavefronts: a wavefront owns a block of 16 position pairs and runs all 35
+// taps for it with every weight in registers (35 x 9 values per lane; the workgroup is alone on its CU, so a
+// wavefront has the SIMD's whole 512-register file).  No cross-wavefront sum, no partial rows in LDS, the epilogue
+// goes straight from the accumulator to HBM, and a SIX-slot ring (the slab being stored is never one of the five
+// being read) leaves one barrier per step of t.
+constexpr int RING6 = KT + 1;
+
+__global__ __launch_bounds__(256) void conv_stem_pair_kernel(const StemFwdArgs q) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const sf_conv_desc& d = q.d;
+  const int slab = KH * q.rowf;
+  float* const ring = lds;  // [RING6][slab]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int fr = lane & 15, fg = lane >> 4;
+  const int slab4 = slab >> 2;
+  constexpr int LD4 = 8;
+
+  // column fr = (h, co): w[co][tap][j - ps h]; chunks j = 16 c + 4 fg + s (c = 0, 1) and j = 32 + fg
+  float wreg[NTAP][2][4], wx[NTAP];
+  const int wco = fr & 7, wsh = (fr >> 3) * q.ps;
+#pragma unroll
+  for (int tap = 0; tap < NTAP; ++tap) {
+    const float* wt = q.w + ((long)wco * NTAP + tap) * d.cin_pad;
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const int j = 16 * c + 4 * fg + s - wsh;
+        wreg[tap][c][s] = (wco < d.Cout && j >= 0 && j < d.Cin) ? wt[j] : 0.f;
+      }
+    const int jx = 32 + fg - wsh;
+    wx[tap] = (wco < d.Cout && jx >= 0 && jx < d.Cin) ? wt[jx] : 0.f;
+  }
+  const float sc = (q.scale && wco < d.Cout) ? q.scale[wco] : 1.f;
+  const float bi = (q.bias && wco < d.Cout) ? q.bias[wco] : 0.f;
+
+  f32x4 rs[LD4];
+  auto load_slab = [&](int n, int ti, int h) {
+    const bool ok = (unsigned)ti < (unsigned)d.Ti;
+    const f32x4* src =
+        reinterpret_cast<const f32x4*>(q.in + (((long)n * d.Ti + (ok ? ti : 0)) * d.Hi + (long)h * d.sH) * q.rowf);
+#pragma unroll
+    for (int u = 0; u < LD4; ++u) {
+      const int f = tid + u * 256;
+      rs[u] = (ok && f < slab4) ? src[f] : (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+  };
+  auto store_slab = [&](int slot) {
+    f32x4* dst = reinterpret_cast<f32x4*>(ring + slot * slab);
+#pragma unroll
+    for (int u = 0; u < LD4; ++u) {
+      const int f = tid + u * 256;
+      if (f < slab4) dst[f] = rs[u];
+    }
+  };
+  auto slot_of = [](int ti) { return ((ti % RING6) + RING6) % RING6; };
+
+  const bool relu = d.act == SF_ACT_RELU || d.act == SF_ACT_RELU6;
+  const float hi = d.act == SF_ACT_RELU6 ? 6.f : 3.0e38f;
+  const int npair = (d.Wo + 1) >> 1;
+
+  for (int unit = blockIdx.x; unit < q.units; unit += gridDim.x) {
+    const int tz = unit % q.tparts;
+    const int nh = unit / q.tparts;
+    const int h = nh % d.Ho, n = nh / d.Ho;
+    const int tper = (d.To + q.tparts - 1) / q.tparts;
+    const int t0 = tz * tper, t1 = min(d.To, t0 + tper);
+    if (t0 >= t1) continue;
+    __syncthreads();  // the previous unit's last step may still read the ring
+    for (int kt = 0; kt < KT - 1; ++kt) {
+      const int ti = t0 - d.pT + kt;
+      load_slab(n, ti, h);
+      store_slab(slot_of(ti));
+    }
+    load_slab(n, t0 - d.pT + KT - 1, h);
+    for (int t = t0; t < t1; ++t) {
+      const int tnew = t - d.pT + KT - 1;
+      store_slab(slot_of(tnew));  // not one of the five slots the step before reads
+      __syncthreads();
+      if (t + 1 < t1) load_slab(n, tnew + 1, h);
+      int soff[KT];
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt) soff[kt] = slot_of(t - d.pT + kt) * slab;
+      const long orow0 = (((long)n * d.To + t) * d.Ho + h) * d.Wo;
+      for (int blk = wave; blk < q.nblk; blk += 4) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};  // two chains: chunk 0 / chunks 1 + x
+        const int pos = min(blk * 16 + fr, npair - 1) * 2 * q.ps;  // rows past the last pair are never stored
+        const bool xin = pos + 32 + fg < q.rowf;                    // see conv_stem_fwd_kernel
+        const float* const a0 = ring + pos + 4 * fg;
+        // the next tap's fragments are read from LDS while this tap's 9 MFMAs run (one wavefront per SIMD: nothing
+        // else hides the ds_read latency); the scheduling barriers keep the compiler from sinking the reads
+        f32x4 a_cur[2];
+        float x_cur;
+        {
+          const float* const ap = a0 + soff[0];
+          a_cur[0] = *reinterpret_cast<const f32x4*>(ap);
+          a_cur[1] = *reinterpret_cast<const f32x4*>(ap + 16);
+          x_cur = xin ? ap[32 - 3 * fg] : 0.f;
+        }
+#pragma unroll
+        for (int tap = 0; tap < NTAP; ++tap) {
+          f32x4 a_nxt[2] = {a_cur[0], a_cur[1]};
+          float x_nxt = x_cur;
+          if (tap + 1 < NTAP) {
+            const float* const ap = a0 + soff[(tap + 1) / KH] + ((tap + 1) % KH) * q.rowf;
+            a_nxt[0] = *reinterpret_cast<const f32x4*>(ap);
+            a_nxt[1] = *reinterpret_cast<const f32x4*>(ap + 16);
+            x_nxt = xin ? ap[32 - 3 * fg] : 0.f;
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int s = 0; s < 4; ++s) {
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[0][s], wreg[tap][0][s], acc, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[1][s], wreg[tap][1][s], acc1, 0, 0, 0);
+          }
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(x_cur, wx[tap], acc, 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+          a_cur[0] = a_nxt[0];
+          a_cur[1] = a_nxt[1];
+          x_cur = x_nxt;
+        }
+        acc += acc1;
+        // C layout: column fr = (h, co), rows 4 fg + r = pair within the block
+        if (wco < d.Cout) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int w = 2 * (blk * 16 + 4 * fg + r) + (fr >> 3);
+            if (w < d.Wo) {
+              float v = acc[r] * sc + bi;
+              if (relu) v = fminf(fmaxf(v, 0.f), hi);
+              q.out[(orow0 + w) * d.out_cs + d.out_coff + wco] = v;
+            }
+          }
+        }
+      }
     }
   }
 }
@@ -159,9 +319,20 @@ int sf_conv_stem_fwd_try(const sf_conv_desc* d, const float* in, const float* w,
   q.rowf = d->Wi * d->in_cs;
   q.ps = d->sW * d->in_cs;
   if ((long)(d->Wo - 1) * q.ps + 32 > q.rowf || (long)(d->Ho - 1) * d->sH + KH > d->Hi) return 1;
-  q.nblk = (d->Wo + 15) / 16;
+  static const bool nopair = [] {
+    const char* e = getenv("SF_STEM_PAIR");
+    return e && e[0] == '0';
+  }();
+  const bool pair = !nopair && d->Cout <= 8 && q.ps == 8 && d->Cin <= 28;
+  q.nblk = pair ? ((d->Wo + 1) / 2 + 15) / 16 : (d->Wo + 15) / 16;
   if (q.nblk > MAXBLK || KH * q.rowf > 8 * 256 * 4) return 1;
-  const size_t lds = ((size_t)KT * KH * q.rowf + (size_t)4 * q.nblk * 16 * 16) * sizeof(float);
+  const size_t lds6 = (size_t)RING6 * KH * q.rowf * sizeof(float);
+  static const bool dealt = [] {  // SF_STEM_PAIR=1: the pair form with the taps dealt to the wavefronts (A/B)
+    const char* e = getenv("SF_STEM_PAIR");
+    return e && e[0] == '1';
+  }();
+  const bool all_taps = pair && !dealt && lds6 <= 160 * 1024 - 512;
+  const size_t lds = all_taps ? lds6 : ((size_t)KT * KH * q.rowf + (size_t)4 * q.nblk * 16 * 16) * sizeof(float);
   if (lds > 160 * 1024 - 512) return 1;
   int best = 1;
   double best_fill = 0.0;
@@ -174,12 +345,21 @@ int sf_conv_stem_fwd_try(const sf_conv_desc* d, const float* in, const float* w,
   q.units = d->N * d->Ho * best;
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_stem_fwd_kernel),
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_stem_fwd_kernel<false>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(conv_stem_fwd_kernel<true>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(conv_stem_pair_kernel),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512) != hipSuccess)
       return SF_ELAUNCH;
     attr_set = true;
   }
-  hipLaunchKernelGGL(conv_stem_fwd_kernel, dim3(q.units < 256 ? q.units : 256), dim3(256), lds, stream, q);
+  if (all_taps)
+    hipLaunchKernelGGL(conv_stem_pair_kernel, dim3(q.units < 256 ? q.units : 256), dim3(256), lds, stream, q);
+  else if (pair)
+    hipLaunchKernelGGL(conv_stem_fwd_kernel<true>, dim3(q.units < 256 ? q.units : 256), dim3(256), lds, stream, q);
+  else
+    hipLaunchKernelGGL(conv_stem_fwd_kernel<false>, dim3(q.units < 256 ? q.units : 256), dim3(256), lds, stream, q);
   SF_CHECK_LAUNCH();
   return SF_OK;
 }

@@ -44,7 +44,7 @@ struct WaveArgs {
   int nk;              // K steps of 16 = ntaps * cin_pad / 16
   int cpk;             // K steps per tap = cin_pad / 16
   unsigned in_bytes, w_bytes;
-  float* stats;        // != NULL: per (M tile, channel) [count, K, sum(v - K), sum((v - K)^2)] of the stored outputs
+  float* stats;        // != NULL: [part][Cout / 4][count, K, sum(v - K), sum((v - K)^2)][4 channels] of the stored outputs
   // n / d for 0 <= n < 2^31 as (mulhi(n, mul) >> sh); d == 1 has mul == 0 (identity)
   unsigned wo_mul, wo_sh, ho_mul, ho_sh, to_mul, to_sh;
 };
@@ -306,29 +306,56 @@ __global__ __launch_bounds__(256) void conv_wave_kernel(const WaveArgs p) {
         st_1[e] += __shfl_xor(st_1[e], off, 64);
         st_2[e] += __shfl_xor(st_2[e], off, 64);
       }
-    __syncthreads();  // the slabs are free now: [wave][LPR][8] partial sums
+    __syncthreads();  // the slabs are free now: [wave][LPR][16] = K, S1, S2, count
     float* const red = smem;
+    const int left = p.M - m0;
+    const float cnt = live ? (float)(left < p.rows ? left : p.rows) : 0.f;
     if (lane < LPR) {
-      *reinterpret_cast<f32x4*>(red + (wave * LPR + lane) * 8) = st_1;
-      *reinterpret_cast<f32x4*>(red + (wave * LPR + lane) * 8 + 4) = st_2;
+      float* const o = red + (wave * LPR + lane) * 16;
+      const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+      *reinterpret_cast<f32x4*>(o) = st_k;
+      *reinterpret_cast<f32x4*>(o + 4) = live ? st_1 : zero;
+      *reinterpret_cast<f32x4*>(o + 8) = live ? st_2 : zero;
+      o[12] = cnt;
     }
     __syncthreads();
+    // KS > 1: the tile's KS wavefronts hold disjoint rows of ONE tile (same K).  KS == 1 with a single channel tile
+    // (nb_n == 1): the workgroup's 4 wavefronts hold 4 consecutive M tiles of the same channels — they are merged
+    // here (shifted to the first tile's K), which leaves a quarter of the rows for the merge kernel.
+    const bool whole = KS == 1 && p.nb_n == 1;
+    const bool writer = whole ? wave == 0 : ksub == 0;
     const int n = n0 + lane * 4;
-    if (ksub == 0 && lane < LPR && live && n < d.Cout) {
-      f32x4 a1 = *reinterpret_cast<const f32x4*>(red + (wave * LPR + lane) * 8);
-      f32x4 a2 = *reinterpret_cast<const f32x4*>(red + (wave * LPR + lane) * 8 + 4);
+    if (writer && lane < LPR && live && n < d.Cout) {
+      const float* const b = red + (wave * LPR + lane) * 16;
+      const f32x4 k0 = *reinterpret_cast<const f32x4*>(b);
+      f32x4 a1 = *reinterpret_cast<const f32x4*>(b + 4);
+      f32x4 a2 = *reinterpret_cast<const f32x4*>(b + 8);
+      float c = cnt;
+      constexpr int NW = KS == 1 ? 4 : KS;
 #pragma unroll
-      for (int s = 1; s < KS; ++s) {  // the tile's other wavefronts, in wavefront order
-        a1 += *reinterpret_cast<const f32x4*>(red + ((wave + s) * LPR + lane) * 8);
-        a2 += *reinterpret_cast<const f32x4*>(red + ((wave + s) * LPR + lane) * 8 + 4);
+      for (int s = 1; s < NW; ++s) {
+        const float* const q = b + s * LPR * 16;
+        const f32x4 s1 = *reinterpret_cast<const f32x4*>(q + 4);
+        const f32x4 s2 = *reinterpret_cast<const f32x4*>(q + 8);
+        if (KS > 1) {
+          a1 += s1;
+          a2 += s2;
+        } else if (whole) {
+          const float cs = q[12];
+          const f32x4 dk = *reinterpret_cast<const f32x4*>(q) - k0;
+          if (cs > 0.f) {
+            a2 += s2 + 2.f * dk * s1 + cs * dk * dk;
+            a1 += s1 + cs * dk;
+            c += cs;
+          }
+        }
       }
-      const int left = p.M - m0;
-      const float cnt = (float)(left < p.rows ? left : p.rows);
-      float* const o = p.stats + ((long)tile_m * 4) * d.Cout + n;
-      *reinterpret_cast<f32x4*>(o) = (f32x4){cnt, cnt, cnt, cnt};
-      *reinterpret_cast<f32x4*>(o + d.Cout) = st_k;
-      *reinterpret_cast<f32x4*>(o + 2 * d.Cout) = a1;
-      *reinterpret_cast<f32x4*>(o + 3 * d.Cout) = a2;
+      const int part = whole ? (int)blockIdx.x : tile_m;
+      float* const o = p.stats + ((long)part * (d.Cout >> 2) + (n >> 2)) * 16;
+      *reinterpret_cast<f32x4*>(o) = (f32x4){c, c, c, c};
+      *reinterpret_cast<f32x4*>(o + 4) = k0;
+      *reinterpret_cast<f32x4*>(o + 8) = a1;
+      *reinterpret_cast<f32x4*>(o + 12) = a2;
     }
   }
 }
@@ -485,9 +512,10 @@ int sf_conv_wave_try(const sf_conv_desc* d, const float* in, const float* w_pack
   a.nwg = sf_cdiv(a.ntiles, 4 / c.ks);
   // statistics of the stored outputs: only for the plain epilogue (raw conv output + bias), dense stores
   const bool scatter = d->os_T > 1 || d->os_H > 1 || d->os_W > 1;
-  a.stats = (stats && stat_parts && !scale && !res && d->act == SF_ACT_NONE && !scatter && sf_aligned16(stats))
+  a.stats = (stats && stat_parts && !scale && !res && d->act == SF_ACT_NONE && !scatter && sf_aligned16(stats) &&
+             d->Cout % 4 == 0)
                 ? stats : nullptr;
-  if (a.stats) *stat_parts = sf_cdiv(M, a.rows);
+  if (a.stats) *stat_parts = (c.ks == 1 && a.nb_n == 1) ? a.nwg : sf_cdiv(M, a.rows);
   switch (best) {
     case 0: return launch_wave<13, 2, 4>(a, kv, stream);
     case 1: return launch_wave<13, 2, 1>(a, kv, stream);

@@ -394,6 +394,7 @@ struct StemArgs {
   int nblk;      // 16-position blocks per output row
   int tparts;    // the t range of a (clip, row) is cut into this many units
   int units;     // N * Ho * tparts
+  int pair;      // 1: conv_wgrad_stem_pair_kernel (nblk = K steps of 4 position pairs)
 };
 
 __global__ __launch_bounds__(256) void conv_wgrad_stem_kernel(const StemArgs q) {
@@ -524,6 +525,166 @@ __global__ __launch_bounds__(256) void conv_wgrad_stem_kernel(const StemArgs q) 
   }
 }
 
+// PAIR form of the stem weight gradient (Cout <= 8, pixel stride 8 floats — the Fast stem itself).  Cout = 8 fills
+// half of the 16 MFMA columns, so a K step is a PAIR of neighbouring output positions and the columns are (h, co) =
+// position 2p + h, channel co (conv_stem.hip has the forward of the same idea).  A pair reads ONE window of 28 + 8 =
+// 36 floats per tap; the 35 x 36 = 1260 window rows are packed densely into 79 tiles of 16 (a tile may straddle two
+// taps: every lane carries its own row address) instead of 35 x 2 tiles per SINGLE position:
+//   D[R = (tap, j')][(h, co)] = sum_pairs x[ring row(tap)][16 pair + j'] * dz[2 pair + h][co]
+//   dW[co][tap][j] = D[(tap, j)][(0, co)] + D[(tap, j + 8)][(1, co)]          (position h sees the window shifted by 8)
+// 79 x 14 MFMAs per step of t instead of 70 x 28; the A fragments of the next K step are read from LDS while this
+// step's MFMAs run.  The two halves are added when the workgroup writes its partial (through LDS, the ring is free).
+constexpr int STEM_WIN = 36;
+constexpr int STEM_ROWS = STEM_KT * STEM_KH * STEM_WIN;   // 1260
+constexpr int STEM_MT = (STEM_ROWS + 15) / 16;            // 79
+constexpr int STEM_NI2 = (STEM_MT + 3) / 4;               // 20 accumulator tiles per wavefront
+
+__global__ __launch_bounds__(256) void conv_wgrad_stem_pair_kernel(const StemArgs q) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const WgradArgs& p = q.w;
+  const sf_conv_desc& d = p.d;
+  const int slab = STEM_KH * q.rowf;
+  float* const ring = lds;                        // [STEM_KT][slab]
+  float* const dzs = lds + STEM_KT * slab;        // [nk * 4 pairs][2 positions][STEM_CO]; rows >= Wo hold zeros
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int fr = lane & 15, fg = lane >> 4;
+  const int slab4 = slab >> 2;
+  constexpr int LD4 = 8;
+  const int npair = (d.Wo + 1) >> 1, nk = q.nblk;  // nblk = K steps of 4 pairs
+
+  f32x4 acc[STEM_NI2];
+#pragma unroll
+  for (int i = 0; i < STEM_NI2; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  // tile mt = wave + 4 i, this lane's window row R = 16 mt + fr -> (tap, j'); rows past 1260 repeat the last one
+  int r_kt[STEM_NI2], r_off[STEM_NI2];
+#pragma unroll
+  for (int i = 0; i < STEM_NI2; ++i) {
+    const int R = min(16 * (wave + 4 * i) + fr, STEM_ROWS - 1);
+    const int tap = R / STEM_WIN, jw = R - tap * STEM_WIN;
+    r_kt[i] = tap / STEM_KH;
+    r_off[i] = (tap % STEM_KH) * q.rowf + jw;
+  }
+
+  f32x4 rs[LD4];
+  float rz[4];
+  auto load_slab = [&](int n, int ti, int h) {
+    const bool ok = (unsigned)ti < (unsigned)d.Ti;
+    const f32x4* src = reinterpret_cast<const f32x4*>(p.x + (((long)n * d.Ti + (ok ? ti : 0)) * d.Hi + (long)h * d.sH) * q.rowf);
+#pragma unroll
+    for (int u = 0; u < LD4; ++u) {
+      const int f = tid + u * 256;
+      rs[u] = (ok && f < slab4) ? src[f] : (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+  };
+  auto store_slab = [&](int slot) {
+    f32x4* dst = reinterpret_cast<f32x4*>(ring + slot * slab);
+#pragma unroll
+    for (int u = 0; u < LD4; ++u) {
+      const int f = tid + u * 256;
+      if (f < slab4) dst[f] = rs[u];
+    }
+  };
+  auto load_dz = [&](int n, int t, int h) {
+    const long m0 = (((long)n * d.To + t) * d.Ho + h) * d.Wo;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int e = tid + u * 256, w = e >> 3, co = e & 7;
+      rz[u] = (w < d.Wo && co < d.Cout) ? p.dz[(m0 + w) * p.dz_cs + p.dz_coff + co] : 0.f;
+    }
+  };
+  auto store_dz = [&]() {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int e = tid + u * 256;
+      if (e < nk * 64) dzs[e] = rz[u];
+    }
+  };
+
+  for (int unit = blockIdx.x; unit < q.units; unit += gridDim.x) {
+    const int tz = unit % q.tparts;
+    const int nh = unit / q.tparts;
+    const int h = nh % d.Ho, n = nh / d.Ho;
+    const int tper = (d.To + q.tparts - 1) / q.tparts;
+    const int t0 = tz * tper, t1 = min(d.To, t0 + tper);
+    if (t0 >= t1) continue;
+    __syncthreads();
+    for (int kt = 0; kt < STEM_KT - 1; ++kt) {
+      const int ti = t0 - d.pT + kt;
+      load_slab(n, ti, h);
+      store_slab(((ti % STEM_KT) + STEM_KT) % STEM_KT);
+    }
+    load_slab(n, t0 - d.pT + STEM_KT - 1, h);
+    load_dz(n, t0, h);
+    for (int t = t0; t < t1; ++t) {
+      const int tnew = t - d.pT + STEM_KT - 1;
+      store_slab(((tnew % STEM_KT) + STEM_KT) % STEM_KT);
+      store_dz();
+      __syncthreads();
+      if (t + 1 < t1) {
+        load_slab(n, tnew + 1, h);
+        load_dz(n, t + 1, h);
+      }
+      const int b5 = (((t - d.pT) % STEM_KT) + STEM_KT) % STEM_KT;  // ring slot of kt = 0
+      int addr[STEM_NI2];
+#pragma unroll
+      for (int i = 0; i < STEM_NI2; ++i) {
+        int sl = b5 + r_kt[i];
+        sl = sl >= STEM_KT ? sl - STEM_KT : sl;
+        addr[i] = sl * slab + r_off[i];
+      }
+      // K step ks: lane quarter fg holds pair 4 ks + fg (A: the pair's window float, B: its two dz rows)
+      float a_cur[STEM_NI2], b_cur;
+      {
+        const int po = min(fg, npair - 1) * 16;
+#pragma unroll
+        for (int i = 0; i < STEM_NI2; ++i) a_cur[i] = ring[addr[i] + po];
+        b_cur = dzs[fg * 16 + fr];
+      }
+      for (int ks = 0; ks < nk; ++ks) {
+        float a_nxt[STEM_NI2], b_nxt;
+        {
+          const int pn = 4 * (ks + 1) + fg;                       // past the last step: re-reads in-range data, unused
+          const int po = min(pn, npair - 1) * 16;
+#pragma unroll
+          for (int i = 0; i < STEM_NI2; ++i) a_nxt[i] = ring[addr[i] + po];
+          b_nxt = dzs[min(pn, 4 * nk - 1) * 16 + fr];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < STEM_NI2; ++i) {
+          if (wave + 4 * i >= STEM_MT) break;  // wave-uniform: the last tile slot of wavefront 3
+          acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[i], b_cur, acc[i], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < STEM_NI2; ++i) a_cur[i] = a_nxt[i];
+        b_cur = b_nxt;
+      }
+      __syncthreads();  // everyone is done with the oldest slab and the dz rows before they are overwritten
+    }
+  }
+  // ---- this workgroup's partial: D through LDS (the ring is free), the two position halves added on the way out
+  __syncthreads();
+  float* const Dl = lds;  // [STEM_MT * 16][16]
+#pragma unroll
+  for (int i = 0; i < STEM_NI2; ++i) {
+    const int mt = wave + 4 * i;
+    if (mt >= STEM_MT) break;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Dl[(16 * mt + 4 * fg + r) * 16 + fr] = acc[i][r];
+  }
+  __syncthreads();
+  float* const out = p.part + (long)blockIdx.x * d.Cout * p.ntaps * d.cin_pad;
+  const int per_co = p.ntaps * d.cin_pad;
+  for (int e = tid; e < d.Cout * per_co; e += 256) {
+    const int co = e / per_co, rem = e - co * per_co;
+    const int tap = rem / d.cin_pad, j = rem - tap * d.cin_pad;
+    float v = 0.f;
+    if (j < d.Cin) v = Dl[(tap * STEM_WIN + j) * 16 + co] + Dl[(tap * STEM_WIN + j + q.ps) * 16 + 8 + co];
+    out[e] = v;
+  }
+}
+
 // Does this problem take the stem kernel, and with how many workgroups (= partials)?
 static bool stem_plan(const sf_conv_desc* d, int dz_cs, StemArgs* q) {
   static const bool off = [] { const char* e = getenv("SF_WGRAD_STEM"); return e && e[0] == '0'; }();
@@ -539,8 +700,13 @@ static bool stem_plan(const sf_conv_desc* d, int dz_cs, StemArgs* q) {
   if (nblk * 16 * STEM_CO > 1024 || STEM_KH * rowf > 8 * 256 * 4) return false; // staging capacity per thread
   const long lds = ((long)STEM_KT * STEM_KH * rowf + (long)nblk * 16 * STEM_CO) * 4;
   if (lds > 160 * 1024 - 512) return false;
+  static const bool nopair = [] { const char* e = getenv("SF_STEM_PAIR"); return e && e[0] == '0'; }();
+  // pair form: the window of the last pair (28 + 8 floats from its first position) stays inside the staged slab
+  const int nk = ((d->Wo + 1) / 2 + 3) / 4;
+  const bool pair = !nopair && ps == 8 && d->Cin <= 28 && d->Cout <= STEM_CO && nk * 64 <= 1024;
   if (q) {
-    q->rowf = rowf; q->ps = ps; q->nblk = nblk;
+    q->rowf = rowf; q->ps = ps; q->nblk = pair ? nk : nblk;
+    q->pair = pair ? 1 : 0;
     // units: (clip, output row) x t parts; cut t so that the units deal evenly onto 256 workgroups
     int best = 1;
     double best_fill = 0.0;
@@ -725,15 +891,22 @@ extern "C" int sf_conv_wgrad(const sf_conv_desc* d, const float* x, const float*
   StemArgs sq;
   if (sf_aligned16(x) && stem_plan(d, dz_cs, &sq)) {
     sq.w = a;
-    const size_t lds = ((size_t)STEM_KT * STEM_KH * sq.rowf + (size_t)sq.nblk * 16 * STEM_CO) * sizeof(float);
+    size_t lds = ((size_t)STEM_KT * STEM_KH * sq.rowf + (size_t)sq.nblk * (sq.pair ? 64 : 16 * STEM_CO)) * sizeof(float);
+    if (sq.pair && lds < (size_t)STEM_MT * 16 * 16 * sizeof(float)) lds = (size_t)STEM_MT * 16 * 16 * sizeof(float);
     static bool attr_set = false;  // raise the dynamic-LDS cap once (129 KB of the CU's 160 KB)
     if (!attr_set) {
       if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_stem_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512) != hipSuccess ||
+          hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_stem_pair_kernel),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512) != hipSuccess)
         return SF_ELAUNCH;
       attr_set = true;
     }
-    hipLaunchKernelGGL(conv_wgrad_stem_kernel, dim3(stem_workgroups(sq)), dim3(256), lds, (hipStream_t)stream, sq);
+    if (sq.pair)
+      hipLaunchKernelGGL(conv_wgrad_stem_pair_kernel, dim3(stem_workgroups(sq)), dim3(256), lds, (hipStream_t)stream,
+                         sq);
+    else
+      hipLaunchKernelGGL(conv_wgrad_stem_kernel, dim3(stem_workgroups(sq)), dim3(256), lds, (hipStream_t)stream, sq);
     SF_CHECK_LAUNCH();
     return SF_OK;
   }

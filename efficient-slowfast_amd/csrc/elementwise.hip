@@ -366,7 +366,23 @@ __global__ void stats_partial_kernel(const float* __restrict__ x, int cs, int co
   if (c < C) {
 #pragma unroll
     for (int e = 0; e < VEC; ++e) k[e] = x[krow * cs + coff + c + e];
-    for (long r = r0 + rl; r < r1; r += rpi) {
+    long r = r0 + rl;
+    if constexpr (VEC == 4) {  // four rows per trip, all four loads issued before the first use
+      for (; r + 3 * (long)rpi < r1; r += 4 * (long)rpi) {
+        f32x4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const f32x4*>(x + (r + (long)u * rpi) * cs + coff + c);
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float d = v[u][e] - k[e];
+            s1[e] += d;
+            s2[e] = fmaf(d, d, s2[e]);
+          }
+      }
+    }
+    for (; r < r1; r += rpi) {
       if (VEC == 4) {
         const f32x4 v = *reinterpret_cast<const f32x4*>(x + r * cs + coff + c);
 #pragma unroll
@@ -810,65 +826,84 @@ static int stats_launch(const float* x, int cs, int coff, int groups, long group
   return SF_OK;
 }
 
-// Merge of the per-tile rows [count, K, S1 = sum(v - K), S2 = sum((v - K)^2)] a conv epilogue left per channel
-// (conv_wave.hip) — Chan's parallel mean / M2 update in fp64, one 64-lane block per channel, fixed order.
+// Merge of the per-part statistics a conv epilogue left (conv_wave.hip): [part][C / 4][count, K, S1 = sum(v - K),
+// S2 = sum((v - K)^2)][4 channels], 64 contiguous bytes per (part, channel quad).  One workgroup per channel quad, one
+// pass: every part is shifted to the reference R = K of part 0 (a sample of the channel, so |mean - R| is a few
+// standard deviations at most and E[(v-R)^2] - E[v-R]^2 loses nothing in fp64):
+//   S1' = S1 + n (K - R),  S2' = S2 + 2 (K - R) S1 + n (K - R)^2.
+// Lanes stride over the parts with 4 rows of loads in flight; lanes, then wavefronts, are combined in a fixed order.
 __global__ void stats_merge_kernel(const float* __restrict__ parts, int P, int C, const StatsFinal f) {
-  __shared__ double r1[64], r2[64];
-  const int c = blockIdx.x;
-  double n = 0.0, t = 0.0;
-  for (int i = threadIdx.x; i < P; i += 64) {
-    const float* q = parts + (long)i * 4 * C + c;
-    const double ni = (double)q[0];
+  __shared__ double red[16][9];
+  const int quad = blockIdx.x, nq = C >> 2;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwave = blockDim.x >> 6;
+  const f32x4 R = *reinterpret_cast<const f32x4*>(parts + (long)quad * 16 + 4);
+  double n = 0.0, s1[4] = {0.0, 0.0, 0.0, 0.0}, s2[4] = {0.0, 0.0, 0.0, 0.0};
+  auto add = [&](const f32x4& cnt, const f32x4& k, const f32x4& a1, const f32x4& a2) {
+    const double ni = (double)cnt[0];
     n += ni;
-    t += ni * (double)q[C] + (double)q[2 * C];
-  }
-  r1[threadIdx.x] = n;
-  r2[threadIdx.x] = t;
-  __syncthreads();
-  for (int s = 32; s > 0; s >>= 1) {
-    if (threadIdx.x < s) {
-      r1[threadIdx.x] += r1[threadIdx.x + s];
-      r2[threadIdx.x] += r2[threadIdx.x + s];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const double dk = (double)k[e] - (double)R[e], t1 = (double)a1[e];
+      s1[e] += t1 + ni * dk;
+      s2[e] += (double)a2[e] + dk * (2.0 * t1 + ni * dk);
     }
-    __syncthreads();
+  };
+  const int step = blockDim.x;
+  int i = tid;
+  for (; i + 3 * step < P; i += 4 * step) {
+    f32x4 v[4][4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const float* q = parts + ((long)(i + u * step) * nq + quad) * 16;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) v[u][w] = *reinterpret_cast<const f32x4*>(q + 4 * w);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) add(v[u][0], v[u][1], v[u][2], v[u][3]);
   }
-  const double N = r1[0], mean = r2[0] / r1[0];
+  for (; i < P; i += step) {
+    const float* q = parts + ((long)i * nq + quad) * 16;
+    add(*reinterpret_cast<const f32x4*>(q), *reinterpret_cast<const f32x4*>(q + 4),
+        *reinterpret_cast<const f32x4*>(q + 8), *reinterpret_cast<const f32x4*>(q + 12));
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    n += __shfl_xor(n, off, 64);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      s1[e] += __shfl_xor(s1[e], off, 64);
+      s2[e] += __shfl_xor(s2[e], off, 64);
+    }
+  }
+  if (lane == 0) {
+    red[wave][0] = n;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { red[wave][1 + e] = s1[e]; red[wave][5 + e] = s2[e]; }
+  }
   __syncthreads();
-  double m2 = 0.0;
-  for (int i = threadIdx.x; i < P; i += 64) {
-    const float* q = parts + (long)i * 4 * C + c;
-    const double ni = (double)q[0], s1 = (double)q[2 * C], s2 = (double)q[3 * C];
-    const double dm = (double)q[C] + s1 / ni - mean;
-    m2 += (s2 - s1 * s1 / ni) + ni * dm * dm;
-  }
-  r1[threadIdx.x] = m2;
-  __syncthreads();
-  for (int s = 32; s > 0; s >>= 1) {
-    if (threadIdx.x < s) r1[threadIdx.x] += r1[threadIdx.x + s];
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) {
-    double v = r1[0] / N;
-    if (v < 0.0) v = 0.0;
+  if (tid < 4) {
+    double N = 0.0, t1 = 0.0, t2 = 0.0;
+    for (int w = 0; w < nwave; ++w) { N += red[w][0]; t1 += red[w][1 + tid]; t2 += red[w][5 + tid]; }
     StatsFinal g = f;
+    g.inv_rows = 1.0 / N;
     g.unbias = N > 1.0 ? N / (N - 1.0) : 1.0;
-    // stats_finish takes sums of (x - K) with one K: hand it the merged moments with K = 0
-    g.inv_rows = 1.0;
-    stats_finish(g, c, mean, v + mean * mean, 0.f);
+    stats_finish(g, quad * 4 + tid, t1, t2, R[tid]);
   }
 }
 
 extern "C" int sf_bn_train_stats_merge(const float* parts, int P, int C, const float* gamma, const float* beta, float eps,
                                        float momentum, float* run_mean, float* run_var, float* mean, float* var,
                                        float* invstd, float* scale, float* shift, void* stream) {
-  if (!parts || P <= 0 || C <= 0 || !gamma || !beta || !mean || !var || !invstd || !scale || !shift) return SF_EINVAL;
-  if ((run_mean == nullptr) != (run_var == nullptr)) return SF_EINVAL;
+  if (!parts || P <= 0 || C <= 0 || (C % 4) != 0 || !gamma || !beta || !mean || !var || !invstd || !scale || !shift)
+    return SF_EINVAL;
+  if ((run_mean == nullptr) != (run_var == nullptr) || !sf_aligned16(parts)) return SF_EINVAL;
   StatsFinal fin;
   fin.inv_rows = 1.0; fin.unbias = 1.0;
   fin.mean = mean; fin.var = var; fin.gamma = gamma; fin.beta = beta; fin.eps = eps; fin.momentum = momentum;
   fin.run_mean = run_mean; fin.run_var = run_var; fin.invstd = invstd; fin.scale = scale; fin.shift = shift;
   fin.tickets = nullptr;
-  hipLaunchKernelGGL(stats_merge_kernel, dim3(C), dim3(64), 0, (hipStream_t)stream, parts, P, C, fin);
+  hipLaunchKernelGGL(stats_merge_kernel, dim3(C / 4), dim3(P > 1024 ? 1024 : 256), 0, (hipStream_t)stream, parts, P, C,
+                     fin);
   SF_CHECK_LAUNCH();
   return SF_OK;
 }

@@ -83,8 +83,8 @@ int sf_conv_fwd_ws(const sf_conv_desc* d, const float* in, const float* w_packed
                    const float* bias, const float* res, float* out, float* ws, void* stream);
 /* Training-mode BN statistics out of the conv's epilogue (Conv3d -> BatchNorm3d of stem_helper.py:239-254,
  * resnet_helper.py:150-215 in train mode): the per-wavefront conv kernels keep shifted sums of the outputs they store
- * and leave ONE row [count, K, sum(v - K), sum((v - K)^2)] per (M tile, channel) in stats_ws
- * [parts][4][Cout]; sf_bn_train_stats_merge below turns those into what sf_bn_train_stats returns without a pass over
+ * and leave [count, K, sum(v - K), sum((v - K)^2)] x 4 channels per (part, channel quad) in stats_ws
+ * [parts][Cout / 4][4][4] (a part = one M tile, or the 4 M tiles of a workgroup); sf_bn_train_stats_merge below turns those into what sf_bn_train_stats returns without a pass over
  * the activation.  sf_conv_stats_ws_floats(d) = floats of stats_ws (0: this shape never produces statistics).
  * sf_conv_fwd_stats sets *parts to the rows written, or to 0 when none were (epilogue with scale / res / act, or the
  * LDS-tiled kernels took the launch): the caller then runs sf_bn_train_stats on the output.                      */
@@ -191,8 +191,8 @@ int sf_channel_stats(const float* x, int cs, int coff, long rows, int C, float* 
 int sf_bn_train_stats(const float* x, int cs, int coff, long rows, int C, const float* gamma, const float* beta,
                       float eps, float momentum, float* run_mean, float* run_var, float* mean, float* var,
                       float* invstd, float* scale, float* shift, float* ws, void* stream);
-/* The same outputs from the per-tile rows of sf_conv_fwd_stats (Chan's parallel mean / M2 merge in fp64, fixed
- * order); parts rows of [count, K, S1, S2] x C.                                                              */
+/* The same outputs from the per-part sums of sf_conv_fwd_stats (every part shifted to one reference, summed in fp64
+ * in a fixed order); C must be a multiple of 4.                                                              */
 int sf_bn_train_stats_merge(const float* parts_ws, int parts, int C, const float* gamma, const float* beta, float eps,
                             float momentum, float* run_mean, float* run_var, float* mean, float* var, float* invstd,
                             float* scale, float* shift, void* stream);
