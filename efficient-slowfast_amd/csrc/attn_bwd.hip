@@ -482,8 +482,11 @@ __global__ __launch_bounds__(64 * NW, (CP >= 64) ? 2 : 1) void attn_bwd_fused_ke
     }
   };
 
-  float* const plane = ws + ((long)b * p.nt + kb) * N * CP;  // this key block's dQ plane [N][CP]
-  const int tz = ((N + QT - 1) / QT + p.zs - 1) / p.zs;  // query tiles per part
+  // dQ partials, query-tile major: [b][query tile][key block][QT][CP] — the key blocks' partials of one query tile
+  // sit in ONE contiguous run of nt * 8 KB, which is what attn_dq_reduce_tiled_kernel sums (plane-major, the 196
+  // addends of an output were 3 MB apart: a TLB miss and a DRAM page per 16-byte load)
+  const int nq = (N + QT - 1) / QT;
+  const int tz = (nq + p.zs - 1) / p.zs;  // query tiles per part
   const int t0 = z * tz;
   const int ntiles = min((N + QT - 1) / QT, t0 + tz);
   load_tile(t0 * QT);
@@ -569,8 +572,7 @@ __global__ __launch_bounds__(64 * NW, (CP >= 64) ? 2 : 1) void attn_bwd_fused_ke
       f32x4 v = *reinterpret_cast<const f32x4*>(slots + e0);
 #pragma unroll
       for (int w = 1; w < NW; ++w) v += *reinterpret_cast<const f32x4*>(slots + w * SLOT + e0);
-      const int qi = t * QT + e0 / CP;
-      if (qi < N) *reinterpret_cast<f32x4*>(plane + (long)qi * CP + (e0 % CP)) = v;
+      *reinterpret_cast<f32x4*>(ws + ((((long)b * nq + t) * p.nt + kb) * (long)SLOT) + e0) = v;  // rows >= N: never read
     }
     __syncthreads();  // slots are reused as transposition tiles by the next iteration
   }
@@ -613,7 +615,47 @@ __global__ void attn_dq_reduce_kernel(const float* __restrict__ ws, float* __res
   const long b = row / N, i = row - b * N;
   const float* src = ws + ((b * nkb) * N + i) * CP + c;
   f32x4 v = {0.f, 0.f, 0.f, 0.f};
-  for (int k = 0; k < nkb; ++k) v += *reinterpret_cast<const f32x4*>(src + (long)k * N * CP);
+  // eight planes per trip, every load issued before the first add (the planes are 3 MB apart: one 16-byte load in
+  // flight per thread leaves HBM at a third of its rate); the sum stays in plane order
+  const long ps = (long)N * CP;
+  int k = 0;
+  for (; k + 8 <= nkb; k += 8) {
+    f32x4 t[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) t[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src + (k + u) * ps));
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v += t[u];
+  }
+  for (; k < nkb; ++k) v += *reinterpret_cast<const f32x4*>(src + k * ps);
+  float* o = dq + row * dq_cs + c;
+#pragma unroll
+  for (int e = 0; e < 4; ++e)
+    if (c + e < C) o[e] = v[e];
+}
+
+// The same sum over the query-tile-major partials of attn_bwd_fused_kernel: [B][nq][nkb][QT][CP].
+__global__ void attn_dq_reduce_tiled_kernel(const float* __restrict__ ws, float* __restrict__ dq, int dq_cs, int B,
+                                            int N, int C, int CP, int nkb, int QT) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;  // float4 index over [B][N][CP/4]
+  const long total = (long)B * N * (CP / 4);
+  if (idx >= total) return;
+  const int c = (int)(idx % (CP / 4)) * 4;
+  const long row = idx / (CP / 4);  // b*N + i
+  const long b = row / N, i = row - b * N;
+  const int nq = (N + QT - 1) / QT;
+  const long it = i / QT, ir = i - it * QT;
+  const long ps = (long)QT * CP;
+  const float* src = ws + ((b * nq + it) * nkb) * ps + ir * CP + c;
+  f32x4 v = {0.f, 0.f, 0.f, 0.f};
+  int k = 0;
+  for (; k + 8 <= nkb; k += 8) {
+    f32x4 t[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) t[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src + (k + u) * ps));
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v += t[u];
+  }
+  for (; k < nkb; ++k) v += *reinterpret_cast<const f32x4*>(src + k * ps);
   float* o = dq + row * dq_cs + c;
 #pragma unroll
   for (int e = 0; e < 4; ++e)
@@ -660,7 +702,7 @@ int launch_fused(BwdArgs a, float* ws, hipStream_t s) {
   a.nt = sf_cdiv(a.N, 32 * NW);  // key blocks (= dQ planes) per clip
   const int qt = (CP >= 64) ? 32 : 64;
   a.zs = sf_sweep_parts((long)a.B * a.nt, sf_cdiv(a.N, qt));
-  const long planes = (long)a.B * a.nt * a.N * CP, part = (long)a.B * a.zs * a.N * CP;
+  const long planes = (long)a.B * a.nt * sf_cdiv(a.N, qt) * qt * CP, part = (long)a.B * a.zs * a.N * CP;
   a.dkp = ws + planes;
   a.dvp = a.dkp + part;
   hipLaunchKernelGGL((attn_bwd_fused_kernel<CP, NW>), dim3(a.B * a.zs * a.nt), dim3(64 * NW), 0, s, a, ws);
@@ -670,7 +712,11 @@ int launch_fused(BwdArgs a, float* ws, hipStream_t s) {
     if (rc == SF_OK) rc = sf_attn_dq_reduce(a.dvp, a.dv, a.dv_cs, a.B, a.N, a.C, CP, a.zs, s);
     if (rc != SF_OK) return rc;
   }
-  return sf_attn_dq_reduce(ws, a.dq, a.dq_cs, a.B, a.N, a.C, CP, a.nt, s);
+  const long total = (long)a.B * a.N * (CP / 4);
+  hipLaunchKernelGGL(attn_dq_reduce_tiled_kernel, dim3(sf_cdiv(total, 256)), dim3(256), 0, s, ws, a.dq, a.dq_cs, a.B,
+                     a.N, a.C, CP, a.nt, qt);
+  SF_CHECK_LAUNCH();
+  return SF_OK;
 }
 
 template <int CP>
@@ -730,7 +776,8 @@ extern "C" long sf_attn_bwd_fused_ws_floats(int B, int N, int C) {
   }
   const int cp = C <= 4 ? 4 : (C <= 8 ? 8 : (C <= 16 ? 16 : (C <= 32 ? 32 : 64)));
   const int keys = C <= 16 ? 64 : (C <= 32 ? FUSED_KEYS_32 : 128);
-  return (long)B * (sf_cdiv(N, keys) + 2 * SF_SWEEP_PARTS_MAX) * N * cp;
+  const long nr = (long)sf_cdiv(N, 64) * 64;  // the dQ partials are stored per (whole) query tile of 32 / 64 rows
+  return (long)B * (sf_cdiv(N, keys) * nr + 2L * SF_SWEEP_PARTS_MAX * N) * cp;
 }
 
 extern "C" int sf_attn_bwd_fused(const float* q, int q_cs, const float* k, int k_cs, const float* v, int v_cs,

@@ -780,7 +780,16 @@ __global__ __launch_bounds__(256) void wgrad_finish_kernel(const float* __restri
     float v = 0.f;
     if (c0 + c < cin_pad) {
       const float* src = part + ((long)co * ptaps + tap) * cin_pad + c0 + c;
-      for (int s = q; s < S; s += 256 / FIN_C) v += src[s * stride];
+      int s = q;
+      for (; s + 12 < S; s += 16) {  // four of this group's splits per trip, loads issued before the adds
+        const float t0 = src[s * stride], t1 = src[(s + 4) * stride], t2 = src[(s + 8) * stride],
+                    t3 = src[(s + 12) * stride];
+        v += t0;
+        v += t1;
+        v += t2;
+        v += t3;
+      }
+      for (; s < S; s += 256 / FIN_C) v += src[s * stride];
     }
     red[q * FIN_C + c] = v;
     __syncthreads();

@@ -79,3 +79,34 @@ sl = defaultdict(float)
 for g in gaps:
     sl[int(g[3] // 5)] += g[0]
 print("idle per 5 ms slice:", " ".join("%d:%.1f" % (k * 5, v / 1e6) for k, v in sorted(sl.items())))
+
+# ---- time with NO MFMA-bound kernel in flight (convolutions, attention sweeps): what runs then is what the two-stream
+#      schedule fails to hide behind the matrix pipes
+MFMA_KEYS = ("conv_wave", "conv_wgrad", "conv_stem", "conv_igemm", "conv_kernel", "attn_fwd_kernel", "attn_bwd",
+             "attn_small", "attn_lane")
+
+
+def is_mfma(name):
+    return any(k in name for k in MFMA_KEYS) and "finish" not in name and "reduce" not in name and "merge" not in name
+
+
+active = defaultdict(int)
+prev = t0
+no_mfma = defaultdict(float)
+no_mfma_total = 0.0
+for ts, d, name in points:
+    dt = ts - prev
+    if dt > 0:
+        live = [n for n, c in active.items() if c > 0]
+        if not any(is_mfma(n) for n in live):
+            no_mfma_total += dt
+            if live:
+                for n in live:
+                    no_mfma[n] += dt / len(live)
+            else:
+                no_mfma["(idle)"] += dt
+    active[name] += d
+    prev = ts
+print("no MFMA-bound kernel in flight: %.2f ms of %.2f; by what runs then:" % (no_mfma_total / 1e6, span))
+for n, v in sorted(no_mfma.items(), key=lambda kv: -kv[1])[:22]:
+    print("  %-44s %7.2f ms" % (n, v / 1e6))
