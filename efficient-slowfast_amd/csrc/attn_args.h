@@ -16,6 +16,7 @@ struct SfAttnArgs {
   int zs;
   float* part_o;   // [B][zs][N][CP]
   float* part_ml;  // [B][zs][N][2]   (m, l)
+  float soft_t;    // attn_fwd_kernel: log2 headroom of the stale softmax reference (set by its launcher)
 };
 
 // Combine the zs key parts of every query row and run the attention epilogue (attn_flash.hip).

@@ -32,8 +32,18 @@ using AttnArgs = SfAttnArgs;
 
 constexpr float NEG_BIG = -3.0e38f;
 constexpr float LOG2E = 1.4426950408889634f;
+constexpr float SOFT_T = 64.f;  // a tile may exceed the stale reference maximum by 2^64 before it is refreshed (default)
 
-template <int CP, int VEC>
+// v_pk_add_f32: two fp32 adds in one vector-ALU pass (the compiler's SLP vectoriser leaves most of them scalar).
+// The s_nop covers the wait state a vector instruction needs after a transcendental one (v_exp_f32) wrote its
+// source: the compiler tracks that hazard for its own instructions, not for inline assembly.
+__device__ __forceinline__ f32x2 pk_add(f32x2 a, f32x2 b) {
+  f32x2 d;
+  asm("s_nop 0\n\tv_pk_add_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+  return d;
+}
+
+template <int CP, int VEC, bool STALE>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
   constexpr int KT = (CP >= 128) ? 32 : 64;   // keys per LDS tile
   constexpr int NSUB = KT / 32;
@@ -85,8 +95,11 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
   for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
     for (int r = 0; r < 16; ++r) o[ct][r] = 0.f;
-  float m_run = NEG_BIG;
-  float l_run = 0.f;
+  float m_run = NEG_BIG;            // the reference maximum m_ref of this lane's query (see the S^T tile below)
+  f32x2 lacc = {0.f, 0.f};          // packed partial row sums of 2^(s - m_ref)
+  f32x16 negm;                      // -m_ref on all 16 registers: the C operand of a tile's first MFMA
+#pragma unroll
+  for (int r = 0; r < 16; ++r) negm[r] = -NEG_BIG;
 
   f32x4 rk[NF], rv[NF];
   auto load_tile = [&](int j0) {
@@ -145,11 +158,81 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
     for (int sub = 0; sub < NSUB; ++sub) {
       const int jbase = t * KT + sub * 32;
       if (jbase >= N) break;  // wave-uniform
-      // ---- S^T tile: rows = keys (registers), cols = queries (lanes)
       f32x16 s;
+      const float* krow;
+      const bool ragged = jbase + 32 > N;  // wave-uniform
+      if constexpr (STALE) {
+      // ---- S^T tile: rows = keys (registers), cols = queries (lanes).  fp32 MFMAs run on the SIMD's vector ALUs —
+      // a v_sub / v_add issued beside them is NOT hidden (tools/microbench/mfma_coexec.hip: +4.5 cycles each, v_exp
+      // +7.5) — so the softmax keeps its vector work minimal: the tile is accumulated ON TOP of -m_ref (the first
+      // MFMA's C operand is a register block holding -m_ref of this lane's query), with m_ref a STALE running
+      // maximum that is only refreshed when a tile exceeds it by more than 2^SOFT_T (then S is recomputed from 0 and
+      // O, l are rescaled — the classic online-softmax step, taken a handful of times per sweep): no subtraction,
+      // no per-tile rescale factor, and the row sums are kept as packed partial sums.
+      krow = Ks + (buf * KT + sub * 32 + li) * KS + lh * 4;
+      s = negm;
+#pragma unroll
+      for (int g = 0; g < QS; ++g) {
+        const f32x4 kf = *reinterpret_cast<const f32x4*>(krow + g * 8);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[e], qf[g * 4 + e], s, 0, 0, 0);
+      }
+      if (ragged) {                        // mask keys >= N
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int j = jbase + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          if (j >= N) s[r] = NEG_BIG;
+        }
+      }
+      float mx = fmaxf(fmaxf(s[0], s[1]), s[2]);
+#pragma unroll
+      for (int r = 3; r < 15; r += 2) mx = fmaxf(fmaxf(mx, s[r]), s[r + 1]);
+      mx = fmaxf(mx, s[15]);
+      if (__any(mx > p.soft_t)) {  // refresh the reference (always on the first tile: -m_ref = +BIG there)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+        for (int g = 0; g < QS; ++g) {
+          const f32x4 kf = *reinterpret_cast<const f32x4*>(krow + g * 8);
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[e], qf[g * 4 + e], s, 0, 0, 0);
+        }
+        if (ragged) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int j = jbase + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            if (j >= N) s[r] = NEG_BIG;
+          }
+        }
+        float mloc = s[0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) mloc = fmaxf(mloc, s[r]);
+        mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+        const float mnew = fmaxf(m_run, mloc);
+        const float alpha = __builtin_amdgcn_exp2f(m_run - mnew);  // 0 on the first tile
+        lacc *= alpha;
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) o[ct][r] *= alpha;
+        m_run = mnew;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          negm[r] = -mnew;
+          s[r] -= mnew;
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[r] = __builtin_amdgcn_exp2f(s[r]);
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) lacc = pk_add(lacc, (f32x2){s[r], s[r + 1]});
+      } else {
+      // ---- S^T tile: rows = keys (registers), cols = queries (lanes)
 #pragma unroll
       for (int r = 0; r < 16; ++r) s[r] = 0.f;
-      const float* krow = Ks + (buf * KT + sub * 32 + li) * KS + lh * 4;
+      krow = Ks + (buf * KT + sub * 32 + li) * KS + lh * 4;
 #pragma unroll
       for (int g = 0; g < QS; ++g) {
         const f32x4 kf = *reinterpret_cast<const f32x4*>(krow + g * 8);
@@ -177,13 +260,14 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
         s[r] = __builtin_amdgcn_exp2f(s[r] - mnew);
         lsum += s[r];
       }
-      l_run = l_run * alpha + lsum;
+      lacc[0] = lacc[0] * alpha + lsum;
       m_run = mnew;
       if (__any(alpha != 1.0f)) {
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
           for (int r = 0; r < 16; ++r) o[ct][r] *= alpha;
+      }
       }
       // ---- O^T += V^T P^T : A = V[key kappa(r,h)][channel lane], B = P^T register r
       const float* vrow = Vs + (buf * KT + sub * 32 + 4 * lh) * VS + (CP >= 32 ? li : (li & (CP - 1)));
@@ -201,6 +285,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
   }
 
   // ---- epilogue: y = gamma * o / l + x ; z = act(scale*y + bias) ; nearest-upsample x alpha along T
+  const float l_run = lacc[0] + lacc[1];
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
   const int qrow = q0 + li;
   if (qrow >= N) return;
@@ -309,12 +394,21 @@ __global__ __launch_bounds__(256) void attn_fwd_merge_kernel(const AttnArgs p, i
 }
 
 template <int CP>
-int launch(const AttnArgs& a, bool vec4, hipStream_t s) {
+int launch(AttnArgs a, bool vec4, hipStream_t s) {
   const int grid = a.B * a.zs * a.nqt;
-  if (vec4)
-    hipLaunchKernelGGL((attn_fwd_kernel<CP, 4>), dim3(grid), dim3(256), 0, s, a);
-  else
-    hipLaunchKernelGGL((attn_fwd_kernel<CP, 1>), dim3(grid), dim3(256), 0, s, a);
+  // SF_ATTN_STALE=0: the per-tile online softmax (running maximum refreshed on every tile); SF_ATTN_SOFT_T: how far
+  // (log2) a tile may exceed the stale reference before it is refreshed
+  static const bool stale_on = [] { const char* e = getenv("SF_ATTN_STALE"); return !(e && e[0] == '0'); }();
+  static const float soft_t = [] { const char* e = getenv("SF_ATTN_SOFT_T"); return e ? (float)atof(e) : SOFT_T; }();
+  a.soft_t = soft_t;
+  const bool stale = stale_on && CP <= 64;  // d = 128: the 16 extra registers cost the second wavefront per SIMD
+  if (vec4) {
+    if (stale) hipLaunchKernelGGL((attn_fwd_kernel<CP, 4, true>), dim3(grid), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((attn_fwd_kernel<CP, 4, false>), dim3(grid), dim3(256), 0, s, a);
+  } else {
+    if (stale) hipLaunchKernelGGL((attn_fwd_kernel<CP, 1, true>), dim3(grid), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((attn_fwd_kernel<CP, 1, false>), dim3(grid), dim3(256), 0, s, a);
+  }
   SF_CHECK_LAUNCH();
   return a.zs > 1 ? sf_attn_fwd_merge(a, CP, s) : SF_OK;
 }
