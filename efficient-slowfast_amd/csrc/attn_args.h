@@ -2,6 +2,7 @@
 #pragma once
 #include "common.h"
 
+#include <stdlib.h>
 struct SfAttnArgs {
   const float* q; const float* k; const float* v; const float* x;
   const float* gamma; const float* scale; const float* bias;
@@ -18,6 +19,15 @@ struct SfAttnArgs {
   float* part_ml;  // [B][zs][N][2]   (m, l)
   float soft_t;    // attn_fwd_kernel: log2 headroom of the stale softmax reference (set by its launcher)
 };
+
+// log2 headroom of the stale softmax reference (SF_ATTN_SOFT_T, default 64: 2^(s - m_ref) stays far inside fp32)
+static inline float sf_attn_soft_t() {
+  static const float t = [] {
+    const char* e = getenv("SF_ATTN_SOFT_T");
+    return e ? (float)atof(e) : 64.f;
+  }();
+  return t;
+}
 
 // Combine the zs key parts of every query row and run the attention epilogue (attn_flash.hip).
 int sf_attn_fwd_merge(const SfAttnArgs& a, int cp, hipStream_t s);

@@ -32,7 +32,6 @@ using AttnArgs = SfAttnArgs;
 
 constexpr float NEG_BIG = -3.0e38f;
 constexpr float LOG2E = 1.4426950408889634f;
-constexpr float SOFT_T = 64.f;  // a tile may exceed the stale reference maximum by 2^64 before it is refreshed (default)
 
 // v_pk_add_f32: two fp32 adds in one vector-ALU pass (the compiler's SLP vectoriser leaves most of them scalar).
 // The s_nop covers the wait state a vector instruction needs after a transcendental one (v_exp_f32) wrote its
@@ -166,7 +165,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
       // a v_sub / v_add issued beside them is NOT hidden (tools/microbench/mfma_coexec.hip: +4.5 cycles each, v_exp
       // +7.5) — so the softmax keeps its vector work minimal: the tile is accumulated ON TOP of -m_ref (the first
       // MFMA's C operand is a register block holding -m_ref of this lane's query), with m_ref a STALE running
-      // maximum that is only refreshed when a tile exceeds it by more than 2^SOFT_T (then S is recomputed from 0 and
+      // maximum that is only refreshed when a tile exceeds it by more than 2^soft_t (then S is recomputed from 0 and
       // O, l are rescaled — the classic online-softmax step, taken a handful of times per sweep): no subtraction,
       // no per-tile rescale factor, and the row sums are kept as packed partial sums.
       krow = Ks + (buf * KT + sub * 32 + li) * KS + lh * 4;
@@ -399,8 +398,7 @@ int launch(AttnArgs a, bool vec4, hipStream_t s) {
   // SF_ATTN_STALE=0: the per-tile online softmax (running maximum refreshed on every tile); SF_ATTN_SOFT_T: how far
   // (log2) a tile may exceed the stale reference before it is refreshed
   static const bool stale_on = [] { const char* e = getenv("SF_ATTN_STALE"); return !(e && e[0] == '0'); }();
-  static const float soft_t = [] { const char* e = getenv("SF_ATTN_SOFT_T"); return e ? (float)atof(e) : SOFT_T; }();
-  a.soft_t = soft_t;
+  a.soft_t = sf_attn_soft_t();
   const bool stale = stale_on && CP <= 64;  // d = 128: the 16 extra registers cost the second wavefront per SIMD
   if (vec4) {
     if (stale) hipLaunchKernelGGL((attn_fwd_kernel<CP, 4, true>), dim3(grid), dim3(256), 0, s, a);

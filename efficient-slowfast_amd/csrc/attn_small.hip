@@ -70,22 +70,39 @@ __global__ __launch_bounds__(256) void attn_small_kernel(const AttnArgs p) {
     o0[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
     o1[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
   }
-  float m_run = NEG_BIG;
+  float m_run = NEG_BIG;                                        // the stale reference maximum m_ref of this lane's query
+  f32x4 negm = {-NEG_BIG, -NEG_BIG, -NEG_BIG, -NEG_BIG};        // -m_ref: the C operand of a score tile's first MFMA
   float l_run = 0.f;
 
-  // ---- staging: float4 f = tid + 256 i (< NLD) is (row = f / F4, channels 4*(f % F4) ..)
+  // ---- staging: float4 f = tid + 256 i (< NLD) is (row = f / F4, channels 4*(f % F4) ..).  The row pointers are
+  // kept and advanced by one tile per call (no 64-bit multiplies in the loop: integer vector work is not hidden
+  // behind fp32 MFMAs either)
   f32x4 rk[LIT], rv[LIT];
-  auto load_tile = [&](int j0) {
+  const float* kptr[LIT];
+  const float* vptr[LIT];
+  int jrow[LIT];
+  const int tz = ((N + KT - 1) / KT + p.zs - 1) / p.zs;  // key tiles per part
+  const int t0 = z * tz;
+  const int ntiles = min((N + KT - 1) / KT, t0 + tz);
+#pragma unroll
+  for (int i = 0; i < LIT; ++i) {
+    const int f = tid + i * 256;
+    const int srow = f / F4, sc4 = (f - srow * F4) * 4;
+    jrow[i] = t0 * KT + srow;
+    kptr[i] = p.k + (brow + jrow[i]) * p.k_cs + sc4;
+    vptr[i] = p.v + (brow + jrow[i]) * p.v_cs + sc4;
+  }
+  const long kstep = (long)KT * p.k_cs, vstep = (long)KT * p.v_cs;
+  auto load_tile = [&]() {  // the next tile in order
 #pragma unroll
     for (int i = 0; i < LIT; ++i) {
       const int f = tid + i * 256;
-      const int srow = f / F4, sc4 = (f - srow * F4) * 4;
+      const int sc4 = (f % F4) * 4;
       rk[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
       rv[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      const int j = j0 + srow;
-      if (f < NLD && j < N) {
-        const float* kp = p.k + (brow + j) * p.k_cs + sc4;
-        const float* vp = p.v + (brow + j) * p.v_cs + sc4;
+      if (f < NLD && jrow[i] < N) {
+        const float* kp = kptr[i];
+        const float* vp = vptr[i];
         if (VEC == 4) {
           if (sc4 < C) {
             rk[i] = *reinterpret_cast<const f32x4*>(kp);
@@ -100,6 +117,9 @@ __global__ __launch_bounds__(256) void attn_small_kernel(const AttnArgs p) {
             }
         }
       }
+      jrow[i] += KT;
+      kptr[i] += kstep;
+      vptr[i] += vstep;
     }
   };
   auto store_tile = [&](int buf) {
@@ -116,55 +136,80 @@ __global__ __launch_bounds__(256) void attn_small_kernel(const AttnArgs p) {
     }
   };
 
-  const int tz = ((N + KT - 1) / KT + p.zs - 1) / p.zs;  // key tiles per part
-  const int t0 = z * tz;
-  const int ntiles = min((N + KT - 1) / KT, t0 + tz);
-  load_tile(t0 * KT);
+  load_tile();
   store_tile(0);
   __syncthreads();
   for (int t = t0; t < ntiles; ++t) {
     const int buf = (t - t0) & 1;
     const bool more = (t + 1) < ntiles;
-    if (more) load_tile((t + 1) * KT);
-    // ---- scores for 4 key tiles of 16
+    if (more) load_tile();
+    // ---- scores for 4 key tiles of 16.  fp32 MFMAs run on the SIMD's vector ALUs, so every v_sub / v_max beside
+    // them costs its full issue time (tools/microbench/mfma_coexec.hip) and this kernel has only 24 MFMAs per 16
+    // exponentials: the scores are accumulated ON TOP of -m_ref (C operand of each tile's first MFMA: all 16 scores
+    // of a lane belong to ONE query, so a 4-register block serves the four tiles), m_ref being a stale running
+    // maximum that is refreshed only when a tile exceeds it by more than 2^soft_t — then the scores are recomputed
+    // from zero and O (with its ones-row denominator) rescaled, the classic online-softmax step.
     f32x4 s[4];
     const float* kbase = Kt + (buf * CP + lg) * KP + li;
 #pragma unroll
     for (int kt = 0; kt < 4; ++kt) {
-      s[kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      s[kt] = negm;
 #pragma unroll
       for (int u = 0; u < QS; ++u)
         s[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(kbase[(4 * u) * KP + kt * 16], qf[u], s[kt], 0, 0, 0);
     }
+    // the second product's A operands (V^T: 16 keys x CTN channel tiles per lane) are read NOW: their LDS latency
+    // passes behind the score MFMAs and the exponentials instead of in front of every MFMA pair
+    const float* vbase = Vs + (buf * KT + 4 * lg) * VP + (ONES_ROW ? (li <= CP ? li : 0) : li);
+    float vfr[4][4][CTN];
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int ct = 0; ct < CTN; ++ct) vfr[kt][r][ct] = vbase[(kt * 16 + r) * VP + 16 * ct];
     const int jbase = t * KT;
-    if (jbase + KT > N) {  // ragged last tile (wave-uniform)
+    const bool ragged = jbase + KT > N;  // last tile (wave-uniform)
+    if (ragged) {
 #pragma unroll
       for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
         for (int r = 0; r < 4; ++r)
           if (jbase + kt * 16 + 4 * lg + r >= N) s[kt][r] = NEG_BIG;
     }
-    // ---- online softmax over the 64 keys: 16 per lane, 4 lane quarters per query row
-    float mloc = s[0][0];
+    float mx = fmaxf(fmaxf(s[0][0], s[0][1]), s[0][2]);
+    mx = fmaxf(fmaxf(mx, s[0][3]), s[1][0]);
+    mx = fmaxf(fmaxf(mx, s[1][1]), s[1][2]);
+    mx = fmaxf(fmaxf(mx, s[1][3]), s[2][0]);
+    mx = fmaxf(fmaxf(mx, s[2][1]), s[2][2]);
+    mx = fmaxf(fmaxf(mx, s[2][3]), s[3][0]);
+    mx = fmaxf(fmaxf(mx, s[3][1]), s[3][2]);
+    mx = fmaxf(mx, s[3][3]);
+    if (__any(mx > p.soft_t)) {  // refresh the reference (always on the first tile: -m_ref = +BIG there)
 #pragma unroll
-    for (int kt = 0; kt < 4; ++kt)
+      for (int kt = 0; kt < 4; ++kt) {
+        s[kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int r = 0; r < 4; ++r) mloc = fmaxf(mloc, s[kt][r]);
-    mloc = fmaxf(mloc, __shfl_xor(mloc, 16, 64));
-    mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
-    const float mnew = fmaxf(m_run, mloc);
-    const float alpha = __builtin_amdgcn_exp2f(m_run - mnew);
-    float lsum = 0.f;
-#pragma unroll
-    for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        s[kt][r] = __builtin_amdgcn_exp2f(s[kt][r] - mnew);
-        if (!ONES_ROW) lsum += s[kt][r];
+        for (int u = 0; u < QS; ++u)
+          s[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(kbase[(4 * u) * KP + kt * 16], qf[u], s[kt], 0, 0, 0);
       }
-    if (!ONES_ROW) l_run = l_run * alpha + lsum;
-    m_run = mnew;
-    if (__any(alpha != 1.0f)) {
+      if (ragged) {
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (jbase + kt * 16 + 4 * lg + r >= N) s[kt][r] = NEG_BIG;
+      }
+      float mloc = s[0][0];
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) mloc = fmaxf(mloc, s[kt][r]);
+      mloc = fmaxf(mloc, __shfl_xor(mloc, 16, 64));
+      mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+      const float mnew = fmaxf(m_run, mloc);
+      const float alpha = __builtin_amdgcn_exp2f(m_run - mnew);  // 0 on the first tile
+      if (!ONES_ROW) l_run *= alpha;
 #pragma unroll
       for (int ct = 0; ct < CTN; ++ct)
 #pragma unroll
@@ -172,18 +217,29 @@ __global__ __launch_bounds__(256) void attn_small_kernel(const AttnArgs p) {
           o0[ct][r] *= alpha;
           o1[ct][r] *= alpha;
         }
+      m_run = mnew;
+      negm = (f32x4){-mnew, -mnew, -mnew, -mnew};
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s[kt][r] -= mnew;
     }
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        s[kt][r] = __builtin_amdgcn_exp2f(s[kt][r]);
+        if (!ONES_ROW) l_run += s[kt][r];
+      }
     // ---- O^T += V^T P^T (lanes li > CP re-read column 0: their output rows are never stored)
-    const float* vbase = Vs + (buf * KT + 4 * lg) * VP + (ONES_ROW ? (li <= CP ? li : 0) : li);
 #pragma unroll
     for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
       for (int r = 0; r < 4; r += 2) {
 #pragma unroll
         for (int ct = 0; ct < CTN; ++ct) {
-          o0[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(vbase[(kt * 16 + r) * VP + 16 * ct], s[kt][r], o0[ct], 0, 0, 0);
-          o1[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(vbase[(kt * 16 + r + 1) * VP + 16 * ct], s[kt][r + 1], o1[ct],
-                                                        0, 0, 0);
+          o0[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(vfr[kt][r][ct], s[kt][r], o0[ct], 0, 0, 0);
+          o1[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(vfr[kt][r + 1][ct], s[kt][r + 1], o1[ct], 0, 0, 0);
         }
       }
     if (more) store_tile(buf ^ 1);
@@ -281,6 +337,7 @@ int sf_attn_small_dispatch(const float* q, int q_cs, const float* k, int k_cs, c
     if (rc != 1) return rc;
   }
   a.nqt = sf_cdiv(a.N, 64);
+  a.soft_t = sf_attn_soft_t();
   a.zs = 1; a.part_o = nullptr; a.part_ml = nullptr;
   if (ws) {
     a.zs = sf_sweep_parts((long)B * a.nqt, sf_cdiv(a.N, 64));

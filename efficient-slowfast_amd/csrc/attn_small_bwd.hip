@@ -379,9 +379,9 @@ __global__ __launch_bounds__(256) void attn_small_fused_kernel(const BwdArgs p, 
       *reinterpret_cast<f32x4*>(Qs + srow * RP + sc4) = rq;
       *reinterpret_cast<f32x4*>(Ds + srow * RP + sc4) = rd;
     }
-    if (tid < ST) {
-      Ls[tid] = rl;
-      Ls[ST + tid] = rD;
+    if (tid < ST) {  // NEGATED: the score / dP tiles start from these as their C operand (S' - lse, dP - D)
+      Ls[tid] = -rl;
+      Ls[ST + tid] = -rD;
     }
   };
 
@@ -406,8 +406,11 @@ __global__ __launch_bounds__(256) void attn_small_fused_kernel(const BwdArgs p, 
     const float* db = Dt + lg * TP + li;
 #pragma unroll
     for (int qt = 0; qt < 4; ++qt) {
-      s[qt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      dp[qt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      // fp32 MFMAs run on the vector ALUs (a v_sub beside them is not hidden, tools/microbench/mfma_coexec.hip):
+      // S' - lse and dP - D ride on the products — register r of tile qt is query 16 qt + 4 lg + r, so the
+      // ds_read_b128 of -lse / -D IS the C operand of the tile's first MFMA
+      s[qt] = *reinterpret_cast<const f32x4*>(Ls + qt * 16 + 4 * lg);
+      dp[qt] = *reinterpret_cast<const f32x4*>(Ls + ST + qt * 16 + 4 * lg);
 #pragma unroll
       for (int u = 0; u < QS; ++u) {
         s[qt] = __builtin_amdgcn_mfma_f32_16x16x4f32(qb[(4 * u) * TP + qt * 16], kf[u], s[qt], 0, 0, 0);    // S'
@@ -417,13 +420,9 @@ __global__ __launch_bounds__(256) void attn_small_fused_kernel(const BwdArgs p, 
     f32x4 pr[4];
 #pragma unroll
     for (int qt = 0; qt < 4; ++qt) {
-      const f32x4 l4 = *reinterpret_cast<const f32x4*>(Ls + qt * 16 + 4 * lg);
-      const f32x4 d4 = *reinterpret_cast<const f32x4*>(Ls + ST + qt * 16 + 4 * lg);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        pr[qt][r] = __builtin_amdgcn_exp2f(s[qt][r] - l4[r]);
-        s[qt][r] = pr[qt][r] * (dp[qt][r] - d4[r]);  // dS
-      }
+      for (int r = 0; r < 4; ++r) pr[qt][r] = __builtin_amdgcn_exp2f(s[qt][r]);
+      s[qt] = pr[qt] * dp[qt];  // dS = P (dP - D)
     }
     const float* qc = Qs + (4 * lg) * RP + (li & (CP - 1));
     const float* dc = Ds + (4 * lg) * RP + (li & (CP - 1));
