@@ -90,7 +90,7 @@ rows.sort(reverse=True)
 tot = sum(r[0] for r in rows)
 print("%-6s %3s %9s %5s %5s %-9s %-9s %-12s %8s %7s" % ("kind", "n", "rows", "cin", "cout", "kernel", "stride", "THW",
                                                       "ms", "TF/s"))
-for ms, kind, n, m, cin, cout, k, s, thw, tf in rows[:70]:
+for ms, kind, n, m, cin, cout, k, s, thw, tf in rows[:int(os.environ.get("PROF_ROWS", "70"))]:
     print("%-6s %3d %9d %5d %5d %-9s %-9s %-12s %8.3f %7.1f" % (kind, n, m, cin, cout, "x".join(map(str, k)),
                                                                 "x".join(map(str, s)), "x".join(map(str, thw)), ms, tf))
 for kind in ("fwd", "dgrad", "wgrad"):
