@@ -12,3 +12,11 @@ for w in dual slowfast ghostnet shufflenetv2; do timeout 600 python bench.py --w
 for d in default train serial; do cp $(find gpurun_out/final/$d -name "*kernel_stats.csv") gpurun_out/final/${d}_kernel_stats.csv; done
 python3 tools/prof_stats.py gpurun_out/final/serial_kernel_stats.csv 8 50 > gpurun_out/final/serial_per_step.txt
 tail -3 gpurun_out/final/serial_per_step.txt; cat gpurun_out/final/pmc_conv_wave.txt | head -20; tail -4 gpurun_out/final/conv_per_shape.txt
+# round-2 additions: attention PMC view, two-stream timeline, fp32 MFMA / VALU co-execution and dependent-chain probes
+bash tools/attn_pmc.sh > /dev/null 2>&1; cp gpurun_out/attn_pmc/summary.txt gpurun_out/final/pmc_attention.txt
+bash tools/timeline_prof.sh > /dev/null 2>&1; cp gpurun_out/timeline/timeline.txt gpurun_out/final/timeline.txt
+bash tools/pmc_step.sh > /dev/null 2>&1; cp gpurun_out/pmc_step/summary.txt gpurun_out/final/pmc_step.txt
+python tools/microbench/attn_bench.py > gpurun_out/final/attn_bench.txt 2>&1
+(cd /tmp && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 $GRAFT_REPO_ROOT/tools/microbench/mfma_coexec.hip -o /tmp/mfma_coexec 2>/dev/null && timeout 100 /tmp/mfma_coexec 4000 > $GRAFT_REPO_ROOT/gpurun_out/final/mfma_coexec.txt)
+(cd /tmp && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 $GRAFT_REPO_ROOT/tools/microbench/mfma_chain.hip -o /tmp/mfma_chain 2>/dev/null && timeout 100 /tmp/mfma_chain 4000 > $GRAFT_REPO_ROOT/gpurun_out/final/mfma_chain.txt)
+ls gpurun_out/final | head -40
