@@ -91,35 +91,69 @@ __global__ __launch_bounds__(256) void conv_wgrad_wave_kernel(const WgWaveArgs p
     x_tap[b] = (unsigned)(((x_kt[b] * d.dT * d.Hi + x_kh[b] * d.dH) * d.Wi + x_kw[b] * d.dW) * d.in_cs) * 4u;
   }
 
+  // ---- this lane's position walk.  load() is called for steps 0, 1, 2, .. in order, so the position (lane quarter
+  // fg of step s is m_begin + 4 s + fg) is DECODED ONCE and then advanced by 4 per call with carries — fp32 MFMAs run
+  // on the vector ALUs (tools/microbench/mfma_coexec.hip), and the three magic divisions + 32-bit multiplies of a
+  // per-step decode were a third of this loop's issue time (14 v_mul_lo_u32 + 6 v_mul_hi_u32 per 64 MFMAs).
+  int left = (int)(m_end - (m_begin + fg));          // > 0: the position exists
+  unsigned zrow, org;                                // byte offsets: dz row, input-window origin (wraps when "negative")
+  int wo, ho, to;
+  {
+    const unsigned mm = left > 0 ? (unsigned)(m_begin + fg) : 0u;
+    zrow = mm * (unsigned)p.dz_cs * 4u;
+    const unsigned q1 = fast_div(mm, p.wo_mul, p.wo_sh);
+    wo = (int)(mm - q1 * (unsigned)d.Wo);
+    const unsigned q2 = fast_div(q1, p.ho_mul, p.ho_sh);
+    ho = (int)(q1 - q2 * (unsigned)d.Ho);
+    const unsigned q3 = fast_div(q2, p.to_mul, p.to_sh);
+    to = (int)(q2 - q3 * (unsigned)d.To);
+    org = p.plain ? mm * (unsigned)d.in_cs * 4u
+                  : (unsigned)(((((int)q3 * d.Ti + to * d.sT - d.pT) * d.Hi + ho * d.sH - d.pH) * d.Wi + wo * d.sW - d.pW) *
+                               d.in_cs) * 4u;
+  }
+  // uniform steps of the origin: 4 positions along w, and the corrections when w / h / t wrap into the next row / frame / clip
+  const unsigned z_step = (unsigned)p.dz_cs * 16u;
+  const unsigned o_step = p.plain ? (unsigned)d.in_cs * 16u : (unsigned)(d.sW * d.in_cs) * 16u;
+  const unsigned o_w = (unsigned)((d.sH * d.Wi - d.Wo * d.sW) * d.in_cs) * 4u;
+  const unsigned o_h = (unsigned)(((d.sT * d.Hi - d.Ho * d.sH) * d.Wi) * d.in_cs) * 4u;
+  const unsigned o_t = (unsigned)((((d.Ti - d.To * d.sT) * d.Hi) * d.Wi) * d.in_cs) * 4u;
+
   struct Frag { f32x4 z[NA]; f32x4 x[NB]; };
-  auto load = [&](Frag& f, int step) {
-    const long m = m_begin + (long)step * 4 + fg;
-    const bool live = m < m_end;
-    const unsigned mm = live ? (unsigned)m : 0u;
-    const unsigned zrow = mm * (unsigned)p.dz_cs * 4u;
+  auto load = [&](Frag& f) {
+    const bool live = left > 0;
 #pragma unroll
     for (int a = 0; a < NA; ++a)
       f.z[a] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(z_rs, live ? zrow + z_col[a] : OOB, 0, 0));
     if (p.plain) {
-      const unsigned xrow = mm * (unsigned)d.in_cs * 4u;
 #pragma unroll
       for (int b = 0; b < NB; ++b)
-        f.x[b] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(x_rs, live ? xrow + x_col[b] : OOB, 0, 0));
+        f.x[b] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(x_rs, live ? org + x_col[b] : OOB, 0, 0));
     } else {
-      const unsigned q1 = fast_div(mm, p.wo_mul, p.wo_sh);
-      const int wo = (int)(mm - q1 * (unsigned)d.Wo);
-      const unsigned q2 = fast_div(q1, p.ho_mul, p.ho_sh);
-      const int ho = (int)(q1 - q2 * (unsigned)d.Ho);
-      const unsigned q3 = fast_div(q2, p.to_mul, p.to_sh);
-      const int to = (int)(q2 - q3 * (unsigned)d.To);
-      const int t0 = to * d.sT - d.pT, h0 = ho * d.sH - d.pH, w0 = wo * d.sW - d.pW;
-      const unsigned org = (unsigned)(((((int)q3 * d.Ti + t0) * d.Hi + h0) * d.Wi + w0) * d.in_cs) * 4u;
+      const int t0 = __mul24(to, d.sT) - d.pT, h0 = __mul24(ho, d.sH) - d.pH, w0 = __mul24(wo, d.sW) - d.pW;
 #pragma unroll
       for (int b = 0; b < NB; ++b) {
-        const bool v = live && (unsigned)(t0 + x_kt[b] * d.dT) < (unsigned)d.Ti &&
-                       (unsigned)(h0 + x_kh[b] * d.dH) < (unsigned)d.Hi && (unsigned)(w0 + x_kw[b] * d.dW) < (unsigned)d.Wi;
+        const bool v = live & ((unsigned)(t0 + x_kt[b] * d.dT) < (unsigned)d.Ti) &
+                       ((unsigned)(h0 + x_kh[b] * d.dH) < (unsigned)d.Hi) & ((unsigned)(w0 + x_kw[b] * d.dW) < (unsigned)d.Wi);
         f.x[b] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(x_rs, v ? org + x_tap[b] + x_col[b] : OOB, 0, 0));
       }
+    }
+    // advance by one K step (4 positions along w; Wo >= 4, so at most one wrap per level)
+    left -= 4;
+    zrow += z_step;
+    org += o_step;
+    if (!p.plain) {
+      wo += 4;  // branch-free carries: m = all ones where the coordinate wrapped
+      const int m1 = -(int)(wo >= d.Wo);
+      wo -= d.Wo & m1;
+      org += o_w & (unsigned)m1;
+      ho -= m1;
+      const int m2 = -(int)(ho >= d.Ho);
+      ho -= d.Ho & m2;
+      org += o_h & (unsigned)m2;
+      to -= m2;
+      const int m3 = -(int)(to >= d.To);
+      to -= d.To & m3;
+      org += o_t & (unsigned)m3;
     }
   };
 
@@ -137,7 +171,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_wave_kernel(const WgWaveArgs p
   {
     Frag ring[DEPTH];
 #pragma unroll
-    for (int u = 0; u < DEPTH; ++u) load(ring[u], u);
+    for (int u = 0; u < DEPTH; ++u) load(ring[u]);
     for (int step = 0; step < nsteps; step += DEPTH) {
 #pragma unroll
       for (int u = 0; u < DEPTH; ++u) {
@@ -151,7 +185,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_wave_kernel(const WgWaveArgs p
               for (int eb = 0; eb < 4; ++eb)
                 acc[a][b][ea][eb] = __builtin_amdgcn_mfma_f32_16x16x4f32(ring[u].z[a][ea], ring[u].x[b][eb],
                                                                          acc[a][b][ea][eb], 0, 0, 0);
-        load(ring[u], step + u + DEPTH);   // positions past m_end read as zero
+        load(ring[u]);   // the next step in order; positions past m_end read as zero
         __builtin_amdgcn_sched_barrier(0);
       }
     }
@@ -226,7 +260,7 @@ static bool wg_plan(const sf_conv_desc* d, WgPlan* pl) {
   if (d->Cout < 64 || d->Cin < 64) return false;
   if ((d->Cin % 4) || (d->in_cs % 4) || (d->in_coff % 4) || (d->Cout % 4) || (d->cin_pad % 16)) return false;
   const long M = (long)d->N * d->To * d->Ho * d->Wo;
-  if (M < 1024) return false;
+  if (M < 1024 || d->Wo < 4) return false;  // the position walk advances 4 along w with at most one wrap per level
   if ((long)d->N * d->Ti * d->Hi * d->Wi * d->in_cs * 4 > 0x7ffffff0L) return false;
   const int ntaps = d->kT * d->kH * d->kW;
   const int nco = sf_cdiv(d->Cout, 64), nci = sf_cdiv(d->cin_pad, 64), ncb = ntaps * nci;
