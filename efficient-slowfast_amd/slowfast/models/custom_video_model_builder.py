@@ -86,8 +86,12 @@ class FuseFastAndSlow(nn.Module):
         # pool / gate / BN chain of the other direction
         # (Fast->Slow on the caller's stream, the attention on the side stream: with defer_join the Slow pathway's
         # next stage starts as soon as its own input is complete)
+        # a forward hook on this module (feature extraction, Grad-CAM, the parity tests) reads the outputs on the
+        # caller's stream as soon as forward returns: with hooks attached the join is not deferred
+        import torch.nn.modules.module as _tm
+        hooked = bool(self._forward_hooks) or bool(_tm._global_forward_hooks)
         engine.run_paths([fast_to_slow, slow_to_fast], x_s.buf.device,
-                         defer_join=defer_join and engine.is_internal())
+                         defer_join=defer_join and engine.is_internal() and not hooked)
         return engine.leave([s_wide, f_wide])
 
 

@@ -33,8 +33,26 @@ pytestmark = pytest.mark.gpu
 # independently (the oracle's rounding differs from the HIP kernels' on identical inputs; the reference's inputs differ
 # by the accumulated forward rounding), so a tensor passes when it is TIGHT against one of them and LOOSE against both:
 # a wrongly wired fan-in / dropped residual term moves a child's gradients by tens of percent against both.
-TOL = 1e-2           # min(vs oracle, vs reference)
+TOL = 1e-2           # min(vs oracle, vs reference), children whose smallest activation has >= 22 500 positions
 TOL_LOOSE = 0.25     # max(vs oracle, vs reference): small tensors lose up to 7e-2 to the other comparator's flips
+
+
+def child_tol(outs):
+    """Tight tolerance of one child: one flipped ReLU / max-pool position in an activation of P = N*T*H*W positions
+    moves 1/sqrt(P) of a channel's gradient mass, and every tensor of the child downstream of it.  The deep Fast
+    stages of the S = 64 fixtures have P = 1024 (s4) and 256 (s5): the SAME model run with three numerically
+    equivalent kernel selections (SF_ATTN_STALE=0, SF_CONV_WAVE=0, SF_STEM_PAIR=0: each re-associates a few sums)
+    gave worst tensors of 4.4e-3, 5.7e-3, 6.2e-3 and — one unlucky flip — 3.8e-2 on dual_r50_subbn_s64.  So the tight
+    bound is max(1e-2, 1.5 / sqrt(P_min)); the loose bound (25 %) on BOTH comparators stays what catches a wrong
+    fan-in or a dropped term, which moves a child's gradients by tens of percent."""
+    pmin = None
+    for o in outs:
+        shp = getattr(o, "shape_ncthw", None)
+        if shp is None:
+            continue
+        pos = int(shp[0]) * int(shp[2]) * int(shp[3]) * int(shp[4])
+        pmin = pos if pmin is None else min(pmin, pos)
+    return TOL if (pmin is None or pmin < 64) else min(0.1, max(TOL, 1.5 / float(np.sqrt(pmin))))  # head: P = N
 
 
 def _report(line):
@@ -110,6 +128,7 @@ def test_stage_gradients_match_reference(name):
             if child == "head":
                 outs = [t.out_act]
             assert len(outs) == nouts, (child, len(outs), nouts)
+            tol = child_tol(outs)
             t.gbuf, t.pgrads, t.sink, t.input_grads = {}, {}, None, {}
             with torch.no_grad():
                 for j, o in enumerate(outs):
@@ -147,7 +166,7 @@ def test_stage_gradients_match_reference(name):
                 er = _l2rel(s, z[tag])
                 _report("%-22s %-12s gin%d   vs oracle %.3e   vs reference %.3e" % (name, child, i, e, er))
                 worst = max(worst, e)
-                if not (min(e, er) < TOL and max(e, er) < TOL_LOOSE):
+                if not (min(e, er) < tol and max(e, er) < TOL_LOOSE):
                     bad.append((child, "gin%d" % i, e, er))
                 checked += 1
             # ---- dL/d(parameters).  Some gradients are analytically ZERO (a conv bias in front of a train-mode BN, the
@@ -172,7 +191,7 @@ def test_stage_gradients_match_reference(name):
                 worst = max(worst, e)
                 if min(e, er) > 0.1 * TOL:
                     _report("%-22s %-12s %-52s vs oracle %.3e   vs reference %.3e" % (name, child, pn, e, er))
-                if not (min(e, er) < TOL and max(e, er) < TOL_LOOSE):
+                if not (min(e, er) < tol and max(e, er) < TOL_LOOSE):
                     bad.append((child, pn, e, er))
                 checked += 1
         _report("%-22s stage-wise gradients: %d tensors checked, worst L2rel %.3e" % (name, checked, worst))
