@@ -22,6 +22,7 @@
 // resnet_helper.py:182-223, :326-335, video_model_builder.py:128-135, custom_video_model_builder.py:102-108,
 // wdf_attention_helper.py:21-29; and, with desc.transposed / the scatter map, their data gradients.
 #include "common.h"
+#include <stdio.h>
 #include <stdlib.h>
 
 namespace {
@@ -405,7 +406,13 @@ static int launch_wave(const WaveArgs& a, int kv, hipStream_t s) {
 // and epilogue are a fixed cost per set of co-resident workgroups; the layer cannot beat its HBM bytes, and the
 // epilogue's stores arrive as one burst when every workgroup finishes together.
 static double plan_score(const sf_conv_desc* d, long M, int nk, bool has_res, const WaveCfg& c, int* rows_out) {
-  const double LD = 60.0, F0 = 10000.0, F1 = 150.0, BW = 4.5e6 / 2.1e3 /* bytes per cycle at 2.1 GHz */, EP = 0.6;
+  // fitted constants (tools/plan/fit_plan.py); SF_PLAN="ld,f0,f1,bw,ep" overrides them for calibration runs
+  static const struct PlanP { double ld, f0, f1, bw, ep; } PP = [] {
+    PlanP q = {60.3, 2229.0, 381.0, 6.64e6, 0.96};  // refit on profiles/r02b_conv_wave_ab.txt (was 60, 10000, 150, 4.5e6, 0.6)
+    if (const char* e = getenv("SF_PLAN")) sscanf(e, "%lf,%lf,%lf,%lf,%lf", &q.ld, &q.f0, &q.f1, &q.bw, &q.ep);
+    return q;
+  }();
+  const double LD = PP.ld, F0 = PP.f0, F1 = PP.f1, BW = PP.bw / 2.1e3 /* bytes per cycle at 2.1 GHz */, EP = PP.ep;
   const int N = d->Cout, ntaps = d->kT * d->kH * d->kW;
   const int nbn = sf_cdiv(N, c.tn * 16);
   const int nbm0 = sf_cdiv(M, c.tm * 16);
