@@ -149,10 +149,11 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
-    # 8 warm-up steps by default: on a box whose GPU has been idle the first few steps run 3-4 ms slow (clock ramp,
-    # stream-pool growth in the caching allocator) — measured 77.7 vs 73.4 ms / step with 3 warm-up steps as the first
-    # GPU process on a fresh box, 73.3 with 10
-    ap.add_argument("--warmup", type=int, default=8)
+    # 30 warm-up steps (2 s) by default: as the FIRST GPU process on a fresh box the first ~2-3 s of steps carry
+    # one-off host stalls (runtime pools growing, rarely used code objects loading, allocator growth: tools/
+    # cold_start.py shows 90-100 ms groups among 68.7 ms ones) — measured as first process: 71.7 / 70.2 ms per step with
+    # 8 warm-up steps, 68.2 with 60; every later process on the same box: 67.9-68.3 with 8
+    ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--workload", default="dual", choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=0, help="clips per GPU (default: the workload's)")
     ap.add_argument("--mode", default="train", choices=["train", "eval"])
@@ -239,6 +240,15 @@ def main():
         if dist.is_initialized():
             dist.barrier()
         torch.cuda.synchronize()
+
+    # ---- host-side hygiene before timing: a full (generation-2) collection of the Python garbage collector walks
+    # every tracked object of the process (modules, parameters, caches: ~10^6) and stalls the launch thread for ~80 ms
+    # about every 20 steps — longer than the launch queue is deep, so the GPU idles (tools/cold_start.py: groups of 4
+    # steps at 68.6 ms with one of 88 ms every fifth group).  Collect once, then FREEZE what exists (gc.freeze moves it
+    # to the permanent generation): the collector stays on, but what it walks from now on is one step's garbage.
+    import gc
+    gc.collect()
+    gc.freeze()
 
     # ---- timed region: exactly K steps
     barrier()
