@@ -187,7 +187,7 @@ def main():
     labels = torch.randint(0, cfg.MODEL.NUM_CLASSES, (batch,), device=device,
                            generator=torch.Generator(device=device).manual_seed(7 + rank))
     train = args.mode == "train"
-    side = torch.cuda.Stream(priority=int(os.environ.get("SF_PRIO_MAIN", "-1")))  # the step's own stream: above the weight-gradient companions
+    side = torch.cuda.Stream(priority=int(os.environ.get("SF_PRIO_MAIN", "0")))
 
     if train:
         model.train()

@@ -136,10 +136,10 @@ _SIDE = {}
 def _side_stream(device):
     s = _SIDE.get(device)
     if s is None:
-        # high priority: the side stream carries the attention chain (critical path); the companion streams' weight
-        # gradients are fillers and stay at normal priority (bench.py runs its step on a high-priority stream too:
-        # 68.35 -> 68.1 ms, SF_PRIO_SIDE / SF_PRIO_COMP / SF_PRIO_MAIN to A/B)
-        s = _SIDE[device] = torch.cuda.Stream(device=device, priority=int(os.environ.get("SF_PRIO_SIDE", "-1")))
+        # priorities: SF_PRIO_SIDE / SF_PRIO_COMP (default 0 = normal).  High priority for this stream gained 0.25 ms of
+        # the eager train step but cost 13-70 % of the eval forward's hipGraph replay (442 -> 383 clips/s, cfg #1 2866
+        # -> 600): graph nodes captured on a high-priority stream replay through a slower path on this stack
+        s = _SIDE[device] = torch.cuda.Stream(device=device, priority=int(os.environ.get("SF_PRIO_SIDE", "0")))
     return s
 
 
