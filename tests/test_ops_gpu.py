@@ -323,24 +323,30 @@ def test_attention(c, thw, alpha):
     assert err < TOL, err
 
 
-def test_attention_online_softmax_rescale_branch():
-    """Force the running-max rescale: one key far above the rest, placed in a LATE tile (guide rule 26)."""
+@pytest.mark.parametrize("c,jump", [(32, 277.0), (32, 45.0), (8, 120.0), (8, 40.0), (64, 150.0), (64, 50.0), (16, 90.0)])
+def test_attention_online_softmax_rescale_branch(c, jump):
+    """The softmax reference maximum of the forward kernels is STALE by design (folded into the score MFMAs' C operand,
+    refreshed only when a tile exceeds it by 2^64): one key far above the rest, placed in a LATE tile, (a) beyond the
+    headroom — the refresh path: scores recomputed from zero, O and the denominator rescaled — and (b) inside it — the
+    reference stays put and 2^(s - m_ref) reaches 2^40 .. 2^50.  `jump` = the spike's score above the rest in log2
+    units (guide rule 26)."""
     import sfhip
     dev = _dev()
     g = torch.Generator().manual_seed(1)
-    c, n = 32, 640
+    n = 640
     q = torch.randn(1, n, c, generator=g)
     k = torch.randn(1, n, c, generator=g)
     v = torch.randn(1, n, c, generator=g)
-    k[0, 517] = q[0, 100] * 6.0   # query 100 (and similar) spikes at key 517 (tile 8)
-    k[0, 3] = q[0, 200] * 5.0     # early spike then nothing larger
+    LOG2E = 1.4426950408889634
+    k[0, 517] = q[0, 100] * (jump / LOG2E / float(q[0, 100].pow(2).sum()))   # query 100 spikes at key 517 (tile 8)
+    k[0, 3] = q[0, 200] * (0.8 * jump / LOG2E / float(q[0, 200].pow(2).sum()))  # early spike then nothing larger
     x = torch.zeros(1, n, c)
     ref = torch.softmax(q.double() @ k.double().transpose(1, 2), -1) @ v.double()
     qa, ka, va, xa = [sfhip.Act(z.view(1, 1, 1, n, c).contiguous().to(dev)) for z in (q, k, v, x)]
     out = sfhip.attention(qa, ka, va, xa, torch.ones(1, device=dev))
     torch.cuda.synchronize()
     err = _rel(out.buf.view(1, n, c), ref)
-    _report("attn/rescale_branch", err)
+    _report("attn/rescale_branch c%d jump%d" % (c, jump), err)
     assert err < TOL
 
 
