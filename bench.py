@@ -344,14 +344,15 @@ def main():
                                        "backward, dQ/dK/dV in one sweep)"}[kind]
             traffic, traffic_src = None, None  # HBM bytes per launch: rocprofv3 PMC passes cannot run inside bench.py
             try:
-                tj = json.load(open(os.path.join(ROOT, "profiles", "r01_attention_hbm_traffic_v3.json")))["kernels"]
+                tj = json.load(open(os.path.join(ROOT, "profiles", "r02b_attention_hbm_traffic.json")))["kernels"]
                 if kind == "attn_bwd_fused" and c == 32 and n == 25088 and b == 8:
-                    # the sweep kernel + its three reductions (dK parts, dV parts, dQ planes)
+                    # the sweep kernel + its three reductions (dQ partials: tiled kernel; dK parts, dV parts)
+                    g = -(-(b * n * 8) // 256) * 256
                     sweep = [v for k, v in tj.items() if k.startswith("attn_bwd_fused_kernel<32, 4>")]
-                    red = tj["attn_dq_reduce_kernel grid=%d" % (-(-(b * n * 8) // 256) * 256)]
-                    traffic = sweep[0]["hbm_bytes_per_launch"] + 3 * red["hbm_bytes_per_launch"]
-                    traffic_src = "profiles/r01_attention_hbm_traffic_v3.json (PMC passes of the same kernel; not " \
-                                  "measured in this run)"
+                    traffic = (sweep[0]["hbm_bytes_per_launch"] + tj["attn_dq_reduce_tiled_kernel grid=%d" % g]["hbm_bytes_per_launch"]
+                               + 2 * tj["attn_dq_reduce_kernel grid=%d" % g]["hbm_bytes_per_launch"])
+                    traffic_src = "profiles/r02b_attention_hbm_traffic.json (rocprofv3 PMC passes FETCH_SIZE / WRITE_SIZE of " \
+                                  "the same kernels, tools/attn_traffic.sh; not measured in this run)"
             except (OSError, KeyError, ValueError, IndexError):
                 traffic = None
             roofline = {"bound": "mfma", "kernel": "%s C=%d N=%d B=%d" % (kname, c, n, b),

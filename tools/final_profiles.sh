@@ -19,4 +19,5 @@ bash tools/pmc_step.sh > /dev/null 2>&1; cp gpurun_out/pmc_step/summary.txt gpur
 python tools/microbench/attn_bench.py > gpurun_out/final/attn_bench.txt 2>&1
 (cd /tmp && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 $GRAFT_REPO_ROOT/tools/microbench/mfma_coexec.hip -o /tmp/mfma_coexec 2>/dev/null && timeout 100 /tmp/mfma_coexec 4000 > $GRAFT_REPO_ROOT/gpurun_out/final/mfma_coexec.txt)
 (cd /tmp && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 $GRAFT_REPO_ROOT/tools/microbench/mfma_chain.hip -o /tmp/mfma_chain 2>/dev/null && timeout 100 /tmp/mfma_chain 4000 > $GRAFT_REPO_ROOT/gpurun_out/final/mfma_chain.txt)
+bash tools/attn_traffic.sh > /dev/null 2>&1; cp gpurun_out/attn_traffic/traffic.json gpurun_out/final/attention_hbm_traffic.json
 ls gpurun_out/final | head -40
