@@ -5,6 +5,11 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
+Called directly with --gpus N > 1 (no launcher in the environment) the process starts N children itself, one per
+GPU, BEFORE any GPU call (the reference spawns its ranks the same way: utils/misc.py:275-303 launch_job ->
+torch.multiprocessing.spawn, utils/multiprocessing.py:9-61), waits for them, lets rank 0 print the JSON line and
+exits non-zero if any child did.  Under torch.distributed.run it is one of the ranks, as before.
+
 --mode train (default): a "step" is one training iteration of the reference's loop (tools/train_net.py:78-96)
 over one batch of synthetic clips already resident in HBM (fp32 NCTHW): train-mode forward (batch-statistics
 BN, dropout), cross-entropy, backward through every kernel, ONE all-reduce of the flat gradient buffer across
@@ -17,8 +22,13 @@ Prints ONE JSON line (rank 0) with the driver's contract fields plus
   roofline:     the dominant kernel (flash attention, C=32, N=25088) — algorithmic FLOPs per launch /
                 its HIP-event duration measured around every launch inside the timed region, vs the dense
                 fp32 MFMA peak (157.3 TFLOP/s);
-  cpu_baseline: the oracle (torch CPU restatement of the reference) timed on this box's host cores
-                (N=1 only, bounded sample: batch 1, 1 warm-up + 2 timed forwards).
+  cpu_baseline: the oracle (torch CPU restatement of the reference) timed on this box's host cores (N=1 only,
+                bounded sample: batch 1 of the SAME workload — train-mode forward + CE + autograd backward in train
+                mode — 3 warm-up + 5 timed iterations, median; `cores` = threads used, `host_cores` = os.cpu_count());
+  fwd_max_rel_err / fwd_logits_max_rel_err / bwd_max_rel_err: the HIP path against that oracle run on the same
+                full-size clip (eval probabilities, pre-activation logits; train-mode loss and every parameter
+                gradient's relative L2 error, worst and median).
+  n_ranks_seen: an all-reduce of ones over the job's process group (RCCL) — the ranks that really took part.
 """
 import argparse
 import contextlib
@@ -85,38 +95,62 @@ def oracle_hparams(cfg):
         width_multi=cfg.SLOWFAST.WIDTH_MULTI)
 
 
-def cpu_baseline(workload, cfg, model, train, device=None):
+def cpu_baseline(workload, cfg, model, train, device=None, hip_train_step=None):
     """The oracle on the host cores, batch 1 (dense attention needs ~6 GB per clip, ~3x that with autograd), timed as
     SURVEY §8d asks: thread count chosen on the SAME workload that is reported (one iteration per candidate), then
-    3 warm-up + 5 timed iterations at that count, median.  The eval-mode output of the same run is the checker of the
-    metric's second half: returns (cpu_baseline dict, fwd max|delta| / max|ref| of the HIP eval forward on that clip)."""
+    3 warm-up + 5 timed iterations at that count, median.  The same oracle runs are the checker of the metric's second
+    half: returns (cpu_baseline dict, parity dict) — the HIP eval forward (probabilities and logits) and, in train
+    mode, the HIP training step (loss, logits, every parameter's gradient) against the oracle on that clip.
+    hip_train_step(xs, label) -> (loss, logits, {param name: grad}) runs the HIP model on the clip (dropout off)."""
     from oracle import slowfast_oracle as oracle
     hp = oracle_hparams(cfg)
-    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
     xs = synthetic_clips(cfg, 1, "cpu", 1)
     name = cfg.MODEL.MODEL_NAME
     label = torch.zeros(1, dtype=torch.long)
+    keep = {}
 
-    def iteration():
+    def iteration(keep_grads=False):
         if not train:
             return oracle.forward(name, sd, xs, hp)["out"]
         sdr = {k: (v.clone().requires_grad_(True) if v.dtype == torch.float32 and "running" not in k else v)
                for k, v in sd.items()}
         acts = oracle.FORWARDS[name](sdr, [x.clone() for x in xs], hp, training=True)
-        torch.nn.functional.cross_entropy(acts["out"], label).backward()
+        loss = torch.nn.functional.cross_entropy(acts["out"], label)
+        loss.backward()
+        if keep_grads:
+            keep["loss"], keep["logits"] = float(loss), acts["out"].detach()
+            keep["grads"] = {k: v.grad for k, v in sdr.items() if getattr(v, "grad", None) is not None}
         return None
 
-    # ---- parity of the forward pass at the full size (BASELINE.json metric: "fwd max|delta| vs ref")
-    fwd_err = None
+    # ---- parity at the full size (BASELINE.json metric: "fwd max|delta| vs ref"), eval forward first: the training
+    #      forward below moves the HIP model's running statistics
+    parity = {}
     if device is not None:
         torch.set_num_threads(min(os.cpu_count() or 1, 32))
-        ref = oracle.forward(name, sd, xs, hp)["out"]
+        ref = oracle.forward(name, sd, xs, hp)
         was_training = model.training
         model.eval()
         with torch.no_grad():
             got = model([x.to(device) for x in xs]).cpu()
         model.train(was_training)
-        fwd_err = float((got - ref).abs().max() / ref.abs().max())
+        parity["fwd_max_rel_err"] = float((got - ref["out"]).abs().max() / ref["out"].abs().max())
+        if train and hip_train_step is not None:
+            iteration(keep_grads=True)
+            loss, logits, grads = hip_train_step([x.to(device) for x in xs], label.to(device))
+            rl = keep["logits"]
+            parity["fwd_logits_max_rel_err"] = float((logits.cpu() - rl).abs().max() / rl.abs().max())
+            parity["train_loss_abs_err"] = abs(float(loss) - keep["loss"])
+            errs = []
+            for k, g in keep["grads"].items():
+                if k in grads and float(g.norm()) > 0:
+                    errs.append((float((grads[k].cpu() - g).norm() / g.norm()), k))
+            errs.sort()
+            parity["bwd_max_rel_err"] = errs[-1][0]
+            parity["bwd_median_rel_err"] = errs[len(errs) // 2][0]
+            parity["bwd_worst_param"] = errs[-1][1]
+            parity["bwd_params_compared"] = len(errs)
+            keep.clear()
     # ATen's CPU conv/softmax stop scaling (and collapse when oversubscribed: 256 SMT threads ran 350x slower
     # than 8 cores) well below this box's core count: one iteration of the reported workload per candidate count
     best = None
@@ -141,8 +175,67 @@ def cpu_baseline(workload, cfg, model, train, device=None):
     what = ("train-mode forward + CE + autograd backward" if train else "eval forward")
     sample = "%s, batch 1; %d threads (fastest of 16/32/64 on one iteration of this workload), %d warm-up + %d timed " \
              "iterations, median (min %.2f s, max %.2f s)" % (what, threads, warm, timed, min(times), max(times))
-    return ({"value": round(1.0 / dt, 4), "unit": "clips/s", "cores": threads, "kind": "port",
-             "sample": "oracle (torch CPU restatement of the reference), same model / clip shape: " + sample}, fwd_err)
+    return ({"value": round(1.0 / dt, 4), "unit": "clips/s", "cores": threads, "host_cores": os.cpu_count(),
+             "kind": "port",
+             "sample": "oracle (torch CPU restatement of the reference), same model / clip shape: " + sample}, parity)
+
+
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def spawn_ranks(n, argv):
+    """Start n copies of this script, one per GPU (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment:
+    what torch.distributed.run would set), wait for all of them and return the exit code: 0 only if every rank
+    exited 0.  Rank 0 inherits stdout (its JSON line is this command's); when a rank fails the others are stopped
+    (exactly the PIDs started here).  The parent never initialises the GPU."""
+    import subprocess
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // n)))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    live = list(procs)
+    while live:
+        for p in list(live):
+            code = p.poll()
+            if code is None:
+                continue
+            live.remove(p)
+            if code != 0 and rc == 0:
+                rc = code if code > 0 else 1
+                print("[bench] rank %d exited with %d: stopping the other ranks" % (procs.index(p), code),
+                      file=sys.stderr)
+                for q in live:
+                    q.terminate()
+        time.sleep(0.05)
+    return rc
+
+
+def spawn_selftest(rank, world):
+    """--spawn-selftest: the launcher's contract without a GPU (tests/test_distributed_cpu.py)."""
+    import torch.distributed as dist
+    if os.environ.get("SF_SELFTEST_FAIL_RANK") == str(rank):
+        raise SystemExit(3)
+    if "RANK" in os.environ:
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    ones = torch.ones(1)
+    if dist.is_initialized():
+        dist.all_reduce(ones)
+    if rank == 0:
+        print(json.dumps({"selftest": True, "n_gpus": world, "n_ranks_seen": int(ones.item())}))
+    if dist.is_initialized():
+        dist.destroy_process_group()
 
 
 def main():
@@ -160,6 +253,10 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
     ap.add_argument("--graph-train", action="store_true", help="(train) capture the whole step into one hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-overlap-allreduce", action="store_true",
+                    help="(train) ONE all-reduce after the backward instead of chunks issued as the stages' gradients land")
+    ap.add_argument("--spawn-selftest", action="store_true",
+                    help="CPU-only check of the launcher logic: ranks join a gloo group, all-reduce ones, rank 0 prints")
     ap.add_argument("--no-extras", action="store_true",
                     help="profiling aid: skip the secondary eval-forward measurement and the HIP-event roofline trace so "
                          "that a rocprofv3 --stats run contains exactly warmup+steps identical steps")
@@ -168,16 +265,29 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world == 1:
-        raise SystemExit("--gpus %d needs the torch.distributed.run launcher (one process per GPU)" % args.gpus)
+    if args.spawn_selftest:
+        if "RANK" not in os.environ and args.gpus > 1:
+            raise SystemExit(spawn_ranks(args.gpus, sys.argv[1:]))
+        return spawn_selftest(rank, world)
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # called directly: become the launcher.  Nothing in this process has touched the GPU yet (no HIP call, no
+        # torch.cuda.is_available()), and it never will: the children do the work
+        raise SystemExit(spawn_ranks(args.gpus, sys.argv[1:]))
+    if args.gpus != world:
+        raise SystemExit("--gpus %d but the launcher started %d ranks" % (args.gpus, world))
     assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback for the hot path)"
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     import torch.distributed as dist
-    if world > 1 or "RANK" in os.environ:  # launched by torch.distributed.run: one process per GPU
+    if world > 1 or "RANK" in os.environ:  # one process per GPU (torch.distributed.run, or spawn_ranks above)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         dist.init_process_group(backend="nccl", rank=rank, world_size=world)  # RCCL over xGMI
+    # the ranks RCCL really connected: an all-reduce of ones
+    ones = torch.ones(1, device=device)
+    if dist.is_initialized():
+        dist.all_reduce(ones)
+    n_ranks_seen = int(ones.item())
 
     import sfhip
     from slowfast.utils.distributed import FlatGradients, max_over_ranks
@@ -194,6 +304,10 @@ def main():
         flat = FlatGradients(model.parameters())
         from slowfast.models import engine
         engine.set_grad_sink(os.environ.get("SF_NO_GRAD_SINK") != "1")  # backward kernels accumulate straight into the flat gradient buffer
+        if not args.no_overlap_allreduce:
+            # res5 + head, then res4 (+ s4_fuse): 85 % of the gradient bytes, final ~10 ms into the backward pass —
+            # their all-reduce runs on its own stream under the rest of the backward; the remainder after it
+            flat.overlap_with_backward(model, boundaries=("s5", "s4"))
         opt = torch.optim.SGD(model.parameters(), lr=1e-3, momentum=0.9, weight_decay=1e-4)
 
         def step():
@@ -298,7 +412,7 @@ def main():
     #      is the roofline object: algorithmic FLOPs or bytes of one launch / its average duration.
     roofline = None
     family_ms = None
-    if rank == 0 and not args.no_extras:
+    if not args.no_extras:  # every rank runs the traced steps (they carry the step's collective); rank 0 reports
         from slowfast.models import engine as _engine
         sfhip.EVENT_TRACE = []
         nsteps = min(args.steps, 3)
@@ -312,81 +426,82 @@ def main():
             torch.cuda.synchronize()
         finally:
             _engine.OVERLAP_PATHS = saved_overlap
-        per = {}
-        for tag, e0, e1 in sfhip.EVENT_TRACE:
-            per.setdefault(tag, []).append(e0.elapsed_time(e1) * 1e-3)
-        sfhip.EVENT_TRACE = None
-        tot = {tag: sum(v) for tag, v in per.items()}
-        fam = {}
-        for tag, v in tot.items():
-            f = "attention" if tag[0].startswith("attn") else tag[0]
-            fam[f] = fam.get(f, 0.0) + v
-        family_ms = {f: round(v / nsteps * 1e3, 3) for f, v in sorted(fam.items(), key=lambda kv: -kv[1])}
-        tag = max(tot, key=tot.get)
-        top_family = "attention" if tag[0].startswith("attn") else tag[0]
-        dur = float(np.mean(per[tag]))
-        if top_family == "attention":
-            kind, b, n, c = tag
-            # algorithmic FLOPs, one product = 2*N^2*C FLOP per clip.  Forward: QK^T + PV = 2.
-            # Backward: 5 products in total (S recompute, dP, dV, dK, dQ); the two-kernel, atomic-free split
-            # re-derives S and dP in both kernels (7 executed), so each kernel is credited only its share of the 5:
-            # dK/dV kernel = dV + dK + half of (S, dP) = 3, dQ kernel = dQ + the other half = 2.
-            # The single-sweep backward (attn_bwd_fused: dK/dV/dQ kernel + the dQ plane reduction, timed together)
-            # executes exactly the 5 algorithmic products.
-            nprod = {"attn": 2, "attn_bwd_dkv": 3, "attn_bwd_dq": 2, "attn_bwd_fused": 5}[kind]
-            executed = {"attn": 2, "attn_bwd_dkv": 4, "attn_bwd_dq": 3, "attn_bwd_fused": 5}[kind]
-            flops = nprod * 2.0 * b * n * n * c
-            ach = flops / dur / 1e12
-            kname = {"attn": "attn_fwd_kernel (flash SpatialAttention forward)",
-                     "attn_bwd_dkv": "attn_bwd_dkv_kernel (flash SpatialAttention backward, dK/dV)",
-                     "attn_bwd_dq": "attn_bwd_dq_kernel (flash SpatialAttention backward, dQ)",
-                     "attn_bwd_fused": "attn_bwd_fused_kernel + attn_dq_reduce_kernel (flash SpatialAttention "
-                                       "backward, dQ/dK/dV in one sweep)"}[kind]
-            traffic, traffic_src = None, None  # HBM bytes per launch: rocprofv3 PMC passes cannot run inside bench.py
-            try:
-                tj = json.load(open(os.path.join(ROOT, "profiles", "r02b_attention_hbm_traffic.json")))["kernels"]
-                if kind == "attn_bwd_fused" and c == 32 and n == 25088 and b == 8:
-                    # the sweep kernel + its three reductions (dQ partials: tiled kernel; dK parts, dV parts)
-                    g = -(-(b * n * 8) // 256) * 256
-                    sweep = [v for k, v in tj.items() if k.startswith("attn_bwd_fused_kernel<32, 4>")]
-                    traffic = (sweep[0]["hbm_bytes_per_launch"] + tj["attn_dq_reduce_tiled_kernel grid=%d" % g]["hbm_bytes_per_launch"]
-                               + 2 * tj["attn_dq_reduce_kernel grid=%d" % g]["hbm_bytes_per_launch"])
-                    traffic_src = "profiles/r02b_attention_hbm_traffic.json (rocprofv3 PMC passes FETCH_SIZE / WRITE_SIZE of " \
-                                  "the same kernels, tools/attn_traffic.sh; not measured in this run)"
-            except (OSError, KeyError, ValueError, IndexError):
-                traffic = None
-            roofline = {"bound": "mfma", "kernel": "%s C=%d N=%d B=%d" % (kname, c, n, b),
-                        "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                        "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "avg_launch_ms": round(dur * 1e3, 4),
-                        "launches_timed": len(per[tag]), "traffic": traffic, "traffic_source": traffic_src,
-                        "executed_mfma_tflops": round(ach * executed / nprod, 2)}
-        elif top_family == "conv":
-            _, m, k, n = tag
-            ach = 2.0 * m * k * n / dur / 1e12
-            # the conv family as a whole: algorithmic FLOPs of every traced launch / their summed durations
-            fl = sum(2.0 * t[1] * t[2] * t[3] * len(v) for t, v in per.items() if t[0] == "conv")
-            agg = fl / fam["conv"] / 1e12
-            roofline = {"bound": "mfma", "kernel": "conv_wave_kernel / conv_wgrad_wave_kernel (dense 3-D conv as "
-                        "implicit GEMM; forward, data- and weight-gradient launches of the shape positions=%d, "
-                        "taps*Cin=%d, Cout=%d)" % (m, k, n),
-                        "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                        "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "avg_launch_ms": round(dur * 1e3, 4),
-                        "launches_timed": len(per[tag]), "traffic": None,
-                        "conv_family": {"achieved": round(agg, 2), "frac": round(agg / PEAK_FP32_MFMA_TFLOPS, 4),
-                                        "note": "algorithmic FLOPs of ALL dense-conv launches of a step / the sum of "
-                                                "their HIP-event durations (conv-arithmetic roofline, SURVEY 8d)"}}
-        else:  # depthwise convs: HBM-bound
-            by = sum(t[1] * len(v) for t, v in per.items() if t[0] == "dwconv")
-            ach = by / fam["dwconv"] / 1e9
-            roofline = {"bound": "hbm", "kernel": "dwconv_kernel (depthwise 3-D conv, GhostNet / ShuffleNetV2 paths)",
-                        "achieved": round(ach, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 4),
-                        "launches_timed": sum(len(v) for t, v in per.items() if t[0] == "dwconv"), "traffic": None}
-        # the HBM-bound depthwise family beside the dominant one (cfg #5's "bandwidth-bound stress")
-        if "dwconv" in fam and roofline is not None and top_family != "dwconv":
-            by = sum(t[1] * len(v) for t, v in per.items() if t[0] == "dwconv")
-            roofline["dwconv_hbm"] = {"achieved": round(by / fam["dwconv"] / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
-                                      "frac": round(by / fam["dwconv"] / 1e9 / 8000.0, 4),
-                                      "ms_per_step": family_ms["dwconv"]}
+        trace, sfhip.EVENT_TRACE = sfhip.EVENT_TRACE, None
+        if rank == 0 and trace:
+            per = {}
+            for tag, e0, e1 in trace:
+                per.setdefault(tag, []).append(e0.elapsed_time(e1) * 1e-3)
+            tot = {tag: sum(v) for tag, v in per.items()}
+            fam = {}
+            for tag, v in tot.items():
+                f = "attention" if tag[0].startswith("attn") else tag[0]
+                fam[f] = fam.get(f, 0.0) + v
+            family_ms = {f: round(v / nsteps * 1e3, 3) for f, v in sorted(fam.items(), key=lambda kv: -kv[1])}
+            tag = max(tot, key=tot.get)
+            top_family = "attention" if tag[0].startswith("attn") else tag[0]
+            dur = float(np.mean(per[tag]))
+            if top_family == "attention":
+                kind, b, n, c = tag
+                # algorithmic FLOPs, one product = 2*N^2*C FLOP per clip.  Forward: QK^T + PV = 2.
+                # Backward: 5 products in total (S recompute, dP, dV, dK, dQ); the two-kernel, atomic-free split
+                # re-derives S and dP in both kernels (7 executed), so each kernel is credited only its share of the 5:
+                # dK/dV kernel = dV + dK + half of (S, dP) = 3, dQ kernel = dQ + the other half = 2.
+                # The single-sweep backward (attn_bwd_fused: dK/dV/dQ kernel + the dQ plane reduction, timed together)
+                # executes exactly the 5 algorithmic products.
+                nprod = {"attn": 2, "attn_bwd_dkv": 3, "attn_bwd_dq": 2, "attn_bwd_fused": 5}[kind]
+                executed = {"attn": 2, "attn_bwd_dkv": 4, "attn_bwd_dq": 3, "attn_bwd_fused": 5}[kind]
+                flops = nprod * 2.0 * b * n * n * c
+                ach = flops / dur / 1e12
+                kname = {"attn": "attn_fwd_kernel (flash SpatialAttention forward)",
+                         "attn_bwd_dkv": "attn_bwd_dkv_kernel (flash SpatialAttention backward, dK/dV)",
+                         "attn_bwd_dq": "attn_bwd_dq_kernel (flash SpatialAttention backward, dQ)",
+                         "attn_bwd_fused": "attn_bwd_fused_kernel + attn_dq_reduce_kernel (flash SpatialAttention "
+                                           "backward, dQ/dK/dV in one sweep)"}[kind]
+                traffic, traffic_src = None, None  # HBM bytes per launch: rocprofv3 PMC passes cannot run inside bench.py
+                try:
+                    tj = json.load(open(os.path.join(ROOT, "profiles", "r02b_attention_hbm_traffic.json")))["kernels"]
+                    if kind == "attn_bwd_fused" and c == 32 and n == 25088 and b == 8:
+                        # the sweep kernel + its three reductions (dQ partials: tiled kernel; dK parts, dV parts)
+                        g = -(-(b * n * 8) // 256) * 256
+                        sweep = [v for k, v in tj.items() if k.startswith("attn_bwd_fused_kernel<32, 4>")]
+                        traffic = (sweep[0]["hbm_bytes_per_launch"] + tj["attn_dq_reduce_tiled_kernel grid=%d" % g]["hbm_bytes_per_launch"]
+                                   + 2 * tj["attn_dq_reduce_kernel grid=%d" % g]["hbm_bytes_per_launch"])
+                        traffic_src = "profiles/r02b_attention_hbm_traffic.json (rocprofv3 PMC passes FETCH_SIZE / WRITE_SIZE of " \
+                                      "the same kernels, tools/attn_traffic.sh; not measured in this run)"
+                except (OSError, KeyError, ValueError, IndexError):
+                    traffic = None
+                roofline = {"bound": "mfma", "kernel": "%s C=%d N=%d B=%d" % (kname, c, n, b),
+                            "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                            "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "avg_launch_ms": round(dur * 1e3, 4),
+                            "launches_timed": len(per[tag]), "traffic": traffic, "traffic_source": traffic_src,
+                            "executed_mfma_tflops": round(ach * executed / nprod, 2)}
+            elif top_family == "conv":
+                _, m, k, n = tag
+                ach = 2.0 * m * k * n / dur / 1e12
+                # the conv family as a whole: algorithmic FLOPs of every traced launch / their summed durations
+                fl = sum(2.0 * t[1] * t[2] * t[3] * len(v) for t, v in per.items() if t[0] == "conv")
+                agg = fl / fam["conv"] / 1e12
+                roofline = {"bound": "mfma", "kernel": "conv_wave_kernel / conv_wgrad_wave_kernel (dense 3-D conv as "
+                            "implicit GEMM; forward, data- and weight-gradient launches of the shape positions=%d, "
+                            "taps*Cin=%d, Cout=%d)" % (m, k, n),
+                            "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                            "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "avg_launch_ms": round(dur * 1e3, 4),
+                            "launches_timed": len(per[tag]), "traffic": None,
+                            "conv_family": {"achieved": round(agg, 2), "frac": round(agg / PEAK_FP32_MFMA_TFLOPS, 4),
+                                            "note": "algorithmic FLOPs of ALL dense-conv launches of a step / the sum of "
+                                                    "their HIP-event durations (conv-arithmetic roofline, SURVEY 8d)"}}
+            else:  # depthwise convs: HBM-bound
+                by = sum(t[1] * len(v) for t, v in per.items() if t[0] == "dwconv")
+                ach = by / fam["dwconv"] / 1e9
+                roofline = {"bound": "hbm", "kernel": "dwconv_kernel (depthwise 3-D conv, GhostNet / ShuffleNetV2 paths)",
+                            "achieved": round(ach, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(ach / 8000.0, 4),
+                            "launches_timed": sum(len(v) for t, v in per.items() if t[0] == "dwconv"), "traffic": None}
+            # the HBM-bound depthwise family beside the dominant one (cfg #5's "bandwidth-bound stress")
+            if "dwconv" in fam and roofline is not None and top_family != "dwconv":
+                by = sum(t[1] * len(v) for t, v in per.items() if t[0] == "dwconv")
+                roofline["dwconv_hbm"] = {"achieved": round(by / fam["dwconv"] / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
+                                          "frac": round(by / fam["dwconv"] / 1e9 / 8000.0, 4),
+                                          "ms_per_step": family_ms["dwconv"]}
 
     if rank == 0:
         clips_total = batch * world * args.steps
@@ -422,13 +537,41 @@ def main():
             roofline["trace_schedule"] = "one stream (two-stream overlap off for the traced steps)"
             res["roofline"] = roofline
             res["kernel_family_ms_per_step"] = family_ms
+        res["n_ranks_seen"] = n_ranks_seen
+        if train:
+            res["allreduce"] = {"chunks_per_step": flat.chunks_last_step,
+                                "schedule": "one collective after the backward" if args.no_overlap_allreduce else
+                                "flat fp32 gradient in chunks [s5+head | s4+s4_fuse | rest] on a comm stream, each issued "
+                                "when its stages' backward is done, joined before the optimizer step",
+                                "bytes": int(flat.flat.numel() * 4)}
         if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"], fwd_err = cpu_baseline(args.workload, cfg, model, train, device)
-            # second half of BASELINE.json's metric: the HIP eval forward against the oracle's on the same full-size
-            # clip (batch 1), max|delta| / max|ref| over the output probabilities (north_star tolerance: 1e-3)
-            res["fwd_max_rel_err"] = None if fwd_err is None else float("%.3e" % fwd_err)
-            res["fwd_max_rel_err_note"] = "HIP eval forward vs oracle (CPU restatement of the reference), 1 clip of " \
-                                          "the benchmark shape; tolerance 1e-3"
+            def hip_train_step(xs, label):  # one HIP training step on the oracle's clip, dropout off (the oracle has none)
+                drops = [(m, m.p) for m in model.modules() if isinstance(m, torch.nn.Dropout)]
+                for m, _ in drops:
+                    m.p = 0.0
+                try:
+                    with torch.cuda.stream(side):
+                        flat.zero()
+                        logits = model(xs)
+                        loss = torch.nn.functional.cross_entropy(logits, label)
+                        loss.backward()
+                    torch.cuda.synchronize()
+                finally:
+                    for m, p_ in drops:
+                        m.p = p_
+                return float(loss), logits.detach(), {k: v.grad.detach().clone() for k, v in model.named_parameters()
+                                                      if v.grad is not None}
+
+            res["cpu_baseline"], parity = cpu_baseline(args.workload, cfg, model, train, device,
+                                                       hip_train_step if train else None)
+            # second half of BASELINE.json's metric: the HIP path against the oracle on the same full-size clip (batch 1).
+            # fwd_max_rel_err: max|delta| / max|ref| over the eval output probabilities; fwd_logits_max_rel_err: the
+            # same over the train-mode pre-activation logits (probabilities hide errors); bwd_*: relative
+            # L2 error of every parameter's gradient of the training step (north_star tolerance: 1e-3 on the forward)
+            for k, v in parity.items():
+                res[k] = float("%.3e" % v) if isinstance(v, float) else v
+            res["parity_note"] = "HIP vs oracle (CPU restatement of the reference), 1 clip of the benchmark shape; " \
+                                 "forward tolerance 1e-3; bwd_* = per-parameter relative L2 of the train step's gradients"
         print(json.dumps(res))
     if dist.is_initialized():
         dist.destroy_process_group()

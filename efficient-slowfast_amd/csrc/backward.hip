@@ -704,6 +704,61 @@ extern "C" int sf_eca_bwd_apply(const float* x, int cs, int coff, int N, int T, 
   return SF_OK;
 }
 
+// ECA's gate algebra on the [N, C] vectors (wdf_attention_helper.py:77-91, backward of conv1d(k=3, pad=1, no bias)
+// ALONG THE CHANNEL AXIS + sigmoid):  a = w (*) pooled,  gate = sigmoid(a),  da = dg * gate * (1 - gate),
+// dpool[c] = w0*da[c+1] + w1*da[c] + w2*da[c-1]  (conv_transpose1d),  dw[k] += sum_{b,c} da[b,c] * pooled[b,c+k-1].
+// One workgroup: N*C <= a few thousand elements; the three dw sums go through LDS in thread order (bit-reproducible).
+namespace {
+__device__ __forceinline__ float eca_da(const float* __restrict__ dg, const float* __restrict__ pooled, int b, int c,
+                                        int C, float w0, float w1, float w2, float* gate_out) {
+  if (c < 0 || c >= C) return 0.f;
+  const float* p = pooled + (long)b * C;
+  const float a = (c > 0 ? w0 * p[c - 1] : 0.f) + w1 * p[c] + (c + 1 < C ? w2 * p[c + 1] : 0.f);
+  const float g = 1.f / (1.f + expf(-a));
+  if (gate_out) *gate_out = g;
+  return dg[(long)b * C + c] * g * (1.f - g);
+}
+
+__global__ void eca_gate_bwd_kernel(const float* __restrict__ dg, const float* __restrict__ pooled,
+                                    const float* __restrict__ w3, int N, int C, float dpool_scale,
+                                    float* __restrict__ gate, float* __restrict__ dpool, float* __restrict__ dw3) {
+  __shared__ float red[3][TPB];
+  const float w0 = w3[0], w1 = w3[1], w2 = w3[2];
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+  for (int i = threadIdx.x; i < N * C; i += TPB) {
+    const int b = i / C, c = i - b * C;
+    float g;
+    const float da = eca_da(dg, pooled, b, c, C, w0, w1, w2, &g);
+    const float dam = eca_da(dg, pooled, b, c - 1, C, w0, w1, w2, nullptr);
+    const float dap = eca_da(dg, pooled, b, c + 1, C, w0, w1, w2, nullptr);
+    gate[i] = g;
+    dpool[i] = (w0 * dap + w1 * da + w2 * dam) * dpool_scale;
+    const float* p = pooled + (long)b * C;
+    s0 += c > 0 ? da * p[c - 1] : 0.f;
+    s1 += da * p[c];
+    s2 += c + 1 < C ? da * p[c + 1] : 0.f;
+  }
+  red[0][threadIdx.x] = s0;
+  red[1][threadIdx.x] = s1;
+  red[2][threadIdx.x] = s2;
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    float t = 0.f;
+    for (int i = 0; i < TPB; ++i) t += red[threadIdx.x][i];
+    dw3[threadIdx.x] += t;
+  }
+}
+}  // namespace
+
+extern "C" int sf_eca_gate_bwd(const float* dg, const float* pooled, const float* w3, int N, int C, float dpool_scale,
+                               float* gate, float* dpool, float* dw3, void* stream) {
+  if (!dg || !pooled || !w3 || !gate || !dpool || !dw3 || N <= 0 || C <= 0) return SF_EINVAL;
+  hipLaunchKernelGGL(eca_gate_bwd_kernel, dim3(1), dim3(TPB), 0, (hipStream_t)stream, dg, pooled, w3, N, C, dpool_scale,
+                     gate, dpool, dw3);
+  SF_CHECK_LAUNCH();
+  return SF_OK;
+}
+
 extern "C" int sf_bcast_add(float* g, int cs, int coff, int N, long rows_per_n, int C, const float* v, float scale,
                             void* stream) {
   if (!g || !v || N <= 0 || rows_per_n <= 0 || C <= 0) return SF_EINVAL;

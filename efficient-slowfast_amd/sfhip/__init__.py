@@ -47,7 +47,7 @@ EXPORTS = [
     "sf_pool_fwd", "sf_tmax_mean_ws_floats", "sf_tmax_mean", "sf_gate_apply", "sf_attn_fwd", "sf_head_act_mean",
     "sf_copy_channels", "sf_channel_stats_ws_floats", "sf_channel_stats", "sf_affine_fwd", "sf_bn_train_stats",
     "sf_conv_wgrad_splits", "sf_conv_wgrad", "sf_bn_bwd_ws_floats", "sf_bn_bwd_reduce", "sf_bn_bwd_apply",
-    "sf_attn_bwd", "sf_maxpool_bwd", "sf_tmax_dot", "sf_eca_bwd_apply", "sf_bcast_add", "sf_rowdot", "sf_axpy", "sf_act_bwd",
+    "sf_attn_bwd", "sf_maxpool_bwd", "sf_tmax_dot", "sf_eca_bwd_apply", "sf_eca_gate_bwd", "sf_bcast_add", "sf_rowdot", "sf_axpy", "sf_act_bwd",
     "sf_dwconv_dgrad", "sf_dwconv_wgrad_ws_floats", "sf_dwconv_wgrad", "sf_gather_add",
     "sf_bn_train_stats_split", "sf_affine_fwd_split", "sf_bn_bwd_reduce_split", "sf_bn_bwd_apply_split",
     "sf_clip_prologue", "sf_conv_wgrad_finish", "sf_bn_bwd_reduce_acc", "sf_row_softmax_fwd", "sf_row_softmax_bwd",
@@ -111,6 +111,7 @@ def lib():
         L.sf_maxpool_bwd.argtypes = [ctypes.POINTER(PoolDesc), vp, vp, vp, ci, ci, vp, ci, ci, vp]
         L.sf_tmax_dot.argtypes = [vp, ci, ci] + [ci] * 6 + [vp, ci, ci, vp, vp, vp]
         L.sf_eca_bwd_apply.argtypes = [vp, ci, ci] + [ci] * 6 + [vp, ci, ci, vp, vp, vp, ci, ci, vp]
+        L.sf_eca_gate_bwd.argtypes = [vp, vp, vp, ci, ci, cf, vp, vp, vp, vp]
         L.sf_bcast_add.argtypes = [vp, ci, ci, ci, cl, ci, vp, cf, vp]
         L.sf_rowdot.argtypes = [vp, ci, ci, vp, ci, ci, cl, ci, cf, vp, vp]
         L.sf_axpy.argtypes = [vp, ci, ci, cf, vp, ci, ci, cl, ci, ci, vp]
@@ -736,6 +737,16 @@ def eca_bwd_apply(x, alpha, dz, gate, dpool, dx):
     _check(lib().sf_eca_bwd_apply(x.ptr(), x.cs, x.coff, x.N, x.T, x.H, x.W, x.C, alpha, dz.ptr(), dz.cs, dz.coff,
                                   _ptr(gate), _ptr(dpool), dx.ptr(), dx.cs, dx.coff, _stream()), "sf_eca_bwd_apply")
     return dx
+
+
+def eca_gate_bwd(dg, pooled, w3, dpool_scale, dw3):
+    """(gate, dpool) of the ECA gate's backward on [N, C] vectors; dw3 (3 floats) is accumulated in place."""
+    n, c = pooled.shape
+    gate = torch.empty_like(pooled)
+    dpool = torch.empty_like(pooled)
+    _check(lib().sf_eca_gate_bwd(_ptr(dg), _ptr(pooled), _ptr(w3), n, c, float(dpool_scale), _ptr(gate), _ptr(dpool),
+                                 _ptr(dw3), _stream()), "sf_eca_gate_bwd")
+    return gate, dpool
 
 
 def bcast_add(g, v, scale):

@@ -126,6 +126,8 @@ class _EfficientTwoPathway(nn.Module):
             names = [n for n, _ in self.named_children()]
             for i, n in enumerate(names):
                 m = getattr(self, n)
+                if not n.endswith("_fuse"):
+                    engine.milestone(n)
                 if n == "head":
                     x = m(x)
                 elif n.endswith("_fuse"):

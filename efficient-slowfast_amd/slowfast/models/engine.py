@@ -122,6 +122,27 @@ def tape():
     return getattr(_tls, "tape", None)
 
 
+_MILESTONE_HOOK = None
+
+
+def set_milestone_hook(fn):
+    """fn(child_name, tape) is called DURING the backward pass at the point where every gradient of the top-level
+    child `child_name` and of all children after it has been issued (on the caller's stream, the side stream — joined
+    by then — or a companion stream listed in tape.joins).  utils.distributed.FlatGradients uses it to start the
+    all-reduce of the finished tail of the flat gradient buffer while the earlier stages' backward still runs (the
+    reference gets the same overlap from DistributedDataParallel's buckets, models/build.py:39-43)."""
+    global _MILESTONE_HOOK
+    _MILESTONE_HOOK = fn
+
+
+def milestone(name):
+    """Called by the models' _forward_impl in front of each top-level child."""
+    t = tape()
+    hook = _MILESTONE_HOOK
+    if t is not None and hook is not None:
+        t.record(lambda: hook(name, t))
+
+
 # ------------------------------------------------------------------------------------------------ two streams
 # The Slow and the Fast pathway are independent between lateral fusions, and so are the two directions of a CMDA
 # fusion: the Fast pathway is a string of small-channel, HBM-bound kernels (and tiny grids), the Slow pathway of

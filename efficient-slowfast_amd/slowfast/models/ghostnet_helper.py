@@ -34,14 +34,10 @@ class SqueezeExcite(nn.Module):
         self.conv_expand = nn.Conv3d(reduced_chs, in_chs, 1, bias=True)
 
     def forward(self, x):
-        import torch.nn.functional as F
         pooled = engine.global_mean(x)                                   # [N,1,1,1,C] (HIP reduction, taped)
-        cr, ce = self.conv_reduce, self.conv_expand
-        # the two FCs act on [N, C] vectors: parameter-sized algebra (torch), gate applied by the HIP kernel
-        e = engine.small_torch_op(
-            [pooled], [cr.weight, cr.bias, ce.weight, ce.bias],
-            lambda f: F.linear(F.relu(F.linear(f[0], cr.weight.view(cr.out_channels, -1), cr.bias)),
-                               ce.weight.view(ce.out_channels, -1), ce.bias))
+        # the two FCs act on [N, C] vectors: 1x1x1 convs over N rows on the library's own GEMM kernels (forward, data
+        # and weight gradients) — no vendor BLAS launch in the step; the gate is applied by the HIP kernel below
+        e = engine.conv_bn_act(engine.conv_bn_act(pooled, self.conv_reduce, relu=True), self.conv_expand)
         y = sfhip.gate_apply(x, 1, e.buf.view(x.N, x.C), w3=None)       # x * hard_sigmoid(e)
         t = engine.tape()
         if t is not None:

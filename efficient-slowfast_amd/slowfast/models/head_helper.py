@@ -229,11 +229,9 @@ class GhostNetBasicHead(nn.Module):
         for x, stage5, conv_head in ((xs[0], self.stage5_conv_slow, self.conv_head_slow),
                                      (xs[1], self.stage5_conv_fast, self.conv_head_fast)):
             y = _global_mean(stage5(x))
-            # conv_head (+bias) + ReLU on the pooled [N, C] features: parameter-sized
-            z = engine.small_torch_op(
-                [y], [conv_head.weight, conv_head.bias],
-                lambda f, cv=conv_head: F.relu(F.linear(f[0], cv.weight.view(cv.out_channels, -1), cv.bias)))
-            engine.copy_channels(z, cat.slice(off, conv_head.out_channels))
+            # conv_head (+bias) + ReLU on the pooled [N, C] features: a 1x1x1 conv over N rows on the library's GEMM
+            # kernels, written straight into its slice of the concatenated feature vector
+            engine.conv_bn_act(y, conv_head, relu=True, out=cat.slice(off, conv_head.out_channels))
             off += conv_head.out_channels
         logits = _project(cat, self.classifier[1], self.classifier[0], self.training)
         return _finish(logits, self.training, "relu")

@@ -152,10 +152,13 @@ class _TwoPathwayResNet(nn.Module):
                 ks = pool.kernel_size if isinstance(pool.kernel_size, (list, tuple)) else [pool.kernel_size] * 3
                 if list(ks) != [1, 1, 1]:  # _POOL1["slowfast"] is the identity (elided)
                     x[pathway] = engine.maxpool(x[pathway], tuple(ks), tuple(ks))
+            engine.milestone("s3")  # backward: the gradients of s3 .. head are complete here (chunked all-reduce)
             x = self.s3(x, reserve=self.s3_fuse.reserve(None))
             x = self._fuse(self.s3_fuse, x)
+            engine.milestone("s4")
             x = self.s4(x, reserve=self.s4_fuse.reserve(None))
             x = self._fuse(self.s4_fuse, x)
+            engine.milestone("s5")
             x = self.s5(x)
             x = self.head(x)
         return x
@@ -250,8 +253,11 @@ class ResNet(nn.Module):
             ks = tuple(ks) if isinstance(ks, (list, tuple)) else (ks,) * 3
             if ks != (1, 1, 1):
                 x[0] = engine.maxpool(x[0], ks, ks)
+            engine.milestone("s3")
             x = self.s3(x)
+            engine.milestone("s4")
             x = self.s4(x)
+            engine.milestone("s5")
             x = self.s5(x)
             x = self.head(x)
         return x

@@ -105,18 +105,15 @@ class ECA(nn.Module):
             w3 = self.conv.weight
 
             def bwd():  # z's buffer holds dL/dz (BN backward wrote it in place)
-                import torch.nn.functional as F
                 dg = sfhip.tmax_dot(x, alpha, z)                       # [N, C] = sum dz * max_r x
-                w = w3.detach()
-                a = F.conv1d(pooled.unsqueeze(1), w, None, 1, 1).squeeze(1)
-                gate = torch.sigmoid(a)
-                da = dg * gate * (1.0 - gate)
-                dpool = F.conv_transpose1d(da.unsqueeze(1), w, None, 1, 1).squeeze(1)
-                pp = F.pad(pooled, (1, 1))
-                C = pooled.shape[1]
-                t.add_pgrad(w3, torch.stack([(da * pp[:, kk:kk + C]).sum() for kk in range(3)]))
                 count = float((x.T // alpha) * x.H * x.W)
-                sfhip.eca_bwd_apply(x, alpha, z, gate.contiguous(), (dpool / count).contiguous(), t.grad_of(x))
+                tgt = t.pgrad_target(w3)
+                dw = tgt if tgt is not None else torch.zeros(3, dtype=torch.float32, device=dg.device)
+                # the 3-tap gate's derivative on the [N, C] vectors: one small HIP launch (no vendor conv kernels)
+                gate, dpool = sfhip.eca_gate_bwd(dg, pooled, w3.detach().contiguous(), 1.0 / count, dw)
+                if tgt is None:
+                    t.add_pgrad(w3, dw)
+                sfhip.eca_bwd_apply(x, alpha, z, gate, dpool, t.grad_of(x))
 
             t.record(bwd)
         return z

@@ -281,6 +281,13 @@ int sf_eca_bwd_apply(const float* x, int cs, int coff, int N, int T, int H, int 
                      const float* dz, int dz_cs, int dz_coff, const float* gate, const float* dpool, float* dx,
                      int dx_cs, int dx_coff, void* stream);
 
+/* ECA's gate algebra on [N, C] vectors — backward of Conv1d(1,1,k=3,pad=1,bias=False) along the channel axis +
+ * sigmoid (reference wdf_attention_helper.py:68-69, 83-88; replaces the F.conv1d / conv_transpose1d calls autograd
+ * would make): gate = sigmoid(w3 (*) pooled), da = dg*gate*(1-gate), dpool = dpool_scale * convT(da, w3),
+ * dw3[k] += sum da * shift_k(pooled).  dg = sf_tmax_dot's output; gate / dpool feed sf_eca_bwd_apply.        */
+int sf_eca_gate_bwd(const float* dg, const float* pooled, const float* w3, int N, int C, float dpool_scale,
+                    float* gate, float* dpool, float* dw3, void* stream);
+
 /* Depthwise conv backward (`d` = forward descriptor, weights [taps][C]): dx accumulates; dw [taps][C] through
  * a fixed-count partial workspace (sf_dwconv_wgrad_ws_floats).                                           */
 int sf_dwconv_dgrad(const sf_conv_desc* d, const float* dz, int dz_cs, int dz_coff, const float* w_packed,

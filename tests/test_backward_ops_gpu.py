@@ -238,21 +238,19 @@ def test_eca_backward(c, alpha):
     y = oracle.eca({"m.conv.weight": w3}, "m", mx)
     dy = torch.randn(y.shape, generator=g)
     dx_ref, dw_ref = torch.autograd.grad(y, (x, w3), dy)
-    # HIP path: reductions on the GPU, the [N, C]-sized gate algebra in torch (parameter-sized plumbing)
+    # HIP path: reductions on the GPU and the [N, C]-sized gate algebra in ONE small HIP launch (sf_eca_gate_bwd)
     xa, dza = _act(x), _act(dy)
     pooled = sfhip.tmax_mean(xa, alpha)
     dg = sfhip.tmax_dot(xa, alpha, dza)
     w = w3.detach().to(dev)
-    a = F.conv1d(pooled.unsqueeze(1), w, None, 1, 1).squeeze(1)
-    gate = torch.sigmoid(a)
-    da = dg * gate * (1 - gate)
-    dpool = F.conv_transpose1d(da.unsqueeze(1), w, None, 1, 1).squeeze(1)
-    dw = torch.stack([(da * F.pad(pooled, (1, 1))[:, kk:kk + c]).sum() for kk in range(3)]).view(1, 1, 3)
     count = (8 // alpha) * 5 * 7
+    dw = torch.full((3,), 0.5, device=dev)  # accumulated in place on top of what is there
+    gate, dpool = sfhip.eca_gate_bwd(dg, pooled, w.contiguous(), 1.0 / count, dw)
+    assert _rel(gate, torch.sigmoid(F.conv1d(pooled.unsqueeze(1), w, None, 1, 1).squeeze(1))) < 1e-6
     dx = sfhip.Act(torch.zeros(2, 8, 5, 7, c, device=dev))
-    sfhip.eca_bwd_apply(xa, alpha, dza, gate.contiguous(), (dpool / count).contiguous(), dx)
+    sfhip.eca_bwd_apply(xa, alpha, dza, gate, dpool, dx)
     torch.cuda.synchronize()
-    e1, e2 = _rel(_back(dx), dx_ref), _rel(dw, dw_ref)
+    e1, e2 = _rel(_back(dx), dx_ref), _rel((dw - 0.5).view(1, 1, 3), dw_ref)
     _report("eca_bwd c%d a%d" % (c, alpha), max(e1, e2))
     assert e1 < TOL and e2 < TOL, (e1, e2)
 

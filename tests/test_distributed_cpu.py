@@ -121,3 +121,100 @@ def _gather_worker(rank, world, port):
 def test_sync_bn_group_gather_world2():
     """GroupGather semantics (batchnorm_helper.py:112-171) and the per-node process group on 2 gloo ranks."""
     mp.spawn(_gather_worker, args=(2, _free_port()), nprocs=2, join=True)
+
+
+class _Staged(torch.nn.Module):
+    """Top-level children named like the models' (s3, s4, s5, head): what FlatGradients cuts the flat buffer at."""
+
+    def __init__(self):
+        super(_Staged, self).__init__()
+        torch.manual_seed(1)
+        self.s3 = torch.nn.Linear(6, 7)
+        self.s4 = torch.nn.Linear(7, 9)
+        self.s4_fuse = torch.nn.Linear(9, 9)
+        self.s5 = torch.nn.Linear(9, 8)
+        self.head = torch.nn.Linear(8, 5)
+
+    def forward(self, x):
+        return self.head(torch.relu(self.s5(self.s4_fuse(torch.relu(self.s4(torch.relu(self.s3(x))))))))
+
+
+def _chunk_worker(rank, world, port, out):
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                    "efficient-slowfast_amd"))
+    from slowfast.models import engine
+    from slowfast.utils.distributed import FlatGradients
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    try:
+        results = []
+        for chunked in (False, True):
+            model = _Staged()
+            flat = FlatGradients(model.parameters())
+            if chunked:
+                flat.overlap_with_backward(model, boundaries=("s5", "s4"))
+                engine.set_grad_sink(True)
+            g = torch.Generator().manual_seed(11 + rank)
+            x, y = torch.randn(3, 6, generator=g), torch.randint(0, 5, (3,), generator=g)
+            flat.zero()
+            torch.nn.functional.cross_entropy(model(x), y).backward()
+            if chunked:  # what the tape's milestones do during the HIP backward, in backward order
+                assert flat._cuts["s4"] < flat._cuts["s5"] < flat.flat.numel()
+                engine._MILESTONE_HOOK("s5", None)
+                engine._MILESTONE_HOOK("s4", None)
+                engine._MILESTONE_HOOK("s3", None)  # not a boundary: nothing happens
+                assert len(flat._pending) == 2 and flat._hi == flat._cuts["s4"]
+            flat.all_reduce_mean()
+            assert flat.chunks_last_step == (3 if chunked else 1)
+            assert flat._hi == flat.flat.numel() and not flat._pending
+            results.append(flat.flat.clone())
+            engine.set_grad_sink(False)
+            engine.set_milestone_hook(None)
+        assert torch.equal(results[0], results[1]), "chunked all-reduce differs from the single collective"
+        if rank == 0:
+            torch.save(results[1], out)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_chunked_allreduce_equals_single_collective_world2(tmp_path):
+    """The overlapped schedule (chunks [s5+head | s4+s4_fuse | rest]) is bit-identical to ONE all-reduce of the flat
+    buffer, and both equal the mean of the two ranks' gradients."""
+    out = str(tmp_path / "g.pt")
+    mp.spawn(_chunk_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    got = torch.load(out)
+    grads = []
+    for r in range(2):
+        model = _Staged()
+        g = torch.Generator().manual_seed(11 + r)
+        x, y = torch.randn(3, 6, generator=g), torch.randint(0, 5, (3,), generator=g)
+        torch.nn.functional.cross_entropy(model(x), y).backward()
+        grads.append(torch.cat([p.grad.reshape(-1) for p in model.parameters()]))
+    assert torch.allclose(got, (grads[0] + grads[1]) / 2, atol=1e-7)
+
+
+def _run_bench(args, env=None):
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    e = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        e.pop(k, None)
+    e.update(env or {})
+    return subprocess.run([sys.executable, os.path.join(root, "bench.py")] + args, env=e, capture_output=True,
+                          text=True, timeout=300)
+
+
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher: the parent starts one child per rank, rank 0's JSON line is the
+    command's output, and every rank took part in the collective (the launcher contract, checked without a GPU)."""
+    import json
+    r = _run_bench(["--gpus", "2", "--spawn-selftest"])
+    assert r.returncode == 0, r.stderr
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    assert json.loads(line) == {"selftest": True, "n_gpus": 2, "n_ranks_seen": 2}
+
+
+def test_bench_launcher_reports_a_failed_rank():
+    r = _run_bench(["--gpus", "2", "--spawn-selftest"], env={"SF_SELFTEST_FAIL_RANK": "1"})
+    assert r.returncode == 3
