@@ -269,7 +269,7 @@ def main():
         if "RANK" not in os.environ and args.gpus > 1:
             raise SystemExit(spawn_ranks(args.gpus, sys.argv[1:]))
         return spawn_selftest(rank, world)
-    if args.gpus > 1 and "RANK" not in os.environ:
+    if (args.gpus > 1 or os.environ.get("SF_BENCH_FORCE_SPAWN") == "1") and "RANK" not in os.environ:
         # called directly: become the launcher.  Nothing in this process has touched the GPU yet (no HIP call, no
         # torch.cuda.is_available()), and it never will: the children do the work
         raise SystemExit(spawn_ranks(args.gpus, sys.argv[1:]))

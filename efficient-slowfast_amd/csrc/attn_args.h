@@ -20,11 +20,17 @@ struct SfAttnArgs {
   float soft_t;    // attn_fwd_kernel: log2 headroom of the stale softmax reference (set by its launcher)
 };
 
-// log2 headroom of the stale softmax reference (SF_ATTN_SOFT_T, default 64: 2^(s - m_ref) stays far inside fp32)
+// log2 headroom of the stale softmax reference (SF_ATTN_SOFT_T, default 64: 2^(s - m_ref) stays far inside fp32).
+// Clamped to [8, 80]: a row sums up to N <= 2^17 terms of at most 2^t, so t <= 80 keeps the sum below 2^97 (fp32 max
+// 2^128); below 8 nearly every tile would refresh.  Unparsable / NaN values fall back to the default.
 static inline float sf_attn_soft_t() {
   static const float t = [] {
     const char* e = getenv("SF_ATTN_SOFT_T");
-    return e ? (float)atof(e) : 64.f;
+    if (!e) return 64.f;
+    char* end = nullptr;
+    const float v = strtof(e, &end);
+    if (end == e || !(v == v)) return 64.f;
+    return v < 8.f ? 8.f : (v > 80.f ? 80.f : v);
   }();
   return t;
 }

@@ -520,7 +520,9 @@ int sf_conv_wave_try(const sf_conv_desc* d, const float* in, const float* w_pack
     }
   }
   const WaveCfg& c = CFGS[best];
-  if (g_force_rows > 0 && g_force_rows <= c.tm * 16) best_rows = g_force_rows;
+  // the microbenchmark knob (sf_conv_tune(2, rows)) must not shrink tiles below what sf_conv_wave_max_parts sized the
+  // statistics workspace for: ignored when this launch leaves statistics
+  if (g_force_rows > 0 && g_force_rows <= c.tm * 16 && !(stats && stat_parts)) best_rows = g_force_rows;
   a.rows = best_rows;
   a.nb_n = sf_cdiv(d->Cout, c.tn * 16);
   a.ntiles = sf_cdiv(M, a.rows) * a.nb_n;

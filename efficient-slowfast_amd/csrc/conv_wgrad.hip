@@ -703,7 +703,11 @@ static bool stem_plan(const sf_conv_desc* d, int dz_cs, StemArgs* q) {
   static const bool nopair = [] { const char* e = getenv("SF_STEM_PAIR"); return e && e[0] == '0'; }();
   // pair form: the window of the last pair (28 + 8 floats from its first position) stays inside the staged slab
   const int nk = ((d->Wo + 1) / 2 + 3) / 4;
-  const bool pair = !nopair && ps == 8 && d->Cin <= 28 && d->Cout <= STEM_CO && nk * 64 <= 1024;
+  // (pair p starts at float 16 p of the row and reads 36 floats: 16 (npair - 1) + 36 <= rowf, else the last pair of
+  // an odd-Wo row would run into the next kh row of the slab — fall back to the one-position form)
+  const int npair = (d->Wo + 1) / 2;
+  const bool pair = !nopair && ps == 8 && d->Cin <= 28 && d->Cout <= STEM_CO && nk * 64 <= 1024 &&
+                    16L * (npair - 1) + 36 <= rowf;
   if (q) {
     q->rowf = rowf; q->ps = ps; q->nblk = pair ? nk : nblk;
     q->pair = pair ? 1 : 0;

@@ -735,14 +735,19 @@ def run_model(model, x):
     """model.forward body shared by all model classes: taped when training with grad enabled."""
     global _NBT
     outer, _NBT = _NBT, []
-    serial = model.__dict__.get("_sf_serial_streams")
-    if serial is None:  # collective-carrying layers (Sync-BN over > 1 local rank): one stream for this model only
-        from slowfast.utils import distributed as du
-        serial = du.get_local_size() > 1 and any(getattr(m, "_sf_collective", False) for m in model.modules())
-        model.__dict__["_sf_serial_streams"] = serial
+    # collective-carrying layers (Sync-BN over > 1 local rank): one stream for this model only.  The decision depends on
+    # the process group's state, so the cache is keyed on it (a forward before init_process_group must not pin False)
+    from slowfast.utils import distributed as du
+    local_size = du.get_local_size()
+    cached = model.__dict__.get("_sf_serial_streams")
+    if cached is None or cached[0] != local_size:
+        serial = local_size > 1 and any(getattr(m, "_sf_collective", False) for m in model.modules())
+        model.__dict__["_sf_serial_streams"] = (local_size, serial)
         if serial and OVERLAP_PATHS:
             print("[sfhip] %s holds Sync-BN layers over %d local ranks: its pathways run on one stream (collectives "
-                  "stay in program order)" % (type(model).__name__, du.get_local_size()))
+                  "stay in program order)" % (type(model).__name__, local_size))
+    else:
+        serial = cached[1]
     outer_serial, _tls.serial = getattr(_tls, "serial", False), serial
     try:
         if model.training and torch.is_grad_enabled():

@@ -34,9 +34,8 @@ def update_bn_stats(model, data_loader, num_iters=200):
         for i, bn in enumerate(layers):
             mean[i] += (bn.running_mean - mean[i]) / (ind + 1)
             var[i] += (bn.running_var - var[i]) / (ind + 1)
-    assert ind == num_iters - 1, (
-        "update_bn_stats is meant to run for {} iterations, but the dataloader stops at {} iterations.".format(
-            num_iters, ind))
+    if ind != num_iters - 1:
+        raise AssertionError("precise-BN pass: the loader ran dry after %d of the %d batches asked for" % (ind + 1, num_iters))
     for i, bn in enumerate(layers):
         bn.running_mean = mean[i]
         bn.running_var = var[i]
