@@ -22,6 +22,21 @@ import math
 import torch
 import torch.nn.functional as F
 
+# Test aid: ACT_HOOK(kind, x) -> tensor or None, kind in {"relu", "relu6"}.  The gradient tests hand the oracle the
+# activation masks of the HIP forward (y = x * mask), so that both sides differentiate the SAME piecewise-linear
+# function: a pre-activation within fp32 rounding of zero otherwise lands on different sides of the kink in the two
+# implementations and moves every upstream gradient (tests/_masks.py).  None (default) = plain F.relu / F.relu6.
+ACT_HOOK = None
+
+
+def _relu(x):
+    if ACT_HOOK is not None:
+        y = ACT_HOOK("relu", x)
+        if y is not None:
+            return y
+    return F.relu(x)
+
+
 # ----------------------------------------------------------------------------- tables
 # video_model_builder.py:16-17 / custom_video_model_builder.py:151-152
 MODEL_STAGE_DEPTH = {50: (3, 4, 6, 3), 101: (3, 4, 23, 3), 18: (2, 2, 2, 2), 34: (3, 4, 6, 3)}
@@ -98,7 +113,7 @@ def _conv(sd, p, x, stride=1, padding=0, dilation=1, groups=1):
 def resnet_basic_stem(sd, p, x, kt, training):
     """stem_helper.py:153-178: conv [kt,7,7]/s(1,2,2)/p(kt//2,3,3) → BN → ReLU → maxpool 1x3x3/2."""
     x = _conv(sd, p + ".conv", x, (1, 2, 2), (kt // 2, 3, 3))
-    x = F.relu(_bn(sd, p + ".bn", x, training))
+    x = _relu(_bn(sd, p + ".bn", x, training))
     return F.max_pool3d(x, (1, 3, 3), (1, 2, 2), (0, 1, 1))
 
 
@@ -106,7 +121,7 @@ def basic_transform(sd, p, x, kt, stride, training):
     """resnet_helper.py:25-107 (BasicTransform._construct :71-96, forward :98-106): [kt,3,3] conv / s(1,s,s) /
     p(kt//2,1,1) -> BN -> ReLU -> [1,3,3] conv / p(0,1,1) -> BN (no final ReLU: ResBlock adds the shortcut first)."""
     x = _conv(sd, p + ".a", x, (1, stride, stride), (kt // 2, 1, 1))
-    x = F.relu(_bn(sd, p + ".a_bn", x, training))
+    x = _relu(_bn(sd, p + ".a_bn", x, training))
     x = _conv(sd, p + ".b", x, 1, (0, 1, 1))
     return _bn(sd, p + ".b_bn", x, training)
 
@@ -114,10 +129,10 @@ def basic_transform(sd, p, x, kt, stride, training):
 def bottleneck(sd, p, x, kt, stride, groups, dilation, training):
     """resnet_helper.py:169-240.  SlowFast* never pass stride_1x1 → stride sits on the 3x3."""
     x = _conv(sd, p + ".a", x, 1, (kt // 2, 0, 0))
-    x = F.relu(_bn(sd, p + ".a_bn", x, training))
+    x = _relu(_bn(sd, p + ".a_bn", x, training))
     x = _conv(sd, p + ".b", x, (1, stride, stride), (0, dilation, dilation),
               (1, dilation, dilation), groups)
-    x = F.relu(_bn(sd, p + ".b_bn", x, training))
+    x = _relu(_bn(sd, p + ".b_bn", x, training))
     x = _conv(sd, p + ".c", x)
     return _bn(sd, p + ".c_bn", x, training)
 
@@ -130,7 +145,7 @@ def res_block(sd, p, x, kt, stride, groups, dilation, training):
         sc = _bn(sd, p + ".branch1_bn", _conv(sd, p + ".branch1", x, (1, stride, stride)), training)
     else:
         sc = x
-    return F.relu(sc + f)
+    return _relu(sc + f)
 
 
 def nonlocal_block(sd, p, x, pool_size, instantiation, training):
@@ -190,7 +205,7 @@ def fuse_fast_to_slow(sd, p, xs, hp, training):
     """video_model_builder.py:128-150: conv [K,1,1]/s(alpha,1,1)/p(K//2) → BN → ReLU → cat on slow."""
     k = hp["fusion_kernel"]
     f = _conv(sd, p + ".conv_f2s", xs[1], (hp["alpha"], 1, 1), (k // 2, 0, 0))
-    f = F.relu(_bn(sd, p + ".bn", f, training))
+    f = _relu(_bn(sd, p + ".bn", f, training))
     return [torch.cat([xs[0], f], 1), xs[1]]
 
 
@@ -221,11 +236,11 @@ def fuse_fast_and_slow(sd, p, xs, hp, training):
     x_s, x_f = xs
     f2s = F.max_pool3d(x_f, (a, 1, 1), (a, 1, 1))
     f2s = eca(sd, p + ".attention_channel_f2s", f2s)
-    f2s = F.relu(_bn(sd, p + ".bn_f2s", f2s, training))
+    f2s = _relu(_bn(sd, p + ".bn_f2s", f2s, training))
     s_out = torch.cat([x_s, f2s], 1)
     s2f = _conv(sd, p + ".downsample_c_of_slow", x_s)
     s2f = spatial_attention(sd, p + ".attention_spatial_s2f", s2f)
-    s2f = F.relu(_bn(sd, p + ".bn_s2f", s2f, training))
+    s2f = _relu(_bn(sd, p + ".bn_s2f", s2f, training))
     s2f = s2f.repeat_interleave(a, dim=2)  # nn.Upsample(scale=(a,1,1), nearest)
     f_out = torch.cat([s2f, x_f], 1)  # slow-derived channels FIRST (:146)
     return [s_out, f_out]
@@ -240,7 +255,7 @@ def _head_tail(x, training, act):
         elif act == "sigmoid":
             x = torch.sigmoid(x)
         elif act == "relu":
-            x = F.relu(x)
+            x = _relu(x)
         x = x.mean((1, 2, 3))
     return x.reshape(x.shape[0], -1)
 
@@ -339,7 +354,7 @@ def channel_shuffle(x, groups):
 def _seq_conv_bn(sd, p, i, x, training, relu, stride=1, padding=0, groups=1):
     """conv at Sequential index i, BN at i+1 (hard-coded nn.BatchNorm3d, eps 1e-5)."""
     x = _bn(sd, "%s.%d" % (p, i + 1), _conv(sd, "%s.%d" % (p, i), x, stride, padding, 1, groups), training)
-    return F.relu(x) if relu else x
+    return _relu(x) if relu else x
 
 
 def shufflev2_block(sd, p, x, stride, training):
@@ -445,7 +460,7 @@ def ghost_bottleneck(sd, p, x, k, mid, out, se_ratio, stride, training):
         y = _bn(sd, p + ".bn_dw", _conv(sd, p + ".conv_dw", y, (1, stride, stride), (0, pad, pad), 1, mid), training)
     if se_ratio is not None and se_ratio > 0:  # SqueezeExcite :34-52, hard_sigmoid gate :27-31
         s = y.mean((2, 3, 4), keepdim=True)
-        s = F.relu(_conv(sd, p + ".se.conv_reduce", s))
+        s = _relu(_conv(sd, p + ".se.conv_reduce", s))
         s = _conv(sd, p + ".se.conv_expand", s)
         y = y * (F.relu6(s + 3.0) / 6.0)
     y = ghost_module(sd, p + ".ghost2", y, out, False, training)
@@ -484,9 +499,9 @@ def ghostnet_forward(sd, inputs, hp, training=False):
             x = _mark(sd, acts, "s%d_fuse" % (st + 1), x)
     pooled = []  # head_helper.py:630-700
     for pw, nm in enumerate(("slow", "fast")):
-        z = F.relu(_bn(sd, "head.stage5_conv_%s.bn1" % nm, _conv(sd, "head.stage5_conv_%s.conv" % nm, x[pw]), training))
+        z = _relu(_bn(sd, "head.stage5_conv_%s.bn1" % nm, _conv(sd, "head.stage5_conv_%s.conv" % nm, x[pw]), training))
         z = z.mean((2, 3, 4), keepdim=True)
-        pooled.append(F.relu(_conv(sd, "head.conv_head_%s" % nm, z)))
+        pooled.append(_relu(_conv(sd, "head.conv_head_%s" % nm, z)))
     z = torch.cat(pooled, 1).permute(0, 2, 3, 4, 1)
     logits = F.linear(z, sd["head.classifier.1.weight"], sd["head.classifier.1.bias"])
     # head_helper.py:640-643 vs :653 — self.act (softmax) is overwritten by nn.ReLU: eval output is
@@ -505,6 +520,10 @@ MOBILENETV2_FUSE_AFTER = {"s2": "s3_fuse", "s4": "s4_fuse", "s5": "s5_fuse", "s7
 
 
 def _relu6(x):
+    if ACT_HOOK is not None:
+        y = ACT_HOOK("relu6", x)
+        if y is not None:
+            return y
     return F.relu6(x)
 
 
@@ -579,14 +598,14 @@ def shufflenet_bottleneck(sd, p, x, stride, groups, training):
     1x1-conv + AvgPool3d((1,3,3),(1,2,2),(0,1,1)) shortcut, stride 1 adds the identity; ReLU last."""
     g1 = 1 if x.shape[1] == 24 else groups
     mid = sd[p + ".conv1.weight"].shape[0]
-    out = F.relu(_bn(sd, p + ".bn1", _conv(sd, p + ".conv1", x, groups=g1), training))
+    out = _relu(_bn(sd, p + ".bn1", _conv(sd, p + ".conv1", x, groups=g1), training))
     out = _channel_shuffle(out, groups)
     out = _bn(sd, p + ".bn2", _conv(sd, p + ".conv2", out, (1, stride, stride), 1, 1, mid), training)
     out = _bn(sd, p + ".bn3", _conv(sd, p + ".conv3", out, groups=groups), training)
     if stride == 2:
         sc = F.avg_pool3d(_conv(sd, p + ".shortcut.0", x), (1, 3, 3), (1, 2, 2), (0, 1, 1))
-        return F.relu(torch.cat([out, sc], 1))
-    return F.relu(out + x)
+        return _relu(torch.cat([out, sc], 1))
+    return _relu(out + x)
 
 
 def shufflenet_forward(sd, inputs, hp, training=False):
@@ -598,7 +617,7 @@ def shufflenet_forward(sd, inputs, hp, training=False):
     x = []
     for pw in range(2):  # stem_helper.py:274-306
         q = "s1.pathway%d_stem" % pw
-        z = F.relu(_bn(sd, q + ".1", _conv(sd, q + ".0", inputs[pw], (1, 2, 2), 1), training))
+        z = _relu(_bn(sd, q + ".1", _conv(sd, q + ".0", inputs[pw], (1, 2, 2), 1), training))
         x.append(F.max_pool3d(z, 3, (1, 2, 2), 1))
     x = _mark(sd, acts, "s1", x)
     x = fuse_fast_and_slow(sd, "s1_fuse", x, hp, training)

@@ -1,0 +1,103 @@
+"""Activation-mask injection for gradient parity (test infrastructure).
+
+A ReLU network's gradient is discontinuous in its activations: a pre-activation within fp32 rounding of zero lands on
+different sides of the kink in two correct implementations, and ONE such flip moves that tensor's gradient by
+1/sqrt(numel) and everything upstream with it.  Summed over ~100 ReLU layers that is a 1-3 % relative-L2 floor that does
+not shrink with tensor size (flips per tensor grow with numel, the share of one flip falls with it) — measured: HIP vs
+oracle at 224^2, forward equal to 5e-6, gradients 2.9e-2 median.  To compare the backward ARITHMETIC the oracle is
+handed the HIP forward's masks (y = x * mask), so both sides differentiate the same piecewise-linear function.
+
+capture():  context that records, in issue order, the mask of every ReLU / ReLU6 output the HIP engine produces in a
+            training forward (engine.bn_train_apply and the bare conv+ReLU of engine.conv_bn_act).
+inject(m):  context that sets oracle.ACT_HOOK to replay them, matched by NCTHW shape in FIFO order (within one shape
+            both sides visit the layers in the same order: blocks of a pathway are sequential, and the pathways /
+            fusion directions never share a shape)."""
+import collections
+import contextlib
+
+import torch
+
+
+class Masks(object):
+    def __init__(self):
+        self.by_shape = collections.defaultdict(collections.deque)
+        self.count = 0
+        self.used = 0
+        self.dropped = 0
+        self.missed = []
+
+    def add(self, y_ncthw, relu):
+        m = y_ncthw > 0
+        if relu in (6, "relu6"):
+            m &= y_ncthw < 6
+        self.by_shape[tuple(m.shape)].append(m.cpu())
+        self.count += 1
+
+    def fork(self):
+        """A fresh replay cursor over the same masks (the oracle starts every child evaluation from the first layer)."""
+        m = Masks()
+        for k, q in self.by_shape.items():
+            m.by_shape[k] = collections.deque(q)
+        m.count = self.count
+        return m
+
+    def hook(self, kind, x):
+        """x * (the next captured mask of this shape).  A captured mask must agree with the oracle's own on all but a
+        few elements (they differ only where a pre-activation sits within rounding of the kink): one that does not is
+        a mask of another layer (a capture the oracle never asks for in this form, e.g. the two halves of ShuffleNet's
+        relu(cat[a, b])) and is dropped; with none left the oracle keeps its own activation (recorded in `missed`)."""
+        q = self.by_shape.get(tuple(x.shape))
+        own = x.detach() > 0
+        if kind == "relu6":
+            own &= x.detach() < 6
+        while q:
+            m = q.popleft()
+            if float((m == own).float().mean()) > 0.99:
+                self.used += 1
+                return x * m.to(x.dtype)
+            self.dropped += 1
+        self.missed.append((kind, tuple(x.shape)))
+        return None
+
+
+@contextlib.contextmanager
+def capture():
+    import sfhip
+    from slowfast.models import engine
+    masks = Masks()
+    orig_bn, orig_conv = engine.bn_train_apply, sfhip.conv
+
+    def bn_train_apply(bn, z, res=None, relu=False, rep=1, out=None, out_reserve=(0, 0), keep=None, out_cmul=1,
+                       conv_stats=None):
+        y = orig_bn(bn, z, res=res, relu=relu, rep=rep, out=out, out_reserve=out_reserve, keep=keep,
+                    out_cmul=out_cmul, conv_stats=conv_stats)
+        if relu and out_cmul == 1:
+            full = sfhip.to_ncthw(y)
+            masks.add(full[:, :, ::rep] if rep > 1 else full, relu)
+        elif relu:  # channel-shuffled store (ShuffleNetV2): channel c of the result sits at out.coff + c * out_cmul
+            c = z.C if keep is None else keep
+            v = y.buf[..., y.coff:y.coff + (c - 1) * out_cmul + 1:out_cmul].permute(0, 4, 1, 2, 3)
+            masks.add(v[:, :, ::rep] if rep > 1 else v, relu)
+        return y
+
+    def conv(x, wp, kernel, *a, **k):  # bare conv + ReLU without a BN (engine.conv_bn_act's taped path)
+        y = orig_conv(x, wp, kernel, *a, **k)
+        if k.get("relu") and k.get("scale") is None and engine.tape() is not None:
+            masks.add(sfhip.to_ncthw(y), k["relu"])
+        return y
+
+    engine.bn_train_apply, sfhip.conv = bn_train_apply, conv
+    try:
+        yield masks
+    finally:
+        engine.bn_train_apply, sfhip.conv = orig_bn, orig_conv
+
+
+@contextlib.contextmanager
+def inject(masks):
+    from oracle import slowfast_oracle as oracle
+    prev, oracle.ACT_HOOK = oracle.ACT_HOOK, masks.hook
+    try:
+        yield masks
+    finally:
+        oracle.ACT_HOOK = prev

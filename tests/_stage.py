@@ -23,9 +23,10 @@ def predecessor(children, child, acts):
     return None
 
 
-def oracle_child_grads(meta, sd, clips, children, child, k, acts0, inputs=None):
+def oracle_child_grads(meta, sd, clips, children, child, k, acts0, inputs=None, masks=None):
     """(outs, input grads, {param name: grad}) of top-level child number k (`child`).  inputs: tensors to evaluate the
-    child on instead of the oracle's own activations at its input boundary."""
+    child on instead of the oracle's own activations at its input boundary.  masks: a tests/_masks.py::Masks cursor —
+    the HIP forward's ReLU masks, replayed by the oracle's activations (same piecewise-linear function on both sides)."""
     prev = predecessor(children, child, acts0)
     sdr = {n: (v.clone().requires_grad_(True) if v.dtype == torch.float32 and "running" not in n else v)
            for n, v in sd.items()}
@@ -40,10 +41,15 @@ def oracle_child_grads(meta, sd, clips, children, child, k, acts0, inputs=None):
         sdr["__override__"] = {prev: leaves}
     if child != "head":
         sdr["__stop__"] = child
+    prev_hook = oracle.ACT_HOOK
+    if masks is not None:
+        oracle.ACT_HOOK = masks.hook
     try:
         acts = oracle.FORWARDS[meta["model"]](sdr, xs, meta["hparams"], training=True)
     except oracle.StopForward as e:
         acts = e.args[0]
+    finally:
+        oracle.ACT_HOOK = prev_hook
     outs = [acts["out"]] if child == "head" else list(acts[child])
     loss = 0.0
     for j, t in enumerate(outs):

@@ -259,10 +259,10 @@ def test_fullsize_eval_forward_matches_oracle(workload):
     assert checked >= 16 and e_log < 1e-3 and e_out < 1e-3
 
 
-# relative-L2 bounds of the full-size training step against the oracle (fp32 both sides).  At 224^2 the deep tensors
-# are 12x larger than in the S = 64 fixtures, so one ReLU-mask flip (the noise floor of the S = 64 gradient tests) is a
-# 1/sqrt(12) smaller share of a tensor; measured on MI355X (gpurun_out/fullsize_report.txt, round 3): see the asserts.
-TRAIN_TOL = {"loss": 1e-4, "logits": 1e-3, "grad_median": 2e-3, "grad_worst": 5e-2, "grad_input": 2e-2}
+# relative-L2 bounds of the full-size training step against the oracle (fp32 both sides), with the HIP forward's ReLU
+# masks injected into the oracle (tests/_masks.py: both sides differentiate the same piecewise-linear function; without
+# that the comparison measures mask flips — 2.9e-2 median at this size with the forward equal to 5e-6).
+TRAIN_TOL = {"loss": 1e-4, "logits": 1e-3, "grad_median": 1e-3, "grad_worst": 1e-2, "grad_input": 1e-2}
 
 
 @pytest.mark.parametrize("workload", ["dual", "slowfast"])
@@ -271,6 +271,7 @@ def test_fullsize_train_step_matches_oracle(workload):
     with batch-statistics BN, cross-entropy, backward through every kernel) against the oracle's autograd on the same
     seeded parameters and clip — loss, train-mode logits, EVERY parameter's gradient (relative L2) and dL/d(clip) of
     both pathways.  The caller being matched is tools/train_net.py:78-96 of the reference."""
+    import _masks
     from oracle import slowfast_oracle as oracle
     dev = _dev()
     bench, cfg, model = _model(workload)
@@ -283,7 +284,8 @@ def test_fullsize_train_step_matches_oracle(workload):
     model.train()
     model.zero_grad(set_to_none=True)
     gx = [x.to(dev).requires_grad_(True) for x in xs]
-    logits = model(gx)
+    with _masks.capture() as masks:
+        logits = model(gx)
     loss = torch.nn.functional.cross_entropy(logits, label.to(dev))
     loss.backward()
     torch.cuda.synchronize()
@@ -294,7 +296,9 @@ def test_fullsize_train_step_matches_oracle(workload):
     sdr = {k: (v.clone().requires_grad_(True) if v.dtype == torch.float32 and "running" not in k else v)
            for k, v in sd.items()}
     rx = [x.clone().requires_grad_(True) for x in xs]
-    acts = oracle.FORWARDS[cfg.MODEL.MODEL_NAME](sdr, rx, bench.oracle_hparams(cfg), training=True)
+    with _masks.inject(masks):
+        acts = oracle.FORWARDS[cfg.MODEL.MODEL_NAME](sdr, rx, bench.oracle_hparams(cfg), training=True)
+    assert not masks.missed and masks.used == masks.count, (masks.missed[:4], masks.used, masks.count)
     rloss = torch.nn.functional.cross_entropy(acts["out"], label)
     rloss.backward()
 
@@ -303,15 +307,24 @@ def test_fullsize_train_step_matches_oracle(workload):
 
     e_logits = float((logits.detach().cpu() - acts["out"].detach()).abs().max() / acts["out"].detach().abs().max())
     e_loss = abs(float(loss) - float(rloss))
-    errs = sorted((l2(got[k], v.grad), k) for k, v in sdr.items()
-                  if getattr(v, "grad", None) is not None and float(v.grad.norm()) > 0)
-    missing = [k for k, v in sdr.items() if getattr(v, "grad", None) is not None and k not in got]
+    ref = {k: v.grad for k, v in sdr.items() if getattr(v, "grad", None) is not None}
+    missing = [k for k in ref if k not in got]
+    # a bias in front of a batch-statistics BN has NO gradient in exact arithmetic (the BN subtracts the batch mean):
+    # SpatialAttention's value bias reaches the output as gamma * b_v (softmax rows sum to one) straight into bn_s2f.
+    # Both sides hold rounding noise there: bound it against the weight gradient of the same conv instead.
+    noise = [k for k in ref if k.endswith("attention_spatial_s2f.value_conv.bias")]
+    for k in noise:
+        wn = float(ref[k.replace(".bias", ".weight")].norm())
+        assert float(got[k].norm()) < 1e-3 * wn and float(ref[k].norm()) < 1e-3 * wn, (k, float(got[k].norm()), wn)
+    errs = sorted((l2(got[k], g), k) for k, g in ref.items() if k not in noise and float(g.norm()) > 0)
     e_in = [l2(a, b.grad) for a, b in zip(got_in, rx)]
     med, worst = errs[len(errs) // 2][0], errs[-1]
-    _report("%s 224^2 T=32 B=1 TRAIN STEP vs oracle: loss |d| %.2e (%.5f), logits %.2e, %d parameter gradients rel-L2 "
-            "median %.2e p90 %.2e worst %.2e (%s), input gradients slow %.2e fast %.2e" % (
-                workload, e_loss, float(rloss), e_logits, len(errs), med, errs[len(errs) * 9 // 10][0], worst[0],
-                worst[1], e_in[0], e_in[1]))
+    _report("%s 224^2 T=32 B=1 TRAIN STEP vs oracle (%d ReLU masks injected): loss |d| %.2e (%.5f), logits %.2e, %d "
+            "parameter gradients rel-L2 median %.2e p90 %.2e worst %.2e (%s), input gradients slow %.2e fast %.2e" % (
+                workload, masks.count, e_loss, float(rloss), e_logits, len(errs), med, errs[len(errs) * 9 // 10][0],
+                worst[0], worst[1], e_in[0], e_in[1]))
+    for e, k in errs[-6:]:
+        _report("    %-70s %.2e" % (k, e))
     assert not missing, missing
     assert len(errs) >= 150
     assert e_loss < TRAIN_TOL["loss"] * max(1.0, abs(float(rloss))) and e_logits < TRAIN_TOL["logits"]

@@ -35,6 +35,12 @@ pytestmark = pytest.mark.gpu
 # a wrongly wired fan-in / dropped residual term moves a child's gradients by tens of percent against both.
 TOL = 1e-2           # min(vs oracle, vs reference), children whose smallest activation has >= 22 500 positions
 TOL_LOOSE = 0.25     # max(vs oracle, vs reference): small tensors lose up to 7e-2 to the other comparator's flips
+# Round 3: the oracle child is handed the HIP forward's ReLU / ReLU6 masks (tests/_masks.py), so that both sides
+# differentiate the SAME piecewise-linear function; what is left is fp32 re-association inside the child.  Every child
+# whose activations were all replayed from masks is held to this ONE bound against the oracle; child_tol() above only
+# remains for the few children with an activation the capture does not cover (channel-shuffled stores of ShuffleNetV2,
+# ShuffleNet-v1's relu(cat[...])), where the oracle falls back to its own mask.
+TOL_MASKED = 2e-3
 
 
 def child_tol(outs):
@@ -79,6 +85,7 @@ def _view(act):
 def test_stage_gradients_match_reference(name):
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
+    import _masks
     import sfhip
     from slowfast.models import engine
     z, meta = load_case(name)
@@ -115,7 +122,7 @@ def test_stage_gradients_match_reference(name):
         acts0 = boundaries(meta, sd, clips_cpu)
         clips_gpu = [x.cuda() for x in clips_cpu]
         t.input_ids = {id(x): i for i, x in enumerate(clips_gpu)}  # ask the stems for dL/d(clip) too
-        with torch.no_grad(), engine.taping(t):
+        with torch.no_grad(), engine.taping(t), _masks.capture() as masks:
             model._forward_impl(clips_gpu)
         torch.cuda.synchronize()
         worst = 0.0
@@ -146,7 +153,10 @@ def test_stage_gradients_match_reference(name):
             torch.cuda.synchronize()
             # ---- the oracle on the same inputs
             ins_cpu = [sfhip.to_ncthw(a).cpu() if isinstance(a, sfhip.Act) else a.detach().cpu() for a in ins]
-            _, ogin, opg = oracle_child_grads(meta, sd, clips_cpu, children, child, k, acts0, inputs=ins_cpu)
+            cursor = masks.fork()
+            _, ogin, opg = oracle_child_grads(meta, sd, clips_cpu, children, child, k, acts0, inputs=ins_cpu,
+                                              masks=cursor)
+            masked = not cursor.missed  # every activation the oracle evaluated up to this child came from a HIP mask
             pscale = max([float(g.norm()) for g in opg.values() if g is not None] + [0.0])
             # ---- dL/d(input)
             for i, a in enumerate(ins):
@@ -166,7 +176,10 @@ def test_stage_gradients_match_reference(name):
                 er = _l2rel(s, z[tag])
                 _report("%-22s %-12s gin%d   vs oracle %.3e   vs reference %.3e" % (name, child, i, e, er))
                 worst = max(worst, e)
-                if not (min(e, er) < tol and max(e, er) < TOL_LOOSE):
+                if masked:
+                    if not (e < TOL_MASKED and er < TOL_LOOSE):
+                        bad.append((child, "gin%d" % i, e, er))
+                elif not (min(e, er) < tol and max(e, er) < TOL_LOOSE):
                     bad.append((child, "gin%d" % i, e, er))
                 checked += 1
             # ---- dL/d(parameters).  Some gradients are analytically ZERO (a conv bias in front of a train-mode BN, the
@@ -189,9 +202,13 @@ def test_stage_gradients_match_reference(name):
                 s, _, _ = sample_activation(gn, 512)
                 er = _l2rel(s, z[tag])
                 worst = max(worst, e)
-                if min(e, er) > 0.1 * TOL:
-                    _report("%-22s %-12s %-52s vs oracle %.3e   vs reference %.3e" % (name, child, pn, e, er))
-                if not (min(e, er) < tol and max(e, er) < TOL_LOOSE):
+                if e > 0.1 * TOL_MASKED:
+                    _report("%-22s %-12s %-52s vs oracle %.3e   vs reference %.3e%s" % (
+                        name, child, pn, e, er, "" if masked else "   (oracle's own masks)"))
+                if masked:
+                    if not (e < TOL_MASKED and er < TOL_LOOSE):
+                        bad.append((child, pn, e, er))
+                elif not (min(e, er) < tol and max(e, er) < TOL_LOOSE):
                     bad.append((child, pn, e, er))
                 checked += 1
         _report("%-22s stage-wise gradients: %d tensors checked, worst L2rel %.3e" % (name, checked, worst))
