@@ -28,9 +28,11 @@ class Masks(object):
 
     def add(self, y_ncthw, relu):
         m = y_ncthw > 0
-        if relu in (6, "relu6"):
+        hi = None
+        if relu in (6, "relu6"):  # ReLU6: pass-through where 0 < y < 6, the constant 6 where it saturates
+            hi = (y_ncthw >= 6).cpu()
             m &= y_ncthw < 6
-        self.by_shape[tuple(m.shape)].append(m.cpu())
+        self.by_shape[tuple(m.shape)].append((m.cpu(), hi))
         self.count += 1
 
     def fork(self):
@@ -51,10 +53,17 @@ class Masks(object):
         if kind == "relu6":
             own &= x.detach() < 6
         while q:
-            m = q.popleft()
+            m, hi = q.popleft()
             if float((m == own).float().mean()) > 0.99:
                 self.used += 1
-                return x * m.to(x.dtype)
+                # torch.where, not x * mask: the product's backward is WRONG on this torch build (2.10 CPU) when the
+                # incoming gradient is the expanded (stride-0) gradient of a mean over size-1 dims — found on
+                # ShuffleNetV2's head, [2, 1024, 4, 1, 1]: relu(x) and where(x > 0, x, 0) agree to the bit, x * (x > 0)
+                # is off by 150 %
+                y = torch.where(m, x, torch.zeros_like(x))
+                if hi is not None:
+                    y = torch.where(hi, torch.full_like(x, 6.0), y)
+                return y
             self.dropped += 1
         self.missed.append((kind, tuple(x.shape)))
         return None

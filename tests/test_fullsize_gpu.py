@@ -262,7 +262,7 @@ def test_fullsize_eval_forward_matches_oracle(workload):
 # relative-L2 bounds of the full-size training step against the oracle (fp32 both sides), with the HIP forward's ReLU
 # masks injected into the oracle (tests/_masks.py: both sides differentiate the same piecewise-linear function; without
 # that the comparison measures mask flips — 2.9e-2 median at this size with the forward equal to 5e-6).
-TRAIN_TOL = {"loss": 1e-4, "logits": 1e-3, "grad_median": 1e-3, "grad_worst": 1e-2, "grad_input": 1e-2}
+TRAIN_TOL = {"loss": 1e-4, "logits": 1e-3, "grad_median": 1e-3, "grad_worst": 1e-2, "grad_input": 5e-3}
 
 
 @pytest.mark.parametrize("workload", ["dual", "slowfast"])
@@ -309,13 +309,18 @@ def test_fullsize_train_step_matches_oracle(workload):
     e_loss = abs(float(loss) - float(rloss))
     ref = {k: v.grad for k, v in sdr.items() if getattr(v, "grad", None) is not None}
     missing = [k for k in ref if k not in got]
-    # a bias in front of a batch-statistics BN has NO gradient in exact arithmetic (the BN subtracts the batch mean):
-    # SpatialAttention's value bias reaches the output as gamma * b_v (softmax rows sum to one) straight into bn_s2f.
-    # Both sides hold rounding noise there: bound it against the weight gradient of the same conv instead.
-    noise = [k for k in ref if k.endswith("attention_spatial_s2f.value_conv.bias")]
+    # Gradients that are ZERO in exact arithmetic — both sides hold rounding noise there, so they are bounded against the
+    # largest parameter gradient of their fusion module instead of against themselves:
+    #   value_conv.bias: reaches the output as gamma * b_v (softmax rows sum to one) straight into the batch-statistics
+    #                    bn_s2f, which subtracts the batch mean;
+    #   key_conv.bias:   adds q.b_k to every score of a query's row — softmax is shift-invariant;
+    #   ECA conv.weight: the gate scales each channel in front of bn_f2s, which divides that scale out again (up to eps).
+    noise = [k for k in ref if k.endswith(("attention_spatial_s2f.value_conv.bias", "attention_spatial_s2f.key_conv.bias",
+                                           "attention_channel_f2s.conv.weight"))]
     for k in noise:
-        wn = float(ref[k.replace(".bias", ".weight")].norm())
-        assert float(got[k].norm()) < 1e-3 * wn and float(ref[k].norm()) < 1e-3 * wn, (k, float(got[k].norm()), wn)
+        mod = k.split(".")[0] + "."
+        scale = max(float(g.norm()) for n, g in ref.items() if n.startswith(mod))
+        assert float((got[k] - ref[k]).norm()) < 2e-3 * scale, (k, float(got[k].norm()), float(ref[k].norm()), scale)
     errs = sorted((l2(got[k], g), k) for k, g in ref.items() if k not in noise and float(g.norm()) > 0)
     e_in = [l2(a, b.grad) for a, b in zip(got_in, rx)]
     med, worst = errs[len(errs) // 2][0], errs[-1]

@@ -198,6 +198,13 @@ def test_stage_gradients_match_reference(name):
                     assert float(np.linalg.norm(gn)) <= 1e-5 * pscale, (child, pn)
                     checked += 1
                     continue
+                if pn.endswith("attention_channel_f2s.conv.weight"):
+                    # ECA's 3-tap gate feeds a batch-statistics BN, which is invariant to the per-channel scale the
+                    # gate applies (up to eps): this gradient is analytically ~0 and both sides hold cancellation
+                    # noise — bounded against the child's largest parameter gradient instead of against itself
+                    assert float(np.linalg.norm(gn - on)) <= TOL_MASKED * pscale, (child, pn)
+                    checked += 1
+                    continue
                 e = _l2rel(gn, on)
                 s, _, _ = sample_activation(gn, 512)
                 er = _l2rel(s, z[tag])
