@@ -491,6 +491,8 @@ extern "C" long sf_conv_fwd_ws_floats(const sf_conv_desc* d) {
 
 int sf_conv_stem_fwd_try(const sf_conv_desc* d, const float* in, const float* w, const float* scale,
                          const float* bias, const float* res, float* out, hipStream_t stream);  // conv_stem.hip
+int sf_conv_small_try(const sf_conv_desc* d, const float* in, const float* w, const float* scale, const float* bias,
+                      const float* res, float* out, hipStream_t stream, float* stats, int* stat_parts);  // conv_small.hip
 
 static int conv_fwd_impl(const sf_conv_desc* d, const float* in, const float* w_packed, const float* scale,
                          const float* bias, const float* res, float* out, float* ws, void* stream,
@@ -513,6 +515,10 @@ static int conv_fwd_impl(const sf_conv_desc* d, const float* in, const float* w_
   }
   {  // the Fast pathway's stem: LDS-ring kernel instead of one L2 fetch per tap
     const int rc = sf_conv_stem_fwd_try(d, in, w_packed, scale, bias, res, out, (hipStream_t)stream);
+    if (rc != 1) return rc;
+  }
+  {  // small channel counts (the Fast pathway's C <= 32 layers): LDS-staged input, scalar-register weights, vector FMAs
+    const int rc = sf_conv_small_try(d, in, w_packed, scale, bias, res, out, (hipStream_t)stream, stats, stat_parts);
     if (rc != 1) return rc;
   }
   {  // the per-wavefront implicit GEMM (no LDS staging, no barrier in the main loop) for every 16-byte aligned shape

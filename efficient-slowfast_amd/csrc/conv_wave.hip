@@ -23,6 +23,7 @@
 // wdf_attention_helper.py:21-29; and, with desc.transposed / the scatter map, their data gradients.
 #include "common.h"
 #include <stdio.h>
+#include <type_traits>
 #include <stdlib.h>
 
 namespace {
@@ -45,6 +46,8 @@ struct WaveArgs {
   int nk;              // K steps of 16 = ntaps * cin_pad / 16
   int cpk;             // K steps per tap = cin_pad / 16
   unsigned in_bytes, w_bytes;
+  unsigned out_bytes, res_bytes;  // persistent form: extents of the output / residual buffers (buffer_store bounds)
+  int dbg;             // sf_conv_tune(5, mask), microbenchmarks only: 1 = drop the stores, 2 = every A row reads row 0
   int plain;           // 1: 1x1x1 kernel, stride 1, no padding, same extents -> input row == output row
   float* stats;        // != NULL: [part][Cout / 4][count, K, sum(v - K), sum((v - K)^2)][4 channels] of the stored outputs
   // n / d for 0 <= n < 2^31 as (mulhi(n, mul) >> sh); d == 1 has mul == 0 (identity)
@@ -369,6 +372,327 @@ __global__ __launch_bounds__(256) void conv_wave_kernel(const WaveArgs p) {
   }
 }
 
+// ---- persistent form (KS = 1) ----------------------------------------------------------------------------------
+// The kernel above is one straight pass per workgroup: row decode -> first loads (a full memory latency with nothing to
+// do) -> K steps -> LDS transposition -> stores, and equal workgroups march through those phases together.  For the
+// short reductions of this network (1x1x1 layers with K = 64 .. 256: 4 .. 16 steps) that fixed part is as long as the
+// MFMA phase: 64 -> 256 at 56^2 ran at 0.40 of its own roofline with the MFMA pipe busy 46 % of the time.
+// This form changes three things (KS = 1 only: no cross-wavefront sum):
+//  * OPERANDS SWAPPED: the weights are the MFMA's A operand and the activations its B operand, so a lane's four
+//    accumulator registers are 4 CONSECUTIVE CHANNELS of one output position — exactly a 16-byte NDHWC store.  No LDS
+//    transposition, no barrier anywhere in the kernel; scale / bias / residual are per-lane float4 operations.
+//  * PERSISTENT wavefronts: a grid of (CUs x occupancy) workgroups whose wavefronts walk the tile list with a fixed
+//    stride.  Wavefronts never synchronise, so they drift apart and one's stores overlap another's MFMA phase.
+//  * CROSS-TILE PREFETCH: in a tile's LAST K step the row state is switched to the wavefront's next tile, and the loads
+//    that step issues "one step ahead" fetch that tile's first fragments — they are in flight during the epilogue.
+// BN batch statistics (sf_conv_fwd_stats): a lane owns fixed channels of a tile; shifted sums (K = the tile's first row,
+// row_newbcast) over the lane's rows, 16-lane DPP reduction per channel, then the tile is Chan-merged into a RUNNING
+// record that lane (j*4+e) of each lane-row keeps for channel (j, e) across all tiles of the wavefront (its channel
+// tile never changes: the stride is a multiple of nb_n).  One record per (wavefront, channel) at the end.
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float row16_sum(float v) {  // sum over the 16 lanes of a DPP row, result in every lane
+  v += dpp_f<0xB1>(v);    // quad_perm [1,0,3,2]
+  v += dpp_f<0x4E>(v);    // quad_perm [2,3,0,1]
+  v += dpp_f<0x141>(v);   // row_half_mirror
+  v += dpp_f<0x140>(v);   // row_mirror
+  return v;
+}
+
+// PLAIN (1x1x1, stride 1, no padding — every short-K layer): the source row of an output row is that row for the one
+// tap, so the per-row state is ONE offset (no validity masks, no tap switching): 2*TM registers less.
+template <int TM, int TN, int KV, bool PLAIN>
+__global__ __launch_bounds__(256, 2) void conv_wave_p_kernel(const WaveArgs p) {
+  constexpr int KB = 16 * KV;
+  constexpr int BN = TN * 16;
+  const sf_conv_desc& d = p.d;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int fr = lane & 15, fg = lane >> 4;
+  const int gw = xcd_remap(blockIdx.x, gridDim.x) * 4 + wave;   // this wavefront's slot in the tile walk
+  const int stride = (int)gridDim.x * 4;
+  const int sg = d.transposed ? -1 : 1;
+  const bool unit_dil = d.dT == 1 && d.dH == 1 && d.dW == 1;
+  const bool want_stats = p.stats != nullptr;
+
+  constexpr int TS = PLAIN ? 1 : TM;
+  unsigned a_base[TS], a_pm[TS], a_cur[TM], b_base[TN];
+  int m0 = 0, n0 = 0;
+  auto setup = [&](int tile) {  // row state of `tile` (all-OOB when it is past the end)
+    const bool live = tile < p.ntiles;
+    const int tile_m = live ? tile / p.nb_n : 0;
+    const int tile_n = live ? tile - tile_m * p.nb_n : 0;
+    m0 = tile_m * p.rows;
+    n0 = tile_n * BN;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int rr = i * 16 + fr;
+      const int m = m0 + rr;
+      const bool ok = live && rr < p.rows && m < p.M;
+      const unsigned mm = ok ? (unsigned)m : 0u;
+      if constexpr (PLAIN) {
+        a_cur[i] = ok ? (((p.dbg & 2) ? (unsigned)fr : mm) * (unsigned)d.in_cs + (unsigned)(d.in_coff + fg * 4 * KV)) * 4u : OOB;
+        continue;
+      }
+      if (p.plain) {
+        a_pm[i % TS] = ok ? (1u | (1u << 10) | (1u << 20)) : 0u;
+        a_base[i % TS] = (mm * (unsigned)d.in_cs + (unsigned)(d.in_coff + fg * 4 * KV)) * 4u;
+        continue;
+      }
+      const unsigned q1 = fast_div(mm, p.wo_mul, p.wo_sh);
+      const int wo = (int)(mm - q1 * (unsigned)d.Wo);
+      const unsigned q2 = fast_div(q1, p.ho_mul, p.ho_sh);
+      const int ho = (int)(q1 - q2 * (unsigned)d.Ho);
+      const unsigned q3 = fast_div(q2, p.to_mul, p.to_sh);
+      const int to = (int)(q2 - q3 * (unsigned)d.To);
+      const int n = (int)q3;
+      const int t0 = d.transposed ? to + d.pT : to * d.sT - d.pT;
+      const int h0 = d.transposed ? ho + d.pH : ho * d.sH - d.pH;
+      const int w0 = d.transposed ? wo + d.pW : wo * d.sW - d.pW;
+      unsigned pm = 0;
+      if (ok) {
+        if (unit_dil) {
+          pm = tap_run(t0, sg, d.Ti, d.kT) | (tap_run(h0, sg, d.Hi, d.kH) << 10) | (tap_run(w0, sg, d.Wi, d.kW) << 20);
+        } else {
+          for (int k = 0; k < d.kT; ++k) pm |= ((unsigned)(t0 + sg * k * d.dT) < (unsigned)d.Ti ? 1u : 0u) << k;
+          for (int k = 0; k < d.kH; ++k) pm |= ((unsigned)(h0 + sg * k * d.dH) < (unsigned)d.Hi ? 1u : 0u) << (10 + k);
+          for (int k = 0; k < d.kW; ++k) pm |= ((unsigned)(w0 + sg * k * d.dW) < (unsigned)d.Wi ? 1u : 0u) << (20 + k);
+        }
+      }
+      a_pm[i % TS] = pm;
+      const int pos = ((n * d.Ti + t0) * d.Hi + h0) * d.Wi + w0;
+      a_base[i % TS] = (unsigned)(pos * d.in_cs + d.in_coff + fg * 4 * KV) * 4u;
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+      b_base[j] = live ? ((unsigned)(n0 + j * 16 + fr) * (unsigned)(p.nk * KB) + (unsigned)(fg * 4 * KV)) * 4u : OOB;
+  };
+
+  const __amdgpu_buffer_rsrc_t a_rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, (int)p.in_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t b_rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, (int)p.w_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t o_rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.out, 0, (int)p.out_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t r_rs =
+      __builtin_amdgcn_make_buffer_rsrc((void*)(p.res ? p.res : p.out), 0, (int)p.res_bytes, 0x00020000);
+
+  int it = 0, c0 = 0, kw = 0, kh = 0, kt = 0;
+  auto set_tap = [&]() {
+    if constexpr (PLAIN) return;  // a_cur is the row state
+    const unsigned tapoff = (unsigned)(sg * ((kt * d.dT * d.Hi + kh * d.dH) * d.Wi + kw * d.dW) * d.in_cs) * 4u;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const unsigned v = (a_pm[i % TS] >> kt) & (a_pm[i % TS] >> (10 + kh)) & (a_pm[i % TS] >> (20 + kw)) & 1u;
+      a_cur[i] = v ? a_base[i % TS] + tapoff : OOB;
+    }
+  };
+  auto rewind = [&]() { it = 0; c0 = 0; kw = 0; kh = 0; kt = 0; set_tap(); };
+  auto load_b = [&](f32x4 (&b)[TN][KV]) {
+    const unsigned boff = (unsigned)it * (unsigned)(KB * 4);
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int v = 0; v < KV; ++v)
+        b[j][v] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(b_rs, b_base[j] + boff + v * 16, 0, 0));
+  };
+  auto load_a = [&](int i, f32x4 (&a)[KV]) {
+    const unsigned koff = (unsigned)c0 * 4u;
+#pragma unroll
+    for (int v = 0; v < KV; ++v) {
+      const bool kin = (c0 + (fg * KV + v) * 4) < d.Cin;
+      a[v] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(a_rs, kin ? a_cur[i] + koff + v * 16 : OOB, 0, 0));
+    }
+  };
+  auto advance = [&]() {
+    ++it;
+    c0 += KB;
+    if constexpr (PLAIN) return;  // one tap: c0 runs over its channels
+    if (c0 >= d.cin_pad) {
+      c0 = 0;
+      if (++kw == d.kW) {
+        kw = 0;
+        if (++kh == d.kH) {
+          kh = 0;
+          ++kt;
+        }
+      }
+      set_tap();
+    }
+  };
+
+  // running statistics of this wavefront: lane (fr = j*4 + e) of every lane-row keeps channel n0 + j*16 + 4*fg + e
+  float run_n = 0.f, run_k = 0.f, run_1 = 0.f, run_2 = 0.f;
+  const int stat_n0 = ((gw % p.nb_n) * BN);  // constant per wavefront (stride % nb_n == 0 when statistics are taken)
+
+  int tile = gw;
+  if (tile < p.ntiles) {
+    const bool scatter = d.os_T > 1 || d.os_H > 1 || d.os_W > 1;
+    const bool relu = d.act == SF_ACT_RELU || d.act == SF_ACT_RELU6;
+    const float hi = d.act == SF_ACT_RELU6 ? 6.f : 3.0e38f;
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    f32x4 fa[TM][KV], fb[TN][KV], fbn[TN][KV];
+    setup(tile);
+    rewind();
+    load_b(fb);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) load_a(i, fa[i]);
+    advance();
+    for (;;) {
+      const int m0c = __builtin_amdgcn_readfirstlane(m0), n0c = __builtin_amdgcn_readfirstlane(n0);
+      const int next = tile + stride;
+      for (int step = 0; step < p.nk; ++step) {
+        if (step == p.nk - 1) {  // everything this step loads "one step ahead" belongs to the next tile
+          setup(next);
+          rewind();
+        }
+        load_b(fbn);
+#pragma unroll
+        for (int i2 = 0; i2 < TM; i2 += 2) {
+#pragma unroll
+          for (int v = 0; v < KV; ++v)
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+              for (int i = i2; i < i2 + 2 && i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)  // A = weights (rows = channels), B = activations (columns = positions)
+                  acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fb[j][v][s], fa[i][v][s], acc[i][j], 0, 0, 0);
+#pragma unroll
+          for (int i = i2; i < i2 + 2 && i < TM; ++i) load_a(i, fa[i]);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int v = 0; v < KV; ++v) fb[j][v] = fbn[j][v];
+        advance();
+      }
+      // ---- epilogue of the tile at (m0c, n0c): lane = position (i*16 + fr), registers = channels 4*fg .. 4*fg+3 of
+      //      channel tile j; the next tile's first fragments are in flight meanwhile.  Branch-free inside a variant
+      //      (statistics / residual / activation are compile-time flags of the lambda): invalid rows / channels get
+      //      an out-of-range buffer offset (loads read zero, stores are dropped), so the residual loads of a column of
+      //      row blocks are issued together instead of one load -> wait -> store per element.
+      auto epilogue = [&](auto STATS, auto RES, auto RELU) {
+        const int left = p.M - m0c;
+        const float cnt = (float)(left < p.rows ? left : p.rows);
+        unsigned orow[TM];  // output row of this lane's position in row block i, 0xffffffff when there is none
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          const int rr = i * 16 + fr;
+          const int m = m0c + rr;
+          unsigned r = (unsigned)m;
+          if (scatter) {
+            const unsigned q1 = fast_div((unsigned)m, p.wo_mul, p.wo_sh);
+            const int wo = m - (int)q1 * d.Wo;
+            const unsigned q2 = fast_div(q1, p.ho_mul, p.ho_sh);
+            const int ho = (int)q1 - (int)q2 * d.Ho;
+            const unsigned q3 = fast_div(q2, p.to_mul, p.to_sh);
+            const int to = (int)q2 - (int)q3 * d.To;
+            const int st = d.os_T > 1 ? d.os_T : 1, sh = d.os_H > 1 ? d.os_H : 1, sw = d.os_W > 1 ? d.os_W : 1;
+            r = (unsigned)((((int)q3 * d.ob_T + to * st + d.oo_T) * d.ob_H + ho * sh + d.oo_H) * d.ob_W + wo * sw + d.oo_W);
+          }
+          orow[i] = (rr < p.rows && m < p.M) ? r : 0xffffffffu;
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const int n = n0c + j * 16 + 4 * fg;
+          const bool nok = n < d.Cout;
+          const int nc = nok ? n : 0;  // clamped: the vectors below are read unconditionally
+          const f32x4 one = {1.f, 1.f, 1.f, 1.f}, zero = {0.f, 0.f, 0.f, 0.f};
+          const f32x4 sc = p.scale ? *reinterpret_cast<const f32x4*>(p.scale + nc) : one;
+          const f32x4 bi = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + nc) : zero;
+          f32x4 st_k = zero, st_1 = zero, st_2 = zero;
+          constexpr int CH = RES.value ? (TM > 7 ? 5 : 7) : 1;  // row blocks per batch of residual loads
+#pragma unroll
+          for (int ib = 0; ib < TM; ib += CH) {
+            f32x4 rv[CH];
+            if constexpr (RES.value) {
+#pragma unroll
+              for (int u = 0; u < CH; ++u) {
+                if (ib + u < TM) {
+                  const bool ok = nok && orow[ib + u] != 0xffffffffu;
+                  const unsigned off = ok ? (orow[ib + u] * (unsigned)d.res_cs + (unsigned)(d.res_coff + n)) * 4u : OOB;
+                  rv[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_rs, off, 0, 0));
+                }
+              }
+            }
+#pragma unroll
+            for (int u = 0; u < CH; ++u) {
+              const int i = ib + u;
+              if (i < TM) {
+                const bool ok = nok && orow[i] != 0xffffffffu;
+                f32x4 v = acc[i][j] * sc + bi;
+                acc[i][j] = zero;
+                if constexpr (STATS.value) {
+                  if (i == 0) {  // K = the tile's first output row (fr == 0), shared by the lane-row
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) st_k[e] = dpp_f<0x150>(v[e]);  // row_newbcast:0
+                  }
+                }
+                if constexpr (RES.value) v += rv[u];
+                if constexpr (RELU.value) {
+#pragma unroll
+                  for (int e = 0; e < 4; ++e) v[e] = fminf(fmaxf(v[e], 0.f), hi);
+                }
+                const unsigned off = (ok && !(p.dbg & 1)) ? (orow[i] * (unsigned)d.out_cs + (unsigned)(d.out_coff + n)) * 4u : OOB;
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), o_rs, off, 0, 0);
+                if constexpr (STATS.value) {
+                  const f32x4 dv = v - st_k;
+                  const float w = ok ? 1.f : 0.f;
+                  st_1 += w * dv;
+                  st_2 += w * dv * dv;
+                }
+              }
+            }
+          }
+          if constexpr (STATS.value) {  // tile totals of channel tile j -> the running record of lane fr == j*4 + e
+            float tk = 0.f, t1 = 0.f, t2 = 0.f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float s1 = row16_sum(st_1[e]), s2 = row16_sum(st_2[e]);
+              const bool mine = fr == j * 4 + e;
+              tk = mine ? st_k[e] : tk;
+              t1 = mine ? s1 : t1;
+              t2 = mine ? s2 : t2;
+            }
+            const bool owner = fr >= j * 4 && fr < j * 4 + 4;
+            const bool first = run_n == 0.f;
+            const float dk = first ? 0.f : tk - run_k;
+            const float n2 = run_2 + t2 + 2.f * dk * t1 + cnt * dk * dk;
+            const float n1 = run_1 + t1 + cnt * dk;
+            run_k = owner && first ? tk : run_k;
+            run_2 = owner ? n2 : run_2;
+            run_1 = owner ? n1 : run_1;
+            run_n = owner ? run_n + cnt : run_n;
+          }
+        }
+      };
+      using T_ = std::true_type;
+      using F_ = std::false_type;
+      if (want_stats) epilogue(T_{}, F_{}, F_{});  // raw conv output (+ bias): no residual, no activation
+      else if (p.res) { if (relu) epilogue(F_{}, T_{}, T_{}); else epilogue(F_{}, T_{}, F_{}); }
+      else { if (relu) epilogue(F_{}, F_{}, T_{}); else epilogue(F_{}, F_{}, F_{}); }
+      if (next >= p.ntiles) break;
+      tile = next;
+    }
+  }
+  if (want_stats && fr < TN * 4) {
+    const int j = fr >> 2, e = fr & 3;
+    const int n = stat_n0 + j * 16 + 4 * fg;
+    if (n < d.Cout) {
+      float* const o = p.stats + ((long)(gw / p.nb_n) * (d.Cout >> 2) + (n >> 2)) * 16;
+      o[e] = run_n;
+      o[4 + e] = run_k;
+      o[8 + e] = run_1;
+      o[12 + e] = run_2;
+    }
+  }
+}
+
 // ---- host side -------------------------------------------------------------------------------------------------
 static void magic(unsigned dv, unsigned* mul, unsigned* sh) {
   if (dv <= 1) { *mul = 0; *sh = 0; return; }
@@ -388,6 +712,51 @@ int g_force_cfg = -1;    // sf_conv_tune(1, c): force configuration c (microbenc
 int g_force_rows = 0;    // sf_conv_tune(2, r): force rows per M tile
 int g_enable = 1;        // sf_conv_tune(0, e): 0 = never take the wave path
 int g_k32 = 0;           // sf_conv_tune(3, 1): 32-channel K steps where the packed rows allow (measured slower)
+
+int g_dbg = 0;           // sf_conv_tune(5, mask): persistent kernel ablations (microbenchmarks)
+int g_persist = 1;       // sf_conv_tune(4, e): 0 = KS == 1 layers on the one-pass kernel (A/B runs)
+
+// 0: never; 1: every KS == 1 layer the instantiations cover; 2: plain (1x1x1) layers only; 3 (default): plain layers
+// with at most 4 K steps
+static int persist_level() {
+  static const int env_on = [] {
+    const char* e = getenv("SF_CONV_WAVE_P");
+    return e ? atoi(e) : 3;
+  }();
+  return g_persist ? env_on : 0;
+}
+
+// launch == false: only report the workgroups of this instantiation a CU holds (registers), asked of the runtime once
+template <int TM, int TN, bool PLAIN>
+static int wave_p(const WaveArgs& a, int nwg, hipStream_t s, bool launch) {
+  if (!launch) {
+    static const int occ = [] {
+      int n = 0;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv_wave_p_kernel<TM, TN, 1, PLAIN>, 256, 0) != hipSuccess || n < 1)
+        n = 1;
+      return n > 4 ? 4 : n;
+    }();
+    return occ;
+  }
+  hipLaunchKernelGGL((conv_wave_p_kernel<TM, TN, 1, PLAIN>), dim3(nwg), dim3(256), 0, s, a);
+  SF_CHECK_LAUNCH();
+  return SF_OK;
+}
+
+static int wave_p_dispatch(int best, const WaveArgs& a, int nwg, hipStream_t s, bool launch) {
+  if (a.plain) {
+    switch (best) {
+      case 1: return wave_p<13, 2, true>(a, nwg, s, launch);
+      case 3: return wave_p<7, 4, true>(a, nwg, s, launch);
+      case 5: return wave_p<7, 2, true>(a, nwg, s, launch);
+      default: return wave_p<13, 1, true>(a, nwg, s, launch);
+    }
+  }
+  switch (best) {  // the 7x4 / 13x2 tiles have no room for a second row-state set: one-pass kernel
+    case 5: return wave_p<7, 2, false>(a, nwg, s, launch);
+    default: return wave_p<13, 1, false>(a, nwg, s, launch);
+  }
+}
 
 template <int TM, int TN, int KS>
 static int launch_wave(const WaveArgs& a, int kv, hipStream_t s) {
@@ -439,6 +808,7 @@ static double plan_score(const sf_conv_desc* d, long M, int nk, bool has_res, co
 }  // namespace
 
 int sf_wgrad_wave_tune(int knob, int value);  // conv_wgrad_wave.hip (knobs 10..)
+int sf_conv_small_tune(int value);            // conv_small.hip
 
 // Runtime knobs for microbenchmarks / A-B runs (not used by the model code).
 extern "C" int sf_conv_tune(int knob, int value) {
@@ -447,6 +817,9 @@ extern "C" int sf_conv_tune(int knob, int value) {
   else if (knob == 1) g_force_cfg = value;
   else if (knob == 2) g_force_rows = value;
   else if (knob == 3) g_k32 = value;
+  else if (knob == 4) g_persist = value;
+  else if (knob == 5) g_dbg = value;
+  else if (knob == 6) return sf_conv_small_tune(value);
   else return SF_EINVAL;
   return SF_OK;
 }
@@ -474,7 +847,11 @@ int sf_conv_wave_takes(const sf_conv_desc* d) {
 }
 
 // Upper bound of the M tiles any configuration makes of M rows (rows per tile >= M / (ceil(M / 112) + 47)).
-long sf_conv_wave_max_parts(long M) { return (M + 111) / 112 + 48; }
+// (the persistent form leaves one record per wavefront of its grid and channel tile: at most 256 CUs x 4 workgroups x 4)
+long sf_conv_wave_max_parts(long M) {
+  const long tiles = (M + 111) / 112 + 48;
+  return tiles > 4096 ? tiles : 4096;
+}
 
 // Returns 1 when the shape is not taken (the caller falls through to conv_igemm), else SF_OK / an error code.
 int sf_conv_wave_try(const sf_conv_desc* d, const float* in, const float* w_packed, const float* scale,
@@ -534,6 +911,42 @@ int sf_conv_wave_try(const sf_conv_desc* d, const float* in, const float* w_pack
   a.stats = (stats && stat_parts && !scale && !res && d->act == SF_ACT_NONE && !scatter && sf_aligned16(stats) &&
              d->Cout % 4 == 0)
                 ? stats : nullptr;
+  // persistent form: every plain (1x1x1) layer, and the other KS == 1 layers on the tiles whose register budget has
+  // room for a second row-state set (13x2 stays on the one-pass kernel there)
+  const long rows_out = scatter ? (long)d->N * d->ob_T * d->ob_H * d->ob_W : M;
+  const long out_b = rows_out * d->out_cs * 4, res_b = res ? rows_out * d->res_cs * 4 : 0;
+  a.dbg = g_dbg;
+  a.out_bytes = (unsigned)out_b;
+  a.res_bytes = (unsigned)res_b;
+  // Where the persistent form pays (tools/microbench/conv_pw_probe.py, MI355X): plain layers with at most 4 K steps
+  // (K <= 64: 64 -> 256 at 56^2 79 us on 7x2 tiles against 86-94 us one-pass on any tile; the C <= 32 Fast-pathway
+  // projections 10-25 % faster) — a tile there is ~7 k MFMA cycles, as long as the one-pass kernel's fixed part.  From
+  // 8 K steps on the two forms are within 3 % of each other and the planner's picks stay on the one-pass kernel.
+  // SF_CONV_WAVE_P=1 sends every KS == 1 layer the instantiations cover to the persistent form (A/B runs).
+  const bool can_p = kv == 1 && persist_level() > 0 && out_b < 0x7ffffff0L && res_b < 0x7ffffff0L;
+  const bool short_k = a.plain && a.nk <= 5;
+  if (can_p && short_k && g_force_cfg < 0 && d->Cout >= 32) {
+    best = 5;  // 7x2 tiles: 3 workgroups per CU at 157 registers
+    plan_score(d, M, a.nk * kv, res != nullptr, CFGS[best], &best_rows);
+    a.rows = best_rows;
+    a.nb_n = sf_cdiv(d->Cout, CFGS[best].tn * 16);
+    a.ntiles = sf_cdiv(M, a.rows) * a.nb_n;
+    a.nwg = sf_cdiv(a.ntiles, 4);
+  }
+  const WaveCfg& cp = CFGS[best];
+  const bool take_p = persist_level() == 1 ? (a.plain || (best != 1 && best != 3)) : (persist_level() == 2 ? a.plain : short_k);
+  if (cp.ks == 1 && can_p && take_p) {
+    const int occ = wave_p_dispatch(best, a, 0, stream, false);
+    int nwg = a.nwg < 256 * occ ? a.nwg : 256 * occ;
+    if (a.stats) {
+      const int g4 = (a.nb_n % 4 == 0) ? 4 : ((a.nb_n % 2 == 0) ? 2 : 1);
+      const int unit = a.nb_n / g4;
+      nwg = (nwg + unit - 1) / unit * unit;
+      *stat_parts = nwg * 4 / a.nb_n;
+      if (*stat_parts > sf_conv_wave_max_parts(M)) { a.stats = nullptr; *stat_parts = 0; }
+    }
+    return wave_p_dispatch(best, a, nwg, stream, true);
+  }
   if (a.stats) *stat_parts = (c.ks == 1 && a.nb_n == 1) ? a.nwg : sf_cdiv(M, a.rows);
   switch (best) {
     case 0: return launch_wave<13, 2, 4>(a, kv, stream);

@@ -56,6 +56,13 @@ CONV_CASES = [
     ("t3_s2t_odd_24_40", 24, 40, (3, 3, 1), (2, 2, 1), (1, 1, 0), (1, 7, 9, 5)),
     ("head_320_1280_m32", 320, 1280, (1, 1, 1), (1, 1, 1), (0, 0, 0), (2, 4, 2, 2)),
     ("pw_96_16_m32", 96, 16, (1, 1, 1), (1, 1, 1), (0, 0, 0), (2, 4, 2, 2)),
+    # small channel counts at >= 4096 positions: the data gradients run on conv_small.hip (mirrored taps)
+    ("sm_8_8_s3", 8, 8, (1, 3, 3), (1, 1, 1), (0, 1, 1), (2, 4, 20, 28)),
+    ("sm_16_16_s3", 16, 16, (1, 3, 3), (1, 1, 1), (0, 1, 1), (2, 3, 28, 28)),
+    ("sm_32_8_t3", 32, 8, (3, 1, 1), (1, 1, 1), (1, 0, 0), (2, 6, 20, 20)),
+    ("sm_128_32_t3", 128, 32, (3, 1, 1), (1, 1, 1), (1, 0, 0), (2, 4, 24, 24)),
+    ("sm_8_32_pw", 8, 32, (1, 1, 1), (1, 1, 1), (0, 0, 0), (2, 4, 24, 25)),
+    ("sm_32_128_pw", 32, 128, (1, 1, 1), (1, 1, 1), (0, 0, 0), (2, 4, 23, 24)),
 ]
 
 

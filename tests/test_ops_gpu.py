@@ -79,6 +79,16 @@ CONV_CASES = [
     ("odd_27_16", 27, 16, (1, 1, 1), (1, 1, 1), (0, 0, 0), (1, 1, 1), (2, 4, 5, 5), True, False, True),
     ("odd_3_24_k333", 3, 24, (3, 3, 3), (1, 2, 2), (1, 1, 1), (1, 1, 1), (2, 4, 16, 16), True, False, True),
     ("fc_2304_400", 2304, 400, (1, 1, 1), (1, 1, 1), (0, 0, 0), (1, 1, 1), (8, 1, 1, 1), False, False, False),
+    # small channel counts at >= 4096 positions: conv_small.hip (LDS-staged input, scalar-register weights)
+    ("sm_8_8_s3", 8, 8, (1, 3, 3), (1, 1, 1), (0, 1, 1), (1, 1, 1), (2, 4, 20, 28), True, True, True),
+    ("sm_16_16_s3_ragged", 16, 16, (1, 3, 3), (1, 1, 1), (0, 1, 1), (1, 1, 1), (2, 3, 28, 28), True, False, True),
+    ("sm_32_32_s3_frame", 32, 32, (1, 3, 3), (1, 1, 1), (0, 1, 1), (1, 1, 1), (4, 6, 14, 14), False, False, True),
+    ("sm_32_8_t3", 32, 8, (3, 1, 1), (1, 1, 1), (1, 0, 0), (1, 1, 1), (2, 6, 20, 20), True, False, True),
+    ("sm_128_32_t3", 128, 32, (3, 1, 1), (1, 1, 1), (1, 0, 0), (1, 1, 1), (2, 4, 24, 24), True, True, True),
+    ("sm_8_32_pw", 8, 32, (1, 1, 1), (1, 1, 1), (0, 0, 0), (1, 1, 1), (2, 4, 24, 25), False, True, True),
+    ("sm_16_64_pw", 16, 64, (1, 1, 1), (1, 1, 1), (0, 0, 0), (1, 1, 1), (2, 4, 24, 24), True, False, True),
+    ("sm_32_128_pw", 32, 128, (1, 1, 1), (1, 1, 1), (0, 0, 0), (1, 1, 1), (2, 4, 23, 24), False, False, False),
+    ("sm_64_16_t3", 64, 16, (3, 1, 1), (1, 1, 1), (1, 0, 0), (1, 1, 1), (1, 5, 30, 30), True, False, True),
 ]
 
 
@@ -442,6 +452,11 @@ STAT_CASES = [
     (512, 128, (3, 1, 1), (1, 1, 1), (1, 0, 0), (2, 4, 7, 7), True),
     (16, 8, (3, 1, 1), (1, 1, 1), (1, 0, 0), (2, 8, 9, 9), False),
     (32, 64, (7, 1, 1), (4, 1, 1), (3, 0, 0), (1, 16, 6, 6), True),
+    # conv_small.hip: one record per workgroup
+    (8, 8, (1, 3, 3), (1, 1, 1), (0, 1, 1), (2, 4, 20, 28), False),
+    (32, 8, (3, 1, 1), (1, 1, 1), (1, 0, 0), (2, 6, 20, 20), True),
+    (16, 64, (1, 1, 1), (1, 1, 1), (0, 0, 0), (2, 4, 24, 25), True),
+    (32, 128, (1, 1, 1), (1, 1, 1), (0, 0, 0), (2, 4, 23, 24), False),
 ]
 
 
