@@ -331,17 +331,48 @@ def main():
     torch.cuda.synchronize()
     graph = None
     graph_note = None
-    if (not train and not args.no_graph) or (train and args.graph_train):
+
+    def capture():
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side):
+            o = step()
+        g.replay()
+        torch.cuda.synchronize()
+        return g, o
+
+    def ms_per(fn, n):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        with torch.cuda.stream(side):
+            for _ in range(n):
+                fn()
+        t_issue = time.perf_counter() - t0
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n * 1e3, t_issue / n * 1e3
+
+    want_graph = (not train and not args.no_graph) or (train and args.graph_train)
+    auto = None
+    if train and not args.graph_train and not args.no_graph and world == 1:
+        # Launch-bound training steps (cfg #1: ~1500 launches of a 0.007 GMAC model): when the Python thread needs as
+        # long to ISSUE a step as the GPU needs to run it, the step is captured into one hipGraph and the faster of
+        # the two forms is timed.  For cfg #2 / #3 the host is 2x ahead (34 of 68 ms) and nothing is captured: their
+        # graph replays slower than the eager streams.
+        eager_ms, issue_ms = ms_per(step, 6)
+        if issue_ms > 0.85 * eager_ms:
+            want_graph = True
+            auto = {"eager_ms": round(eager_ms, 3), "host_issue_ms": round(issue_ms, 3)}
+    if want_graph:
         # eval forward: one hipGraph.  The train step (forward, backward with the tape's streams as graph branches,
-        # SGD) also captures (--graph-train; the capture runs right after an optimizer step, so every conv's weight
-        # re-packing is part of the graph), but replays SLOWER than eager launches on this stack (89.2 vs 81.0 ms:
-        # the graph's branches overlap less than the eager streams do), so eager stays the default for training.
+        # SGD) also captures (the capture runs right after an optimizer step, so every conv's weight re-packing is part
+        # of the graph).
         try:
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph, stream=side):
-                out = step()
-            graph.replay()
-            torch.cuda.synchronize()
+            graph, out = capture()
+            if auto is not None:
+                graph_ms, _ = ms_per(graph.replay, 6)
+                auto["graph_ms"] = round(graph_ms, 3)
+                if graph_ms >= auto["eager_ms"]:
+                    graph = None
+                    graph_note = "eager (host-bound, but the hipGraph replay was not faster: %s)" % json.dumps(auto)
         except Exception as e:  # noqa: BLE001 — fall back to eager launches and say so in the JSON line
             graph, graph_note = None, "hipGraph capture failed (%s: %s); eager launches" % (type(e).__name__, str(e)[:120])
             torch.cuda.synchronize()
@@ -516,7 +547,9 @@ def main():
                        "mode": "train step: train-mode forward + CE + backward + 1 flat-gradient all-reduce + SGD"
                        if train else "eval forward (inference)",
                        "clips_per_gpu": batch, "global_batch": batch * world, "layout": "NCTHW in, NDHWC inside",
-                       "launch": (graph_note or "eager") if graph is None else "hipGraph replay",
+                       "launch": (graph_note or "eager") if graph is None else (
+                           "hipGraph replay" if auto is None else
+                           "hipGraph replay (chosen at warm-up: the eager step is host-bound, %s)" % json.dumps(auto)),
                        "parallelism": "dp%d (clip-sharded replicas; %s)" % (
                            world, "one RCCL all-reduce of the flat fp32 gradient per step" if train
                            else "no data-path collective in forward")},

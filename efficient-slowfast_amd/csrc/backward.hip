@@ -847,6 +847,42 @@ __global__ void dwconv_dgrad_kernel(const sf_conv_desc d, const float* __restric
   dx[rin * dx_cs + dx_coff + c] += acc;
 }
 
+// The same with 4 channels per thread (16-byte loads / stores) and 32-bit position arithmetic.
+__global__ void dwconv_dgrad_vec4_kernel(const sf_conv_desc d, const float* __restrict__ dz, int dz_cs, int dz_coff,
+                                         const float* __restrict__ w, float* __restrict__ dx, int dx_cs, int dx_coff,
+                                         int CV, unsigned total) {
+  const unsigned idx = blockIdx.x * TPB + threadIdx.x;
+  if (idx >= total) return;
+  const unsigned rin = idx / (unsigned)CV;
+  const int c = (int)(idx - rin * (unsigned)CV) * 4;
+  unsigned r = rin;
+  const unsigned q1 = r / (unsigned)d.Wi;
+  const int wi = (int)(r - q1 * (unsigned)d.Wi);
+  const unsigned q2 = q1 / (unsigned)d.Hi;
+  const int hi = (int)(q1 - q2 * (unsigned)d.Hi);
+  const unsigned n = q2 / (unsigned)d.Ti;
+  const int ti = (int)(q2 - n * (unsigned)d.Ti);
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  int tap = 0;
+  for (int kt = 0; kt < d.kT; ++kt) {
+    const int nt = ti + d.pT - kt * d.dT;
+    for (int kh = 0; kh < d.kH; ++kh) {
+      const int nh = hi + d.pH - kh * d.dH;
+      for (int kw = 0; kw < d.kW; ++kw, ++tap) {
+        const int nw = wi + d.pW - kw * d.dW;
+        if (nt < 0 || nh < 0 || nw < 0 || (nt % d.sT) || (nh % d.sH) || (nw % d.sW)) continue;
+        const int to = nt / d.sT, ho = nh / d.sH, wo = nw / d.sW;
+        if (to >= d.To || ho >= d.Ho || wo >= d.Wo) continue;
+        const long ro = (((long)n * d.To + to) * d.Ho + ho) * d.Wo + wo;
+        acc += *reinterpret_cast<const f32x4*>(dz + ro * dz_cs + dz_coff + c) *
+               *reinterpret_cast<const f32x4*>(w + (long)tap * d.cin_pad + c);
+      }
+    }
+  }
+  f32x4* const o = reinterpret_cast<f32x4*>(dx + (long)rin * dx_cs + dx_coff + c);
+  *o += acc;
+}
+
 // dw[tap, c] = sum_m dz[m, c] * x[row(m, tap), c]: partial[blk][tap][c] over the block's output rows
 constexpr int DW_P = 256;
 __global__ void dwconv_wgrad_partial_kernel(const sf_conv_desc d, const float* __restrict__ x,
@@ -891,12 +927,95 @@ __global__ void dwconv_wgrad_partial_kernel(const sf_conv_desc d, const float* _
   }
 }
 
-__global__ void dwconv_wgrad_final_kernel(const float* __restrict__ partial, int n, float* __restrict__ out) {
+// One pass over the rows instead of one per tap: a thread owns 4 channels (16-byte loads) of a strided subset of the
+// block's output rows, decodes each row ONCE, loads dz once and x at every tap (neighbouring taps hit L1), and keeps
+// all taps' sums in registers (NT x 4 accumulators); the row lanes of a channel quad are then summed in lane order
+// through LDS.  The per-tap kernel above re-read dz and re-decoded the position (four 64-bit divisions) once per tap and
+// row: 82 launches of SlowFastGhostNet at 8 clips took 98 ms of a 219 ms step (profiles/r03_ghostnet_b8_*).
+template <int NT>
+__global__ __launch_bounds__(256) void dwconv_wgrad_partial4_kernel(const sf_conv_desc d, const float* __restrict__ x,
+                                                                    const float* __restrict__ dz, int dz_cs, int dz_coff,
+                                                                    int C, int CQ, long rows, int nblk,
+                                                                    float* __restrict__ partial) {
+  __shared__ f32x4 red[9][TPB];
+  const int blk = blockIdx.x, cb = blockIdx.y;
+  const int ql = threadIdx.x % CQ, rl = threadIdx.x / CQ, rpi = TPB / CQ;
+  const int c = (cb * CQ + ql) * 4;
+  const bool cok = c < C;
+  const long per = (rows + nblk - 1) / nblk;
+  const long r0 = (long)blk * per;
+  const long r1 = (r0 + per < rows) ? r0 + per : rows;
+  const int ntaps = d.kT * d.kH * d.kW;
+  f32x4 acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  if (cok) {
+    for (long m = r0 + rl; m < r1; m += rpi) {
+      const unsigned mu = (unsigned)m;                       // rows < 2^31 (checked by the launcher)
+      const unsigned q1 = mu / (unsigned)d.Wo;
+      const int wo = (int)(mu - q1 * (unsigned)d.Wo);
+      const unsigned q2 = q1 / (unsigned)d.Ho;
+      const int ho = (int)(q1 - q2 * (unsigned)d.Ho);
+      const unsigned n = q2 / (unsigned)d.To;
+      const int to = (int)(q2 - n * (unsigned)d.To);
+      const f32x4 g = *reinterpret_cast<const f32x4*>(dz + m * dz_cs + dz_coff + c);
+      const int t0 = to * d.sT - d.pT, h0 = ho * d.sH - d.pH, w0 = wo * d.sW - d.pW;
+      const float* const xb = x + (((long)n * d.Ti) * d.Hi * d.Wi) * d.in_cs + d.in_coff + c;
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        if (t < ntaps) {
+          const int kw = t % d.kW, kh = (t / d.kW) % d.kH, kt = t / (d.kW * d.kH);
+          const int ti = t0 + kt * d.dT, hi = h0 + kh * d.dH, wi = w0 + kw * d.dW;
+          if ((unsigned)ti < (unsigned)d.Ti && (unsigned)hi < (unsigned)d.Hi && (unsigned)wi < (unsigned)d.Wi) {
+            const f32x4 xv = *reinterpret_cast<const f32x4*>(xb + (((long)ti * d.Hi + hi) * d.Wi + wi) * d.in_cs);
+            acc[t] += g * xv;
+          }
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < (NT + 8) / 9; ++r) {                    // 9 taps per round through LDS
+    const int t0 = r * 9;
+    if (t0 < ntaps) {                                         // uniform
+#pragma unroll
+      for (int u = 0; u < 9; ++u)
+        if (t0 + u < NT) red[u][threadIdx.x] = acc[t0 + u];
+      __syncthreads();
+      if (rl == 0 && cok) {
+        for (int u = 0; u < 9 && t0 + u < ntaps; ++u) {
+          f32x4 tot = {0.f, 0.f, 0.f, 0.f};
+          for (int i = 0; i < rpi; ++i) tot += red[u][i * CQ + ql];
+          *reinterpret_cast<f32x4*>(partial + ((long)blk * ntaps + t0 + u) * C + c) = tot;
+        }
+      }
+      __syncthreads();
+    }
+  }
+}
+
+__global__ void dwconv_wgrad_final_kernel(const float* __restrict__ partial, int n, int nblk, float* __restrict__ out) {
   const int i = blockIdx.x * TPB + threadIdx.x;  // i over ntaps*C
   if (i >= n) return;
   double s = 0.0;
-  for (int b = 0; b < DW_P; ++b) s += (double)partial[(long)b * n + i];
+  for (int b = 0; b < nblk; ++b) s += (double)partial[(long)b * n + i];
   out[i] = (float)s;
+}
+
+// Row blocks of the one-pass kernel: enough workgroups to fill the chip when the layer has few channel blocks
+// (C = 32: one channel block — 256 row blocks were one workgroup per CU, every load latency exposed).
+static inline int dw_quads_per_block(int C) {
+  int CQ = 1;
+  while (CQ < C / 4 && CQ < 64) CQ <<= 1;
+  return CQ;
+}
+static inline int dw_row_blocks(int C, long rows) {
+  if (C % 4) return DW_P;
+  const int ncb = sf_cdiv(C / 4, dw_quads_per_block(C));
+  long nb = 2048 / ncb;
+  if (nb > rows / 64) nb = rows / 64;
+  if (nb < DW_P) nb = DW_P;
+  return (int)nb;
 }
 
 // out[r, c] (+)= in[r, in_coff + c * in_cmul]   (backward of a channel-strided store / shuffle)
@@ -918,6 +1037,13 @@ extern "C" int sf_dwconv_dgrad(const sf_conv_desc* d, const float* dz, int dz_cs
                                float* dx, int dx_cs, int dx_coff, int C, void* stream) {
   if (!d || !dz || !w_packed || !dx || C <= 0) return SF_EINVAL;
   const long total = (long)d->N * d->Ti * d->Hi * d->Wi * C;
+  if (C % 4 == 0 && dz_cs % 4 == 0 && dz_coff % 4 == 0 && dx_cs % 4 == 0 && dx_coff % 4 == 0 && d->cin_pad % 4 == 0 &&
+      sf_aligned16(dz) && sf_aligned16(dx) && sf_aligned16(w_packed) && total / 4 < 0x7fffffffL) {
+    hipLaunchKernelGGL(dwconv_dgrad_vec4_kernel, dim3(sf_cdiv(total / 4, TPB)), dim3(TPB), 0, (hipStream_t)stream, *d, dz,
+                       dz_cs, dz_coff, w_packed, dx, dx_cs, dx_coff, C / 4, (unsigned)(total / 4));
+    SF_CHECK_LAUNCH();
+    return SF_OK;
+  }
   hipLaunchKernelGGL(dwconv_dgrad_kernel, dim3(sf_cdiv(total, TPB)), dim3(TPB), 0, (hipStream_t)stream, *d, dz, dz_cs,
                      dz_coff, w_packed, dx, dx_cs, dx_coff, C, total);
   SF_CHECK_LAUNCH();
@@ -925,7 +1051,9 @@ extern "C" int sf_dwconv_dgrad(const sf_conv_desc* d, const float* dz, int dz_cs
 }
 
 extern "C" long sf_dwconv_wgrad_ws_floats(const sf_conv_desc* d, int C) {
-  return d ? (long)DW_P * d->kT * d->kH * d->kW * C : 0;
+  if (!d) return 0;
+  const long rows = (long)d->N * d->To * d->Ho * d->Wo;
+  return (long)dw_row_blocks(C, rows) * d->kT * d->kH * d->kW * C;
 }
 
 extern "C" int sf_dwconv_wgrad(const sf_conv_desc* d, const float* x, const float* dz, int dz_cs, int dz_coff, int C,
@@ -934,10 +1062,25 @@ extern "C" int sf_dwconv_wgrad(const sf_conv_desc* d, const float* x, const floa
   const long rows = (long)d->N * d->To * d->Ho * d->Wo;
   const int CB = pow2ceil_b(C) < TPB ? pow2ceil_b(C) : TPB;
   const int ntaps = d->kT * d->kH * d->kW;
-  hipLaunchKernelGGL(dwconv_wgrad_partial_kernel, dim3(DW_P, sf_cdiv(C, CB)), dim3(TPB), 0, (hipStream_t)stream, *d, x,
-                     dz, dz_cs, dz_coff, C, CB, rows, ws);
+  const bool vec4 = (C % 4 == 0) && (d->in_cs % 4 == 0) && (d->in_coff % 4 == 0) && (dz_cs % 4 == 0) &&
+                    (dz_coff % 4 == 0) && sf_aligned16(x) && sf_aligned16(dz) && sf_aligned16(ws) && rows < 0x7fffffffL &&
+                    ntaps <= 27;
+  int nblk = DW_P;
+  if (vec4) {
+    const int CQ = dw_quads_per_block(C);                     // channel quads per block: a power of two <= 64
+    nblk = dw_row_blocks(C, rows);
+    const dim3 grid(nblk, sf_cdiv(C / 4, CQ));
+    if (ntaps <= 9)
+      hipLaunchKernelGGL(dwconv_wgrad_partial4_kernel<9>, grid, dim3(TPB), 0, (hipStream_t)stream, *d, x, dz, dz_cs,
+                         dz_coff, C, CQ, rows, nblk, ws);
+    else
+      hipLaunchKernelGGL(dwconv_wgrad_partial4_kernel<27>, grid, dim3(TPB), 0, (hipStream_t)stream, *d, x, dz, dz_cs,
+                         dz_coff, C, CQ, rows, nblk, ws);
+  } else
+    hipLaunchKernelGGL(dwconv_wgrad_partial_kernel, dim3(DW_P, sf_cdiv(C, CB)), dim3(TPB), 0, (hipStream_t)stream, *d, x,
+                       dz, dz_cs, dz_coff, C, CB, rows, ws);
   hipLaunchKernelGGL(dwconv_wgrad_final_kernel, dim3(sf_cdiv(ntaps * C, TPB)), dim3(TPB), 0, (hipStream_t)stream, ws,
-                     ntaps * C, dw);
+                     ntaps * C, nblk, dw);
   SF_CHECK_LAUNCH();
   return SF_OK;
 }

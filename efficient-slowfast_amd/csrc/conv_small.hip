@@ -44,6 +44,7 @@ struct SmallArgs {
   int tiles_per_frame; // spatial
   int c4_shift;        // log2(CK / 4)
   int M;
+  int dbg;             // microbenchmarks: 1 = no staging loads, 2 = no FMA loop, 4 = no stores
   unsigned hw_mul, hw_sh, t_mul, t_sh, w_mul, w_sh;  // n / HW, n / T, n / W as mulhi + shift (mul == 0: divisor 1)
 };
 
@@ -104,41 +105,56 @@ __global__ __launch_bounds__(256) void conv_small_kernel(const SmallArgs p) {
 
   for (int k0 = 0; k0 < p.Cin; k0 += CK) {
     if (k0) __syncthreads();                     // everyone is done reading the previous chunk
-    // ---- stage: [slab][row][col][CK] <- input, zero outside the frame / the tensor / the channel range
+    // ---- stage: [slab][row][col][CK] <- input, zero outside the frame / the tensor / the channel range.  U loads per
+    //      thread are issued before the first LDS store (one load -> wait -> store per iteration made the kernel wait a
+    //      full memory latency per 16 bytes: 32 -> 8 3x1x1 took 148 us for 128 MB)
     {
       const int per_slab = R * Wp << p.c4_shift;               // float4 items per slab
       const int total = per_slab * nslab;
-      for (int idx = tid; idx < total; idx += 256) {
-        const int s = idx / per_slab;                          // nslab <= 3: cheap
-        const int it = idx - s * per_slab;
-        const int c4 = it & ((1 << p.c4_shift) - 1);
-        const int cell = it >> p.c4_shift;                     // row * Wp + col
-        long src = -1;
-        if (p.spatial) {
-          const int rr = cell / Wp, cc = cell - rr * Wp;
-          const int hh = h0 + rr - (p.kH >> 1), ww = cc - (p.kW >> 1);
-          if ((unsigned)hh < (unsigned)p.H && (unsigned)ww < (unsigned)p.W) src = (long)frame * p.HW + hh * p.W + ww;
-        } else {
-          const int mm = m0 + cell;
-          if (mm < p.M) {
-            const int o = s - (p.kT >> 1);                     // temporal offset of this slab
-            if (o == 0) src = mm;
-            else {
-              const unsigned f = fdiv((unsigned)mm, p.hw_mul, p.hw_sh);
-              const int t = (int)(f - fdiv(f, p.t_mul, p.t_sh) * (unsigned)p.T);
-              if ((unsigned)(t + o) < (unsigned)p.T) src = (long)mm + (long)o * p.HW;
+      constexpr int U = 6;
+      for (int base = tid; base < total; base += 256 * U) {
+        f32x4 v[U];
+        int dst[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int idx = base + u * 256;
+          dst[u] = -1;
+          v[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+          if (idx < total) {
+            const int s = idx / per_slab;                      // nslab <= 3: cheap
+            const int it = idx - s * per_slab;
+            const int c4 = it & ((1 << p.c4_shift) - 1);
+            const int cell = it >> p.c4_shift;                 // row * Wp + col
+            long src = -1;
+            if (p.spatial) {
+              const int rr = cell / Wp, cc = cell - rr * Wp;
+              const int hh = h0 + rr - (p.kH >> 1), ww = cc - (p.kW >> 1);
+              if ((unsigned)hh < (unsigned)p.H && (unsigned)ww < (unsigned)p.W) src = (long)frame * p.HW + hh * p.W + ww;
+            } else {
+              const int mm = m0 + cell;
+              if (mm < p.M) {
+                const int o = s - (p.kT >> 1);                 // temporal offset of this slab
+                if (o == 0) src = mm;
+                else {
+                  const unsigned f = fdiv((unsigned)mm, p.hw_mul, p.hw_sh);
+                  const int t = (int)(f - fdiv(f, p.t_mul, p.t_sh) * (unsigned)p.T);
+                  if ((unsigned)(t + o) < (unsigned)p.T) src = (long)mm + (long)o * p.HW;
+                }
+              }
             }
+            const int ch = k0 + c4 * 4;
+            dst[u] = s * slab_floats + cell * PITCH + c4 * 4;
+            if (src >= 0 && ch < p.Cin && !(p.dbg & 1)) v[u] = *reinterpret_cast<const f32x4*>(p.in + src * p.in_cs + p.in_coff + ch);
           }
         }
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        const int ch = k0 + c4 * 4;
-        if (src >= 0 && ch < p.Cin) v = *reinterpret_cast<const f32x4*>(p.in + src * p.in_cs + p.in_coff + ch);
-        *reinterpret_cast<f32x4*>(lds + s * slab_floats + cell * PITCH + c4 * 4) = v;
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+          if (dst[u] >= 0) *reinterpret_cast<f32x4*>(lds + dst[u]) = v[u];
       }
     }
     __syncthreads();
     // ---- compute: this thread's position x CO_T output channels over the chunk's CK input channels of every tap
-    if (active) {
+    if (active && !(p.dbg & 2)) {
       for (int kt = 0; kt < p.kT; ++kt)
         for (int kh = 0; kh < p.kH; ++kh)
           for (int kw = 0; kw < p.kW; ++kw) {
@@ -175,7 +191,7 @@ __global__ __launch_bounds__(256) void conv_small_kernel(const SmallArgs p) {
       acc[c] = v;
     }
   }
-  if (active) {
+  if (active && !(p.dbg & 4)) {
     float* const o = p.out + (long)m * p.out_cs + p.out_coff + n0;
     const float* const r = p.res ? p.res + (long)m * p.res_cs + p.res_coff + n0 : nullptr;
 #pragma unroll
@@ -234,7 +250,8 @@ static void magic(unsigned dv, unsigned* mul, unsigned* sh) {
   *sh = l - 1;
 }
 
-int g_small_enable = 1;  // sf_conv_tune(6, e)
+int g_small_enable = 1;  // sf_conv_tune(6, e): bit 0 = enable, bits 4.. = ablation mask (microbenchmarks)
+int g_small_dbg = 0;
 
 static int small_level() {
   static const int env_on = [] {
@@ -261,7 +278,7 @@ static int launch_small(const SmallArgs& a, int ntile, size_t lds_bytes, hipStre
 
 }  // namespace
 
-int sf_conv_small_tune(int value) { g_small_enable = value; return SF_OK; }
+int sf_conv_small_tune(int value) { g_small_enable = value & 1; g_small_dbg = value >> 4; return SF_OK; }
 
 // Shape-only decision (pointer alignment is checked at launch).  parts_out: workgroups = statistics records.
 int sf_conv_small_takes(const sf_conv_desc* d, int* parts_out) {
@@ -322,6 +339,7 @@ int sf_conv_small_try(const sf_conv_desc* d, const float* in, const float* w_pac
   a.flip = d->transposed ? 1 : 0;
   a.act = d->act;
   a.M = (int)((long)d->N * d->To * d->Ho * d->Wo);
+  a.dbg = g_small_dbg;
   a.G = d->Cout > 32 ? d->Cout / 32 : 1;
   const int co_t = d->Cout > 32 ? 32 : d->Cout;
   a.spatial = (d->kH > 1 || d->kW > 1) ? 1 : 0;

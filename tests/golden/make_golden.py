@@ -48,6 +48,11 @@ CASES = [
     dict(name="ghostnet_w2_s64", yaml="SLOWFAST_GHOSTNET_8x8_R50_stepwise_multigrid.yaml",
          model="SlowFastGhostNet", batch=1, t=16, alpha=4, size=64,
          over=["SLOWFAST.WIDTH_MULTI", 2.0, "SLOWFAST.ALPHA", 4] + small(64, 16)),
+    # ... and at the LARGEST size the reference itself can run (SURVEY §8c / BASELINE.md §2: dense attention over
+    # N = 8 x 56 x 56 = 25 088 positions at s1_fuse, 2 x 2.5 GB per call): S = 112, T = 32 (the 32x2 sampling of cfg #5)
+    dict(name="ghostnet_w2_s112", yaml="SLOWFAST_GHOSTNET_8x8_R50_stepwise_multigrid.yaml",
+         model="SlowFastGhostNet", batch=1, t=32, alpha=4, size=112,
+         over=["SLOWFAST.WIDTH_MULTI", 2.0, "SLOWFAST.ALPHA", 4] + small(112, 32)),
     # SlowFastMoibleNetV2 (sic) w1.0 + CMDA at S=64, T=16
     dict(name="mobilenetv2_w1_s64", yaml="SLOWFAST_MOBILENETV2_8x8_R50_stepwise_multigrid.yaml",
          model="SlowFastMoibleNetV2", batch=2, t=16, alpha=4, size=64,
