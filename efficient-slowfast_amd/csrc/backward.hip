@@ -932,23 +932,38 @@ __global__ void dwconv_wgrad_partial_kernel(const sf_conv_desc d, const float* _
 // all taps' sums in registers (NT x 4 accumulators); the row lanes of a channel quad are then summed in lane order
 // through LDS.  The per-tap kernel above re-read dz and re-decoded the position (four 64-bit divisions) once per tap and
 // row: 82 launches of SlowFastGhostNet at 8 clips took 98 ms of a 219 ms step (profiles/r03_ghostnet_b8_*).
-template <int NT>
+template <int V> struct DwVec;
+template <> struct DwVec<4> {
+  typedef f32x4 T;
+  static __device__ __forceinline__ T zero() { return (T){0.f, 0.f, 0.f, 0.f}; }
+  static __device__ __forceinline__ T load(const float* p) { return *reinterpret_cast<const T*>(p); }
+  static __device__ __forceinline__ void store(float* p, T v) { *reinterpret_cast<T*>(p) = v; }
+};
+template <> struct DwVec<1> {
+  typedef float T;
+  static __device__ __forceinline__ T zero() { return 0.f; }
+  static __device__ __forceinline__ T load(const float* p) { return *p; }
+  static __device__ __forceinline__ void store(float* p, T v) { *p = v; }
+};
+
+template <int NT, int V>
 __global__ __launch_bounds__(256) void dwconv_wgrad_partial4_kernel(const sf_conv_desc d, const float* __restrict__ x,
                                                                     const float* __restrict__ dz, int dz_cs, int dz_coff,
                                                                     int C, int CQ, long rows, int nblk,
                                                                     float* __restrict__ partial) {
-  __shared__ f32x4 red[9][TPB];
+  typedef typename DwVec<V>::T VT;
+  __shared__ VT red[9][TPB];
   const int blk = blockIdx.x, cb = blockIdx.y;
   const int ql = threadIdx.x % CQ, rl = threadIdx.x / CQ, rpi = TPB / CQ;
-  const int c = (cb * CQ + ql) * 4;
+  const int c = (cb * CQ + ql) * V;
   const bool cok = c < C;
   const long per = (rows + nblk - 1) / nblk;
   const long r0 = (long)blk * per;
   const long r1 = (r0 + per < rows) ? r0 + per : rows;
   const int ntaps = d.kT * d.kH * d.kW;
-  f32x4 acc[NT];
+  VT acc[NT];
 #pragma unroll
-  for (int t = 0; t < NT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int t = 0; t < NT; ++t) acc[t] = DwVec<V>::zero();
   if (cok) {
     for (long m = r0 + rl; m < r1; m += rpi) {
       const unsigned mu = (unsigned)m;                       // rows < 2^31 (checked by the launcher)
@@ -958,7 +973,7 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_partial4_kernel(const sf_con
       const int ho = (int)(q1 - q2 * (unsigned)d.Ho);
       const unsigned n = q2 / (unsigned)d.To;
       const int to = (int)(q2 - n * (unsigned)d.To);
-      const f32x4 g = *reinterpret_cast<const f32x4*>(dz + m * dz_cs + dz_coff + c);
+      const VT g = DwVec<V>::load(dz + m * dz_cs + dz_coff + c);
       const int t0 = to * d.sT - d.pT, h0 = ho * d.sH - d.pH, w0 = wo * d.sW - d.pW;
       const float* const xb = x + (((long)n * d.Ti) * d.Hi * d.Wi) * d.in_cs + d.in_coff + c;
 #pragma unroll
@@ -967,7 +982,7 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_partial4_kernel(const sf_con
           const int kw = t % d.kW, kh = (t / d.kW) % d.kH, kt = t / (d.kW * d.kH);
           const int ti = t0 + kt * d.dT, hi = h0 + kh * d.dH, wi = w0 + kw * d.dW;
           if ((unsigned)ti < (unsigned)d.Ti && (unsigned)hi < (unsigned)d.Hi && (unsigned)wi < (unsigned)d.Wi) {
-            const f32x4 xv = *reinterpret_cast<const f32x4*>(xb + (((long)ti * d.Hi + hi) * d.Wi + wi) * d.in_cs);
+            const VT xv = DwVec<V>::load(xb + (((long)ti * d.Hi + hi) * d.Wi + wi) * d.in_cs);
             acc[t] += g * xv;
           }
         }
@@ -984,9 +999,9 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_partial4_kernel(const sf_con
       __syncthreads();
       if (rl == 0 && cok) {
         for (int u = 0; u < 9 && t0 + u < ntaps; ++u) {
-          f32x4 tot = {0.f, 0.f, 0.f, 0.f};
+          VT tot = DwVec<V>::zero();
           for (int i = 0; i < rpi; ++i) tot += red[u][i * CQ + ql];
-          *reinterpret_cast<f32x4*>(partial + ((long)blk * ntaps + t0 + u) * C + c) = tot;
+          DwVec<V>::store(partial + ((long)blk * ntaps + t0 + u) * C + c, tot);
         }
       }
       __syncthreads();
@@ -998,23 +1013,32 @@ __global__ void dwconv_wgrad_final_kernel(const float* __restrict__ partial, int
   const int i = blockIdx.x * TPB + threadIdx.x;  // i over ntaps*C
   if (i >= n) return;
   double s = 0.0;
-  for (int b = 0; b < nblk; ++b) s += (double)partial[(long)b * n + i];
+  int b = 0;
+  for (; b + 8 <= nblk; b += 8) {  // 8 independent loads in flight, summed in block order
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = partial[(long)(b + u) * n + i];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += (double)v[u];
+  }
+  for (; b < nblk; ++b) s += (double)partial[(long)b * n + i];
   out[i] = (float)s;
 }
 
 // Row blocks of the one-pass kernel: enough workgroups to fill the chip when the layer has few channel blocks
 // (C = 32: one channel block — 256 row blocks were one workgroup per CU, every load latency exposed).
-static inline int dw_quads_per_block(int C) {
+static inline int dw_quads_per_block(int nq) {  // nq = channel groups (quads, or single channels when C % 4 != 0)
   int CQ = 1;
-  while (CQ < C / 4 && CQ < 64) CQ <<= 1;
+  while (CQ < nq && CQ < 64) CQ <<= 1;
   return CQ;
 }
 static inline int dw_row_blocks(int C, long rows) {
-  if (C % 4) return DW_P;
-  const int ncb = sf_cdiv(C / 4, dw_quads_per_block(C));
-  long nb = 2048 / ncb;
+  const int nq = (C % 4 == 0) ? C / 4 : C;
+  const int ncb = sf_cdiv(nq, dw_quads_per_block(nq));
+  long nb = 1024 / ncb;                                    // ~1024 workgroups in all: 4 per CU
+  if (nb > 512) nb = 512;                                  // what the final kernel sums per output
   if (nb > rows / 64) nb = rows / 64;
-  if (nb < DW_P) nb = DW_P;
+  if (nb < 64) nb = 64;
   return (int)nb;
 }
 
@@ -1053,7 +1077,8 @@ extern "C" int sf_dwconv_dgrad(const sf_conv_desc* d, const float* dz, int dz_cs
 extern "C" long sf_dwconv_wgrad_ws_floats(const sf_conv_desc* d, int C) {
   if (!d) return 0;
   const long rows = (long)d->N * d->To * d->Ho * d->Wo;
-  return (long)dw_row_blocks(C, rows) * d->kT * d->kH * d->kW * C;
+  const int nb = dw_row_blocks(C, rows);
+  return (long)(nb > DW_P ? nb : DW_P) * d->kT * d->kH * d->kW * C;
 }
 
 extern "C" int sf_dwconv_wgrad(const sf_conv_desc* d, const float* x, const float* dz, int dz_cs, int dz_coff, int C,
@@ -1063,19 +1088,27 @@ extern "C" int sf_dwconv_wgrad(const sf_conv_desc* d, const float* x, const floa
   const int CB = pow2ceil_b(C) < TPB ? pow2ceil_b(C) : TPB;
   const int ntaps = d->kT * d->kH * d->kW;
   const bool vec4 = (C % 4 == 0) && (d->in_cs % 4 == 0) && (d->in_coff % 4 == 0) && (dz_cs % 4 == 0) &&
-                    (dz_coff % 4 == 0) && sf_aligned16(x) && sf_aligned16(dz) && sf_aligned16(ws) && rows < 0x7fffffffL &&
-                    ntaps <= 27;
+                    (dz_coff % 4 == 0) && sf_aligned16(x) && sf_aligned16(dz) && sf_aligned16(ws);
   int nblk = DW_P;
-  if (vec4) {
-    const int CQ = dw_quads_per_block(C);                     // channel quads per block: a power of two <= 64
+  if (rows < 0x7fffffffL && ntaps <= 27) {                   // one pass over the rows, all taps in registers
+    const int nq = (C % 4 == 0) ? C / 4 : C;                 // (the row-block count follows C % 4 alone: see ws_floats)
+    const int CQ = dw_quads_per_block(nq);
     nblk = dw_row_blocks(C, rows);
-    const dim3 grid(nblk, sf_cdiv(C / 4, CQ));
-    if (ntaps <= 9)
-      hipLaunchKernelGGL(dwconv_wgrad_partial4_kernel<9>, grid, dim3(TPB), 0, (hipStream_t)stream, *d, x, dz, dz_cs,
-                         dz_coff, C, CQ, rows, nblk, ws);
-    else
-      hipLaunchKernelGGL(dwconv_wgrad_partial4_kernel<27>, grid, dim3(TPB), 0, (hipStream_t)stream, *d, x, dz, dz_cs,
-                         dz_coff, C, CQ, rows, nblk, ws);
+    const dim3 grid(nblk, sf_cdiv(nq, CQ));
+    hipStream_t st = (hipStream_t)stream;
+    if (C % 4 == 0 && vec4) {
+      if (ntaps <= 9)
+        hipLaunchKernelGGL((dwconv_wgrad_partial4_kernel<9, 4>), grid, dim3(TPB), 0, st, *d, x, dz, dz_cs, dz_coff, C, CQ, rows, nblk, ws);
+      else
+        hipLaunchKernelGGL((dwconv_wgrad_partial4_kernel<27, 4>), grid, dim3(TPB), 0, st, *d, x, dz, dz_cs, dz_coff, C, CQ, rows, nblk, ws);
+    } else {
+      const int CQ1 = dw_quads_per_block(C);
+      const dim3 grid1(nblk, sf_cdiv(C, CQ1));
+      if (ntaps <= 9)
+        hipLaunchKernelGGL((dwconv_wgrad_partial4_kernel<9, 1>), grid1, dim3(TPB), 0, st, *d, x, dz, dz_cs, dz_coff, C, CQ1, rows, nblk, ws);
+      else
+        hipLaunchKernelGGL((dwconv_wgrad_partial4_kernel<27, 1>), grid1, dim3(TPB), 0, st, *d, x, dz, dz_cs, dz_coff, C, CQ1, rows, nblk, ws);
+    }
   } else
     hipLaunchKernelGGL(dwconv_wgrad_partial_kernel, dim3(DW_P, sf_cdiv(C, CB)), dim3(TPB), 0, (hipStream_t)stream, *d, x,
                        dz, dz_cs, dz_coff, C, CB, rows, ws);
