@@ -22,22 +22,29 @@ class SpatialAttention(nn.Module):
         self.softmax = nn.Softmax(dim=-1)
 
     def qkv(self, x):
-        """One pointwise GEMM producing [q | k | v] rows: [N,T,H,W, 2*C/r + C]."""
-        if self.query_conv.out_channels != self.value_conv.out_channels:
-            raise NotImplementedError("SpatialAttention(reduction != 1) is never instantiated by the reference "
-                                      "models and is not on the HIP path")
+        """One pointwise GEMM producing [q | k | v] rows: [N,T,H,W, 3*C].  With reduction r > 1 (the reference class's
+        default is 8; no shipped model uses it) q and k have C/r channels: their rows of the merged weight are padded
+        with ZERO rows up to C, so the padded channels of q / k are exactly zero, q k^T is unchanged and the flash
+        kernels run as for r = 1 (correct, not tuned: the score product is taken over C instead of C/r channels)."""
+        c = self.input_channel
+        cr = self.query_conv.out_channels
         convs = (self.query_conv, self.key_conv, self.value_conv)
 
+        def padded(t, rows):
+            if t.shape[0] == rows:
+                return t
+            return torch.cat([t, t.new_zeros((rows - t.shape[0],) + tuple(t.shape[1:]))], 0)
+
         def make():
-            w = torch.cat([c.weight for c in convs], 0)
-            b = torch.cat([c.bias for c in convs], 0)
+            w = torch.cat([padded(cv.weight, c) for cv in convs], 0)
+            b = torch.cat([padded(cv.bias, c) for cv in convs], 0)
             return sfhip.pack_conv_weight(w), b.contiguous()
 
-        wp, b = engine._cached(self, "_sf_qkv", engine._key(*[t for c in convs for t in (c.weight, c.bias)]), make)
+        wp, b = engine._cached(self, "_sf_qkv", engine._key(*[t for cv in convs for t in (cv.weight, cv.bias)]), make)
         qkv = sfhip.conv(x, wp, (1, 1, 1), bias=b)
         t = engine.tape()
         if t is not None:
-            c = self.input_channel
+            nout = (cr, cr, c)
 
             def bwd():  # merged q|k|v projection: one wgrad / dgrad, then split per conv
                 g = t.grad_of(qkv)
@@ -45,9 +52,9 @@ class SpatialAttention(nn.Module):
                 dw = sfhip.unpack_conv_weight_grad(dwp, (3 * c, c, 1, 1, 1))
                 db = engine._colsum(g)
                 for i, cv in enumerate(convs):
-                    t.add_pgrad(cv.weight, dw[i * c:(i + 1) * c])
-                    t.add_pgrad(cv.bias, db[i * c:(i + 1) * c])
-                w_all = torch.cat([cv.weight for cv in convs], 0).detach()
+                    t.add_pgrad(cv.weight, dw[i * c:i * c + nout[i]])
+                    t.add_pgrad(cv.bias, db[i * c:i * c + nout[i]])
+                w_all = torch.cat([padded(cv.weight, c) for cv in convs], 0).detach()
                 wtp = sfhip.pack_conv_weight(w_all.transpose(0, 1).contiguous())
                 sfhip.conv_dgrad(g, wtp, x, (1, 1, 1), out=t.grad_of(x), accumulate=True)
 

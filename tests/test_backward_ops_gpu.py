@@ -232,6 +232,54 @@ def test_maxpool_backward(k, s, p, c):
     assert torch.equal(dx.buf, first.buf)
 
 
+@pytest.mark.parametrize("c,reduction", [(32, 8), (32, 1), (64, 4)])
+def test_spatial_attention_module_with_reduction(c, reduction):
+    """SpatialAttention(channel, reduction) as the reference class builds it (wdf_attention_helper.py:17-31: q / k with
+    channel // reduction outputs, default reduction 8): forward and every gradient (x, q/k/v weights and biases, gamma)
+    of the HIP module against autograd through the oracle.  r > 1 runs on zero-padded q / k rows of the merged
+    projection (models/wdf_attention_helper.py::SpatialAttention.qkv)."""
+    import sfhip
+    from oracle import slowfast_oracle as oracle
+    from slowfast.models import engine
+    from slowfast.models.wdf_attention_helper import SpatialAttention
+    dev = _dev()
+    g = torch.Generator().manual_seed(c + reduction)
+    x = torch.randn(2, c, 2, 6, 7, generator=g).requires_grad_(True)
+    m = SpatialAttention(c, reduction=reduction)
+    with torch.no_grad():
+        for nm, cv in (("query_conv", m.query_conv), ("key_conv", m.key_conv), ("value_conv", m.value_conv)):
+            cv.weight.copy_(torch.randn(cv.weight.shape, generator=g) * (0.7 / np.sqrt(c)))
+            cv.bias.copy_(torch.randn(cv.bias.shape, generator=g) * 0.1)
+        m.gamma.fill_(0.6)
+    sd = {"m." + k: v.detach().clone().requires_grad_(True) for k, v in m.state_dict().items()}
+    ref = oracle.spatial_attention(sd, "m", x)
+    dy = torch.randn(ref.shape, generator=g)
+    names = sorted(sd)
+    grads = torch.autograd.grad(ref, [x] + [sd[k] for k in names], dy)
+    m = m.to(dev)
+    t = engine.Tape()
+    with torch.no_grad(), engine.taping(t):
+        xa = sfhip.from_ncthw(x.detach().to(dev))
+        z = m.run(xa)
+        torch.cuda.synchronize()
+        e_fwd = _rel(_back(z), ref)
+        # the taped attention reads dL/dz from z's own buffer (where the BN backward leaves it in a model)
+        z.buf[..., z.coff:z.coff + c] = dy.permute(0, 2, 3, 4, 1).to(dev)
+        for fn, side in reversed(t.ops):
+            fn()
+    torch.cuda.synchronize()
+    e_dx = _rel(_back(t.grad_of(xa)), grads[0])
+    errs = {"fwd": e_fwd, "dx": e_dx}
+    for k, gref in zip(names, grads[1:]):
+        got = t.pgrads[getattr(m, k.split(".")[1]) if k.count(".") == 1 else getattr(getattr(m, k.split(".")[1]), k.split(".")[2])]
+        if k.endswith("key_conv.bias"):  # shift-invariance of the softmax: analytically zero, both sides hold noise
+            assert float(got.abs().max()) < 1e-3 * float(grads[1 + names.index(k.replace("bias", "weight"))].abs().max())
+            continue
+        errs[k] = _rel(got.reshape(gref.shape), gref)
+    _report("SpatialAttention c%d r%d" % (c, reduction), max(errs.values()))
+    assert max(errs.values()) < TOL, errs
+
+
 @pytest.mark.parametrize("c,alpha", [(8, 4), (32, 4), (3, 8)])
 def test_eca_backward(c, alpha):
     """d/dx and d/dw3 of  max-pool_alpha -> ECA gate  against autograd of the oracle's functions."""
