@@ -517,7 +517,7 @@ static int conv_fwd_impl(const sf_conv_desc* d, const float* in, const float* w_
     const int rc = sf_conv_stem_fwd_try(d, in, w_packed, scale, bias, res, out, (hipStream_t)stream);
     if (rc != 1) return rc;
   }
-  {  // small channel counts (the Fast pathway's C <= 32 layers): LDS-staged input, scalar-register weights, vector FMAs
+  {  // the tiniest channel counts (8 -> 8 spatial layers of the Fast pathway): LDS-staged input, scalar-register weights, vector FMAs
     const int rc = sf_conv_small_try(d, in, w_packed, scale, bias, res, out, (hipStream_t)stream, stats, stat_parts);
     if (rc != 1) return rc;
   }

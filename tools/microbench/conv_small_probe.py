@@ -39,14 +39,19 @@ def run(name, shp, cin, cout, k, stats=False):
         return sfhip.conv(x, wp, k, (1, 1, 1), p, out=out, stats=stats)
 
     L.sf_conv_tune(6, 0)
+    L.sf_conv_tune(7, 0)
     t0 = bench(f)
+    L.sf_conv_tune(7, 1)
+    th = bench(f)
+    L.sf_conv_tune(7, 0)
     res = []
     for mask in (0, 1, 2, 4, 7):
         L.sf_conv_tune(6, 1 | (mask << 4))
         res.append(bench(f))
     L.sf_conv_tune(6, 1)
-    print("%-22s rows %7d  HBM floor %5.1f us | mfma %6.1f | small %6.1f  no-loads %6.1f  no-fma %6.1f  no-stores %6.1f  none %6.1f" % (
-        name + (" +stats" if stats else ""), rows, by / 6.3e6, t0, *res))
+    L.sf_conv_tune(7, 1)
+    print("%-22s rows %7d  HBM floor %5.1f us | wave %6.1f | HALO %6.1f | small %6.1f  no-loads %6.1f  no-fma %6.1f  no-stores %6.1f  none %6.1f" % (
+        name + (" +stats" if stats else ""), rows, by / 6.3e6, t0, th, *res))
 
 
 run("8->8 1x3x3", (8, 32, 56, 56), 8, 8, (1, 3, 3))
@@ -59,3 +64,6 @@ run("64->16 3x1x1", (8, 32, 28, 28), 64, 16, (3, 1, 1))
 run("16->64 1x1x1", (8, 32, 28, 28), 16, 64, (1, 1, 1))
 run("32->32 1x3x3", (8, 32, 14, 14), 32, 32, (1, 3, 3))
 run("128->32 3x1x1", (8, 32, 14, 14), 128, 32, (3, 1, 1))
+run("32->128 1x1x1", (8, 32, 14, 14), 32, 128, (1, 1, 1))
+run("16->8 3x1x1", (8, 32, 56, 56), 16, 8, (3, 1, 1))
+run("32->32 1x3x3", (8, 32, 14, 14), 32, 32, (1, 3, 3), stats=True)
