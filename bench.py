@@ -490,7 +490,9 @@ def main():
                                            "backward, dQ/dK/dV in one sweep)"}[kind]
                 traffic, traffic_src = None, None  # HBM bytes per launch: rocprofv3 PMC passes cannot run inside bench.py
                 try:
-                    tj = json.load(open(os.path.join(ROOT, "profiles", "r02b_attention_hbm_traffic.json")))["kernels"]
+                    tfile = next(f for f in ("r03_attention_hbm_traffic.json", "r02b_attention_hbm_traffic.json")
+                             if os.path.exists(os.path.join(ROOT, "profiles", f)))
+                tj = json.load(open(os.path.join(ROOT, "profiles", tfile)))["kernels"]
                     if kind == "attn_bwd_fused" and c == 32 and n == 25088 and b == 8:
                         # the sweep kernel + its three reductions (dQ partials: tiled kernel; dK parts, dV parts)
                         g = -(-(b * n * 8) // 256) * 256
@@ -499,7 +501,7 @@ def main():
                                    + 2 * tj["attn_dq_reduce_kernel grid=%d" % g]["hbm_bytes_per_launch"])
                         traffic_src = "profiles/r02b_attention_hbm_traffic.json (rocprofv3 PMC passes FETCH_SIZE / WRITE_SIZE of " \
                                       "the same kernels, tools/attn_traffic.sh; not measured in this run)"
-                except (OSError, KeyError, ValueError, IndexError):
+                except (OSError, KeyError, ValueError, IndexError, StopIteration):
                     traffic = None
                 roofline = {"bound": "mfma", "kernel": "%s C=%d N=%d B=%d" % (kname, c, n, b),
                             "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
