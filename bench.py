@@ -491,8 +491,8 @@ def main():
                 traffic, traffic_src = None, None  # HBM bytes per launch: rocprofv3 PMC passes cannot run inside bench.py
                 try:
                     tfile = next(f for f in ("r03_attention_hbm_traffic.json", "r02b_attention_hbm_traffic.json")
-                             if os.path.exists(os.path.join(ROOT, "profiles", f)))
-                tj = json.load(open(os.path.join(ROOT, "profiles", tfile)))["kernels"]
+                                 if os.path.exists(os.path.join(ROOT, "profiles", f)))
+                    tj = json.load(open(os.path.join(ROOT, "profiles", tfile)))["kernels"]
                     if kind == "attn_bwd_fused" and c == 32 and n == 25088 and b == 8:
                         # the sweep kernel + its three reductions (dQ partials: tiled kernel; dK parts, dV parts)
                         g = -(-(b * n * 8) // 256) * 256
