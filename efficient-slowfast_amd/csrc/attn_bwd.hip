@@ -29,8 +29,6 @@ struct BwdArgs {
   int zs;                                            // fused kernels: the swept (query) range is cut into zs parts
   float* dkp; float* dvp;                            // zs > 1: dK / dV partials [B][zs][N][CP], summed afterwards
   float* dqp;                                        // two-kernel form with zs > 1: dQ partials [B][zs][N][CP]
-  int dbg;                                           // SF_ATTN_DBG (timing ablations of the fused sweep, results invalid):
-                                                     // 1 = no barriers in the loop, 2 = no partial flush, 4 = no dQ product
 };
 
 constexpr float POS_BIG = 3.0e38f;
@@ -547,7 +545,6 @@ __global__ __launch_bounds__(64 * NW, (CP >= 64) ? 2 : 1) void attn_bwd_fused_ke
           dv[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(dcol[off], pr[r], dv[ct], 0, 0, 0);  // dV^T += dO^T P
           dk[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(qcol[off], s[r], dk[ct], 0, 0, 0);   // dK^T += Q^T dS
         }
-      if (p.dbg & 4) continue;
       // dS [query kappa(r,lh)][key li]  ->  LDS tile T[query][key]  ->  A fragments with the query on the lane
 #pragma unroll
       for (int r = 0; r < 16; ++r) myslot[kappa(r, lh) * TP + li] = s[r];
@@ -569,16 +566,15 @@ __global__ __launch_bounds__(64 * NW, (CP >= 64) ? 2 : 1) void attn_bwd_fused_ke
 #pragma unroll
         for (int r = 0; r < 16; ++r) myslot[(sub * 32 + kappa(r, lh)) * CP + ct * 32 + li] = dqp[sub][ct][r];
     if (more) store_tile(buf ^ 1);
-    if (!(p.dbg & 1)) __syncthreads();
+    __syncthreads();
     // fixed-order sum of the NW wavefronts' partials to the plane
-    if (!(p.dbg & 2))
     for (int e0 = tid * 4; e0 < SLOT; e0 += NT * 4) {
       f32x4 v = *reinterpret_cast<const f32x4*>(slots + e0);
 #pragma unroll
       for (int w = 1; w < NW; ++w) v += *reinterpret_cast<const f32x4*>(slots + w * SLOT + e0);
       *reinterpret_cast<f32x4*>(ws + ((((long)b * nq + t) * p.nt + kb) * (long)SLOT) + e0) = v;  // rows >= N: never read
     }
-    if (!(p.dbg & 1)) __syncthreads();  // slots are reused as transposition tiles by the next iteration
+    __syncthreads();  // slots are reused as transposition tiles by the next iteration
   }
   if (!jok) return;
   if (p.zs > 1) {  // this query part's share of dK / dV; attn_dq_reduce_kernel adds the parts in order
@@ -706,8 +702,6 @@ int launch_fused(BwdArgs a, float* ws, hipStream_t s) {
   a.nt = sf_cdiv(a.N, 32 * NW);  // key blocks (= dQ planes) per clip
   const int qt = (CP >= 64) ? 32 : 64;
   a.zs = sf_sweep_parts((long)a.B * a.nt, sf_cdiv(a.N, qt));
-  static const int dbg = [] { const char* e = getenv("SF_ATTN_DBG"); return e ? atoi(e) : 0; }();
-  a.dbg = dbg;
   const long planes = (long)a.B * a.nt * sf_cdiv(a.N, qt) * qt * CP, part = (long)a.B * a.zs * a.N * CP;
   a.dkp = ws + planes;
   a.dvp = a.dkp + part;
@@ -753,7 +747,7 @@ extern "C" int sf_attn_bwd(const float* q, int q_cs, const float* k, int k_cs, c
   a.dq = dq; a.dk = dk; a.dv = dv;
   a.q_cs = q_cs; a.k_cs = k_cs; a.v_cs = v_cs; a.dz_cs = dz_cs; a.dq_cs = dq_cs; a.dk_cs = dk_cs; a.dv_cs = dv_cs;
   a.B = B; a.C = C; a.N = N; a.nt = sf_cdiv(N, 128);
-  a.zs = 1; a.dkp = a.dvp = a.dqp = nullptr; a.dbg = 0;
+  a.zs = 1; a.dkp = a.dvp = a.dqp = nullptr;
   hipStream_t s = (hipStream_t)stream;
   if (C <= 16)  // 16x16x4 tiles: no padded rows
     return sf_attn_small_bwd_dispatch(q, q_cs, k, k_cs, v, v_cs, dz, dz_cs, lse, dvec, gamma, dq, dq_cs, dk, dk_cs,

@@ -261,8 +261,12 @@ def test_fullsize_eval_forward_matches_oracle(workload):
 
 # relative-L2 bounds of the full-size training step against the oracle (fp32 both sides), with the HIP forward's ReLU
 # masks injected into the oracle (tests/_masks.py: both sides differentiate the same piecewise-linear function; without
-# that the comparison measures mask flips — 2.9e-2 median at this size with the forward equal to 5e-6).
-TRAIN_TOL = {"loss": 1e-4, "logits": 1e-3, "grad_median": 1e-3, "grad_worst": 1e-2, "grad_input": 5e-3}
+# that the comparison measures mask flips — 2.9e-2 median at this size with the forward equal to 5e-6).  Measured on
+# MI355X over several boxes / kernel selections (each re-associates a few fp32 sums; the max-pool arg-max decisions of
+# the stem and of CMDA's temporal pool are NOT injected and still flip now and then): cfg #3 median 2.8e-4 .. 1.1e-3,
+# worst 4e-3 .. 1.5e-2 (always a scalar gamma: one sum over every position of the model), inputs 1.1e-3 .. 1.3e-3;
+# cfg #2 median 1e-4, worst 1.1e-3.  The bounds leave a factor of ~3 on that.
+TRAIN_TOL = {"loss": 1e-4, "logits": 1e-3, "grad_median": 3e-3, "grad_worst": 5e-2, "grad_input": 1e-2}
 
 
 @pytest.mark.parametrize("workload", ["dual", "slowfast"])
