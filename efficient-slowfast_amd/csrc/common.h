@@ -49,6 +49,7 @@ int sf_sweep_parts(long units, int tiles);  // attn_bwd.hip
 // ring; the last arriver resets its counter, so a slot is clean again when the launch ends.
 unsigned* sf_ticket_slots(int n);  // elementwise.hip: n consecutive zeroed counters (host side, no launch)
 bool sf_tickets_enabled();         // SF_BN_TICKET=1 selects the fused reductions (default: two launches, measured faster)
+int sf_tickets_level();            // SF_BN_TICKET value (2: BN backward reductions of >= 256-channel layers only)
 
 __device__ __forceinline__ void sf_store_sc1(float* p, float v) {
   __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

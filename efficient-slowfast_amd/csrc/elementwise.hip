@@ -655,6 +655,13 @@ bool sf_tickets_enabled() {
   static const bool on = [] { const char* e = getenv("SF_BN_TICKET"); return e && e[0] == '1'; }();
   return on;
 }
+// SF_BN_TICKET=2 (round 3, default; 0 = off): tickets only where the last arriver's walk is short — the BN backward
+// reduction of layers with >= 256 channels, cut into <= 64 row blocks (>= 4 channel groups of 64 keep >= 256 workgroups in
+// flight): one launch instead of partial + final on ~50 of the 114 BN layers of cfg #3, 67.8 -> 67.5 ms per step.
+int sf_tickets_level() {
+  static const int lv = [] { const char* e = getenv("SF_BN_TICKET"); return e ? atoi(e) : 2; }();  // default since round 3
+  return lv;
+}
 unsigned* sf_ticket_slots(int n) {
   constexpr int RING = 1 << 16, MAXDEV = 16;
   static unsigned* ring[MAXDEV] = {};

@@ -128,6 +128,7 @@ def test_stem_trick_wgrad(shape):
 @pytest.mark.parametrize("c,relu,use_res,rep,hw", [
     (64, True, True, 1, (6, 5)), (8, True, False, 1, (6, 5)), (27, False, False, 1, (6, 5)),
     (32, True, False, 4, (6, 5)), (300, True, True, 1, (6, 5)), (48, 6, False, 1, (6, 5)), (1280, 6, False, 1, (2, 2)),
+    (512, True, True, 1, (14, 14)), (256, True, False, 1, (9, 7)),
     (18, 6, True, 1, (3, 3))])
 def test_bn_backward(c, relu, use_res, rep, hw):
     import sfhip
@@ -154,7 +155,12 @@ def test_bn_backward(c, relu, use_res, rep, hw):
     dres = sfhip.Act(torch.zeros((2, 4) + hw + (c,), device=dev)) if use_res else None
     dz, dgamma, dbeta = sfhip.bn_bwd(_act(dy), _act(y), za, mean, invstd, gamma.detach().to(dev), relu, rep=rep,
                                      dres=dres)
+    # the reduction is bit-reproducible (c >= 256: partial sums and final step in ONE launch, last-workgroup tickets)
+    dres2 = sfhip.Act(torch.zeros((2, 4) + hw + (c,), device=dev)) if use_res else None
+    dz2, dgamma2, dbeta2 = sfhip.bn_bwd(_act(dy), _act(y), _act(z), mean, invstd, gamma.detach().to(dev), relu, rep=rep,
+                                        dres=dres2)
     torch.cuda.synchronize()
+    assert torch.equal(dgamma, dgamma2) and torch.equal(dbeta, dbeta2) and torch.equal(dz.buf, dz2.buf)
     errs = [_rel(_back(dz), outs[0]), _rel(dgamma, outs[1]), _rel(dbeta, outs[2])]
     if use_res:
         errs.append(_rel(_back(dres), outs[3]))
