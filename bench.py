@@ -499,8 +499,8 @@ def main():
                         sweep = [v for k, v in tj.items() if k.startswith("attn_bwd_fused_kernel<32, 4>")]
                         traffic = (sweep[0]["hbm_bytes_per_launch"] + tj["attn_dq_reduce_tiled_kernel grid=%d" % g]["hbm_bytes_per_launch"]
                                    + 2 * tj["attn_dq_reduce_kernel grid=%d" % g]["hbm_bytes_per_launch"])
-                        traffic_src = "profiles/r02b_attention_hbm_traffic.json (rocprofv3 PMC passes FETCH_SIZE / WRITE_SIZE of " \
-                                      "the same kernels, tools/attn_traffic.sh; not measured in this run)"
+                        traffic_src = "profiles/%s (rocprofv3 PMC passes FETCH_SIZE / WRITE_SIZE of the same kernels, " \
+                                      "tools/attn_traffic.sh; not measured in this run)" % tfile
                 except (OSError, KeyError, ValueError, IndexError, StopIteration):
                     traffic = None
                 roofline = {"bound": "mfma", "kernel": "%s C=%d N=%d B=%d" % (kname, c, n, b),
