@@ -29,6 +29,22 @@ import torch.nn.functional as F
 ACT_HOOK = None
 
 
+POOL_HOOK = None  # POOL_HOOK(x, kernel, stride, padding) -> tensor or None: the HIP forward's arg-max decisions (same aid)
+
+
+def _t3(v):
+    return (v, v, v) if isinstance(v, int) else tuple(int(e) for e in v)
+
+
+def _max_pool3d(x, kernel, stride=None, padding=0):
+    kernel, stride, padding = _t3(kernel), _t3(kernel if stride is None else stride), _t3(padding)
+    if POOL_HOOK is not None:
+        y = POOL_HOOK(x, kernel, stride, padding)
+        if y is not None:
+            return y
+    return F.max_pool3d(x, kernel, stride, padding)
+
+
 def _relu(x):
     if ACT_HOOK is not None:
         y = ACT_HOOK("relu", x)
@@ -114,7 +130,7 @@ def resnet_basic_stem(sd, p, x, kt, training):
     """stem_helper.py:153-178: conv [kt,7,7]/s(1,2,2)/p(kt//2,3,3) → BN → ReLU → maxpool 1x3x3/2."""
     x = _conv(sd, p + ".conv", x, (1, 2, 2), (kt // 2, 3, 3))
     x = _relu(_bn(sd, p + ".bn", x, training))
-    return F.max_pool3d(x, (1, 3, 3), (1, 2, 2), (0, 1, 1))
+    return _max_pool3d(x, (1, 3, 3), (1, 2, 2), (0, 1, 1))
 
 
 def basic_transform(sd, p, x, kt, stride, training):
@@ -156,7 +172,7 @@ def nonlocal_block(sd, p, x, pool_size, instantiation, training):
     d = theta.shape[1]
     xp = x
     if pool_size is not None and any(k > 1 for k in pool_size):
-        xp = F.max_pool3d(x, tuple(pool_size), tuple(pool_size))
+        xp = _max_pool3d(x, tuple(pool_size), tuple(pool_size))
     phi = _conv(sd, p + ".conv_phi", xp).reshape(n, d, -1)
     g = _conv(sd, p + ".conv_g", xp).reshape(n, d, -1)
     tp = torch.einsum("nct,ncp->ntp", theta.reshape(n, d, -1), phi)
@@ -234,7 +250,7 @@ def fuse_fast_and_slow(sd, p, xs, hp, training):
     """CMDA, custom_video_model_builder.py:123-148."""
     a = hp["alpha"]
     x_s, x_f = xs
-    f2s = F.max_pool3d(x_f, (a, 1, 1), (a, 1, 1))
+    f2s = _max_pool3d(x_f, (a, 1, 1), (a, 1, 1))
     f2s = eca(sd, p + ".attention_channel_f2s", f2s)
     f2s = _relu(_bn(sd, p + ".bn_f2s", f2s, training))
     s_out = torch.cat([x_s, f2s], 1)
@@ -331,7 +347,7 @@ def resnet_forward(sd, inputs, hp, training=False):
         x = res_stage(sd, "s%d" % (si + 2), x, si, hp, training)
         x = _mark(sd, acts, "s%d" % (si + 2), x)
         if si == 0 and SINGLE_POOL1[arch] != (1, 1, 1):
-            x = _mark(sd, acts, "pathway0_pool", [F.max_pool3d(x[0], SINGLE_POOL1[arch], SINGLE_POOL1[arch])])
+            x = _mark(sd, acts, "pathway0_pool", [_max_pool3d(x[0], SINGLE_POOL1[arch], SINGLE_POOL1[arch])])
     acts["logits"], acts["out"] = resnet_basic_head(sd, "head", x, hp, training)
     return acts
 
@@ -384,7 +400,7 @@ def shufflenetv2_forward(sd, inputs, hp, training=False):
     x = []
     for pw in range(2):  # stem_helper.py:237-270: conv3x3x3/s(1,2,2) BN ReLU MaxPool3d(3,(1,2,2),1)
         z = _seq_conv_bn(sd, "s1.pathway%d_stem" % pw, 0, inputs[pw], training, True, (1, 2, 2), 1)
-        x.append(F.max_pool3d(z, 3, (1, 2, 2), 1))
+        x.append(_max_pool3d(z, 3, (1, 2, 2), 1))
     x = _mark(sd, acts, "s1", x)
     x = fuse_fast_and_slow(sd, "s1_fuse", x, hp, training)
     x = _mark(sd, acts, "s1_fuse", x)
@@ -618,7 +634,7 @@ def shufflenet_forward(sd, inputs, hp, training=False):
     for pw in range(2):  # stem_helper.py:274-306
         q = "s1.pathway%d_stem" % pw
         z = _relu(_bn(sd, q + ".1", _conv(sd, q + ".0", inputs[pw], (1, 2, 2), 1), training))
-        x.append(F.max_pool3d(z, 3, (1, 2, 2), 1))
+        x.append(_max_pool3d(z, 3, (1, 2, 2), 1))
     x = _mark(sd, acts, "s1", x)
     x = fuse_fast_and_slow(sd, "s1_fuse", x, hp, training)
     x = _mark(sd, acts, "s1_fuse", x)

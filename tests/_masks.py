@@ -8,10 +8,12 @@ oracle at 224^2, forward equal to 5e-6, gradients 2.9e-2 median.  To compare the
 handed the HIP forward's masks (y = x * mask), so both sides differentiate the same piecewise-linear function.
 
 capture():  context that records, in issue order, the mask of every ReLU / ReLU6 output the HIP engine produces in a
-            training forward (engine.bn_train_apply and the bare conv+ReLU of engine.conv_bn_act).
-inject(m):  context that sets oracle.ACT_HOOK to replay them, matched by NCTHW shape in FIFO order (within one shape
-            both sides visit the layers in the same order: blocks of a pathway are sequential, and the pathways /
-            fusion directions never share a shape)."""
+            training forward (engine.bn_train_apply and the bare conv+ReLU of engine.conv_bn_act), and the arg-max
+            decisions of every max-pool (engine.maxpool, and CMDA's temporal max inside ECA.run): the window winner by
+            ATen's own first-maximum rule on the HIP input — the rule the HIP backward implements.
+inject(m):  context that sets oracle.ACT_HOOK / oracle.POOL_HOOK to replay them, matched by NCTHW shape in FIFO order
+            (within one shape both sides visit the layers in the same order: blocks of a pathway are sequential, and
+            the pathways / fusion directions never share a shape)."""
 import collections
 import contextlib
 
@@ -21,6 +23,9 @@ import torch
 class Masks(object):
     def __init__(self):
         self.by_shape = collections.defaultdict(collections.deque)
+        self.pools = collections.defaultdict(collections.deque)   # (shape, kernel, stride, padding) -> flat indices
+        self.pool_count = 0
+        self.pool_used = 0
         self.count = 0
         self.used = 0
         self.dropped = 0
@@ -40,8 +45,35 @@ class Masks(object):
         m = Masks()
         for k, q in self.by_shape.items():
             m.by_shape[k] = collections.deque(q)
-        m.count = self.count
+        for k, q in self.pools.items():
+            m.pools[k] = collections.deque(q)
+        m.count, m.pool_count = self.count, self.pool_count
         return m
+
+    def add_pool(self, x_ncthw, kernel, stride, padding):
+        import torch.nn.functional as F
+        x = x_ncthw.detach().float().cpu()
+        _, idx = F.max_pool3d(x, kernel, stride, padding, return_indices=True)
+        self.pools[(tuple(x.shape), tuple(kernel), tuple(stride), tuple(padding))].append(idx)
+        self.pool_count += 1
+
+    def pool_hook(self, x, kernel, stride, padding):
+        """max_pool3d(x) with the window winners of the HIP forward: y = x[argmax_HIP].  A captured index set must
+        reproduce the oracle's own pooled values up to rounding (it differs only where two window elements tie within
+        it); one that does not belongs to another layer and is dropped."""
+        import torch.nn.functional as F
+        q = self.pools.get((tuple(x.shape), tuple(kernel), tuple(stride), tuple(padding)))
+        own = F.max_pool3d(x.detach(), kernel, stride, padding)
+        while q:
+            idx = q.popleft()
+            if idx.shape == own.shape:
+                y = x.flatten(2).gather(2, idx.flatten(2)).view(idx.shape)
+                if float((y.detach() - own).abs().max()) <= 1e-4 * float(own.abs().max().clamp_min(1e-30)):
+                    self.pool_used += 1
+                    return y
+            self.dropped += 1
+        self.missed.append(("pool", tuple(x.shape)))
+        return None
 
     def hook(self, kind, x):
         """x * (the next captured mask of this shape).  A captured mask must agree with the oracle's own on all but a
@@ -95,18 +127,32 @@ def capture():
             masks.add(sfhip.to_ncthw(y), k["relu"])
         return y
 
-    engine.bn_train_apply, sfhip.conv = bn_train_apply, conv
+    from slowfast.models import wdf_attention_helper as wah
+    orig_pool, orig_eca = engine.maxpool, wah.ECA.run
+
+    def maxpool(x, kernel, stride, padding=(0, 0, 0), out_reserve=(0, 0)):
+        masks.add_pool(sfhip.to_ncthw(x), tuple(kernel), tuple(stride), tuple(padding))
+        return orig_pool(x, kernel, stride, padding, out_reserve=out_reserve)
+
+    def eca_run(self, x, alpha=1, **k):
+        if alpha > 1:  # CMDA's MaxPool3d((alpha, 1, 1)) is fused into the ECA kernels
+            masks.add_pool(sfhip.to_ncthw(x), (alpha, 1, 1), (alpha, 1, 1), (0, 0, 0))
+        return orig_eca(self, x, alpha=alpha, **k)
+
+    engine.bn_train_apply, sfhip.conv, engine.maxpool, wah.ECA.run = bn_train_apply, conv, maxpool, eca_run
     try:
         yield masks
     finally:
-        engine.bn_train_apply, sfhip.conv = orig_bn, orig_conv
+        engine.bn_train_apply, sfhip.conv, engine.maxpool, wah.ECA.run = orig_bn, orig_conv, orig_pool, orig_eca
 
 
 @contextlib.contextmanager
 def inject(masks):
     from oracle import slowfast_oracle as oracle
     prev, oracle.ACT_HOOK = oracle.ACT_HOOK, masks.hook
+    prev_pool, oracle.POOL_HOOK = oracle.POOL_HOOK, masks.pool_hook
     try:
         yield masks
     finally:
         oracle.ACT_HOOK = prev
+        oracle.POOL_HOOK = prev_pool

@@ -41,15 +41,15 @@ def oracle_child_grads(meta, sd, clips, children, child, k, acts0, inputs=None, 
         sdr["__override__"] = {prev: leaves}
     if child != "head":
         sdr["__stop__"] = child
-    prev_hook = oracle.ACT_HOOK
+    prev_hook, prev_pool = oracle.ACT_HOOK, oracle.POOL_HOOK
     if masks is not None:
-        oracle.ACT_HOOK = masks.hook
+        oracle.ACT_HOOK, oracle.POOL_HOOK = masks.hook, masks.pool_hook
     try:
         acts = oracle.FORWARDS[meta["model"]](sdr, xs, meta["hparams"], training=True)
     except oracle.StopForward as e:
         acts = e.args[0]
     finally:
-        oracle.ACT_HOOK = prev_hook
+        oracle.ACT_HOOK, oracle.POOL_HOOK = prev_hook, prev_pool
     outs = [acts["out"]] if child == "head" else list(acts[child])
     loss = 0.0
     for j, t in enumerate(outs):
