@@ -54,6 +54,7 @@ WORKLOADS = {
     "shufflenetv2": ("SLOWFAST_SHUFFLENETV2_4x16.yaml", 2, "SlowFastShuffleNetV2 w0.25, 4x16, 32^2"),
 }
 PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense f32-in MFMA = vector peak
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA
 PARAM_SEED = 7
 
 
@@ -495,6 +496,10 @@ def main():
                 executed = {"attn": 2, "attn_bwd_dkv": 4, "attn_bwd_dq": 3, "attn_bwd_fused": 5}[kind]
                 flops = nprod * 2.0 * b * n * n * c
                 ach = flops / dur / 1e12
+                # 17 <= d <= 32: every fp32 product runs as six bf16 MFMAs on three-way split operands (attn_bx.h);
+                # the pipe this kernel is bound by is then the bf16 one, and its ceiling in ALGORITHMIC fp32 FLOP/s is
+                # the dense bf16 peak / 6
+                split6 = sfhip.lib().sf_attn_products_per_fp32(c) == 6 and kind in ("attn", "attn_bwd_fused")
                 kname = {"attn": "attn_fwd_kernel (flash SpatialAttention forward)",
                          "attn_bwd_dkv": "attn_bwd_dkv_kernel (flash SpatialAttention backward, dK/dV)",
                          "attn_bwd_dq": "attn_bwd_dq_kernel (flash SpatialAttention backward, dQ)",
@@ -502,24 +507,40 @@ def main():
                                            "backward, dQ/dK/dV in one sweep)"}[kind]
                 traffic, traffic_src = None, None  # HBM bytes per launch: rocprofv3 PMC passes cannot run inside bench.py
                 try:
-                    tfile = next(f for f in ("r03_attention_hbm_traffic.json", "r02b_attention_hbm_traffic.json")
+                    tfile = next(f for f in ("r03b_attention_hbm_traffic.json", "r03_attention_hbm_traffic.json",
+                                             "r02b_attention_hbm_traffic.json")
                                  if os.path.exists(os.path.join(ROOT, "profiles", f)))
                     tj = json.load(open(os.path.join(ROOT, "profiles", tfile)))["kernels"]
                     if kind == "attn_bwd_fused" and c == 32 and n == 25088 and b == 8:
                         # the sweep kernel + its three reductions (dQ partials: tiled kernel; dK parts, dV parts)
                         g = -(-(b * n * 8) // 256) * 256
-                        sweep = [v for k, v in tj.items() if k.startswith("attn_bwd_fused_kernel<32, 4>")]
+                        sweep = [v for k, v in tj.items() if k.startswith(
+                            "attn_bwd_bx_kernel" if split6 else "attn_bwd_fused_kernel<32, 4>")]
+                        if split6:  # + the two launches that write the bf16 planes of Q and gamma dz
+                            sweep[0] = dict(sweep[0], hbm_bytes_per_launch=sweep[0]["hbm_bytes_per_launch"] + 2 * next(
+                                v for k, v in tj.items() if k.startswith("attn_bx_split_kernel"))["hbm_bytes_per_launch"])
                         traffic = (sweep[0]["hbm_bytes_per_launch"] + tj["attn_dq_reduce_tiled_kernel grid=%d" % g]["hbm_bytes_per_launch"]
                                    + 2 * tj["attn_dq_reduce_kernel grid=%d" % g]["hbm_bytes_per_launch"])
                         traffic_src = "profiles/%s (rocprofv3 PMC passes FETCH_SIZE / WRITE_SIZE of the same kernels, " \
                                       "tools/attn_traffic.sh; not measured in this run)" % tfile
                 except (OSError, KeyError, ValueError, IndexError, StopIteration):
                     traffic = None
+                peak = PEAK_BF16_MFMA_TFLOPS / 6.0 if split6 else PEAK_FP32_MFMA_TFLOPS
+                if split6:
+                    kname = {"attn": "sf_attn_bx_split x2 + attn_fwd_bx_kernel (flash SpatialAttention forward",
+                             "attn_bwd_fused": "sf_attn_bx_split x2 + attn_bwd_bx_kernel + attn_dq_reduce kernels (flash "
+                                               "SpatialAttention backward, dQ/dK/dV in one sweep"}[kind] + \
+                        "; fp32 operands as three bf16 pieces, six v_mfma_f32_32x32x16_bf16 per fp32 product)"
                 roofline = {"bound": "mfma", "kernel": "%s C=%d N=%d B=%d" % (kname, c, n, b),
-                            "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                            "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "avg_launch_ms": round(dur * 1e3, 4),
+                            "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
+                            "frac": round(ach / peak, 4), "avg_launch_ms": round(dur * 1e3, 4),
                             "launches_timed": len(per[tag]), "traffic": traffic, "traffic_source": traffic_src,
-                            "executed_mfma_tflops": round(ach * executed / nprod, 2)}
+                            "executed_mfma_tflops": round(ach * (6.0 if split6 else executed / nprod), 2)}
+                if split6:
+                    roofline["peak_basis"] = ("algorithmic fp32 FLOP/s against the dense bf16 MFMA peak (%.0f TFLOP/s) / 6 "
+                                              "products per fp32 product; executed_mfma_tflops is the bf16 rate; the "
+                                              "f32-input MFMA peak this path replaces is %.1f TFLOP/s" % (
+                                                  PEAK_BF16_MFMA_TFLOPS, PEAK_FP32_MFMA_TFLOPS))
             elif top_family == "conv":
                 _, m, k, n = tag
                 ach = 2.0 * m * k * n / dur / 1e12

@@ -18,6 +18,7 @@ struct SfAttnArgs {
   float* part_o;   // [B][zs][N][CP]
   float* part_ml;  // [B][zs][N][2]   (m, l)
   float soft_t;    // attn_fwd_kernel: log2 headroom of the stale softmax reference (set by its launcher)
+  float* bx_planes;  // d = 32 with a workspace: room for the bf16 pieces of K and V^T (attn_bx_split_kernel), else null
 };
 
 // log2 headroom of the stale softmax reference (SF_ATTN_SOFT_T, default 64: 2^(s - m_ref) stays far inside fp32).
@@ -33,6 +34,17 @@ static inline float sf_attn_soft_t() {
     return v < 8.f ? 8.f : (v > 80.f ? 80.f : v);
   }();
   return t;
+}
+
+// SF_ATTN_BX (default 1): the d = 17..32 attention kernels with a workspace run their fp32 products on the bf16 matrix
+// pipe (attn_bx.h: three-way operand split, six products — fp32-level results at 6/16 of the f32-MFMA cost);
+// 0 = v_mfma_f32_32x32x2_f32.
+static inline int sf_attn_bx_level() {
+  static const int v = [] {
+    const char* e = getenv("SF_ATTN_BX");
+    return e ? atoi(e) : 1;
+  }();
+  return v;
 }
 
 // Combine the zs key parts of every query row and run the attention epilogue (attn_flash.hip).

@@ -12,7 +12,8 @@
 // swept index arrives in the accumulator's 16 registers in the order kappa(r,h) = (r&3)+8(r>>2)+4h, so
 // every transposed product takes the recomputed P / dS registers directly as its B operand and reads
 // its A operand from the LDS tile with conflict-free ds_read_b32; row-fragment operands are ds_read_b128.
-#include "common.h"
+#include "attn_args.h"
+#include "attn_bx.h"
 #include <stdlib.h>
 
 namespace {
@@ -604,6 +605,270 @@ __global__ __launch_bounds__(64 * NW, (CP >= 64) ? 2 : 1) void attn_bwd_fused_ke
     }
 }
 
+// ---------------------------------------------------------------------------------------------- fused, bf16 pieces
+// The fused sweep above with its five products on the bf16 matrix pipe (attn_bx.h: every operand as three bf16
+// pieces, six v_mfma_f32_32x32x16_bf16 per fp32 product), d <= 32, 16-byte aligned rows.  Same ownership — a
+// wavefront owns 32 keys (on the lane), the workgroup sweeps 64-query tiles — and the same dQ hand-over (per-wavefront
+// slots, fixed-order sum, one workspace plane per key block).  What changes:
+//   * Q and dO = gamma dz arrive pre-split (sf_attn_bx_split row planes): a tile is six 4 KB pieces, staged with one
+//     16-byte load + LDS store per thread and piece, no vector work.  ONE LDS image per tile serves both kinds of
+//     read: rows (ds_read_b128) as the A operand of S' = Q K'^T and dP = dO V^T, columns (ds_read_b64_tr_b16, the
+//     hardware transposing read) as the A operand of dV^T += dO^T P and dK^T += Q^T dS.
+//   * -LSE and -D are the INITIAL accumulators of S' and dP, so P = exp2(S') and dS = P dP need no subtraction.
+//   * K', V (B operands of the first two products) and K (B operand of dQ += dS K) are split once, in registers.
+//   * P and dS are split in registers (the only per-element splits of the loop); dS crosses LDS once, as pieces: each
+//     lane stores 4 consecutive queries of its key (8 bytes) into a [key][query] image and the dQ product reads it
+//     back transposed with ds_read_b64_tr_b16.
+// The tile is single-buffered (30 KB + 32 KB of slots: two workgroups per CU); the two barriers per tile are the ones
+// the slot sum needs anyway.
+constexpr int BXB_QT = 64;                        // queries per tile
+constexpr int BXB_PL = BXB_QT * BX_KP;            // one piece of one tile in LDS (bf16 elements)
+constexpr int BXB_TP = 36;                        // dS image row pitch (bf16): 72 B
+template <int DBG>
+__global__ __launch_bounds__(256, 2) void attn_bwd_bx_kernel(const BwdArgs p, float* __restrict__ ws,
+                                                             const unsigned short* __restrict__ qb,
+                                                             const unsigned short* __restrict__ db, int n64) {
+  constexpr int CP = 32, NW = 4, QT = BXB_QT, KP = BX_KP, PL = BXB_PL, TP = BXB_TP;
+  constexpr int SLOT = QT * CP;                   // one wavefront's dQ partial [QT][CP] (floats)
+  static_assert(3 * 32 * TP * 2 <= SLOT * 4, "the dS image lives in the slot");
+  __shared__ __attribute__((aligned(16))) unsigned short tile[6 * PL];  // Q pieces 0..2, dO pieces 3..5
+  __shared__ __attribute__((aligned(16))) float lsd[2 * QT];            // -LSE, -D of the tile's queries
+  __shared__ __attribute__((aligned(16))) float slots[NW * SLOT];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int bz = blockIdx.x / p.nt;  // workgroup -> (clip b, query part z, key block kb)
+  const int kb = blockIdx.x - bz * p.nt;
+  const int b = bz / p.zs, z = bz - b * p.zs;
+  const int j0 = kb * (32 * NW) + wave * 32;
+  const int N = p.N, C = p.C;
+  const long brow = (long)b * N;
+  const float gamma = p.gamma[0];
+  float* const myslot = slots + wave * SLOT;
+  unsigned short* const img = reinterpret_cast<unsigned short*>(myslot);  // [piece][key 32][TP]
+
+  // ---- this wavefront's keys: K' = K log2(e) and V as B operands [k = channel][col = key], K as [k = key][col = channel]
+  u32x4 kfb[2][3], vfb[2][3], kbr[2][3];
+  const int jrow = j0 + li;
+  const bool jok = jrow < N;
+  {
+    const float* kp = p.k + (brow + (jok ? jrow : 0)) * p.k_cs + 8 * lh;
+    const float* vp = p.v + (brow + (jok ? jrow : 0)) * p.v_cs + 8 * lh;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      f32x4 k0 = {0.f, 0.f, 0.f, 0.f}, k1 = k0, v0 = k0, v1 = k0;
+      if (jok && 16 * c + 8 * lh < C) {
+        k0 = *reinterpret_cast<const f32x4*>(kp + 16 * c);
+        v0 = *reinterpret_cast<const f32x4*>(vp + 16 * c);
+      }
+      if (jok && 16 * c + 8 * lh + 4 < C) {
+        k1 = *reinterpret_cast<const f32x4*>(kp + 16 * c + 4);
+        v1 = *reinterpret_cast<const f32x4*>(vp + 16 * c + 4);
+      }
+      k0 *= LOG2E;
+      k1 *= LOG2E;
+      split_pair(k0[0], k0[1], kfb[c], 0);
+      split_pair(k0[2], k0[3], kfb[c], 1);
+      split_pair(k1[0], k1[1], kfb[c], 2);
+      split_pair(k1[2], k1[3], kfb[c], 3);
+      split_pair(v0[0], v0[1], vfb[c], 0);
+      split_pair(v0[2], v0[3], vfb[c], 1);
+      split_pair(v1[0], v1[1], vfb[c], 2);
+      split_pair(v1[2], v1[3], vfb[c], 3);
+    }
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      float kv[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int key = j0 + 16 * m + 8 * lh + e;
+        kv[e] = (key < N && li < C) ? p.k[(brow + key) * p.k_cs + li] : 0.f;
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) split_pair(kv[2 * e], kv[2 * e + 1], kbr[m], e);
+    }
+  }
+  f32x16 dk, dv;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { dk[r] = 0.f; dv[r] = 0.f; }
+
+  // ---- staging: a piece of a tile is 4 KB of its plane = one 16-byte element per thread
+  const long plane = (long)n64 * QT * 32;
+  const unsigned short* qg = qb + (long)b * 3 * plane + tid * 8;
+  const unsigned short* dg = db + (long)b * 3 * plane + tid * 8;
+  const int st_off = (tid >> 2) * KP + (tid & 3) * 8;
+  u32x4 rq[3], rd[3];
+  float rl = 0.f, rD = 0.f;
+  auto load_tile = [&](int t) {
+#pragma unroll
+    for (int pc = 0; pc < 3; ++pc) {
+      rq[pc] = *reinterpret_cast<const u32x4*>(qg + pc * plane + (long)t * (QT * 32));
+      rd[pc] = *reinterpret_cast<const u32x4*>(dg + pc * plane + (long)t * (QT * 32));
+    }
+    if (tid < QT) {
+      const int i = t * QT + tid;
+      rl = (i < N) ? -p.lse[brow + i] : -POS_BIG;  // P = 2^(s - BIG) = 0 for padded queries
+      rD = (i < N) ? -p.dvec[brow + i] * gamma : 0.f;
+    }
+  };
+  auto store_tile = [&]() {
+#pragma unroll
+    for (int pc = 0; pc < 3; ++pc) {
+      *reinterpret_cast<u32x4*>(tile + pc * PL + st_off) = rq[pc];
+      *reinterpret_cast<u32x4*>(tile + (3 + pc) * PL + st_off) = rd[pc];
+    }
+    if (tid < QT) {
+      lsd[tid] = rl;
+      lsd[QT + tid] = rD;
+    }
+  };
+  // transposing reads: lane 4q+p of a 16-lane group addresses row q, columns 4p..4p+3 of the block
+  const int tr_row = (lane & 15) >> 2, tr_col = 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+
+  const int nq = (N + QT - 1) / QT;
+  const int tz = (nq + p.zs - 1) / p.zs;  // query tiles per part
+  const int t0 = z * tz;
+  const int ntiles = min(nq, t0 + tz);
+  if (t0 < ntiles) {
+    load_tile(t0);
+    store_tile();
+  }
+  __syncthreads();
+  for (int t = t0; t < ntiles; ++t) {
+    const bool more = (t + 1) < ntiles;
+    if (more) load_tile(t + 1);
+    f32x16 dqp[2];
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dqp[sub][r] = 0.f;
+      if (t * QT + sub * 32 >= N) continue;  // wave-uniform
+      // ---- S' = Q K'^T - LSE,  dP = dO V^T - D   (rows = queries in registers, key on the lane)
+      f32x16 s, dp;
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const f32x4 l4 = *reinterpret_cast<const f32x4*>(lsd + sub * 32 + 8 * g4 + 4 * lh);
+        const f32x4 d4 = *reinterpret_cast<const f32x4*>(lsd + QT + sub * 32 + 8 * g4 + 4 * lh);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          s[4 * g4 + e] = l4[e];
+          dp[4 * g4 + e] = d4[e];
+        }
+      }
+      const unsigned short* rowp = tile + (sub * 32 + li) * KP + 8 * lh;
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        u32x4 qa[3], da[3];
+#pragma unroll
+        for (int pc = 0; pc < 3; ++pc) {
+          qa[pc] = *reinterpret_cast<const u32x4*>(rowp + pc * PL + 16 * c);
+          da[pc] = *reinterpret_cast<const u32x4*>(rowp + (3 + pc) * PL + 16 * c);
+        }
+        s = mfma_split(qa, kfb[c], s);
+        dp = mfma_split(da, vfb[c], dp);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[r] = __builtin_amdgcn_exp2f(s[r]);  // P
+      // ---- dV^T += dO^T P : A = dO columns (transposed reads), B = P pieces (registers 8m..8m+7 = k-step m)
+      const unsigned short* colp = tile + (sub * 32 + 4 * lh + tr_row) * KP + tr_col;
+      {
+        u32x4 pf[2][3];
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) split_pair(s[8 * m + 2 * e], s[8 * m + 2 * e + 1], pf[m], e);
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+          u32x4 a[3];
+#pragma unroll
+          for (int pc = 0; pc < 3; ++pc) {
+            const u32x2 lo = lds_read_tr(colp + (3 + pc) * PL + (16 * m) * KP);
+            const u32x2 hi = lds_read_tr(colp + (3 + pc) * PL + (16 * m + 8) * KP);
+            a[pc] = (u32x4){lo[0], lo[1], hi[0], hi[1]};
+          }
+          dv = mfma_split(a, pf[m], dv);
+        }
+      }
+      // ---- dS = P dP;  dK^T += Q^T dS
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[r] *= dp[r];
+      u32x4 sf[2][3];
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) split_pair(s[8 * m + 2 * e], s[8 * m + 2 * e + 1], sf[m], e);
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        u32x4 a[3];
+#pragma unroll
+        for (int pc = 0; pc < 3; ++pc) {
+          const u32x2 lo = lds_read_tr(colp + pc * PL + (16 * m) * KP);
+          const u32x2 hi = lds_read_tr(colp + pc * PL + (16 * m + 8) * KP);
+          a[pc] = (u32x4){lo[0], lo[1], hi[0], hi[1]};
+        }
+        dk = mfma_split(a, sf[m], dk);
+      }
+      // ---- dS pieces -> [key][query] image (registers 4g..4g+3 = queries 8g + 4h .. +3 of this lane's key)
+#pragma unroll
+      for (int pc = 0; pc < 3; ++pc)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          *reinterpret_cast<u32x2*>(img + (pc * 32 + li) * TP + 8 * g + 4 * lh) =
+              (u32x2){sf[g >> 1][pc][2 * (g & 1)], sf[g >> 1][pc][2 * (g & 1) + 1]};
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      // ---- dQ(i, c) += dS(i, j) K(j, c) : A = dS with the query on the lane (transposed reads of the image)
+      const unsigned short* imgp = img + (8 * lh + tr_row) * TP + tr_col;
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        u32x4 a[3];
+#pragma unroll
+        for (int pc = 0; pc < 3; ++pc) {
+          const u32x2 lo = lds_read_tr(imgp + (pc * 32 + 16 * m) * TP);
+          const u32x2 hi = lds_read_tr(imgp + (pc * 32 + 16 * m + 4) * TP);
+          a[pc] = (u32x4){lo[0], lo[1], hi[0], hi[1]};
+        }
+        dqp[sub] = mfma_split(a, kbr[m], dqp[sub]);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();  // the image is rewritten by the next block
+    }
+    // this wavefront's partial [QT][CP] into its slot (rows kappa(r,lh), channel on the lane)
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) myslot[(sub * 32 + kappa(r, lh)) * CP + li] = dqp[sub][r];
+    __syncthreads();  // every wavefront is done with the tile and has its partial in place
+    if (more) store_tile();
+    for (int e0 = tid * 4; e0 < SLOT; e0 += 256 * 4) {  // fixed-order sum of the NW partials to the plane
+      f32x4 v = *reinterpret_cast<const f32x4*>(slots + e0);
+#pragma unroll
+      for (int w = 1; w < NW; ++w) v += *reinterpret_cast<const f32x4*>(slots + w * SLOT + e0);
+      *reinterpret_cast<f32x4*>(ws + ((((long)b * nq + t) * p.nt + kb) * (long)SLOT) + e0) = v;  // rows >= N: never read
+    }
+    __syncthreads();
+  }
+  if (!jok) return;
+  float* okp;
+  float* ovp;
+  if (p.zs > 1) {  // this query part's share of dK / dV; attn_dq_reduce_kernel adds the parts in order
+    okp = p.dkp + ((long)bz * N + jrow) * CP;
+    ovp = p.dvp + ((long)bz * N + jrow) * CP;
+  } else {
+    okp = p.dk + (brow + jrow) * p.dk_cs;
+    ovp = p.dv + (brow + jrow) * p.dv_cs;
+  }
+#pragma unroll
+  for (int r = 0; r < 16; r += 4) {
+    const int c = 8 * (r >> 2) + 4 * lh;
+    if (p.zs > 1 || c < C) {  // C % 4 == 0 on this path
+      *reinterpret_cast<f32x4*>(okp + c) = (f32x4){dk[r], dk[r + 1], dk[r + 2], dk[r + 3]};
+      *reinterpret_cast<f32x4*>(ovp + c) = (f32x4){dv[r], dv[r + 1], dv[r + 2], dv[r + 3]};
+    }
+  }
+}
+
 // dq[b, i, c] = sum over the key-block planes, in plane order.
 __global__ void attn_dq_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dq, int dq_cs, int B, int N,
                                       int C, int CP, int nkb) {
@@ -719,6 +984,34 @@ int launch_fused(BwdArgs a, float* ws, hipStream_t s) {
   return SF_OK;
 }
 
+// The bf16-piece form (d <= 32): split Q and gamma dz into row planes behind the fp32 form's workspace, then the sweep.
+int launch_fused_bx(BwdArgs a, float* ws, float* bx_ws, hipStream_t s) {
+  constexpr int CP = 32, NW = 4, qt = BXB_QT;
+  a.nt = sf_cdiv(a.N, 32 * NW);
+  a.zs = sf_sweep_parts((long)a.B * a.nt, sf_cdiv(a.N, qt));
+  const long planes = (long)a.B * a.nt * sf_cdiv(a.N, qt) * qt * CP, part = (long)a.B * a.zs * a.N * CP;
+  a.dkp = ws + planes;
+  a.dvp = a.dkp + part;
+  unsigned short* qb = reinterpret_cast<unsigned short*>(bx_ws);
+  unsigned short* db = qb + sf_attn_bx_plane_elems(a.B, a.N);
+  int rc = sf_attn_bx_split(a.q, a.q_cs, nullptr, a.B, a.N, a.C, qb, nullptr, s);
+  if (rc == SF_OK) rc = sf_attn_bx_split(a.dz, a.dz_cs, a.gamma, a.B, a.N, a.C, db, nullptr, s);
+  if (rc != SF_OK) return rc;
+  hipLaunchKernelGGL((attn_bwd_bx_kernel<0>), dim3(a.B * a.zs * a.nt), dim3(64 * NW), 0, s, a, ws, qb, db,
+                     sf_cdiv(a.N, qt));
+  SF_CHECK_LAUNCH();
+  if (a.zs > 1) {
+    rc = sf_attn_dq_reduce(a.dkp, a.dk, a.dk_cs, a.B, a.N, a.C, CP, a.zs, s);
+    if (rc == SF_OK) rc = sf_attn_dq_reduce(a.dvp, a.dv, a.dv_cs, a.B, a.N, a.C, CP, a.zs, s);
+    if (rc != SF_OK) return rc;
+  }
+  const long total = (long)a.B * a.N * (CP / 4);
+  hipLaunchKernelGGL(attn_dq_reduce_tiled_kernel, dim3(sf_cdiv(total, 256)), dim3(256), 0, s, ws, a.dq, a.dq_cs, a.B,
+                     a.N, a.C, CP, a.nt, qt);
+  SF_CHECK_LAUNCH();
+  return SF_OK;
+}
+
 template <int CP>
 int launch(const BwdArgs& a, int which, hipStream_t s) {
   const int grid = a.B * a.zs * a.nt;
@@ -777,7 +1070,9 @@ extern "C" long sf_attn_bwd_fused_ws_floats(int B, int N, int C) {
   const int cp = C <= 4 ? 4 : (C <= 8 ? 8 : (C <= 16 ? 16 : (C <= 32 ? 32 : 64)));
   const int keys = C <= 16 ? 64 : (C <= 32 ? FUSED_KEYS_32 : 128);
   const long nr = (long)sf_cdiv(N, 64) * 64;  // the dQ partials are stored per (whole) query tile of 32 / 64 rows
-  return (long)B * (sf_cdiv(N, keys) * nr + 2L * SF_SWEEP_PARTS_MAX * N) * cp;
+  long n = (long)B * (sf_cdiv(N, keys) * nr + 2L * SF_SWEEP_PARTS_MAX * N) * cp;
+  if (cp == 32) n += sf_attn_bx_plane_elems(B, N);  // Q and gamma dz as three bf16 row planes each (2 x 2 B = 1 float)
+  return n;
 }
 
 extern "C" int sf_attn_bwd_fused(const float* q, int q_cs, const float* k, int k_cs, const float* v, int v_cs,
@@ -810,6 +1105,14 @@ extern "C" int sf_attn_bwd_fused(const float* q, int q_cs, const float* k, int k
     if (rc == SF_OK) rc = sf_attn_dq_reduce(a.dvp, dv, dv_cs, B, N, C, 128, a.zs, st);
     return rc;
   }
-  if (C <= 32) return launch_fused<32, FUSED_KEYS_32 / 32>(a, ws, (hipStream_t)stream);
+  if (C <= 32) {
+    const bool vec4 = (C % 4 == 0) && (q_cs % 4 == 0) && (k_cs % 4 == 0) && (v_cs % 4 == 0) && (dz_cs % 4 == 0) &&
+                      (dk_cs % 4 == 0) && (dv_cs % 4 == 0) && sf_aligned16(q) && sf_aligned16(k) && sf_aligned16(v) &&
+                      sf_aligned16(dz) && sf_aligned16(dk) && sf_aligned16(dv);
+    if (vec4 && sf_attn_bx_level() >= 1)
+      return launch_fused_bx(a, ws, ws + (sf_attn_bwd_fused_ws_floats(B, N, C) - sf_attn_bx_plane_elems(B, N)),
+                             (hipStream_t)stream);
+    return launch_fused<32, FUSED_KEYS_32 / 32>(a, ws, (hipStream_t)stream);
+  }
   return launch_fused<64, 4>(a, ws, (hipStream_t)stream);
 }

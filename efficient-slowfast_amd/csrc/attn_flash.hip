@@ -24,7 +24,9 @@
 //     buffered, one barrier per tile.
 // fp32 throughout (the reference never leaves fp32; gfx950 has no reduced-precision f32 MFMA path).
 #include "attn_args.h"
+#include "attn_bx.h"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace {
 
@@ -40,6 +42,70 @@ __device__ __forceinline__ f32x2 pk_add(f32x2 a, f32x2 b) {
   f32x2 d;
   asm("s_nop 0\n\tv_pk_add_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
   return d;
+}
+
+// What a wavefront does with its finished O^T tile (query on the lane, channels in registers): either park the key
+// part's unnormalised (O^T, m, l) for attn_fwd_merge_kernel, or normalise and run the attention epilogue
+// y = gamma * o / l + x ; z = act(scale*y + bias) ; nearest-upsample x alpha along T.
+template <int CP, int VEC>
+__device__ __forceinline__ void attn_fwd_finish(const AttnArgs& p, const f32x16 (&o)[(CP + 31) / 32], float m_run,
+                                                float l_tot, int b, int bz, int qrow, int lh) {
+  constexpr int CT = (CP + 31) / 32;
+  const int N = p.N, C = p.C;
+  const long brow = (long)b * N;
+  if (qrow >= N) return;
+  if (p.zs > 1) {  // this key part's (O^T, m, l): merged and finished by attn_fwd_merge_kernel
+    const long prow = (long)bz * N + qrow;
+    if (lh == 0) *reinterpret_cast<float2*>(p.part_ml + prow * 2) = make_float2(m_run, l_tot);
+    float* po = p.part_o + prow * CP;
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int c0 = ct * 32 + 8 * g + 4 * lh;
+        if (c0 < CP)
+          *reinterpret_cast<f32x4*>(po + c0) =
+              (f32x4){o[ct][4 * g], o[ct][4 * g + 1], o[ct][4 * g + 2], o[ct][4 * g + 3]};
+      }
+    return;
+  }
+  const float inv_l = 1.0f / l_tot;
+  const float gamma = p.gamma ? p.gamma[0] : 1.0f;
+  const int HW = p.H * p.W;
+  const int tq = qrow / HW;
+  const int hw = qrow - tq * HW;
+  const float* xp = p.x + (brow + qrow) * p.x_cs;
+  const long orow0 = ((long)b * p.T * p.alpha + (long)tq * p.alpha) * HW + hw;
+  if (p.lse_save && lh == 0) p.lse_save[brow + qrow] = m_run + __log2f(l_tot);
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int c0 = ct * 32 + 8 * g + 4 * lh;
+      if (c0 >= C) continue;
+      float y[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int c = c0 + e;
+        const bool okc = c < C;
+        if (p.o_save && okc) p.o_save[(brow + qrow) * C + c] = o[ct][4 * g + e] * inv_l;
+        float v = gamma * (o[ct][4 * g + e] * inv_l) + (okc ? xp[c] : 0.f);
+        if (p.scale && okc) v = v * p.scale[c] + p.bias[c];
+        if (p.act == SF_ACT_RELU) v = fmaxf(v, 0.f);
+        y[e] = v;
+      }
+      for (int r = 0; r < p.alpha; ++r) {
+        float* op = p.out + (orow0 + (long)r * HW) * p.out_cs + p.out_coff + c0;
+        if (VEC == 4) {
+          *reinterpret_cast<f32x4*>(op) = (f32x4){y[0], y[1], y[2], y[3]};
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if ((c0 + e) < C) op[e] = y[e];
+        }
+      }
+    }
+  }
 }
 
 template <int CP, int VEC, bool STALE>
@@ -285,61 +351,273 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs p) {
 
   // ---- epilogue: y = gamma * o / l + x ; z = act(scale*y + bias) ; nearest-upsample x alpha along T
   const float l_run = lacc[0] + lacc[1];
-  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-  const int qrow = q0 + li;
-  if (qrow >= N) return;
-  if (p.zs > 1) {  // this key part's (O^T, m, l): merged and finished by attn_fwd_merge_kernel
-    const long prow = (long)bz * N + qrow;
-    if (lh == 0) *reinterpret_cast<float2*>(p.part_ml + prow * 2) = make_float2(m_run, l_tot);
-    float* po = p.part_o + prow * CP;
+  attn_fwd_finish<CP, VEC>(p, o, m_run, l_run + __shfl_xor(l_run, 32, 64), b, bz, q0 + li, lh);
+}
+
+// ---- split planes (attn_bx.h) -----------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void attn_bx_split_kernel(const float* __restrict__ src, int cs,
+                                                            const float* __restrict__ mul, int N, int C,
+                                                            unsigned short* rows, unsigned short* cols, int n64) {
+  __shared__ float vt[BX_KT][33];
+  const int tid = threadIdx.x;
+  const int b = blockIdx.x / n64, tile = blockIdx.x - b * n64;
+  const long brow = (long)b * N;
+  const long plane = (long)n64 * BX_KT * 32;  // elements of one piece of one clip
+  const float m = mul ? mul[0] : 1.0f;
 #pragma unroll
-    for (int ct = 0; ct < CT; ++ct)
+  for (int u = 0; u < 2; ++u) {  // coalesced rows into LDS
+    const int f = tid + u * 256;
+    const int row = f >> 3, c0 = (f & 7) * 4;
+    const int j = tile * BX_KT + row;
+    f32x4 t = {0.f, 0.f, 0.f, 0.f};
+    if (j < N && c0 < C) t = *reinterpret_cast<const f32x4*>(src + (brow + j) * cs + c0);
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int c0 = ct * 32 + 8 * g + 4 * lh;
-        if (c0 < CP)
-          *reinterpret_cast<f32x4*>(po + c0) =
-              (f32x4){o[ct][4 * g], o[ct][4 * g + 1], o[ct][4 * g + 2], o[ct][4 * g + 3]};
-      }
-    return;
+    for (int e = 0; e < 4; ++e) vt[row][c0 + e] = (c0 + e < C) ? t[e] * m : 0.f;
   }
-  const float inv_l = 1.0f / l_tot;
-  const float gamma = p.gamma ? p.gamma[0] : 1.0f;
-  const int HW = p.H * p.W;
-  const int tq = qrow / HW;
-  const int hw = qrow - tq * HW;
-  const float* xp = p.x + (brow + qrow) * p.x_cs;
-  const long orow0 = ((long)b * p.T * p.alpha + (long)tq * p.alpha) * HW + hw;
-  if (p.lse_save && lh == 0) p.lse_save[brow + qrow] = m_run + __log2f(l_tot);
+  __syncthreads();
+  if (rows) {  // thread = (row, 8 channels)
+    const int row = tid >> 2, c0 = (tid & 3) * 8;
+    u32x4 w[3];
 #pragma unroll
-  for (int ct = 0; ct < CT; ++ct) {
+    for (int e = 0; e < 4; ++e) split_pair(vt[row][c0 + 2 * e], vt[row][c0 + 2 * e + 1], w, e);
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const int c0 = ct * 32 + 8 * g + 4 * lh;
-      if (c0 >= C) continue;
-      float y[4];
+    for (int pc = 0; pc < 3; ++pc)
+      *reinterpret_cast<u32x4*>(rows + ((long)b * 3 + pc) * plane + ((long)tile * BX_KT + row) * 32 + c0) = w[pc];
+  }
+  if (cols) {  // thread = (channel, 8 row positions)
+    const int c = tid >> 3, pos0 = (tid & 7) * 8;
+    u32x4 w[3];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int c = c0 + e;
-        const bool okc = c < C;
-        if (p.o_save && okc) p.o_save[(brow + qrow) * C + c] = o[ct][4 * g + e] * inv_l;
-        float v = gamma * (o[ct][4 * g + e] * inv_l) + (okc ? xp[c] : 0.f);
-        if (p.scale && okc) v = v * p.scale[c] + p.bias[c];
-        if (p.act == SF_ACT_RELU) v = fmaxf(v, 0.f);
-        y[e] = v;
+    for (int e = 0; e < 4; ++e)
+      split_pair(vt[bx_key_of_pos(pos0 + 2 * e)][c], vt[bx_key_of_pos(pos0 + 2 * e + 1)][c], w, e);
+#pragma unroll
+    for (int pc = 0; pc < 3; ++pc)
+      *reinterpret_cast<u32x4*>(cols + ((long)b * 3 + pc) * plane + ((long)tile * 32 + c) * BX_KT + pos0) = w[pc];
+  }
+}
+
+// The streaming kernel above on split operands (d = 32, 16-byte aligned rows).  Same mapping — S^T = K Q^T with the
+// query on the lane, O^T = V^T P^T with P^T's accumulator registers as the B operand — on v_mfma_f32_32x32x16_bf16.
+// K / V^T tiles come pre-split from the planes above (six 16-byte loads and LDS stores per thread and tile, no vector
+// work); Q's pieces live in registers for the whole sweep; P's are made from the exp2 results — the only per-element
+// split in the loop.  Stale-reference softmax as above (the tile accumulates on top of -m_ref).
+//
+// A bf16 MFMA is 32 cycles against 64 for the f32 one, and a wavefront's exp2 / split instructions only hide in the
+// 24 issue cycles each MFMA leaves free if they stand BETWEEN MFMAs in program order.  So the loop is software
+// pipelined over 32-key blocks: one straight-line step issues the first product of block g+1 (independent of
+// everything else in the step) around the softmax of block g, then the second product of block g around the
+// reference check of block g+1.  K is therefore needed one block earlier than V: three K buffers (tile t+2 is staged
+// while t is swept), two V buffers, one barrier per 64-key tile.
+// DBG (timing ablations, results invalid): 1 = P^T is not split (its leading piece three times), 4 = one product
+// instead of six.
+template <int DBG, class V>
+__device__ __forceinline__ void split_pair_dbg(float a, float b, V (&dst)[3], int idx) {
+  if constexpr (DBG != 0) {
+    dst[0][idx] = dst[1][idx] = dst[2][idx] = cvt_pk_bf16(a, b);
+  } else {
+    split_pair(a, b, dst, idx);
+  }
+}
+template <int DBG>
+__device__ __forceinline__ f32x16 mfma_split_dbg(const u32x4 (&a)[3], const u32x4 (&b)[3], f32x16 c) {
+  if constexpr (DBG & 4) return mfma_bf(a[0], b[0], c);
+  return mfma_split(a, b, c);
+}
+
+constexpr int BX_VP = BX_KT + 8;         // V^T plane row pitch in LDS (144 B)
+constexpr int BX_KPL = BX_KT * BX_KP, BX_VPL = 32 * BX_VP;
+constexpr int BX_LDS_BYTES = (3 * 3 * BX_KPL + 2 * 3 * BX_VPL) * 2;  // 72 KB: two workgroups per CU
+
+template <int CP, int DBG = 0>
+__global__ __launch_bounds__(256, 2) void attn_fwd_bx_kernel(const AttnArgs p, const unsigned short* kb,
+                                                             const unsigned short* vb, int n64) {
+  static_assert(CP == 32, "plane layout and staging are laid out for d = 32");
+  constexpr int KT = BX_KT, KP = BX_KP, VP = BX_VP, KPL = BX_KPL, VPL = BX_VPL;
+  constexpr int NC = CP / 16;             // k-steps of the first product
+  extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
+  unsigned short* const Ks = smem;                 // [3 buffers][piece][key][KP]
+  unsigned short* const Vs = smem + 3 * 3 * KPL;   // [2 buffers][piece][channel][VP]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int li = lane & 31;
+  const int lh = lane >> 5;
+  const int bz = blockIdx.x / p.nqt;
+  const int b = bz / p.zs, z = bz - b * p.zs;
+  const int q0 = (blockIdx.x - bz * p.nqt) * 128 + wave * 32;
+  const int N = p.N;
+  const long brow = (long)b * N;
+
+  // ---- Q pieces (B operand of S^T = K Q^T): lane (i, h), k-step c holds Q[i][16c + 8h + j] * log2(e)
+  u32x4 qf[NC][3];
+  {
+    const int qrow = q0 + li;
+    const float* qp = p.q + (brow + (qrow < N ? qrow : 0)) * p.q_cs + 8 * lh;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      f32x4 t0 = {0.f, 0.f, 0.f, 0.f}, t1 = t0;
+      if (qrow < N) {
+        if (16 * c + 8 * lh < p.C) t0 = *reinterpret_cast<const f32x4*>(qp + 16 * c);
+        if (16 * c + 8 * lh + 4 < p.C) t1 = *reinterpret_cast<const f32x4*>(qp + 16 * c + 4);
       }
-      for (int r = 0; r < p.alpha; ++r) {
-        float* op = p.out + (orow0 + (long)r * HW) * p.out_cs + p.out_coff + c0;
-        if (VEC == 4) {
-          *reinterpret_cast<f32x4*>(op) = (f32x4){y[0], y[1], y[2], y[3]};
-        } else {
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-            if ((c0 + e) < C) op[e] = y[e];
-        }
-      }
+      t0 *= LOG2E;
+      t1 *= LOG2E;
+      split_pair(t0[0], t0[1], qf[c], 0);
+      split_pair(t0[2], t0[3], qf[c], 1);
+      split_pair(t1[0], t1[1], qf[c], 2);
+      split_pair(t1[2], t1[3], qf[c], 3);
     }
   }
+
+  f32x16 o[1];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) o[0][r] = 0.f;
+  float m_run = NEG_BIG;
+  f32x2 lacc = {0.f, 0.f};
+  f32x16 negm;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) negm[r] = -NEG_BIG;
+
+  // ---- staging: a piece of a tile is 4 KB in either plane = one 16-byte element per thread
+  const long plane = (long)n64 * KT * 32;
+  const unsigned short* kg = kb + (long)b * 3 * plane + tid * 8;
+  const unsigned short* vg = vb + (long)b * 3 * plane + tid * 8;
+  const int ks_off = (tid >> 2) * KP + (tid & 3) * 8;
+  const int vs_off = (tid >> 3) * VP + (tid & 7) * 8;
+  u32x4 rk[3], rv[3];
+  auto load_k = [&](int t) {
+#pragma unroll
+    for (int pc = 0; pc < 3; ++pc) rk[pc] = *reinterpret_cast<const u32x4*>(kg + pc * plane + (long)t * (KT * 32));
+  };
+  auto load_v = [&](int t) {
+#pragma unroll
+    for (int pc = 0; pc < 3; ++pc) rv[pc] = *reinterpret_cast<const u32x4*>(vg + pc * plane + (long)t * (KT * 32));
+  };
+  auto store_k = [&](int buf) {
+#pragma unroll
+    for (int pc = 0; pc < 3; ++pc) *reinterpret_cast<u32x4*>(Ks + (buf * 3 + pc) * KPL + ks_off) = rk[pc];
+  };
+  auto store_v = [&](int buf) {
+#pragma unroll
+    for (int pc = 0; pc < 3; ++pc) *reinterpret_cast<u32x4*>(Vs + (buf * 3 + pc) * VPL + vs_off) = rv[pc];
+  };
+
+  const int tz = (n64 + p.zs - 1) / p.zs;
+  const int t0 = z * tz;
+  const int nt = min(n64, t0 + tz) - t0;  // tiles of this key part (<= 0: an empty part)
+
+  // first product of block (tile buffer kbuf, half sub): S^T on top of -m_ref
+  f32x16 s_next;
+  u32x4 kf[NC][3];
+  auto qk = [&](int kbuf, int sub) {
+    const unsigned short* krow = Ks + kbuf * 3 * KPL + (sub * 32 + li) * KP + 8 * lh;
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+#pragma unroll
+      for (int pc = 0; pc < 3; ++pc) kf[c][pc] = *reinterpret_cast<const u32x4*>(krow + pc * KPL + 16 * c);
+    s_next = negm;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) s_next = mfma_split_dbg<DBG>(kf[c], qf[c], s_next);
+  };
+  // Slow path, a handful of times per sweep: the block exceeds the stale reference by more than 2^soft_t somewhere
+  // (always on the first block, where -m_ref = +BIG), or it reaches past N (the planes are zero there, the scores must
+  // be -BIG).  Recompute it from 0, mask, move the reference, rescale O and l.
+  auto refresh = [&](int jbase) {
+    f32x16 s;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) s = mfma_split_dbg<DBG>(kf[c], qf[c], s);
+    if (jbase + 32 > N) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        if (jbase + (r & 3) + 8 * (r >> 2) + 4 * lh >= N) s[r] = NEG_BIG;
+    }
+    float mloc = s[0];
+#pragma unroll
+    for (int r = 1; r < 16; ++r) mloc = fmaxf(mloc, s[r]);
+    mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+    const float mnew = fmaxf(m_run, mloc);
+    const float alpha = __builtin_amdgcn_exp2f(m_run - mnew);  // 0 on the first block
+    lacc *= alpha;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[0][r] *= alpha;
+    m_run = mnew;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      negm[r] = -mnew;
+      s_next[r] = s[r] - mnew;
+    }
+  };
+  auto check = [&](int jbase) {
+    float mx = fmaxf(fmaxf(s_next[0], s_next[1]), s_next[2]);
+#pragma unroll
+    for (int r = 3; r < 15; r += 2) mx = fmaxf(fmaxf(mx, s_next[r]), s_next[r + 1]);
+    mx = fmaxf(mx, s_next[15]);
+    if (__any(mx > p.soft_t) || jbase + 32 > N) refresh(jbase);
+  };
+  // one pipeline step: softmax + second product of the block in s_next, first product of the block after it
+  auto step = [&](auto HAS_NEXT, int vbuf, int sub, int kbuf_n, int sub_n) {
+    f32x16 s = s_next;
+    if constexpr (decltype(HAS_NEXT)::value) qk(kbuf_n, sub_n);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s[r] = __builtin_amdgcn_exp2f(s[r]);
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) {
+      lacc[0] += s[r];
+      lacc[1] += s[r + 1];
+    }
+    u32x4 pf[2][3];  // P^T pieces: registers 8m .. 8m+7 are the fragment of k-step m
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) split_pair_dbg<(DBG & 1)>(s[8 * m + 2 * e], s[8 * m + 2 * e + 1], pf[m], e);
+    const unsigned short* vrow = Vs + vbuf * 3 * VPL + li * VP + sub * 32 + 8 * lh;
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      u32x4 vf[3];
+#pragma unroll
+      for (int pc = 0; pc < 3; ++pc) vf[pc] = *reinterpret_cast<const u32x4*>(vrow + pc * VPL + 16 * m);
+      o[0] = mfma_split_dbg<DBG>(vf, pf[m], o[0]);
+    }
+  };
+  using T = std::true_type;
+  using F = std::false_type;
+
+  if (nt > 0) {
+    load_k(t0);
+    load_v(t0);
+    store_k(0);
+    store_v(0);
+    load_k(min(t0 + 1, n64 - 1));
+    store_k(1);
+    __syncthreads();
+    qk(0, 0);
+    check(t0 * KT);
+    int kcur = 0;  // K buffer of the tile being swept
+    for (int r = 0; r < nt; ++r) {
+      const int t = t0 + r;
+      const int knext = kcur == 2 ? 0 : kcur + 1, kafter = knext == 2 ? 0 : knext + 1;
+      load_k(min(t + 2, n64 - 1));  // past the part's end: a tile nobody reads
+      load_v(min(t + 1, n64 - 1));
+      step(T{}, r & 1, 0, kcur, 1);
+      check(t * KT + 32);
+      if (r + 1 < nt) {
+        step(T{}, r & 1, 1, knext, 0);
+        check(t * KT + 64);
+      } else {
+        step(F{}, r & 1, 1, 0, 0);
+      }
+      store_k(kafter);
+      store_v((r + 1) & 1);
+      __syncthreads();
+      kcur = knext;
+    }
+  }
+
+  const float l_run = lacc[0] + lacc[1];
+  attn_fwd_finish<CP, 4>(p, o, m_run, l_run + __shfl_xor(l_run, 32, 64), b, bz, q0 + li, lh);
 }
 
 // One thread per (query row, 4 channels): O = sum_z o_z 2^(m_z - m) / sum_z l_z 2^(m_z - m), m = max_z m_z, then the
@@ -400,6 +678,30 @@ int launch(AttnArgs a, bool vec4, hipStream_t s) {
   static const bool stale_on = [] { const char* e = getenv("SF_ATTN_STALE"); return !(e && e[0] == '0'); }();
   a.soft_t = sf_attn_soft_t();
   const bool stale = stale_on && CP <= 64;  // d = 128: the 16 extra registers cost the second wavefront per SIMD
+  if constexpr (CP == 32) {
+    if (vec4 && a.bx_planes) {
+      const int n64 = sf_cdiv(a.N, BX_KT);
+      unsigned short* kb = reinterpret_cast<unsigned short*>(a.bx_planes);
+      unsigned short* vb = kb + (long)a.B * 3 * n64 * BX_KT * 32;
+      if (sf_attn_bx_split(a.k, a.k_cs, nullptr, a.B, a.N, a.C, kb, nullptr, s) != SF_OK ||
+          sf_attn_bx_split(a.v, a.v_cs, nullptr, a.B, a.N, a.C, nullptr, vb, s) != SF_OK)
+        return SF_ELAUNCH;
+      using Kern = void (*)(const AttnArgs, const unsigned short*, const unsigned short*, int);
+      static const Kern kern = [] {  // SF_ATTN_BX_DBG: timing ablations (see the kernel)
+        const char* e = getenv("SF_ATTN_BX_DBG");
+        const int dbg = e ? atoi(e) : 0;
+        return dbg == 1 ? (Kern)attn_fwd_bx_kernel<32, 1> : dbg == 4 ? (Kern)attn_fwd_bx_kernel<32, 4>
+                                                                      : (Kern)attn_fwd_bx_kernel<32, 0>;
+      }();
+      static const bool attr_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                                      hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                      BX_LDS_BYTES) == hipSuccess;  // 72 KB of dynamic LDS
+      if (!attr_ok) return SF_ELAUNCH;
+      hipLaunchKernelGGL(kern, dim3(grid), dim3(256), BX_LDS_BYTES, s, a, kb, vb, n64);
+      SF_CHECK_LAUNCH();
+      return a.zs > 1 ? sf_attn_fwd_merge(a, CP, s) : SF_OK;
+    }
+  }
   if (vec4) {
     if (stale) hipLaunchKernelGGL((attn_fwd_kernel<CP, 4, true>), dim3(grid), dim3(256), 0, s, a);
     else hipLaunchKernelGGL((attn_fwd_kernel<CP, 4, false>), dim3(grid), dim3(256), 0, s, a);
@@ -412,6 +714,15 @@ int launch(AttnArgs a, bool vec4, hipStream_t s) {
 }
 
 }  // namespace
+
+int sf_attn_bx_split(const float* src, int cs, const float* mul, int B, int N, int C, unsigned short* rows,
+                     unsigned short* cols, hipStream_t s) {
+  if (!src || C > 32 || (cs & 3) || !sf_aligned16(src)) return SF_EINVAL;
+  const int n64 = sf_cdiv(N, BX_KT);
+  hipLaunchKernelGGL(attn_bx_split_kernel, dim3(B * n64), dim3(256), 0, s, src, cs, mul, N, C, rows, cols, n64);
+  SF_CHECK_LAUNCH();
+  return SF_OK;
+}
 
 int sf_attn_fwd_merge(const SfAttnArgs& a, int cp, hipStream_t s) {
   const long total = (long)a.B * a.N * (cp / 4);
@@ -461,9 +772,12 @@ static int attn_fwd_impl(const float* q, int q_cs, const float* k, int k_cs, con
     return sf_attn_small_dispatch(q, q_cs, k, k_cs, v, v_cs, x, x_cs, gamma, scale, bias, act, out, out_cs,
                                   out_coff, B, T, H, W, C, alpha, o_save, lse_save, vec4, ws, s);
   const int cp = C <= 32 ? 32 : (C <= 64 ? 64 : 128);
+  a.bx_planes = nullptr;
   if (ws) {
     a.zs = sf_sweep_parts((long)B * a.nqt, sf_cdiv(N, cp >= 128 ? 32 : 64));
     sf_attn_place_parts(a, cp, ws);
+    if (cp == 32 && sf_attn_bx_level() >= 1)  // the split K / V^T planes live behind the part buffers
+      a.bx_planes = ws + (long)B * SF_SWEEP_PARTS_MAX * N * (cp + 2);
   }
   if (C <= 32) return launch<32>(a, vec4, s);
   if (C <= 64) return launch<64>(a, vec4, s);
@@ -478,11 +792,15 @@ extern "C" int sf_attn_fwd(const float* q, int q_cs, const float* k, int k_cs, c
                        W, C, alpha, o_save, lse_save, nullptr, stream);
 }
 
+extern "C" int sf_attn_products_per_fp32(int C) { return (C > 16 && C <= 32 && sf_attn_bx_level() >= 1) ? 6 : 0; }
+
 // Room for the (O^T, m, l) of up to SF_SWEEP_PARTS_MAX key parts per query row.
 extern "C" long sf_attn_fwd_ws_floats(int B, int N, int C) {
   if (B <= 0 || N <= 0 || C <= 0 || C > 128) return 0;
   const int cp = C <= 4 ? 4 : (C <= 8 ? 8 : (C <= 16 ? 16 : (C <= 32 ? 32 : (C <= 64 ? 64 : 128))));
-  return (long)B * SF_SWEEP_PARTS_MAX * N * (cp + 2);
+  long n = (long)B * SF_SWEEP_PARTS_MAX * N * (cp + 2);
+  if (cp == 32) n += (long)B * sf_cdiv(N, 64) * 64 * 32 * 3;  // K and V^T as three bf16 planes each (12 B per element)
+  return n;
 }
 
 extern "C" int sf_attn_fwd_ws(const float* q, int q_cs, const float* k, int k_cs, const float* v, int v_cs,
