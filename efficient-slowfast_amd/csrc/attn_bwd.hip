@@ -624,16 +624,33 @@ __global__ __launch_bounds__(64 * NW, (CP >= 64) ? 2 : 1) void attn_bwd_fused_ke
 constexpr int BXB_QT = 64;                        // queries per tile
 constexpr int BXB_PL = BXB_QT * BX_KP;            // one piece of one tile in LDS (bf16 elements)
 constexpr int BXB_TP = 36;                        // dS image row pitch (bf16): 72 B
+// DBG (timing ablations, results invalid): 1 = P and dS are not split (leading piece three times), 2 = no dQ product
+// (no image write / transposed read), 4 = one MFMA per product instead of six.
+template <int DBG, class V>
+__device__ __forceinline__ void bxb_split(float a, float b, V (&dst)[3], int idx) {
+  if constexpr (DBG & 1) {
+    dst[0][idx] = dst[1][idx] = dst[2][idx] = cvt_pk_bf16(a, b);
+  } else {
+    split_pair(a, b, dst, idx);
+  }
+}
 template <int DBG>
-__global__ __launch_bounds__(256, 2) void attn_bwd_bx_kernel(const BwdArgs p, float* __restrict__ ws,
-                                                             const unsigned short* __restrict__ qb,
-                                                             const unsigned short* __restrict__ db, int n64) {
-  constexpr int CP = 32, NW = 4, QT = BXB_QT, KP = BX_KP, PL = BXB_PL, TP = BXB_TP;
+__device__ __forceinline__ f32x16 bxb_mfma(const u32x4 (&a)[3], const u32x4 (&b)[3], f32x16 c) {
+  if constexpr (DBG & 4) return mfma_bf(a[0], b[0], c);
+  return mfma_split(a, b, c);
+}
+constexpr int bxb_lds_bytes(int nw) { return 6 * BXB_PL * 2 + 2 * BXB_QT * 4 + nw * BXB_QT * 32 * 4; }
+template <int DBG, int NW>
+__global__ __launch_bounds__(64 * NW, 8 / NW) void attn_bwd_bx_kernel(const BwdArgs p, float* __restrict__ ws,
+                                                                      const unsigned short* __restrict__ qb,
+                                                                      const unsigned short* __restrict__ db, int n64) {
+  constexpr int CP = 32, NT = 64 * NW, QT = BXB_QT, KP = BX_KP, PL = BXB_PL, TP = BXB_TP;
   constexpr int SLOT = QT * CP;                   // one wavefront's dQ partial [QT][CP] (floats)
   static_assert(3 * 32 * TP * 2 <= SLOT * 4, "the dS image lives in the slot");
-  __shared__ __attribute__((aligned(16))) unsigned short tile[6 * PL];  // Q pieces 0..2, dO pieces 3..5
-  __shared__ __attribute__((aligned(16))) float lsd[2 * QT];            // -LSE, -D of the tile's queries
-  __shared__ __attribute__((aligned(16))) float slots[NW * SLOT];
+  extern __shared__ __attribute__((aligned(16))) unsigned short bxb_smem[];
+  unsigned short* const tile = bxb_smem;                                  // Q pieces 0..2, dO pieces 3..5
+  float* const lsd = reinterpret_cast<float*>(bxb_smem + 6 * PL);         // -LSE, -D of the tile's queries
+  float* const slots = lsd + 2 * QT;                                      // NW x SLOT
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, lh = lane >> 5;
@@ -694,16 +711,18 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_bx_kernel(const BwdArgs p, fl
 
   // ---- staging: a piece of a tile is 4 KB of its plane = one 16-byte element per thread
   const long plane = (long)n64 * QT * 32;
-  const unsigned short* qg = qb + (long)b * 3 * plane + tid * 8;
-  const unsigned short* dg = db + (long)b * 3 * plane + tid * 8;
-  const int st_off = (tid >> 2) * KP + (tid & 3) * 8;
-  u32x4 rq[3], rd[3];
+  // (8 wavefronts: the first four stage the Q pieces, the other four the dO pieces)
+  const int st = tid & 255;
+  const unsigned short* qg = ((NW == 8 && tid >= 256) ? db : qb) + (long)b * 3 * plane + st * 8;
+  const unsigned short* dg = db + (long)b * 3 * plane + st * 8;
+  const int st_off = (st >> 2) * KP + (st & 3) * 8 + ((NW == 8 && tid >= 256) ? 3 * PL : 0);
+  u32x4 rq[3], rd[NW == 8 ? 1 : 3];
   float rl = 0.f, rD = 0.f;
   auto load_tile = [&](int t) {
 #pragma unroll
     for (int pc = 0; pc < 3; ++pc) {
       rq[pc] = *reinterpret_cast<const u32x4*>(qg + pc * plane + (long)t * (QT * 32));
-      rd[pc] = *reinterpret_cast<const u32x4*>(dg + pc * plane + (long)t * (QT * 32));
+      if constexpr (NW == 4) rd[pc] = *reinterpret_cast<const u32x4*>(dg + pc * plane + (long)t * (QT * 32));
     }
     if (tid < QT) {
       const int i = t * QT + tid;
@@ -715,7 +734,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_bx_kernel(const BwdArgs p, fl
 #pragma unroll
     for (int pc = 0; pc < 3; ++pc) {
       *reinterpret_cast<u32x4*>(tile + pc * PL + st_off) = rq[pc];
-      *reinterpret_cast<u32x4*>(tile + (3 + pc) * PL + st_off) = rd[pc];
+      if constexpr (NW == 4) *reinterpret_cast<u32x4*>(tile + (3 + pc) * PL + st_off) = rd[pc];
     }
     if (tid < QT) {
       lsd[tid] = rl;
@@ -764,8 +783,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_bx_kernel(const BwdArgs p, fl
           qa[pc] = *reinterpret_cast<const u32x4*>(rowp + pc * PL + 16 * c);
           da[pc] = *reinterpret_cast<const u32x4*>(rowp + (3 + pc) * PL + 16 * c);
         }
-        s = mfma_split(qa, kfb[c], s);
-        dp = mfma_split(da, vfb[c], dp);
+        s = bxb_mfma<DBG>(qa, kfb[c], s);
+        dp = bxb_mfma<DBG>(da, vfb[c], dp);
       }
 #pragma unroll
       for (int r = 0; r < 16; ++r) s[r] = __builtin_amdgcn_exp2f(s[r]);  // P
@@ -776,7 +795,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_bx_kernel(const BwdArgs p, fl
 #pragma unroll
         for (int m = 0; m < 2; ++m)
 #pragma unroll
-          for (int e = 0; e < 4; ++e) split_pair(s[8 * m + 2 * e], s[8 * m + 2 * e + 1], pf[m], e);
+          for (int e = 0; e < 4; ++e) bxb_split<DBG>(s[8 * m + 2 * e], s[8 * m + 2 * e + 1], pf[m], e);
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
           u32x4 a[3];
@@ -786,7 +805,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_bx_kernel(const BwdArgs p, fl
             const u32x2 hi = lds_read_tr(colp + (3 + pc) * PL + (16 * m + 8) * KP);
             a[pc] = (u32x4){lo[0], lo[1], hi[0], hi[1]};
           }
-          dv = mfma_split(a, pf[m], dv);
+          dv = bxb_mfma<DBG>(a, pf[m], dv);
         }
       }
       // ---- dS = P dP;  dK^T += Q^T dS
@@ -796,7 +815,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_bx_kernel(const BwdArgs p, fl
 #pragma unroll
       for (int m = 0; m < 2; ++m)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) split_pair(s[8 * m + 2 * e], s[8 * m + 2 * e + 1], sf[m], e);
+        for (int e = 0; e < 4; ++e) bxb_split<DBG>(s[8 * m + 2 * e], s[8 * m + 2 * e + 1], sf[m], e);
 #pragma unroll
       for (int m = 0; m < 2; ++m) {
         u32x4 a[3];
@@ -806,8 +825,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_bx_kernel(const BwdArgs p, fl
           const u32x2 hi = lds_read_tr(colp + pc * PL + (16 * m + 8) * KP);
           a[pc] = (u32x4){lo[0], lo[1], hi[0], hi[1]};
         }
-        dk = mfma_split(a, sf[m], dk);
+        dk = bxb_mfma<DBG>(a, sf[m], dk);
       }
+      if constexpr (DBG & 2) continue;
       // ---- dS pieces -> [key][query] image (registers 4g..4g+3 = queries 8g + 4h .. +3 of this lane's key)
 #pragma unroll
       for (int pc = 0; pc < 3; ++pc)
@@ -829,7 +849,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_bx_kernel(const BwdArgs p, fl
           const u32x2 hi = lds_read_tr(imgp + (pc * 32 + 16 * m + 4) * TP);
           a[pc] = (u32x4){lo[0], lo[1], hi[0], hi[1]};
         }
-        dqp[sub] = mfma_split(a, kbr[m], dqp[sub]);
+        dqp[sub] = bxb_mfma<DBG>(a, kbr[m], dqp[sub]);
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();  // the image is rewritten by the next block
@@ -841,7 +861,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_bx_kernel(const BwdArgs p, fl
       for (int r = 0; r < 16; ++r) myslot[(sub * 32 + kappa(r, lh)) * CP + li] = dqp[sub][r];
     __syncthreads();  // every wavefront is done with the tile and has its partial in place
     if (more) store_tile();
-    for (int e0 = tid * 4; e0 < SLOT; e0 += 256 * 4) {  // fixed-order sum of the NW partials to the plane
+    for (int e0 = tid * 4; e0 < SLOT; e0 += NT * 4) {  // fixed-order sum of the NW partials to the plane
       f32x4 v = *reinterpret_cast<const f32x4*>(slots + e0);
 #pragma unroll
       for (int w = 1; w < NW; ++w) v += *reinterpret_cast<const f32x4*>(slots + w * SLOT + e0);
@@ -985,8 +1005,9 @@ int launch_fused(BwdArgs a, float* ws, hipStream_t s) {
 }
 
 // The bf16-piece form (d <= 32): split Q and gamma dz into row planes behind the fp32 form's workspace, then the sweep.
+template <int NW>
 int launch_fused_bx(BwdArgs a, float* ws, float* bx_ws, hipStream_t s) {
-  constexpr int CP = 32, NW = 4, qt = BXB_QT;
+  constexpr int CP = 32, qt = BXB_QT;
   a.nt = sf_cdiv(a.N, 32 * NW);
   a.zs = sf_sweep_parts((long)a.B * a.nt, sf_cdiv(a.N, qt));
   const long planes = (long)a.B * a.nt * sf_cdiv(a.N, qt) * qt * CP, part = (long)a.B * a.zs * a.N * CP;
@@ -997,7 +1018,25 @@ int launch_fused_bx(BwdArgs a, float* ws, float* bx_ws, hipStream_t s) {
   int rc = sf_attn_bx_split(a.q, a.q_cs, nullptr, a.B, a.N, a.C, qb, nullptr, s);
   if (rc == SF_OK) rc = sf_attn_bx_split(a.dz, a.dz_cs, a.gamma, a.B, a.N, a.C, db, nullptr, s);
   if (rc != SF_OK) return rc;
-  hipLaunchKernelGGL((attn_bwd_bx_kernel<0>), dim3(a.B * a.zs * a.nt), dim3(64 * NW), 0, s, a, ws, qb, db,
+  using Kern = void (*)(const BwdArgs, float*, const unsigned short*, const unsigned short*, int);
+  static const Kern kern = [] {  // SF_ATTN_BX_DBG: timing ablations (see the kernel)
+    const char* e = getenv("SF_ATTN_BX_DBG");
+    const int dbg = e ? atoi(e) : 0;
+    if (NW == 8) return (Kern)attn_bwd_bx_kernel<0, 8>;
+    switch (dbg) {
+      case 1: return (Kern)attn_bwd_bx_kernel<1, 4>;
+      case 2: return (Kern)attn_bwd_bx_kernel<2, 4>;
+      case 3: return (Kern)attn_bwd_bx_kernel<3, 4>;
+      case 4: return (Kern)attn_bwd_bx_kernel<4, 4>;
+      case 7: return (Kern)attn_bwd_bx_kernel<7, 4>;
+      default: return (Kern)attn_bwd_bx_kernel<0, 4>;
+    }
+  }();
+  static const bool attr_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                  bxb_lds_bytes(NW)) == hipSuccess;
+  if (!attr_ok) return SF_ELAUNCH;
+  hipLaunchKernelGGL(kern, dim3(a.B * a.zs * a.nt), dim3(64 * NW), bxb_lds_bytes(NW), s, a, ws, qb, db,
                      sf_cdiv(a.N, qt));
   SF_CHECK_LAUNCH();
   if (a.zs > 1) {
@@ -1109,9 +1148,15 @@ extern "C" int sf_attn_bwd_fused(const float* q, int q_cs, const float* k, int k
     const bool vec4 = (C % 4 == 0) && (q_cs % 4 == 0) && (k_cs % 4 == 0) && (v_cs % 4 == 0) && (dz_cs % 4 == 0) &&
                       (dk_cs % 4 == 0) && (dv_cs % 4 == 0) && sf_aligned16(q) && sf_aligned16(k) && sf_aligned16(v) &&
                       sf_aligned16(dz) && sf_aligned16(dk) && sf_aligned16(dv);
-    if (vec4 && sf_attn_bx_level() >= 1)
-      return launch_fused_bx(a, ws, ws + (sf_attn_bwd_fused_ws_floats(B, N, C) - sf_attn_bx_plane_elems(B, N)),
-                             (hipStream_t)stream);
+    if (vec4 && sf_attn_bx_level() >= 1) {
+      // 256 keys (8 wavefronts, one workgroup per CU) per workgroup where that still fills the chip: half the dQ
+      // planes to write and to sum (N = 25 088, B = 8: 9.20 -> 8.70 ms).  SF_ATTN_BX_NW=4|8 forces either.
+      static const int forced = [] { const char* e = getenv("SF_ATTN_BX_NW"); return e ? atoi(e) : 0; }();
+      const bool wide = forced == 8 || (forced != 4 && (long)B * sf_cdiv(N, 256) >= 256);
+      float* const bx_ws = ws + (sf_attn_bwd_fused_ws_floats(B, N, C) - sf_attn_bx_plane_elems(B, N));
+      return wide ? launch_fused_bx<8>(a, ws, bx_ws, (hipStream_t)stream)
+                  : launch_fused_bx<4>(a, ws, bx_ws, (hipStream_t)stream);
+    }
     return launch_fused<32, FUSED_KEYS_32 / 32>(a, ws, (hipStream_t)stream);
   }
   return launch_fused<64, 4>(a, ws, (hipStream_t)stream);

@@ -408,8 +408,8 @@ __global__ __launch_bounds__(256) void attn_bx_split_kernel(const float* __restr
 // everything else in the step) around the softmax of block g, then the second product of block g around the
 // reference check of block g+1.  K is therefore needed one block earlier than V: three K buffers (tile t+2 is staged
 // while t is swept), two V buffers, one barrier per 64-key tile.
-// DBG (timing ablations, results invalid): 1 = P^T is not split (its leading piece three times), 4 = one product
-// instead of six.
+// DBG: 1 = P^T is not split (its leading piece three times), 4 = one product instead of six (timing ablations,
+// results invalid); 32 = the compiler's instruction order instead of the placed one (valid results, 4 % slower).
 template <int DBG, class V>
 __device__ __forceinline__ void split_pair_dbg(float a, float b, V (&dst)[3], int idx) {
   if constexpr (DBG != 0) {
@@ -582,6 +582,77 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bx_kernel(const AttnArgs p, c
       o[0] = mfma_split_dbg<DBG>(vf, pf[m], o[0]);
     }
   };
+  // The same step with its vector work PLACED: one MFMA, then the fillers that fit the 24 issue cycles it leaves
+  // (v_exp 8, the others ~4.3 each), pinned by sched_barrier — the compiler's own order front-loads the softmax and
+  // leaves the second product's MFMAs bare.  Worth 4 % (3.61 -> 3.48 ms at N = 25 088, B = 8): with two wavefronts per
+  // SIMD the issue port is shared, and under this load the part holds ~1.6 GHz (20 ns per 32x32x16 MFMA).
+  auto step_placed = [&](int vbuf, int sub, int kbuf_n, int sub_n) {
+    constexpr int OA[6] = {0, 2, 1, 0, 1, 0}, OB[6] = {2, 0, 1, 1, 0, 0};  // mfma_split's order, small terms first
+    f32x16 s = s_next;
+    const unsigned short* krow = Ks + kbuf_n * 3 * KPL + (sub_n * 32 + li) * KP + 8 * lh;
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+#pragma unroll
+      for (int pc = 0; pc < 3; ++pc) kf[c][pc] = *reinterpret_cast<const u32x4*>(krow + pc * KPL + 16 * c);
+    const unsigned short* vrow = Vs + vbuf * 3 * VPL + li * VP + sub * 32 + 8 * lh;
+    u32x4 vf[2][3];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int pc = 0; pc < 3; ++pc) vf[m][pc] = *reinterpret_cast<const u32x4*>(vrow + pc * VPL + 16 * m);
+    u32x4 pf[2][3];
+    float xa[8], xb[8];
+    auto E = [&](int r) { s[r] = __builtin_amdgcn_exp2f(s[r]); };
+    auto SA = [&](int m, int e) {
+      const float a = s[8 * m + 2 * e], b = s[8 * m + 2 * e + 1];
+      const unsigned p1 = cvt_pk_bf16(a, b);
+      pf[m][0][e] = p1;
+      xa[4 * m + e] = a - __builtin_bit_cast(float, p1 << 16);
+      xb[4 * m + e] = b - __builtin_bit_cast(float, p1 & 0xffff0000u);
+    };
+    auto SB = [&](int m, int e) {
+      const unsigned p2 = cvt_pk_bf16(xa[4 * m + e], xb[4 * m + e]);
+      pf[m][1][e] = p2;
+      xa[4 * m + e] -= __builtin_bit_cast(float, p2 << 16);
+      xb[4 * m + e] -= __builtin_bit_cast(float, p2 & 0xffff0000u);
+      pf[m][2][e] = cvt_pk_bf16(xa[4 * m + e], xb[4 * m + e]);
+    };
+    auto QK = [&](int i) {  // MFMA i of the first product of the next block
+      const int c = i / 6, t = i % 6;
+      s_next = mfma_bf(kf[c][OA[t]], qf[c][OB[t]], i == 0 ? negm : s_next);
+    };
+    auto PV = [&](int i) {
+      const int m = i / 6, t = i % 6;
+      o[0] = mfma_bf(vf[m][OA[t]], pf[m][OB[t]], o[0]);
+    };
+#define SF_GAP() __builtin_amdgcn_sched_barrier(0)
+    QK(0); E(0); E(1); E(2); SF_GAP();
+    QK(1); E(3); E(4); E(5); SF_GAP();
+    QK(2); E(6); E(7); E(8); SF_GAP();
+    QK(3); SA(0, 0); SF_GAP();
+    QK(4); SB(0, 0); SF_GAP();
+    QK(5); SA(0, 1); SF_GAP();
+    QK(6); SB(0, 1); SF_GAP();
+    QK(7); SA(0, 2); SF_GAP();
+    QK(8); SB(0, 2); SF_GAP();
+    QK(9); SA(0, 3); SF_GAP();
+    QK(10); SB(0, 3); SF_GAP();
+    QK(11); E(9); E(10); E(11); SF_GAP();
+    PV(0); E(12); E(13); E(14); SF_GAP();
+    PV(1); E(15); SA(1, 0); SF_GAP();
+    PV(2); SB(1, 0); SF_GAP();
+    PV(3); SA(1, 1); SF_GAP();
+    PV(4); SB(1, 1); SF_GAP();
+    PV(5); SA(1, 2); SF_GAP();
+    SB(1, 2); SA(1, 3); SB(1, 3); SF_GAP();
+    PV(6); lacc[0] += s[0]; lacc[1] += s[1]; lacc[0] += s[2]; lacc[1] += s[3]; lacc[0] += s[4]; SF_GAP();
+    PV(7); lacc[1] += s[5]; lacc[0] += s[6]; lacc[1] += s[7]; lacc[0] += s[8]; lacc[1] += s[9]; SF_GAP();
+    PV(8); lacc[0] += s[10]; lacc[1] += s[11]; lacc[0] += s[12]; lacc[1] += s[13]; lacc[0] += s[14]; SF_GAP();
+    PV(9); lacc[1] += s[15]; SF_GAP();
+    PV(10); SF_GAP();
+    PV(11); SF_GAP();
+#undef SF_GAP
+  };
   using T = std::true_type;
   using F = std::false_type;
 
@@ -601,10 +672,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bx_kernel(const AttnArgs p, c
       const int knext = kcur == 2 ? 0 : kcur + 1, kafter = knext == 2 ? 0 : knext + 1;
       load_k(min(t + 2, n64 - 1));  // past the part's end: a tile nobody reads
       load_v(min(t + 1, n64 - 1));
-      step(T{}, r & 1, 0, kcur, 1);
+      if constexpr (DBG & 32) step(T{}, r & 1, 0, kcur, 1); else step_placed(r & 1, 0, kcur, 1);
       check(t * KT + 32);
       if (r + 1 < nt) {
-        step(T{}, r & 1, 1, knext, 0);
+        if constexpr (DBG & 32) step(T{}, r & 1, 1, knext, 0); else step_placed(r & 1, 1, knext, 0);
         check(t * KT + 64);
       } else {
         step(F{}, r & 1, 1, 0, 0);
@@ -690,7 +761,7 @@ int launch(AttnArgs a, bool vec4, hipStream_t s) {
       static const Kern kern = [] {  // SF_ATTN_BX_DBG: timing ablations (see the kernel)
         const char* e = getenv("SF_ATTN_BX_DBG");
         const int dbg = e ? atoi(e) : 0;
-        return dbg == 1 ? (Kern)attn_fwd_bx_kernel<32, 1> : dbg == 4 ? (Kern)attn_fwd_bx_kernel<32, 4>
+        return dbg == 1 ? (Kern)attn_fwd_bx_kernel<32, 1> : dbg == 32 ? (Kern)attn_fwd_bx_kernel<32, 32> : dbg == 4 ? (Kern)attn_fwd_bx_kernel<32, 4>
                                                                       : (Kern)attn_fwd_bx_kernel<32, 0>;
       }();
       static const bool attr_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
