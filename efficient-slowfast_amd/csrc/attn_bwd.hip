@@ -889,6 +889,247 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void attn_bwd_bx_kernel(const BwdA
   }
 }
 
+// ---------------------------------------------------------------------------------------------- fused, packed planes
+// The sweep above for C <= 8 on packed planes (attn_bx.h): one 32-column plane per operand holds the three pieces of
+// its 8 channels.  S' and dP are three MFMAs each ([q1|q1][k1|k2], [q2|q2][k1|k2], [q1|q3][k3|k1]); dV^T, dK^T and dQ
+// are three per k-step (the packed operand times each piece of P / dS; row or column groups 0-7 / 8-15 / 16-23 summed
+// at the end).  24 MFMAs per 32 x 32 block instead of 60, a third of the LDS row traffic, and dQ planes of 8 columns.
+constexpr int bxbp_lds_bytes(int nw) { return 2 * BXB_PL * 2 + 2 * BXB_QT * 4 + nw * BXB_QT * 32 * 4; }
+template <int NW>
+__global__ __launch_bounds__(64 * NW, 8 / NW) void attn_bwd_bxp_kernel(const BwdArgs p, float* __restrict__ ws,
+                                                                       const unsigned short* __restrict__ qb,
+                                                                       const unsigned short* __restrict__ db, int n64) {
+  constexpr int CP = 8, NT = 64 * NW, QT = BXB_QT, KP = BX_KP, PL = BXB_PL, TP = BXB_TP;
+  constexpr int SLOT = QT * 32;                   // one wavefront's dQ partial [QT][32 packed columns] (floats)
+  extern __shared__ __attribute__((aligned(16))) unsigned short bxb_smem[];
+  unsigned short* const tile = bxb_smem;                                  // Q packed rows, then dO packed rows
+  float* const lsd = reinterpret_cast<float*>(bxb_smem + 2 * PL);         // -LSE, -D of the tile's queries
+  float* const slots = lsd + 2 * QT;                                      // NW x SLOT
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int bz = blockIdx.x / p.nt;
+  const int kb = blockIdx.x - bz * p.nt;
+  const int b = bz / p.zs, z = bz - b * p.zs;
+  const int j0 = kb * (32 * NW) + wave * 32;
+  const int N = p.N, C = p.C;
+  const long brow = (long)b * N;
+  const float gamma = p.gamma[0];
+  float* const myslot = slots + wave * SLOT;
+  unsigned short* const img = reinterpret_cast<unsigned short*>(myslot);  // [piece][key 32][TP]
+
+  // ---- this wavefront's keys: [k1|k2], [k3|k1] of K' = K log2(e) and of V (B operands of S', dP), K packed columns
+  u32x4 ka, kc, va, vc, kbr[2];
+  const int jrow = j0 + li;
+  const bool jok = jrow < N;
+  {
+    const float* kp = p.k + (brow + (jok ? jrow : 0)) * p.k_cs;
+    const float* vp = p.v + (brow + (jok ? jrow : 0)) * p.v_cs;
+    f32x4 k0 = {0.f, 0.f, 0.f, 0.f}, k1 = k0, v0 = k0, v1 = k0;
+    if (jok) {
+      k0 = *reinterpret_cast<const f32x4*>(kp);
+      v0 = *reinterpret_cast<const f32x4*>(vp);
+      if (C > 4) {
+        k1 = *reinterpret_cast<const f32x4*>(kp + 4);
+        v1 = *reinterpret_cast<const f32x4*>(vp + 4);
+      }
+    }
+    k0 *= LOG2E;
+    k1 *= LOG2E;
+    u32x4 wk[3], wv[3];
+    split_pair(k0[0], k0[1], wk, 0);
+    split_pair(k0[2], k0[3], wk, 1);
+    split_pair(k1[0], k1[1], wk, 2);
+    split_pair(k1[2], k1[3], wk, 3);
+    split_pair(v0[0], v0[1], wv, 0);
+    split_pair(v0[2], v0[3], wv, 1);
+    split_pair(v1[0], v1[1], wv, 2);
+    split_pair(v1[2], v1[3], wv, 3);
+    ka = lh ? wk[1] : wk[0];
+    kc = lh ? wk[0] : wk[2];
+    va = lh ? wv[1] : wv[0];
+    vc = lh ? wv[0] : wv[2];
+    const int pc = li >> 3, ch = li & 7;  // this lane's packed column
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      float kv[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int key = j0 + 16 * m + 8 * lh + e;
+        kv[e] = (key < N && ch < C && pc < 3) ? p.k[(brow + key) * p.k_cs + ch] : 0.f;
+      }
+      u32x4 w[3];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) split_pair(kv[2 * e], kv[2 * e + 1], w, e);
+      kbr[m] = pc == 0 ? w[0] : (pc == 1 ? w[1] : w[2]);  // pc == 3: kv = 0
+    }
+  }
+  f32x16 dk, dv;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { dk[r] = 0.f; dv[r] = 0.f; }
+
+  // ---- staging: a tile is 4 KB of either plane = one 16-byte element per thread (8 wavefronts: half each)
+  const int st = tid & 255;
+  const bool st_d = NW == 8 && tid >= 256;
+  const unsigned short* qg = (st_d ? db : qb) + (long)b * n64 * (QT * 32) + st * 8;
+  const unsigned short* dg = db + (long)b * n64 * (QT * 32) + st * 8;
+  const int st_off = (st >> 2) * KP + (st & 3) * 8 + (st_d ? PL : 0);
+  u32x4 rq, rd;
+  float rl = 0.f, rD = 0.f;
+  auto load_tile = [&](int t) {
+    rq = *reinterpret_cast<const u32x4*>(qg + (long)t * (QT * 32));
+    if constexpr (NW == 4) rd = *reinterpret_cast<const u32x4*>(dg + (long)t * (QT * 32));
+    if (tid < QT) {
+      const int i = t * QT + tid;
+      rl = (i < N) ? -p.lse[brow + i] : -POS_BIG;
+      rD = (i < N) ? -p.dvec[brow + i] * gamma : 0.f;
+    }
+  };
+  auto store_tile = [&]() {
+    *reinterpret_cast<u32x4*>(tile + st_off) = rq;
+    if constexpr (NW == 4) *reinterpret_cast<u32x4*>(tile + PL + st_off) = rd;
+    if (tid < QT) {
+      lsd[tid] = rl;
+      lsd[QT + tid] = rD;
+    }
+  };
+  const int tr_row = (lane & 15) >> 2, tr_col = 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+
+  const int nq = (N + QT - 1) / QT;
+  const int tz = (nq + p.zs - 1) / p.zs;
+  const int t0 = z * tz;
+  const int ntiles = min(nq, t0 + tz);
+  if (t0 < ntiles) {
+    load_tile(t0);
+    store_tile();
+  }
+  __syncthreads();
+  for (int t = t0; t < ntiles; ++t) {
+    const bool more = (t + 1) < ntiles;
+    if (more) load_tile(t + 1);
+    f32x16 dqp[2];
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dqp[sub][r] = 0.f;
+      if (t * QT + sub * 32 >= N) continue;  // wave-uniform
+      f32x16 s, dp;
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const f32x4 l4 = *reinterpret_cast<const f32x4*>(lsd + sub * 32 + 8 * g4 + 4 * lh);
+        const f32x4 d4 = *reinterpret_cast<const f32x4*>(lsd + QT + sub * 32 + 8 * g4 + 4 * lh);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          s[4 * g4 + e] = l4[e];
+          dp[4 * g4 + e] = d4[e];
+        }
+      }
+      {  // S' = Q K'^T - LSE, dP = dO V^T - D: [x1|x3][y3|y1], [x2|x2][y1|y2], [x1|x1][y1|y2]
+        const unsigned short* rowp = tile + (sub * 32 + li) * KP;
+        const int o3 = lh ? 16 : 0;
+        const u32x4 q1 = *reinterpret_cast<const u32x4*>(rowp), q2 = *reinterpret_cast<const u32x4*>(rowp + 8),
+                    q3 = *reinterpret_cast<const u32x4*>(rowp + o3);
+        const u32x4 d1 = *reinterpret_cast<const u32x4*>(rowp + PL), d2 = *reinterpret_cast<const u32x4*>(rowp + PL + 8),
+                    d3 = *reinterpret_cast<const u32x4*>(rowp + PL + o3);
+        s = mfma_bf(q3, kc, s);
+        dp = mfma_bf(d3, vc, dp);
+        s = mfma_bf(q2, ka, s);
+        dp = mfma_bf(d2, va, dp);
+        s = mfma_bf(q1, ka, s);
+        dp = mfma_bf(d1, va, dp);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[r] = __builtin_amdgcn_exp2f(s[r]);  // P
+      const unsigned short* colp = tile + (sub * 32 + 4 * lh + tr_row) * KP + tr_col;
+      {  // dV^T (packed rows) += dO^T P
+        u32x4 pf[2][3];
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) split_pair(s[8 * m + 2 * e], s[8 * m + 2 * e + 1], pf[m], e);
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+          const u32x2 lo = lds_read_tr(colp + PL + (16 * m) * KP);
+          const u32x2 hi = lds_read_tr(colp + PL + (16 * m + 8) * KP);
+          const u32x4 a = {lo[0], lo[1], hi[0], hi[1]};
+          dv = mfma_bf(a, pf[m][2], dv);
+          dv = mfma_bf(a, pf[m][1], dv);
+          dv = mfma_bf(a, pf[m][0], dv);
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[r] *= dp[r];  // dS
+      u32x4 sf[2][3];
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) split_pair(s[8 * m + 2 * e], s[8 * m + 2 * e + 1], sf[m], e);
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {  // dK^T (packed rows) += Q^T dS
+        const u32x2 lo = lds_read_tr(colp + (16 * m) * KP);
+        const u32x2 hi = lds_read_tr(colp + (16 * m + 8) * KP);
+        const u32x4 a = {lo[0], lo[1], hi[0], hi[1]};
+        dk = mfma_bf(a, sf[m][2], dk);
+        dk = mfma_bf(a, sf[m][1], dk);
+        dk = mfma_bf(a, sf[m][0], dk);
+      }
+#pragma unroll
+      for (int pc = 0; pc < 3; ++pc)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          *reinterpret_cast<u32x2*>(img + (pc * 32 + li) * TP + 8 * g + 4 * lh) =
+              (u32x2){sf[g >> 1][pc][2 * (g & 1)], sf[g >> 1][pc][2 * (g & 1) + 1]};
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      const unsigned short* imgp = img + (8 * lh + tr_row) * TP + tr_col;
+#pragma unroll
+      for (int m = 0; m < 2; ++m)  // dQ (packed columns) += dS K
+#pragma unroll
+        for (int pc = 2; pc >= 0; --pc) {
+          const u32x2 lo = lds_read_tr(imgp + (pc * 32 + 16 * m) * TP);
+          const u32x2 hi = lds_read_tr(imgp + (pc * 32 + 16 * m + 4) * TP);
+          dqp[sub] = mfma_bf((u32x4){lo[0], lo[1], hi[0], hi[1]}, kbr[m], dqp[sub]);
+        }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) myslot[(sub * 32 + kappa(r, lh)) * 32 + li] = dqp[sub][r];
+    __syncthreads();
+    if (more) store_tile();
+    if (tid < QT * CP / 4) {  // fixed-order sum of the NW partials and of the three column groups -> plane [QT][8]
+      const int row = tid >> 1, c0 = (tid & 1) * 4;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int w = 0; w < NW; ++w)
+#pragma unroll
+        for (int g = 0; g < 3; ++g) v += *reinterpret_cast<const f32x4*>(slots + w * SLOT + row * 32 + g * 8 + c0);
+      *reinterpret_cast<f32x4*>(ws + ((((long)b * nq + t) * p.nt + kb) * (long)(QT * CP)) + row * CP + c0) = v;
+    }
+    __syncthreads();
+  }
+  if (!jok) return;
+  float* okp;
+  float* ovp;
+  if (p.zs > 1) {
+    okp = p.dkp + ((long)bz * N + jrow) * CP;
+    ovp = p.dvp + ((long)bz * N + jrow) * CP;
+  } else {
+    okp = p.dk + (brow + jrow) * p.dk_cs;
+    ovp = p.dv + (brow + jrow) * p.dv_cs;
+  }
+  const int c = 4 * lh;  // channels (r & 3) + 4h live in registers r, r + 4, r + 8 (packed row groups)
+  if (p.zs > 1 || c < C) {
+    *reinterpret_cast<f32x4*>(okp + c) = (f32x4){dk[0] + dk[4] + dk[8], dk[1] + dk[5] + dk[9], dk[2] + dk[6] + dk[10],
+                                                 dk[3] + dk[7] + dk[11]};
+    *reinterpret_cast<f32x4*>(ovp + c) = (f32x4){dv[0] + dv[4] + dv[8], dv[1] + dv[5] + dv[9], dv[2] + dv[6] + dv[10],
+                                                 dv[3] + dv[7] + dv[11]};
+  }
+}
+
 // dq[b, i, c] = sum over the key-block planes, in plane order.
 __global__ void attn_dq_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dq, int dq_cs, int B, int N,
                                       int C, int CP, int nkb) {
@@ -1051,6 +1292,39 @@ int launch_fused_bx(BwdArgs a, float* ws, float* bx_ws, hipStream_t s) {
   return SF_OK;
 }
 
+// The packed form (C <= 8): planes of Q and gamma dz behind the fp32 form's workspace, then the sweep.
+template <int NW>
+int launch_fused_bxp(BwdArgs a, float* ws, float* bx_ws, hipStream_t s) {
+  constexpr int CP = 8, qt = BXB_QT;
+  a.nt = sf_cdiv(a.N, 32 * NW);
+  a.zs = sf_sweep_parts((long)a.B * a.nt, sf_cdiv(a.N, qt));
+  const long planes = (long)a.B * a.nt * sf_cdiv(a.N, qt) * qt * CP, part = (long)a.B * a.zs * a.N * CP;
+  a.dkp = ws + planes;
+  a.dvp = a.dkp + part;
+  unsigned short* qb = reinterpret_cast<unsigned short*>(bx_ws);
+  unsigned short* db = qb + sf_attn_bx_packed_elems(a.B, a.N);
+  int rc = sf_attn_bx_split_packed(a.q, a.q_cs, nullptr, a.B, a.N, a.C, qb, nullptr, s);
+  if (rc == SF_OK) rc = sf_attn_bx_split_packed(a.dz, a.dz_cs, a.gamma, a.B, a.N, a.C, db, nullptr, s);
+  if (rc != SF_OK) return rc;
+  static const bool attr_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_bxp_kernel<NW>),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                  bxbp_lds_bytes(NW)) == hipSuccess;
+  if (!attr_ok) return SF_ELAUNCH;
+  hipLaunchKernelGGL((attn_bwd_bxp_kernel<NW>), dim3(a.B * a.zs * a.nt), dim3(64 * NW), bxbp_lds_bytes(NW), s, a, ws, qb,
+                     db, sf_cdiv(a.N, qt));
+  SF_CHECK_LAUNCH();
+  if (a.zs > 1) {
+    rc = sf_attn_dq_reduce(a.dkp, a.dk, a.dk_cs, a.B, a.N, a.C, CP, a.zs, s);
+    if (rc == SF_OK) rc = sf_attn_dq_reduce(a.dvp, a.dv, a.dv_cs, a.B, a.N, a.C, CP, a.zs, s);
+    if (rc != SF_OK) return rc;
+  }
+  const long total = (long)a.B * a.N * (CP / 4);
+  hipLaunchKernelGGL(attn_dq_reduce_tiled_kernel, dim3(sf_cdiv(total, 256)), dim3(256), 0, s, ws, a.dq, a.dq_cs, a.B,
+                     a.N, a.C, CP, a.nt, qt);
+  SF_CHECK_LAUNCH();
+  return SF_OK;
+}
+
 template <int CP>
 int launch(const BwdArgs& a, int which, hipStream_t s) {
   const int grid = a.B * a.zs * a.nt;
@@ -1111,6 +1385,7 @@ extern "C" long sf_attn_bwd_fused_ws_floats(int B, int N, int C) {
   const long nr = (long)sf_cdiv(N, 64) * 64;  // the dQ partials are stored per (whole) query tile of 32 / 64 rows
   long n = (long)B * (sf_cdiv(N, keys) * nr + 2L * SF_SWEEP_PARTS_MAX * N) * cp;
   if (cp == 32) n += sf_attn_bx_plane_elems(B, N);  // Q and gamma dz as three bf16 row planes each (2 x 2 B = 1 float)
+  if (cp == 8) n += sf_attn_bx_packed_elems(B, N);  // Q and gamma dz as one packed plane each
   return n;
 }
 
@@ -1120,6 +1395,21 @@ extern "C" int sf_attn_bwd_fused(const float* q, int q_cs, const float* k, int k
                                  float* ws, void* stream) {
   if (!q || !k || !v || !dz || !lse || !dvec || !gamma || !dq || !dk || !dv || !ws) return SF_EINVAL;
   if (sf_attn_bwd_fused_ws_floats(B, N, C) == 0 || !sf_aligned16(ws)) return SF_EINVAL;
+  if (C > 4 && C <= 8 && C % 4 == 0 && sf_attn_bx_level() >= 1 && (q_cs % 4 == 0) && (k_cs % 4 == 0) &&
+      (v_cs % 4 == 0) && (dz_cs % 4 == 0) && (dk_cs % 4 == 0) && (dv_cs % 4 == 0) && sf_aligned16(q) &&
+      sf_aligned16(k) && sf_aligned16(v) && sf_aligned16(dz) && sf_aligned16(dk) && sf_aligned16(dv)) {
+    BwdArgs a;  // packed planes on the bf16 pipe
+    a.q = q; a.k = k; a.v = v; a.dz = dz; a.lse = lse; a.dvec = dvec; a.gamma = gamma;
+    a.dq = dq; a.dk = dk; a.dv = dv;
+    a.q_cs = q_cs; a.k_cs = k_cs; a.v_cs = v_cs; a.dz_cs = dz_cs; a.dq_cs = dq_cs; a.dk_cs = dk_cs; a.dv_cs = dv_cs;
+    a.B = B; a.C = C; a.N = N; a.dqp = nullptr;
+    // 128 keys per workgroup: the dQ planes are a quarter of the d = 32 ones, and 8-wavefront barriers cost more than
+    // halving them saves (N = 25 088, B = 8: 5.00 ms against 5.26).  SF_ATTN_BX_NW=8 forces the wide form.
+    static const bool wide = [] { const char* e = getenv("SF_ATTN_BX_NW"); return e && atoi(e) == 8; }();
+    float* const bx_ws = ws + (sf_attn_bwd_fused_ws_floats(B, N, C) - sf_attn_bx_packed_elems(B, N));
+    return wide ? launch_fused_bxp<8>(a, ws, bx_ws, (hipStream_t)stream)
+                : launch_fused_bxp<4>(a, ws, bx_ws, (hipStream_t)stream);
+  }
   if (C <= 16)
     return sf_attn_small_fused_dispatch(q, q_cs, k, k_cs, v, v_cs, dz, dz_cs, lse, dvec, gamma, dq, dq_cs, dk, dk_cs,
                                         dv, dv_cs, B, N, C, ws, (hipStream_t)stream);

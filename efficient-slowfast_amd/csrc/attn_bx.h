@@ -19,3 +19,17 @@ __device__ __forceinline__ int bx_key_of_pos(int pos) {  // position within a 64
 int sf_attn_bx_split(const float* src, int cs, const float* mul, int B, int N, int C, unsigned short* rows,
                      unsigned short* cols, hipStream_t s);
 static inline long sf_attn_bx_plane_elems(int B, int N) { return (long)B * 3 * sf_cdiv(N, BX_KT) * BX_KT * 32; }
+
+// ---- packed planes, C <= 8 ---------------------------------------------------------------------------------------------
+// With at most 8 channels the three pieces of a row fit ONE 32-column row  [p1 ch0..7 | p2 ch0..7 | p3 ch0..7 | 0 x 8]:
+//   * a product over the CHANNELS (S = Q K^T, dP = dO V^T; 8 of the MFMA's 16 k slots per lane half) takes two piece
+//     pairs per instruction — A = [x|y] (lane half h reads piece x or y of its row: a 16-byte offset), B = [u|v] —
+//     so [a1|a1][b1|b2], [a2|a2][b1|b2], [a1|a3][b3|b1] are the six kept terms in THREE MFMAs;
+//   * a product whose OUTPUT is the channels (O^T = V^T P^T, dV^T, dK^T, dQ) takes the packed row as its 32 output
+//     rows / columns: one MFMA per piece of the other operand yields that piece times all three of this one in row
+//     groups 0-7 / 8-15 / 16-23, summed at the end (all nine terms) — three MFMAs per k-step instead of six.
+// packed rows    [B][n64 * 64 rows][32]                 (one plane)
+// packed columns [B][n64 tiles][32 packed channels][64 row positions]
+int sf_attn_bx_split_packed(const float* src, int cs, const float* mul, int B, int N, int C, unsigned short* rows,
+                            unsigned short* cols, hipStream_t s);
+static inline long sf_attn_bx_packed_elems(int B, int N) { return (long)B * sf_cdiv(N, BX_KT) * BX_KT * 32; }

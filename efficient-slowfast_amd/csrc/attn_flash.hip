@@ -396,6 +396,45 @@ __global__ __launch_bounds__(256) void attn_bx_split_kernel(const float* __restr
   }
 }
 
+// Packed planes (attn_bx.h), C <= 8.
+__global__ __launch_bounds__(256) void attn_bx_split_packed_kernel(const float* __restrict__ src, int cs,
+                                                                   const float* __restrict__ mul, int N, int C,
+                                                                   unsigned short* rows, unsigned short* cols, int n64) {
+  __shared__ float vt[BX_KT][9];
+  const int tid = threadIdx.x;
+  const int b = blockIdx.x / n64, tile = blockIdx.x - b * n64;
+  const long brow = (long)b * N;
+  const float m = mul ? mul[0] : 1.0f;
+  if (tid < 128) {  // coalesced rows into LDS: thread = (row, 4 channels)
+    const int row = tid >> 1, c0 = (tid & 1) * 4;
+    const int j = tile * BX_KT + row;
+    f32x4 t = {0.f, 0.f, 0.f, 0.f};
+    if (j < N && c0 < C) t = *reinterpret_cast<const f32x4*>(src + (brow + j) * cs + c0);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) vt[row][c0 + e] = (c0 + e < C) ? t[e] * m : 0.f;
+  }
+  __syncthreads();
+  if (rows && tid < BX_KT) {  // thread = row: [p1 | p2 | p3 | 0]
+    u32x4 w[3];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) split_pair(vt[tid][2 * e], vt[tid][2 * e + 1], w, e);
+    unsigned short* o = rows + ((long)b * n64 * BX_KT + (long)tile * BX_KT + tid) * 32;
+#pragma unroll
+    for (int pc = 0; pc < 3; ++pc) *reinterpret_cast<u32x4*>(o + 8 * pc) = w[pc];
+    *reinterpret_cast<u32x4*>(o + 24) = (u32x4){0u, 0u, 0u, 0u};
+  }
+  if (cols) {  // thread = (packed channel, 8 row positions)
+    const int pr = tid >> 3, pos0 = (tid & 7) * 8;
+    u32x4 w[3];
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      split_pair(vt[bx_key_of_pos(pos0 + 2 * e)][pr & 7], vt[bx_key_of_pos(pos0 + 2 * e + 1)][pr & 7], w, e);
+    const int pc = pr >> 3;
+    const u32x4 v = pc == 0 ? w[0] : (pc == 1 ? w[1] : (pc == 2 ? w[2] : (u32x4){0u, 0u, 0u, 0u}));
+    *reinterpret_cast<u32x4*>(cols + (((long)b * n64 + tile) * 32 + pr) * BX_KT + pos0) = v;
+  }
+}
+
 // The streaming kernel above on split operands (d = 32, 16-byte aligned rows).  Same mapping — S^T = K Q^T with the
 // query on the lane, O^T = V^T P^T with P^T's accumulator registers as the B operand — on v_mfma_f32_32x32x16_bf16.
 // K / V^T tiles come pre-split from the planes above (six 16-byte loads and LDS stores per thread and tile, no vector
@@ -691,6 +730,189 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bx_kernel(const AttnArgs p, c
   attn_fwd_finish<CP, 4>(p, o, m_run, l_run + __shfl_xor(l_run, 32, 64), b, bz, q0 + li, lh);
 }
 
+// ---- C <= 8 on packed planes (attn_bx.h) ----------------------------------------------------------------------------
+// The kernel above with one plane per operand: S^T = K Q^T is three MFMAs ([k1|k1][q1|q2], [k2|k2][q1|q2],
+// [k1|k3][q3|q1]), O^T = V^T P^T three per k-step (the packed V^T rows times P^T's pieces) with
+// O[c] = rows c + (8 + c) + (16 + c) at the end.  9 MFMAs per 32-key block instead of 24; the exp2 / split work per
+// element is unchanged, so this form is bound by the vector pipe — which the f32 MFMAs of attn_small.hip share with
+// it and these do not.
+constexpr int BXP_LDS_BYTES = (3 * BX_KPL + 2 * BX_VPL) * 2;
+__global__ __launch_bounds__(256, 2) void attn_fwd_bxp_kernel(const AttnArgs p, const unsigned short* kb,
+                                                              const unsigned short* vb, int n64) {
+  constexpr int KT = BX_KT, KP = BX_KP, VP = BX_VP, KPL = BX_KPL, VPL = BX_VPL;
+  __shared__ __attribute__((aligned(16))) unsigned short smem[3 * KPL + 2 * VPL];
+  unsigned short* const Ks = smem;             // [3 buffers][key][KP]
+  unsigned short* const Vs = smem + 3 * KPL;   // [2 buffers][packed channel][VP]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int li = lane & 31;
+  const int lh = lane >> 5;
+  const int bz = blockIdx.x / p.nqt;
+  const int b = bz / p.zs, z = bz - b * p.zs;
+  const int q0 = (blockIdx.x - bz * p.nqt) * 128 + wave * 32;
+  const int N = p.N;
+  const long brow = (long)b * N;
+
+  // ---- Q as B operands [q1|q2] and [q3|q1] (lane half h holds the left / right piece of its query's 8 channels)
+  u32x4 qa, qc;
+  {
+    const int qrow = q0 + li;
+    const float* qp = p.q + (brow + (qrow < N ? qrow : 0)) * p.q_cs;
+    f32x4 t0 = {0.f, 0.f, 0.f, 0.f}, t1 = t0;
+    if (qrow < N) {
+      t0 = *reinterpret_cast<const f32x4*>(qp);
+      if (p.C > 4) t1 = *reinterpret_cast<const f32x4*>(qp + 4);
+    }
+    t0 *= LOG2E;
+    t1 *= LOG2E;
+    u32x4 w[3];
+    split_pair(t0[0], t0[1], w, 0);
+    split_pair(t0[2], t0[3], w, 1);
+    split_pair(t1[0], t1[1], w, 2);
+    split_pair(t1[2], t1[3], w, 3);
+    qa = lh ? w[1] : w[0];
+    qc = lh ? w[0] : w[2];
+  }
+
+  f32x16 o;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) o[r] = 0.f;
+  float m_run = NEG_BIG;
+  f32x2 lacc = {0.f, 0.f};
+  f32x16 negm;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) negm[r] = -NEG_BIG;
+
+  // ---- staging: a tile is 4 KB in either plane = one 16-byte element per thread
+  const unsigned short* kg = kb + (long)b * n64 * (KT * 32) + tid * 8;
+  const unsigned short* vg = vb + (long)b * n64 * (KT * 32) + tid * 8;
+  const int ks_off = (tid >> 2) * KP + (tid & 3) * 8;
+  const int vs_off = (tid >> 3) * VP + (tid & 7) * 8;
+  u32x4 rk, rv;
+  auto load_k = [&](int t) { rk = *reinterpret_cast<const u32x4*>(kg + (long)t * (KT * 32)); };
+  auto load_v = [&](int t) { rv = *reinterpret_cast<const u32x4*>(vg + (long)t * (KT * 32)); };
+  auto store_k = [&](int buf) { *reinterpret_cast<u32x4*>(Ks + buf * KPL + ks_off) = rk; };
+  auto store_v = [&](int buf) { *reinterpret_cast<u32x4*>(Vs + buf * VPL + vs_off) = rv; };
+
+  const int tz = (n64 + p.zs - 1) / p.zs;
+  const int t0 = z * tz;
+  const int nt = min(n64, t0 + tz) - t0;
+
+  f32x16 s_next;
+  u32x4 kf[3];  // [k1|k1], [k2|k2], [k1|k3] of the block in s_next
+  auto qk3 = [&](f32x16 c) {
+    c = mfma_bf(kf[2], qc, c);   // k1 q3 + k3 q1
+    c = mfma_bf(kf[1], qa, c);   // k2 q1 + k2 q2
+    return mfma_bf(kf[0], qa, c);  // k1 q1 + k1 q2
+  };
+  auto qk = [&](int kbuf, int sub) {
+    const unsigned short* krow = Ks + kbuf * KPL + (sub * 32 + li) * KP;
+    kf[0] = *reinterpret_cast<const u32x4*>(krow);
+    kf[1] = *reinterpret_cast<const u32x4*>(krow + 8);
+    kf[2] = *reinterpret_cast<const u32x4*>(krow + (lh ? 16 : 0));
+    s_next = qk3(negm);
+  };
+  auto refresh = [&](int jbase) {  // see attn_fwd_bx_kernel
+    f32x16 s;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s[r] = 0.f;
+    s = qk3(s);
+    if (jbase + 32 > N) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        if (jbase + (r & 3) + 8 * (r >> 2) + 4 * lh >= N) s[r] = NEG_BIG;
+    }
+    float mloc = s[0];
+#pragma unroll
+    for (int r = 1; r < 16; ++r) mloc = fmaxf(mloc, s[r]);
+    mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+    const float mnew = fmaxf(m_run, mloc);
+    const float alpha = __builtin_amdgcn_exp2f(m_run - mnew);
+    lacc *= alpha;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[r] *= alpha;
+    m_run = mnew;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      negm[r] = -mnew;
+      s_next[r] = s[r] - mnew;
+    }
+  };
+  auto check = [&](int jbase) {
+    float mx = fmaxf(fmaxf(s_next[0], s_next[1]), s_next[2]);
+#pragma unroll
+    for (int r = 3; r < 15; r += 2) mx = fmaxf(fmaxf(mx, s_next[r]), s_next[r + 1]);
+    mx = fmaxf(mx, s_next[15]);
+    if (__any(mx > p.soft_t) || jbase + 32 > N) refresh(jbase);
+  };
+  auto step = [&](auto HAS_NEXT, int vbuf, int sub, int kbuf_n, int sub_n) {
+    f32x16 s = s_next;
+    if constexpr (decltype(HAS_NEXT)::value) qk(kbuf_n, sub_n);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s[r] = __builtin_amdgcn_exp2f(s[r]);
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) {
+      lacc[0] += s[r];
+      lacc[1] += s[r + 1];
+    }
+    u32x4 pf[2][3];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) split_pair(s[8 * m + 2 * e], s[8 * m + 2 * e + 1], pf[m], e);
+    const unsigned short* vrow = Vs + vbuf * VPL + li * VP + sub * 32 + 8 * lh;
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      const u32x4 vf = *reinterpret_cast<const u32x4*>(vrow + 16 * m);
+      o = mfma_bf(vf, pf[m][2], o);
+      o = mfma_bf(vf, pf[m][1], o);
+      o = mfma_bf(vf, pf[m][0], o);
+    }
+  };
+  using T = std::true_type;
+  using F = std::false_type;
+
+  if (nt > 0) {
+    load_k(t0);
+    load_v(t0);
+    store_k(0);
+    store_v(0);
+    load_k(min(t0 + 1, n64 - 1));
+    store_k(1);
+    __syncthreads();
+    qk(0, 0);
+    check(t0 * KT);
+    int kcur = 0;
+    for (int r = 0; r < nt; ++r) {
+      const int t = t0 + r;
+      const int knext = kcur == 2 ? 0 : kcur + 1, kafter = knext == 2 ? 0 : knext + 1;
+      load_k(min(t + 2, n64 - 1));
+      load_v(min(t + 1, n64 - 1));
+      step(T{}, r & 1, 0, kcur, 1);
+      check(t * KT + 32);
+      if (r + 1 < nt) {
+        step(T{}, r & 1, 1, knext, 0);
+        check(t * KT + 64);
+      } else {
+        step(F{}, r & 1, 1, 0, 0);
+      }
+      store_k(kafter);
+      store_v((r + 1) & 1);
+      __syncthreads();
+      kcur = knext;
+    }
+  }
+
+  // O[c] for c = (r & 3) + 4h: packed row groups 0-7 / 8-15 / 16-23 are registers r, r + 4, r + 8
+  f32x16 of[1];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) of[0][r] = r < 4 ? o[r] + o[r + 4] + o[r + 8] : 0.f;
+  const float l_run = lacc[0] + lacc[1];
+  attn_fwd_finish<8, 4>(p, of, m_run, l_run + __shfl_xor(l_run, 32, 64), b, bz, q0 + li, lh);
+}
+
 // One thread per (query row, 4 channels): O = sum_z o_z 2^(m_z - m) / sum_z l_z 2^(m_z - m), m = max_z m_z, then the
 // same epilogue as above.  An empty part carries (m, l, o) = (-BIG, 0, 0) and drops out with weight 0.
 __global__ __launch_bounds__(256) void attn_fwd_merge_kernel(const AttnArgs p, int cp) {
@@ -795,6 +1017,15 @@ int sf_attn_bx_split(const float* src, int cs, const float* mul, int B, int N, i
   return SF_OK;
 }
 
+int sf_attn_bx_split_packed(const float* src, int cs, const float* mul, int B, int N, int C, unsigned short* rows,
+                            unsigned short* cols, hipStream_t s) {
+  if (!src || C > 8 || (cs & 3) || (C & 3) || !sf_aligned16(src)) return SF_EINVAL;
+  const int n64 = sf_cdiv(N, BX_KT);
+  hipLaunchKernelGGL(attn_bx_split_packed_kernel, dim3(B * n64), dim3(256), 0, s, src, cs, mul, N, C, rows, cols, n64);
+  SF_CHECK_LAUNCH();
+  return SF_OK;
+}
+
 int sf_attn_fwd_merge(const SfAttnArgs& a, int cp, hipStream_t s) {
   const long total = (long)a.B * a.N * (cp / 4);
   hipLaunchKernelGGL(attn_fwd_merge_kernel, dim3(sf_cdiv(total, 256)), dim3(256), 0, s, a, cp);
@@ -839,6 +1070,20 @@ static int attn_fwd_impl(const float* q, int q_cs, const float* k, int k_cs, con
     const char* e = getenv("SF_ATTN_FWD32");
     return e && e[0] == 's';
   }();
+  if (C > 4 && C <= 8 && C % 4 == 0 && vec4 && ws && sf_attn_bx_level() >= 1) {  // packed planes on the bf16 pipe
+    a.nqt = sf_cdiv(N, 128);
+    a.zs = sf_sweep_parts((long)B * a.nqt, sf_cdiv(N, 64));
+    sf_attn_place_parts(a, 8, ws);
+    a.soft_t = sf_attn_soft_t();
+    unsigned short* kb = reinterpret_cast<unsigned short*>(ws + (long)B * SF_SWEEP_PARTS_MAX * N * (8 + 2));
+    unsigned short* vb = kb + sf_attn_bx_packed_elems(B, (int)N);
+    if (sf_attn_bx_split_packed(k, k_cs, nullptr, B, (int)N, C, kb, nullptr, s) != SF_OK ||
+        sf_attn_bx_split_packed(v, v_cs, nullptr, B, (int)N, C, nullptr, vb, s) != SF_OK)
+      return SF_ELAUNCH;
+    hipLaunchKernelGGL(attn_fwd_bxp_kernel, dim3(B * a.zs * a.nqt), dim3(256), 0, s, a, kb, vb, sf_cdiv(N, BX_KT));
+    SF_CHECK_LAUNCH();
+    return a.zs > 1 ? sf_attn_fwd_merge(a, 8, s) : SF_OK;
+  }
   if (C <= 16 || (C <= 32 && small32))
     return sf_attn_small_dispatch(q, q_cs, k, k_cs, v, v_cs, x, x_cs, gamma, scale, bias, act, out, out_cs,
                                   out_coff, B, T, H, W, C, alpha, o_save, lse_save, vec4, ws, s);
@@ -863,7 +1108,10 @@ extern "C" int sf_attn_fwd(const float* q, int q_cs, const float* k, int k_cs, c
                        W, C, alpha, o_save, lse_save, nullptr, stream);
 }
 
-extern "C" int sf_attn_products_per_fp32(int C) { return (C > 16 && C <= 32 && sf_attn_bx_level() >= 1) ? 6 : 0; }
+extern "C" int sf_attn_products_per_fp32(int C) {
+  if (sf_attn_bx_level() < 1) return 0;
+  return ((C > 16 && C <= 32) || (C > 4 && C <= 8 && C % 4 == 0)) ? 6 : 0;  // C <= 8: packed planes (attn_bx.h)
+}
 
 // Room for the (O^T, m, l) of up to SF_SWEEP_PARTS_MAX key parts per query row.
 extern "C" long sf_attn_fwd_ws_floats(int B, int N, int C) {
@@ -871,6 +1119,7 @@ extern "C" long sf_attn_fwd_ws_floats(int B, int N, int C) {
   const int cp = C <= 4 ? 4 : (C <= 8 ? 8 : (C <= 16 ? 16 : (C <= 32 ? 32 : (C <= 64 ? 64 : 128))));
   long n = (long)B * SF_SWEEP_PARTS_MAX * N * (cp + 2);
   if (cp == 32) n += (long)B * sf_cdiv(N, 64) * 64 * 32 * 3;  // K and V^T as three bf16 planes each (12 B per element)
+  if (cp == 8) n += (long)B * sf_cdiv(N, 64) * 64 * 32;       // K and V^T as one packed plane each (2 x 64 B per row)
   return n;
 }
 

@@ -125,9 +125,11 @@ def test_launch_planning_queries_are_host_only_and_fill_the_chip():
     # [B, N rounded up to 64, 32], two tensors per direction (Q and gamma dz backward; K and V^T forward)
     planes = B * 3 * N * 32  # N % 64 == 0 here; in floats: 2 tensors x 2 B = 4 B per piece element
     assert L.sf_attn_bwd_fused_ws_floats(B, N, 32) == B * (N // 128 + 16) * N * 32 + planes
-    assert L.sf_attn_bwd_fused_ws_floats(B, N, 8) == B * (N // 64 + 16) * N * 8
+    assert L.sf_attn_bwd_fused_ws_floats(B, N, 8) == B * (N // 64 + 16) * N * 8 + B * N * 32  # + packed planes (d <= 8)
     assert L.sf_attn_bwd_fused_ws_floats(B, N, 128) == 0                       # d = 128 keeps the two-kernel form
     assert L.sf_attn_fwd_ws_floats(B, N, 32) == B * 8 * N * 34 + planes
     assert L.sf_attn_fwd_ws_floats(B, N, 64) == B * 8 * N * 66
+    assert L.sf_attn_fwd_ws_floats(B, N, 8) == B * 8 * N * 10 + B * N * 32
     assert L.sf_attn_products_per_fp32(32) in (0, 6) and L.sf_attn_products_per_fp32(64) == 0
+    assert L.sf_attn_products_per_fp32(8) in (0, 6) and L.sf_attn_products_per_fp32(4) == 0
     assert L.sf_attn_fwd_ws_floats(0, N, 32) == 0 and L.sf_attn_fwd_ws_floats(B, N, 129) == 0

@@ -1,5 +1,5 @@
 #!/bin/bash
 mkdir -p gpurun_out/r3bx; cd /root/repo
-timeout 3000 python -m pytest tests -q -m gpu -x 2>&1 | tail -8 > gpurun_out/r3bx/tests_all.txt
-timeout 900 python bench.py --steps 20 --warmup 5 > gpurun_out/r3bx/bench.json 2> gpurun_out/r3bx/bench.err
-cat gpurun_out/r3bx/tests_all.txt; tail -3 gpurun_out/r3bx/bench.err; cat gpurun_out/r3bx/bench.json
+timeout 900 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > gpurun_out/r3bx/bench.json 2> gpurun_out/r3bx/bench.err
+tail -2 gpurun_out/r3bx/bench.err; cat gpurun_out/r3bx/bench.json | cut -c1-1200
+timeout 900 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extras --no-graph | cut -c1-400
