@@ -1263,7 +1263,7 @@ int launch_fused_bx(BwdArgs a, float* ws, float* bx_ws, hipStream_t s) {
   static const Kern kern = [] {  // SF_ATTN_BX_DBG: timing ablations (see the kernel)
     const char* e = getenv("SF_ATTN_BX_DBG");
     const int dbg = e ? atoi(e) : 0;
-    if (NW == 8) return (Kern)attn_bwd_bx_kernel<0, 8>;
+    if (NW == 8) return dbg == 2 ? (Kern)attn_bwd_bx_kernel<2, 8> : (Kern)attn_bwd_bx_kernel<0, 8>;
     switch (dbg) {
       case 1: return (Kern)attn_bwd_bx_kernel<1, 4>;
       case 2: return (Kern)attn_bwd_bx_kernel<2, 4>;
