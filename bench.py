@@ -545,6 +545,7 @@ def main():
                             "launches_timed": len(per[tag]), "traffic": traffic, "traffic_source": traffic_src,
                             "executed_mfma_tflops": round(ach * (6.0 if split6 else executed / nprod), 2)}
                 if split6:
+                    roofline["frac_of_f32_mfma_peak"] = round(ach / PEAK_FP32_MFMA_TFLOPS, 4)  # the round-2 / 3a basis
                     roofline["peak_basis"] = ("algorithmic fp32 FLOP/s against the dense bf16 MFMA peak (%.0f TFLOP/s) / 6 "
                                               "products per fp32 product; executed_mfma_tflops is the bf16 rate; the "
                                               "f32-input MFMA peak this path replaces is %.1f TFLOP/s" % (
