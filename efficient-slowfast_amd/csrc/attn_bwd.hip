@@ -1273,11 +1273,12 @@ int launch_fused_bx(BwdArgs a, float* ws, float* bx_ws, hipStream_t s) {
       default: return (Kern)attn_bwd_bx_kernel<0, 4>;
     }
   }();
+  static const int pad = [] { const char* e = getenv("SF_ATTN_BX_PADLDS"); return e ? atoi(e) : 0; }();  // occupancy probe
   static const bool attr_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                                   hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                  bxb_lds_bytes(NW)) == hipSuccess;
+                                                  bxb_lds_bytes(NW) + pad) == hipSuccess;
   if (!attr_ok) return SF_ELAUNCH;
-  hipLaunchKernelGGL(kern, dim3(a.B * a.zs * a.nt), dim3(64 * NW), bxb_lds_bytes(NW), s, a, ws, qb, db,
+  hipLaunchKernelGGL(kern, dim3(a.B * a.zs * a.nt), dim3(64 * NW), bxb_lds_bytes(NW) + pad, s, a, ws, qb, db,
                      sf_cdiv(a.N, qt));
   SF_CHECK_LAUNCH();
   if (a.zs > 1) {

@@ -625,7 +625,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bx_kernel(const AttnArgs p, c
   // (v_exp 8, the others ~4.3 each), pinned by sched_barrier — the compiler's own order front-loads the softmax and
   // leaves the second product's MFMAs bare.  Worth 4 % (3.61 -> 3.48 ms at N = 25 088, B = 8): with two wavefronts per
   // SIMD the issue port is shared, and under this load the part holds ~1.6 GHz (20 ns per 32x32x16 MFMA).
+  unsigned long long st_acc[5] = {0, 0, 0, 0, 0};  // DBG & 64: cycles per phase (s_memtime), printed by one wavefront
   auto step_placed = [&](int vbuf, int sub, int kbuf_n, int sub_n) {
+    unsigned long long tq0 = 0, tq1 = 0, tq2 = 0, tq3 = 0;
+    if constexpr (DBG & 64) { __builtin_amdgcn_sched_barrier(0); tq0 = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
     constexpr int OA[6] = {0, 2, 1, 0, 1, 0}, OB[6] = {2, 0, 1, 1, 0, 0};  // mfma_split's order, small terms first
     f32x16 s = s_next;
     const unsigned short* krow = Ks + kbuf_n * 3 * KPL + (sub_n * 32 + li) * KP + 8 * lh;
@@ -677,6 +680,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bx_kernel(const AttnArgs p, c
     QK(9); SA(0, 3); SF_GAP();
     QK(10); SB(0, 3); SF_GAP();
     QK(11); E(9); E(10); E(11); SF_GAP();
+    if constexpr (DBG & 64) { tq1 = __builtin_amdgcn_s_memtime(); SF_GAP(); }
     PV(0); E(12); E(13); E(14); SF_GAP();
     PV(1); E(15); SA(1, 0); SF_GAP();
     PV(2); SB(1, 0); SF_GAP();
@@ -684,17 +688,28 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bx_kernel(const AttnArgs p, c
     PV(4); SB(1, 1); SF_GAP();
     PV(5); SA(1, 2); SF_GAP();
     SB(1, 2); SA(1, 3); SB(1, 3); SF_GAP();
+    if constexpr (DBG & 64) { tq2 = __builtin_amdgcn_s_memtime(); SF_GAP(); }
     PV(6); lacc[0] += s[0]; lacc[1] += s[1]; lacc[0] += s[2]; lacc[1] += s[3]; lacc[0] += s[4]; SF_GAP();
     PV(7); lacc[1] += s[5]; lacc[0] += s[6]; lacc[1] += s[7]; lacc[0] += s[8]; lacc[1] += s[9]; SF_GAP();
     PV(8); lacc[0] += s[10]; lacc[1] += s[11]; lacc[0] += s[12]; lacc[1] += s[13]; lacc[0] += s[14]; SF_GAP();
     PV(9); lacc[1] += s[15]; SF_GAP();
     PV(10); SF_GAP();
     PV(11); SF_GAP();
+    if constexpr (DBG & 64) {
+      tq3 = __builtin_amdgcn_s_memtime();
+      SF_GAP();
+      st_acc[0] += tq1 - tq0;
+      st_acc[1] += tq2 - tq1;
+      st_acc[2] += tq3 - tq2;
+      st_acc[3] += 1;
+    }
 #undef SF_GAP
   };
   using T = std::true_type;
   using F = std::false_type;
 
+  unsigned long long tl0 = 0, st_tile[6] = {0, 0, 0, 0, 0, 0};
+  if constexpr (DBG & 64) tl0 = __builtin_amdgcn_s_memtime();
   if (nt > 0) {
     load_k(t0);
     load_v(t0);
@@ -709,23 +724,48 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bx_kernel(const AttnArgs p, c
     for (int r = 0; r < nt; ++r) {
       const int t = t0 + r;
       const int knext = kcur == 2 ? 0 : kcur + 1, kafter = knext == 2 ? 0 : knext + 1;
+      unsigned long long u0 = 0, u1 = 0, u2 = 0, u3 = 0, u4 = 0, u5 = 0;
+      if constexpr (DBG & 64) u0 = __builtin_amdgcn_s_memtime();
       load_k(min(t + 2, n64 - 1));  // past the part's end: a tile nobody reads
       load_v(min(t + 1, n64 - 1));
+      if constexpr (DBG & 64) { __builtin_amdgcn_sched_barrier(0); u1 = __builtin_amdgcn_s_memtime(); }
       if constexpr (DBG & 32) step(T{}, r & 1, 0, kcur, 1); else step_placed(r & 1, 0, kcur, 1);
+      if constexpr (DBG & 64) { __builtin_amdgcn_sched_barrier(0); u2 = __builtin_amdgcn_s_memtime(); }
       check(t * KT + 32);
+      if constexpr (DBG & 64) { __builtin_amdgcn_sched_barrier(0); u3 = __builtin_amdgcn_s_memtime(); }
       if (r + 1 < nt) {
         if constexpr (DBG & 32) step(T{}, r & 1, 1, knext, 0); else step_placed(r & 1, 1, knext, 0);
         check(t * KT + 64);
       } else {
         step(F{}, r & 1, 1, 0, 0);
       }
+      if constexpr (DBG & 64) { __builtin_amdgcn_sched_barrier(0); u4 = __builtin_amdgcn_s_memtime(); }
       store_k(kafter);
       store_v((r + 1) & 1);
       __syncthreads();
+      if constexpr (DBG & 64) {
+        u5 = __builtin_amdgcn_s_memtime();
+        st_tile[0] += u1 - u0;  // loads issue
+        st_tile[1] += u2 - u1;  // step a
+        st_tile[2] += u3 - u2;  // check a
+        st_tile[3] += u4 - u3;  // step b + check b
+        st_tile[4] += u5 - u4;  // stores + barrier
+        st_tile[5] += 1;
+      }
       kcur = knext;
     }
   }
 
+  if constexpr (DBG & 64) {
+    st_acc[4] = __builtin_amdgcn_s_memtime() - tl0;
+    if (blockIdx.x == 7 && tid == 0)
+      printf("fwd_bx stamps (wave 0 of workgroup 7): steps %llu  per step: qk-phase %llu  pv0-phase %llu  pv1-phase %llu  | sweep total %llu = %llu per step\n",
+             st_acc[3], st_acc[0] / st_acc[3], st_acc[1] / st_acc[3], st_acc[2] / st_acc[3], st_acc[4], st_acc[4] / st_acc[3]);
+    if (blockIdx.x == 7 && tid == 0)
+      printf("fwd_bx per tile: loads %llu  step a %llu  check a %llu  step b + check %llu  stores + barrier %llu\n",
+             st_tile[0] / st_tile[5], st_tile[1] / st_tile[5], st_tile[2] / st_tile[5], st_tile[3] / st_tile[5],
+             st_tile[4] / st_tile[5]);
+  }
   const float l_run = lacc[0] + lacc[1];
   attn_fwd_finish<CP, 4>(p, o, m_run, l_run + __shfl_xor(l_run, 32, 64), b, bz, q0 + li, lh);
 }
@@ -983,14 +1023,15 @@ int launch(AttnArgs a, bool vec4, hipStream_t s) {
       static const Kern kern = [] {  // SF_ATTN_BX_DBG: timing ablations (see the kernel)
         const char* e = getenv("SF_ATTN_BX_DBG");
         const int dbg = e ? atoi(e) : 0;
-        return dbg == 1 ? (Kern)attn_fwd_bx_kernel<32, 1> : dbg == 32 ? (Kern)attn_fwd_bx_kernel<32, 32> : dbg == 4 ? (Kern)attn_fwd_bx_kernel<32, 4>
+        return dbg == 1 ? (Kern)attn_fwd_bx_kernel<32, 1> : dbg == 32 ? (Kern)attn_fwd_bx_kernel<32, 32> : dbg == 64 ? (Kern)attn_fwd_bx_kernel<32, 64> : dbg == 4 ? (Kern)attn_fwd_bx_kernel<32, 4>
                                                                       : (Kern)attn_fwd_bx_kernel<32, 0>;
       }();
+      static const int pad = [] { const char* e = getenv("SF_ATTN_BX_PADLDS"); return e ? atoi(e) : 0; }();  // occupancy probe
       static const bool attr_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                                       hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                      BX_LDS_BYTES) == hipSuccess;  // 72 KB of dynamic LDS
+                                                      BX_LDS_BYTES + pad) == hipSuccess;  // 72 KB of dynamic LDS
       if (!attr_ok) return SF_ELAUNCH;
-      hipLaunchKernelGGL(kern, dim3(grid), dim3(256), BX_LDS_BYTES, s, a, kb, vb, n64);
+      hipLaunchKernelGGL(kern, dim3(grid), dim3(256), BX_LDS_BYTES + pad, s, a, kb, vb, n64);
       SF_CHECK_LAUNCH();
       return a.zs > 1 ? sf_attn_fwd_merge(a, CP, s) : SF_OK;
     }
