@@ -519,19 +519,25 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bx_kernel(const AttnArgs p, c
   for (int r = 0; r < 16; ++r) negm[r] = -NEG_BIG;
 
   // ---- staging: a piece of a tile is 4 KB in either plane = one 16-byte element per thread
+  // (buffer loads: per-thread byte offset in a vector register once, the tile's offset as the scalar operand — no
+  // 64-bit address arithmetic per load; a clip's three planes are < 2^31 bytes)
   const long plane = (long)n64 * KT * 32;
-  const unsigned short* kg = kb + (long)b * 3 * plane + tid * 8;
-  const unsigned short* vg = vb + (long)b * 3 * plane + tid * 8;
+  const __amdgpu_buffer_rsrc_t k_rs =
+      __builtin_amdgcn_make_buffer_rsrc((void*)(kb + (long)b * 3 * plane), 0, (int)(3 * plane * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t v_rs =
+      __builtin_amdgcn_make_buffer_rsrc((void*)(vb + (long)b * 3 * plane), 0, (int)(3 * plane * 2), 0x00020000);
   const int ks_off = (tid >> 2) * KP + (tid & 3) * 8;
   const int vs_off = (tid >> 3) * VP + (tid & 7) * 8;
   u32x4 rk[3], rv[3];
   auto load_k = [&](int t) {
 #pragma unroll
-    for (int pc = 0; pc < 3; ++pc) rk[pc] = *reinterpret_cast<const u32x4*>(kg + pc * plane + (long)t * (KT * 32));
+    for (int pc = 0; pc < 3; ++pc)
+      rk[pc] = __builtin_amdgcn_raw_buffer_load_b128(k_rs, tid * 16 + pc * (int)(plane * 2), t * (KT * 32 * 2), 0);
   };
   auto load_v = [&](int t) {
 #pragma unroll
-    for (int pc = 0; pc < 3; ++pc) rv[pc] = *reinterpret_cast<const u32x4*>(vg + pc * plane + (long)t * (KT * 32));
+    for (int pc = 0; pc < 3; ++pc)
+      rv[pc] = __builtin_amdgcn_raw_buffer_load_b128(v_rs, tid * 16 + pc * (int)(plane * 2), t * (KT * 32 * 2), 0);
   };
   auto store_k = [&](int buf) {
 #pragma unroll
@@ -625,6 +631,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bx_kernel(const AttnArgs p, c
   // (v_exp 8, the others ~4.3 each), pinned by sched_barrier — the compiler's own order front-loads the softmax and
   // leaves the second product's MFMAs bare.  Worth 4 % (3.61 -> 3.48 ms at N = 25 088, B = 8): with two wavefronts per
   // SIMD the issue port is shared, and under this load the part holds ~1.6 GHz (20 ns per 32x32x16 MFMA).
+  float mx_next = 0.f;  // max of s_next over this lane's 16 keys, formed in the step's last MFMA gaps
+  auto check_placed = [&](int jbase) {
+    if (__any(mx_next > p.soft_t) || jbase + 32 > N) refresh(jbase);
+  };
   unsigned long long st_acc[5] = {0, 0, 0, 0, 0};  // DBG & 64: cycles per phase (s_memtime), printed by one wavefront
   auto step_placed = [&](int vbuf, int sub, int kbuf_n, int sub_n) {
     unsigned long long tq0 = 0, tq1 = 0, tq2 = 0, tq3 = 0;
@@ -692,9 +702,11 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bx_kernel(const AttnArgs p, c
     PV(6); lacc[0] += s[0]; lacc[1] += s[1]; lacc[0] += s[2]; lacc[1] += s[3]; lacc[0] += s[4]; SF_GAP();
     PV(7); lacc[1] += s[5]; lacc[0] += s[6]; lacc[1] += s[7]; lacc[0] += s[8]; lacc[1] += s[9]; SF_GAP();
     PV(8); lacc[0] += s[10]; lacc[1] += s[11]; lacc[0] += s[12]; lacc[1] += s[13]; lacc[0] += s[14]; SF_GAP();
-    PV(9); lacc[1] += s[15]; SF_GAP();
-    PV(10); SF_GAP();
-    PV(11); SF_GAP();
+    PV(9); lacc[1] += s[15]; mx_next = fmaxf(fmaxf(s_next[0], s_next[1]), s_next[2]);
+    mx_next = fmaxf(fmaxf(mx_next, s_next[3]), s_next[4]); mx_next = fmaxf(fmaxf(mx_next, s_next[5]), s_next[6]); SF_GAP();
+    PV(10); mx_next = fmaxf(fmaxf(mx_next, s_next[7]), s_next[8]); mx_next = fmaxf(fmaxf(mx_next, s_next[9]), s_next[10]);
+    mx_next = fmaxf(fmaxf(mx_next, s_next[11]), s_next[12]); SF_GAP();
+    PV(11); mx_next = fmaxf(fmaxf(mx_next, s_next[13]), s_next[14]); mx_next = fmaxf(mx_next, s_next[15]); SF_GAP();
     if constexpr (DBG & 64) {
       tq3 = __builtin_amdgcn_s_memtime();
       SF_GAP();
@@ -731,11 +743,11 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bx_kernel(const AttnArgs p, c
       if constexpr (DBG & 64) { __builtin_amdgcn_sched_barrier(0); u1 = __builtin_amdgcn_s_memtime(); }
       if constexpr (DBG & 32) step(T{}, r & 1, 0, kcur, 1); else step_placed(r & 1, 0, kcur, 1);
       if constexpr (DBG & 64) { __builtin_amdgcn_sched_barrier(0); u2 = __builtin_amdgcn_s_memtime(); }
-      check(t * KT + 32);
+      if constexpr (DBG & 32) check(t * KT + 32); else check_placed(t * KT + 32);
       if constexpr (DBG & 64) { __builtin_amdgcn_sched_barrier(0); u3 = __builtin_amdgcn_s_memtime(); }
       if (r + 1 < nt) {
         if constexpr (DBG & 32) step(T{}, r & 1, 1, knext, 0); else step_placed(r & 1, 1, knext, 0);
-        check(t * KT + 64);
+        if constexpr (DBG & 32) check(t * KT + 64); else check_placed(t * KT + 64);
       } else {
         step(F{}, r & 1, 1, 0, 0);
       }
