@@ -635,6 +635,40 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, int Cout, int Ci
   }
 }
 
+// The same for MANY weights in one launch (a training step re-packs every conv once: ~108 launches of ~6 us otherwise).
+// items[i] describes one weight; blk0[i] is its first workgroup (blk0[n] = grid size).
+struct PackItem {
+  const float* w;
+  float* wp;
+  float* wtp;
+  int Cout, Cin, taps, cin_pad, cout_pad, pad_;
+  long n_wp, total;
+};
+__global__ void pack_weights_batched_kernel(const PackItem* __restrict__ items, const int* __restrict__ blk0, int n) {
+  int lo = 0, hi = n;  // the item whose block range holds blockIdx.x
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (blk0[mid] <= (int)blockIdx.x) lo = mid; else hi = mid;
+  }
+  const PackItem it = items[lo];
+  const long idx = (long)((int)blockIdx.x - blk0[lo]) * TPB + threadIdx.x;
+  if (idx >= it.total) return;
+  if (idx < it.n_wp) {
+    const int c = (int)(idx % it.cin_pad);
+    const long r = idx / it.cin_pad;
+    const int tap = (int)(r % it.taps);
+    const int co = (int)(r / it.taps);
+    it.wp[idx] = c < it.Cin ? it.w[((long)co * it.Cin + c) * it.taps + tap] : 0.f;
+  } else {
+    const long j = idx - it.n_wp;
+    const int co = (int)(j % it.cout_pad);
+    const long r = j / it.cout_pad;
+    const int tap = (int)(r % it.taps);
+    const int ci = (int)(r / it.taps);
+    it.wtp[j] = co < it.Cout ? it.w[((long)co * it.Cin + ci) * it.taps + tap] : 0.f;
+  }
+}
+
 inline int pow2ceil(int v) {
   int p = 1;
   while (p < v) p <<= 1;
@@ -1014,6 +1048,14 @@ extern "C" int sf_pack_conv_weight(const float* w, int Cout, int Cin, int taps, 
   const long total = n_wp + (wtp ? (long)Cin * taps * cout_pad : 0);
   hipLaunchKernelGGL(pack_weight_kernel, dim3(sf_cdiv(total, TPB)), dim3(TPB), 0, (hipStream_t)stream, w, Cout, Cin,
                      taps, wp, cin_pad, wtp, cout_pad, n_wp, total);
+  SF_CHECK_LAUNCH();
+  return SF_OK;
+}
+
+extern "C" int sf_pack_conv_weights(const void* items, const int* blk0, int n, int nblocks, void* stream) {
+  if (!items || !blk0 || n <= 0 || nblocks <= 0) return SF_EINVAL;
+  hipLaunchKernelGGL(pack_weights_batched_kernel, dim3(nblocks), dim3(TPB), 0, (hipStream_t)stream,
+                     reinterpret_cast<const PackItem*>(items), blk0, n);
   SF_CHECK_LAUNCH();
   return SF_OK;
 }

@@ -54,7 +54,7 @@ EXPORTS = [
     "sf_attn_bwd_fused_ws_floats", "sf_attn_bwd_fused", "sf_pack_conv_weight", "sf_conv_fwd_ws_floats",
     "sf_conv_fwd_ws", "sf_attn_fwd_ws_floats", "sf_attn_fwd_ws", "sf_affine_fwd_mask", "sf_bn_bwd_apply_first", "sf_maxpool_bwd_first",
     "sf_conv_tune", "sf_conv_stats_ws_floats", "sf_conv_fwd_stats", "sf_bn_train_stats_merge",
-    "sf_attn_products_per_fp32",
+    "sf_attn_products_per_fp32", "sf_pack_conv_weights",
 ]
 _LONG_RET = ("sf_tmax_mean_ws_floats", "sf_channel_stats_ws_floats", "sf_bn_bwd_ws_floats",
              "sf_dwconv_wgrad_ws_floats", "sf_attn_bwd_fused_ws_floats", "sf_conv_fwd_ws_floats",
@@ -338,6 +338,43 @@ def pack_conv_weight_pair(w):
     _check(lib().sf_pack_conv_weight(_ptr(w), cout, cin, taps, _ptr(wp), cin_pad, _ptr(wtp), cout_pad, _stream()),
            "sf_pack_conv_weight")
     return wp, wtp
+
+
+_PACK_TABLES = {}
+
+
+def pack_conv_weight_pairs(weights, outs):
+    """pack_conv_weight_pair for many weights in ONE launch.  outs: per weight the (wp, wtp) tensors to fill (None =
+    allocate).  Returns the list of (wp, wtp).  The device-side table of pointers is cached per pointer set."""
+    import struct
+    import numpy as np
+    res, recs, blk0, nb = [], [], [0], 0
+    for w, o in zip(weights, outs):
+        _require_gpu(w, "pack_conv_weight_pairs")
+        assert w.is_contiguous() and w.dtype == torch.float32
+        cout, cin = w.shape[0], w.shape[1]
+        taps = w.shape[2] * w.shape[3] * w.shape[4]
+        cin_pad, cout_pad = (cin + 15) // 16 * 16, (cout + 15) // 16 * 16
+        if o is None or tuple(o[0].shape) != (cout, taps, cin_pad) or tuple(o[1].shape) != (cin, taps, cout_pad):
+            o = (torch.empty((cout, taps, cin_pad), dtype=torch.float32, device=w.device),
+                 torch.empty((cin, taps, cout_pad), dtype=torch.float32, device=w.device))
+        res.append(o)
+        n_wp = cout * taps * cin_pad
+        total = n_wp + cin * taps * cout_pad
+        recs.append((w.data_ptr(), o[0].data_ptr(), o[1].data_ptr(), cout, cin, taps, cin_pad, cout_pad, 0, n_wp, total))
+        nb += (total + 255) // 256
+        blk0.append(nb)
+    key = tuple(r[:3] for r in recs)
+    dev = weights[0].device
+    tab = _PACK_TABLES.get(dev)
+    if tab is None or tab[0] != key:
+        raw = b"".join(struct.pack("<QQQiiiiiiqq", *r) for r in recs)
+        items = torch.from_numpy(np.frombuffer(raw, dtype=np.uint8).copy()).to(dev)
+        starts = torch.tensor(blk0, dtype=torch.int32).to(dev)
+        tab = (key, items, starts)
+        _PACK_TABLES[dev] = tab
+    _check(lib().sf_pack_conv_weights(_ptr(tab[1]), _ptr(tab[2]), len(recs), nb, _stream()), "sf_pack_conv_weights")
+    return res
 
 
 def pack_dw_weight(w):

@@ -490,12 +490,47 @@ def norm_forward(bn, x):
     return leave([y])[0]
 
 
+import weakref
+
+_PAIR_WEIGHTS = {}  # id(weight) -> weakref of the dense conv weights that have been packed as a pair (tensors compare
+# elementwise, so no WeakSet): repack_all's candidates
+BATCHED_REPACK = os.environ.get("SF_BATCH_REPACK", "1") != "0"
+
+
 def _packed_pair(weight):
     """(forward, data-gradient) packed copies of a dense conv weight, built together by one kernel and cached per
-    parameter version (training re-packs every conv once per optimizer step)."""
+    parameter version (training re-packs every conv once per optimizer step — repack_all does that in one launch)."""
     if not weight.is_cuda:  # CPU construction / state_dict work: torch fallback for the forward layout only
         return sfhip.pack_conv_weight(weight), None
+    if id(weight) not in _PAIR_WEIGHTS:
+        wid = id(weight)
+        _PAIR_WEIGHTS[wid] = weakref.ref(weight, lambda _r, wid=wid: _PAIR_WEIGHTS.pop(wid, None))
     return _cached_t(weight, "_sf_wpair", _key(weight), lambda: sfhip.pack_conv_weight_pair(weight))
+
+
+def repack_all(model):
+    """Re-pack, in ONE launch, every dense conv weight of `model` whose packed pair is stale (after an optimizer step:
+    all of them — ~108 launches of ~6 us and 216 allocations otherwise).  The packed tensors are overwritten in place:
+    the previous step's kernels that read them were joined before the optimizer ran."""
+    if not BATCHED_REPACK:
+        return
+    cand = model.__dict__.get("_sf_pair_params")
+    if cand is None or cand[0] != len(_PAIR_WEIGHTS):
+        cand = (len(_PAIR_WEIGHTS), [p for p in model.parameters()
+                                     if id(p) in _PAIR_WEIGHTS and _PAIR_WEIGHTS[id(p)]() is p])
+        model.__dict__["_sf_pair_params"] = cand
+    stale, old = [], []
+    for w in cand[1]:
+        c = w.__dict__.get("_sf_cache", {}).get("_sf_wpair")
+        if c is not None and c[0] != _key(w) and w.is_cuda and w.is_contiguous():
+            stale.append(w)
+            old.append(c[1])
+    if len(stale) < 2:
+        return
+    with torch.no_grad():
+        new = sfhip.pack_conv_weight_pairs([w.detach() for w in stale], old)
+    for w, o in zip(stale, new):
+        w.__dict__["_sf_cache"]["_sf_wpair"] = (_key(w), o)
 
 
 def packed_weight(conv):
@@ -756,6 +791,7 @@ def run_model(model, x):
                                    "DistributedDataParallel's all-reduce depends on: switch the sink off, or use "
                                    "utils.distributed.FlatGradients on the unwrapped model")
             params = [p for p in model.parameters()]
+            repack_all(model)
             return TapedForward.apply(model, len(x), *x, *params)
         return model._forward_impl(x)
     finally:

@@ -102,6 +102,11 @@ int sf_conv_tune(int knob, int value);
  * wtp [Cin][taps][cout_pad] (the data-gradient order), zero padded, in one launch.                           */
 int sf_pack_conv_weight(const float* w, int Cout, int Cin, int taps, float* wp, int cin_pad, float* wtp,
                         int cout_pad, void* stream);
+/* The same for n weights in ONE launch (a training step re-packs every conv after the optimizer step).  items: device
+ * array of n records { const float* w; float* wp; float* wtp; int Cout, Cin, taps, cin_pad, cout_pad, pad; long n_wp
+ * (= Cout*taps*cin_pad), total (= n_wp + Cin*taps*cout_pad, or n_wp when wtp is NULL) } (64 bytes each); blk0: device
+ * array of n + 1 ints, blk0[i] = first 256-thread workgroup of weight i, blk0[n] = nblocks.                     */
+int sf_pack_conv_weights(const void* items, const int* blk0, int n, int nblocks, void* stream);
 
 /* ---- depthwise convolution (groups == channels) ----------------------------------------------
  * ghostnet_helper.py:88-90,114-120,137-143; shufflenetv2_helper.py:62-64,74-75,89-91.
