@@ -255,7 +255,7 @@ def _record_conv(x, conv_weight, conv_bias, wp_shape, gsrc, kernel, stride, padd
     def bwd():
         g = gsrc() if callable(gsrc) else gsrc
         dev = x.buf.device
-        if OVERLAP_PATHS and not t.serial and x_needs_grad and dev.type == "cuda":
+        if OVERLAP_PATHS and WGRAD_COMPANION and not t.serial and x_needs_grad and dev.type == "cuda":
             # the weight gradient only feeds the parameter's .grad: issue it on a companion stream so that it
             # overlaps the data gradient (both are short-grid GEMMs on the res4 / res5 layers); joined by
             # Tape.backward before the gradients are handed back
@@ -495,6 +495,7 @@ import weakref
 _PAIR_WEIGHTS = {}  # id(weight) -> weakref of the dense conv weights that have been packed as a pair (tensors compare
 # elementwise, so no WeakSet): repack_all's candidates
 BATCHED_REPACK = os.environ.get("SF_BATCH_REPACK", "1") != "0"
+WGRAD_COMPANION = os.environ.get("SF_WGRAD_COMPANION", "1") != "0"  # weight gradients on a companion stream
 
 
 def _packed_pair(weight):
