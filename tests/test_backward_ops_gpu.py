@@ -578,3 +578,25 @@ def test_gather_add_is_the_adjoint_of_the_shuffled_store():
     sfhip.gather_add(sfhip.Act(wide.buf, 3, 21), 2, back, accumulate=True)
     torch.cuda.synchronize()
     assert torch.equal(back.buf.cpu(), x + 1)
+
+
+@pytest.mark.gpu
+def test_batched_weight_repack_matches_per_weight_pack():
+    """engine.repack_all's single launch (sf_pack_conv_weights over a device table) == sf_pack_conv_weight per weight,
+    bit for bit, incl. in-place reuse of the previous packed buffers and odd channel counts (zero padding)."""
+    import sfhip
+    g = torch.Generator().manual_seed(5)
+    shapes = [(64, 24, 1, 3, 3), (8, 32, 3, 1, 1), (256, 64, 1, 1, 1), (20, 12, 5, 7, 1), (512, 128, 3, 1, 1)]
+    ws = [torch.randn(*s, generator=g).to(_dev()) for s in shapes]
+    ref = [sfhip.pack_conv_weight_pair(w) for w in ws]
+    got = sfhip.pack_conv_weight_pairs(ws, [None] * len(ws))
+    for (rp, rt), (gp, gt) in zip(ref, got):
+        assert torch.equal(rp, gp) and torch.equal(rt, gt)
+    ws2 = [w * 1.5 + 0.25 for w in ws]  # new values, same buffers: the cached pointer table is keyed on the pointers
+    for w, w2 in zip(ws, ws2):
+        w.copy_(w2)
+    again = sfhip.pack_conv_weight_pairs(ws, got)
+    for w, (gp, gt), (ap, at) in zip(ws, got, again):
+        assert ap.data_ptr() == gp.data_ptr() and at.data_ptr() == gt.data_ptr()
+        rp, rt = sfhip.pack_conv_weight_pair(w)
+        assert torch.equal(rp, ap) and torch.equal(rt, at)
