@@ -889,6 +889,278 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void attn_bwd_bx_kernel(const BwdA
   }
 }
 
+// ---------------------------------------------------------------------------------------------- fused, bf16 pieces, d <= 64
+// attn_bwd_bx_kernel for 33..64 channels: the channels are two 32-wide BLOCKS, each with its own plane set (the split
+// launch runs once per block), K' / V / K register operands, dK^T / dV^T accumulators and dQ column tile; S' and dP
+// sum over both blocks' k-steps.  24 + 24 + 24 + 24 + 24 = 120 MFMAs per 32 x 32 block of the score matrix.  The
+// register operands alone are 144 VGPRs, so this form runs one wavefront per SIMD (one 256-thread workgroup per CU,
+// 125 KB of LDS: two blocks' images + four 16 KB dQ slots).
+constexpr int BXB2_LDS_BYTES = 2 * 6 * BXB_PL * 2 + 2 * BXB_QT * 4 + 4 * BXB_QT * 64 * 4;
+__global__ __launch_bounds__(256, 1) void attn_bwd_bx2_kernel(const BwdArgs p, float* __restrict__ ws,
+                                                              const unsigned short* __restrict__ qb,
+                                                              const unsigned short* __restrict__ db, int n64,
+                                                              long blk_elems) {
+  constexpr int CP = 64, NW = 4, QT = BXB_QT, KP = BX_KP, PL = BXB_PL, TP = BXB_TP;
+  constexpr int SLOT = QT * CP;
+  extern __shared__ __attribute__((aligned(16))) unsigned short bxb_smem[];
+  unsigned short* const tile = bxb_smem;                                  // [block][Q pieces 0..2, dO pieces 3..5][QT][KP]
+  float* const lsd = reinterpret_cast<float*>(bxb_smem + 2 * 6 * PL);
+  float* const slots = lsd + 2 * QT;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int bz = blockIdx.x / p.nt;
+  const int kb = blockIdx.x - bz * p.nt;
+  const int b = bz / p.zs, z = bz - b * p.zs;
+  const int j0 = kb * (32 * NW) + wave * 32;
+  const int N = p.N, C = p.C;
+  const long brow = (long)b * N;
+  const float gamma = p.gamma[0];
+  float* const myslot = slots + wave * SLOT;
+  unsigned short* const img = reinterpret_cast<unsigned short*>(myslot);  // [piece][key 32][TP]
+
+  u32x4 kfb[2][2][3], vfb[2][2][3], kbr[2][2][3];
+  const int jrow = j0 + li;
+  const bool jok = jrow < N;
+  {
+    const float* kp = p.k + (brow + (jok ? jrow : 0)) * p.k_cs + 8 * lh;
+    const float* vp = p.v + (brow + (jok ? jrow : 0)) * p.v_cs + 8 * lh;
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        const int ch = 32 * blk + 16 * c + 8 * lh;
+        f32x4 k0 = {0.f, 0.f, 0.f, 0.f}, k1 = k0, v0 = k0, v1 = k0;
+        if (jok && ch < C) {
+          k0 = *reinterpret_cast<const f32x4*>(kp + 32 * blk + 16 * c);
+          v0 = *reinterpret_cast<const f32x4*>(vp + 32 * blk + 16 * c);
+        }
+        if (jok && ch + 4 < C) {
+          k1 = *reinterpret_cast<const f32x4*>(kp + 32 * blk + 16 * c + 4);
+          v1 = *reinterpret_cast<const f32x4*>(vp + 32 * blk + 16 * c + 4);
+        }
+        k0 *= LOG2E;
+        k1 *= LOG2E;
+        split_pair(k0[0], k0[1], kfb[blk][c], 0);
+        split_pair(k0[2], k0[3], kfb[blk][c], 1);
+        split_pair(k1[0], k1[1], kfb[blk][c], 2);
+        split_pair(k1[2], k1[3], kfb[blk][c], 3);
+        split_pair(v0[0], v0[1], vfb[blk][c], 0);
+        split_pair(v0[2], v0[3], vfb[blk][c], 1);
+        split_pair(v1[0], v1[1], vfb[blk][c], 2);
+        split_pair(v1[2], v1[3], vfb[blk][c], 3);
+      }
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        float kv[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int key = j0 + 16 * m + 8 * lh + e;
+          kv[e] = (key < N && 32 * blk + li < C) ? p.k[(brow + key) * p.k_cs + 32 * blk + li] : 0.f;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) split_pair(kv[2 * e], kv[2 * e + 1], kbr[blk][m], e);
+      }
+  }
+  f32x16 dk[2], dv[2];
+#pragma unroll
+  for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { dk[blk][r] = 0.f; dv[blk][r] = 0.f; }
+
+  // ---- staging: per block and piece 4 KB of each plane = one 16-byte element per thread
+  const long plane = (long)n64 * QT * 32;
+  const unsigned short* qg = qb + (long)b * 3 * plane + tid * 8;
+  const unsigned short* dg = db + (long)b * 3 * plane + tid * 8;
+  const int st_off = (tid >> 2) * KP + (tid & 3) * 8;
+  u32x4 rq[2][3], rd[2][3];
+  float rl = 0.f, rD = 0.f;
+  auto load_tile = [&](int t) {
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+      for (int pc = 0; pc < 3; ++pc) {
+        rq[blk][pc] = *reinterpret_cast<const u32x4*>(qg + blk * blk_elems + pc * plane + (long)t * (QT * 32));
+        rd[blk][pc] = *reinterpret_cast<const u32x4*>(dg + blk * blk_elems + pc * plane + (long)t * (QT * 32));
+      }
+    if (tid < QT) {
+      const int i = t * QT + tid;
+      rl = (i < N) ? -p.lse[brow + i] : -POS_BIG;
+      rD = (i < N) ? -p.dvec[brow + i] * gamma : 0.f;
+    }
+  };
+  auto store_tile = [&]() {
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+      for (int pc = 0; pc < 3; ++pc) {
+        *reinterpret_cast<u32x4*>(tile + (blk * 6 + pc) * PL + st_off) = rq[blk][pc];
+        *reinterpret_cast<u32x4*>(tile + (blk * 6 + 3 + pc) * PL + st_off) = rd[blk][pc];
+      }
+    if (tid < QT) {
+      lsd[tid] = rl;
+      lsd[QT + tid] = rD;
+    }
+  };
+  const int tr_row = (lane & 15) >> 2, tr_col = 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+
+  const int nq = (N + QT - 1) / QT;
+  const int tz = (nq + p.zs - 1) / p.zs;
+  const int t0 = z * tz;
+  const int ntiles = min(nq, t0 + tz);
+  if (t0 < ntiles) {
+    load_tile(t0);
+    store_tile();
+  }
+  __syncthreads();
+  for (int t = t0; t < ntiles; ++t) {
+    const bool more = (t + 1) < ntiles;
+    if (more) load_tile(t + 1);
+    f32x16 dqp[2][2];
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub) {
+#pragma unroll
+      for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dqp[sub][blk][r] = 0.f;
+      if (t * QT + sub * 32 >= N) continue;  // wave-uniform
+      f32x16 s, dp;
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const f32x4 l4 = *reinterpret_cast<const f32x4*>(lsd + sub * 32 + 8 * g4 + 4 * lh);
+        const f32x4 d4 = *reinterpret_cast<const f32x4*>(lsd + QT + sub * 32 + 8 * g4 + 4 * lh);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          s[4 * g4 + e] = l4[e];
+          dp[4 * g4 + e] = d4[e];
+        }
+      }
+#pragma unroll
+      for (int blk = 0; blk < 2; ++blk) {
+        const unsigned short* rowp = tile + blk * 6 * PL + (sub * 32 + li) * KP + 8 * lh;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          u32x4 qa[3], da[3];
+#pragma unroll
+          for (int pc = 0; pc < 3; ++pc) {
+            qa[pc] = *reinterpret_cast<const u32x4*>(rowp + pc * PL + 16 * c);
+            da[pc] = *reinterpret_cast<const u32x4*>(rowp + (3 + pc) * PL + 16 * c);
+          }
+          s = mfma_split(qa, kfb[blk][c], s);
+          dp = mfma_split(da, vfb[blk][c], dp);
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[r] = __builtin_amdgcn_exp2f(s[r]);  // P
+      {
+        u32x4 pf[2][3];
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) split_pair(s[8 * m + 2 * e], s[8 * m + 2 * e + 1], pf[m], e);
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk) {
+          const unsigned short* colp = tile + blk * 6 * PL + (sub * 32 + 4 * lh + tr_row) * KP + tr_col;
+#pragma unroll
+          for (int m = 0; m < 2; ++m) {
+            u32x4 a[3];
+#pragma unroll
+            for (int pc = 0; pc < 3; ++pc) {
+              const u32x2 lo = lds_read_tr(colp + (3 + pc) * PL + (16 * m) * KP);
+              const u32x2 hi = lds_read_tr(colp + (3 + pc) * PL + (16 * m + 8) * KP);
+              a[pc] = (u32x4){lo[0], lo[1], hi[0], hi[1]};
+            }
+            dv[blk] = mfma_split(a, pf[m], dv[blk]);
+          }
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[r] *= dp[r];  // dS
+      u32x4 sf[2][3];
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) split_pair(s[8 * m + 2 * e], s[8 * m + 2 * e + 1], sf[m], e);
+#pragma unroll
+      for (int blk = 0; blk < 2; ++blk) {
+        const unsigned short* colp = tile + blk * 6 * PL + (sub * 32 + 4 * lh + tr_row) * KP + tr_col;
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+          u32x4 a[3];
+#pragma unroll
+          for (int pc = 0; pc < 3; ++pc) {
+            const u32x2 lo = lds_read_tr(colp + pc * PL + (16 * m) * KP);
+            const u32x2 hi = lds_read_tr(colp + pc * PL + (16 * m + 8) * KP);
+            a[pc] = (u32x4){lo[0], lo[1], hi[0], hi[1]};
+          }
+          dk[blk] = mfma_split(a, sf[m], dk[blk]);
+        }
+      }
+#pragma unroll
+      for (int pc = 0; pc < 3; ++pc)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          *reinterpret_cast<u32x2*>(img + (pc * 32 + li) * TP + 8 * g + 4 * lh) =
+              (u32x2){sf[g >> 1][pc][2 * (g & 1)], sf[g >> 1][pc][2 * (g & 1) + 1]};
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      const unsigned short* imgp = img + (8 * lh + tr_row) * TP + tr_col;
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        u32x4 a[3];
+#pragma unroll
+        for (int pc = 0; pc < 3; ++pc) {
+          const u32x2 lo = lds_read_tr(imgp + (pc * 32 + 16 * m) * TP);
+          const u32x2 hi = lds_read_tr(imgp + (pc * 32 + 16 * m + 4) * TP);
+          a[pc] = (u32x4){lo[0], lo[1], hi[0], hi[1]};
+        }
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk) dqp[sub][blk] = mfma_split(a, kbr[blk][m], dqp[sub][blk]);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+      for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) myslot[(sub * 32 + kappa(r, lh)) * CP + 32 * blk + li] = dqp[sub][blk][r];
+    __syncthreads();
+    if (more) store_tile();
+    for (int e0 = tid * 4; e0 < SLOT; e0 += 256 * 4) {
+      f32x4 v = *reinterpret_cast<const f32x4*>(slots + e0);
+#pragma unroll
+      for (int w = 1; w < NW; ++w) v += *reinterpret_cast<const f32x4*>(slots + w * SLOT + e0);
+      *reinterpret_cast<f32x4*>(ws + ((((long)b * nq + t) * p.nt + kb) * (long)SLOT) + e0) = v;
+    }
+    __syncthreads();
+  }
+  if (!jok) return;
+  float* okp;
+  float* ovp;
+  if (p.zs > 1) {
+    okp = p.dkp + ((long)bz * N + jrow) * CP;
+    ovp = p.dvp + ((long)bz * N + jrow) * CP;
+  } else {
+    okp = p.dk + (brow + jrow) * p.dk_cs;
+    ovp = p.dv + (brow + jrow) * p.dv_cs;
+  }
+#pragma unroll
+  for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+    for (int r = 0; r < 16; r += 4) {
+      const int c = 32 * blk + 8 * (r >> 2) + 4 * lh;
+      if (p.zs > 1 || c < C) {
+        *reinterpret_cast<f32x4*>(okp + c) = (f32x4){dk[blk][r], dk[blk][r + 1], dk[blk][r + 2], dk[blk][r + 3]};
+        *reinterpret_cast<f32x4*>(ovp + c) = (f32x4){dv[blk][r], dv[blk][r + 1], dv[blk][r + 2], dv[blk][r + 3]};
+      }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------- fused, packed planes
 // The sweep above for C <= 8 on packed planes (attn_bx.h): one 32-column plane per operand holds the three pieces of
 // its 8 channels.  S' and dP are three MFMAs each ([q1|q1][k1|k2], [q2|q2][k1|k2], [q1|q3][k3|k1]); dV^T, dK^T and dQ
@@ -1326,6 +1598,45 @@ int launch_fused_bxp(BwdArgs a, float* ws, float* bx_ws, hipStream_t s) {
   return SF_OK;
 }
 
+// 33 <= C <= 64 on bf16 pieces: two 32-channel blocks (see attn_bwd_bx2_kernel)
+int launch_fused_bx2(BwdArgs a, float* ws, float* bx_ws, hipStream_t s) {
+  constexpr int CP = 64, NW = 4, qt = BXB_QT;
+  a.nt = sf_cdiv(a.N, 32 * NW);
+  a.zs = sf_sweep_parts((long)a.B * a.nt, sf_cdiv(a.N, qt));
+  const long planes = (long)a.B * a.nt * sf_cdiv(a.N, qt) * qt * CP, part = (long)a.B * a.zs * a.N * CP;
+  a.dkp = ws + planes;
+  a.dvp = a.dkp + part;
+  const long blk_elems = sf_attn_bx_plane_elems(a.B, a.N);
+  unsigned short* qb = reinterpret_cast<unsigned short*>(bx_ws);
+  unsigned short* db = qb + 2 * blk_elems;
+  int rc = SF_OK;
+  for (int blk = 0; blk < 2 && rc == SF_OK; ++blk) {
+    rc = sf_attn_bx_split(a.q + 32 * blk, a.q_cs, nullptr, a.B, a.N, a.C - 32 * blk > 32 ? 32 : a.C - 32 * blk,
+                          qb + blk * blk_elems, nullptr, s);
+    if (rc == SF_OK)
+      rc = sf_attn_bx_split(a.dz + 32 * blk, a.dz_cs, a.gamma, a.B, a.N, a.C - 32 * blk > 32 ? 32 : a.C - 32 * blk,
+                            db + blk * blk_elems, nullptr, s);
+  }
+  if (rc != SF_OK) return rc;
+  static const bool attr_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_bx2_kernel),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                  BXB2_LDS_BYTES) == hipSuccess;
+  if (!attr_ok) return SF_ELAUNCH;
+  hipLaunchKernelGGL(attn_bwd_bx2_kernel, dim3(a.B * a.zs * a.nt), dim3(256), BXB2_LDS_BYTES, s, a, ws, qb, db,
+                     sf_cdiv(a.N, qt), blk_elems);
+  SF_CHECK_LAUNCH();
+  if (a.zs > 1) {
+    rc = sf_attn_dq_reduce(a.dkp, a.dk, a.dk_cs, a.B, a.N, a.C, CP, a.zs, s);
+    if (rc == SF_OK) rc = sf_attn_dq_reduce(a.dvp, a.dv, a.dv_cs, a.B, a.N, a.C, CP, a.zs, s);
+    if (rc != SF_OK) return rc;
+  }
+  const long total = (long)a.B * a.N * (CP / 4);
+  hipLaunchKernelGGL(attn_dq_reduce_tiled_kernel, dim3(sf_cdiv(total, 256)), dim3(256), 0, s, ws, a.dq, a.dq_cs, a.B,
+                     a.N, a.C, CP, a.nt, qt);
+  SF_CHECK_LAUNCH();
+  return SF_OK;
+}
+
 template <int CP>
 int launch(const BwdArgs& a, int which, hipStream_t s) {
   const int grid = a.B * a.zs * a.nt;
@@ -1387,6 +1698,7 @@ extern "C" long sf_attn_bwd_fused_ws_floats(int B, int N, int C) {
   long n = (long)B * (sf_cdiv(N, keys) * nr + 2L * SF_SWEEP_PARTS_MAX * N) * cp;
   if (cp == 32) n += sf_attn_bx_plane_elems(B, N);  // Q and gamma dz as three bf16 row planes each (2 x 2 B = 1 float)
   if (cp == 8) n += sf_attn_bx_packed_elems(B, N);  // Q and gamma dz as one packed plane each
+  if (cp == 64) n += 2 * sf_attn_bx_plane_elems(B, N);  // two 32-channel blocks of Q and gamma dz planes
   return n;
 }
 
@@ -1449,6 +1761,15 @@ extern "C" int sf_attn_bwd_fused(const float* q, int q_cs, const float* k, int k
                   : launch_fused_bx<4>(a, ws, bx_ws, (hipStream_t)stream);
     }
     return launch_fused<32, FUSED_KEYS_32 / 32>(a, ws, (hipStream_t)stream);
+  }
+  {
+    const bool vec4 = (C % 4 == 0) && (q_cs % 4 == 0) && (k_cs % 4 == 0) && (v_cs % 4 == 0) && (dz_cs % 4 == 0) &&
+                      (dk_cs % 4 == 0) && (dv_cs % 4 == 0) && sf_aligned16(q) && sf_aligned16(k) && sf_aligned16(v) &&
+                      sf_aligned16(dz) && sf_aligned16(dk) && sf_aligned16(dv);
+    static const bool bx64 = [] { const char* e = getenv("SF_ATTN_BX64"); return !(e && e[0] == '0'); }();
+    if (vec4 && bx64 && sf_attn_bx_level() >= 1)
+      return launch_fused_bx2(a, ws, ws + (sf_attn_bwd_fused_ws_floats(B, N, C) - 2 * sf_attn_bx_plane_elems(B, N)),
+                              (hipStream_t)stream);
   }
   return launch_fused<64, 4>(a, ws, (hipStream_t)stream);
 }

@@ -127,6 +127,7 @@ def test_launch_planning_queries_are_host_only_and_fill_the_chip():
     assert L.sf_attn_bwd_fused_ws_floats(B, N, 32) == B * (N // 128 + 16) * N * 32 + planes
     assert L.sf_attn_bwd_fused_ws_floats(B, N, 8) == B * (N // 64 + 16) * N * 8 + B * N * 32  # + packed planes (d <= 8)
     assert L.sf_attn_bwd_fused_ws_floats(B, N, 128) == 0                       # d = 128 keeps the two-kernel form
+    assert L.sf_attn_bwd_fused_ws_floats(B, N, 64) == B * (N // 128 + 16) * N * 64 + 2 * planes  # two channel blocks
     assert L.sf_attn_fwd_ws_floats(B, N, 32) == B * 8 * N * 34 + planes
     assert L.sf_attn_fwd_ws_floats(B, N, 64) == B * 8 * N * 66
     assert L.sf_attn_fwd_ws_floats(B, N, 8) == B * 8 * N * 10 + B * N * 32
