@@ -591,8 +591,8 @@ def main():
                        "mode": "train step: train-mode forward + CE + backward + 1 flat-gradient all-reduce + SGD"
                        if train else "eval forward (inference)",
                        "clips_per_gpu": batch, "global_batch": batch * world, "layout": "NCTHW in, NDHWC inside",
-                       "arithmetic": "fp32 tensors, fp32 accumulation everywhere; convs and d >= 64 attention on "
-                                     "v_mfma_f32_*_f32; attention products of head widths 17..32 and 8 as exact "
+                       "arithmetic": "fp32 tensors, fp32 accumulation everywhere; convs and d = 128 attention on "
+                                     "v_mfma_f32_*_f32; attention products of head widths 17..64 and 8 as exact "
                                      "three-way bf16 splits, six v_mfma_f32_32x32x16_bf16 per fp32 product "
                                      "(fp32-level results: DESIGN 6a-4)"
                        if sfhip.lib().sf_attn_products_per_fp32(32) == 6 else "fp32 (v_mfma_f32_*_f32)",

@@ -965,6 +965,220 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bxp_kernel(const AttnArgs p, 
   attn_fwd_finish<8, 4>(p, of, m_run, l_run + __shfl_xor(l_run, 32, 64), b, bz, q0 + li, lh);
 }
 
+// ---- 33 <= C <= 64: two 32-channel blocks -----------------------------------------------------------------------------
+// attn_fwd_bx_kernel with the channels as two 32-wide blocks, each with its own K / V^T plane set (the split launches
+// run once per block), Q pieces and O^T accumulator tile; S^T sums over both blocks' k-steps.  48 MFMAs per 32-key
+// block.  The operands take ~290 registers and the planes 147 KB of LDS: one workgroup per CU, one wavefront per SIMD;
+// the same software pipeline over 32-key blocks, in the compiler's instruction order.
+constexpr int BX2_LDS_BYTES = 2 * (3 * 3 * BX_KPL + 2 * 3 * BX_VPL) * 2;
+__global__ __launch_bounds__(256, 1) void attn_fwd_bx2_kernel(const AttnArgs p, const unsigned short* kb,
+                                                              const unsigned short* vb, int n64, long blk_elems) {
+  constexpr int KT = BX_KT, KP = BX_KP, VP = BX_VP, KPL = BX_KPL, VPL = BX_VPL;
+  extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
+  unsigned short* const Ks = smem;                     // [3 buffers][block][piece][key][KP]
+  unsigned short* const Vs = smem + 3 * 2 * 3 * KPL;   // [2 buffers][block][piece][channel][VP]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int li = lane & 31;
+  const int lh = lane >> 5;
+  const int bz = blockIdx.x / p.nqt;
+  const int b = bz / p.zs, z = bz - b * p.zs;
+  const int q0 = (blockIdx.x - bz * p.nqt) * 128 + wave * 32;
+  const int N = p.N;
+  const long brow = (long)b * N;
+
+  u32x4 qf[2][2][3];  // [block][k-step][piece]
+  {
+    const int qrow = q0 + li;
+    const float* qp = p.q + (brow + (qrow < N ? qrow : 0)) * p.q_cs + 8 * lh;
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        const int ch = 32 * blk + 16 * c + 8 * lh;
+        f32x4 t0 = {0.f, 0.f, 0.f, 0.f}, t1 = t0;
+        if (qrow < N) {
+          if (ch < p.C) t0 = *reinterpret_cast<const f32x4*>(qp + 32 * blk + 16 * c);
+          if (ch + 4 < p.C) t1 = *reinterpret_cast<const f32x4*>(qp + 32 * blk + 16 * c + 4);
+        }
+        t0 *= LOG2E;
+        t1 *= LOG2E;
+        split_pair(t0[0], t0[1], qf[blk][c], 0);
+        split_pair(t0[2], t0[3], qf[blk][c], 1);
+        split_pair(t1[0], t1[1], qf[blk][c], 2);
+        split_pair(t1[2], t1[3], qf[blk][c], 3);
+      }
+  }
+
+  f32x16 o[2];
+#pragma unroll
+  for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[blk][r] = 0.f;
+  float m_run = NEG_BIG;
+  f32x2 lacc = {0.f, 0.f};
+  f32x16 negm;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) negm[r] = -NEG_BIG;
+
+  const long plane = (long)n64 * KT * 32;
+  const unsigned short* kg = kb + (long)b * 3 * plane + tid * 8;
+  const unsigned short* vg = vb + (long)b * 3 * plane + tid * 8;
+  const int ks_off = (tid >> 2) * KP + (tid & 3) * 8;
+  const int vs_off = (tid >> 3) * VP + (tid & 7) * 8;
+  u32x4 rk[2][3], rv[2][3];
+  auto load_k = [&](int t) {
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+      for (int pc = 0; pc < 3; ++pc)
+        rk[blk][pc] = *reinterpret_cast<const u32x4*>(kg + blk * blk_elems + pc * plane + (long)t * (KT * 32));
+  };
+  auto load_v = [&](int t) {
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+      for (int pc = 0; pc < 3; ++pc)
+        rv[blk][pc] = *reinterpret_cast<const u32x4*>(vg + blk * blk_elems + pc * plane + (long)t * (KT * 32));
+  };
+  auto store_k = [&](int buf) {
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+      for (int pc = 0; pc < 3; ++pc) *reinterpret_cast<u32x4*>(Ks + ((buf * 2 + blk) * 3 + pc) * KPL + ks_off) = rk[blk][pc];
+  };
+  auto store_v = [&](int buf) {
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+      for (int pc = 0; pc < 3; ++pc) *reinterpret_cast<u32x4*>(Vs + ((buf * 2 + blk) * 3 + pc) * VPL + vs_off) = rv[blk][pc];
+  };
+
+  const int tz = (n64 + p.zs - 1) / p.zs;
+  const int t0 = z * tz;
+  const int nt = min(n64, t0 + tz) - t0;
+
+  f32x16 s_next;
+  u32x4 kf[2][2][3];
+  auto qk_all = [&](f32x16 c) {
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+      for (int cc = 0; cc < 2; ++cc) c = mfma_split(kf[blk][cc], qf[blk][cc], c);
+    return c;
+  };
+  auto qk = [&](int kbuf, int sub) {
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk) {
+      const unsigned short* krow = Ks + (kbuf * 2 + blk) * 3 * KPL + (sub * 32 + li) * KP + 8 * lh;
+#pragma unroll
+      for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+        for (int pc = 0; pc < 3; ++pc) kf[blk][cc][pc] = *reinterpret_cast<const u32x4*>(krow + pc * KPL + 16 * cc);
+    }
+    s_next = qk_all(negm);
+  };
+  auto refresh = [&](int jbase) {  // see attn_fwd_bx_kernel
+    f32x16 s;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s[r] = 0.f;
+    s = qk_all(s);
+    if (jbase + 32 > N) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        if (jbase + (r & 3) + 8 * (r >> 2) + 4 * lh >= N) s[r] = NEG_BIG;
+    }
+    float mloc = s[0];
+#pragma unroll
+    for (int r = 1; r < 16; ++r) mloc = fmaxf(mloc, s[r]);
+    mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+    const float mnew = fmaxf(m_run, mloc);
+    const float alpha = __builtin_amdgcn_exp2f(m_run - mnew);
+    lacc *= alpha;
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[blk][r] *= alpha;
+    m_run = mnew;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      negm[r] = -mnew;
+      s_next[r] = s[r] - mnew;
+    }
+  };
+  auto check = [&](int jbase) {
+    float mx = fmaxf(fmaxf(s_next[0], s_next[1]), s_next[2]);
+#pragma unroll
+    for (int r = 3; r < 15; r += 2) mx = fmaxf(fmaxf(mx, s_next[r]), s_next[r + 1]);
+    mx = fmaxf(mx, s_next[15]);
+    if (__any(mx > p.soft_t) || jbase + 32 > N) refresh(jbase);
+  };
+  auto step = [&](auto HAS_NEXT, int vbuf, int sub, int kbuf_n, int sub_n) {
+    f32x16 s = s_next;
+    if constexpr (decltype(HAS_NEXT)::value) qk(kbuf_n, sub_n);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s[r] = __builtin_amdgcn_exp2f(s[r]);
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) {
+      lacc[0] += s[r];
+      lacc[1] += s[r + 1];
+    }
+    u32x4 pf[2][3];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) split_pair(s[8 * m + 2 * e], s[8 * m + 2 * e + 1], pf[m], e);
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk) {
+      const unsigned short* vrow = Vs + (vbuf * 2 + blk) * 3 * VPL + li * VP + sub * 32 + 8 * lh;
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        u32x4 vf[3];
+#pragma unroll
+        for (int pc = 0; pc < 3; ++pc) vf[pc] = *reinterpret_cast<const u32x4*>(vrow + pc * VPL + 16 * m);
+        o[blk] = mfma_split(vf, pf[m], o[blk]);
+      }
+    }
+  };
+  using T = std::true_type;
+  using F = std::false_type;
+
+  if (nt > 0) {
+    load_k(t0);
+    load_v(t0);
+    store_k(0);
+    store_v(0);
+    load_k(min(t0 + 1, n64 - 1));
+    store_k(1);
+    __syncthreads();
+    qk(0, 0);
+    check(t0 * KT);
+    int kcur = 0;
+    for (int r = 0; r < nt; ++r) {
+      const int t = t0 + r;
+      const int knext = kcur == 2 ? 0 : kcur + 1, kafter = knext == 2 ? 0 : knext + 1;
+      load_k(min(t + 2, n64 - 1));
+      load_v(min(t + 1, n64 - 1));
+      step(T{}, r & 1, 0, kcur, 1);
+      check(t * KT + 32);
+      if (r + 1 < nt) {
+        step(T{}, r & 1, 1, knext, 0);
+        check(t * KT + 64);
+      } else {
+        step(F{}, r & 1, 1, 0, 0);
+      }
+      store_k(kafter);
+      store_v((r + 1) & 1);
+      __syncthreads();
+      kcur = knext;
+    }
+  }
+  const float l_run = lacc[0] + lacc[1];
+  attn_fwd_finish<64, 4>(p, o, m_run, l_run + __shfl_xor(l_run, 32, 64), b, bz, q0 + li, lh);
+}
+
 // One thread per (query row, 4 channels): O = sum_z o_z 2^(m_z - m) / sum_z l_z 2^(m_z - m), m = max_z m_z, then the
 // same epilogue as above.  An empty part carries (m, l, o) = (-BIG, 0, 0) and drops out with weight 0.
 __global__ __launch_bounds__(256) void attn_fwd_merge_kernel(const AttnArgs p, int cp) {
@@ -1023,6 +1237,28 @@ int launch(AttnArgs a, bool vec4, hipStream_t s) {
   static const bool stale_on = [] { const char* e = getenv("SF_ATTN_STALE"); return !(e && e[0] == '0'); }();
   a.soft_t = sf_attn_soft_t();
   const bool stale = stale_on && CP <= 64;  // d = 128: the 16 extra registers cost the second wavefront per SIMD
+  if constexpr (CP == 64) {
+    static const bool bx64 = [] { const char* e = getenv("SF_ATTN_BX64"); return !(e && e[0] == '0'); }();
+    if (vec4 && a.bx_planes && bx64) {
+      const int n64 = sf_cdiv(a.N, BX_KT);
+      const long blk_elems = sf_attn_bx_plane_elems(a.B, a.N);
+      unsigned short* kb = reinterpret_cast<unsigned short*>(a.bx_planes);
+      unsigned short* vb = kb + 2 * blk_elems;
+      for (int blk = 0; blk < 2; ++blk) {
+        const int cb = a.C - 32 * blk > 32 ? 32 : a.C - 32 * blk;
+        if (sf_attn_bx_split(a.k + 32 * blk, a.k_cs, nullptr, a.B, a.N, cb, kb + blk * blk_elems, nullptr, s) != SF_OK ||
+            sf_attn_bx_split(a.v + 32 * blk, a.v_cs, nullptr, a.B, a.N, cb, nullptr, vb + blk * blk_elems, s) != SF_OK)
+          return SF_ELAUNCH;
+      }
+      static const bool attr_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_bx2_kernel),
+                                                      hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                      BX2_LDS_BYTES) == hipSuccess;
+      if (!attr_ok) return SF_ELAUNCH;
+      hipLaunchKernelGGL(attn_fwd_bx2_kernel, dim3(grid), dim3(256), BX2_LDS_BYTES, s, a, kb, vb, n64, blk_elems);
+      SF_CHECK_LAUNCH();
+      return a.zs > 1 ? sf_attn_fwd_merge(a, CP, s) : SF_OK;
+    }
+  }
   if constexpr (CP == 32) {
     if (vec4 && a.bx_planes) {
       const int n64 = sf_cdiv(a.N, BX_KT);
@@ -1145,7 +1381,7 @@ static int attn_fwd_impl(const float* q, int q_cs, const float* k, int k_cs, con
   if (ws) {
     a.zs = sf_sweep_parts((long)B * a.nqt, sf_cdiv(N, cp >= 128 ? 32 : 64));
     sf_attn_place_parts(a, cp, ws);
-    if (cp == 32 && sf_attn_bx_level() >= 1)  // the split K / V^T planes live behind the part buffers
+    if ((cp == 32 || (cp == 64 && C > 32)) && sf_attn_bx_level() >= 1)  // the split K / V^T planes live behind the part buffers
       a.bx_planes = ws + (long)B * SF_SWEEP_PARTS_MAX * N * (cp + 2);
   }
   if (C <= 32) return launch<32>(a, vec4, s);
@@ -1163,7 +1399,8 @@ extern "C" int sf_attn_fwd(const float* q, int q_cs, const float* k, int k_cs, c
 
 extern "C" int sf_attn_products_per_fp32(int C) {
   if (sf_attn_bx_level() < 1) return 0;
-  return ((C > 16 && C <= 32) || (C > 4 && C <= 8 && C % 4 == 0)) ? 6 : 0;  // C <= 8: packed planes (attn_bx.h)
+  static const bool bx64 = [] { const char* e = getenv("SF_ATTN_BX64"); return !(e && e[0] == '0'); }();
+  return ((C > 16 && C <= 32) || (C > 32 && C <= 64 && bx64) || (C > 4 && C <= 8 && C % 4 == 0)) ? 6 : 0;
 }
 
 // Room for the (O^T, m, l) of up to SF_SWEEP_PARTS_MAX key parts per query row.
@@ -1173,6 +1410,7 @@ extern "C" long sf_attn_fwd_ws_floats(int B, int N, int C) {
   long n = (long)B * SF_SWEEP_PARTS_MAX * N * (cp + 2);
   if (cp == 32) n += (long)B * sf_cdiv(N, 64) * 64 * 32 * 3;  // K and V^T as three bf16 planes each (12 B per element)
   if (cp == 8) n += (long)B * sf_cdiv(N, 64) * 64 * 32;       // K and V^T as one packed plane each (2 x 64 B per row)
+  if (cp == 64) n += (long)B * sf_cdiv(N, 64) * 64 * 32 * 6;  // two 32-channel blocks of three-plane K and V^T sets
   return n;
 }
 

@@ -164,8 +164,8 @@ long sf_attn_fwd_ws_floats(int B, int N, int C);
 /* Which arithmetic serves the attention products of head width C when a workspace is given (sf_attn_fwd_ws,
  * sf_attn_bwd_fused): 0 = v_mfma_f32_*_f32 (fp32 operands); 6 = every fp32 operand as the exact sum of three bf16
  * pieces and every fp32 product as six v_mfma_f32_32x32x16_bf16 (fp32 accumulate; the dropped terms are below
- * 2^-24 |a||b|, one fp32 rounding) — 17 <= C <= 32 and C = 8 with 16-byte aligned rows, unless SF_ATTN_BX=0.
- * (sf_attn_bwd_fused also runs 33 <= C <= 64 that way, as two 32-channel blocks; its forward stays on the f32 MFMA.) */
+ * 2^-24 |a||b|, one fp32 rounding) — 17 <= C <= 64 (33..64 as two 32-channel blocks; SF_ATTN_BX64=0 keeps those on
+ * the f32 MFMA) and C = 8 (packed planes) with 16-byte aligned rows, unless SF_ATTN_BX=0.                        */
 int sf_attn_products_per_fp32(int C);
 int sf_attn_fwd_ws(const float* q, int q_cs, const float* k, int k_cs, const float* v, int v_cs,
                    const float* x, int x_cs, const float* gamma, const float* scale, const float* bias,

@@ -1,4 +1,4 @@
-"""The d = 32, d = 8 (packed planes) and d <= 64 (backward, two channel blocks) attention kernels on the bf16 matrix pipe (attn_bx.h: fp32 operands as three
+"""The d = 32, d = 8 (packed planes) and d <= 64 (two channel blocks) attention kernels on the bf16 matrix pipe (attn_bx.h: fp32 operands as three
 bf16 pieces, six products per fp32 product) against an fp64 softmax attention and its autograd gradients on the same inputs — the bounds are
 those the f32-MFMA kernels meet (tools/microbench/attn_precision.py prints both paths side by side: at unit-scale
 scores O 1.2e-6 / 1.3e-6, gradients 3.7-5.0e-6 / 3.2-3.9e-6 of the tensor's max, split / f32 path)."""
@@ -16,8 +16,7 @@ def test_split_product_attention_matches_fp64(scale, thw, c):
     import sfhip
     if os.environ.get("SF_ATTN_BX", "1") == "0":
         pytest.skip("SF_ATTN_BX=0: the f32-MFMA kernels are selected")
-    # d = 33..64: the fused backward runs on bf16 pieces (two 32-channel blocks), the forward on the f32 MFMA
-    assert sfhip.lib().sf_attn_products_per_fp32(c) == (6 if c <= 32 else 0)
+    assert sfhip.lib().sf_attn_products_per_fp32(c) == 6  # d = 33..64: two 32-channel blocks
     dev = torch.device("cuda:0")
     B = 2
     t, h, w = thw

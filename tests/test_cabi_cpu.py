@@ -129,8 +129,9 @@ def test_launch_planning_queries_are_host_only_and_fill_the_chip():
     assert L.sf_attn_bwd_fused_ws_floats(B, N, 128) == 0                       # d = 128 keeps the two-kernel form
     assert L.sf_attn_bwd_fused_ws_floats(B, N, 64) == B * (N // 128 + 16) * N * 64 + 2 * planes  # two channel blocks
     assert L.sf_attn_fwd_ws_floats(B, N, 32) == B * 8 * N * 34 + planes
-    assert L.sf_attn_fwd_ws_floats(B, N, 64) == B * 8 * N * 66
+    assert L.sf_attn_fwd_ws_floats(B, N, 64) == B * 8 * N * 66 + 2 * planes
     assert L.sf_attn_fwd_ws_floats(B, N, 8) == B * 8 * N * 10 + B * N * 32
-    assert L.sf_attn_products_per_fp32(32) in (0, 6) and L.sf_attn_products_per_fp32(64) == 0
+    assert L.sf_attn_products_per_fp32(32) in (0, 6) and L.sf_attn_products_per_fp32(64) in (0, 6)
+    assert L.sf_attn_products_per_fp32(128) == 0 and L.sf_attn_products_per_fp32(16) == 0
     assert L.sf_attn_products_per_fp32(8) in (0, 6) and L.sf_attn_products_per_fp32(4) == 0
     assert L.sf_attn_fwd_ws_floats(0, N, 32) == 0 and L.sf_attn_fwd_ws_floats(B, N, 129) == 0
