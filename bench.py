@@ -148,15 +148,19 @@ def cpu_baseline(workload, cfg, model, train, device=None, hip_train_step=None):
             rl = keep["logits"]
             parity["fwd_logits_max_rel_err"] = float((logits.cpu() - rl).abs().max() / rl.abs().max())
             parity["train_loss_abs_err"] = abs(float(loss) - keep["loss"])
-            # analytically zero gradients (value / key bias of SpatialAttention, ECA's 3-tap weight in front of a
-            # batch-statistics BN) hold rounding noise on both sides: not part of the statistic
-            zero = ("attention_spatial_s2f.value_conv.bias", "attention_spatial_s2f.key_conv.bias",
-                    "attention_channel_f2s.conv.weight")
+            # analytically zero gradients (tests/_zero_grads.py: value / key bias of SpatialAttention, ECA's 3-tap
+            # weight, BN biases that only meet 1x1x1 convs + batch-statistics BNs) hold rounding noise on both sides:
+            # not part of the relative statistic, bounded absolutely (reported as bwd_zero_class_*)
+            import _zero_grads
+            noise, gmax = _zero_grads.split(keep["grads"])
             errs = []
             for k, g in keep["grads"].items():
-                if k in grads and float(g.norm()) > 0 and not k.endswith(zero):
+                if k in grads and float(g.norm()) > 0 and k not in noise:
                     errs.append((float((grads[k].cpu() - g).norm() / g.norm()), k))
             errs.sort()
+            parity["bwd_zero_class_params"] = len(noise)
+            parity["bwd_zero_class_max_abs_err_over_gmax"] = max(
+                [float((grads[k].cpu() - keep["grads"][k]).norm()) / gmax for k in noise if k in grads] or [0.0])
             parity["bwd_max_rel_err"] = errs[-1][0]
             parity["bwd_median_rel_err"] = errs[len(errs) // 2][0]
             parity["bwd_worst_param"] = errs[-1][1]
@@ -644,6 +648,12 @@ def main():
                 return float(loss), logits.detach(), {k: v.grad.detach().clone() for k, v in model.named_parameters()
                                                       if v.grad is not None}
 
+            # parity on the SEEDED parameters (the state tests/test_fullsize_gpu.py bounds): the timed SGD steps on random
+            # labels moved the weights, and after ~55 steps of them the same comparison read 5x larger gradient errors
+            # (round 3: median 1.4e-3 against 2.6e-4) — weights, BN buffers and momentum-free: re-filled in place
+            from paramgen import fill_state_dict
+            with torch.no_grad():
+                fill_state_dict(model.state_dict(), PARAM_SEED)
             res["cpu_baseline"], parity = cpu_baseline(args.workload, cfg, model, train, device,
                                                        hip_train_step if train else None)
             # second half of BASELINE.json's metric: the HIP path against the oracle on the same full-size clip (batch 1).
@@ -652,9 +662,12 @@ def main():
             # L2 error of every parameter's gradient of the training step (north_star tolerance: 1e-3 on the forward)
             for k, v in parity.items():
                 res[k] = float("%.3e" % v) if isinstance(v, float) else v
-            res["parity_note"] = "HIP vs oracle (CPU restatement of the reference), 1 clip of the benchmark shape; forward " \
-                                 "tolerance 1e-3; bwd_* = per-parameter relative L2 of the train step's gradients, the " \
-                                 "oracle differentiating with the HIP forward's ReLU masks / max-pool winners (tests/_masks.py)"
+            res["parity_note"] = "HIP vs oracle (CPU restatement of the reference), 1 clip of the benchmark shape, on the " \
+                                 "seeded parameters (re-filled after the timed steps); forward tolerance 1e-3; bwd_* = " \
+                                 "per-parameter relative L2 of the train step's gradients, the oracle differentiating with " \
+                                 "the HIP forward's ReLU masks / max-pool winners (tests/_masks.py); gradients that are zero " \
+                                 "in exact arithmetic (tests/_zero_grads.py) are bounded absolutely: bwd_zero_class_*; " \
+                                 "8-clip parity: tests/test_fullsize_gpu.py (eval rows vs 8 oracle forwards, 3-clip train step)"
         print(json.dumps(res))
     if dist.is_initialized():
         dist.destroy_process_group()

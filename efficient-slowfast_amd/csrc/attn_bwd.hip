@@ -1470,11 +1470,20 @@ int sf_attn_dq_reduce(const float* ws, float* dq, int dq_cs, int B, int N, int C
   return SF_OK;
 }
 
+// sf_attn_tune knobs (process-wide; the environment gives the initial values): keys per workgroup of the bf16-piece
+// backward sweeps (0 = by shape, 4 = 128 keys, 8 = 256 keys) and the number of sweep parts (0 = by fill)
+static int g_attn_nw = [] { const char* e = getenv("SF_ATTN_BX_NW"); return e ? atoi(e) : 0; }();
+static int g_sweep_parts = [] { const char* e = getenv("SF_SWEEP_PARTS"); return e ? atoi(e) : 0; }();
+
+extern "C" int sf_attn_tune(int knob, int value) {
+  if (knob == 0 && (value == 0 || value == 4 || value == 8)) g_attn_nw = value;
+  else if (knob == 1 && value >= 0 && value <= SF_SWEEP_PARTS_MAX) g_sweep_parts = value;
+  else return SF_EINVAL;
+  return SF_OK;
+}
+
 int sf_sweep_parts(long units, int tiles) {
-  static const int forced = [] {
-    const char* e = getenv("SF_SWEEP_PARTS");
-    return e ? atoi(e) : 0;
-  }();
+  const int forced = g_sweep_parts;
   static const int cus = [] {
     int dev = 0, n = 0;
     if (hipGetDevice(&dev) != hipSuccess ||
@@ -1546,10 +1555,8 @@ int launch_fused_bx(BwdArgs a, float* ws, float* bx_ws, hipStream_t s) {
     }
   }();
   static const int pad = [] { const char* e = getenv("SF_ATTN_BX_PADLDS"); return e ? atoi(e) : 0; }();  // occupancy probe
-  static const bool attr_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                                  hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                  bxb_lds_bytes(NW) + pad) == hipSuccess;
-  if (!attr_ok) return SF_ELAUNCH;
+  static SfLdsAttr lds_attr;
+  if (!sf_ensure_dyn_lds(lds_attr, reinterpret_cast<const void*>(kern), bxb_lds_bytes(NW) + pad)) return SF_ELAUNCH;
   hipLaunchKernelGGL(kern, dim3(a.B * a.zs * a.nt), dim3(64 * NW), bxb_lds_bytes(NW) + pad, s, a, ws, qb, db,
                      sf_cdiv(a.N, qt));
   SF_CHECK_LAUNCH();
@@ -1579,10 +1586,9 @@ int launch_fused_bxp(BwdArgs a, float* ws, float* bx_ws, hipStream_t s) {
   int rc = sf_attn_bx_split_packed(a.q, a.q_cs, nullptr, a.B, a.N, a.C, qb, nullptr, s);
   if (rc == SF_OK) rc = sf_attn_bx_split_packed(a.dz, a.dz_cs, a.gamma, a.B, a.N, a.C, db, nullptr, s);
   if (rc != SF_OK) return rc;
-  static const bool attr_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_bxp_kernel<NW>),
-                                                  hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                  bxbp_lds_bytes(NW)) == hipSuccess;
-  if (!attr_ok) return SF_ELAUNCH;
+  static SfLdsAttr lds_attr;
+  if (!sf_ensure_dyn_lds(lds_attr, reinterpret_cast<const void*>(attn_bwd_bxp_kernel<NW>), bxbp_lds_bytes(NW)))
+    return SF_ELAUNCH;
   hipLaunchKernelGGL((attn_bwd_bxp_kernel<NW>), dim3(a.B * a.zs * a.nt), dim3(64 * NW), bxbp_lds_bytes(NW), s, a, ws, qb,
                      db, sf_cdiv(a.N, qt));
   SF_CHECK_LAUNCH();
@@ -1618,10 +1624,8 @@ int launch_fused_bx2(BwdArgs a, float* ws, float* bx_ws, hipStream_t s) {
                             db + blk * blk_elems, nullptr, s);
   }
   if (rc != SF_OK) return rc;
-  static const bool attr_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_bx2_kernel),
-                                                  hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                  BXB2_LDS_BYTES) == hipSuccess;
-  if (!attr_ok) return SF_ELAUNCH;
+  static SfLdsAttr lds_attr;
+  if (!sf_ensure_dyn_lds(lds_attr, reinterpret_cast<const void*>(attn_bwd_bx2_kernel), BXB2_LDS_BYTES)) return SF_ELAUNCH;
   hipLaunchKernelGGL(attn_bwd_bx2_kernel, dim3(a.B * a.zs * a.nt), dim3(256), BXB2_LDS_BYTES, s, a, ws, qb, db,
                      sf_cdiv(a.N, qt), blk_elems);
   SF_CHECK_LAUNCH();
@@ -1702,6 +1706,25 @@ extern "C" long sf_attn_bwd_fused_ws_floats(int B, int N, int C) {
   return n;
 }
 
+static bool sf_attn_bx_wide(int B, int N) {
+  return g_attn_nw == 8 || (g_attn_nw != 4 && (long)B * sf_cdiv(N, 256) >= 256);
+}
+
+// Which instantiation sf_attn_bwd_fused launches for (B, N, C) on 16-byte aligned views (tests assert that the variant
+// the benchmark runs at 8 clips is the one they compare with fp64): 10 * family + wavefronts per workgroup, family
+// 1 = f32 MFMA d <= 16, 2 = packed bf16 planes (d = 8), 3 = bf16 pieces d <= 32, 4 = bf16 pieces d <= 64 (two blocks),
+// 5 / 6 = f32 MFMA d <= 32 / d <= 64, 7 = two-kernel form (d = 128); 0 = shape not served.
+extern "C" int sf_attn_bwd_variant(int B, int N, int C) {
+  if (sf_attn_bwd_fused_ws_floats(B, N, C) == 0) return 0;
+  const bool bx = sf_attn_bx_level() >= 1;
+  if (C > 4 && C <= 8 && C % 4 == 0 && bx) return 20 + (g_attn_nw == 8 ? 8 : 4);
+  if (C <= 16) return 14;
+  if (C > 64) return 74;
+  if (C <= 32) return (C % 4 == 0 && bx) ? 30 + (sf_attn_bx_wide(B, N) ? 8 : 4) : 54;
+  static const bool bx64 = [] { const char* e = getenv("SF_ATTN_BX64"); return !(e && e[0] == '0'); }();
+  return (C % 4 == 0 && bx && bx64) ? 44 : 64;
+}
+
 extern "C" int sf_attn_bwd_fused(const float* q, int q_cs, const float* k, int k_cs, const float* v, int v_cs,
                                  const float* dz, int dz_cs, const float* lse, const float* dvec, const float* gamma,
                                  float* dq, int dq_cs, float* dk, int dk_cs, float* dv, int dv_cs, int B, int N, int C,
@@ -1718,7 +1741,7 @@ extern "C" int sf_attn_bwd_fused(const float* q, int q_cs, const float* k, int k
     a.B = B; a.C = C; a.N = N; a.dqp = nullptr;
     // 128 keys per workgroup: the dQ planes are a quarter of the d = 32 ones, and 8-wavefront barriers cost more than
     // halving them saves (N = 25 088, B = 8: 5.00 ms against 5.26).  SF_ATTN_BX_NW=8 forces the wide form.
-    static const bool wide = [] { const char* e = getenv("SF_ATTN_BX_NW"); return e && atoi(e) == 8; }();
+    const bool wide = g_attn_nw == 8;
     float* const bx_ws = ws + (sf_attn_bwd_fused_ws_floats(B, N, C) - sf_attn_bx_packed_elems(B, N));
     return wide ? launch_fused_bxp<8>(a, ws, bx_ws, (hipStream_t)stream)
                 : launch_fused_bxp<4>(a, ws, bx_ws, (hipStream_t)stream);
@@ -1754,8 +1777,7 @@ extern "C" int sf_attn_bwd_fused(const float* q, int q_cs, const float* k, int k
     if (vec4 && sf_attn_bx_level() >= 1) {
       // 256 keys (8 wavefronts, one workgroup per CU) per workgroup where that still fills the chip: half the dQ
       // planes to write and to sum (N = 25 088, B = 8: 9.20 -> 8.70 ms).  SF_ATTN_BX_NW=4|8 forces either.
-      static const int forced = [] { const char* e = getenv("SF_ATTN_BX_NW"); return e ? atoi(e) : 0; }();
-      const bool wide = forced == 8 || (forced != 4 && (long)B * sf_cdiv(N, 256) >= 256);
+      const bool wide = sf_attn_bx_wide(B, N);
       float* const bx_ws = ws + (sf_attn_bwd_fused_ws_floats(B, N, C) - sf_attn_bx_plane_elems(B, N));
       return wide ? launch_fused_bx<8>(a, ws, bx_ws, (hipStream_t)stream)
                   : launch_fused_bx<4>(a, ws, bx_ws, (hipStream_t)stream);

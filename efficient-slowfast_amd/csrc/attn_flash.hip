@@ -1250,10 +1250,8 @@ int launch(AttnArgs a, bool vec4, hipStream_t s) {
             sf_attn_bx_split(a.v + 32 * blk, a.v_cs, nullptr, a.B, a.N, cb, nullptr, vb + blk * blk_elems, s) != SF_OK)
           return SF_ELAUNCH;
       }
-      static const bool attr_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_bx2_kernel),
-                                                      hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                      BX2_LDS_BYTES) == hipSuccess;
-      if (!attr_ok) return SF_ELAUNCH;
+      static SfLdsAttr lds_attr2;
+      if (!sf_ensure_dyn_lds(lds_attr2, reinterpret_cast<const void*>(attn_fwd_bx2_kernel), BX2_LDS_BYTES)) return SF_ELAUNCH;
       hipLaunchKernelGGL(attn_fwd_bx2_kernel, dim3(grid), dim3(256), BX2_LDS_BYTES, s, a, kb, vb, n64, blk_elems);
       SF_CHECK_LAUNCH();
       return a.zs > 1 ? sf_attn_fwd_merge(a, CP, s) : SF_OK;
@@ -1275,10 +1273,8 @@ int launch(AttnArgs a, bool vec4, hipStream_t s) {
                                                                       : (Kern)attn_fwd_bx_kernel<32, 0>;
       }();
       static const int pad = [] { const char* e = getenv("SF_ATTN_BX_PADLDS"); return e ? atoi(e) : 0; }();  // occupancy probe
-      static const bool attr_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                                      hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                      BX_LDS_BYTES + pad) == hipSuccess;  // 72 KB of dynamic LDS
-      if (!attr_ok) return SF_ELAUNCH;
+      static SfLdsAttr lds_attr;  // 72 KB of dynamic LDS
+      if (!sf_ensure_dyn_lds(lds_attr, reinterpret_cast<const void*>(kern), BX_LDS_BYTES + pad)) return SF_ELAUNCH;
       hipLaunchKernelGGL(kern, dim3(grid), dim3(256), BX_LDS_BYTES + pad, s, a, kb, vb, n64);
       SF_CHECK_LAUNCH();
       return a.zs > 1 ? sf_attn_fwd_merge(a, CP, s) : SF_OK;

@@ -481,8 +481,10 @@ static int bn_bwd_reduce_launch(const float* dy, int dy_cs, int dy_coff, const f
   const int groups = S > 1 ? N : 1;
   const long group_rows = rows / groups;
   int CB, P;
-  const bool few = sf_tickets_level() == 2 && S == 1 && vec4 && C >= 256;  // short last-arriver walk: <= 64 partials
-  const bool fused = sf_tickets_enabled() || few;
+  // the ticket ring is allocated on first use; while a stream capture is under way before that, the two-launch form runs
+  const bool ring = sf_ticket_ring_ready((hipStream_t)stream);
+  const bool few = ring && sf_tickets_level() == 2 && S == 1 && vec4 && C >= 256;  // short last-arriver walk: <= 64 partials
+  const bool fused = (ring && sf_tickets_enabled()) || few;
   red_geometry(group_rows, C, vec4 ? 4 : 1, &CB, &P);
   const int max_p = few ? 64 : (fused ? 512 : MAX_P);
   if (fused && CB > 16) {  // <= 64 channels per channel group: the groups' last workgroups finish in parallel

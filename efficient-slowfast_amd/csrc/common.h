@@ -48,6 +48,20 @@ int sf_sweep_parts(long units, int tiles);  // attn_bwd.hip
 // for another, so nothing depends on residency or dispatch order.  Counters live in a library-owned, zero-initialised
 // ring; the last arriver resets its counter, so a slot is clean again when the launch ends.
 unsigned* sf_ticket_slots(int n);  // elementwise.hip: n consecutive zeroed counters (host side, no launch)
+bool sf_ticket_ring_ready(hipStream_t stream);  // allocates the ring on first use; false while `stream` is captured
+                                                // before that happened (callers then take their two-launch form)
+
+// Dynamic LDS above 64 KB needs hipFuncAttributeMaxDynamicSharedMemorySize, which is a PER-DEVICE property of the
+// kernel: remembered per device (bit d of `done`), retried when it failed.
+struct SfLdsAttr { unsigned long long done = 0; };
+static inline bool sf_ensure_dyn_lds(SfLdsAttr& m, const void* fn, int bytes) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return false;
+  if (dev >= 0 && dev < 64 && ((m.done >> dev) & 1ull)) return true;
+  if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) return false;
+  if (dev >= 0 && dev < 64) m.done |= 1ull << dev;
+  return true;
+}
 bool sf_tickets_enabled();         // SF_BN_TICKET=1 selects the fused reductions (default: two launches, measured faster)
 int sf_tickets_level();            // SF_BN_TICKET value (2: BN backward reductions of >= 256-channel layers only)
 

@@ -250,7 +250,8 @@ static void magic(unsigned dv, unsigned* mul, unsigned* sh) {
   *sh = l - 1;
 }
 
-int g_small_enable = 1;  // sf_conv_tune(6, e): bit 0 = enable, bits 4.. = ablation mask (microbenchmarks)
+int g_small_enable = 1;  // sf_conv_tune(6, e): bit 0 = enable, bit 1 = every shape the instantiations cover (as
+int g_small_all = 0;     // SF_CONV_SMALL=2; tests), bits 4.. = ablation mask (microbenchmarks)
 int g_small_dbg = 0;
 
 static int small_level() {
@@ -258,19 +259,16 @@ static int small_level() {
     const char* e = getenv("SF_CONV_SMALL");
     return e ? atoi(e) : 1;
   }();
-  return g_small_enable ? env_on : 0;
+  return g_small_enable ? (g_small_all ? 2 : env_on) : 0;
 }
 static bool small_enabled() { return small_level() > 0; }
 
 template <int CO_T, int CK>
 static int launch_small(const SmallArgs& a, int ntile, size_t lds_bytes, hipStream_t s) {
-  static bool attr_set = false;
-  if (!attr_set && lds_bytes > 48 * 1024) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_small_kernel<CO_T, CK>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess)
-      return SF_ELAUNCH;
-    attr_set = true;
-  }
+  static SfLdsAttr lds_attr;
+  if (lds_bytes > 48 * 1024 &&
+      !sf_ensure_dyn_lds(lds_attr, reinterpret_cast<const void*>(conv_small_kernel<CO_T, CK>), 96 * 1024))
+    return SF_ELAUNCH;
   hipLaunchKernelGGL((conv_small_kernel<CO_T, CK>), dim3(ntile), dim3(256), lds_bytes, s, a);
   SF_CHECK_LAUNCH();
   return SF_OK;
@@ -278,7 +276,14 @@ static int launch_small(const SmallArgs& a, int ntile, size_t lds_bytes, hipStre
 
 }  // namespace
 
-int sf_conv_small_tune(int value) { g_small_enable = value & 1; g_small_dbg = value >> 4; return SF_OK; }
+int sf_conv_small_tune(int value) {
+  g_small_enable = value & 1;
+  g_small_all = (value >> 1) & 1;
+  g_small_dbg = value >> 4;
+  return SF_OK;
+}
+
+long sf_conv_wave_max_parts(long M);  // conv_wave.hip: what sf_conv_stats_ws_floats sized the statistics rows for
 
 // Shape-only decision (pointer alignment is checked at launch).  parts_out: workgroups = statistics records.
 int sf_conv_small_takes(const sf_conv_desc* d, int* parts_out) {
@@ -363,7 +368,10 @@ int sf_conv_small_try(const sf_conv_desc* d, const float* in, const float* w_pac
   magic((unsigned)a.HW, &a.hw_mul, &a.hw_sh);
   magic((unsigned)a.T, &a.t_mul, &a.t_sh);
   magic((unsigned)a.W, &a.w_mul, &a.w_sh);
-  const bool want = stats && stat_parts && !scale && !res && d->act == SF_ACT_NONE && sf_aligned16(stats);
+  // one statistics record per workgroup: frames of fewer than 112 positions can make more of them than the workspace
+  // (sized for conv_wave's tiles) holds — no statistics then, the caller runs the separate pass
+  const bool want = stats && stat_parts && !scale && !res && d->act == SF_ACT_NONE && sf_aligned16(stats) &&
+                    parts <= sf_conv_wave_max_parts((long)d->N * d->To * d->Ho * d->Wo);
   a.stats = want ? stats : nullptr;
   if (want) *stat_parts = parts;
   const size_t lb = lds_floats * sizeof(float);

@@ -343,17 +343,11 @@ int sf_conv_stem_fwd_try(const sf_conv_desc* d, const float* in, const float* w,
   }
   q.tparts = best;
   q.units = d->N * d->Ho * best;
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_stem_fwd_kernel<false>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(conv_stem_fwd_kernel<true>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(conv_stem_pair_kernel),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512) != hipSuccess)
-      return SF_ELAUNCH;
-    attr_set = true;
-  }
+  static SfLdsAttr at0, at1, at2;
+  if (!sf_ensure_dyn_lds(at0, reinterpret_cast<const void*>(conv_stem_fwd_kernel<false>), 160 * 1024 - 512) ||
+      !sf_ensure_dyn_lds(at1, reinterpret_cast<const void*>(conv_stem_fwd_kernel<true>), 160 * 1024 - 512) ||
+      !sf_ensure_dyn_lds(at2, reinterpret_cast<const void*>(conv_stem_pair_kernel), 160 * 1024 - 512))
+    return SF_ELAUNCH;
   if (all_taps)
     hipLaunchKernelGGL(conv_stem_pair_kernel, dim3(q.units < 256 ? q.units : 256), dim3(256), lds, stream, q);
   else if (pair)

@@ -723,7 +723,7 @@ static int persist_level() {
     const char* e = getenv("SF_CONV_WAVE_P");
     return e ? atoi(e) : 3;
   }();
-  return g_persist ? env_on : 0;
+  return g_persist >= 10 ? g_persist - 10 : (g_persist ? env_on : 0);
 }
 
 // launch == false: only report the workgroups of this instantiation a CU holds (registers), asked of the runtime once

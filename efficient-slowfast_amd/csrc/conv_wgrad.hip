@@ -906,15 +906,10 @@ extern "C" int sf_conv_wgrad(const sf_conv_desc* d, const float* x, const float*
     sq.w = a;
     size_t lds = ((size_t)STEM_KT * STEM_KH * sq.rowf + (size_t)sq.nblk * (sq.pair ? 64 : 16 * STEM_CO)) * sizeof(float);
     if (sq.pair && lds < (size_t)STEM_MT * 16 * 16 * sizeof(float)) lds = (size_t)STEM_MT * 16 * 16 * sizeof(float);
-    static bool attr_set = false;  // raise the dynamic-LDS cap once (129 KB of the CU's 160 KB)
-    if (!attr_set) {
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_stem_kernel),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512) != hipSuccess ||
-          hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_stem_pair_kernel),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512) != hipSuccess)
-        return SF_ELAUNCH;
-      attr_set = true;
-    }
+    static SfLdsAttr at0, at1;  // raise the dynamic-LDS cap once per device (129 KB of the CU's 160 KB)
+    if (!sf_ensure_dyn_lds(at0, reinterpret_cast<const void*>(conv_wgrad_stem_kernel), 160 * 1024 - 512) ||
+        !sf_ensure_dyn_lds(at1, reinterpret_cast<const void*>(conv_wgrad_stem_pair_kernel), 160 * 1024 - 512))
+      return SF_ELAUNCH;
     if (sq.pair)
       hipLaunchKernelGGL(conv_wgrad_stem_pair_kernel, dim3(stem_workgroups(sq)), dim3(256), lds, (hipStream_t)stream,
                          sq);

@@ -696,22 +696,37 @@ int sf_tickets_level() {
   static const int lv = [] { const char* e = getenv("SF_BN_TICKET"); return e ? atoi(e) : 2; }();  // default since round 3
   return lv;
 }
-unsigned* sf_ticket_slots(int n) {
-  constexpr int RING = 1 << 16, MAXDEV = 16;
-  static unsigned* ring[MAXDEV] = {};
-  static std::atomic<unsigned> next[MAXDEV];
+namespace {
+constexpr int TICKET_RING = 1 << 16, TICKET_MAXDEV = 16;
+unsigned* g_ticket_ring[TICKET_MAXDEV] = {};
+std::atomic<unsigned> g_ticket_next[TICKET_MAXDEV];
+}  // namespace
+
+// The ring is allocated and zeroed on first use (hipMalloc + a synchronous hipMemset): never inside a stream capture.
+// False = no ring on this device and `stream` is being captured: the caller takes its two-launch form.
+bool sf_ticket_ring_ready(hipStream_t stream) {
   int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAXDEV || n <= 0 || n > 4096) return nullptr;
-  if (!ring[dev]) {  // first use on this device (warm-up, never inside a graph capture): allocate and zero once
-    unsigned* p = nullptr;
-    if (hipMalloc(&p, RING * sizeof(unsigned)) != hipSuccess) return nullptr;
-    if (hipMemset(p, 0, RING * sizeof(unsigned)) != hipSuccess) return nullptr;
-    ring[dev] = p;
-  }
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= TICKET_MAXDEV) return false;
+  if (g_ticket_ring[dev]) return true;
+  hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(stream, &st) != hipSuccess || st != hipStreamCaptureStatusNone) return false;
+  unsigned* p = nullptr;
+  if (hipMalloc(&p, TICKET_RING * sizeof(unsigned)) != hipSuccess) return false;
+  if (hipMemset(p, 0, TICKET_RING * sizeof(unsigned)) != hipSuccess) return false;
+  g_ticket_ring[dev] = p;
+  return true;
+}
+
+unsigned* sf_ticket_slots(int n) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= TICKET_MAXDEV || n <= 0 || n > 4096) return nullptr;
+  if (!g_ticket_ring[dev]) return nullptr;  // sf_ticket_ring_ready() first
   const unsigned take = ((unsigned)n + 63u) & ~63u;
-  unsigned off = next[dev].fetch_add(take) % RING;
-  if (off + take > RING) off = next[dev].fetch_add(take) % RING, off = (off + take > RING) ? 0 : off;
-  return ring[dev] + off;
+  unsigned off;
+  do {  // a range that would straddle the end of the ring is skipped, never folded onto slot 0 (another launch's)
+    off = g_ticket_next[dev].fetch_add(take) % TICKET_RING;
+  } while (off + take > (unsigned)TICKET_RING);
+  return g_ticket_ring[dev] + off;
 }
 
 extern "C" int sf_abi_version(void) { return 1; }
@@ -832,7 +847,7 @@ static int stats_launch(const float* x, int cs, int coff, int groups, long group
   if (groups > STAT_MAX_P || S <= 0 || groups % S != 0) return SF_EINVAL;
   const bool vec4 = (C % 4 == 0) && (cs % 4 == 0) && (coff % 4 == 0) && sf_aligned16(x);
   const int cv = sf_cdiv(C, vec4 ? 4 : 1);
-  const bool fused = sf_tickets_enabled();
+  const bool fused = sf_tickets_enabled() && sf_ticket_ring_ready(s);
   // fused launch: <= 16 lanes (64 channels) per channel group, so that the group's last workgroup finishes few outputs
   // while the groups finish in parallel, and <= 512 partials per output
   const int cb_max = fused ? 16 : TPB;

@@ -54,7 +54,7 @@ EXPORTS = [
     "sf_attn_bwd_fused_ws_floats", "sf_attn_bwd_fused", "sf_pack_conv_weight", "sf_conv_fwd_ws_floats",
     "sf_conv_fwd_ws", "sf_attn_fwd_ws_floats", "sf_attn_fwd_ws", "sf_affine_fwd_mask", "sf_bn_bwd_apply_first", "sf_maxpool_bwd_first",
     "sf_conv_tune", "sf_conv_stats_ws_floats", "sf_conv_fwd_stats", "sf_bn_train_stats_merge",
-    "sf_attn_products_per_fp32", "sf_pack_conv_weights",
+    "sf_attn_products_per_fp32", "sf_pack_conv_weights", "sf_attn_bwd_variant", "sf_attn_tune",
 ]
 _LONG_RET = ("sf_tmax_mean_ws_floats", "sf_channel_stats_ws_floats", "sf_bn_bwd_ws_floats",
              "sf_dwconv_wgrad_ws_floats", "sf_attn_bwd_fused_ws_floats", "sf_conv_fwd_ws_floats",
@@ -136,6 +136,8 @@ def lib():
         L.sf_conv_fwd_ws.argtypes = [ctypes.POINTER(ConvDesc)] + [vp] * 8
         L.sf_pack_conv_weight.argtypes = [vp, ci, ci, ci, vp, ci, vp, ci, vp]
         L.sf_conv_tune.argtypes = [ci, ci]
+        L.sf_attn_tune.argtypes = [ci, ci]
+        L.sf_attn_bwd_variant.argtypes = [ci, ci, ci]
         L.sf_row_softmax_fwd.argtypes = [vp, ci, ci, cl, ci, cf, vp]
         L.sf_row_softmax_bwd.argtypes = [vp, ci, ci, vp, ci, ci, cl, ci, cf, vp]
         L.sf_conv_wgrad_finish.argtypes = [vp, ci, ci, ci, ci, ci, ci, vp, ci, vp]
@@ -355,7 +357,10 @@ def pack_conv_weight_pairs(weights, outs):
         cout, cin = w.shape[0], w.shape[1]
         taps = w.shape[2] * w.shape[3] * w.shape[4]
         cin_pad, cout_pad = (cin + 15) // 16 * 16, (cout + 15) // 16 * 16
-        if o is None or tuple(o[0].shape) != (cout, taps, cin_pad) or tuple(o[1].shape) != (cin, taps, cout_pad):
+        ok = (o is not None and o[0] is not None and o[1] is not None and
+              all(t.device == w.device and t.dtype == torch.float32 and t.is_contiguous() for t in o) and
+              tuple(o[0].shape) == (cout, taps, cin_pad) and tuple(o[1].shape) == (cin, taps, cout_pad))
+        if not ok:  # e.g. the (wp, None) a CPU forward cached, or a pair left on another GPU by .to(device)
             o = (torch.empty((cout, taps, cin_pad), dtype=torch.float32, device=w.device),
                  torch.empty((cin, taps, cout_pad), dtype=torch.float32, device=w.device))
         res.append(o)
@@ -364,7 +369,7 @@ def pack_conv_weight_pairs(weights, outs):
         recs.append((w.data_ptr(), o[0].data_ptr(), o[1].data_ptr(), cout, cin, taps, cin_pad, cout_pad, 0, n_wp, total))
         nb += (total + 255) // 256
         blk0.append(nb)
-    key = tuple(r[:3] for r in recs)
+    key = tuple(r[:8] for r in recs)  # pointers AND dims: a freed buffer's address may come back with another shape
     dev = weights[0].device
     tab = _PACK_TABLES.get(dev)
     if tab is None or tab[0] != key:

@@ -5,6 +5,7 @@ every top-level child be called on its own with the reference's list-of-NCTHW-te
 (Grad-CAM contract, wdf_visualization/gradcam_video.py:92-105)."""
 import os
 import threading
+import weakref
 
 import torch
 import torch.nn as nn
@@ -60,6 +61,7 @@ class Tape(object):
         self.input_ids = {}    # id(clip tensor) -> input index, for the inputs whose gradient autograd asked for
         self.input_grads = {}  # input index -> dL/d(clip), NCTHW (written by the stems' backward)
         self.joins = set()  # companion streams with weight-gradient work in flight (joined at the end of backward)
+        self.model = None   # the model whose forward this tape records (milestone hooks are bound to it)
 
     def pgrad_target(self, param):
         """The tensor kernels may accumulate this parameter's gradient into directly, or None."""
@@ -122,24 +124,29 @@ def tape():
     return getattr(_tls, "tape", None)
 
 
-_MILESTONE_HOOK = None
+_MILESTONE_HOOKS = weakref.WeakKeyDictionary()  # model -> hook: a hook only ever sees the backward of ITS model
 
 
-def set_milestone_hook(fn):
-    """fn(child_name, tape) is called DURING the backward pass at the point where every gradient of the top-level
-    child `child_name` and of all children after it has been issued (on the caller's stream, the side stream — joined
-    by then — or a companion stream listed in tape.joins).  utils.distributed.FlatGradients uses it to start the
-    all-reduce of the finished tail of the flat gradient buffer while the earlier stages' backward still runs (the
-    reference gets the same overlap from DistributedDataParallel's buckets, models/build.py:39-43)."""
-    global _MILESTONE_HOOK
-    _MILESTONE_HOOK = fn
+def set_milestone_hook(fn, model):
+    """fn(child_name, tape) is called DURING the backward pass of `model` at the point where every gradient of the
+    top-level child `child_name` and of all children after it has been issued (on the caller's stream, the side stream
+    — joined by then — or a companion stream listed in tape.joins).  utils.distributed.FlatGradients uses it to start
+    the all-reduce of the finished tail of the flat gradient buffer while the earlier stages' backward still runs (the
+    reference gets the same overlap from DistributedDataParallel's buckets, models/build.py:39-43).  fn = None removes
+    the model's hook."""
+    if fn is None:
+        _MILESTONE_HOOKS.pop(model, None)
+    else:
+        _MILESTONE_HOOKS[model] = fn
 
 
 def milestone(name):
     """Called by the models' _forward_impl in front of each top-level child."""
     t = tape()
-    hook = _MILESTONE_HOOK
-    if t is not None and hook is not None:
+    if t is None or t.model is None:
+        return
+    hook = _MILESTONE_HOOKS.get(t.model)
+    if hook is not None:
         t.record(lambda: hook(name, t))
 
 
@@ -490,8 +497,6 @@ def norm_forward(bn, x):
     return leave([y])[0]
 
 
-import weakref
-
 _PAIR_WEIGHTS = {}  # id(weight) -> weakref of the dense conv weights that have been packed as a pair (tensors compare
 # elementwise, so no WeakSet): repack_all's candidates
 BATCHED_REPACK = os.environ.get("SF_BATCH_REPACK", "1") != "0"
@@ -737,6 +742,7 @@ class TapedForward(torch.autograd.Function):
     def forward(ctx, model, n_in, *args):
         inputs, params = list(args[:n_in]), args[n_in:]
         t = Tape()
+        t.model = model
         t.input_ids = {id(x): i for i, x in enumerate(inputs)
                        if isinstance(x, torch.Tensor) and ctx.needs_input_grad[2 + i]}
         with taping(t):

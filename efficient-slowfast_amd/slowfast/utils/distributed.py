@@ -75,10 +75,19 @@ class FlatGradients(object):
         self._cuts = {}      # top-level child name -> flat offset of its first parameter
         self._hi = n         # [self._hi, n) is already being reduced this step
         self._pending = []   # async work handles of this step's chunks
+        self._tape = None    # the backward pass whose milestones launched this step's chunks
+        self._model = None   # weakref of the model overlap_with_backward was registered for
         self._comm = None
         self.chunks_last_step = 0
 
     def zero(self):
+        """Start a step: zero the buffer.  Chunks a previous, unfinished step left in flight (a step that skipped
+        all_reduce_mean after an error / NaN) are waited for first, and the chunk state starts over."""
+        for w in self._pending:
+            w.wait()
+        self._pending = []
+        self._hi = self.flat.numel()
+        self._tape = None
         self.flat.zero_()
 
     def rebind(self):
@@ -101,25 +110,59 @@ class FlatGradients(object):
         range [offset(X), previous cut) is all-reduced on a dedicated stream while the earlier stages' backward goes
         on.  all_reduce_mean() then reduces what is left and waits for all of it.  Chunks are contiguous ranges of
         the same buffer, so the result equals the single collective's element for element."""
+        import weakref
         from slowfast.models import engine
         off, where = 0, {}
         for p in self.params:
             where[id(p)] = off
             off += p.numel()
+        children = list(model.named_children())
         self._cuts = {}
         for name in boundaries:
-            child = getattr(model, name, None)
-            first = None if child is None else next((p for p in child.parameters() if p.requires_grad), None)
-            if first is not None:
-                self._cuts[name] = where[id(first)]
-        engine.set_milestone_hook(self._on_milestone)
+            idx = next((i for i, (n, _) in enumerate(children) if n == name), None)
+            if idx is None:
+                continue
+            tail = [p for _, c in children[idx:] for p in c.parameters() if p.requires_grad]
+            if not tail:
+                continue
+            cut = min(where.get(id(p), -1) for p in tail)
+            # the range [cut, end) must hold exactly the parameters of this child and of every later child: with a
+            # re-ordered parameter list (e.g. BN / non-BN groups, as the reference's optimizer builder makes them:
+            # models/optimizer.py:25-40) a range would be reduced before all of its gradients are complete
+            behind = {id(p) for p, o in zip(self.params, self._offsets()) if o >= cut}
+            if cut < 0 or behind != {id(p) for p in tail}:
+                raise ValueError(
+                    "FlatGradients.overlap_with_backward: the parameters behind the first parameter of %r are not "
+                    "exactly those of %r and the children after it — build FlatGradients from model.parameters() in "
+                    "the model's own order, or reduce in one collective (no overlap)" % (name, name))
+            self._cuts[name] = cut
+        self._model = weakref.ref(model)
+        engine.set_milestone_hook(self._on_milestone, model)
         return self
+
+    def _offsets(self):
+        off = 0
+        for p in self.params:
+            yield off
+            off += p.numel()
 
     def _on_milestone(self, name, tape):
         from slowfast.models import engine
+        if self._model is None or getattr(tape, "model", None) is not self._model():
+            return  # the backward of another model
         lo = self._cuts.get(name)
-        if lo is None or lo >= self._hi or not self._active() or not engine._GRAD_SINK:
+        if lo is None or not self._active() or not engine._GRAD_SINK:
             return
+        if self._tape is not None and tape is not self._tape and self._hi < self.flat.numel():
+            # a SECOND backward since zero() (gradient accumulation) while ranges of the first are already being summed
+            # over the ranks: its gradients would land on top of reduced values and the ranks would diverge silently
+            raise RuntimeError(
+                "FlatGradients: a second backward pass ran before all_reduce_mean() while chunks of the first were "
+                "already being all-reduced; for gradient accumulation build it without overlap_with_backward (one "
+                "collective after the last backward) or call zero() / all_reduce_mean() between the passes")
+        if lo >= self._hi:
+            return
+        self._tape = tape
         self._launch(lo, self._hi, tape)
         self._hi = lo
 
@@ -148,6 +191,7 @@ class FlatGradients(object):
             self.chunks_last_step = len(self._pending)
             self._pending = []
             self._hi = self.flat.numel()
+            self._tape = None
             self.flat.div_(dist.get_world_size(self.group))
         return self.flat
 

@@ -94,7 +94,9 @@ int sf_conv_fwd_stats(const sf_conv_desc* d, const float* in, const float* w_pac
 /* Tuning knobs of the dense-conv launcher for microbenchmarks and A/B runs (process-wide, not used by the model code):
  * knob 0: value 0 routes every conv to the LDS-tiled kernels of conv_igemm.hip instead of the per-wavefront kernels of
  * conv_wave.hip; knob 1: force tile configuration `value` of conv_wave.hip (-1: planner); knob 2: force the rows per
- * M tile (0: planner); knob 3: value 1 selects 32-channel K steps; knobs 10 / 11 / 12: the weight-gradient kernels of
+ * M tile (0: planner); knob 3: value 1 selects 32-channel K steps; knob 4: the persistent
+ * swapped-operand form (0 = never, 1 = the SF_CONV_WAVE_P level, 10 + L = level L: 1 every KS == 1 layer it covers,
+ * 2 plain layers, 3 plain layers with <= 5 K steps); knob 6: conv_small.hip (bit 0 enable); knobs 10 / 11 / 12: the weight-gradient kernels of
  * conv_wgrad_wave.hip — 10: value 0 routes every weight gradient to conv_wgrad.hip, 11: force the blocks per
  * wavefront (-1: planner), 12: workgroups to aim at (0: default).  Returns SF_EINVAL for an unknown knob.      */
 int sf_conv_tune(int knob, int value);
@@ -188,6 +190,16 @@ long sf_attn_bwd_fused_ws_floats(int B, int N, int C);
 int sf_attn_bwd_fused(const float* q, int q_cs, const float* k, int k_cs, const float* v, int v_cs, const float* dz,
                       int dz_cs, const float* lse, const float* dvec, const float* gamma, float* dq, int dq_cs,
                       float* dk, int dk_cs, float* dv, int dv_cs, int B, int N, int C, float* ws, void* stream);
+
+/* Which kernel instantiation sf_attn_bwd_fused launches for (B, N, C) on 16-byte aligned views, as 10 * family +
+ * wavefronts per workgroup (family 1 = f32 MFMA d <= 16, 2 = packed bf16 planes d = 8, 3 = bf16 pieces d <= 32,
+ * 4 = bf16 pieces d <= 64 in two channel blocks, 5 / 6 = f32 MFMA d <= 32 / <= 64, 7 = two-kernel form d = 128;
+ * 0 = shape not served).  The choice depends on the batch (B * ceil(N / 256) >= 256 selects the 8-wavefront form of
+ * family 3, i.e. B >= 3 at N = 25 088): parity tests assert which one they exercised.                             */
+int sf_attn_bwd_variant(int B, int N, int C);
+/* Process-wide knobs of the attention launchers for tests / A-B runs: knob 0 = wavefronts per workgroup of the
+ * bf16-piece backward (0 = by shape, 4, 8); knob 1 = parts every sweep is cut into (0 = by fill, 1..8).          */
+int sf_attn_tune(int knob, int value);
 
 /* ---- training-mode BatchNorm3d forward pieces (batchnorm_helper.py:15-34 -> nn.BatchNorm3d, training=True)
  * sf_channel_stats: per-channel mean and BIASED variance over all rows of an NDHWC slice, reduced through

@@ -79,14 +79,19 @@ class Masks(object):
         """x * (the next captured mask of this shape).  A captured mask must agree with the oracle's own on all but a
         few elements (they differ only where a pre-activation sits within rounding of the kink): one that does not is
         a mask of another layer (a capture the oracle never asks for in this form, e.g. the two halves of ShuffleNet's
-        relu(cat[a, b])) and is dropped; with none left the oracle keeps its own activation (recorded in `missed`)."""
+        relu(cat[a, b])) and is left in place; with no agreeing one the oracle keeps its own activation (recorded in
+        `missed`)."""
         q = self.by_shape.get(tuple(x.shape))
         own = x.detach() > 0
         if kind == "relu6":
             own &= x.detach() < 6
-        while q:
-            m, hi = q.popleft()
+        # the first captured mask of this shape that agrees: normally the head of the queue; the two sides may visit
+        # same-shaped layers of DIFFERENT pathways in another order (cfg #1: the Slow and the Fast pathway of
+        # SlowFastShuffleNetV2 at 32^2 meet in shapes like [2, 16, 4, 1, 1]), so a non-matching head is skipped, not
+        # dropped
+        for i, (m, hi) in enumerate(q or ()):
             if float((m == own).float().mean()) > 0.99:
+                del q[i]
                 self.used += 1
                 # torch.where, not x * mask: the product's backward is WRONG on this torch build (2.10 CPU) when the
                 # incoming gradient is the expanded (stride-0) gradient of a mean over size-1 dims — found on
@@ -96,7 +101,6 @@ class Masks(object):
                 if hi is not None:
                     y = torch.where(hi, torch.full_like(x, 6.0), y)
                 return y
-            self.dropped += 1
         self.missed.append((kind, tuple(x.shape)))
         return None
 

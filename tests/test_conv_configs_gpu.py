@@ -1,0 +1,188 @@
+"""Forced-configuration sweep of the dense-conv kernels: the planner of conv_wave.hip picks a
+(TM, TN, KS) tile, the persistent swapped-operand form, conv_small.hip or — for the weight gradient — a block shape and
+a position-split count FROM THE BATCH SIZE, so the picks the benchmark makes at 8 clips are not the picks the small
+parity cases make.  Here every configuration is forced with sf_conv_tune on shapes each of them covers and compared
+with an fp64 convolution of the same inputs (forward with bias, data gradient = transposed descriptor, conv-epilogue
+BN statistics, weight gradient), at the per-op tolerance of tests/test_ops_gpu.py.
+
+Reference ops being matched: nn.Conv3d of resnet_helper.py:182-223, 326-335 and its autograd gradients."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+TOL = 2e-4
+
+# name, Cin, Cout, kernel, pad, (N, T, H, W): ragged row counts (not multiples of 16 / 112 / 196) on purpose
+SHAPES = [
+    ("plain_64_256", 64, 256, (1, 1, 1), (0, 0, 0), (3, 2, 23, 21)),        # 4 K steps: the persistent form's home
+    ("s3_128_128", 128, 128, (1, 3, 3), (0, 1, 1), (3, 2, 19, 17)),         # K = 1152, border taps
+    ("t3_256_128", 256, 128, (3, 1, 1), (1, 0, 0), (2, 5, 13, 11)),         # K = 768, temporal borders
+    ("plain_320_64", 320, 64, (1, 1, 1), (0, 0, 0), (2, 3, 17, 19)),        # 20 K steps, narrow output
+]
+
+
+def _dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    return torch.device("cuda:0")
+
+
+@pytest.fixture
+def tune():
+    import sfhip
+    L = sfhip.lib()
+    yield L
+    for knob, v in ((0, 1), (1, -1), (2, 0), (3, 0), (4, 1), (5, 0), (6, 1), (10, 1), (11, -1), (12, 0)):
+        L.sf_conv_tune(knob, v)
+
+
+def _case(shape, seed=0):
+    name, cin, cout, k, p, (n, t, h, w) = shape
+    dev = _dev()
+    g = torch.Generator().manual_seed(seed + cin * 7 + cout)
+    x = torch.randn(n, cin, t, h, w, generator=g).to(dev)
+    wt = (torch.randn(cout, cin, *k, generator=g) / np.sqrt(cin * k[0] * k[1] * k[2])).to(dev)
+    bias = (torch.randn(cout, generator=g) * 0.1).to(dev)
+    dy = torch.randn(n, cout, t, h, w, generator=g).to(dev)
+    return x, wt, bias, dy
+
+
+def _rel(a, b):
+    return float((a.double() - b).abs().max() / b.abs().max())
+
+
+def _act(x):
+    import sfhip
+    return sfhip.Act(x.permute(0, 2, 3, 4, 1).contiguous())
+
+
+def _ncthw(a):
+    return a.buf[..., a.coff:a.coff + a.C].permute(0, 4, 1, 2, 3)
+
+
+# cfg: index into conv_wave.hip's CFGS = (13x2, 7x4, 7x2, 13x1) x (KS 4, KS 1); persist: sf_conv_tune(4, .)
+# (0 = one-pass kernels only, 1 = default level, 11 = the persistent form for every KS == 1 layer it covers)
+@pytest.mark.parametrize("persist", [0, 1, 11])
+@pytest.mark.parametrize("cfg", list(range(8)))
+@pytest.mark.parametrize("shape", SHAPES, ids=[s[0] for s in SHAPES])
+def test_forced_conv_wave_configuration(shape, cfg, persist, tune):
+    import sfhip
+    name, cin, cout, k, p, dims = shape
+    if persist and cfg % 2 == 0:
+        pytest.skip("KS = 4 configurations have no persistent form")
+    x, wt, bias, dy = _case(shape)
+    assert tune.sf_conv_tune(1, cfg) == 0 and tune.sf_conv_tune(4, persist) == 0
+    tune.sf_conv_tune(6, 0)  # conv_small has its own test
+    xa = _act(x)
+    wp, wtp = sfhip.pack_conv_weight_pair(wt)
+    # forward with the BN statistics taken in the epilogue
+    z, st = sfhip.conv(xa, wp, k, (1, 1, 1), p, bias=bias, stats=True)
+    ref = F.conv3d(x.double(), wt.double(), bias.double(), 1, p)
+    assert _rel(_ncthw(z), ref) < TOL, (name, cfg, persist)
+    if st is not None:
+        g = torch.rand(cout, device=x.device) + 0.5
+        b = torch.randn(cout, device=x.device)
+        mean, invstd, scale, shift = sfhip.bn_train_stats_merge(st, cout, g, b, 1e-5, 0.1, None, None)
+        flat = ref.transpose(0, 1).reshape(cout, -1)
+        rm, rv = flat.mean(1), flat.var(1, unbiased=False)
+        assert float((mean.double() - rm).abs().max()) < 1e-5 * float(rm.abs().max() + flat.std())
+        assert _rel(invstd, torch.rsqrt(rv + 1e-5)) < 1e-4
+    # epilogue variants: scale + residual + ReLU (the eval-mode form)
+    res = torch.randn_like(ref, dtype=torch.float32)
+    sc = torch.rand(cout, device=x.device) + 0.5
+    y = sfhip.conv(xa, wp, k, (1, 1, 1), p, scale=sc, bias=bias, relu=True, res=_act(res))
+    ref2 = F.relu(F.conv3d(x.double(), wt.double(), None, 1, p) * sc.double().view(1, -1, 1, 1, 1) +
+                  bias.double().view(1, -1, 1, 1, 1) + res.double())
+    assert _rel(_ncthw(y), ref2) < TOL, (name, cfg, persist)
+    # data gradient: written, then accumulated on top of itself
+    xd = x.double().requires_grad_(True)
+    F.conv3d(xd, wt.double(), None, 1, p).backward(dy.double())
+    dxa = sfhip.conv_dgrad(_act(dy), wtp, xa, k, (1, 1, 1), p)
+    assert _rel(_ncthw(dxa), xd.grad) < TOL, (name, cfg, persist)
+    sfhip.conv_dgrad(_act(dy), wtp, xa, k, (1, 1, 1), p, out=dxa, accumulate=True)
+    assert _rel(_ncthw(dxa), 2 * xd.grad) < TOL, (name, cfg, persist)
+    torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("rows", [16, 48, 100, 112])
+def test_forced_rows_per_tile(rows, tune):
+    """sf_conv_tune(2, rows): tiles with a runtime row count below TM * 16 (the planner picks 196 / 112 / ... rows
+    from M = 49 * 2^k; other batch sizes give other remainders)."""
+    import sfhip
+    shape = SHAPES[1]
+    name, cin, cout, k, p, dims = shape
+    x, wt, bias, dy = _case(shape, seed=rows)
+    tune.sf_conv_tune(6, 0)
+    wp, _ = sfhip.pack_conv_weight_pair(wt)
+    ref = F.conv3d(x.double(), wt.double(), bias.double(), 1, p)
+    for cfg in (0, 3, 5, 6):
+        tune.sf_conv_tune(1, cfg)
+        tune.sf_conv_tune(2, rows)
+        z = sfhip.conv(_act(x), wp, k, (1, 1, 1), p, bias=bias)
+        assert _rel(_ncthw(z), ref) < TOL, (cfg, rows)
+
+
+SMALL = [
+    ("sm_8_8_s3", 8, 8, (1, 3, 3), (0, 1, 1), (2, 4, 24, 28)),
+    ("sm_16_32_s3", 16, 32, (1, 3, 3), (0, 1, 1), (2, 3, 28, 28)),
+    ("sm_32_8_t3", 32, 8, (3, 1, 1), (1, 0, 0), (2, 6, 20, 20)),
+    ("sm_128_32_t3", 128, 32, (3, 1, 1), (1, 0, 0), (2, 4, 24, 24)),
+    ("sm_16_64_pw", 16, 64, (1, 1, 1), (0, 0, 0), (2, 4, 24, 24)),
+]
+
+
+@pytest.mark.parametrize("shape", SMALL, ids=[s[0] for s in SMALL])
+def test_conv_small_every_shape_it_covers(shape, tune):
+    """conv_small.hip forced onto every shape its instantiations cover (sf_conv_tune(6, 3) = SF_CONV_SMALL=2): forward
+    with epilogue statistics and the data gradient (flipped taps) against fp64."""
+    import sfhip
+    name, cin, cout, k, p, dims = shape
+    x, wt, bias, dy = _case(shape)
+    assert tune.sf_conv_tune(6, 3) == 0
+    wp, wtp = sfhip.pack_conv_weight_pair(wt)
+    z, st = sfhip.conv(_act(x), wp, k, (1, 1, 1), p, bias=bias, stats=True)
+    ref = F.conv3d(x.double(), wt.double(), bias.double(), 1, p)
+    assert _rel(_ncthw(z), ref) < TOL, name
+    if st is not None:
+        ones = torch.ones(cout, device=x.device)
+        mean, invstd, _, _ = sfhip.bn_train_stats_merge(st, cout, ones, ones, 1e-5, 0.1, None, None)
+        flat = ref.transpose(0, 1).reshape(cout, -1)
+        assert float((mean.double() - flat.mean(1)).abs().max()) < 1e-5 * float(flat.std() + flat.mean(1).abs().max())
+        assert _rel(invstd, torch.rsqrt(flat.var(1, unbiased=False) + 1e-5)) < 1e-4
+    xd = x.double().requires_grad_(True)
+    F.conv3d(xd, wt.double(), None, 1, p).backward(dy.double())
+    dxa = sfhip.conv_dgrad(_act(dy), wtp, _act(x), k, (1, 1, 1), p)
+    assert _rel(_ncthw(dxa), xd.grad) < TOL, name
+
+
+WG_SHAPES = [
+    ("s3_128_128", 128, 128, (1, 3, 3), (0, 1, 1), (3, 2, 19, 17)),
+    ("t3_256_192", 256, 192, (3, 1, 1), (1, 0, 0), (2, 5, 13, 12)),
+    ("plain_64_256", 64, 256, (1, 1, 1), (0, 0, 0), (3, 2, 23, 21)),
+    ("plain_320_72", 320, 72, (1, 1, 1), (0, 0, 0), (2, 3, 17, 19)),   # ragged channel blocks on both sides
+]
+
+
+@pytest.mark.parametrize("target", [0, 40, 200, 1536])
+@pytest.mark.parametrize("blocks", [-1, 0, 1, 2, 3])
+@pytest.mark.parametrize("shape", WG_SHAPES, ids=[s[0] for s in WG_SHAPES])
+def test_forced_wgrad_wave_configuration(shape, blocks, target, tune):
+    """conv_wgrad_wave.hip: every blocks-per-wavefront shape (sf_conv_tune(11, .): 1x1, 2x1, 1x2, 2x2) and several
+    workgroup targets = position-split counts (sf_conv_tune(12, .)) against the fp64 weight gradient, both through the
+    returned packed gradient and through the finish kernel that accumulates into a .grad-shaped tensor."""
+    import sfhip
+    name, cin, cout, k, p, dims = shape
+    if blocks == -1 and target not in (0, 200):
+        pytest.skip("planner's block shape: two split counts are enough")
+    x, wt, bias, dy = _case(shape)
+    assert tune.sf_conv_tune(11, blocks) == 0 and tune.sf_conv_tune(12, target) == 0
+    wd = wt.double().requires_grad_(True)
+    F.conv3d(x.double(), wd, None, 1, p).backward(dy.double())
+    dwp = sfhip.conv_wgrad(_act(x), _act(dy), cout, k, (1, 1, 1), p)
+    dw = sfhip.unpack_conv_weight_grad(dwp, wt.shape)
+    assert _rel(dw, wd.grad) < TOL, (name, blocks, target)
+    acc = torch.ones_like(wt)
+    sfhip.conv_wgrad(_act(x), _act(dy), cout, k, (1, 1, 1), p, finish_into=(acc, cin, 0))
+    assert _rel(acc - 1.0, wd.grad) < TOL, (name, blocks, target)

@@ -139,6 +139,27 @@ class _Staged(torch.nn.Module):
         return self.head(torch.relu(self.s5(self.s4_fuse(torch.relu(self.s4(torch.relu(self.s3(x))))))))
 
 
+class _FakeTape(object):
+    def __init__(self, model):
+        self.model, self.joins = model, ()
+
+
+def test_overlap_refuses_a_reordered_parameter_list():
+    """Chunk ranges are only complete when the buffer keeps the model's own parameter order (the reference's optimizer
+    builder groups BN and non-BN parameters, models/optimizer.py:25-40: such a list must not be cut)."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                    "efficient-slowfast_amd"))
+    from slowfast.utils.distributed import FlatGradients
+    model = _Staged()
+    weights = [p for p in model.parameters() if p.dim() > 1]
+    biases = [p for p in model.parameters() if p.dim() == 1]
+    flat = FlatGradients(weights + biases)
+    with pytest.raises(ValueError, match="model's own order"):
+        flat.overlap_with_backward(model, boundaries=("s5", "s4"))
+    FlatGradients(model.parameters()).overlap_with_backward(model, boundaries=("s5", "s4"))
+
+
 def _chunk_worker(rank, world, port, out):
     import sys
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
@@ -160,16 +181,28 @@ def _chunk_worker(rank, world, port, out):
             torch.nn.functional.cross_entropy(model(x), y).backward()
             if chunked:  # what the tape's milestones do during the HIP backward, in backward order
                 assert flat._cuts["s4"] < flat._cuts["s5"] < flat.flat.numel()
-                engine._MILESTONE_HOOK("s5", None)
-                engine._MILESTONE_HOOK("s4", None)
-                engine._MILESTONE_HOOK("s3", None)  # not a boundary: nothing happens
+                hook = engine._MILESTONE_HOOKS[model]
+                tape = _FakeTape(model)
+                hook("s5", _FakeTape(_Staged()))  # the backward of ANOTHER model: not this buffer's business
+                assert not flat._pending
+                hook("s5", tape)
+                hook("s4", tape)
+                hook("s3", tape)  # not a boundary: nothing happens
                 assert len(flat._pending) == 2 and flat._hi == flat._cuts["s4"]
+                with pytest.raises(RuntimeError, match="second backward"):
+                    hook("s5", _FakeTape(model))  # gradient accumulation on top of ranges already being reduced
             flat.all_reduce_mean()
             assert flat.chunks_last_step == (3 if chunked else 1)
             assert flat._hi == flat.flat.numel() and not flat._pending
             results.append(flat.flat.clone())
+            if chunked:  # a step that never reaches all_reduce_mean(): zero() waits for its chunks and starts over
+                flat.zero()
+                hook("s5", _FakeTape(model))
+                assert len(flat._pending) == 1
+                flat.zero()
+                assert not flat._pending and flat._hi == flat.flat.numel() and float(flat.flat.abs().sum()) == 0.0
             engine.set_grad_sink(False)
-            engine.set_milestone_hook(None)
+            engine.set_milestone_hook(None, model)
         assert torch.equal(results[0], results[1]), "chunked all-reduce differs from the single collective"
         if rank == 0:
             torch.save(results[1], out)
