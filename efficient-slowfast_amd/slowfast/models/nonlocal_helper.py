@@ -56,56 +56,62 @@ class Nonlocal(nn.Module):
             xp = engine.maxpool(x, ks, ks)
         phi = engine.conv_bn_act(xp, self.conv_phi)
         g = engine.conv_bn_act(xp, self.conv_g)
-        y = self._attend(theta, phi, g)
+        y = dense_attention(theta, phi, g, self.instantiation == "softmax", float(self.dim_inner) ** -0.5)
         return engine.conv_bn_act(y, self.conv_out, self.bn, relu=False, res=x, out_reserve=reserve)
 
-    def _attend(self, theta, phi, g):
-        N, d = theta.N, theta.C
-        nq, nk = theta.T * theta.H * theta.W, phi.T * phi.H * phi.W
-        if d % 16 != 0:
-            raise NotImplementedError("Nonlocal dim_inner must be a multiple of 16 on the HIP path (got %d)" % d)
-        assert theta.cs == d and phi.cs == d and g.cs == d and theta.coff == phi.coff == g.coff == 0
-        softmax = self.instantiation == "softmax"
-        dev = theta.buf.device
-        nk_pad = (nk + 15) // 16 * 16
-        inv_nk = None if softmax else torch.full((max(nk, d),), 1.0 / nk, dtype=torch.float32, device=dev)
 
-        def transposed(a):  # [N, Tp, Hp, Wp, d] -> [N][d][nk_pad]: the packed weights of "multiply by a"
-            t = sfhip.to_ncthw(a).view(N, d, nk)
-            return t if nk_pad == nk else F.pad(t, (0, nk_pad - nk)).contiguous()
+def dense_attention(theta, phi, g, softmax=True, sm_scale=1.0):
+    """Y = normalise(theta phi^T) g per sample with the score matrix MATERIALISED: softmax(sm_scale * S) over the keys,
+    or S / N_k (softmax=False: Nonlocal's "dot_product").  theta [N, ., d] queries, phi [N, ., d] keys, g [N, ., dv]
+    values, dense NDHWC buffers.  Taped.  Serves Nonlocal (d = 256 / 512) and SpatialAttention heads wider than the
+    flash kernels' 128 channels (SlowFastShuffleNet w2.0 / g3: d = 240 at s4_fuse, N <= 64 positions)."""
+    N, d, dv = theta.N, theta.C, g.C
+    nq, nk = theta.T * theta.H * theta.W, phi.T * phi.H * phi.W
+    if d % 16 != 0:
+        raise NotImplementedError("materialised attention needs a key width that is a multiple of 16 on the HIP "
+                                  "path (got %d)" % d)
+    assert theta.cs == d and phi.cs == d and g.cs == dv and theta.coff == phi.coff == g.coff == 0
+    assert phi.C == d and (g.T, g.H, g.W) == (phi.T, phi.H, phi.W)
+    dev = theta.buf.device
+    nk_pad = (nk + 15) // 16 * 16
+    inv_nk = None if softmax else torch.full((max(nk, d),), 1.0 / nk, dtype=torch.float32, device=dev)
 
-        def sample(a, n):
-            return sfhip.Act(a.buf[n:n + 1], a.coff, a.C)
+    def transposed(a):  # [N, Tp, Hp, Wp, c] -> [N][c][nk_pad]: the packed weights of "multiply by a"
+        t = sfhip.to_ncthw(a).view(N, a.C, nk)
+        return t if nk_pad == nk else F.pad(t, (0, nk_pad - nk)).contiguous()
 
-        one = (1, 1, 1)
-        P = sfhip.new_act(theta, N, theta.T, theta.H, theta.W, nk)
-        g_t = transposed(g)
-        y = sfhip.new_act(theta, N, theta.T, theta.H, theta.W, d)
-        for n in range(N):  # S_n = theta_n phi_n^T (x 1/N_k for dot_product)
-            sfhip.conv(sample(theta, n), phi.buf[n].view(nk, 1, d), one, scale=None if softmax else inv_nk[:nk],
-                       out=sample(P, n))
-        if softmax:
-            sfhip.row_softmax(P, scale=float(d) ** -0.5)
-        for n in range(N):  # Y_n = P_n g_n
-            sfhip.conv(sample(P, n), g_t[n].view(d, 1, nk_pad), one, out=sample(y, n))
-        t = engine.tape()
-        if t is not None:
-            def bwd():
-                dy = t.grad_of(y)
-                dth, dph, dg = t.grad_of(theta), t.grad_of(phi), t.grad_of(g)
-                phi_t = transposed(phi)
-                dP = sfhip.new_act(P, N, P.T, P.H, P.W, nk)
-                for n in range(N):  # dP_n = dY_n g_n^T ;  dg_n = P_n^T dY_n
-                    sfhip.conv(sample(dy, n), g.buf[n].view(nk, 1, d), one, scale=None if softmax else inv_nk[:nk],
-                               out=sample(dP, n))
-                    dgn = sfhip.conv_wgrad(sample(dy, n), sample(P, n), nk, one, cin_pad=d)
-                    dg.buf[n].view(nk, d).add_(dgn.view(nk, d))
-                if softmax:
-                    sfhip.row_softmax_bwd(P, dP, scale=float(d) ** -0.5)  # dP now holds dL/dS
-                for n in range(N):  # dtheta_n += dS_n phi_n ;  dphi_n = dS_n^T theta_n
-                    dthn = sample(dth, n)
-                    sfhip.conv(sample(dP, n), phi_t[n].view(d, 1, nk_pad), one, res=dthn, out=dthn)
-                    dpn = sfhip.conv_wgrad(sample(theta, n), sample(dP, n), nk, one, cin_pad=d)
-                    dph.buf[n].view(nk, d).add_(dpn.view(nk, d))
-            t.record(bwd)
-        return y
+    def sample(a, n):
+        return sfhip.Act(a.buf[n:n + 1], a.coff, a.C)
+
+    one = (1, 1, 1)
+    P = sfhip.new_act(theta, N, theta.T, theta.H, theta.W, nk)
+    g_t = transposed(g)
+    y = sfhip.new_act(theta, N, theta.T, theta.H, theta.W, dv)
+    for n in range(N):  # S_n = theta_n phi_n^T (x 1/N_k for dot_product)
+        sfhip.conv(sample(theta, n), phi.buf[n].view(nk, 1, d), one, scale=None if softmax else inv_nk[:nk],
+                   out=sample(P, n))
+    if softmax:
+        sfhip.row_softmax(P, scale=sm_scale)
+    for n in range(N):  # Y_n = P_n g_n
+        sfhip.conv(sample(P, n), g_t[n].view(dv, 1, nk_pad), one, out=sample(y, n))
+    t = engine.tape()
+    if t is not None:
+        def bwd():
+            dy = t.grad_of(y)
+            dth, dph, dg = t.grad_of(theta), t.grad_of(phi), t.grad_of(g)
+            phi_t = transposed(phi)
+            dP = sfhip.new_act(P, N, P.T, P.H, P.W, nk)
+            for n in range(N):  # dP_n = dY_n g_n^T ;  dg_n = P_n^T dY_n
+                sfhip.conv(sample(dy, n), g.buf[n].view(nk, 1, dv), one, scale=None if softmax else inv_nk[:nk],
+                           out=sample(dP, n))
+                dgn = sfhip.conv_wgrad(sample(dy, n), sample(P, n), nk, one, cin_pad=dv)
+                dg.buf[n].view(nk, dv).add_(dgn.view(nk, dv))
+            if softmax:
+                sfhip.row_softmax_bwd(P, dP, scale=sm_scale)  # dP now holds dL/dS
+            for n in range(N):  # dtheta_n += dS_n phi_n ;  dphi_n = dS_n^T theta_n
+                dthn = sample(dth, n)
+                sfhip.conv(sample(dP, n), phi_t[n].view(d, 1, nk_pad), one, res=dthn, out=dthn)
+                dpn = sfhip.conv_wgrad(sample(theta, n), sample(dP, n), nk, one, cin_pad=d)
+                dph.buf[n].view(nk, d).add_(dpn.view(nk, d))
+        t.record(bwd)
+    return y

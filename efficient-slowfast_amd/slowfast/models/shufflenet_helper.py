@@ -1,6 +1,8 @@
-"""ShuffleNet v1 stages (reference shufflenet_helper.py).  With GROUPS = 1 — the only group count for which
-the reference's two-pathway channel tables are constructible (its fast widths are not divisible by 2/3/4/8)
-— the 1x1 convs are plain GEMMs and channel_shuffle(x, 1) is the identity.  The stride-2 shortcut
+"""ShuffleNet v1 stages (reference shufflenet_helper.py).  SLOWFAST.GROUPS = 1 (the shipped YAML): the 1x1 convs are
+plain GEMMs and channel_shuffle(x, 1) is the identity.  GROUPS > 1 (the published w2.0 / g3 model, README.md:260,
+wdf_all_run_scripts/run_shufflenet_w2_g3.sh): the 1x1 convs are block-diagonal GEMMs — one launch per group on channel
+slices of the same buffers (engine.grouped_conv) — and channel_shuffle is index math of conv1's stores in eval mode,
+G strided channel copies behind the batch-statistics BN in training mode.  The stride-2 shortcut
 conv1x1 -> AvgPool3d((1,3,3),(1,2,2),(0,1,1)) is evaluated as pool -> conv1x1 (both linear, no bias: same
 result, a quarter of the GEMM), and its ReLU and the concat are the GEMM's epilogue and store slice."""
 import torch.nn as nn
@@ -38,9 +40,12 @@ class Bottleneck(nn.Module):
             )
 
     def forward(self, x, reserve=(0, 0)):
-        if self.conv1.groups != 1 or self.conv3.groups != 1:
-            raise NotImplementedError("SLOWFAST.GROUPS > 1: grouped 1x1 convolutions are not on the HIP path")
-        y = engine.conv_bn_act(x, self.conv1, self.bn1, relu=True)      # channel_shuffle(., 1) == identity
+        # conv1 runs with g = 1 behind a 24-channel input but the shuffle always uses self.groups
+        # (shufflenet_helper.py:47-51, 73): a grouped conv1 stores shuffled, a dense one is shuffled by copies
+        if self.conv1.groups == self.groups or self.groups == 1:
+            y = engine.conv_bn_act(x, self.conv1, self.bn1, relu=True, shuffle=self.groups > 1)
+        else:
+            y = engine.channel_shuffle(engine.conv_bn_act(x, self.conv1, self.bn1, relu=True), self.groups)
         y = engine.conv_bn_act(y, self.conv2, self.bn2, relu=False)
         if self.stride != 2:
             return engine.conv_bn_act(y, self.conv3, self.bn3, relu=True, res=x, out_reserve=reserve)

@@ -61,8 +61,40 @@ class SpatialAttention(nn.Module):
             t.record(bwd)
         return qkv
 
+    def _run_wide(self, x, scale, bias, relu, alpha, out):
+        """Heads wider than the flash kernels' 128 channels (SlowFastShuffleNet w2.0 / g3: C = 240 at s4_fuse, where
+        N = T*H*W <= 64): three dense 1x1x1 projections and the materialised-score attention of the Nonlocal block
+        (nonlocal_helper.dense_attention, no 1/sqrt(d)), then z = gamma * O + x (and the eval-mode BN affine / ReLU /
+        nearest T-upsample as one more small pass)."""
+        from .nonlocal_helper import dense_attention
+        c = self.input_channel
+        q = engine.conv_bn_act(x, self.query_conv)
+        k = engine.conv_bn_act(x, self.key_conv)
+        v = engine.conv_bn_act(x, self.value_conv)
+        o = dense_attention(q, k, v, softmax=True, sm_scale=1.0)
+        gvec = self.gamma.detach().expand(c).contiguous()
+        zero = torch.zeros_like(gvec)  # sf_affine_fwd takes scale and bias together
+        t = engine.tape()
+        if t is None:
+            plain = scale is None and bias is None and not relu and alpha == 1
+            z = sfhip.affine(o, scale=gvec, bias=zero, res=x, out=out if plain else None)
+            return z if plain else sfhip.affine(z, scale=scale, bias=bias, relu=relu, rep=alpha, out=out)
+        assert scale is None and not relu and alpha == 1 and out is None, "taped attention runs un-fused"
+        z = sfhip.affine(o, scale=gvec, bias=zero, res=x)
+
+        def bwd():  # z's buffer holds dL/dz (the BN backward wrote it in place), as in run()
+            gz = z if getattr(bwd, "grad_in_place", True) else t.grad_of(z)
+            t.add_pgrad(self.gamma, sfhip.rowdot(gz, o).sum().reshape(1))
+            sfhip.affine(gz, scale=self.gamma.detach().expand(c).contiguous(), bias=zero, out=t.grad_of(o))  # dO = gamma * dz
+            sfhip.axpy(gz, t.grad_of(x), 1.0, accumulate=True)                                     # residual
+
+        t.record(bwd)
+        return z
+
     def run(self, x, scale=None, bias=None, relu=False, alpha=1, out=None):
         c = self.input_channel
+        if c > 128:
+            return self._run_wide(x, scale, bias, relu, alpha, out)
         qkv = self.qkv(x)
         t = engine.tape()
         save = {} if t is not None else None

@@ -8,7 +8,7 @@ import torch
 from paramgen import fill_array, make_clip, sample_activation  # noqa: F401  (tests/golden on sys.path)
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-MODEL_CASES = ["shufflenetv2_cfg1", "slowfast_r50_s64", "dual_r50_s64", "ghostnet_w2_s64", "ghostnet_w2_s112", "mobilenetv2_w1_s64", "shufflenet_g1_s64", "dual_r50_subbn_s64", "i3d_r50_s64", "slow_r18_s64", "slowfast_nln_s64", "c2d_nln_s64"]
+MODEL_CASES = ["shufflenetv2_cfg1", "slowfast_r50_s64", "dual_r50_s64", "ghostnet_w2_s64", "ghostnet_w2_s112", "mobilenetv2_w1_s64", "shufflenet_g1_s64", "shufflenet_w2_g3_s64", "dual_r50_subbn_s64", "i3d_r50_s64", "slow_r18_s64", "slowfast_nln_s64", "c2d_nln_s64"]
 
 
 def load_case(name):

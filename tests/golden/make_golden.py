@@ -79,6 +79,15 @@ CASES = [
     dict(name="shufflenet_g1_s64", yaml="SLOWFAST_SHUFFLENET_8x8_R50_stepwise_multigrid.yaml",
          model="SlowFastShuffleNet", batch=2, t=16, alpha=4, size=64,
          over=["SLOWFAST.ALPHA", 4] + small(64, 16)),
+    # ... and the reference's PUBLISHED ShuffleNet-v1 configuration: width 2.0, 3 groups (README.md:260, 53.84 top-1;
+    # wdf_all_run_scripts/run_shufflenet_w2_g3.sh:12) — grouped 1x1 convs + channel_shuffle(., 3)
+    dict(name="shufflenet_w2_g3_s64", yaml="SLOWFAST_SHUFFLENET_8x8_R50_stepwise_multigrid.yaml",
+         model="SlowFastShuffleNet", batch=2, t=16, alpha=4, size=64,
+         over=["SLOWFAST.ALPHA", 4, "SLOWFAST.WIDTH_MULTI", 2.0, "SLOWFAST.GROUPS", 3] + small(64, 16),
+         grad_keys=["s1.pathway0_stem.0.weight", "s2.pathway0_channel_480.features.0.shortcut.0.weight",
+                    "s2.pathway0_channel_480.features.0.conv1.weight", "s3.pathway1_channel_120.features.2.conv2.weight",
+                    "s3.pathway1_channel_120.features.1.conv3.weight", "s3_fuse.bn_s2f.weight",
+                    "s4.pathway0_channel_1920.features.1.conv3.weight", "head.classifier.1.weight"]),
 ]
 
 GRAD_KEYS = {
@@ -214,7 +223,7 @@ def run_case(case, get_cfg, build_model):
                 s, amax, mean = sample_activation(a.numpy())
                 out["train/%s/%d" % (k, i)] = s
     params = dict(model.named_parameters())
-    for k in GRAD_KEYS[case["model"]]:
+    for k in case.get("grad_keys") or GRAD_KEYS[case["model"]]:
         g = params[k].grad
         s, amax, mean = sample_activation(g.numpy(), 4096)
         out["grad/" + k] = s
@@ -329,7 +338,7 @@ def init_digests(get_cfg, build_model):
     out = {}
     for case in CASES:
         if case["name"] not in ("shufflenetv2_cfg1", "slowfast_r50_s64", "dual_r50_s64", "ghostnet_w2_s64",
-                                "mobilenetv2_w1_s64", "shufflenet_g1_s64", "i3d_r50_s64"):
+                                "mobilenetv2_w1_s64", "shufflenet_g1_s64", "i3d_r50_s64", "shufflenet_w2_g3_s64"):
             continue
         cfg = get_cfg()
         cfg.merge_from_file(ref_yaml(case["yaml"]))

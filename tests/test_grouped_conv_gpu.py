@@ -1,0 +1,129 @@
+"""Grouped convolutions (1 < groups < channels) on the HIP path — engine.grouped_conv: one launch of the dense kernels
+per group on channel slices — against torch's nn.Conv3d(groups=G) on the same parameters: ShuffleNet-v1's grouped
+1x1x1 convs with channel_shuffle folded into the stores (shufflenet_helper.py:22-34, 48-63, 73) and ResNeXt's grouped
+1x3x3 (resnet_helper.py:196-205, RESNET.NUM_GROUPS > 1).  Eval (folded BN epilogue) and the taped training path
+(batch-statistics BN, gradients of input / weight / BN)."""
+import pytest
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+CASES = [
+    # name, Cin, Cout, groups, kernel, stride, pad, (N, T, H, W), shuffle
+    ("shuffle_v1_54_240_g3", 54, 240, 3, (1, 1, 1), (1, 1, 1), (0, 0, 0), (2, 3, 9, 11), True),
+    ("shuffle_v1_12_30_g3", 12, 30, 3, (1, 1, 1), (1, 1, 1), (0, 0, 0), (2, 8, 9, 11), True),
+    ("shuffle_v1_240_240_g3_noshuffle", 240, 240, 3, (1, 1, 1), (1, 1, 1), (0, 0, 0), (2, 3, 9, 11), False),
+    ("resnext_64_64_g4_s3", 64, 64, 4, (1, 3, 3), (1, 1, 1), (0, 1, 1), (2, 2, 12, 12), False),
+    ("resnext_128_128_g32_s3_stride2", 128, 128, 32, (1, 3, 3), (1, 2, 2), (0, 1, 1), (1, 2, 14, 14), False),
+]
+
+
+def _shuffle(x, g):
+    b, c = x.shape[:2]
+    return x.view(b, g, c // g, *x.shape[2:]).transpose(1, 2).reshape(x.shape)
+
+
+def _rel(a, b):
+    return float((a.double().cpu() - b.double().cpu()).abs().max() / b.double().abs().max().cpu())
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
+def test_grouped_conv_eval_and_train(case):
+    import sfhip
+    from slowfast.models import engine
+    name, cin, cout, G, k, s, p, (n, t, h, w), shuffle = case
+    dev = torch.device("cuda:0")
+    torch.manual_seed(len(name))
+    conv = nn.Conv3d(cin, cout, k, s, p, groups=G, bias=False).to(dev)
+    bn = nn.BatchNorm3d(cout).to(dev)
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5)
+        bn.bias.normal_()
+        bn.running_mean.normal_()
+        bn.running_var.uniform_(0.5, 1.5)
+    x = torch.randn(n, cin, t, h, w, device=dev)
+    xa = sfhip.from_ncthw(x)
+    # ---- eval: conv + folded BN + ReLU (+ shuffle as index math of the stores)
+    bn.eval()
+    with torch.no_grad():
+        ref = F.relu(bn.double()(F.conv3d(x.double(), conv.weight.double(), None, s, p, 1, G)))
+        ref = _shuffle(ref, G) if shuffle else ref
+        bn.float()
+        y = engine.conv_bn_act(xa, conv, bn, relu=True, shuffle=shuffle)
+    assert _rel(sfhip.to_ncthw(y), ref) < 2e-4, name
+    # ---- training: taped, batch statistics; gradients against autograd in fp64
+    bn.train()
+    up = torch.randn_like(ref, dtype=torch.float32)
+    t_ = engine.Tape()
+    with engine.taping(t_):
+        y = engine.conv_bn_act(xa, conv, bn, relu=True, shuffle=shuffle)
+    g = t_.grad_of(y)
+    g.buf[..., g.coff:g.coff + g.C].copy_(up.permute(0, 2, 3, 4, 1))
+    dxa = t_.grad_of(xa)  # the (zero-initialised) buffer the data gradients accumulate into
+    with torch.no_grad():
+        t_.backward()
+    xd = x.double().requires_grad_(True)
+    wd = conv.weight.detach().double().requires_grad_(True)
+    gam, bet = bn.weight.detach().double().requires_grad_(True), bn.bias.detach().double().requires_grad_(True)
+    z = F.conv3d(xd, wd, None, s, p, 1, G)
+    yr = F.relu(F.batch_norm(z, None, None, gam, bet, True, 0.1, bn.eps))
+    yr = _shuffle(yr, G) if shuffle else yr
+    assert _rel(sfhip.to_ncthw(y), yr.detach()) < 2e-4, name
+    (yr * up.double()).sum().backward()
+    dx = sfhip.to_ncthw(dxa)
+    assert _rel(t_.pgrads[conv.weight], wd.grad) < 5e-4, name
+    assert _rel(t_.pgrads[bn.weight], gam.grad) < 5e-4 and _rel(t_.pgrads[bn.bias], bet.grad) < 5e-4, name
+    assert _rel(dx, xd.grad) < 5e-4, name
+
+
+@pytest.mark.parametrize("c,red,thw", [(240, 1, (4, 2, 2)), (144, 1, (2, 5, 7)), (256, 8, (2, 4, 4))])
+def test_wide_head_spatial_attention(c, red, thw):
+    """SpatialAttention heads wider than the flash kernels' 128 channels (SlowFastShuffleNet w2.0 / g3: C = 240 at
+    s4_fuse) run on materialised scores (wdf_attention_helper.SpatialAttention._run_wide): module forward against an
+    fp64 restatement of wdf_attention_helper.py:41-54, eval and taped training (all parameter and input gradients)."""
+    import sfhip
+    from slowfast.models import engine
+    from slowfast.models.wdf_attention_helper import SpatialAttention
+    dev = torch.device("cuda:0")
+    torch.manual_seed(c)
+    m = SpatialAttention(c, reduction=red).to(dev)
+    with torch.no_grad():
+        m.gamma.fill_(0.6)
+        for cv in (m.query_conv, m.key_conv):
+            cv.weight.mul_(0.5)
+    b, (t, h, w) = 2, thw
+    x = torch.randn(b, c, t, h, w, device=dev)
+    up = torch.randn(b, c, t, h, w, device=dev)
+
+    def ref(xd, params):
+        wq, bq, wk, bk, wv, bv, gam = params
+        n = t * h * w
+        q = F.conv3d(xd, wq, bq).view(b, -1, n).permute(0, 2, 1)
+        k = F.conv3d(xd, wk, bk).view(b, -1, n)
+        v = F.conv3d(xd, wv, bv).view(b, -1, n)
+        p = torch.softmax(torch.bmm(q, k), dim=-1)
+        return gam * torch.bmm(v, p.permute(0, 2, 1)).view(b, c, t, h, w) + xd
+
+    names = ("query_conv.weight", "query_conv.bias", "key_conv.weight", "key_conv.bias", "value_conv.weight",
+             "value_conv.bias", "gamma")
+    pd = dict(m.named_parameters())
+    params = [pd[k].detach().double().requires_grad_(True) for k in names]
+    xd = x.double().requires_grad_(True)
+    yr = ref(xd, params)
+    with torch.no_grad():
+        y = m(x)
+    assert _rel(y, yr.detach()) < 2e-5
+    tape = engine.Tape()
+    xa = sfhip.from_ncthw(x)
+    with engine.taping(tape):
+        z = m.run(xa)
+    z.buf.copy_(up.permute(0, 2, 3, 4, 1))  # dL/dz arrives IN PLACE over z (the BN backward's convention)
+    dxa = tape.grad_of(xa)
+    with torch.no_grad():
+        tape.backward()
+    (yr * up.double()).sum().backward()
+    assert _rel(sfhip.to_ncthw(dxa), xd.grad) < 2e-4
+    for k, pr in zip(names, params):
+        assert _rel(tape.pgrads[pd[k]].reshape(pr.shape), pr.grad) < 2e-4, k

@@ -104,7 +104,8 @@ def test_init_weights_semantics():
 
 
 @pytest.mark.parametrize("name", ["shufflenetv2_cfg1", "slowfast_r50_s64", "dual_r50_s64", "ghostnet_w2_s64",
-                                  "mobilenetv2_w1_s64", "shufflenet_g1_s64", "i3d_r50_s64"])
+                                  "mobilenetv2_w1_s64", "shufflenet_g1_s64", "i3d_r50_s64",
+                                  "shufflenet_w2_g3_s64"])
 def test_fresh_init_is_bit_identical_to_the_reference(name):
     """build_model(cfg) under torch.manual_seed(0) yields the reference's parameters BIT FOR BIT (tests/golden/
     init_digests.json: SHA-256 per tensor of the reference's fresh state_dict, make_golden.py::init_digests): same
