@@ -1,0 +1,444 @@
+// conv_bx.hip — long-reduction dense convolutions as an implicit GEMM on the BF16 matrix pipe with fp32-exact
+// operands (gfx950).
+//
+// gfx950's f32-input MFMA runs at the vector rate; its bf16 MFMA is 16x that.  Every fp32 operand is the exact sum of
+// three bf16 pieces and six v_mfma_f32_32x32x16_bf16 per product give the fp32 product to fp32 rounding level (bx.h),
+// at 6/16 of the f32 MFMA's cycles.  The long-K layers of the Slow pathway (1x3x3 and 3x1x1 over 128..2048 channels,
+// resnet_helper.py:182-223) are MFMA-bound at ~0.7 of the f32 peak in conv_wave.hip — that instruction is the ceiling —
+// so they run here instead:
+//
+//   * operands as PLANES, written once per call: the activation rows as planes[3][rows + 1][Cin] bf16 (row `rows` is
+//     zeros: every padded tap and every ragged tile row points there, so the loop has no predicate) and the packed
+//     weights as planes[3][Cout + 1][taps * Cin] (sf_bx_split_rows: one pass, 4 B read + 6 B written per element);
+//   * workgroup = 8 wavefronts, tile 256 x BN (BN = 256 | 128) outputs, K step 16: per step and plane the tile's rows
+//     arrive by direct-to-LDS buffer loads (buffer_load_dwordx4 ... lds, 1 KiB = 32 rows x 32 B per wave-instruction,
+//     no staging VGPRs), three stages deep with a counted vmcnt and ONE raw barrier per step.  A row's two 16-byte
+//     chunks are swapped in rows 16..31 of each 32-row block (on the SOURCE address — the LDS image of an LDS-DMA is
+//     lane-linear), which makes every ds_read_b128 fragment read conflict-free;
+//   * wavefront tile 64 x BN/2 = 2 x (BN/64) MFMA tiles, 6 MFMAs per tile and step on three A and three B pieces;
+//   * short-M layers (res4 / res5: 49 / 26 tiles) share a tile's K steps between S workgroups; every workgroup stores a
+//     raw fp32 partial tile to ws[S][M][Cout] and the split-K finish kernel of conv_igemm.hip sums them in split order
+//     and applies the epilogue (scale, bias, residual, activation, scattered stores) — no float atomics.
+//
+// Replaces (same descriptors, same results to fp32 rounding): sf_conv_fwd_ws for the shapes sf_conv_bx_takes accepts,
+// forward and (desc.transposed) data gradient.
+#include "bx.h"
+#include <stdlib.h>
+
+namespace {
+
+constexpr int BXC_BM = 256;      // rows per tile
+constexpr int BXC_BK = 16;       // channels per K step (one 32x32x16 MFMA k extent)
+constexpr int BXC_STAGES = 3;
+constexpr int BXC_ROWB = BXC_BK * 2;            // bytes of a row per plane and step
+constexpr int BXC_A_STAGE = 3 * BXC_BM * BXC_ROWB;  // 24 KiB
+
+struct BxArgs {
+  sf_conv_desc d;
+  const unsigned short* ap;  // activation planes [3][a_rows + 1][Cin]
+  const unsigned short* bp;  // weight planes [3][Cout + 1][K]
+  float* ws;                 // [S][M][Cout] (S > 1, or an epilogue the kernel does not do itself)
+  const float* scale;        // DIRECT epilogue: out = act(scale * acc + bias + res)
+  const float* bias;
+  const float* res;
+  float* out;
+  int M, ntaps, cpk, nk, S, nk_per, nb_n, tiles;
+  unsigned a_rows, a_bytes, b_bytes;      // rows of a plane (the zero row's index), bytes of all three planes
+  unsigned a_plane, b_plane;              // bytes per plane
+  unsigned wo_mul, wo_sh, ho_mul, ho_sh, to_mul, to_sh;
+};
+
+__device__ __forceinline__ unsigned mdiv(unsigned n, unsigned mul, unsigned sh) {
+  return mul ? (__umulhi(n, mul) >> sh) : n;
+}
+
+typedef __attribute__((address_space(3))) void lds_void;
+
+template <int BN, bool DIRECT>
+__global__ __launch_bounds__(512, 2) void conv_bx_kernel(const BxArgs p) {
+  constexpr int B_STAGE = 3 * BN * BXC_ROWB;
+  constexpr int STAGE = BXC_A_STAGE + B_STAGE;
+  constexpr int NT = BN / 64;  // 32-column MFMA tiles per wavefront
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const sf_conv_desc& d = p.d;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave & 3, wn = wave >> 2;
+  // ---- which tile and which share of the K steps
+  const int bid = xcd_remap(blockIdx.x, p.tiles * p.S);
+  const int split = bid / p.tiles, tile = bid - split * p.tiles;
+  const int tile_m = tile / p.nb_n, tile_n = tile - tile_m * p.nb_n;
+  const int m0 = tile_m * BXC_BM, n0 = tile_n * BN;
+  const int ks0 = split * p.nk_per;
+  const int ks1 = ks0 + p.nk_per < p.nk ? ks0 + p.nk_per : p.nk;
+  const int nsteps = ks1 - ks0;
+
+  // ---- loader role.  A: wave w brings rows 32w .. 32w+31 of the tile (all three planes); lane = (row, chunk).
+  const int lrow = lane >> 1;
+  const unsigned lchunk = (unsigned)((lane & 1) ^ ((lrow >> 4) & 1)) * 16u;  // source chunk (swizzle, see header)
+  const int am = m0 + 32 * wave + lrow;
+  const bool a_ok = am < p.M;
+  int t0, h0, w0, nimg;
+  {
+    const unsigned mm = a_ok ? (unsigned)am : 0u;
+    const unsigned q1 = mdiv(mm, p.wo_mul, p.wo_sh);
+    const unsigned wo = mm - q1 * (unsigned)d.Wo;
+    const unsigned q2 = mdiv(q1, p.ho_mul, p.ho_sh);
+    const unsigned ho = q1 - q2 * (unsigned)d.Ho;
+    const unsigned q3 = mdiv(q2, p.to_mul, p.to_sh);
+    const unsigned to = q2 - q3 * (unsigned)d.To;
+    nimg = (int)q3;
+    t0 = d.transposed ? (int)to + d.pT : (int)to * d.sT - d.pT;
+    h0 = d.transposed ? (int)ho + d.pH : (int)ho * d.sH - d.pH;
+    w0 = d.transposed ? (int)wo + d.pW : (int)wo * d.sW - d.pW;
+  }
+  const unsigned row_bytes = (unsigned)d.Cin * 2u;
+  auto a_voff = [&](int kt, int kh, int kw) -> unsigned {  // byte offset of this lane's row for a tap (or the zero row)
+    const int ti = d.transposed ? t0 - kt * d.dT : t0 + kt * d.dT;
+    const int hi = d.transposed ? h0 - kh * d.dH : h0 + kh * d.dH;
+    const int wi = d.transposed ? w0 - kw * d.dW : w0 + kw * d.dW;
+    const bool ok = a_ok && (unsigned)ti < (unsigned)d.Ti && (unsigned)hi < (unsigned)d.Hi && (unsigned)wi < (unsigned)d.Wi;
+    const unsigned r = ok ? (unsigned)(((nimg * d.Ti + ti) * d.Hi + hi) * d.Wi + wi) : p.a_rows;
+    return r * row_bytes + lchunk;
+  };
+  // B: BN = 256: wave w brings rows 32w .. 32w+31; BN = 128: waves 0..3 only
+  const bool b_loader = BN == 256 || wave < 4;
+  const int bn = n0 + 32 * wave + lrow;
+  const unsigned kbytes = (unsigned)p.nk * (unsigned)BXC_ROWB;  // bytes of a weight row per plane
+  const unsigned b_voff = (unsigned)((b_loader && bn < d.Cout) ? bn : d.Cout) * kbytes + lchunk;
+
+  const __amdgpu_buffer_rsrc_t a_rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.ap, 0, p.a_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t b_rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.bp, 0, p.b_bytes, 0x00020000);
+
+  // ---- K iteration state of the loader (runs two steps ahead of the MFMAs)
+  int l_tap = ks0 / p.cpk;
+  int l_c = ks0 - l_tap * p.cpk;  // 16-channel chunk within the tap
+  int l_kw = l_tap % d.kW, l_kh = (l_tap / d.kW) % d.kH, l_kt = l_tap / (d.kW * d.kH);
+  unsigned l_voff = a_voff(l_kt, l_kh, l_kw);
+  int l_ks = ks0;
+  auto issue = [&](int stage) {
+    char* const sa = smem + stage * STAGE + wave * 1024;
+    const unsigned a_so = (unsigned)l_c * (unsigned)BXC_ROWB;
+#pragma unroll
+    for (int pc = 0; pc < 3; ++pc)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rs, (lds_void*)(sa + pc * (BXC_BM * BXC_ROWB)), 16, l_voff,
+                                               a_so + (unsigned)pc * p.a_plane, 0, 0);
+    if (b_loader) {
+      char* const sb = smem + stage * STAGE + BXC_A_STAGE + wave * 1024;
+      const unsigned b_so = (unsigned)l_ks * (unsigned)BXC_ROWB;
+#pragma unroll
+      for (int pc = 0; pc < 3; ++pc)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(b_rs, (lds_void*)(sb + pc * (BN * BXC_ROWB)), 16, b_voff,
+                                                 b_so + (unsigned)pc * p.b_plane, 0, 0);
+    }
+    ++l_ks;
+    if (++l_c == p.cpk) {  // next tap
+      l_c = 0;
+      if (++l_kw == d.kW) {
+        l_kw = 0;
+        if (++l_kh == d.kH) { l_kh = 0; ++l_kt; }
+      }
+      l_voff = a_voff(l_kt, l_kh, l_kw);
+    }
+  };
+
+  // ---- fragment addresses: lane (r = lane & 31, h = lane >> 5) reads 16 bytes of row r, k = 8h .. 8h+7
+  const unsigned frag_lane = (unsigned)(lane & 31) * BXC_ROWB + (unsigned)(((lane >> 5) ^ ((lane >> 4) & 1)) * 16);
+  const unsigned a_frag = (unsigned)(wm * 64) * BXC_ROWB + frag_lane;
+  const unsigned b_frag = BXC_A_STAGE + (unsigned)(wn * (BN / 2)) * BXC_ROWB + frag_lane;
+
+  f32x16 acc[2][NT];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  if (nsteps > 0) issue(0);
+  if (nsteps > 1) issue(1);
+  for (int it = 0; it < nsteps; ++it) {
+    // this wave's loads of step `it` have landed once at most the loads of step it + 1 are outstanding
+    if (it + 1 < nsteps) {
+      if (b_loader) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();  // ... and every other wave's: the stage is complete, and stage it - 1 is free
+    if (it + 2 < nsteps) issue((it + 2) % BXC_STAGES);
+    const char* const st = smem + (it % BXC_STAGES) * STAGE;
+    u32x4 af[2][3], bf[NT][3];
+#pragma unroll
+    for (int pc = 0; pc < 3; ++pc) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+        af[i][pc] = *reinterpret_cast<const u32x4*>(st + a_frag + pc * (BXC_BM * BXC_ROWB) + i * (32 * BXC_ROWB));
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+        bf[j][pc] = *reinterpret_cast<const u32x4*>(st + b_frag + pc * (BN * BXC_ROWB) + j * (32 * BXC_ROWB));
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) acc[i][j] = mfma_split(af[i], bf[j], acc[i][j]);
+  }
+
+  // ---- an accumulator register holds column lane & 31 of rows (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5): 128
+  // contiguous bytes per half-wave and row.  DIRECT (one workgroup per tile, dense stores): the conv epilogue here;
+  // otherwise the raw partial tile -> ws[split][m][n] for the finish kernel
+  const int col = lane & 31, rsub = 4 * (lane >> 5);
+  if (DIRECT) {
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int n = n0 + wn * (BN / 2) + j * 32 + col;
+      const bool n_ok = n < d.Cout;
+      const float sc = (p.scale && n_ok) ? p.scale[n] : 1.f;
+      const float bi = (p.bias && n_ok) ? p.bias[n] : 0.f;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int m = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + rsub;
+          if (m < p.M && n_ok) {
+            float v = acc[i][j][e] * sc + bi;
+            if (p.res) v += p.res[(long)m * d.res_cs + d.res_coff + n];
+            p.out[(long)m * d.out_cs + d.out_coff + n] = sf_act(v, d.act);
+          }
+        }
+    }
+    return;
+  }
+  float* const wsp = p.ws + (long)split * p.M * d.Cout;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int n = n0 + wn * (BN / 2) + j * 32 + col;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int m = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + rsub;
+        if (m < p.M && n < d.Cout) wsp[(long)m * d.Cout + n] = acc[i][j][e];
+      }
+    }
+}
+
+// fp32 rows (pitch cs, C channels from coff) -> three bf16 piece planes [3][rows + 1][C]; row `rows` of every plane is
+// written as zeros.  Thread = 8 channels of a row (32 B read, 3 x 16 B written).
+__global__ __launch_bounds__(256) void bx_split_rows_kernel(const float* __restrict__ x, int cs, int coff, long rows,
+                                                            int C, unsigned short* __restrict__ planes) {
+  const int c8 = C >> 3;
+  const long total = (rows + 1) * c8;
+  const long plane = (rows + 1) * (long)C;
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const long r = idx / c8;
+    const int c = (int)(idx - r * c8) * 8;
+    u32x4 w[3];
+    if (r < rows) {
+      const f32x4 v0 = *reinterpret_cast<const f32x4*>(x + r * cs + coff + c);
+      const f32x4 v1 = *reinterpret_cast<const f32x4*>(x + r * cs + coff + c + 4);
+      split_pair(v0[0], v0[1], w, 0);
+      split_pair(v0[2], v0[3], w, 1);
+      split_pair(v1[0], v1[1], w, 2);
+      split_pair(v1[2], v1[3], w, 3);
+    } else {
+      w[0] = w[1] = w[2] = (u32x4){0u, 0u, 0u, 0u};
+    }
+#pragma unroll
+    for (int pc = 0; pc < 3; ++pc) *reinterpret_cast<u32x4*>(planes + pc * plane + r * C + c) = w[pc];
+  }
+}
+
+void magic(unsigned dv, unsigned* mul, unsigned* sh) {
+  if (dv <= 1) { *mul = 0; *sh = 0; return; }
+  unsigned l = 0;
+  while ((1u << l) < dv) ++l;
+  const unsigned long long num = 1ull << (31 + l);
+  *mul = (unsigned)((num + dv - 1) / dv);
+  *sh = l - 1;
+}
+
+int g_bx_enable = 1;  // sf_conv_tune(7, e)
+int g_bx_dbg = 0;     // sf_conv_tune(8, mask): timing ablations (microbenchmarks): 1 = skip the operand splits (planes of
+                      // the previous call), 2 = skip the finish kernel, 4 = skip the GEMM
+
+bool bx_enabled() {
+  static const int env_on = [] {
+    const char* e = getenv("SF_CONV_BX");
+    return e ? atoi(e) : 1;
+  }();
+  return env_on && g_bx_enable;
+}
+
+struct BxPlan { int bn, S, nk, nk_per, nb_n, tiles, direct; long a_rows; };
+
+// Which shapes run here: long reductions (>= 32 K steps = 512 channel-taps) into >= 128 output channels over >= 2048
+// positions — the 1x3x3 / 3x1x1 layers of res3..res5 and the 1x1x1 layers over >= 512 channels.  `gate`: also apply
+// the measured win / lose rule (tools/microbench/conv_bx_bench.py); the shape rules alone decide what the kernel CAN run.
+bool bx_plan(const sf_conv_desc* d, BxPlan* pl, bool gate = true) {
+  if (!bx_enabled()) return false;
+  const long M = (long)d->N * d->To * d->Ho * d->Wo;
+  const int ntaps = d->kT * d->kH * d->kW;
+  if ((d->Cin % 16) || d->cin_pad != d->Cin || (d->in_cs % 4) || (d->in_coff % 4)) return false;
+  if (d->Cout < 128 || (d->Cout % 4) || d->out_cmul != 1) return false;
+  const int nk = ntaps * (d->Cin / BXC_BK);
+  if (nk < 32 || M < 2048 || M > 0x7fffffffL) return false;
+  if (d->transposed && (d->sT != 1 || d->sH != 1 || d->sW != 1)) return false;
+  const long a_rows = (long)d->N * d->Ti * d->Hi * d->Wi;
+  if (3 * (a_rows + 1) * d->Cin * 2 > 0xfffffff0L) return false;
+  if (3L * (d->Cout + 1) * nk * BXC_ROWB > 0xfffffff0L) return false;
+  pl->bn = d->Cout >= 256 ? 256 : 128;
+  pl->nb_n = sf_cdiv(d->Cout, pl->bn);
+  pl->tiles = sf_cdiv(M, BXC_BM) * pl->nb_n;
+  pl->nk = nk;
+  pl->a_rows = a_rows;
+  // Time model in microseconds (fitted on MI355X, conv_bx_bench.py): a workgroup needs ~2.0 us per K step of a 256-wide
+  // tile (96 MFMAs per SIMD at ~70 % of the pipe), 1.1 for a 128-wide one; the launch ends with its busiest CU; S > 1
+  // writes S partial tiles and the finish kernel reads them back (~4 TB/s each way) — one workgroup per tile stores the
+  // finished outputs itself.
+  const bool scatter = d->os_T > 1 || d->os_H > 1 || d->os_W > 1;
+  const double step_us = pl->bn == 256 ? 2.0 : 1.1;
+  const double out_mb = (double)M * d->Cout * 4e-6;
+  int best = 1;
+  double best_t = 1e30;
+  for (int S = 1; S <= 16 && nk / S >= 8; ++S) {
+    const long wg = (long)pl->tiles * S;
+    if (wg > 2048) break;
+    const long rounds = sf_cdiv(wg, 256);
+    double t = 6.0 + (double)rounds * sf_cdiv(nk, S) * step_us;
+    if (S > 1 || scatter) t += 3.0 + out_mb * (2.0 * S + 1.0) / 4.0;  // partials out + back in, outputs out; MB / (4 TB/s) = 0.25 us
+    else t += out_mb / 4.0;
+    if (t < best_t - 1e-9) { best_t = t; best = S; }
+  }
+  static const int forced_s = [] { const char* e = getenv("SF_CONV_BX_S"); return e ? atoi(e) : 0; }();
+  if (forced_s > 0 && nk / forced_s >= 1) best = forced_s;
+  pl->S = best;
+  pl->nk_per = sf_cdiv(nk, best);
+  pl->direct = (best == 1 && !scatter) ? 1 : 0;
+  if (gate && g_bx_enable < 2) {
+    // against conv_wave.hip at ~100 TFLOP/s (x 0.9 for the short reductions) plus this path's activation split
+    const double flop = 2.0 * M * (double)nk * BXC_BK * d->Cout;
+    const double wave_us = flop / (nk >= 64 ? 103e6 : 92e6);
+    const double split_us = 4.0 + (double)a_rows * d->Cin * 10e-6 / 3.0;  // 10 B per element at ~3 TB/s
+    if (best_t + split_us > 0.93 * wave_us) return false;
+  }
+  return true;
+}
+
+long align4(long floats) { return (floats + 3) & ~3L; }
+long a_plane_floats(const sf_conv_desc* d, long a_rows) { return align4((3 * (a_rows + 1) * d->Cin + 1) / 2); }
+long b_plane_floats(const sf_conv_desc* d, int nk) { return align4((3L * (d->Cout + 1) * nk * BXC_BK + 1) / 2); }
+
+template <int BN, bool DIRECT>
+int launch_bx(const BxArgs& a, int grid, hipStream_t stream) {
+  constexpr int lds = BXC_STAGES * (BXC_A_STAGE + 3 * BN * BXC_ROWB);
+  static SfLdsAttr at;
+  if (!sf_ensure_dyn_lds(at, reinterpret_cast<const void*>(conv_bx_kernel<BN, DIRECT>), lds)) return SF_ELAUNCH;
+  hipLaunchKernelGGL((conv_bx_kernel<BN, DIRECT>), dim3(grid), dim3(512), lds, stream, a);
+  SF_CHECK_LAUNCH();
+  return SF_OK;
+}
+
+}  // namespace
+
+int sf_conv_bx_tune(int value) { g_bx_enable = value; return SF_OK; }  // 0 off, 1 on where it wins, 2 every shape it covers
+int sf_conv_bx_dbg(int value) { g_bx_dbg = value; return SF_OK; }
+
+int sf_conv_bx_takes(const sf_conv_desc* d) {
+  BxPlan pl;
+  return bx_plan(d, &pl) ? 1 : 0;
+}
+
+// bf16 elements of the planes [3][rows + 1][C] of a [rows][C] fp32 operand
+extern "C" long sf_bx_planes_elems(long rows, int C) { return 3 * (rows + 1) * (long)C; }
+
+int sf_bx_split_rows(const float* x, int cs, int coff, long rows, int C, unsigned short* planes, hipStream_t s) {
+  if ((C & 7) || (cs & 3) || (coff & 3) || !sf_aligned16(x) || !sf_aligned16(planes)) return SF_EALIGN;
+  const long total = (rows + 1) * (C >> 3);
+  long blocks = (total + 255) / 256;
+  if (blocks > 256 * 16) blocks = 256 * 16;
+  hipLaunchKernelGGL(bx_split_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, cs, coff, rows, C, planes);
+  SF_CHECK_LAUNCH();
+  return SF_OK;
+}
+
+// x [rows][cs] fp32 (C channels from coff) -> planes: every fp32 value as the exact sum of three bf16 pieces
+extern "C" int sf_bx_split(const float* x, int cs, int coff, long rows, int C, unsigned short* planes, void* stream) {
+  if (!x || !planes || rows <= 0 || C <= 0) return SF_EINVAL;
+  return sf_bx_split_rows(x, cs, coff, rows, C, planes, (hipStream_t)stream);
+}
+
+// workspace floats of sf_conv_fwd_bx: the planes the call has to make itself + the S partial tiles (0: shape not served)
+extern "C" long sf_conv_bx_ws_floats(const sf_conv_desc* d, int have_in_planes, int have_w_planes) {
+  BxPlan pl;
+  if (!d || !bx_plan(d, &pl)) return 0;
+  const long M = (long)d->N * d->To * d->Ho * d->Wo;
+  return 4 + (have_in_planes ? 0 : a_plane_floats(d, pl.a_rows)) + (have_w_planes ? 0 : b_plane_floats(d, pl.nk)) +
+         (pl.direct ? 0 : (long)pl.S * M * d->Cout);
+}
+
+int sf_conv_splitk_finish(const sf_conv_desc* d, const float* ws, int S, const float* scale, const float* bias,
+                          const float* res, float* out, hipStream_t s);  // conv_igemm.hip
+
+// Returns 1 when the shape is not taken, else SF_OK / an error code.  in_planes / w_planes: sf_bx_split of the input
+// view ([rows of the input][Cin]) and of the packed weights ([Cout][taps * Cin]), or NULL (made here, in ws).
+int sf_conv_bx_try(const sf_conv_desc* d, const float* in, const unsigned short* in_planes, const float* w_packed,
+                   const unsigned short* w_planes, const float* scale, const float* bias, const float* res, float* out,
+                   float* ws, hipStream_t stream) {
+  BxPlan pl;
+  if (!ws || !bx_plan(d, &pl)) return 1;
+  if (!sf_aligned16(in) || !sf_aligned16(w_packed) || !sf_aligned16(ws)) return 1;
+  if ((in_planes && !sf_aligned16(in_planes)) || (w_planes && !sf_aligned16(w_planes))) return SF_EALIGN;
+  const long M = (long)d->N * d->To * d->Ho * d->Wo;
+  float* cur = ws;
+  int rc = SF_OK;
+  if (!in_planes) {
+    unsigned short* const ap = reinterpret_cast<unsigned short*>(cur);
+    cur += a_plane_floats(d, pl.a_rows);
+    if (!(g_bx_dbg & 1)) rc = sf_bx_split_rows(in, d->in_cs, d->in_coff, pl.a_rows, d->Cin, ap, stream);
+    if (rc != SF_OK) return rc;
+    in_planes = ap;
+  }
+  if (!w_planes) {
+    unsigned short* const bp = reinterpret_cast<unsigned short*>(cur);
+    cur += b_plane_floats(d, pl.nk);
+    if (!(g_bx_dbg & 1)) rc = sf_bx_split_rows(w_packed, pl.nk * BXC_BK, 0, d->Cout, pl.nk * BXC_BK, bp, stream);
+    if (rc != SF_OK) return rc;
+    w_planes = bp;
+  }
+  BxArgs a;
+  a.d = *d;
+  a.ap = in_planes; a.bp = w_planes; a.ws = cur;
+  a.scale = scale; a.bias = bias; a.res = res; a.out = out;
+  a.M = (int)M;
+  a.ntaps = d->kT * d->kH * d->kW;
+  a.cpk = d->Cin / BXC_BK;
+  a.nk = pl.nk; a.S = pl.S; a.nk_per = pl.nk_per; a.nb_n = pl.nb_n; a.tiles = pl.tiles;
+  a.a_rows = (unsigned)pl.a_rows;
+  a.a_plane = (unsigned)((pl.a_rows + 1) * d->Cin * 2);
+  a.a_bytes = 3u * a.a_plane;
+  a.b_plane = (unsigned)((long)(d->Cout + 1) * pl.nk * BXC_ROWB);
+  a.b_bytes = 3u * a.b_plane;
+  magic((unsigned)d->Wo, &a.wo_mul, &a.wo_sh);
+  magic((unsigned)d->Ho, &a.ho_mul, &a.ho_sh);
+  magic((unsigned)d->To, &a.to_mul, &a.to_sh);
+  const int grid = pl.tiles * pl.S;
+  if (!(g_bx_dbg & 4)) {
+    if (pl.bn == 256) rc = pl.direct ? launch_bx<256, true>(a, grid, stream) : launch_bx<256, false>(a, grid, stream);
+    else rc = pl.direct ? launch_bx<128, true>(a, grid, stream) : launch_bx<128, false>(a, grid, stream);
+    if (rc != SF_OK) return rc;
+  }
+  if (pl.direct || (g_bx_dbg & 2)) return SF_OK;
+  return sf_conv_splitk_finish(d, cur, pl.S, scale, bias, res, out, stream);
+}
+
+// sf_conv_fwd_ws with the operands' bf16 piece planes handed in (sf_bx_split of the input view and / or of the packed
+// weights; either may be NULL): a weight's planes are made once per optimizer step, an activation's once for its
+// forward conv and its weight gradient.  SF_EINVAL when the shape is not served (sf_conv_bx_ws_floats(d, ., .) == 0).
+extern "C" int sf_conv_fwd_bx(const sf_conv_desc* d, const float* in, const unsigned short* in_planes,
+                              const float* w_packed, const unsigned short* w_planes, const float* scale,
+                              const float* bias, const float* res, float* out, float* ws, void* stream) {
+  if (!d || !in || !w_packed || !out || !ws) return SF_EINVAL;
+  const int rc = sf_conv_bx_try(d, in, in_planes, w_packed, w_planes, scale, bias, res, out, ws, (hipStream_t)stream);
+  return rc == 1 ? SF_EINVAL : rc;
+}

@@ -384,6 +384,27 @@ __global__ void conv_splitk_finish_kernel(const ConvArgs p) {
   p.out[orow * d.out_cs + d.out_coff + (long)n * d.out_cmul] = v;
 }
 
+// The same for dense 16-byte addressable outputs: four channels per thread, the S partial loads in flight together.
+__global__ void conv_splitk_finish4_kernel(const ConvArgs p) {
+  const sf_conv_desc& d = p.d;
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  const int c4 = d.Cout >> 2;
+  const long total4 = (long)p.M * c4;
+  if (idx >= total4) return;
+  const long m = idx / c4;
+  const int n = (int)(idx - m * c4) * 4;
+  const long stride = (long)p.M * d.Cout;
+  const float* src = p.ws + m * d.Cout + n;
+  f32x4 v = *reinterpret_cast<const f32x4*>(src);
+  for (int s = 1; s < p.ksplit; ++s) v += *reinterpret_cast<const f32x4*>(src + (long)s * stride);
+  if (p.scale) v *= *reinterpret_cast<const f32x4*>(p.scale + n);
+  if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
+  if (p.res) v += *reinterpret_cast<const f32x4*>(p.res + m * d.res_cs + d.res_coff + n);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) v[e] = sf_act(v[e], d.act);
+  *reinterpret_cast<f32x4*>(p.out + m * d.out_cs + d.out_coff + n) = v;
+}
+
 template <int BM, int BN, int WM, int WN>
 int launch(const ConvArgs& a, bool vec4, hipStream_t s) {
   ConvArgs p = a;
@@ -474,6 +495,36 @@ static ConvCfg conv_cfg(const sf_conv_desc* d, long M, int ksplit) {
 
 }  // namespace
 
+// Sum S raw partial tiles ws[S][M][Cout] in split order and apply the conv epilogue (conv_bx.hip's finish step).
+int sf_conv_splitk_finish(const sf_conv_desc* d, const float* ws, int S, const float* scale, const float* bias,
+                          const float* res, float* out, hipStream_t s) {
+  ConvArgs p;
+  p.d = *d;
+  p.in = nullptr; p.w = nullptr; p.scale = scale; p.bias = bias; p.res = res; p.out = out;
+  p.M = (int)((long)d->N * d->To * d->Ho * d->Wo);
+  p.ntaps = d->kT * d->kH * d->kW;
+  p.nb_n = 0; p.nblocks = 0; p.vec_epi = 0;
+  p.ksplit = S;
+  p.ws = const_cast<float*>(ws);
+  const long total = (long)p.M * d->Cout;
+  const bool scatter = d->os_T > 1 || d->os_H > 1 || d->os_W > 1;
+  const bool vec = !scatter && d->out_cmul == 1 && (d->Cout % 4 == 0) && (d->out_cs % 4 == 0) && (d->out_coff % 4 == 0) &&
+                   sf_aligned16(out) && sf_aligned16(ws) && (!scale || sf_aligned16(scale)) &&
+                   (!bias || sf_aligned16(bias)) &&
+                   (!res || ((d->res_cs % 4 == 0) && (d->res_coff % 4 == 0) && sf_aligned16(res)));
+  if (vec)
+    hipLaunchKernelGGL(conv_splitk_finish4_kernel, dim3(sf_cdiv(total / 4, 256)), dim3(256), 0, s, p);
+  else
+    hipLaunchKernelGGL(conv_splitk_finish_kernel, dim3(sf_cdiv(total, 256)), dim3(256), 0, s, p);
+  SF_CHECK_LAUNCH();
+  return SF_OK;
+}
+
+int sf_conv_bx_takes(const sf_conv_desc* d);                                                  // conv_bx.hip
+extern "C" long sf_conv_bx_ws_floats(const sf_conv_desc* d, int have_in_planes, int have_w_planes);  // conv_bx.hip
+int sf_conv_bx_try(const sf_conv_desc* d, const float* in, const unsigned short* in_planes, const float* w,
+                   const unsigned short* w_planes, const float* scale, const float* bias, const float* res, float* out,
+                   float* ws, hipStream_t stream);                                           // conv_bx.hip
 int sf_conv_wave_try(const sf_conv_desc* d, const float* in, const float* w, const float* scale,
                      const float* bias, const float* res, float* out, hipStream_t stream, float* stats,
                      int* stat_parts);                                                       // conv_wave.hip
@@ -484,6 +535,7 @@ extern "C" long sf_conv_fwd_ws_floats(const sf_conv_desc* d) {
   if (!d) return 0;
   const long M = (long)d->N * d->To * d->Ho * d->Wo;
   if (M <= 0 || d->Cout <= 0 || d->cin_pad <= 0) return 0;
+  if (sf_conv_bx_takes(d)) return sf_conv_bx_ws_floats(d, 0, 0);  // operand planes + split-K partial tiles
   if (sf_conv_wave_takes(d)) return 0;  // conv_wave.hip splits long reductions inside the workgroup
   const int S = splitk_factor(d, M);
   return S > 1 ? (long)S * M * d->Cout : 0;
@@ -519,6 +571,10 @@ static int conv_fwd_impl(const sf_conv_desc* d, const float* in, const float* w_
   }
   {  // the tiniest channel counts (8 -> 8 spatial layers of the Fast pathway): LDS-staged input, scalar-register weights, vector FMAs
     const int rc = sf_conv_small_try(d, in, w_packed, scale, bias, res, out, (hipStream_t)stream, stats, stat_parts);
+    if (rc != 1) return rc;
+  }
+  if (ws && !stats) {  // long reductions on the bf16 matrix pipe (fp32-exact operand pieces), conv_bx.hip
+    const int rc = sf_conv_bx_try(d, in, nullptr, w_packed, nullptr, scale, bias, res, out, ws, (hipStream_t)stream);
     if (rc != 1) return rc;
   }
   {  // the per-wavefront implicit GEMM (no LDS staging, no barrier in the main loop) for every 16-byte aligned shape
@@ -574,6 +630,7 @@ extern "C" int sf_conv_fwd_ws(const sf_conv_desc* d, const float* in, const floa
 // S2] rows per channel it left in stats_ws (0: none were produced — run sf_bn_train_stats on the output instead).
 extern "C" long sf_conv_stats_ws_floats(const sf_conv_desc* d) {
   if (!d || !sf_conv_wave_takes(d) || d->transposed) return 0;
+  if (sf_conv_bx_takes(d)) return 0;  // conv_bx.hip leaves no statistics: the caller's statistics pass runs
   const long M = (long)d->N * d->To * d->Ho * d->Wo;
   return sf_conv_wave_max_parts(M) * 4 * d->Cout;
 }

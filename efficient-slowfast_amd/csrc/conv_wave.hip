@@ -809,6 +809,8 @@ static double plan_score(const sf_conv_desc* d, long M, int nk, bool has_res, co
 
 int sf_wgrad_wave_tune(int knob, int value);  // conv_wgrad_wave.hip (knobs 10..)
 int sf_conv_small_tune(int value);            // conv_small.hip
+int sf_conv_bx_tune(int value);               // conv_bx.hip
+int sf_conv_bx_dbg(int value);                // conv_bx.hip
 
 // Runtime knobs for microbenchmarks / A-B runs (not used by the model code).
 extern "C" int sf_conv_tune(int knob, int value) {
@@ -820,6 +822,8 @@ extern "C" int sf_conv_tune(int knob, int value) {
   else if (knob == 4) g_persist = value;
   else if (knob == 5) g_dbg = value;
   else if (knob == 6) return sf_conv_small_tune(value);
+  else if (knob == 7) return sf_conv_bx_tune(value);
+  else if (knob == 8) return sf_conv_bx_dbg(value);
   else return SF_EINVAL;
   return SF_OK;
 }

@@ -55,10 +55,11 @@ EXPORTS = [
     "sf_conv_fwd_ws", "sf_attn_fwd_ws_floats", "sf_attn_fwd_ws", "sf_affine_fwd_mask", "sf_bn_bwd_apply_first", "sf_maxpool_bwd_first",
     "sf_conv_tune", "sf_conv_stats_ws_floats", "sf_conv_fwd_stats", "sf_bn_train_stats_merge",
     "sf_attn_products_per_fp32", "sf_pack_conv_weights", "sf_attn_bwd_variant", "sf_attn_tune",
+    "sf_bx_planes_elems", "sf_bx_split", "sf_conv_bx_ws_floats", "sf_conv_fwd_bx",
 ]
 _LONG_RET = ("sf_tmax_mean_ws_floats", "sf_channel_stats_ws_floats", "sf_bn_bwd_ws_floats",
              "sf_dwconv_wgrad_ws_floats", "sf_attn_bwd_fused_ws_floats", "sf_conv_fwd_ws_floats",
-             "sf_attn_fwd_ws_floats", "sf_conv_stats_ws_floats")
+             "sf_attn_fwd_ws_floats", "sf_conv_stats_ws_floats", "sf_bx_planes_elems", "sf_conv_bx_ws_floats")
 
 
 def lib_path():
@@ -137,6 +138,12 @@ def lib():
         L.sf_pack_conv_weight.argtypes = [vp, ci, ci, ci, vp, ci, vp, ci, vp]
         L.sf_conv_tune.argtypes = [ci, ci]
         L.sf_attn_tune.argtypes = [ci, ci]
+        L.sf_bx_planes_elems.argtypes = [cl, ci]
+        L.sf_bx_planes_elems.restype = cl
+        L.sf_bx_split.argtypes = [vp, ci, ci, cl, ci, vp, vp]
+        L.sf_conv_bx_ws_floats.argtypes = [ctypes.POINTER(ConvDesc), ci, ci]
+        L.sf_conv_bx_ws_floats.restype = cl
+        L.sf_conv_fwd_bx.argtypes = [ctypes.POINTER(ConvDesc)] + [vp] * 10
         L.sf_attn_bwd_variant.argtypes = [ci, ci, ci]
         L.sf_row_softmax_fwd.argtypes = [vp, ci, ci, cl, ci, cf, vp]
         L.sf_row_softmax_bwd.argtypes = [vp, ci, ci, vp, ci, ci, cl, ci, cf, vp]
@@ -311,10 +318,36 @@ def pack_conv_weight(w, cin_pad=None):
     return wp.contiguous()
 
 
-def _conv_launch(d, x_ptr, w_ptr, scale, bias, res_ptr, out_ptr, device, what):
+def bx_planes(t, rows, C, cs=None, coff=0):
+    """The bf16 piece planes [3][rows + 1][C] (uint16 tensor) of a [rows][cs] fp32 operand: sf_bx_split."""
+    planes = torch.empty((lib().sf_bx_planes_elems(rows, C),), dtype=torch.int16, device=t.device)
+    _check(lib().sf_bx_split(_ptr(t), C if cs is None else cs, coff, rows, C, _ptr(planes), _stream()), "sf_bx_split")
+    return planes
+
+
+def _weight_planes(wp):
+    """Planes of a packed conv weight [Cout][taps][cin_pad], cached ON the tensor object (pack_conv_weight_pairs
+    refreshes them when it overwrites the packed weight in place)."""
+    pl = wp.__dict__.get("_sf_bx")
+    if pl is None:
+        pl = bx_planes(wp, wp.shape[0], wp.shape[1] * wp.shape[2])
+        wp.__dict__["_sf_bx"] = pl
+    return pl
+
+
+def _conv_launch(d, x_ptr, w_ptr, scale, bias, res_ptr, out_ptr, device, what, w_tensor=None):
     """sf_conv_fwd, through the split-K schedule when the shape asks for it (workspace from the caching allocator).
-    Trace tag: ("conv", output positions, taps * Cin, Cout) — 2 * product = the launch's algorithmic FLOPs."""
+    Trace tag: ("conv", output positions, taps * Cin, Cout) — 2 * product = the launch's algorithmic FLOPs.
+    w_tensor: the packed weight as a tensor — lets the bf16-piece path (conv_bx.hip) keep its planes across calls."""
     tag = ("conv", d.N * d.To * d.Ho * d.Wo, d.kT * d.kH * d.kW * d.Cin, d.Cout)
+    if SPLIT_K and w_tensor is not None and w_tensor.shape[2] == d.Cin:
+        n = lib().sf_conv_bx_ws_floats(ctypes.byref(d), 0, 1)
+        if n > 0:
+            planes = _weight_planes(w_tensor)
+            ws = torch.empty((n,), dtype=torch.float32, device=device)
+            _check(_traced(tag, lambda: lib().sf_conv_fwd_bx(ctypes.byref(d), x_ptr, None, w_ptr, _ptr(planes), scale,
+                                                             bias, res_ptr, out_ptr, _ptr(ws), _stream())), what)
+            return
     n = lib().sf_conv_fwd_ws_floats(ctypes.byref(d)) if SPLIT_K else 0
     if n > 0:
         ws = torch.empty((n,), dtype=torch.float32, device=device)
@@ -379,6 +412,13 @@ def pack_conv_weight_pairs(weights, outs):
         tab = (key, items, starts)
         _PACK_TABLES[dev] = tab
     _check(lib().sf_pack_conv_weights(_ptr(tab[1]), _ptr(tab[2]), len(recs), nb, _stream()), "sf_pack_conv_weights")
+    for o in res:  # packed weights overwritten in place: their bf16 piece planes (conv_bx.hip) follow
+        for t in o:
+            pl = t.__dict__.get("_sf_bx")
+            if pl is not None:
+                _check(lib().sf_bx_split(_ptr(t), t.shape[1] * t.shape[2], 0, t.shape[0], t.shape[1] * t.shape[2],
+                                         _ptr(pl), _stream()), "sf_bx_split")
+            t.__dict__.pop("_sf_classes", None)  # tap-subset copies of the previous contents (strided data gradients)
     return res
 
 
@@ -430,7 +470,7 @@ def conv(x, wp, kernel, stride=(1, 1, 1), padding=(0, 0, 0), dilation=(1, 1, 1),
                                                                 _stream())), "sf_conv_fwd_stats")
             return out, ((ws, parts.value) if parts.value > 0 else None)
     _conv_launch(d, x.ptr(), _ptr(wp), _ptr(scale), _ptr(bias), res.ptr() if res is not None else None, out.ptr(),
-                 x.buf.device, "sf_conv_fwd")
+                 x.buf.device, "sf_conv_fwd", w_tensor=wp)
     return (out, None) if stats else out
 
 
@@ -611,7 +651,7 @@ def conv_dgrad(dz, wt_packed, x_like, kernel, stride=(1, 1, 1), padding=(0, 0, 0
                  padding[2], dilation[0], dilation[1], dilation[2], cout_pad, ACT_NONE,
                  out.cs if accumulate else 0, out.coff if accumulate else 0, 1)
     _conv_launch(d, dz.ptr(), _ptr(wt_packed), None, None, out.ptr() if accumulate else None, out.ptr(),
-                 dz.buf.device, "sf_conv_fwd(transposed)")
+                 dz.buf.device, "sf_conv_fwd(transposed)", w_tensor=wt_packed)
     return out
 
 
@@ -670,7 +710,7 @@ def _conv_dgrad_strided(dz, wt_packed, out, kernel, stride, padding, accumulate)
                              cout_pad, ACT_NONE, out.cs, out.coff, 0, stride[0], stride[1], stride[2], at, ah, aw,
                              out.T, out.H, out.W)
                 _conv_launch(d, dz.ptr(), _ptr(wsub), None, None, out.ptr() if add else None, out.ptr(),
-                             dz.buf.device, "sf_conv_fwd(strided dgrad class)")
+                             dz.buf.device, "sf_conv_fwd(strided dgrad class)", w_tensor=wsub)
     return out
 
 

@@ -96,10 +96,28 @@ int sf_conv_fwd_stats(const sf_conv_desc* d, const float* in, const float* w_pac
  * conv_wave.hip; knob 1: force tile configuration `value` of conv_wave.hip (-1: planner); knob 2: force the rows per
  * M tile (0: planner); knob 3: value 1 selects 32-channel K steps; knob 4: the persistent
  * swapped-operand form (0 = never, 1 = the SF_CONV_WAVE_P level, 10 + L = level L: 1 every KS == 1 layer it covers,
- * 2 plain layers, 3 plain layers with <= 5 K steps); knob 6: conv_small.hip (bit 0 enable); knobs 10 / 11 / 12: the weight-gradient kernels of
+ * 2 plain layers, 3 plain layers with <= 5 K steps); knob 6: conv_small.hip (bit 0 enable); knob 7: conv_bx.hip (0 off,
+ * 1 where it wins, 2 every shape it covers); knob 8: its timing ablations; knobs 10 / 11 / 12: the weight-gradient kernels of
  * conv_wgrad_wave.hip — 10: value 0 routes every weight gradient to conv_wgrad.hip, 11: force the blocks per
  * wavefront (-1: planner), 12: workgroups to aim at (0: default).  Returns SF_EINVAL for an unknown knob.      */
 int sf_conv_tune(int knob, int value);
+/* ---- long reductions on the bf16 matrix pipe with fp32-exact operands (conv_bx.hip) --------------------------------
+ * gfx950's f32-input MFMA runs at the vector rate, its bf16 MFMA at 16x that.  Every fp32 value is the EXACT sum of
+ * three bf16 pieces (8 significand bits each) and six bf16 MFMAs with fp32 accumulation give the fp32 product to fp32
+ * rounding level (the dropped terms are below 2^-24 |a||b|): the 1x3x3 / 3x1x1 layers over >= 128 channels of
+ * resnet_helper.py:182-223 and their data gradients run that way where it is faster than v_mfma_f32_*_f32
+ * (sf_conv_fwd_ws routes them itself; sf_conv_tune(7, 0) switches it off, (7, 2) takes every shape the kernel covers).
+ * sf_bx_split: x [rows][cs] fp32 (C channels from coff; C % 8 == 0) -> planes[3][rows + 1][C] bf16 (row `rows` = 0),
+ *   sf_bx_planes_elems(rows, C) 16-bit elements, 16-byte aligned.
+ * sf_conv_fwd_bx: sf_conv_fwd_ws with the operand planes handed in — in_planes = sf_bx_split of the input view
+ *   ([N*Ti*Hi*Wi][Cin]), w_planes = sf_bx_split of the packed weights ([Cout][taps*Cin]); either may be NULL (made in
+ *   ws).  ws: sf_conv_bx_ws_floats(d, have_in_planes, have_w_planes) floats; 0 = the shape is not served (SF_EINVAL). */
+long sf_bx_planes_elems(long rows, int C);
+int sf_bx_split(const float* x, int cs, int coff, long rows, int C, unsigned short* planes, void* stream);
+long sf_conv_bx_ws_floats(const sf_conv_desc* d, int have_in_planes, int have_w_planes);
+int sf_conv_fwd_bx(const sf_conv_desc* d, const float* in, const unsigned short* in_planes, const float* w_packed,
+                   const unsigned short* w_planes, const float* scale, const float* bias, const float* res, float* out,
+                   float* ws, void* stream);
 /* Packs an nn.Conv3d weight [Cout][Cin][kT*kH*kW] (device) into wp [Cout][taps][cin_pad] and — when wtp != NULL —
  * wtp [Cin][taps][cout_pad] (the data-gradient order), zero padded, in one launch.                           */
 int sf_pack_conv_weight(const float* w, int Cout, int Cin, int taps, float* wp, int cin_pad, float* wtp,

@@ -125,5 +125,10 @@ def test_wide_head_spatial_attention(c, red, thw):
         tape.backward()
     (yr * up.double()).sum().backward()
     assert _rel(sfhip.to_ncthw(dxa), xd.grad) < 2e-4
+    gmax = max(float(pr.grad.abs().max()) for pr in params)
     for k, pr in zip(names, params):
-        assert _rel(tape.pgrads[pd[k]].reshape(pr.shape), pr.grad) < 2e-4, k
+        got = tape.pgrads[pd[k]].reshape(pr.shape)
+        if k == "key_conv.bias":  # zero in exact arithmetic (q.b_k shifts a whole softmax row): rounding noise on both sides
+            assert float(got.abs().max()) < 1e-5 * gmax, k
+        else:
+            assert _rel(got, pr.grad) < 2e-4, k
