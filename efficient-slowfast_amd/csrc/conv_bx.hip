@@ -223,6 +223,181 @@ __global__ __launch_bounds__(512, 2) void conv_bx_kernel(const BxArgs p) {
     }
 }
 
+// ---- weight gradient ---------------------------------------------------------------------------------------------------
+// dW[co][tap][ci] = sum_m dz[m][co] * x[row(m, tap)][ci]: the reduction runs over the POSITIONS and both operands lie
+// position-major with channels contiguous, so a K step is 16 positions: the dz rows [16][BCO channels] and, per tap of
+// the column tile, the gathered x rows [16][channels] arrive by LDS-DMA as they lie in memory, and the MFMA fragments
+// (8 consecutive positions of one channel per lane) are read with ds_read_b64_tr_b16, the transposing LDS read: per 16
+// lanes a block of 4 positions x 16 channels comes back channel-major.  A row's 16-byte chunks are XOR-swizzled by
+// 4 * (position & 3) (on the DMA's source address) so that the four position rows of a block — 512 bytes apart, the
+// same banks — land on four different 16-bank windows: conflict-free.
+// Tile: BCO output channels x 256 (tap, ci) columns, 8 wavefronts, wavefront tile 64 x (128 | 64); the positions are
+// shared by S workgroups per tile, each storing a raw partial tile part[S][Cout][taps * Cin] — exactly what
+// sf_conv_wgrad_finish sums and un-packs.
+struct BxwArgs {
+  sf_conv_desc d;
+  const unsigned short* xp;  // input planes [3][x_rows + 1][Cin]
+  const unsigned short* zp;  // dz planes [3][M + 1][Cout]
+  float* part;               // [S][Cout][Kc]
+  int M, Kc, S, chunk, nb_col, tiles;
+  unsigned x_rows, x_plane, x_bytes, z_plane, z_bytes;
+  unsigned wo_mul, wo_sh, ho_mul, ho_sh, to_mul, to_sh, ci_mul, ci_sh;
+};
+
+__device__ __forceinline__ u32x2 lds_tr(const char* p) {
+  return lds_read_tr(reinterpret_cast<const unsigned short*>(p));
+}
+
+template <int BCO>
+__global__ __launch_bounds__(512, 2) void conv_bx_wgrad_kernel(const BxwArgs p) {
+  constexpr int BCOL = 256;
+  constexpr int NWC = BCO == 256 ? 2 : 4;     // wavefronts along the columns
+  constexpr int NT = BCOL / NWC / 32;         // 32-column MFMA tiles per wavefront
+  constexpr int ROW_A = BCO * 2, ROW_B = BCOL * 2;              // bytes of a position row per plane
+  constexpr int PL_A = 16 * ROW_A, PL_B = 16 * ROW_B;           // bytes of a plane per stage
+  constexpr int A_STAGE = 3 * PL_A, STAGE = A_STAGE + 3 * PL_B;
+  constexpr int NA = PL_A / 1024;             // A loader wavefronts (one 1 KiB piece per plane each)
+  constexpr int CPR_A = BCO / 8;              // 16-byte chunks per position row
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const sf_conv_desc& d = p.d;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave / NWC, wc = wave - wr * NWC;
+  const int bid = xcd_remap(blockIdx.x, p.tiles * p.S);
+  const int split = bid / p.tiles, tile = bid - split * p.tiles;
+  const int tile_co = tile / p.nb_col, tile_col = tile - tile_co * p.nb_col;
+  const int co0 = tile_co * BCO, col0 = tile_col * BCOL;
+  const int mb = split * p.chunk;
+  const int me = mb + p.chunk < p.M ? mb + p.chunk : p.M;
+  const int nsteps = me > mb ? (me - mb + 15) / 16 : 0;
+
+  // ---- B loader (every wave): position 2 * wave + (lane >> 5) of the step, LDS chunk lane & 31 holds source chunk cs
+  const int b_pos = 2 * wave + (lane >> 5);
+  const int b_cs = (lane & 31) ^ ((b_pos & 3) << 2);
+  const int b_col = col0 + b_cs * 8;
+  const bool b_colok = b_col < p.Kc;
+  const unsigned b_tap = b_colok ? mdiv((unsigned)b_col, p.ci_mul, p.ci_sh) : 0u;
+  const unsigned b_ci = b_colok ? (unsigned)b_col - b_tap * (unsigned)d.Cin : 0u;
+  const int b_kw = (int)(b_tap % (unsigned)d.kW), b_kh = (int)((b_tap / (unsigned)d.kW) % (unsigned)d.kH),
+            b_kt = (int)(b_tap / (unsigned)(d.kW * d.kH));
+  const int b_dt = b_kt * d.dT - d.pT, b_dh = b_kh * d.dH - d.pH, b_dw = b_kw * d.dW - d.pW;
+  const unsigned x_rowb = (unsigned)d.Cin * 2u;
+  auto b_voff = [&](int m) -> unsigned {
+    unsigned r = p.x_rows;
+    if (m < me && b_colok) {
+      const unsigned q1 = mdiv((unsigned)m, p.wo_mul, p.wo_sh);
+      const int wo = (int)((unsigned)m - q1 * (unsigned)d.Wo);
+      const unsigned q2 = mdiv(q1, p.ho_mul, p.ho_sh);
+      const int ho = (int)(q1 - q2 * (unsigned)d.Ho);
+      const unsigned q3 = mdiv(q2, p.to_mul, p.to_sh);
+      const int to = (int)(q2 - q3 * (unsigned)d.To);
+      const int ti = to * d.sT + b_dt, hi = ho * d.sH + b_dh, wi = wo * d.sW + b_dw;
+      if ((unsigned)ti < (unsigned)d.Ti && (unsigned)hi < (unsigned)d.Hi && (unsigned)wi < (unsigned)d.Wi)
+        r = (unsigned)((((int)q3 * d.Ti + ti) * d.Hi + hi) * d.Wi + wi);
+    }
+    return r * x_rowb + b_ci * 2u;
+  };
+  // ---- A loader (waves 0 .. NA-1): dz rows, no gather
+  const bool a_loader = wave < NA;
+  const int a_pos = wave * (64 / CPR_A) + lane / CPR_A;
+  const int a_cs = (lane % CPR_A) ^ ((a_pos & 3) << 2);
+  const int a_co = co0 + a_cs * 8;
+  const unsigned z_rowb = (unsigned)d.Cout * 2u;
+  auto a_voff = [&](int m) -> unsigned {
+    const unsigned r = (m < me && a_co < d.Cout) ? (unsigned)m : (unsigned)p.M;
+    return r * z_rowb + (unsigned)(a_co < d.Cout ? a_co : 0) * 2u;
+  };
+  const __amdgpu_buffer_rsrc_t x_rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.xp, 0, p.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t z_rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.zp, 0, p.z_bytes, 0x00020000);
+  int l_m = mb;  // first position of the step the loader issues next
+  auto issue = [&](int stage) {
+    char* const st = smem + stage * STAGE;
+    if (a_loader) {
+      const unsigned vo = a_voff(l_m + a_pos);
+#pragma unroll
+      for (int pc = 0; pc < 3; ++pc)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(z_rs, (lds_void*)(st + pc * PL_A + wave * 1024), 16, vo,
+                                                 (unsigned)pc * p.z_plane, 0, 0);
+    }
+    const unsigned vb = b_voff(l_m + b_pos);
+#pragma unroll
+    for (int pc = 0; pc < 3; ++pc)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rs, (lds_void*)(st + A_STAGE + pc * PL_B + wave * 1024), 16, vb,
+                                               (unsigned)pc * p.x_plane, 0, 0);
+    l_m += 16;
+  };
+
+  // ---- transposing fragment reads: lane = 16 g + 4 q + pq, k half h = g >> 1; read u brings positions 8h + 4u + {0..3}
+  // of channels cb + 16 (g & 1) + {0..15}; this lane addresses position row q, channels 4 pq .. 4 pq + 3 of the block
+  const int g = lane >> 4, q = (lane & 15) >> 2, pq = lane & 3, h = g >> 1;
+  unsigned a_addr[2], b_addr[NT];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int ch = wr * 64 + i * 32 + 16 * (g & 1) + 4 * pq;
+    a_addr[i] = (unsigned)((8 * h + q) * ROW_A + (((ch >> 3) ^ (q << 2)) << 4) + (ch & 7) * 2);
+  }
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int ch = wc * (BCOL / NWC) + j * 32 + 16 * (g & 1) + 4 * pq;
+    b_addr[j] = (unsigned)(A_STAGE + (8 * h + q) * ROW_B + (((ch >> 3) ^ (q << 2)) << 4) + (ch & 7) * 2);
+  }
+
+  f32x16 acc[2][NT];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  if (nsteps > 0) issue(0);
+  if (nsteps > 1) issue(1);
+  for (int it = 0; it < nsteps; ++it) {
+    if (it + 1 < nsteps) {
+      if (a_loader) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    if (it + 2 < nsteps) issue((it + 2) % BXC_STAGES);
+    const char* const st = smem + (it % BXC_STAGES) * STAGE;
+    u32x4 af[2][3], bf[NT][3];
+#pragma unroll
+    for (int pc = 0; pc < 3; ++pc) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const u32x2 lo = lds_tr(st + a_addr[i] + pc * PL_A), hi = lds_tr(st + a_addr[i] + pc * PL_A + 4 * ROW_A);
+        af[i][pc] = (u32x4){lo[0], lo[1], hi[0], hi[1]};
+      }
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const u32x2 lo = lds_tr(st + b_addr[j] + pc * PL_B), hi = lds_tr(st + b_addr[j] + pc * PL_B + 4 * ROW_B);
+        bf[j][pc] = (u32x4){lo[0], lo[1], hi[0], hi[1]};
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) acc[i][j] = mfma_split(af[i], bf[j], acc[i][j]);
+  }
+
+  // ---- raw partial tile -> part[split][co][col]: register e of a lane = column lane & 31, rows (e & 3) + 8 (e >> 2) + 4h
+  float* const out = p.part + (long)split * d.Cout * p.Kc;
+  const int ccol = lane & 31, rsub = 4 * (lane >> 5);
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int col = col0 + wc * (BCOL / NWC) + j * 32 + ccol;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int co = co0 + wr * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + rsub;
+        if (co < d.Cout && col < p.Kc) out[(long)co * p.Kc + col] = acc[i][j][e];
+      }
+    }
+}
+
 // fp32 rows (pitch cs, C channels from coff) -> three bf16 piece planes [3][rows + 1][C]; row `rows` of every plane is
 // written as zeros.  Thread = 8 channels of a row (32 B read, 3 x 16 B written).
 __global__ __launch_bounds__(256) void bx_split_rows_kernel(const float* __restrict__ x, int cs, int coff, long rows,
@@ -441,4 +616,132 @@ extern "C" int sf_conv_fwd_bx(const sf_conv_desc* d, const float* in, const unsi
   if (!d || !in || !w_packed || !out || !ws) return SF_EINVAL;
   const int rc = sf_conv_bx_try(d, in, in_planes, w_packed, w_planes, scale, bias, res, out, ws, (hipStream_t)stream);
   return rc == 1 ? SF_EINVAL : rc;
+}
+
+// ---- weight gradient on the bf16 pipe ---------------------------------------------------------------------------------
+namespace {
+
+struct BxwPlan { int bco, S, nb_col, tiles; long chunk, x_rows; };
+
+int g_bxw_enable = 1;  // sf_conv_tune(9, e): 0 off, 1 where it wins, 2 every shape it covers
+
+bool bxw_plan(const sf_conv_desc* d, BxwPlan* pl) {
+  static const int env_on = [] { const char* e = getenv("SF_WGRAD_BX"); return e ? atoi(e) : 1; }();
+  if (!env_on || !g_bxw_enable) return false;
+  const long M = (long)d->N * d->To * d->Ho * d->Wo;
+  const int ntaps = d->kT * d->kH * d->kW;
+  if ((d->Cin % 8) || d->cin_pad != d->Cin || (d->in_cs % 4) || (d->in_coff % 4)) return false;
+  if (d->Cout < 128 || (d->Cout % 8)) return false;
+  const long Kc = (long)ntaps * d->Cin;
+  if (Kc < 512 || M < 2048 || M > 0x7ffffff0L) return false;
+  const long x_rows = (long)d->N * d->Ti * d->Hi * d->Wi;
+  if (3 * (x_rows + 1) * d->Cin * 2 > 0xfffffff0L || 3 * (M + 1) * d->Cout * 2 > 0xfffffff0L) return false;
+  pl->bco = d->Cout >= 256 ? 256 : 128;
+  pl->nb_col = sf_cdiv(Kc, 256);
+  pl->tiles = sf_cdiv(d->Cout, pl->bco) * pl->nb_col;
+  pl->x_rows = x_rows;
+  // positions are shared by S workgroups per tile: aim at whole rounds of 256 workgroups, >= 256 positions each
+  const double step_us = pl->bco == 256 ? 2.0 : 1.1;
+  const double out_mb = (double)d->Cout * Kc * 4e-6;
+  int best = 1;
+  double best_t = 1e30;
+  const int maxS = (int)(M / 256 > 512 ? 512 : M / 256);
+  for (int S = 1; S <= maxS; ++S) {
+    const long wg = (long)pl->tiles * S;
+    if (wg > 1536) break;
+    const long rounds = sf_cdiv(wg, 256);
+    const long steps = sf_cdiv(sf_cdiv(M, S), 16);
+    const double t = 6.0 + (double)rounds * steps * step_us + out_mb * (2.0 * S + 1.0) / 4.0;
+    if (t < best_t - 1e-9) { best_t = t; best = S; }
+  }
+  static const int forced_s = [] { const char* e = getenv("SF_WGRAD_BX_S"); return e ? atoi(e) : 0; }();
+  if (forced_s > 0) best = forced_s;
+  pl->S = best;
+  pl->chunk = (sf_cdiv(M, best) + 15) / 16 * 16;
+  if (g_bxw_enable < 2) {
+    const double flop = 2.0 * M * (double)Kc * d->Cout;
+    const double wave_us = flop / 95e6;
+    const double split_us = 8.0 + ((double)x_rows * d->Cin + (double)M * d->Cout) * 10e-6 / 3.0;
+    if (best_t + split_us > 0.93 * wave_us) return false;
+  }
+  return true;
+}
+
+long x_plane_floats(const sf_conv_desc* d, long x_rows) { return align4((3 * (x_rows + 1) * d->Cin + 1) / 2); }
+long z_plane_floats(const sf_conv_desc* d, long M) { return align4((3 * (M + 1) * d->Cout + 1) / 2); }
+
+template <int BCO>
+int launch_bxw(const BxwArgs& a, int grid, hipStream_t stream) {
+  constexpr int lds = BXC_STAGES * (3 * 16 * BCO * 2 + 3 * 16 * 256 * 2);
+  static SfLdsAttr at;
+  if (!sf_ensure_dyn_lds(at, reinterpret_cast<const void*>(conv_bx_wgrad_kernel<BCO>), lds)) return SF_ELAUNCH;
+  hipLaunchKernelGGL((conv_bx_wgrad_kernel<BCO>), dim3(grid), dim3(512), lds, stream, a);
+  SF_CHECK_LAUNCH();
+  return SF_OK;
+}
+
+}  // namespace
+
+int sf_conv_bxw_tune(int value) { g_bxw_enable = value; return SF_OK; }
+
+// Position splits S of the bf16-piece weight-gradient kernel (0: the shape is not served — sf_conv_wgrad_splits /
+// sf_conv_wgrad plan their own); the partial buffer is [S][Cout][taps][Cin] as for sf_conv_wgrad.
+extern "C" int sf_conv_wgrad_bx_splits(const sf_conv_desc* d) {
+  BxwPlan pl;
+  return (d && bxw_plan(d, &pl)) ? pl.S : 0;
+}
+
+// workspace floats: the operand planes the call has to make itself (x: [rows of the input][Cin], dz: [M][Cout])
+extern "C" long sf_conv_wgrad_bx_ws_floats(const sf_conv_desc* d, int have_x_planes, int have_dz_planes) {
+  BxwPlan pl;
+  if (!d || !bxw_plan(d, &pl)) return 0;
+  const long M = (long)d->N * d->To * d->Ho * d->Wo;
+  return 4 + (have_x_planes ? 0 : x_plane_floats(d, pl.x_rows)) + (have_dz_planes ? 0 : z_plane_floats(d, M));
+}
+
+// sf_conv_wgrad on the bf16 matrix pipe: partial[S][Cout][taps][Cin] with S = sf_conv_wgrad_bx_splits(d);
+// x_planes / dz_planes = sf_bx_split of the input view / of dz ([M][Cout]), or NULL (made in ws).
+extern "C" int sf_conv_wgrad_bx(const sf_conv_desc* d, const float* x, const unsigned short* x_planes, const float* dz,
+                                int dz_cs, int dz_coff, const unsigned short* dz_planes, float* partial, float* ws,
+                                void* stream) {
+  BxwPlan pl;
+  if (!d || !x || !dz || !partial || !ws || !bxw_plan(d, &pl)) return SF_EINVAL;
+  if (!sf_aligned16(x) || !sf_aligned16(dz) || !sf_aligned16(ws) || !sf_aligned16(partial) || (dz_cs % 4) || (dz_coff % 4))
+    return SF_EALIGN;
+  hipStream_t s = (hipStream_t)stream;
+  const long M = (long)d->N * d->To * d->Ho * d->Wo;
+  float* cur = ws;
+  int rc = SF_OK;
+  if (!x_planes) {
+    unsigned short* const xp = reinterpret_cast<unsigned short*>(cur);
+    cur += x_plane_floats(d, pl.x_rows);
+    if (!(g_bx_dbg & 1)) rc = sf_bx_split_rows(x, d->in_cs, d->in_coff, pl.x_rows, d->Cin, xp, s);
+    if (rc != SF_OK) return rc;
+    x_planes = xp;
+  }
+  if (!dz_planes) {
+    unsigned short* const zp = reinterpret_cast<unsigned short*>(cur);
+    cur += z_plane_floats(d, M);
+    if (!(g_bx_dbg & 1)) rc = sf_bx_split_rows(dz, dz_cs, dz_coff, M, d->Cout, zp, s);
+    if (rc != SF_OK) return rc;
+    dz_planes = zp;
+  }
+  BxwArgs a;
+  a.d = *d;
+  a.xp = x_planes; a.zp = dz_planes; a.part = partial;
+  a.M = (int)M;
+  a.Kc = d->kT * d->kH * d->kW * d->Cin;
+  a.S = pl.S; a.chunk = (int)pl.chunk; a.nb_col = pl.nb_col; a.tiles = pl.tiles;
+  a.x_rows = (unsigned)pl.x_rows;
+  a.x_plane = (unsigned)((pl.x_rows + 1) * d->Cin * 2);
+  a.x_bytes = 3u * a.x_plane;
+  a.z_plane = (unsigned)((M + 1) * d->Cout * 2);
+  a.z_bytes = 3u * a.z_plane;
+  magic((unsigned)d->Wo, &a.wo_mul, &a.wo_sh);
+  magic((unsigned)d->Ho, &a.ho_mul, &a.ho_sh);
+  magic((unsigned)d->To, &a.to_mul, &a.to_sh);
+  magic((unsigned)d->Cin, &a.ci_mul, &a.ci_sh);
+  if (g_bx_dbg & 4) return SF_OK;
+  const int grid = pl.tiles * pl.S;
+  return pl.bco == 256 ? launch_bxw<256>(a, grid, s) : launch_bxw<128>(a, grid, s);
 }

@@ -811,6 +811,7 @@ int sf_wgrad_wave_tune(int knob, int value);  // conv_wgrad_wave.hip (knobs 10..
 int sf_conv_small_tune(int value);            // conv_small.hip
 int sf_conv_bx_tune(int value);               // conv_bx.hip
 int sf_conv_bx_dbg(int value);                // conv_bx.hip
+int sf_conv_bxw_tune(int value);              // conv_bx.hip
 
 // Runtime knobs for microbenchmarks / A-B runs (not used by the model code).
 extern "C" int sf_conv_tune(int knob, int value) {
@@ -824,6 +825,7 @@ extern "C" int sf_conv_tune(int knob, int value) {
   else if (knob == 6) return sf_conv_small_tune(value);
   else if (knob == 7) return sf_conv_bx_tune(value);
   else if (knob == 8) return sf_conv_bx_dbg(value);
+  else if (knob == 9) return sf_conv_bxw_tune(value);
   else return SF_EINVAL;
   return SF_OK;
 }

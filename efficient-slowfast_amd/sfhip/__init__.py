@@ -55,11 +55,13 @@ EXPORTS = [
     "sf_conv_fwd_ws", "sf_attn_fwd_ws_floats", "sf_attn_fwd_ws", "sf_affine_fwd_mask", "sf_bn_bwd_apply_first", "sf_maxpool_bwd_first",
     "sf_conv_tune", "sf_conv_stats_ws_floats", "sf_conv_fwd_stats", "sf_bn_train_stats_merge",
     "sf_attn_products_per_fp32", "sf_pack_conv_weights", "sf_attn_bwd_variant", "sf_attn_tune",
-    "sf_bx_planes_elems", "sf_bx_split", "sf_conv_bx_ws_floats", "sf_conv_fwd_bx",
+    "sf_bx_planes_elems", "sf_bx_split", "sf_conv_bx_ws_floats", "sf_conv_fwd_bx", "sf_conv_wgrad_bx_splits",
+    "sf_conv_wgrad_bx_ws_floats", "sf_conv_wgrad_bx",
 ]
 _LONG_RET = ("sf_tmax_mean_ws_floats", "sf_channel_stats_ws_floats", "sf_bn_bwd_ws_floats",
              "sf_dwconv_wgrad_ws_floats", "sf_attn_bwd_fused_ws_floats", "sf_conv_fwd_ws_floats",
-             "sf_attn_fwd_ws_floats", "sf_conv_stats_ws_floats", "sf_bx_planes_elems", "sf_conv_bx_ws_floats")
+             "sf_attn_fwd_ws_floats", "sf_conv_stats_ws_floats", "sf_bx_planes_elems", "sf_conv_bx_ws_floats",
+             "sf_conv_wgrad_bx_ws_floats")
 
 
 def lib_path():
@@ -144,6 +146,10 @@ def lib():
         L.sf_conv_bx_ws_floats.argtypes = [ctypes.POINTER(ConvDesc), ci, ci]
         L.sf_conv_bx_ws_floats.restype = cl
         L.sf_conv_fwd_bx.argtypes = [ctypes.POINTER(ConvDesc)] + [vp] * 10
+        L.sf_conv_wgrad_bx_splits.argtypes = [ctypes.POINTER(ConvDesc)]
+        L.sf_conv_wgrad_bx_ws_floats.argtypes = [ctypes.POINTER(ConvDesc), ci, ci]
+        L.sf_conv_wgrad_bx_ws_floats.restype = cl
+        L.sf_conv_wgrad_bx.argtypes = [ctypes.POINTER(ConvDesc), vp, vp, vp, ci, ci, vp, vp, vp, vp]
         L.sf_attn_bwd_variant.argtypes = [ci, ci, ci]
         L.sf_row_softmax_fwd.argtypes = [vp, ci, ci, cl, ci, cf, vp]
         L.sf_row_softmax_bwd.argtypes = [vp, ci, ci, vp, ci, ci, cl, ci, cf, vp]
@@ -335,18 +341,30 @@ def _weight_planes(wp):
     return pl
 
 
-def _conv_launch(d, x_ptr, w_ptr, scale, bias, res_ptr, out_ptr, device, what, w_tensor=None):
+def act_planes(a):
+    """bf16 piece planes of an activation view (all rows, its C channels): what conv_bx.hip's kernels read."""
+    return bx_planes(a.buf, a.rows, a.C, cs=a.cs, coff=a.coff)
+
+
+def _conv_launch(d, x_ptr, w_ptr, scale, bias, res_ptr, out_ptr, device, what, w_tensor=None, x_act=None,
+                 in_planes=None, keep=None):
     """sf_conv_fwd, through the split-K schedule when the shape asks for it (workspace from the caching allocator).
     Trace tag: ("conv", output positions, taps * Cin, Cout) — 2 * product = the launch's algorithmic FLOPs.
-    w_tensor: the packed weight as a tensor — lets the bf16-piece path (conv_bx.hip) keep its planes across calls."""
+    w_tensor: the packed weight as a tensor — lets the bf16-piece path (conv_bx.hip) keep its planes across calls.
+    in_planes: act_planes of the input view when the caller already has them; keep (a dict, with x_act): the planes this
+    call makes are left in keep["x"] for the layer's weight gradient."""
     tag = ("conv", d.N * d.To * d.Ho * d.Wo, d.kT * d.kH * d.kW * d.Cin, d.Cout)
     if SPLIT_K and w_tensor is not None and w_tensor.shape[2] == d.Cin:
-        n = lib().sf_conv_bx_ws_floats(ctypes.byref(d), 0, 1)
+        if in_planes is None and keep is not None and x_act is not None and \
+                lib().sf_conv_bx_ws_floats(ctypes.byref(d), 1, 1) > 0:
+            in_planes = keep["x"] = act_planes(x_act)
+        n = lib().sf_conv_bx_ws_floats(ctypes.byref(d), 1 if in_planes is not None else 0, 1)
         if n > 0:
             planes = _weight_planes(w_tensor)
             ws = torch.empty((n,), dtype=torch.float32, device=device)
-            _check(_traced(tag, lambda: lib().sf_conv_fwd_bx(ctypes.byref(d), x_ptr, None, w_ptr, _ptr(planes), scale,
-                                                             bias, res_ptr, out_ptr, _ptr(ws), _stream())), what)
+            _check(_traced(tag, lambda: lib().sf_conv_fwd_bx(ctypes.byref(d), x_ptr, _ptr(in_planes), w_ptr,
+                                                             _ptr(planes), scale, bias, res_ptr, out_ptr, _ptr(ws),
+                                                             _stream())), what)
             return
     n = lib().sf_conv_fwd_ws_floats(ctypes.byref(d)) if SPLIT_K else 0
     if n > 0:
@@ -432,7 +450,8 @@ CONV_STATS = os.environ.get("SF_CONV_STATS", "1") != "0"
 
 
 def conv(x, wp, kernel, stride=(1, 1, 1), padding=(0, 0, 0), dilation=(1, 1, 1), scale=None, bias=None,
-         relu=False, res=None, out=None, cin=None, out_cmul=1, out_reserve=(0, 0), out_thw=None, stats=False):
+         relu=False, res=None, out=None, cin=None, out_cmul=1, out_reserve=(0, 0), out_thw=None, stats=False,
+         keep=None):
     """Dense conv (implicit GEMM, sf_conv_fwd).  `wp` = pack_conv_weight(...).  `out`: Act to write into
     (a slice of a wider buffer) or None to allocate [.., before + Cout + after].
     stats=True returns (out, parts) with parts = (workspace, rows) of per-tile channel statistics of the output taken
@@ -470,7 +489,7 @@ def conv(x, wp, kernel, stride=(1, 1, 1), padding=(0, 0, 0), dilation=(1, 1, 1),
                                                                 _stream())), "sf_conv_fwd_stats")
             return out, ((ws, parts.value) if parts.value > 0 else None)
     _conv_launch(d, x.ptr(), _ptr(wp), _ptr(scale), _ptr(bias), res.ptr() if res is not None else None, out.ptr(),
-                 x.buf.device, "sf_conv_fwd", w_tensor=wp)
+                 x.buf.device, "sf_conv_fwd", w_tensor=wp, x_act=x if cin == x.C else None, keep=keep)
     return (out, None) if stats else out
 
 
@@ -635,7 +654,7 @@ def affine(x, scale=None, bias=None, res=None, relu=False, rep=1, out=None, out_
 
 
 def conv_dgrad(dz, wt_packed, x_like, kernel, stride=(1, 1, 1), padding=(0, 0, 0), dilation=(1, 1, 1),
-               out=None, accumulate=False):
+               out=None, accumulate=False, dz_planes=None):
     """Data gradient of a dense conv: dL/dx[N,Ti,Hi,Wi,Cin] (+)= conv^T(dL/dz, W).  `wt_packed` =
     pack_conv_weight(W.transpose(0, 1)) i.e. [Cin][tap][Cout_pad]; `x_like` gives the forward input's dims."""
     _require_gpu(dz.buf, "conv_dgrad")
@@ -645,13 +664,13 @@ def conv_dgrad(dz, wt_packed, x_like, kernel, stride=(1, 1, 1), padding=(0, 0, 0
         accumulate = False
     assert (out.N, out.T, out.H, out.W, out.C) == (x_like.N, x_like.T, x_like.H, x_like.W, cin), (out, x_like)
     if max(stride) > 1 and tuple(dilation) == (1, 1, 1) and (accumulate or (out.coff == 0 and out.cs == out.C)):
-        return _conv_dgrad_strided(dz, wt_packed, out, kernel, stride, padding, accumulate)
+        return _conv_dgrad_strided(dz, wt_packed, out, kernel, stride, padding, accumulate, dz_planes)
     d = ConvDesc(dz.N, dz.T, dz.H, dz.W, dz.C, dz.cs, dz.coff, out.T, out.H, out.W, cin, out.cs, out.coff, 1,
                  kernel[0], kernel[1], kernel[2], stride[0], stride[1], stride[2], padding[0], padding[1],
                  padding[2], dilation[0], dilation[1], dilation[2], cout_pad, ACT_NONE,
                  out.cs if accumulate else 0, out.coff if accumulate else 0, 1)
     _conv_launch(d, dz.ptr(), _ptr(wt_packed), None, None, out.ptr() if accumulate else None, out.ptr(),
-                 dz.buf.device, "sf_conv_fwd(transposed)", w_tensor=wt_packed)
+                 dz.buf.device, "sf_conv_fwd(transposed)", w_tensor=wt_packed, in_planes=dz_planes)
     return out
 
 
@@ -667,7 +686,7 @@ def _residue_taps(k, s, p, a):
 _TAP_INDEX = {}
 
 
-def _conv_dgrad_strided(dz, wt_packed, out, kernel, stride, padding, accumulate):
+def _conv_dgrad_strided(dz, wt_packed, out, kernel, stride, padding, accumulate, dz_planes=None):
     """Data gradient of a strided conv as one DENSE small conv over dL/dz per residue class of the input position
     (the transposed-gather formulation evaluates every tap at every input position and predicates s^2-1 of s^2
     of them away).  Class (a_t, a_h, a_w): dx[s*i + a] = sum_j dz[i - pad' + j] * W[tap_j]; stores are scattered
@@ -710,13 +729,35 @@ def _conv_dgrad_strided(dz, wt_packed, out, kernel, stride, padding, accumulate)
                              cout_pad, ACT_NONE, out.cs, out.coff, 0, stride[0], stride[1], stride[2], at, ah, aw,
                              out.T, out.H, out.W)
                 _conv_launch(d, dz.ptr(), _ptr(wsub), None, None, out.ptr() if add else None, out.ptr(),
-                             dz.buf.device, "sf_conv_fwd(strided dgrad class)", w_tensor=wsub)
+                             dz.buf.device, "sf_conv_fwd(strided dgrad class)", w_tensor=wsub, in_planes=dz_planes)
     return out
 
 
 # ------------------------------------------------------------------------------------------------ backward
+def bx_backward_wants_dz_planes(x, dz, cout, kernel, stride, padding, dilation, cin=None, cin_pad=None,
+                                dgrad=True):
+    """True when the layer's weight gradient or (stride-1) data gradient runs on conv_bx.hip: the caller then makes
+    dz's planes ONCE (act_planes) and hands them to both."""
+    cin = x.C if cin is None else cin
+    cin_pad = (cin + 15) // 16 * 16 if cin_pad is None else cin_pad
+    if cin_pad != cin or not SPLIT_K:
+        return False
+    kT, kH, kW = kernel
+    d = ConvDesc(x.N, x.T, x.H, x.W, cin, x.cs, x.coff, dz.T, dz.H, dz.W, cout, 0, 0, 1,
+                 kT, kH, kW, stride[0], stride[1], stride[2], padding[0], padding[1], padding[2],
+                 dilation[0], dilation[1], dilation[2], cin_pad, ACT_NONE, 0, 0, 0)
+    if lib().sf_conv_wgrad_bx_ws_floats(ctypes.byref(d), 1, 1) > 0:
+        return True
+    if dgrad and max(stride) == 1 and cout % 16 == 0:
+        dt = ConvDesc(dz.N, dz.T, dz.H, dz.W, cout, dz.cs, dz.coff, x.T, x.H, x.W, cin, cin, 0, 1,
+                      kT, kH, kW, 1, 1, 1, padding[0], padding[1], padding[2], dilation[0], dilation[1], dilation[2],
+                      cout, ACT_NONE, 0, 0, 1)
+        return lib().sf_conv_bx_ws_floats(ctypes.byref(dt), 1, 1) > 0
+    return False
+
+
 def conv_wgrad(x, dz, cout, kernel, stride=(1, 1, 1), padding=(0, 0, 0), dilation=(1, 1, 1), cin=None,
-               cin_pad=None, finish_into=None):
+               cin_pad=None, finish_into=None, x_planes=None, dz_planes=None):
     """dW packed [Cout, taps, cin_pad] = sum over positions of dz (x) x (split partials summed in fixed order).
     finish_into=(dst, Cin, fold_kw): instead of returning the packed gradient, sum the partials and ACCUMULATE
     them into dst, a contiguous tensor in nn.Conv3d's [Cout, Cin, kT, kH, kW] layout (e.g. the weight's .grad)."""
@@ -727,10 +768,20 @@ def conv_wgrad(x, dz, cout, kernel, stride=(1, 1, 1), padding=(0, 0, 0), dilatio
     d = ConvDesc(x.N, x.T, x.H, x.W, cin, x.cs, x.coff, dz.T, dz.H, dz.W, cout, 0, 0, 1,
                  kT, kH, kW, stride[0], stride[1], stride[2], padding[0], padding[1], padding[2],
                  dilation[0], dilation[1], dilation[2], cin_pad, ACT_NONE, 0, 0, 0)
-    S = lib().sf_conv_wgrad_splits(ctypes.byref(d))
-    part = torch.empty((S, cout, kT * kH * kW, cin_pad), dtype=torch.float32, device=x.buf.device)
-    _check(_traced(("conv", dz.rows, kT * kH * kW * cin, cout), lambda: lib().sf_conv_wgrad(
-        ctypes.byref(d), x.ptr(), dz.ptr(), dz.cs, dz.coff, _ptr(part), _stream())), "sf_conv_wgrad")
+    nws = lib().sf_conv_wgrad_bx_ws_floats(ctypes.byref(d), 1 if x_planes is not None else 0,
+                                           1 if dz_planes is not None else 0) if cin_pad == cin else 0
+    if nws > 0:  # long reductions: the bf16-piece kernel of conv_bx.hip (operand planes handed in or made in ws)
+        S = lib().sf_conv_wgrad_bx_splits(ctypes.byref(d))
+        part = torch.empty((S, cout, kT * kH * kW, cin_pad), dtype=torch.float32, device=x.buf.device)
+        ws = torch.empty((nws,), dtype=torch.float32, device=x.buf.device)
+        _check(_traced(("conv", dz.rows, kT * kH * kW * cin, cout), lambda: lib().sf_conv_wgrad_bx(
+            ctypes.byref(d), x.ptr(), _ptr(x_planes), dz.ptr(), dz.cs, dz.coff, _ptr(dz_planes), _ptr(part), _ptr(ws),
+            _stream())), "sf_conv_wgrad_bx")
+    else:
+        S = lib().sf_conv_wgrad_splits(ctypes.byref(d))
+        part = torch.empty((S, cout, kT * kH * kW, cin_pad), dtype=torch.float32, device=x.buf.device)
+        _check(_traced(("conv", dz.rows, kT * kH * kW * cin, cout), lambda: lib().sf_conv_wgrad(
+            ctypes.byref(d), x.ptr(), dz.ptr(), dz.cs, dz.coff, _ptr(part), _stream())), "sf_conv_wgrad")
     if finish_into is not None:
         dst, real_cin, fold_kw = finish_into
         assert dst.is_contiguous() and dst.dtype == torch.float32

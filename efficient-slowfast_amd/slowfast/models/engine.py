@@ -239,22 +239,24 @@ def _colsum(act):
 
 
 def _record_conv(x, conv_weight, conv_bias, wp_shape, gsrc, kernel, stride, padding, dilation, x_needs_grad=True,
-                 cin=None, unpack=None, fold_kw=0):
+                 cin=None, unpack=None, fold_kw=0, x_planes=None):
     """Backward of a dense conv whose output gradient will be found in `gsrc` (an Act).  fold_kw: the stem layout
-    (packed channel = (kw, ci)); `unpack` maps the packed gradient to the parameter's layout on the autograd path."""
+    (packed channel = (kw, ci)); `unpack` maps the packed gradient to the parameter's layout on the autograd path.
+    x_planes: the bf16 piece planes of x the forward conv made (conv_bx.hip), reused by the weight gradient."""
     t = tape()
     if t is None:
         return
     cout = conv_weight.shape[0]
 
-    def wgrad(g):
+    def wgrad(g, zp):
         tgt = t.pgrad_target(conv_weight)
         if tgt is not None:  # partial sum + un-pack + accumulate into .grad in one kernel
             real_cin = conv_weight.shape[1]
             sfhip.conv_wgrad(x, g, cout, kernel, stride, padding, dilation, cin=cin, cin_pad=wp_shape[2],
-                             finish_into=(tgt, real_cin, fold_kw))
+                             finish_into=(tgt, real_cin, fold_kw), x_planes=x_planes, dz_planes=zp)
         else:
-            dwp = sfhip.conv_wgrad(x, g, cout, kernel, stride, padding, dilation, cin=cin, cin_pad=wp_shape[2])
+            dwp = sfhip.conv_wgrad(x, g, cout, kernel, stride, padding, dilation, cin=cin, cin_pad=wp_shape[2],
+                                   x_planes=x_planes, dz_planes=zp)
             t.add_pgrad(conv_weight, unpack(dwp) if unpack else sfhip.unpack_conv_weight_grad(dwp, conv_weight.shape))
         if conv_bias is not None:
             t.add_pgrad(conv_bias, _colsum(g))
@@ -262,6 +264,12 @@ def _record_conv(x, conv_weight, conv_bias, wp_shape, gsrc, kernel, stride, padd
     def bwd():
         g = gsrc() if callable(gsrc) else gsrc
         dev = x.buf.device
+        # dL/dz as bf16 piece planes, made once on this stream for the weight gradient and the data gradient when
+        # either runs on conv_bx.hip
+        zp = None
+        if fold_kw == 0 and sfhip.bx_backward_wants_dz_planes(x, g, cout, kernel, stride, padding, dilation, cin=cin,
+                                                               cin_pad=wp_shape[2], dgrad=x_needs_grad):
+            zp = sfhip.act_planes(g)
         if OVERLAP_PATHS and WGRAD_COMPANION and not t.serial and x_needs_grad and dev.type == "cuda":
             # the weight gradient only feeds the parameter's .grad: issue it on a companion stream so that it
             # overlaps the data gradient (both are short-grid GEMMs on the res4 / res5 layers); joined by
@@ -270,12 +278,15 @@ def _record_conv(x, conv_weight, conv_bias, wp_shape, gsrc, kernel, stride, padd
             wg = _companion_stream(cur)
             _sync_streams(cur, wg)
             with torch.cuda.stream(wg):
-                wgrad(g)
+                wgrad(g, zp)
             g.buf.record_stream(wg)  # e.g. the masked-gradient temporary of a bare ReLU dies with this closure
             x.buf.record_stream(wg)
+            for pl in (zp, x_planes):
+                if pl is not None:
+                    pl.record_stream(wg)
             t.joins.add(wg)
         else:
-            wgrad(g)
+            wgrad(g, zp)
         if x_needs_grad:
             if conv_weight.dim() == 5 and tuple(conv_weight.shape[2:]) == tuple(kernel):
                 wtp = _packed_pair(conv_weight)[1]
@@ -285,9 +296,11 @@ def _record_conv(x, conv_weight, conv_bias, wp_shape, gsrc, kernel, stride, padd
                                     conv_weight.shape[0], conv_weight.shape[1], *kernel).transpose(0, 1).contiguous()))
             fresh = t.grad_of_uninitialised(x)
             if fresh is not None:  # first consumer of x: write, do not accumulate
-                sfhip.conv_dgrad(g, wtp, x, kernel, stride, padding, dilation, out=fresh, accumulate=False)
+                sfhip.conv_dgrad(g, wtp, x, kernel, stride, padding, dilation, out=fresh, accumulate=False,
+                                 dz_planes=zp)
             else:
-                sfhip.conv_dgrad(g, wtp, x, kernel, stride, padding, dilation, out=t.grad_of(x), accumulate=True)
+                sfhip.conv_dgrad(g, wtp, x, kernel, stride, padding, dilation, out=t.grad_of(x), accumulate=True,
+                                 dz_planes=zp)
 
     t.record(bwd)
 
@@ -665,9 +678,10 @@ def conv_bn_act(x, conv, bn=None, relu=False, res=None, out=None, out_reserve=(0
         if conv.groups == 1:
             # plain BatchNorm3d: its batch statistics come out of the conv's epilogue (no extra pass over z)
             want = _plain_bn(bn) and bn.affine
-            z = sfhip.conv(x, wp, k, s, p, d, bias=conv.bias, stats=want)
+            keep = {} if tape() is not None else None
+            z = sfhip.conv(x, wp, k, s, p, d, bias=conv.bias, stats=want, keep=keep)
             z, st = z if want else (z, None)
-            _record_conv(x, conv.weight, conv.bias, wp.shape, z, k, s, p, d)
+            _record_conv(x, conv.weight, conv.bias, wp.shape, z, k, s, p, d, x_planes=keep.get("x") if keep else None)
         else:
             ones = _cached(conv, "_sf_ones", (conv.out_channels, str(x.buf.device)),
                            lambda: torch.ones(conv.out_channels, dtype=torch.float32, device=x.buf.device))

@@ -261,6 +261,16 @@ int sf_copy_channels(const float* in, int in_cs, int in_coff, float* out, int ou
  * Weight gradient: partial[s][co][tap][ci] over S = sf_conv_wgrad_splits(d) position splits; the caller
  * sums the S partials (fixed order).  `d` is the FORWARD descriptor; dz is dL/d(conv output).          */
 int sf_conv_wgrad_splits(const sf_conv_desc* d);
+/* The same on the bf16 matrix pipe (conv_bx.hip: fp32 operands as three exact bf16 pieces, six MFMAs per product,
+ * fragments by transposing LDS reads) for the long-reduction layers: sf_conv_wgrad_bx_splits(d) = S of its partial
+ * buffer [S][Cout][taps][Cin] (0: shape not served, use sf_conv_wgrad); x_planes / dz_planes = sf_bx_split of the
+ * input view ([N*Ti*Hi*Wi][Cin]) / of dz ([M][Cout]) or NULL (made in ws: sf_conv_wgrad_bx_ws_floats(d, have_x,
+ * have_dz) floats).  sf_conv_wgrad_finish sums and un-packs the partials as for sf_conv_wgrad.  sf_conv_tune(9, 0 | 1
+ * | 2): off / where it wins / every shape it covers.                                                              */
+int sf_conv_wgrad_bx_splits(const sf_conv_desc* d);
+long sf_conv_wgrad_bx_ws_floats(const sf_conv_desc* d, int have_x_planes, int have_dz_planes);
+int sf_conv_wgrad_bx(const sf_conv_desc* d, const float* x, const unsigned short* x_planes, const float* dz, int dz_cs,
+                     int dz_coff, const unsigned short* dz_planes, float* partial, float* ws, void* stream);
 int sf_conv_wgrad(const sf_conv_desc* d, const float* x, const float* dz, int dz_cs, int dz_coff,
                   float* partial, void* stream);
 /* Sum the S split partials [S][Cout][packed_taps][cin_pad] in a fixed order and store / accumulate them in
