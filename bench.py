@@ -595,10 +595,11 @@ def main():
                        "mode": "train step: train-mode forward + CE + backward + 1 flat-gradient all-reduce + SGD"
                        if train else "eval forward (inference)",
                        "clips_per_gpu": batch, "global_batch": batch * world, "layout": "NCTHW in, NDHWC inside",
-                       "arithmetic": "fp32 tensors, fp32 accumulation everywhere; convs and d = 128 attention on "
-                                     "v_mfma_f32_*_f32; attention products of head widths 17..64 and 8 as exact "
-                                     "three-way bf16 splits, six v_mfma_f32_32x32x16_bf16 per fp32 product "
-                                     "(fp32-level results: DESIGN 6a-4)"
+                       "arithmetic": "fp32 tensors, fp32 accumulation everywhere; short-reduction convs and d = 128 "
+                                     "attention on v_mfma_f32_*_f32; the long-reduction convs (forward, data and weight "
+                                     "gradient of the 1x3x3 / 3x1x1 layers over >= 128 channels) and the attention "
+                                     "products of head widths 17..64 and 8 as exact three-way bf16 splits, six "
+                                     "v_mfma_f32_32x32x16_bf16 per fp32 product (fp32-level results: DESIGN 6a-4, 6a-5)"
                        if sfhip.lib().sf_attn_products_per_fp32(32) == 6 else "fp32 (v_mfma_f32_*_f32)",
                        "launch": (graph_note or "eager") if graph is None else (
                            "hipGraph replay" if auto is None else

@@ -43,6 +43,7 @@ struct BxArgs {
   const float* res;
   float* out;
   int M, ntaps, cpk, nk, S, nk_per, nb_n, tiles;
+  int tap_major;             // K order: 1 = tap outer / channel chunk inner (strided layers), 0 = chunk outer / tap inner
   unsigned a_rows, a_bytes, b_bytes;      // rows of a plane (the zero row's index), bytes of all three planes
   unsigned a_plane, b_plane;              // bytes per plane
   unsigned wo_mul, wo_sh, ho_mul, ho_sh, to_mul, to_sh;
@@ -54,7 +55,7 @@ __device__ __forceinline__ unsigned mdiv(unsigned n, unsigned mul, unsigned sh) 
 
 typedef __attribute__((address_space(3))) void lds_void;
 
-template <int BN, bool DIRECT>
+template <int BN, bool DIRECT, int VAR>
 __global__ __launch_bounds__(512, 2) void conv_bx_kernel(const BxArgs p) {
   constexpr int B_STAGE = 3 * BN * BXC_ROWB;
   constexpr int STAGE = BXC_A_STAGE + B_STAGE;
@@ -110,36 +111,59 @@ __global__ __launch_bounds__(512, 2) void conv_bx_kernel(const BxArgs p) {
   const __amdgpu_buffer_rsrc_t a_rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.ap, 0, p.a_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t b_rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.bp, 0, p.b_bytes, 0x00020000);
 
-  // ---- K iteration state of the loader (runs two steps ahead of the MFMAs)
-  int l_tap = ks0 / p.cpk;
-  int l_c = ks0 - l_tap * p.cpk;  // 16-channel chunk within the tap
+  // ---- K iteration state of the loader (runs two steps ahead of the MFMAs).  K order: 16-channel chunk OUTER, tap
+  // INNER — consecutive steps read the same input rows shifted by one tap, so a workgroup's share of the K steps
+  // touches (rows + halo) x (its few channel chunks) and the taps' re-reads hit L1 / L2; tap-major order streamed
+  // whole rows of all channels once per tap.  Strided layers (whose taps' rows do not overlap) keep the tap-major order:
+  // measured 171 vs 135 TFLOP/s on the 1x3x3 stride-2 layer; the stride-1 layers are within noise either way.
+  int l_c = p.tap_major ? ks0 % p.cpk : ks0 / p.ntaps;          // 16-channel chunk
+  int l_tap = p.tap_major ? ks0 / p.cpk : ks0 - l_c * p.ntaps;
   int l_kw = l_tap % d.kW, l_kh = (l_tap / d.kW) % d.kH, l_kt = l_tap / (d.kW * d.kH);
-  unsigned l_voff = a_voff(l_kt, l_kh, l_kw);
-  int l_ks = ks0;
-  auto issue = [&](int stage) {
-    char* const sa = smem + stage * STAGE + wave * 1024;
-    const unsigned a_so = (unsigned)l_c * (unsigned)BXC_ROWB;
-#pragma unroll
-    for (int pc = 0; pc < 3; ++pc)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rs, (lds_void*)(sa + pc * (BXC_BM * BXC_ROWB)), 16, l_voff,
-                                               a_so + (unsigned)pc * p.a_plane, 0, 0);
-    if (b_loader) {
+  // one step's loads = 6 LDS-DMA pieces per wave (3 A planes, 3 B planes): `piece(stage, g)` issues piece g of the
+  // loader's current step, `advance()` moves the loader to the next step
+  unsigned cur_voff = 0, cur_aso = 0, cur_bso = 0;
+  auto prepare = [&]() {
+    cur_voff = a_voff(l_kt, l_kh, l_kw);
+    cur_aso = (unsigned)l_c * (unsigned)BXC_ROWB;
+    cur_bso = (unsigned)(l_tap * p.cpk + l_c) * (unsigned)BXC_ROWB;
+  };
+  auto piece = [&](int stage, int g) {
+    if (g < 3) {
+      char* const sa = smem + stage * STAGE + wave * 1024;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rs, (lds_void*)(sa + g * (BXC_BM * BXC_ROWB)), 16, cur_voff,
+                                               cur_aso + (unsigned)g * p.a_plane, 0, 0);
+    } else if (b_loader) {
       char* const sb = smem + stage * STAGE + BXC_A_STAGE + wave * 1024;
-      const unsigned b_so = (unsigned)l_ks * (unsigned)BXC_ROWB;
-#pragma unroll
-      for (int pc = 0; pc < 3; ++pc)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(b_rs, (lds_void*)(sb + pc * (BN * BXC_ROWB)), 16, b_voff,
-                                                 b_so + (unsigned)pc * p.b_plane, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(b_rs, (lds_void*)(sb + (g - 3) * (BN * BXC_ROWB)), 16, b_voff,
+                                               cur_bso + (unsigned)(g - 3) * p.b_plane, 0, 0);
     }
-    ++l_ks;
-    if (++l_c == p.cpk) {  // next tap
-      l_c = 0;
-      if (++l_kw == d.kW) {
-        l_kw = 0;
-        if (++l_kh == d.kH) { l_kh = 0; ++l_kt; }
+  };
+  auto advance = [&]() {
+    if (p.tap_major) {
+      if (++l_c == p.cpk) {
+        l_c = 0;
+        ++l_tap;
+        if (++l_kw == d.kW) {
+          l_kw = 0;
+          if (++l_kh == d.kH) { l_kh = 0; ++l_kt; }
+        }
       }
-      l_voff = a_voff(l_kt, l_kh, l_kw);
+      return;
     }
+    ++l_tap;
+    if (++l_kw == d.kW) {
+      l_kw = 0;
+      if (++l_kh == d.kH) {
+        l_kh = 0;
+        if (++l_kt == d.kT) { l_kt = 0; l_tap = 0; ++l_c; }  // next channel chunk
+      }
+    }
+  };
+  auto issue = [&](int stage) {
+    prepare();
+#pragma unroll
+    for (int g = 0; g < 6; ++g) piece(stage, g);
+    advance();
   };
 
   // ---- fragment addresses: lane (r = lane & 31, h = lane >> 5) reads 16 bytes of row r, k = 8h .. 8h+7
@@ -166,7 +190,7 @@ __global__ __launch_bounds__(512, 2) void conv_bx_kernel(const BxArgs p) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __builtin_amdgcn_s_barrier();  // ... and every other wave's: the stage is complete, and stage it - 1 is free
-    if (it + 2 < nsteps) issue((it + 2) % BXC_STAGES);
+    if (!(VAR & 16) && it + 2 < nsteps) issue((it + 2) % BXC_STAGES);
     const char* const st = smem + (it % BXC_STAGES) * STAGE;
     u32x4 af[2][3], bf[NT][3];
 #pragma unroll
@@ -178,16 +202,31 @@ __global__ __launch_bounds__(512, 2) void conv_bx_kernel(const BxArgs p) {
       for (int j = 0; j < NT; ++j)
         bf[j][pc] = *reinterpret_cast<const u32x4*>(st + b_frag + pc * (BN * BXC_ROWB) + j * (32 * BXC_ROWB));
     }
+    if (VAR & 8) {  // ablation: no MFMAs (the fragments stay live through one xor chain)
+      unsigned x = 0;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+      for (int pc = 0; pc < 3; ++pc) {
 #pragma unroll
-      for (int j = 0; j < NT; ++j) acc[i][j] = mfma_split(af[i], bf[j], acc[i][j]);
+        for (int i = 0; i < 2; ++i) x ^= af[i][pc][0] ^ af[i][pc][1] ^ af[i][pc][2] ^ af[i][pc][3];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) x ^= bf[j][pc][0] ^ bf[j][pc][1] ^ bf[j][pc][2] ^ bf[j][pc][3];
+      }
+      acc[0][0][0] += __builtin_bit_cast(float, x & 0x007fffffu);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = mfma_split(af[i], bf[j], acc[i][j]);
+    }
   }
 
   // ---- an accumulator register holds column lane & 31 of rows (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5): 128
   // contiguous bytes per half-wave and row.  DIRECT (one workgroup per tile, dense stores): the conv epilogue here;
   // otherwise the raw partial tile -> ws[split][m][n] for the finish kernel
   const int col = lane & 31, rsub = 4 * (lane >> 5);
+  if ((VAR & 4) && p.M > 0) {  // ablation: no stores (the accumulators stay live: the sum goes out when M <= 0, i.e. never)
+    return;
+  }
   if (DIRECT) {
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
@@ -196,16 +235,21 @@ __global__ __launch_bounds__(512, 2) void conv_bx_kernel(const BxArgs p) {
       const float sc = (p.scale && n_ok) ? p.scale[n] : 1.f;
       const float bi = (p.bias && n_ok) ? p.bias[n] : 0.f;
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < 2; ++i) {
+        // the residual may BE the output buffer (accumulating data gradients): all 16 loads of a tile are issued
+        // before its first store, so they are in flight together instead of one round trip per element
+        float r[16];
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
           const int m = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + rsub;
-          if (m < p.M && n_ok) {
-            float v = acc[i][j][e] * sc + bi;
-            if (p.res) v += p.res[(long)m * d.res_cs + d.res_coff + n];
-            p.out[(long)m * d.out_cs + d.out_coff + n] = sf_act(v, d.act);
-          }
+          r[e] = (p.res && m < p.M && n_ok) ? p.res[(long)m * d.res_cs + d.res_coff + n] : 0.f;
         }
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int m = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + rsub;
+          if (m < p.M && n_ok) p.out[(long)m * d.out_cs + d.out_coff + n] = sf_act(acc[i][j][e] * sc + bi + r[e], d.act);
+        }
+      }
     }
     return;
   }
@@ -504,14 +548,31 @@ long align4(long floats) { return (floats + 3) & ~3L; }
 long a_plane_floats(const sf_conv_desc* d, long a_rows) { return align4((3 * (a_rows + 1) * d->Cin + 1) / 2); }
 long b_plane_floats(const sf_conv_desc* d, int nk) { return align4((3L * (d->Cout + 1) * nk * BXC_BK + 1) / 2); }
 
-template <int BN, bool DIRECT>
-int launch_bx(const BxArgs& a, int grid, hipStream_t stream) {
+template <int BN, bool DIRECT, int VAR>
+int launch_bx_v(const BxArgs& a, int grid, hipStream_t stream) {
   constexpr int lds = BXC_STAGES * (BXC_A_STAGE + 3 * BN * BXC_ROWB);
   static SfLdsAttr at;
-  if (!sf_ensure_dyn_lds(at, reinterpret_cast<const void*>(conv_bx_kernel<BN, DIRECT>), lds)) return SF_ELAUNCH;
-  hipLaunchKernelGGL((conv_bx_kernel<BN, DIRECT>), dim3(grid), dim3(512), lds, stream, a);
+  if (!sf_ensure_dyn_lds(at, reinterpret_cast<const void*>(conv_bx_kernel<BN, DIRECT, VAR>), lds)) return SF_ELAUNCH;
+  hipLaunchKernelGGL((conv_bx_kernel<BN, DIRECT, VAR>), dim3(grid), dim3(512), lds, stream, a);
   SF_CHECK_LAUNCH();
   return SF_OK;
+}
+
+template <int BN, bool DIRECT>
+int launch_bx(const BxArgs& a, int grid, hipStream_t stream) {
+  // SF_CONV_BX_VAR: timing ablations (results invalid) — 4 no stores, 8 no MFMAs, 16 no loads inside the loop.
+  // Measured with them on the res4 1x3x3 layer (85 us): fragment reads + barriers alone 25 us, + the LDS-DMA loads
+  // 53 us, MFMAs + fragment reads without the loads 63 us: the loop is bound by the ~48 GB/s per CU at which the
+  // operand pieces arrive in LDS, not by the matrix pipe.  Tried without gain: the loads behind the fragment reads,
+  // s_setprio around the MFMAs, one LDS-DMA piece per MFMA group instead of a burst behind the barrier, tap-major K order.
+  static const int var = [] { const char* e = getenv("SF_CONV_BX_VAR"); return e ? atoi(e) : 0; }();
+  switch (var) {
+    case 4: return launch_bx_v<BN, DIRECT, 4>(a, grid, stream);
+    case 12: return launch_bx_v<BN, DIRECT, 12>(a, grid, stream);
+    case 20: return launch_bx_v<BN, DIRECT, 20>(a, grid, stream);
+    case 28: return launch_bx_v<BN, DIRECT, 28>(a, grid, stream);
+    default: return launch_bx_v<BN, DIRECT, 0>(a, grid, stream);
+  }
 }
 
 }  // namespace
@@ -589,6 +650,7 @@ int sf_conv_bx_try(const sf_conv_desc* d, const float* in, const unsigned short*
   a.ntaps = d->kT * d->kH * d->kW;
   a.cpk = d->Cin / BXC_BK;
   a.nk = pl.nk; a.S = pl.S; a.nk_per = pl.nk_per; a.nb_n = pl.nb_n; a.tiles = pl.tiles;
+  a.tap_major = (d->sT > 1 || d->sH > 1 || d->sW > 1) ? 1 : 0;
   a.a_rows = (unsigned)pl.a_rows;
   a.a_plane = (unsigned)((pl.a_rows + 1) * d->Cin * 2);
   a.a_bytes = 3u * a.a_plane;

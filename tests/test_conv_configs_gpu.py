@@ -34,7 +34,8 @@ def tune():
     import sfhip
     L = sfhip.lib()
     yield L
-    for knob, v in ((0, 1), (1, -1), (2, 0), (3, 0), (4, 1), (5, 0), (6, 1), (10, 1), (11, -1), (12, 0)):
+    for knob, v in ((0, 1), (1, -1), (2, 0), (3, 0), (4, 1), (5, 0), (6, 1), (7, 1), (8, 0), (9, 1), (10, 1), (11, -1),
+                    (12, 0)):
         L.sf_conv_tune(knob, v)
 
 
@@ -74,7 +75,8 @@ def test_forced_conv_wave_configuration(shape, cfg, persist, tune):
         pytest.skip("KS = 4 configurations have no persistent form")
     x, wt, bias, dy = _case(shape)
     assert tune.sf_conv_tune(1, cfg) == 0 and tune.sf_conv_tune(4, persist) == 0
-    tune.sf_conv_tune(6, 0)  # conv_small has its own test
+    tune.sf_conv_tune(6, 0)  # conv_small and conv_bx have their own tests
+    tune.sf_conv_tune(7, 0)
     xa = _act(x)
     wp, wtp = sfhip.pack_conv_weight_pair(wt)
     # forward with the BN statistics taken in the epilogue
@@ -115,6 +117,7 @@ def test_forced_rows_per_tile(rows, tune):
     name, cin, cout, k, p, dims = shape
     x, wt, bias, dy = _case(shape, seed=rows)
     tune.sf_conv_tune(6, 0)
+    tune.sf_conv_tune(7, 0)
     wp, _ = sfhip.pack_conv_weight_pair(wt)
     ref = F.conv3d(x.double(), wt.double(), bias.double(), 1, p)
     for cfg in (0, 3, 5, 6):
@@ -177,7 +180,7 @@ def test_forced_wgrad_wave_configuration(shape, blocks, target, tune):
     if blocks == -1 and target not in (0, 200):
         pytest.skip("planner's block shape: two split counts are enough")
     x, wt, bias, dy = _case(shape)
-    assert tune.sf_conv_tune(11, blocks) == 0 and tune.sf_conv_tune(12, target) == 0
+    assert tune.sf_conv_tune(11, blocks) == 0 and tune.sf_conv_tune(12, target) == 0 and tune.sf_conv_tune(9, 0) == 0
     wd = wt.double().requires_grad_(True)
     F.conv3d(x.double(), wd, None, 1, p).backward(dy.double())
     dwp = sfhip.conv_wgrad(_act(x), _act(dy), cout, k, (1, 1, 1), p)
@@ -186,3 +189,71 @@ def test_forced_wgrad_wave_configuration(shape, blocks, target, tune):
     acc = torch.ones_like(wt)
     sfhip.conv_wgrad(_act(x), _act(dy), cout, k, (1, 1, 1), p, finish_into=(acc, cin, 0))
     assert _rel(acc - 1.0, wd.grad) < TOL, (name, blocks, target)
+
+
+# ---- conv_bx.hip: fp32 products as six bf16 MFMAs on operand piece planes (forward, data gradient, weight gradient),
+# forced onto every shape it covers (sf_conv_tune(7, 2) / (9, 2)) and held to an fp32-LEVEL bound against fp64 — the
+# three-way split is exact and the dropped product terms are below 2^-24, so the results are as close as the f32 MFMA's
+BX_TOL = 5e-6
+BX_SHAPES = [
+    # name, Cin, Cout, kernel, stride, pad, dil, (N, T, H, W)
+    ("direct_128_128_s3", 128, 128, (1, 3, 3), (1, 1, 1), (0, 1, 1), (1, 1, 1), (2, 4, 23, 21)),       # S = 1, ragged M
+    ("splitk_512_512_s3", 512, 512, (1, 3, 3), (1, 1, 1), (0, 1, 1), (1, 1, 1), (2, 8, 14, 14)),       # 26 tiles: S > 1
+    ("t3_1024_256", 1024, 256, (3, 1, 1), (1, 1, 1), (1, 0, 0), (1, 1, 1), (3, 5, 13, 11)),            # temporal borders
+    ("stride2_256_256", 256, 256, (1, 3, 3), (1, 2, 2), (0, 1, 1), (1, 1, 1), (3, 4, 28, 28)),          # tap-major K order
+    ("ragged_144_192_dil2", 144, 192, (1, 3, 3), (1, 1, 1), (0, 2, 2), (1, 2, 2), (2, 3, 19, 23)),      # ragged N tile
+    ("plain_1152_512", 1152, 512, (1, 1, 1), (1, 1, 1), (0, 0, 0), (1, 1, 1), (2, 2, 25, 27)),
+]
+
+
+@pytest.mark.parametrize("shape", BX_SHAPES, ids=[s[0] for s in BX_SHAPES])
+def test_bf16_piece_conv_forward_dgrad_wgrad(shape, tune):
+    import ctypes
+    import sfhip
+    name, cin, cout, k, s, p, dl, (n, t, h, w) = shape
+    dev = _dev()
+    g = torch.Generator().manual_seed(len(name))
+    x = torch.randn(n, cin, t, h, w, generator=g).to(dev)
+    wt = (torch.randn(cout, cin, *k, generator=g) / np.sqrt(cin * k[0] * k[1] * k[2])).to(dev)
+    bias = (torch.randn(cout, generator=g) * 0.1).to(dev)
+    assert tune.sf_conv_tune(7, 2) == 0 and tune.sf_conv_tune(9, 2) == 0
+    try:
+        # the input is a channel slice of a wider buffer, the output lands in a slice of a wider buffer
+        xfull = sfhip.Act(torch.randn(n, t, h, w, cin + 32, generator=g).to(dev))
+        xa = xfull.slice(16, cin)
+        xa.buf[..., 16:16 + cin] = x.permute(0, 2, 3, 4, 1)
+        wp, wtp = sfhip.pack_conv_weight_pair(wt)
+        ref = F.conv3d(x.double(), wt.double(), bias.double(), s, p, dl)
+        od = ref.shape[2:]
+        d = sfhip.ConvDesc(n, t, h, w, cin, xa.cs, xa.coff, od[0], od[1], od[2], cout, cout, 0, 1, k[0], k[1], k[2],
+                           s[0], s[1], s[2], p[0], p[1], p[2], dl[0], dl[1], dl[2], cin, 0, 0, 0, 0)
+        assert tune.sf_conv_bx_ws_floats(ctypes.byref(d), 0, 1) > 0, "the forced kernel must take this shape"
+        z = sfhip.conv(xa, wp, k, s, p, dl, bias=bias, out_reserve=(8, 4))
+        assert _rel(_ncthw(z), ref) < BX_TOL, name
+        # scale + residual + ReLU epilogue, with the input's planes handed in (what the training path does)
+        res = torch.randn_like(ref, dtype=torch.float32)
+        sc = torch.rand(cout, device=dev) + 0.5
+        keep = {}
+        y = sfhip.conv(xa, wp, k, s, p, dl, scale=sc, bias=bias, relu=True, res=_act(res), keep=keep)
+        assert "x" in keep
+        ref2 = F.relu(F.conv3d(x.double(), wt.double(), None, s, p, dl) * sc.double().view(1, -1, 1, 1, 1) +
+                      bias.double().view(1, -1, 1, 1, 1) + res.double())
+        assert _rel(_ncthw(y), ref2) < BX_TOL, name
+        # gradients
+        dy = torch.randn(ref.shape, generator=g).to(dev)
+        xd, wd = x.double().requires_grad_(True), wt.double().requires_grad_(True)
+        F.conv3d(xd, wd, None, s, p, dl).backward(dy.double())
+        dya = _act(dy)
+        zp = sfhip.act_planes(dya)
+        dxa = sfhip.conv_dgrad(dya, wtp, xa, k, s, p, dl, dz_planes=zp)
+        assert _rel(_ncthw(dxa), xd.grad) < BX_TOL, name
+        sfhip.conv_dgrad(dya, wtp, xa, k, s, p, dl, out=dxa, accumulate=True)     # planes made inside this time
+        assert _rel(_ncthw(dxa), 2 * xd.grad) < BX_TOL, name
+        dwp = sfhip.conv_wgrad(xa, dya, cout, k, s, p, dl, x_planes=keep["x"], dz_planes=zp)
+        assert _rel(sfhip.unpack_conv_weight_grad(dwp, wt.shape), wd.grad) < BX_TOL, name
+        acc = torch.ones_like(wt)
+        sfhip.conv_wgrad(xa, dya, cout, k, s, p, dl, finish_into=(acc, cin, 0))  # planes made inside
+        assert _rel(acc - 1.0, wd.grad) < BX_TOL, name
+    finally:
+        tune.sf_conv_tune(7, 1)
+        tune.sf_conv_tune(9, 1)

@@ -97,7 +97,7 @@ for name, T, H, W, cin, cout, k, s, p, tr in SHAPES:
         parts.append(timeit(run))
     L.sf_conv_tune(8, 0)
     L.sf_conv_tune(7, 1)
-    y1 = run()  # default gate: did the planner take it?
+    gated = timeit(run)  # default gate: did the planner take it?
     M = y.rows
     K = cin * k[0] * k[1] * k[2]
     fl = 2.0 * M * K * cout
@@ -105,5 +105,6 @@ for name, T, H, W, cin, cout, k, s, p, tr in SHAPES:
     tot[1] += res[1][0]
     print("%-28s %7d %6d | %9.4f %6.1f %9.2e | %9.4f %6.1f %9.2e | %5.2f | split %.4f gemm %.4f (%5.1f TF/s) finish %.4f" % (
         name, M, K, res[0][0], fl / res[0][0] / 1e9, res[0][1], res[1][0], fl / res[1][0] / 1e9, res[1][1],
-        res[0][0] / res[1][0], parts[0], parts[1], fl / parts[1] / 1e9, parts[2]))
+        res[0][0] / res[1][0], parts[0], parts[1], fl / parts[1] / 1e9, parts[2]) +
+          ("  gate: %s" % ("bx" if abs(gated - res[1][0]) < abs(gated - res[0][0]) else "wave")))
 print("total: wave %.3f ms, bx %.3f ms" % (tot[0], tot[1]))

@@ -68,7 +68,7 @@ def d_dgrad(dz, wtp, x_like, kernel, stride=(1, 1, 1), padding=(0, 0, 0), dilati
             (x_like.T, x_like.H, x_like.W), dz.N)
 
 
-def d_wgrad(x, dz, cout, kernel, stride=(1, 1, 1), padding=(0, 0, 0), dilation=(1, 1, 1), cin=None, cin_pad=None):
+def d_wgrad(x, dz, cout, kernel, stride=(1, 1, 1), padding=(0, 0, 0), dilation=(1, 1, 1), cin=None, cin_pad=None, **k):
     return (dz.N * dz.T * dz.H * dz.W, cin or x.C, cout, tuple(kernel), tuple(stride), (x.T, x.H, x.W), dz.N)
 
 
