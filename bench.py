@@ -206,6 +206,51 @@ def _free_port():
     return port
 
 
+def _parse_cpulist(txt):
+    cpus = set()
+    for part in txt.strip().split(","):
+        if not part:
+            continue
+        a, _, b = part.partition("-")
+        cpus.update(range(int(a), int(b or a) + 1))
+    return cpus
+
+
+def rank_cpu_sets(n):
+    """CPUs for each of n ranks of this node, WITHOUT touching the GPU: the CPUs of the NUMA node GPU r hangs off
+    (/sys/class/drm/renderD<128 + r>/device/numa_node) shared evenly between the ranks on that node; an even split of
+    the allowed CPUs where sysfs does not say.  The launcher threads of 8 ranks otherwise wander over one host."""
+    allowed = sorted(os.sched_getaffinity(0))
+    nodes = []
+    for r in range(n):
+        node = -1
+        try:
+            with open("/sys/class/drm/renderD%d/device/numa_node" % (128 + r)) as f:
+                node = int(f.read().strip())
+        except (OSError, ValueError):
+            pass
+        nodes.append(node)
+    out = []
+    for r in range(n):
+        cpus = None
+        if nodes[r] >= 0:
+            try:
+                with open("/sys/devices/system/node/node%d/cpulist" % nodes[r]) as f:
+                    on_node = sorted(_parse_cpulist(f.read()) & set(allowed))
+                peers = [q for q in range(n) if nodes[q] == nodes[r]]
+                share = len(on_node) // len(peers)
+                if share >= 1:
+                    i = peers.index(r)
+                    cpus = on_node[i * share:(i + 1) * share]
+            except (OSError, ValueError):
+                cpus = None
+        if not cpus:
+            share = max(1, len(allowed) // n)
+            cpus = allowed[r * share:(r + 1) * share] or allowed
+        out.append((nodes[r], cpus))
+    return out
+
+
 def spawn_ranks(n, argv):
     """Start n copies of this script, one per GPU (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment:
     what torch.distributed.run would set), wait for all of them and return the exit code: 0 only if every rank
@@ -214,11 +259,15 @@ def spawn_ranks(n, argv):
     import subprocess
     port = _free_port()
     procs = []
+    cpu_sets = rank_cpu_sets(n)
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // n)))
+        env.setdefault("OMP_NUM_THREADS", str(max(1, min(len(cpu_sets[r][1]), (os.cpu_count() or 8) // n))))
+        # each rank pins itself (before its first GPU call) to the CPUs next to its GPU: main() applies SF_RANK_CPUS
+        env.setdefault("SF_RANK_CPUS", ",".join(str(c) for c in cpu_sets[r][1]))
+        env.setdefault("SF_RANK_NUMA", str(cpu_sets[r][0]))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
                                       stdout=None if r == 0 else subprocess.DEVNULL))
     rc = 0
@@ -292,6 +341,15 @@ def main():
         raise SystemExit(spawn_ranks(args.gpus, sys.argv[1:]))
     if args.gpus != world:
         raise SystemExit("--gpus %d but the launcher started %d ranks" % (args.gpus, world))
+    affinity = None
+    if os.environ.get("SF_RANK_CPUS"):  # set by spawn_ranks: pin this rank's threads before anything touches the GPU
+        try:
+            cpus = sorted(int(c) for c in os.environ["SF_RANK_CPUS"].split(",") if c)
+            os.sched_setaffinity(0, cpus)
+            affinity = {"numa_node": int(os.environ.get("SF_RANK_NUMA", "-1")), "cpus": len(cpus),
+                        "first_cpu": cpus[0], "last_cpu": cpus[-1]}
+        except (OSError, ValueError):
+            affinity = None
     assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback for the hot path)"
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
@@ -625,8 +683,13 @@ def main():
             res["roofline"] = roofline
             res["kernel_family_ms_per_step"] = family_ms
         res["n_ranks_seen"] = n_ranks_seen
+        if affinity is not None:
+            res["rank0_cpu_affinity"] = affinity
         if train:
-            res["allreduce"] = {"chunks_per_step": flat.chunks_last_step,
+            # the flat gradient buffer of the last timed step as one integer (every kernel and RCCL's reduction order are
+            # deterministic: the chunked and the single-collective schedule must agree on it bit for bit)
+            ghash = int(flat.flat.view(torch.int32).to(torch.int64).sum().item()) & 0xffffffffffff
+            res["allreduce"] = {"chunks_per_step": flat.chunks_last_step, "grad_hash": ghash,
                                 "schedule": "one collective after the backward" if args.no_overlap_allreduce else
                                 "flat fp32 gradient in chunks [s5+head | s4+s4_fuse | rest] on a comm stream, each issued "
                                 "when its stages' backward is done, joined before the optimizer step",

@@ -65,3 +65,32 @@ def test_flat_gradients_two_ranks_equal_mean_of_rank_gradients():
         assert rep["flat_err"] < 1e-6 and rep["flat_err_host"] < 1e-6, rep
         assert rep["differs_from_local"] > 1e-3, rep   # the two shards really have different gradients
         assert rep["grad_norm"] > 0
+
+
+def test_spawned_rank_runs_the_chunked_allreduce_on_rccl():
+    """The multi-GPU path as far as ONE GPU can prove it (the reference: models/build.py:39-43 DDP buckets,
+    utils/misc.py:275-303 launch_job): `bench.py` started without a launcher spawns its rank (pinned to the CPUs next
+    to its GPU before any GPU call), the rank joins a world-1 RCCL group, and with SF_FORCE_ALLREDUCE=1 the flat
+    gradient buffer really goes through ncclAllReduce — in 3 chunks issued at the backward's milestones on the comm
+    stream, or in one collective after the backward (--no-overlap-allreduce).  Both schedules must leave the SAME
+    gradient buffer, bit for bit."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SF_BENCH_FORCE_SPAWN="1", SF_FORCE_ALLREDUCE="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "SF_RANK_CPUS"):
+        env.pop(k, None)
+    lines = []
+    for extra in ([], ["--no-overlap-allreduce"]):
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "2",
+                            "--no-cpu-baseline", "--no-extras", "--batch", "2"] + extra, env=env, capture_output=True,
+                           text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        lines.append(json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]))
+    chunked, single = lines
+    assert chunked["n_ranks_seen"] == 1 and chunked["n_gpus"] == 1
+    assert chunked["allreduce"]["chunks_per_step"] == 3 and single["allreduce"]["chunks_per_step"] == 1
+    assert chunked["allreduce"]["grad_hash"] == single["allreduce"]["grad_hash"]
+    aff = chunked["rank0_cpu_affinity"]
+    assert aff["cpus"] >= 1 and aff["last_cpu"] >= aff["first_cpu"]
