@@ -40,16 +40,16 @@ def conv(x, wp, kernel, *a, **k):
     cin = k.get("cin") or x.C
     cout = wp.shape[0]
     if ("conv_small" in SKIP and small(cin, cout)) or ("conv_fwd_big" in SKIP and not small(cin, cout)):
-        saved = L.sf_conv_fwd, L.sf_conv_fwd_ws, L.sf_conv_fwd_stats
+        saved = L.sf_conv_fwd, L.sf_conv_fwd_ws, L.sf_conv_fwd_stats, L.sf_conv_fwd_bx, L.sf_bx_split
         try:
-            L.sf_conv_fwd = L.sf_conv_fwd_ws = lambda *aa: 0
+            L.sf_conv_fwd = L.sf_conv_fwd_ws = L.sf_conv_fwd_bx = L.sf_bx_split = lambda *aa: 0
             # statistics launches still need a parts count: fall back to "no statistics from the epilogue"
             k2 = dict(k)
             st = k2.pop("stats", False)
             y = orig["conv"](x, wp, kernel, *a, **k2)
             return (y, None) if st else y
         finally:
-            L.sf_conv_fwd, L.sf_conv_fwd_ws, L.sf_conv_fwd_stats = saved
+            L.sf_conv_fwd, L.sf_conv_fwd_ws, L.sf_conv_fwd_stats, L.sf_conv_fwd_bx, L.sf_bx_split = saved
     return orig["conv"](x, wp, kernel, *a, **k)
 
 
@@ -76,7 +76,14 @@ def bn_bwd(*a, **k):
     return orig["bn_bwd"](*a, **k)
 
 
+def attention_bwd(q, k, v, dz, o, lse, gamma, dq, dk, dv):
+    if "attn_bwd" in SKIP:
+        return torch.zeros((o.shape[0], o.shape[1]), device=o.device)
+    return orig["attention_bwd"](q, k, v, dz, o, lse, gamma, dq, dk, dv)
+
+
 sfhip.conv, sfhip.conv_dgrad, sfhip.conv_wgrad, sfhip.bn_bwd = conv, conv_dgrad, conv_wgrad, bn_bwd
+sfhip.attention_bwd = attention_bwd
 
 
 def step():
@@ -112,12 +119,24 @@ with torch.cuda.stream(side):
 torch.cuda.synchronize()
 gc.collect()
 gc.freeze()
-base = measure("full step", [])
-for tag, skip in (("without convs with Cin or Cout <= 32 (all 3 kinds)", ["conv_small"]),
-                  ("without the other forward convs", ["conv_fwd_big"]),
-                  ("without the other data gradients", ["conv_dgrad_big"]),
-                  ("without the other weight gradients", ["wgrad_big"]),
-                  ("without the BN backward kernels", ["bn_bwd"]),
-                  ("full step again", [])):
-    ms = measure(tag, skip)
-    print("    -> worth %.2f ms" % (base - ms), flush=True)
+# every configuration REPS times, interleaved (one after the other inside a repetition): a family's worth is the median
+# of its per-repetition drops against that repetition's full step; the spread says what the number can carry
+REPS = int(os.environ.get("WHATIF_REPS", "3"))
+CONFIGS = (("full step", []),
+           ("without convs with Cin or Cout <= 32 (all 3 kinds)", ["conv_small"]),
+           ("without the other forward convs", ["conv_fwd_big"]),
+           ("without the other data gradients", ["conv_dgrad_big"]),
+           ("without the other weight gradients", ["wgrad_big"]),
+           ("without the BN backward kernels", ["bn_bwd"]),
+           ("without the attention backward kernels", ["attn_bwd"]))
+results = {tag: [] for tag, _ in CONFIGS}
+for rep in range(REPS):
+    print("repetition %d" % rep, flush=True)
+    for tag, skip in CONFIGS:
+        results[tag].append(measure(tag, skip))
+full = results["full step"]
+print("\nfull step: median %.2f ms (min %.2f, max %.2f over %d repetitions)" % (
+    sorted(full)[len(full) // 2], min(full), max(full), REPS))
+for tag, _ in CONFIGS[1:]:
+    drops = sorted(f - v for f, v in zip(full, results[tag]))
+    print("%-52s worth %.2f ms of step (min %.2f, max %.2f)" % (tag, drops[len(drops) // 2], drops[0], drops[-1]))
