@@ -78,6 +78,8 @@ def test_spawned_rank_runs_the_chunked_allreduce_on_rccl():
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()  # the child is another process on the same GPU: hand it what this one's allocator caches
     env = dict(os.environ, SF_BENCH_FORCE_SPAWN="1", SF_FORCE_ALLREDUCE="1")
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "SF_RANK_CPUS"):
         env.pop(k, None)
@@ -86,7 +88,7 @@ def test_spawned_rank_runs_the_chunked_allreduce_on_rccl():
         r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "2",
                             "--no-cpu-baseline", "--no-extras", "--batch", "2"] + extra, env=env, capture_output=True,
                            text=True, timeout=600)
-        assert r.returncode == 0, r.stderr[-2000:]
+        assert r.returncode == 0, (r.stderr[:3000], r.stderr[-1500:])
         lines.append(json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]))
     chunked, single = lines
     assert chunked["n_ranks_seen"] == 1 and chunked["n_gpus"] == 1
