@@ -511,12 +511,14 @@ bool bx_plan(const sf_conv_desc* d, BxPlan* pl, bool gate = true) {
   pl->tiles = sf_cdiv(M, BXC_BM) * pl->nb_n;
   pl->nk = nk;
   pl->a_rows = a_rows;
-  // Time model in microseconds (fitted on MI355X, conv_bx_bench.py): a workgroup needs ~2.0 us per K step of a 256-wide
-  // tile (96 MFMAs per SIMD at ~70 % of the pipe), 1.1 for a 128-wide one; the launch ends with its busiest CU; S > 1
+  // Time model in microseconds, fitted on MI355X with COLD operands (conv_bx_bench.py flushes the Infinity Cache in
+  // front of every timed call, as inside a training step; back-to-back calls read 20-30 % faster): a workgroup needs
+  // ~2.4 us per K step of a 256-wide tile and ~1.85 of a 128-wide one — the loop is bound by the arrival of the
+  // operand pieces in LDS, so the narrow tile is not half the wide one; the launch ends with its busiest CU; S > 1
   // writes S partial tiles and the finish kernel reads them back (~4 TB/s each way) — one workgroup per tile stores the
   // finished outputs itself.
   const bool scatter = d->os_T > 1 || d->os_H > 1 || d->os_W > 1;
-  const double step_us = pl->bn == 256 ? 2.0 : 1.1;
+  const double step_us = pl->bn == 256 ? 2.4 : 1.85;
   const double out_mb = (double)M * d->Cout * 4e-6;
   int best = 1;
   double best_t = 1e30;
@@ -537,7 +539,7 @@ bool bx_plan(const sf_conv_desc* d, BxPlan* pl, bool gate = true) {
   if (gate && g_bx_enable < 2) {
     // against conv_wave.hip at ~100 TFLOP/s (x 0.9 for the short reductions) plus this path's activation split
     const double flop = 2.0 * M * (double)nk * BXC_BK * d->Cout;
-    const double wave_us = flop / (nk >= 64 ? 103e6 : 92e6);
+    const double wave_us = flop / (nk >= 64 ? 100e6 : 90e6);
     const double split_us = 4.0 + (double)a_rows * d->Cin * 10e-6 / 3.0;  // 10 B per element at ~3 TB/s
     if (best_t + split_us > 0.93 * wave_us) return false;
   }
