@@ -806,6 +806,48 @@ __global__ __launch_bounds__(256) void wgrad_finish_kernel(const float* __restri
   for (int e = threadIdx.x; e < ncols * ptaps; e += 256) out[e] = accumulate ? out[e] + tile[e] : tile[e];
 }
 
+// Small weights (the Fast pathway, the lateral / q|k|v projections: <= 64 K partial elements, up to ~1000 splits): the
+// kernel above would run Cout x 1 workgroups that walk taps x S/4 strided loads one barrier pair per tap (10-14 us for
+// a 2 KB result).  Here a workgroup owns EPW consecutive elements of the partial layout and 256 / EPW groups of splits
+// (EPW = 16 for long split lists): thread (e, q) adds splits q, q + SG, ... in order, eight loads in flight, the SG
+// sub-sums are combined in group order — a fixed summation order — and thread (e, 0) writes its element un-packed.
+template <int EPW>
+__global__ __launch_bounds__(256) void wgrad_finish_flat_kernel(const float* __restrict__ part, int S, int total,
+                                                                int ptaps, int cin_pad, int Cin,
+                                                                float* __restrict__ dst, int accumulate) {
+  constexpr int SG = 256 / EPW;
+  __shared__ float red[256];
+  const int e = threadIdx.x % EPW, q = threadIdx.x / EPW;
+  const int idx = blockIdx.x * EPW + e;
+  float v = 0.f;
+  if (idx < total) {
+    const float* src = part + idx;
+    int s = q;
+    for (; s + 7 * SG < S; s += 8 * SG) {
+      float t[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) t[u] = src[(long)(s + u * SG) * total];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v += t[u];
+    }
+    for (; s < S; s += SG) v += src[(long)s * total];
+  }
+  red[threadIdx.x] = v;
+  __syncthreads();
+  if (q == 0 && idx < total) {
+    float t = red[e];
+#pragma unroll
+    for (int k = 1; k < SG; ++k) t += red[k * EPW + e];
+    const int c = idx % cin_pad;
+    const int r = idx / cin_pad;
+    const int tap = r % ptaps, co = r / ptaps;
+    if (c < Cin) {
+      float* o = dst + ((long)co * Cin + c) * ptaps + tap;
+      *o = accumulate ? *o + t : t;
+    }
+  }
+}
+
 // stem layout: a packed "channel" c' is (kw, ci) = (c' / 4, c' % 4) and a packed tap is (kt, kh); tiny tensors.
 __global__ void wgrad_finish_stem_kernel(const float* __restrict__ part, int S, int Cout, int ptaps, int cin_pad,
                                          int Cin, int fold_kw, float* __restrict__ dst, int accumulate, long total) {
@@ -835,6 +877,14 @@ extern "C" int sf_conv_wgrad_finish(const float* partial, int S, int Cout, int p
     const long total = (long)Cout * packed_taps * cin_pad;
     hipLaunchKernelGGL(wgrad_finish_stem_kernel, dim3(sf_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, partial,
                        S, Cout, packed_taps, cin_pad, Cin, fold_kw, dst, accumulate, total);
+  } else if ((long)Cout * packed_taps * cin_pad <= 65536L) {
+    const int total = Cout * packed_taps * cin_pad;
+    if (S > 32)
+      hipLaunchKernelGGL(wgrad_finish_flat_kernel<16>, dim3(sf_cdiv(total, 16)), dim3(256), 0, (hipStream_t)stream,
+                         partial, S, total, packed_taps, cin_pad, Cin, dst, accumulate);
+    else
+      hipLaunchKernelGGL(wgrad_finish_flat_kernel<64>, dim3(sf_cdiv(total, 64)), dim3(256), 0, (hipStream_t)stream,
+                         partial, S, total, packed_taps, cin_pad, Cin, dst, accumulate);
   } else {
     hipLaunchKernelGGL(wgrad_finish_kernel, dim3(Cout, sf_cdiv(cin_pad, FIN_C)), dim3(256),
                        (size_t)FIN_C * (packed_taps + 4) * sizeof(float), (hipStream_t)stream, partial, S, Cout, packed_taps,
@@ -844,6 +894,9 @@ extern "C" int sf_conv_wgrad_finish(const float* partial, int S, int Cout, int p
   return SF_OK;
 }
 
+int sf_wgrad_rows_splits(const sf_conv_desc* d);  // conv_wgrad_rows.hip
+int sf_wgrad_rows_try(const sf_conv_desc* d, const float* x, const float* dz, int dz_cs, int dz_coff, float* partial,
+                      hipStream_t stream);
 int sf_wgrad_wave_splits(const sf_conv_desc* d);  // conv_wgrad_wave.hip
 int sf_wgrad_wave_try(const sf_conv_desc* d, const float* x, const float* dz, int dz_cs, int dz_coff, float* partial,
                       hipStream_t stream);
@@ -853,6 +906,10 @@ extern "C" int sf_conv_wgrad_splits(const sf_conv_desc* d) {
   if (!d) return 0;
   StemArgs sq;
   if (stem_plan(d, 0, &sq)) return stem_workgroups(sq);
+  {
+    const int s = sf_wgrad_rows_splits(d);  // small-channel stride-1 "same" layers: the rows kernel's plan
+    if (s > 0) return s;
+  }
   {
     const int s = sf_wgrad_wave_splits(d);  // >= 64 channels on both sides: the per-wavefront kernel's own plan
     if (s > 0) return s;
@@ -917,6 +974,10 @@ extern "C" int sf_conv_wgrad(const sf_conv_desc* d, const float* x, const float*
       hipLaunchKernelGGL(conv_wgrad_stem_kernel, dim3(stem_workgroups(sq)), dim3(256), lds, (hipStream_t)stream, sq);
     SF_CHECK_LAUNCH();
     return SF_OK;
+  }
+  {
+    const int rc = sf_wgrad_rows_try(d, x, dz, dz_cs, dz_coff, partial, (hipStream_t)stream);
+    if (rc != 1) return rc;
   }
   {
     const int rc = sf_wgrad_wave_try(d, x, dz, dz_cs, dz_coff, partial, (hipStream_t)stream);

@@ -1,0 +1,353 @@
+// conv_wgrad_rows.hip — weight gradient of the small-channel stride-1 "same" convolutions (Cin <= 32 or Cout <= 32:
+// the Fast pathway's 1x3x3 / 3x1x1 / 1x1x1 layers, the q|k|v and lateral projections) — gfx950.
+//
+//   dW[co, tap, ci] = sum_m dz[m, co] * x[m + off(tap), ci]       (m over the N*T*H*W positions)
+//
+// conv_wgrad_small_kernel (conv_wgrad.hip) gives every TAP its own workgroups and stages 64 positions per barrier
+// through registers: x and dz are re-read once per tap, a stage is 4 MFMAs per wavefront, and the launch runs at a
+// sixth of what its operands cost at HBM speed whatever the split count.  For a stride-1 conv with "same" padding the
+// input row of (position m, tap) is the FLAT row m + (kt - pT) H W + (kh - pH) W + (kw - pW) wherever the tap is inside
+// the clip, so here a workgroup owns a run of positions and walks it in stages of L (128 / 64):
+//   * one stage = L rows of dz + per kt ONE window of L + 2 halo rows of x (halo = pH W + pW), copied HBM -> LDS by
+//     direct-to-LDS buffer loads (16 bytes per lane, no registers; rows outside the tensor come back as zeros from the
+//     buffer bounds check), double buffered: stage s + 1 is in flight while stage s is multiplied;
+//   * ALL taps are accumulated from that image: lane (c, k) of a v_mfma_f32_16x16x4_f32 reads dz[4g + k][co tile + c]
+//     once per group of 4 positions and x[4g + k + kh W + kw][ci tile + c] per tap (ds_read_b32, conflict free for
+//     rows of 8 / 16 / 32 floats); taps that fall outside the clip for a position (other row / frame / clip in flat
+//     order) are masked on the dz operand with a per-position validity word the staging threads leave in LDS;
+//   * the four wavefronts split the position groups; their accumulators are summed through LDS tap by tap and the
+//     workgroup writes ONE partial [Cout block][taps][Cin block] (the usual [S][Cout][taps][cin_pad] workspace, summed
+//     in split order by sf_conv_wgrad_finish: bit-reproducible, no float atomics).
+// Channel blocks are 16 or 32 wide on both sides (wider layers — 32 -> 128, 128 -> 32 — take blockIdx.y blocks).
+#include "common.h"
+#include <stdlib.h>
+
+namespace {
+
+typedef __attribute__((address_space(3))) void lds_void;
+
+struct RowsArgs {
+  sf_conv_desc d;
+  const float* x;
+  const float* dz;
+  float* part;           // [S][Cout][ntaps][cin_pad]
+  int dz_cs, dz_coff;
+  int M, S, chunk, L;    // positions, splits, positions per split (multiple of L), positions per stage
+  int nb_ci;             // blockIdx.y = co block * nb_ci + ci block
+  int zw, xw;            // floats per dz / x row in LDS: 8, 16 or 32
+  int wrp;               // rows of one x window in LDS (L + 2 halo, padded to whole 1 KiB pieces)
+  int halo, HW;
+  unsigned x_bytes, z_bytes;
+  unsigned w_mul, w_sh, h_mul, h_sh, t_mul, t_sh;
+  int stage_floats;      // one stage buffer: dz rows, x windows, validity words
+};
+
+__device__ __forceinline__ unsigned mdiv(unsigned n, unsigned mul, unsigned sh) {
+  return mul ? (__umulhi(n, mul) >> sh) : n;
+}
+
+constexpr unsigned ROWS_OOB = 0x80000000u;  // >= every buffer's size (checked by the launcher): reads as zeros
+
+// ZW / XW: floats per dz / x row in LDS (8, 16, 32; compile-time so that the kw offsets are immediates).  PACK
+// (8 -> 8 channels): an MFMA's rows 8..15 and columns 8..15 take a SECOND position set (the stage's upper half), so the
+// two diagonal 8 x 8 blocks of the accumulator both hold wanted sums — half the MFMAs; the blocks are added at the end.
+template <int NTAP, int NCO, int ZW, int NCI, int XW>
+__global__ __launch_bounds__(256) void conv_wgrad_rows_kernel(const RowsArgs p) {
+  constexpr int BCO = 16 * NCO, BCI = 16 * NCI;
+  constexpr int KT = (NTAP == 3) ? 3 : 1;
+  constexpr bool PACK = (ZW == 8 && XW == 8);
+  extern __shared__ __attribute__((aligned(16))) float rows_smem[];
+  const sf_conv_desc& d = p.d;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int split = blockIdx.x;
+  const int bco = blockIdx.y / p.nb_ci, bci = blockIdx.y - bco * p.nb_ci;
+  const int co0 = bco * BCO, ci0 = bci * BCI;
+  const int L = p.L;
+  constexpr int zw = ZW, xw = XW;
+  const int mb = split * p.chunk;
+  const int me = (mb + p.chunk < p.M) ? mb + p.chunk : p.M;
+  const int nst = (me > mb) ? (me - mb + L - 1) / L : 0;
+  const int nzb = (L * zw) >> 8;          // 1 KiB pieces of the dz rows
+  const int nxb = (p.wrp * xw) >> 8;      // ... of one x window
+  const int nblk = nzb + KT * nxb;
+  constexpr int zq_sh = (ZW == 8) ? 1 : (ZW == 16 ? 2 : 3);  // log2(chunks per row)
+  constexpr int xq_sh = (XW == 8) ? 1 : (XW == 16 ? 2 : 3);
+  const __amdgpu_buffer_rsrc_t x_rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t z_rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.dz, 0, p.z_bytes, 0x00020000);
+  const int rows_total = p.M;  // "same" geometry: input positions = output positions
+
+  auto issue = [&](int st, int buf) {
+    const int m0 = mb + st * L;
+    float* const sb = rows_smem + buf * p.stage_floats;
+    for (int b = wave; b < nblk; b += 4) {
+      unsigned vo = ROWS_OOB;
+      if (b < nzb) {
+        const int c = (b << 6) + lane;
+        const int row = c >> zq_sh, col = (c - (row << zq_sh)) << 2;
+        const int m = m0 + row;
+        if (m < me && co0 + col < d.Cout) vo = ((unsigned)m * (unsigned)p.dz_cs + (unsigned)(p.dz_coff + co0 + col)) << 2;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(z_rs, (lds_void*)(sb + (b << 8)), 16, vo, 0, 0, 0);
+      } else {
+        const int bb = b - nzb;
+        const int kt = (KT == 1) ? 0 : bb / nxb;
+        const int c = ((bb - kt * nxb) << 6) + lane;
+        const int row = c >> xq_sh, col = (c - (row << xq_sh)) << 2;
+        const int q = m0 + (kt - d.pT) * p.HW - p.halo + row;
+        if (q >= 0 && q < rows_total && ci0 + col < d.Cin)
+          vo = ((unsigned)q * (unsigned)d.in_cs + (unsigned)(d.in_coff + ci0 + col)) << 2;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rs, (lds_void*)(sb + (b << 8)), 16, vo, 0, 0, 0);
+      }
+    }
+    if (NTAP > 1 && tid < L) {  // which taps of position m0 + tid lie inside its clip
+      const unsigned m = (unsigned)(m0 + tid);
+      const unsigned q1 = mdiv(m, p.w_mul, p.w_sh);
+      const int w = (int)(m - q1 * (unsigned)d.Wo);
+      const unsigned q2 = mdiv(q1, p.h_mul, p.h_sh);
+      const int h = (int)(q1 - q2 * (unsigned)d.Ho);
+      const unsigned q3 = mdiv(q2, p.t_mul, p.t_sh);
+      const int t = (int)(q2 - q3 * (unsigned)d.To);
+      unsigned bits = 0;
+      if (NTAP == 3) {
+#pragma unroll
+        for (int kt = 0; kt < 3; ++kt)
+          if ((unsigned)(t + kt - 1) < (unsigned)d.To) bits |= 1u << kt;
+      } else {  // separable: bits 0..2 = row h + kh - 1 inside, bits 4..6 = column w + kw - 1 inside
+#pragma unroll
+        for (int kk = 0; kk < 3; ++kk) {
+          if ((unsigned)(h + kk - 1) < (unsigned)d.Ho) bits |= 1u << kk;
+          if ((unsigned)(w + kk - 1) < (unsigned)d.Wo) bits |= 16u << kk;
+        }
+      }
+      reinterpret_cast<unsigned*>(sb + L * zw + KT * p.wrp * xw)[tid] = bits;
+    }
+  };
+
+  f32x4 acc[NTAP][NCO][NCI];
+#pragma unroll
+  for (int t = 0; t < NTAP; ++t)
+#pragma unroll
+    for (int i = 0; i < NCO; ++i)
+#pragma unroll
+      for (int j = 0; j < NCI; ++j) acc[t][i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int m16 = lane & 15, k4 = lane >> 4;
+  const int win = p.wrp * xw;  // floats of one x window
+  if (nst > 0) issue(0, 0);
+  for (int st = 0; st < nst; ++st) {
+    const int buf = st & 1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this thread's pieces of stage st have landed ...
+    __syncthreads();                                   // ... and everybody's; buffer buf ^ 1 is free again
+    if (st + 1 < nst) issue(st + 1, buf ^ 1);
+    const float* const zs = rows_smem + buf * p.stage_floats;
+    const float* const xs = zs + L * zw;
+    const unsigned* const vm = reinterpret_cast<const unsigned*>(xs + KT * win);
+    const int ngroups = PACK ? (L >> 3) : (L >> 2);
+    const int half = (PACK && m16 >= 8) ? (L >> 1) : 0;  // PACK: rows / columns 8..15 work on the stage's upper half
+    const int mc = PACK ? (m16 & 7) : m16;
+    for (int g = wave; g < ngroups; g += 4) {
+      const int pp = 4 * g + k4 + half;
+      // every operand of the group first (one wait), then the MFMAs
+      float a[NCO];
+#pragma unroll
+      for (int i = 0; i < NCO; ++i) a[i] = zs[pp * ZW + 16 * i + mc];
+      const unsigned vb = (NTAP > 1) ? vm[pp] : 1u;
+      const float* const xr = xs + pp * XW + mc;
+      float bv[NTAP][NCI];
+#pragma unroll
+      for (int t = 0; t < NTAP; ++t) {
+        const int off = (NTAP == 3) ? t * win : ((NTAP == 9) ? (t / 3) * d.Wi * XW + (t % 3) * XW : 0);
+#pragma unroll
+        for (int j = 0; j < NCI; ++j) bv[t][j] = xr[off + 16 * j];
+      }
+      // validity: 3x1x1 one bit per kt; 1x3x3 separable — bits 0..2 = kh inside, bits 4..6 = kw inside
+      float am[NTAP][NCO];
+      if constexpr (NTAP == 1) {
+#pragma unroll
+        for (int i = 0; i < NCO; ++i) am[0][i] = a[i];
+      } else if constexpr (NTAP == 3) {
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+          for (int i = 0; i < NCO; ++i) am[t][i] = ((vb >> t) & 1u) ? a[i] : 0.f;
+      } else {
+#pragma unroll
+        for (int i = 0; i < NCO; ++i) {
+          const float w0 = (vb & 16u) ? a[i] : 0.f, w2 = (vb & 64u) ? a[i] : 0.f;  // kw = 1 is always inside
+          const bool h0 = (vb & 1u) != 0, h2 = (vb & 4u) != 0;
+          am[0][i] = h0 ? w0 : 0.f; am[1][i] = h0 ? a[i] : 0.f; am[2][i] = h0 ? w2 : 0.f;
+          am[3][i] = w0;            am[4][i] = a[i];            am[5][i] = w2;
+          am[6][i] = h2 ? w0 : 0.f; am[7][i] = h2 ? a[i] : 0.f; am[8][i] = h2 ? w2 : 0.f;
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < NTAP; ++t)
+#pragma unroll
+        for (int i = 0; i < NCO; ++i)
+#pragma unroll
+          for (int j = 0; j < NCI; ++j)
+            acc[t][i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(am[t][i], bv[t][j], acc[t][i][j], 0, 0, 0);
+    }
+  }
+
+  // cross-wavefront sum, tap by tap (the stage buffers are free: nothing is in flight after the last stage)
+  float* const red = rows_smem;  // [4][BCO][BCI]
+  float* const base = p.part + (long)split * d.Cout * NTAP * d.cin_pad;
+#pragma unroll
+  for (int t = 0; t < NTAP; ++t) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NCO; ++i)
+#pragma unroll
+      for (int j = 0; j < NCI; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[(wave * BCO + 16 * i + 4 * k4 + r) * BCI + 16 * j + m16] = acc[t][i][j][r];
+    __syncthreads();
+    for (int e = tid; e < BCO * BCI; e += 256) {
+      const int co = co0 + e / BCI, ci = ci0 + e % BCI;
+      if (co < d.Cout && ci < d.cin_pad) {
+        float v = (red[e] + red[BCO * BCI + e]) + (red[2 * BCO * BCI + e] + red[3 * BCO * BCI + e]);
+        if constexpr (PACK) {
+          if (e / BCI < 8 && e % BCI < 8) {
+            const int e2 = e + 8 * BCI + 8;
+            v += (red[e2] + red[BCO * BCI + e2]) + (red[2 * BCO * BCI + e2] + red[3 * BCO * BCI + e2]);
+          }
+        }
+        base[((long)co * NTAP + t) * d.cin_pad + ci] = (ci < d.Cin) ? v : 0.f;
+      }
+    }
+  }
+}
+
+void magic(unsigned dv, unsigned* mul, unsigned* sh) {
+  if (dv <= 1) { *mul = 0; *sh = 0; return; }
+  unsigned l = 0;
+  while ((1u << l) < dv) ++l;
+  const unsigned long long num = 1ull << (31 + l);
+  *mul = (unsigned)((num + dv - 1) / dv);
+  *sh = l - 1;
+}
+
+int g_rows_enable = 1;  // sf_conv_tune(10, e)
+
+bool rows_enabled() {
+  static const int env_on = [] {
+    const char* e = getenv("SF_WGRAD_ROWS");
+    return e ? atoi(e) : 1;
+  }();
+  return env_on && g_rows_enable;
+}
+
+int pow2_width(int c) { return c <= 8 ? 8 : (c <= 16 ? 16 : 32); }
+
+// Geometry + schedule for a problem this kernel covers; false = leave it to the other weight-gradient kernels.
+bool rows_plan(const sf_conv_desc* d, RowsArgs* a) {
+  if (!rows_enabled() || d->transposed) return false;
+  if (d->sT != 1 || d->sH != 1 || d->sW != 1 || d->dT != 1 || d->dH != 1 || d->dW != 1) return false;
+  if (d->To != d->Ti || d->Ho != d->Hi || d->Wo != d->Wi) return false;
+  int ntap;
+  if (d->kT == 1 && d->kH == 1 && d->kW == 1 && d->pT == 0 && d->pH == 0 && d->pW == 0) ntap = 1;
+  else if (d->kT == 3 && d->kH == 1 && d->kW == 1 && d->pT == 1 && d->pH == 0 && d->pW == 0) ntap = 3;
+  else if (d->kT == 1 && d->kH == 3 && d->kW == 3 && d->pT == 0 && d->pH == 1 && d->pW == 1) ntap = 9;
+  else return false;
+  if (d->Cin > 32 && d->Cout > 32) return false;  // both wide: conv_wgrad_wave / conv_bx
+  if (d->Cin < 8 || d->Cout < 8) return false;
+  if (d->Cin % 4 || d->in_cs % 4 || d->in_coff % 4 || d->Cout % 4) return false;
+  const long M = (long)d->N * d->To * d->Ho * d->Wo;
+  if (M <= 0 || M > 0x3fffffffL) return false;
+  const long xb = ((M - 1) * d->in_cs + d->in_coff + d->Cin) * 4L;
+  if (xb >= 0x7fffffffL) return false;
+  a->d = *d;
+  a->M = (int)M;
+  a->x_bytes = (unsigned)xb;
+  const int bco = d->Cout <= 16 ? 16 : 32, bci = d->cin_pad <= 16 ? 16 : 32;
+  a->zw = pow2_width(d->Cout < bco ? d->Cout : bco);
+  a->xw = pow2_width(d->Cin < bci ? d->Cin : bci);
+  a->nb_ci = sf_cdiv(d->cin_pad, bci);
+  a->HW = d->Hi * d->Wi;
+  a->halo = d->pH * d->Wi + d->pW;
+  const int KT = ntap == 3 ? 3 : 1;
+  int L = 128;
+  for (;; L = 64) {
+    const int gran = 256 / a->xw;  // window rows per 1 KiB piece
+    a->wrp = (L + 2 * a->halo + gran - 1) / gran * gran;
+    a->stage_floats = L * a->zw + KT * a->wrp * a->xw + L;
+    if (a->stage_floats * 8 <= 72 * 1024 || L == 64) break;
+  }
+  if (a->stage_floats * 8 > 150 * 1024) return false;
+  if (a->stage_floats * 2 < 4 * bco * bci) return false;  // the reduction image lives in the stage buffers
+  a->L = L;
+  magic((unsigned)d->Wo, &a->w_mul, &a->w_sh);
+  magic((unsigned)d->Ho, &a->h_mul, &a->h_sh);
+  magic((unsigned)d->To, &a->t_mul, &a->t_sh);
+  // splits: ~640 workgroups over the channel blocks, at least two stages each
+  const int blocks = sf_cdiv(d->Cout, bco) * a->nb_ci;
+  const long stages = (M + L - 1) / L;
+  long S = 640 / blocks;
+  if (S < 1) S = 1;
+  if (S > (stages + 1) / 2) S = (stages + 1) / 2;
+  if (S < 1) S = 1;
+  if (S > 1024) S = 1024;
+  long chunk = ((M + S - 1) / S + L - 1) / L * L;
+  S = (M + chunk - 1) / chunk;
+  a->S = (int)S;
+  a->chunk = (int)chunk;
+  return true;
+}
+
+template <int NTAP, int NCO, int ZW, int NCI, int XW>
+int launch_rows(const RowsArgs& a, hipStream_t s) {
+  const size_t lds = (size_t)a.stage_floats * 8;
+  static SfLdsAttr attr;
+  if (!sf_ensure_dyn_lds(attr, reinterpret_cast<const void*>(conv_wgrad_rows_kernel<NTAP, NCO, ZW, NCI, XW>),
+                         152 * 1024))
+    return SF_ELAUNCH;
+  const int nb_co = sf_cdiv(a.d.Cout, 16 * NCO);
+  hipLaunchKernelGGL((conv_wgrad_rows_kernel<NTAP, NCO, ZW, NCI, XW>), dim3(a.S, nb_co * a.nb_ci), dim3(256), lds, s,
+                     a);
+  SF_CHECK_LAUNCH();
+  return SF_OK;
+}
+
+template <int NTAP, int NCO, int ZW>
+int launch_rows_x(const RowsArgs& a, hipStream_t s) {
+  if (a.xw == 8) return launch_rows<NTAP, NCO, ZW, 1, 8>(a, s);
+  if (a.xw == 16) return launch_rows<NTAP, NCO, ZW, 1, 16>(a, s);
+  return launch_rows<NTAP, NCO, ZW, 2, 32>(a, s);
+}
+
+template <int NTAP>
+int launch_rows_tiles(const RowsArgs& a, hipStream_t s) {
+  if (a.zw == 8) return launch_rows_x<NTAP, 1, 8>(a, s);
+  if (a.zw == 16) return launch_rows_x<NTAP, 1, 16>(a, s);
+  return launch_rows_x<NTAP, 2, 32>(a, s);
+}
+
+}  // namespace
+
+int sf_wgrad_rows_tune(int value) {
+  g_rows_enable = value ? 1 : 0;
+  return SF_OK;
+}
+
+// Split count of the rows kernel for this problem, 0 = not covered.
+int sf_wgrad_rows_splits(const sf_conv_desc* d) {
+  RowsArgs a;
+  return rows_plan(d, &a) ? a.S : 0;
+}
+
+// 1 = not covered (the caller goes on to its other kernels), else SF_OK / an error.
+int sf_wgrad_rows_try(const sf_conv_desc* d, const float* x, const float* dz, int dz_cs, int dz_coff, float* partial,
+                      hipStream_t stream) {
+  RowsArgs a;
+  if (dz_cs % 4 || dz_coff % 4 || !sf_aligned16(x) || !sf_aligned16(dz)) return 1;
+  if (!rows_plan(d, &a)) return 1;
+  const long zb = ((long)(a.M - 1) * dz_cs + dz_coff + d->Cout) * 4L;
+  if (zb >= 0x7fffffffL) return 1;
+  a.z_bytes = (unsigned)zb;
+  a.x = x; a.dz = dz; a.part = partial; a.dz_cs = dz_cs; a.dz_coff = dz_coff;
+  const int ntap = d->kT * d->kH * d->kW;
+  if (ntap == 1) return launch_rows_tiles<1>(a, stream);
+  if (ntap == 3) return launch_rows_tiles<3>(a, stream);
+  return launch_rows_tiles<9>(a, stream);
+}

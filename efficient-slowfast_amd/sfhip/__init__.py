@@ -785,8 +785,8 @@ def conv_wgrad(x, dz, cout, kernel, stride=(1, 1, 1), padding=(0, 0, 0), dilatio
     if finish_into is not None:
         dst, real_cin, fold_kw = finish_into
         assert dst.is_contiguous() and dst.dtype == torch.float32
-        if S > 128:  # tiny weights over millions of positions (Fast pathway): few finish workgroups, each would walk
-            part, S = part.sum(0, keepdim=True), 1  # S / 4 partials per thread — a parallel tree sum first
+        if S > 128 and cout * kT * kH * kW * cin_pad > 65536:  # long split lists of large weights (does not occur
+            part, S = part.sum(0, keepdim=True), 1  # in the shipped models): a parallel tree sum first
         assert dst.numel() == cout * real_cin * kT * kH * kW * max(fold_kw, 1), (dst.shape, cout, real_cin, kernel)
         _check(lib().sf_conv_wgrad_finish(_ptr(part), S, cout, kT * kH * kW, cin_pad, real_cin, fold_kw, _ptr(dst), 1,
                                           _stream()), "sf_conv_wgrad_finish")

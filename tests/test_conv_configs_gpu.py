@@ -35,7 +35,7 @@ def tune():
     L = sfhip.lib()
     yield L
     for knob, v in ((0, 1), (1, -1), (2, 0), (3, 0), (4, 1), (5, 0), (6, 1), (7, 1), (8, 0), (9, 1), (10, 1), (11, -1),
-                    (12, 0)):
+                    (12, 0), (20, 1)):
         L.sf_conv_tune(knob, v)
 
 
@@ -257,3 +257,60 @@ def test_bf16_piece_conv_forward_dgrad_wgrad(shape, tune):
     finally:
         tune.sf_conv_tune(7, 1)
         tune.sf_conv_tune(9, 1)
+
+
+# ---- conv_wgrad_rows.hip: the small-channel stride-1 "same" layers (all taps of a run of positions from one LDS image,
+# direct-to-LDS loads, tap validity masks).  Ragged position counts (tails of the last stage and of the last split),
+# clips whose borders fall inside a stage, channel counts that fill a 16- / 32-wide block partly, wide other sides.
+ROWS_SHAPES = [
+    ("s3_8_8", 8, 8, (1, 3, 3), (0, 1, 1), (2, 3, 19, 17)),
+    ("s3_16_16", 16, 16, (1, 3, 3), (0, 1, 1), (3, 2, 13, 29)),
+    ("s3_32_32", 32, 32, (1, 3, 3), (0, 1, 1), (2, 5, 14, 14)),
+    ("s3_24_8", 24, 8, (1, 3, 3), (0, 1, 1), (1, 2, 56, 56)),
+    ("t3_32_8", 32, 8, (3, 1, 1), (1, 0, 0), (2, 5, 13, 11)),
+    ("t3_16_8", 16, 8, (3, 1, 1), (1, 0, 0), (3, 1, 9, 10)),      # T = 1: only the centre tap is ever inside
+    ("t3_128_32", 128, 32, (3, 1, 1), (1, 0, 0), (2, 4, 7, 9)),
+    ("t3_8_32", 8, 32, (3, 1, 1), (1, 0, 0), (2, 6, 11, 10)),
+    ("plain_8_32", 8, 32, (1, 1, 1), (0, 0, 0), (2, 3, 23, 21)),
+    ("plain_16_64", 16, 64, (1, 1, 1), (0, 0, 0), (3, 2, 17, 19)),
+    ("plain_32_128", 32, 128, (1, 1, 1), (0, 0, 0), (2, 7, 14, 14)),
+    ("plain_32_96", 32, 96, (1, 1, 1), (0, 0, 0), (1, 2, 9, 33)),
+    ("plain_8_24", 8, 24, (1, 1, 1), (0, 0, 0), (2, 2, 15, 15)),
+    ("plain_256_32", 256, 32, (1, 1, 1), (0, 0, 0), (1, 3, 11, 13)),
+]
+
+
+@pytest.mark.parametrize("sliced", [False, True])
+@pytest.mark.parametrize("shape", ROWS_SHAPES, ids=[s[0] for s in ROWS_SHAPES])
+def test_small_channel_wgrad_rows_kernel(shape, sliced, tune):
+    """sf_conv_wgrad on the shapes conv_wgrad_rows.hip takes, against the fp64 weight gradient — through the packed
+    gradient and through the finish kernel — and against the kernel it replaces (sf_conv_tune(20, 0)) as a cross-check
+    that the launcher really switched paths (the split counts differ).  `sliced`: both operands are channel slices of
+    wider buffers (pitch > channels, offset > 0), as the concatenating layers hand them over."""
+    import ctypes
+    import sfhip
+    name, cin, cout, k, p, dims = shape
+    x, wt, bias, dy = _case(shape)
+    xa, dya = _act(x), _act(dy)
+    if sliced:
+        def widen(a, before, after):
+            buf = torch.randn(a.buf.shape[:-1] + (before + a.C + after,), device=a.buf.device)
+            buf[..., before:before + a.C] = a.buf
+            return sfhip.Act(buf, before, a.C)
+        xa, dya = widen(xa, 8, 4), widen(dya, 4, 12)
+    wd = wt.double().requires_grad_(True)
+    F.conv3d(x.double(), wd, None, 1, p).backward(dy.double())
+    d = sfhip.ConvDesc(xa.N, xa.T, xa.H, xa.W, cin, xa.cs, xa.coff, dya.T, dya.H, dya.W, cout, 0, 0, 1, k[0], k[1], k[2],
+                       1, 1, 1, p[0], p[1], p[2], 1, 1, 1, (cin + 15) // 16 * 16, 0, 0, 0, 0)
+    assert tune.sf_conv_tune(20, 1) == 0
+    s_on = tune.sf_conv_wgrad_splits(ctypes.byref(d))
+    dwp = sfhip.conv_wgrad(xa, dya, cout, k, (1, 1, 1), p)
+    assert _rel(sfhip.unpack_conv_weight_grad(dwp, wt.shape), wd.grad) < 2e-6, name
+    acc = torch.ones_like(wt)
+    sfhip.conv_wgrad(xa, dya, cout, k, (1, 1, 1), p, finish_into=(acc, cin, 0))
+    assert _rel(acc - 1.0, wd.grad) < 2e-6, name
+    assert tune.sf_conv_tune(20, 0) == 0
+    s_off = tune.sf_conv_wgrad_splits(ctypes.byref(d))
+    dwp0 = sfhip.conv_wgrad(xa, dya, cout, k, (1, 1, 1), p)
+    assert _rel(sfhip.unpack_conv_weight_grad(dwp0, wt.shape), wd.grad) < 2e-6, name
+    assert (s_on, s_off) != (0, 0)

@@ -8,6 +8,7 @@
 #include <cstdlib>
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 template <int FILL, int KIND, int SHAPE>
 __global__ __launch_bounds__(256) void probe(float* out, int iters) {
@@ -23,11 +24,16 @@ __global__ __launch_bounds__(256) void probe(float* out, int iters) {
   for (int it = 0; it < iters; ++it) {
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
-      if (SHAPE == 32) acc32[u & 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc32[u & 1], 0, 0, 0);
+      if (SHAPE == 3216) {  // the bf16 matrix pipe (round 4: do ITS MFMAs hide vector work?)
+        bf16x8 av, bv;
+        for (int e = 0; e < 8; ++e) { av[e] = (__bf16)a; bv[e] = (__bf16)b; }
+        acc32[u & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc32[u & 1], 0, 0, 0);
+      } else if (SHAPE == 32) acc32[u & 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc32[u & 1], 0, 0, 0);
       else acc16[u & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc16[u & 1], 0, 0, 0);
 #pragma unroll
       for (int q = 0; q < FILL; ++q) {
         if (KIND == 0) asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(f[q & 7]) : "v"(b));
+        else if (KIND == 2) asm volatile("v_cvt_pk_bf16_f32 %0, %0, %1" : "+v"(f[q & 7]) : "v"(b));
         else asm volatile("v_exp_f32 %0, %0" : "+v"(f[q & 7]));
       }
     }
@@ -59,7 +65,7 @@ void run(float* out, int blocks, int iters, const char* tag) {
   // ns per MFMA per wavefront slot: waves per SIMD = blocks / 256 (one wave of a block per SIMD)
   const double per_simd = 8.0 * iters * (blocks / 256.0);
   printf("%-10s shape=%dx fill=%d %s blocks=%d: %.3f ms, %.2f ns per MFMA on a SIMD\n", tag, SHAPE, FILL,
-         KIND ? "v_exp" : "v_fma", blocks, best, best * 1e6 / per_simd);
+         KIND == 2 ? "v_cvt_pk" : KIND ? "v_exp" : "v_fma", blocks, best, best * 1e6 / per_simd);
 }
 
 int main(int argc, char** argv) {
@@ -75,6 +81,16 @@ int main(int argc, char** argv) {
     run<2, 1, 32>(out, blocks, iters, "fillers");
     run<4, 1, 32>(out, blocks, iters, "fillers");
     run<8, 1, 32>(out, blocks, iters, "fillers");
+    run<0, 0, 3216>(out, blocks, iters, "bare");
+    run<2, 0, 3216>(out, blocks, iters, "fillers");
+    run<4, 0, 3216>(out, blocks, iters, "fillers");
+    run<6, 0, 3216>(out, blocks, iters, "fillers");
+    run<8, 0, 3216>(out, blocks, iters, "fillers");
+    run<12, 0, 3216>(out, blocks, iters, "fillers");
+    run<2, 1, 3216>(out, blocks, iters, "fillers");
+    run<4, 1, 3216>(out, blocks, iters, "fillers");
+    run<4, 2, 3216>(out, blocks, iters, "fillers");
+    run<8, 2, 3216>(out, blocks, iters, "fillers");
     run<0, 0, 16>(out, blocks, iters, "bare");
     run<2, 0, 16>(out, blocks, iters, "fillers");
     run<4, 0, 16>(out, blocks, iters, "fillers");
