@@ -104,20 +104,29 @@ def test_launch_planning_queries_are_host_only_and_fill_the_chip():
     wg = 9 * S
     assert 512 <= wg <= 1024 and wg / (-(-wg // 256) * 256) >= 0.94, (S, wg)
     assert L.sf_conv_fwd_ws_floats(ctypes.byref(d)) == 0                       # 1568 tiles: no split-K
-    # res4 3x1x1 1024->256 at M = 12544 (K = 3072): the bf16-piece kernel (conv_bx.hip) takes it — 49 tiles of 256 x 256
-    # share their K steps between S workgroups that together fill the chip; workspace = the activation planes
-    # [3][rows + 1][1024] bf16 (+ the weight planes unless handed in) + S partial tiles.  Without it
-    # (sf_conv_tune(7, 0)) the per-wavefront kernel splits K inside the workgroup (no workspace), and the LDS-tiled
-    # fallback (sf_conv_tune(0, 0)): 196 tiles, 192 K steps -> split-K with a [S][M][Cout] workspace
+    # res4 3x1x1 1024->256 at M = 12544 (K = 3072) on the bf16-piece kernel (conv_bx.hip, forced: sf_conv_tune(7, 2)) —
+    # 49 tiles of 256 x 256 share their K steps between S workgroups that together fill the chip; workspace = the
+    # activation planes [3][rows + 1][1024] bf16 (+ the weight planes unless handed in) + S partial tiles.  The
+    # launcher's time model (cold-operand fit) leaves THIS layer to the per-wavefront kernel, which splits K inside the
+    # workgroup (no workspace), and takes res5a's 3x1x1 1152 -> 512 at the same M; the LDS-tiled fallback
+    # (sf_conv_tune(0, 0)): 196 tiles, 192 K steps -> split-K with a [S][M][Cout] workspace
     d4 = _conv_desc(8, 8, 14, 14, 1024, 256, (3, 1, 1))
+    d5a = _conv_desc(8, 8, 14, 14, 1152, 512, (3, 1, 1))
     a_planes = -(-(3 * (12544 + 1) * 1024 // 2) // 4) * 4
     w_planes = -(-(3 * (256 + 1) * 3072 // 2) // 4) * 4
-    n_bx = L.sf_conv_bx_ws_floats(ctypes.byref(d4), 0, 1)
-    S = (n_bx - 4 - a_planes) // (12544 * 256)
-    assert n_bx == 4 + a_planes + S * 12544 * 256 and 200 <= 49 * S <= 256, (n_bx, S)
-    assert L.sf_conv_bx_ws_floats(ctypes.byref(d4), 0, 0) == n_bx + w_planes
-    assert L.sf_conv_bx_ws_floats(ctypes.byref(d4), 1, 1) == n_bx - a_planes
-    assert L.sf_conv_fwd_ws_floats(ctypes.byref(d4)) == n_bx + w_planes
+    assert L.sf_conv_bx_ws_floats(ctypes.byref(d4), 0, 1) == 0 and L.sf_conv_fwd_ws_floats(ctypes.byref(d4)) == 0
+    assert L.sf_conv_bx_ws_floats(ctypes.byref(d5a), 0, 1) > 0
+    assert L.sf_conv_fwd_ws_floats(ctypes.byref(d5a)) > L.sf_conv_bx_ws_floats(ctypes.byref(d5a), 0, 1)
+    assert L.sf_conv_tune(7, 2) == 0
+    try:
+        n_bx = L.sf_conv_bx_ws_floats(ctypes.byref(d4), 0, 1)
+        S = (n_bx - 4 - a_planes) // (12544 * 256)
+        assert n_bx == 4 + a_planes + S * 12544 * 256 and 200 <= 49 * S <= 256, (n_bx, S)
+        assert L.sf_conv_bx_ws_floats(ctypes.byref(d4), 0, 0) == n_bx + w_planes
+        assert L.sf_conv_bx_ws_floats(ctypes.byref(d4), 1, 1) == n_bx - a_planes
+        assert L.sf_conv_fwd_ws_floats(ctypes.byref(d4)) == n_bx + w_planes
+    finally:
+        L.sf_conv_tune(7, 1)
     assert L.sf_bx_planes_elems(12544, 1024) == 3 * 12545 * 1024
     assert L.sf_conv_bx_ws_floats(ctypes.byref(d), 0, 0) == 0                  # res2 3x3 64 -> 64: not a bx shape
     assert L.sf_conv_tune(7, 0) == 0
@@ -132,6 +141,16 @@ def test_launch_planning_queries_are_host_only_and_fill_the_chip():
     finally:
         L.sf_conv_tune(7, 1)
     assert n > 0 and n % (12544 * 256) == 0 and 2 <= n // (12544 * 256) <= 12
+    # Fast pathway res2 1x3x3 8 -> 8 at 8x32x56x56 (M = 802 816): the rows kernel (conv_wgrad_rows.hip) — ONE channel block,
+    # ~640 workgroups of >= 2 stages of 128 positions; without it (sf_conv_tune(20, 0)) 9 per-tap tiles x 85 splits
+    df = _conv_desc(8, 32, 56, 56, 8, 8, (1, 3, 3))
+    S = L.sf_conv_wgrad_splits(ctypes.byref(df))
+    assert 512 <= S <= 640 and -(-802816 // S) >= 256, S
+    assert L.sf_conv_tune(20, 0) == 0
+    try:
+        assert L.sf_conv_wgrad_splits(ctypes.byref(df)) == 85
+    finally:
+        L.sf_conv_tune(20, 1)
     # Fast stem in the stem-trick layout (5x7x1 over pixels of 8 floats, 28 packed channels): persistent ring kernel
     ds = _conv_desc(8, 32, 230, 115, 28, 8, (5, 7, 1), stride=(1, 2, 1), cin_pad=32, in_cs=8, pad=(2, 0, 0))
     ds.Wo = 112
