@@ -1452,12 +1452,19 @@ __global__ void attn_dq_reduce_tiled_kernel(const float* __restrict__ ws, float*
   const float* src = ws + ((b * nq + it) * nkb) * ps + ir * CP + c;
   f32x4 v = {0.f, 0.f, 0.f, 0.f};
   int k = 0;
-  for (; k + 8 <= nkb; k += 8) {
-    f32x4 t[8];
+  for (; k + 14 <= nkb; k += 14) {  // 14 planes in flight per thread (N = 25 088 at 256 keys per plane: 98 = 7 x 14)
+    f32x4 t[14];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) t[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src + (k + u) * ps));
+    for (int u = 0; u < 14; ++u) t[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src + (k + u) * ps));
 #pragma unroll
-    for (int u = 0; u < 8; ++u) v += t[u];
+    for (int u = 0; u < 14; ++u) v += t[u];
+  }
+  for (; k + 4 <= nkb; k += 4) {
+    f32x4 t[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) t[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src + (k + u) * ps));
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v += t[u];
   }
   for (; k < nkb; ++k) v += *reinterpret_cast<const f32x4*>(src + k * ps);
   float* o = dq + row * dq_cs + c;

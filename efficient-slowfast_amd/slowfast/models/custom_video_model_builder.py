@@ -91,7 +91,7 @@ class FuseFastAndSlow(nn.Module):
         import torch.nn.modules.module as _tm
         hooked = bool(self._forward_hooks) or bool(_tm._global_forward_hooks)
         engine.run_paths([fast_to_slow, slow_to_fast], x_s.buf.device,
-                         defer_join=defer_join and engine.is_internal() and not hooked)
+                         defer_join=defer_join and engine.is_internal() and not hooked, fuse=True)
         return engine.leave([s_wide, f_wide])
 
 

@@ -62,6 +62,7 @@ class Tape(object):
         self.input_grads = {}  # input index -> dL/d(clip), NCTHW (written by the stems' backward)
         self.joins = set()  # companion streams with weight-gradient work in flight (joined at the end of backward)
         self.model = None   # the model whose forward this tape records (milestone hooks are bound to it)
+        self.early = None   # backward: event a fusion region left for the next region's side stream (run_paths)
 
     def pgrad_target(self, param):
         """The tensor kernels may accumulate this parameter's gradient into directly, or None."""
@@ -189,21 +190,62 @@ def _sync_streams(first, then):
     then.wait_event(ev)
 
 
-def run_paths(fns, device, defer_join=False):
+_FUSE = {}
+# SF_FUSE_STREAM=1 (default 0): the CMDA fusions' attention direction runs on a side stream of its own, so that in the
+# backward pass the Fast pathway's stage k (which does not depend on the attention's gradient) runs BESIDE the
+# attention backward of fusion k instead of queueing behind it on the shared side stream.  Measured (cfg #3, 8 clips,
+# one box, two alternations): 57.20 / 57.03 ms with it against 56.28 / 56.30 without — the attention sweeps hold 384 of
+# the 512 registers per lane, the Fast pathway's wavefronts that squeeze in beside them slow the sweep by more than
+# their own kernels were worth next to the Slow pathway's.  Kept as a switch (and in the stream-equivalence test).
+FUSE_STREAM = os.environ.get("SF_FUSE_STREAM", "0") == "1"
+
+
+def _fuse_stream(device):
+    s = _FUSE.get(device)
+    if s is None:
+        s = _FUSE[device] = torch.cuda.Stream(device=device, priority=int(os.environ.get("SF_PRIO_SIDE", "0")))
+    return s
+
+
+def run_paths(fns, device, defer_join=False, fuse=False):
     """[f() for f in fns] with fns[1] issued on the side stream (two callables on a CUDA device; otherwise serial).
     defer_join: do not make the caller's stream wait for the side stream at the end of the FORWARD region — only
     valid when the next work on the caller's stream does not read what fns[1] produced before the next region's
     join (a CMDA fusion followed by a stage: the attention keeps running beside the Slow pathway's next stage).
-    The backward pass is unaffected: its fork at this point is always recorded."""
+    fuse: a CMDA fusion's region — fns[1] (the attention direction) gets the fusion stream.  Forward: the next
+    region's side stream waits for it (the Fast pathway reads the attention's output).  Backward: the caller's stream
+    leaves an event behind fns[0]'s gradient ops BEFORE it waits for the attention's, and the next region's side stream
+    (the Fast pathway's previous stage, which needs only those) starts from that event."""
     if not OVERLAP_PATHS or getattr(_tls, "serial", False) or len(fns) != 2 or device.type != "cuda":
         return [f() for f in fns]
     t = tape()
     if t is not None and t.side is not None:
         return [f() for f in fns]  # already inside a region
-    main, side = torch.cuda.current_stream(device), _side_stream(device)
+    fuse = fuse and FUSE_STREAM
+    main, side = torch.cuda.current_stream(device), (_fuse_stream(device) if fuse else _side_stream(device))
+
+    def bwd_join():  # last op of the region's backward
+        cur = torch.cuda.current_stream(device)
+        if fuse:
+            ev = torch.cuda.Event()
+            ev.record(cur)
+            t.early = ev
+        _sync_streams(side, cur)
+
+    def bwd_fork():  # first op of the region's backward
+        cur = torch.cuda.current_stream(device)
+        ev, t.early = t.early, None
+        if ev is not None and not fuse:
+            side.wait_event(ev)
+        else:
+            _sync_streams(cur, side)
+
     if t is not None:
-        t.record(lambda: _sync_streams(side, torch.cuda.current_stream(device)))  # backward: join
+        t.record(bwd_join)
     _sync_streams(main, side)                                                       # forward: fork
+    pend = getattr(_tls, "pending_side", None)
+    if pend is not None and pend is not side:
+        _sync_streams(pend, side)            # ... and behind a deferred region on another stream (its output is read here)
     out0 = fns[0]()
     with torch.cuda.stream(side):
         if t is not None:
@@ -215,9 +257,21 @@ def run_paths(fns, device, defer_join=False):
                 t.side = None
     if not defer_join:
         _sync_streams(side, main)                                                   # forward: join
+        _tls.pending_side = None  # (a pending stream was waited for by `side` above: joined transitively)
+    else:
+        _tls.pending_side = side
     if t is not None:
-        t.record(lambda: _sync_streams(torch.cuda.current_stream(device), side))  # backward: fork
+        t.record(bwd_fork)
     return [out0, out1]
+
+
+def join_pending(device):
+    """Make the caller's stream wait for a region whose forward join was deferred and never followed by another
+    region (end of a forward pass)."""
+    pend = getattr(_tls, "pending_side", None)
+    if pend is not None:
+        _sync_streams(pend, torch.cuda.current_stream(device))
+        _tls.pending_side = None
 
 
 class taping(object):
@@ -924,6 +978,8 @@ def run_model(model, x):
             return TapedForward.apply(model, len(x), *x, *params)
         return model._forward_impl(x)
     finally:
+        if x and hasattr(x[0], "device") and x[0].device.type == "cuda":
+            join_pending(x[0].device)  # a fusion whose join was deferred and that no later region picked up
         _tls.serial = outer_serial
         counters, _NBT = _NBT, outer
         if counters:

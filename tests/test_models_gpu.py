@@ -415,14 +415,17 @@ def test_two_stream_overlap_is_deterministic_and_equal_to_serial(name):
         torch.cuda.synchronize()
         return torch.cat([out.detach().reshape(-1)] + [p.grad.reshape(-1) for p in model.parameters()]).clone()
 
-    saved = engine.OVERLAP_PATHS
+    saved, saved_fuse = engine.OVERLAP_PATHS, engine.FUSE_STREAM
     try:
         engine.OVERLAP_PATHS = False
         serial = step()
         engine.OVERLAP_PATHS = True
+        engine.FUSE_STREAM = False
         runs = [step() for _ in range(5)]
+        engine.FUSE_STREAM = True   # SF_FUSE_STREAM=1: the fusions' attention direction on a stream of its own, the
+        runs += [step() for _ in range(5)]  # Fast pathway's backward released early (run_paths(fuse=True))
     finally:
-        engine.OVERLAP_PATHS = saved
+        engine.OVERLAP_PATHS, engine.FUSE_STREAM = saved, saved_fuse
     for r in runs:
         assert torch.equal(r, serial)
     model.eval()
