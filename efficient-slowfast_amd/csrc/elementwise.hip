@@ -101,6 +101,93 @@ __global__ void pool_kernel(const sf_pool_desc d, const float* __restrict__ in, 
   }
 }
 
+// Max pooling that also records WHICH tap won (first maximum in (kt, kh, kw) scan order, nn.MaxPool3d's rule) as one
+// byte per output element, [positions][C] dense: the backward pass then needs neither x nor y and no tie search
+// (sf_maxpool_bwd_arg: 335 -> 70 us on the Slow pathway's pool1 at 8 clips).  Four channels per thread.
+__global__ void pool_arg_kernel(const sf_pool_desc d, const float* __restrict__ in, float* __restrict__ out,
+                                unsigned char* __restrict__ arg, long total) {
+  const long idx = (long)blockIdx.x * TPB + threadIdx.x;
+  if (idx >= total) return;
+  const int cv = d.C >> 2;
+  const int c = (int)(idx % cv) * 4;
+  const long row = idx / cv;
+  long r = row;
+  const int wo = (int)(r % d.Wo);
+  r /= d.Wo;
+  const int ho = (int)(r % d.Ho);
+  r /= d.Ho;
+  const int to = (int)(r % d.To);
+  const int n = (int)(r / d.To);
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  unsigned win = 0;  // four tap indices, one byte each
+  bool first = true;
+  for (int kt = 0; kt < d.kT; ++kt) {
+    const int ti = to * d.sT - d.pT + kt;
+    if ((unsigned)ti >= (unsigned)d.Ti) continue;
+    for (int kh = 0; kh < d.kH; ++kh) {
+      const int hi = ho * d.sH - d.pH + kh;
+      if ((unsigned)hi >= (unsigned)d.Hi) continue;
+      for (int kw = 0; kw < d.kW; ++kw) {
+        const int wi = wo * d.sW - d.pW + kw;
+        if ((unsigned)wi >= (unsigned)d.Wi) continue;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(
+            in + ((((long)n * d.Ti + ti) * d.Hi + hi) * d.Wi + wi) * d.in_cs + d.in_coff + c);
+        const unsigned tap = (unsigned)((kt * d.kH + kh) * d.kW + kw);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (first || v[e] > acc[e]) {
+            acc[e] = v[e];
+            win = (win & ~(0xffu << (8 * e))) | (tap << (8 * e));
+          }
+        first = false;
+      }
+    }
+  }
+  *reinterpret_cast<f32x4*>(out + row * d.out_cs + d.out_coff + c) = acc;
+  *reinterpret_cast<unsigned*>(arg + row * d.C + c) = win;
+}
+
+// dx[input element] (+)= sum of dy over the windows that recorded this element as their winner.
+__global__ __launch_bounds__(256) void maxpool_bwd_arg_kernel(const sf_pool_desc d, const unsigned char* __restrict__ arg,
+                                                              const float* __restrict__ dy, int dy_cs, int dy_coff,
+                                                              float* __restrict__ dx, int dx_cs, int dx_coff, int acc,
+                                                              unsigned total) {
+  const unsigned idx = blockIdx.x * TPB + threadIdx.x;
+  if (idx >= total) return;
+  const unsigned cv = d.C >> 2;
+  const unsigned rin = idx / cv;
+  const int c = (int)(idx - rin * cv) * 4;
+  unsigned r = rin;
+  const int wi = (int)(r % (unsigned)d.Wi);
+  r /= (unsigned)d.Wi;
+  const int hi = (int)(r % (unsigned)d.Hi);
+  r /= (unsigned)d.Hi;
+  const int ti = (int)(r % (unsigned)d.Ti);
+  const int n = (int)(r / (unsigned)d.Ti);
+  auto lo = [](int i, int p, int k, int s) { const int a = i + p - k + 1; return a <= 0 ? 0 : (a + s - 1) / s; };
+  const int t0 = lo(ti, d.pT, d.kT, d.sT), t1 = min((ti + d.pT) / d.sT, d.To - 1);
+  const int h0 = lo(hi, d.pH, d.kH, d.sH), h1 = min((hi + d.pH) / d.sH, d.Ho - 1);
+  const int w0 = lo(wi, d.pW, d.kW, d.sW), w1 = min((wi + d.pW) / d.sW, d.Wo - 1);
+  f32x4 g = {0.f, 0.f, 0.f, 0.f};
+  for (int to = t0; to <= t1; ++to)
+    for (int ho = h0; ho <= h1; ++ho)
+      for (int wo = w0; wo <= w1; ++wo) {
+        const long ro = (((long)n * d.To + to) * d.Ho + ho) * d.Wo + wo;
+        const unsigned tap = (unsigned)(((ti - (to * d.sT - d.pT)) * d.kH + (hi - (ho * d.sH - d.pH))) * d.kW +
+                                        (wi - (wo * d.sW - d.pW)));
+        const unsigned a = *reinterpret_cast<const unsigned*>(arg + ro * d.C + c);
+        const unsigned x4 = a ^ (tap * 0x01010101u);  // a zero byte = this element won that channel of the window
+        if (((x4 - 0x01010101u) & ~x4 & 0x80808080u) != 0u) {
+          const f32x4 gv = *reinterpret_cast<const f32x4*>(dy + ro * dy_cs + dy_coff + c);
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (((x4 >> (8 * e)) & 0xffu) == 0u) g[e] += gv[e];
+        }
+      }
+  f32x4* o = reinterpret_cast<f32x4*>(dx + (long)rin * dx_cs + dx_coff + c);
+  *o = acc ? *o + g : g;
+}
+
 // ------------------------------------------------------------------------------------------------
 // Depthwise convolution + folded BN + residual + ReLU, thread per (output position, VEC channels).
 // Neighbouring threads share taps through L1/L2; the op moves ~2 floats per MAC and is HBM-bound.
@@ -771,6 +858,32 @@ extern "C" int sf_pool_fwd(const sf_pool_desc* d, const float* in, float* out, v
     hipLaunchKernelGGL(pool_kernel<1>, dim3(sf_cdiv(total, TPB)), dim3(TPB), 0, (hipStream_t)stream, *d, in, out,
                        total);
   }
+  SF_CHECK_LAUNCH();
+  return SF_OK;
+}
+
+extern "C" int sf_maxpool_fwd_arg(const sf_pool_desc* d, const float* in, float* out, unsigned char* arg, void* stream) {
+  if (!d || !in || !out || !arg || d->C <= 0 || d->kT <= 0 || d->kH <= 0 || d->kW <= 0 || d->is_avg) return SF_EINVAL;
+  const bool vec4 = (d->C % 4 == 0) && (d->in_cs % 4 == 0) && (d->in_coff % 4 == 0) && (d->out_cs % 4 == 0) &&
+                    (d->out_coff % 4 == 0) && sf_aligned16(in) && sf_aligned16(out) && ((uintptr_t)arg % 4 == 0);
+  if (!vec4 || (long)d->kT * d->kH * d->kW > 255) return SF_EINVAL;
+  const long total = (long)d->N * d->To * d->Ho * d->Wo * (d->C / 4);
+  hipLaunchKernelGGL(pool_arg_kernel, dim3(sf_cdiv(total, TPB)), dim3(TPB), 0, (hipStream_t)stream, *d, in, out, arg,
+                     total);
+  SF_CHECK_LAUNCH();
+  return SF_OK;
+}
+
+extern "C" int sf_maxpool_bwd_arg(const sf_pool_desc* d, const unsigned char* arg, const float* dy, int dy_cs,
+                                  int dy_coff, float* dx, int dx_cs, int dx_coff, int overwrite, void* stream) {
+  if (!d || !arg || !dy || !dx || d->is_avg || d->C <= 0) return SF_EINVAL;
+  const long total = (long)d->N * d->Ti * d->Hi * d->Wi * (d->C / 4);
+  const bool vec4 = (d->C % 4 == 0) && (dy_cs % 4 == 0) && (dy_coff % 4 == 0) && (dx_cs % 4 == 0) &&
+                    (dx_coff % 4 == 0) && sf_aligned16(dy) && sf_aligned16(dx) && ((uintptr_t)arg % 4 == 0) &&
+                    total < 0x7fffffffL;
+  if (!vec4 || (long)d->kT * d->kH * d->kW > 255) return SF_EINVAL;
+  hipLaunchKernelGGL(maxpool_bwd_arg_kernel, dim3(sf_cdiv(total, TPB)), dim3(TPB), 0, (hipStream_t)stream, *d, arg, dy,
+                     dy_cs, dy_coff, dx, dx_cs, dx_coff, overwrite ? 0 : 1, (unsigned)total);
   SF_CHECK_LAUNCH();
   return SF_OK;
 }

@@ -44,7 +44,7 @@ class PoolDesc(ctypes.Structure):
 
 EXPORTS = [
     "sf_abi_version", "sf_build_arch", "sf_ncthw_to_ndhwc", "sf_ndhwc_to_ncthw", "sf_conv_fwd", "sf_dwconv_fwd",
-    "sf_pool_fwd", "sf_tmax_mean_ws_floats", "sf_tmax_mean", "sf_gate_apply", "sf_attn_fwd", "sf_head_act_mean",
+    "sf_pool_fwd", "sf_maxpool_fwd_arg", "sf_maxpool_bwd_arg", "sf_tmax_mean_ws_floats", "sf_tmax_mean", "sf_gate_apply", "sf_attn_fwd", "sf_head_act_mean",
     "sf_copy_channels", "sf_channel_stats_ws_floats", "sf_channel_stats", "sf_affine_fwd", "sf_bn_train_stats",
     "sf_conv_wgrad_splits", "sf_conv_wgrad", "sf_bn_bwd_ws_floats", "sf_bn_bwd_reduce", "sf_bn_bwd_apply",
     "sf_attn_bwd", "sf_maxpool_bwd", "sf_tmax_dot", "sf_eca_bwd_apply", "sf_eca_gate_bwd", "sf_bcast_add", "sf_rowdot", "sf_axpy", "sf_act_bwd",
@@ -85,6 +85,8 @@ def lib():
         L.sf_conv_fwd.argtypes = [ctypes.POINTER(ConvDesc)] + [vp] * 7
         L.sf_dwconv_fwd.argtypes = [ctypes.POINTER(ConvDesc)] + [vp] * 7
         L.sf_pool_fwd.argtypes = [ctypes.POINTER(PoolDesc), vp, vp, vp]
+        L.sf_maxpool_fwd_arg.argtypes = [ctypes.POINTER(PoolDesc), vp, vp, vp, vp]
+        L.sf_maxpool_bwd_arg.argtypes = [ctypes.POINTER(PoolDesc), vp, vp, ci, ci, vp, ci, ci, ci, vp]
         L.sf_tmax_mean_ws_floats.argtypes = [ci, ci]
         L.sf_tmax_mean_ws_floats.restype = cl
         L.sf_tmax_mean.argtypes = [vp, ci, ci] + [ci] * 6 + [vp, vp, vp]
@@ -520,7 +522,9 @@ def dwconv(x, wp, kernel, stride=(1, 1, 1), padding=(0, 0, 0), scale=None, bias=
     return out
 
 
-def pool(x, kernel, stride, padding=(0, 0, 0), avg=False, out=None, out_reserve=(0, 0)):
+def pool(x, kernel, stride, padding=(0, 0, 0), avg=False, out=None, out_reserve=(0, 0), want_arg=False):
+    """want_arg (max pooling): also return the byte map of window winners for maxpool_bwd_arg — (out, arg), arg None
+    when the views are not float4-addressable or the window has more than 255 taps."""
     _require_gpu(x.buf, "pool")
     To = _out_dim(x.T, kernel[0], stride[0], padding[0], 1)
     Ho = _out_dim(x.H, kernel[1], stride[1], padding[1], 1)
@@ -532,8 +536,16 @@ def pool(x, kernel, stride, padding=(0, 0, 0), avg=False, out=None, out_reserve=
     d = PoolDesc(x.N, x.T, x.H, x.W, x.C, x.cs, x.coff, To, Ho, Wo, out.cs, out.coff,
                  kernel[0], kernel[1], kernel[2], stride[0], stride[1], stride[2],
                  padding[0], padding[1], padding[2], 1 if avg else 0)
+    if want_arg and not avg:
+        ok = (x.C % 4 == 0 and x.cs % 4 == 0 and x.coff % 4 == 0 and out.cs % 4 == 0 and out.coff % 4 == 0 and
+              kernel[0] * kernel[1] * kernel[2] <= 255 and x.buf.data_ptr() % 16 == 0 and out.buf.data_ptr() % 16 == 0)
+        if ok:
+            arg = torch.empty((out.rows, x.C), dtype=torch.uint8, device=x.buf.device)
+            _check(lib().sf_maxpool_fwd_arg(ctypes.byref(d), x.ptr(), out.ptr(), _ptr(arg), _stream()),
+                   "sf_maxpool_fwd_arg")
+            return out, arg
     _check(lib().sf_pool_fwd(ctypes.byref(d), x.ptr(), out.ptr(), _stream()), "sf_pool_fwd")
-    return out
+    return (out, None) if want_arg else out
 
 
 def tmax_mean(x, alpha):
@@ -857,6 +869,20 @@ def maxpool_bwd(x, y, dy, dx, kernel, stride, padding=(0, 0, 0), overwrite=False
     _check(fn(ctypes.byref(d), x.ptr(), y.ptr(), dy.ptr(), dy.cs, dy.coff, dx.ptr(), dx.cs, dx.coff, _stream()),
            "sf_maxpool_bwd")
     return dx
+
+
+def maxpool_bwd_arg(x_like, arg, dy, dx, kernel, stride, padding=(0, 0, 0), overwrite=False):
+    """dx (+)= dy gathered through the winner map `arg` of pool(..., want_arg=True); x_like gives the input dims.
+    Returns False (nothing launched) when the gradient views are not float4-addressable."""
+    if not (dy.cs % 4 == 0 and dy.coff % 4 == 0 and dx.cs % 4 == 0 and dx.coff % 4 == 0 and
+            dy.buf.data_ptr() % 16 == 0 and dx.buf.data_ptr() % 16 == 0):
+        return False
+    d = PoolDesc(x_like.N, x_like.T, x_like.H, x_like.W, x_like.C, x_like.cs, x_like.coff, dy.T, dy.H, dy.W, dy.cs,
+                 dy.coff, kernel[0], kernel[1], kernel[2], stride[0], stride[1], stride[2],
+                 padding[0], padding[1], padding[2], 0)
+    _check(lib().sf_maxpool_bwd_arg(ctypes.byref(d), _ptr(arg), dy.ptr(), dy.cs, dy.coff, dx.ptr(), dx.cs, dx.coff,
+                                    1 if overwrite else 0, _stream()), "sf_maxpool_bwd_arg")
+    return True
 
 
 def tmax_dot(x, alpha, dz):

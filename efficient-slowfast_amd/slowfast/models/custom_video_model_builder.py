@@ -132,7 +132,7 @@ class _EfficientTwoPathway(nn.Module):
                     x = m(x)
                 elif n.endswith("_fuse"):
                     nxt = names[i + 1] if i + 1 < len(names) else "head"
-                    x = m(x, defer_join=(nxt != "head"))  # followed by a stage: the attention overlaps it
+                    x = m(x, defer_join=(nxt != "head") and engine.DEFER_JOIN)  # followed by a stage: the attention overlaps it
                 else:
                     nxt = getattr(self, names[i + 1]) if i + 1 < len(names) else None
                     x = m(x, reserve=nxt.reserve(None) if isinstance(nxt, FuseFastAndSlow) else None)

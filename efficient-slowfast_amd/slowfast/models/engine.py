@@ -191,6 +191,7 @@ def _sync_streams(first, then):
 
 
 _FUSE = {}
+DEFER_JOIN = os.environ.get("SF_DEFER_JOIN", "1") != "0"  # forward: the Slow pathway's next stage starts beside the attention
 # SF_FUSE_STREAM=1 (default 0): the CMDA fusions' attention direction runs on a side stream of its own, so that in the
 # backward pass the Fast pathway's stage k (which does not depend on the attention's gradient) runs BESIDE the
 # attention backward of fusion k instead of queueing behind it on the shared side stream.  Measured (cfg #3, 8 clips,
@@ -882,13 +883,19 @@ def _record_stem_input_grad(x, conv, z, view, ncthw, geom, Wo):
 
 def maxpool(x, kernel, stride, padding=(0, 0, 0), out_reserve=(0, 0)):
     """MaxPool3d (+ its backward on the tape)."""
-    y = sfhip.pool(x, kernel, stride, padding, out_reserve=out_reserve)
     t = tape()
+    if t is None:
+        return sfhip.pool(x, kernel, stride, padding, out_reserve=out_reserve)
+    y, arg = sfhip.pool(x, kernel, stride, padding, out_reserve=out_reserve, want_arg=True)
     if t is not None:
         def bwd():
             fresh = t.grad_of_uninitialised(x)  # first writer of x's gradient: write, no zero fill / read
-            sfhip.maxpool_bwd(x, y, t.grad_of(y), fresh if fresh is not None else t.grad_of(x), kernel, stride,
-                              padding, overwrite=fresh is not None)
+            dx = fresh if fresh is not None else t.grad_of(x)
+            # the forward's winner map: no x / y reads, no tie search (else: the search form)
+            if arg is not None and sfhip.maxpool_bwd_arg(x, arg, t.grad_of(y), dx, kernel, stride, padding,
+                                                         overwrite=fresh is not None):
+                return
+            sfhip.maxpool_bwd(x, y, t.grad_of(y), dx, kernel, stride, padding, overwrite=fresh is not None)
 
         t.record(bwd)
     return y

@@ -168,7 +168,7 @@ class _TwoPathwayResNet(nn.Module):
         (the stage's own two-stream region orders everything again); the identity pools in between touch nothing."""
         pools_are_identity = all(
             list(getattr(self, "pathway{}_pool".format(p)).kernel_size) == [1, 1, 1] for p in range(self.num_pathways))
-        return fuse(x, defer_join=pools_are_identity)
+        return fuse(x, defer_join=pools_are_identity and engine.DEFER_JOIN)
 
 
 @MODEL_REGISTRY.register()

@@ -145,6 +145,15 @@ typedef struct sf_pool_desc {
   int is_avg;
 } sf_pool_desc;
 int sf_pool_fwd(const sf_pool_desc* d, const float* in, float* out, void* stream);
+/* Max pooling that also records the winning tap of every window — the FIRST maximum in (kt, kh, kw) scan order,
+ * nn.MaxPool3d's rule (stem_helper.py:117-119 pool1, nonlocal_helper.py:75-79) — as one byte per output element, arg
+ * [N*To*Ho*Wo][C] dense.  sf_maxpool_bwd_arg then gathers dL/dy into dL/dx from `arg` alone (no x, no y, no tie
+ * search); overwrite != 0: dx is written (zero where an element won no window), else accumulated.  Both need
+ * float4-addressable views (C, pitches, offsets multiples of 4, 16-byte aligned bases) and <= 255 taps: SF_EINVAL
+ * otherwise (callers keep sf_pool_fwd / sf_maxpool_bwd for those).                                                 */
+int sf_maxpool_fwd_arg(const sf_pool_desc* d, const float* in, float* out, unsigned char* arg, void* stream);
+int sf_maxpool_bwd_arg(const sf_pool_desc* d, const unsigned char* arg, const float* dy, int dy_cs, int dy_coff,
+                       float* dx, int dx_cs, int dx_coff, int overwrite, void* stream);
 
 /* ---- CMDA Fast->Slow edge: MaxPool3d(alpha,1,1) -> ECA -> BN -> ReLU -> concat ------------------
  * custom_video_model_builder.py:131-135 + wdf_attention_helper.py:77-91, two launches:

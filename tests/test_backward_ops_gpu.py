@@ -238,6 +238,44 @@ def test_maxpool_backward(k, s, p, c):
     assert torch.equal(dx.buf, first.buf)
 
 
+@pytest.mark.parametrize("ties", [False, True])
+@pytest.mark.parametrize("k,s,p", [((1, 3, 3), (1, 2, 2), (0, 1, 1)), ((3, 3, 3), (1, 2, 2), (1, 1, 1)),
+                                   ((2, 2, 2), (2, 2, 2), (0, 0, 0)), ((4, 1, 1), (4, 1, 1), (0, 0, 0))])
+def test_maxpool_winner_map_backward(k, s, p, ties):
+    """sf_maxpool_fwd_arg / sf_maxpool_bwd_arg (stem pool1, the Nonlocal key pooling): the forward records the first
+    maximum of every window, the backward gathers dL/dy through that map alone — equal to autograd through
+    F.max_pool3d, also where windows overlap and where elements TIE (ReLU outputs: runs of zeros; ties = quantised
+    inputs), in both the accumulating and the first-writer form, on channel-slice views."""
+    import sfhip
+    dev = _dev()
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 8, 4, 13, 12, generator=g)
+    if ties:
+        x = torch.relu((x * 2).round() / 2)
+    x.requires_grad_(True)
+    y = F.max_pool3d(x, k, s, p)
+    dy = torch.randn(y.shape, generator=g)
+    (dx_ref,) = torch.autograd.grad(y, (x,), dy)
+    xa = sfhip.Act(torch.randn(2, 4, 13, 12, 20, device=dev), 8, 8)  # a channel slice of a wider buffer
+    xa.buf[..., 8:16] = x.detach().permute(0, 2, 3, 4, 1).to(dev)
+    ya, arg = sfhip.pool(xa, k, s, p, want_arg=True, out_reserve=(4, 0))
+    assert arg is not None and arg.dtype == torch.uint8
+    assert torch.equal(_back(ya), y.detach())
+    dya = sfhip.Act(torch.zeros(ya.buf.shape, device=dev), ya.coff, ya.C)
+    dya.buf[..., ya.coff:ya.coff + 8] = dy.permute(0, 2, 3, 4, 1).to(dev)
+    dx = sfhip.Act(torch.ones(2, 4, 13, 12, 8, device=dev))
+    assert sfhip.maxpool_bwd_arg(xa, arg, dya, dx, k, s, p)
+    first = sfhip.Act(torch.full((2, 4, 13, 12, 8), float("nan"), device=dev))
+    assert sfhip.maxpool_bwd_arg(xa, arg, dya, first, k, s, p, overwrite=True)
+    torch.cuda.synchronize()
+    assert _rel(_back(first), dx_ref) < 1e-6
+    assert torch.equal(dx.buf - 1.0, first.buf) or _rel(_back(dx) - 1.0, dx_ref) < 1e-6
+    # the search form (no map) agrees bit for bit
+    ref2 = sfhip.Act(torch.zeros(2, 4, 13, 12, 8, device=dev))
+    sfhip.maxpool_bwd(xa, ya, dya, ref2, k, s, p)
+    assert torch.equal(ref2.buf, first.buf)
+
+
 @pytest.mark.parametrize("c,reduction", [(32, 8), (32, 1), (64, 4)])
 def test_spatial_attention_module_with_reduction(c, reduction):
     """SpatialAttention(channel, reduction) as the reference class builds it (wdf_attention_helper.py:17-31: q / k with
