@@ -410,9 +410,14 @@ def main():
     graph = None
     graph_note = None
 
+    # With a process group up, RCCL's watchdog thread polls its events at any time: under the default (global)
+    # capture mode such a call from ANOTHER thread aborts the process ("operation not permitted when stream is
+    # capturing"); thread-local mode restricts the check to the capturing thread's own calls.
+    capture_mode = "thread_local" if dist.is_initialized() else "global"
+
     def capture():
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g, stream=side):
+        with torch.cuda.graph(g, stream=side, capture_error_mode=capture_mode):
             o = step()
         g.replay()
         torch.cuda.synchronize()
@@ -430,11 +435,12 @@ def main():
 
     want_graph = (not train and not args.no_graph) or (train and args.graph_train)
     auto = None
-    if train and not args.graph_train and not args.no_graph and world == 1:
+    if train and not args.graph_train and not args.no_graph and world == 1 and not dist.is_initialized():
         # Launch-bound training steps (cfg #1: ~1500 launches of a 0.007 GMAC model): when the Python thread needs as
         # long to ISSUE a step as the GPU needs to run it, the step is captured into one hipGraph and the faster of
         # the two forms is timed.  For cfg #2 / #3 the host is 2x ahead (34 of 68 ms) and nothing is captured: their
-        # graph replays slower than the eager streams.
+        # graph replays slower than the eager streams.  Not with a process group up: the step then holds
+        # RCCL collectives on a comm stream, which stay eager.
         eager_ms, issue_ms = ms_per(step, 6)
         if issue_ms > 0.85 * eager_ms:
             want_graph = True
@@ -508,7 +514,7 @@ def main():
             estep()
         torch.cuda.synchronize()
         eg = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(eg, stream=side):
+        with torch.cuda.graph(eg, stream=side, capture_error_mode=capture_mode):
             estep()
         eg.replay()
         barrier()

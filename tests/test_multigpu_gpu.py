@@ -88,6 +88,13 @@ def test_spawned_rank_runs_the_chunked_allreduce_on_rccl():
         r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "2",
                             "--no-cpu-baseline", "--no-extras", "--batch", "2"] + extra, env=env, capture_output=True,
                            text=True, timeout=600)
+        if r.returncode != 0:  # keep the whole log where a gpurun call can bring it back
+            try:
+                os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
+                with open(os.path.join(root, "gpurun_out", "spawned_rank_stderr.txt"), "w") as f:
+                    f.write(r.stderr)
+            except OSError:
+                pass
         assert r.returncode == 0, (r.stderr[:3000], r.stderr[-1500:])
         lines.append(json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]))
     chunked, single = lines

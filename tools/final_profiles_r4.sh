@@ -16,6 +16,7 @@ bash tools/attn_traffic.sh > /dev/null 2>&1; cp gpurun_out/attn_traffic/traffic.
 timeout 400 python tools/prof_convs.py dual > $O/conv_per_shape.txt 2>&1
 timeout 300 python tools/microbench/conv_bx_bench.py > $O/conv_bx_ab.txt 2>&1
 timeout 300 python tools/microbench/wgrad_bx_bench.py > $O/wgrad_bx_ab.txt 2>&1
+(echo "conv_wgrad_rows.hip + flat finish (default)"; timeout 200 python tools/microbench/wgrad_small_bench.py; echo; echo "SF_WGRAD_ROWS=0 (conv_wgrad_small_kernel)"; SF_WGRAD_ROWS=0 timeout 200 python tools/microbench/wgrad_small_bench.py) 2>&1 | grep -v "amdgpu.ids" > $O/wgrad_small_ab.txt
 timeout 600 python tools/whatif_skip.py > $O/whatif_skip.txt 2>&1
 timeout 300 python tools/host_lead.py > $O/host_lead.txt 2>&1
 timeout 700 python bench.py > $O/bench_dual.json 2> $O/bench_dual.err
