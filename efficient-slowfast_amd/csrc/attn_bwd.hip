@@ -663,12 +663,6 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void attn_bwd_bx_kernel(const BwdA
   const float gamma = p.gamma[0];
   float* const myslot = slots + wave * SLOT;
   unsigned short* const img = reinterpret_cast<unsigned short*>(myslot);  // [piece][key 32][TP]
-  if constexpr ((DBG & 8) != 0) {
-    if ((wave >> 2) & 1) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(3);
-  }
-  if constexpr ((DBG & 16) != 0) {
-    if (wave & 1) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(3);
-  }
 
   // ---- this wavefront's keys: K' = K log2(e) and V as B operands [k = channel][col = key], K as [k = key][col = channel]
   u32x4 kfb[2][3], vfb[2][3], kbr[2][3];
@@ -1557,10 +1551,7 @@ int launch_fused_bx(BwdArgs a, float* ws, float* bx_ws, hipStream_t s) {
   static const Kern kern = [] {  // SF_ATTN_BX_DBG: timing ablations (see the kernel)
     const char* e = getenv("SF_ATTN_BX_DBG");
     const int dbg = e ? atoi(e) : 0;
-    if (NW == 8)
-      return dbg == 2 ? (Kern)attn_bwd_bx_kernel<2, 8>
-             : dbg == 8 ? (Kern)attn_bwd_bx_kernel<8, 8>
-             : dbg == 16 ? (Kern)attn_bwd_bx_kernel<16, 8> : (Kern)attn_bwd_bx_kernel<0, 8>;
+    if (NW == 8) return dbg == 2 ? (Kern)attn_bwd_bx_kernel<2, 8> : (Kern)attn_bwd_bx_kernel<0, 8>;
     switch (dbg) {
       case 1: return (Kern)attn_bwd_bx_kernel<1, 4>;
       case 2: return (Kern)attn_bwd_bx_kernel<2, 4>;
