@@ -537,9 +537,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_stem_kernel(const StemArgs q) 
 constexpr int STEM_WIN = 36;
 constexpr int STEM_ROWS = STEM_KT * STEM_KH * STEM_WIN;   // 1260
 constexpr int STEM_MT = (STEM_ROWS + 15) / 16;            // 79
-constexpr int STEM_NI2 = (STEM_MT + 3) / 4;               // 20 accumulator tiles per wavefront
 
-__global__ __launch_bounds__(256) void conv_wgrad_stem_pair_kernel(const StemArgs q) {
+// NW wavefronts per workgroup (4 or 8) share the ring; with 8, two wavefronts per SIMD cover each other's LDS
+// latencies and instruction issue (the f32 MFMA shares the vector ALUs with everything else a wavefront does).
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void conv_wgrad_stem_pair_kernel(const StemArgs q) {
+  constexpr int STEM_NI2 = (STEM_MT + NW - 1) / NW;  // accumulator tiles per wavefront (20 / 10)
+  constexpr int NT = 64 * NW;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const WgradArgs& p = q.w;
   const sf_conv_desc& d = p.d;
@@ -549,30 +553,31 @@ __global__ __launch_bounds__(256) void conv_wgrad_stem_pair_kernel(const StemArg
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int fr = lane & 15, fg = lane >> 4;
   const int slab4 = slab >> 2;
-  constexpr int LD4 = 8;
+  constexpr int LD4 = 2048 / NT;  // float4s of a slab per thread (capacity 8 * 256, checked by stem_plan)
+  constexpr int LDZ = 1024 / NT;  // dz floats per thread
   const int npair = (d.Wo + 1) >> 1, nk = q.nblk;  // nblk = K steps of 4 pairs
 
   f32x4 acc[STEM_NI2];
 #pragma unroll
   for (int i = 0; i < STEM_NI2; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  // tile mt = wave + 4 i, this lane's window row R = 16 mt + fr -> (tap, j'); rows past 1260 repeat the last one
+  // tile mt = wave + NW i, this lane's window row R = 16 mt + fr -> (tap, j'); rows past 1260 repeat the last one
   int r_kt[STEM_NI2], r_off[STEM_NI2];
 #pragma unroll
   for (int i = 0; i < STEM_NI2; ++i) {
-    const int R = min(16 * (wave + 4 * i) + fr, STEM_ROWS - 1);
+    const int R = min(16 * (wave + NW * i) + fr, STEM_ROWS - 1);
     const int tap = R / STEM_WIN, jw = R - tap * STEM_WIN;
     r_kt[i] = tap / STEM_KH;
     r_off[i] = (tap % STEM_KH) * q.rowf + jw;
   }
 
   f32x4 rs[LD4];
-  float rz[4];
+  float rz[LDZ];
   auto load_slab = [&](int n, int ti, int h) {
     const bool ok = (unsigned)ti < (unsigned)d.Ti;
     const f32x4* src = reinterpret_cast<const f32x4*>(p.x + (((long)n * d.Ti + (ok ? ti : 0)) * d.Hi + (long)h * d.sH) * q.rowf);
 #pragma unroll
     for (int u = 0; u < LD4; ++u) {
-      const int f = tid + u * 256;
+      const int f = tid + u * NT;
       rs[u] = (ok && f < slab4) ? src[f] : (f32x4){0.f, 0.f, 0.f, 0.f};
     }
   };
@@ -580,22 +585,22 @@ __global__ __launch_bounds__(256) void conv_wgrad_stem_pair_kernel(const StemArg
     f32x4* dst = reinterpret_cast<f32x4*>(ring + slot * slab);
 #pragma unroll
     for (int u = 0; u < LD4; ++u) {
-      const int f = tid + u * 256;
+      const int f = tid + u * NT;
       if (f < slab4) dst[f] = rs[u];
     }
   };
   auto load_dz = [&](int n, int t, int h) {
     const long m0 = (((long)n * d.To + t) * d.Ho + h) * d.Wo;
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int e = tid + u * 256, w = e >> 3, co = e & 7;
+    for (int u = 0; u < LDZ; ++u) {
+      const int e = tid + u * NT, w = e >> 3, co = e & 7;
       rz[u] = (w < d.Wo && co < d.Cout) ? p.dz[(m0 + w) * p.dz_cs + p.dz_coff + co] : 0.f;
     }
   };
   auto store_dz = [&]() {
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int e = tid + u * 256;
+    for (int u = 0; u < LDZ; ++u) {
+      const int e = tid + u * NT;
       if (e < nk * 64) dzs[e] = rz[u];
     }
   };
@@ -652,7 +657,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_stem_pair_kernel(const StemArg
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 0; i < STEM_NI2; ++i) {
-          if (wave + 4 * i >= STEM_MT) break;  // wave-uniform: the last tile slot of wavefront 3
+          if (wave + NW * i >= STEM_MT) break;  // wave-uniform: the last tile slot of the last wavefronts
           acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[i], b_cur, acc[i], 0, 0, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -668,7 +673,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_stem_pair_kernel(const StemArg
   float* const Dl = lds;  // [STEM_MT * 16][16]
 #pragma unroll
   for (int i = 0; i < STEM_NI2; ++i) {
-    const int mt = wave + 4 * i;
+    const int mt = wave + NW * i;
     if (mt >= STEM_MT) break;
 #pragma unroll
     for (int r = 0; r < 4; ++r) Dl[(16 * mt + 4 * fg + r) * 16 + fr] = acc[i][r];
@@ -676,7 +681,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_stem_pair_kernel(const StemArg
   __syncthreads();
   float* const out = p.part + (long)blockIdx.x * d.Cout * p.ntaps * d.cin_pad;
   const int per_co = p.ntaps * d.cin_pad;
-  for (int e = tid; e < d.Cout * per_co; e += 256) {
+  for (int e = tid; e < d.Cout * per_co; e += NT) {
     const int co = e / per_co, rem = e - co * per_co;
     const int tap = rem / d.cin_pad, j = rem - tap * d.cin_pad;
     float v = 0.f;
@@ -965,10 +970,17 @@ extern "C" int sf_conv_wgrad(const sf_conv_desc* d, const float* x, const float*
     if (sq.pair && lds < (size_t)STEM_MT * 16 * 16 * sizeof(float)) lds = (size_t)STEM_MT * 16 * 16 * sizeof(float);
     static SfLdsAttr at0, at1;  // raise the dynamic-LDS cap once per device (129 KB of the CU's 160 KB)
     if (!sf_ensure_dyn_lds(at0, reinterpret_cast<const void*>(conv_wgrad_stem_kernel), 160 * 1024 - 512) ||
-        !sf_ensure_dyn_lds(at1, reinterpret_cast<const void*>(conv_wgrad_stem_pair_kernel), 160 * 1024 - 512))
+        !sf_ensure_dyn_lds(at1, reinterpret_cast<const void*>(conv_wgrad_stem_pair_kernel<4>), 160 * 1024 - 512))
       return SF_ELAUNCH;
-    if (sq.pair)
-      hipLaunchKernelGGL(conv_wgrad_stem_pair_kernel, dim3(stem_workgroups(sq)), dim3(256), lds, (hipStream_t)stream,
+    static SfLdsAttr at2;
+    if (!sf_ensure_dyn_lds(at2, reinterpret_cast<const void*>(conv_wgrad_stem_pair_kernel<8>), 160 * 1024 - 512))
+      return SF_ELAUNCH;
+    static const int stem_nw = [] { const char* e = getenv("SF_STEM_NW"); return e ? atoi(e) : 8; }();
+    if (sq.pair && stem_nw == 8)
+      hipLaunchKernelGGL(conv_wgrad_stem_pair_kernel<8>, dim3(stem_workgroups(sq)), dim3(512), lds,
+                         (hipStream_t)stream, sq);
+    else if (sq.pair)
+      hipLaunchKernelGGL(conv_wgrad_stem_pair_kernel<4>, dim3(stem_workgroups(sq)), dim3(256), lds, (hipStream_t)stream,
                          sq);
     else
       hipLaunchKernelGGL(conv_wgrad_stem_kernel, dim3(stem_workgroups(sq)), dim3(256), lds, (hipStream_t)stream, sq);
