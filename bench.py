@@ -386,7 +386,17 @@ def main():
             # res5 + head, then res4 (+ s4_fuse): 85 % of the gradient bytes, final ~10 ms into the backward pass —
             # their all-reduce runs on its own stream under the rest of the backward; the remainder after it
             flat.overlap_with_backward(model, boundaries=("s5", "s4"))
-        opt = torch.optim.SGD(model.parameters(), lr=1e-3, momentum=0.9, weight_decay=1e-4)
+        # torch's SGD (the reference: models/optimizer.py:53-60 torch.optim.SGD with momentum + weight decay); fused=True is
+        # torch's single multi-tensor kernel per step instead of its four foreach passes (SF_SGD_FUSED=0: the foreach form)
+        sgd = dict(lr=1e-3, momentum=0.9, weight_decay=1e-4)
+        opt = None
+        if os.environ.get("SF_SGD_FUSED", "1") != "0":
+            try:
+                opt = torch.optim.SGD(model.parameters(), fused=True, **sgd)
+            except (TypeError, RuntimeError):
+                opt = None
+        if opt is None:
+            opt = torch.optim.SGD(model.parameters(), **sgd)  # torch's default: the foreach implementation
 
         def step():
             flat.zero()
@@ -659,7 +669,7 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": desc,
-                       "mode": "train step: train-mode forward + CE + backward + 1 flat-gradient all-reduce + SGD"
+                       "mode": "train step: train-mode forward + CE + backward + 1 flat-gradient all-reduce + SGD (momentum 0.9, weight decay 1e-4; torch.optim.SGD%s)" % (", fused" if getattr(opt, "defaults", {}).get("fused") else "")
                        if train else "eval forward (inference)",
                        "clips_per_gpu": batch, "global_batch": batch * world, "layout": "NCTHW in, NDHWC inside",
                        "arithmetic": "fp32 tensors, fp32 accumulation everywhere; short-reduction convs and d = 128 "

@@ -55,7 +55,7 @@ EXPORTS = [
     "sf_conv_fwd_ws", "sf_attn_fwd_ws_floats", "sf_attn_fwd_ws", "sf_affine_fwd_mask", "sf_bn_bwd_apply_first", "sf_maxpool_bwd_first",
     "sf_conv_tune", "sf_conv_stats_ws_floats", "sf_conv_fwd_stats", "sf_bn_train_stats_merge",
     "sf_attn_products_per_fp32", "sf_pack_conv_weights", "sf_attn_bwd_variant", "sf_attn_tune",
-    "sf_bx_planes_elems", "sf_bx_split", "sf_conv_bx_ws_floats", "sf_conv_fwd_bx", "sf_conv_wgrad_bx_splits",
+    "sf_bx_planes_elems", "sf_bx_split", "sf_bx_split_batched", "sf_conv_bx_ws_floats", "sf_conv_fwd_bx", "sf_conv_wgrad_bx_splits",
     "sf_conv_wgrad_bx_ws_floats", "sf_conv_wgrad_bx",
 ]
 _LONG_RET = ("sf_tmax_mean_ws_floats", "sf_channel_stats_ws_floats", "sf_bn_bwd_ws_floats",
@@ -145,6 +145,7 @@ def lib():
         L.sf_bx_planes_elems.argtypes = [cl, ci]
         L.sf_bx_planes_elems.restype = cl
         L.sf_bx_split.argtypes = [vp, ci, ci, cl, ci, vp, vp]
+        L.sf_bx_split_batched.argtypes = [vp, vp, ci, ci, vp]
         L.sf_conv_bx_ws_floats.argtypes = [ctypes.POINTER(ConvDesc), ci, ci]
         L.sf_conv_bx_ws_floats.restype = cl
         L.sf_conv_fwd_bx.argtypes = [ctypes.POINTER(ConvDesc)] + [vp] * 10
@@ -398,6 +399,9 @@ def pack_conv_weight_pair(w):
 _PACK_TABLES = {}
 
 
+_SPLIT_TABLES = {}
+
+
 def pack_conv_weight_pairs(weights, outs):
     """pack_conv_weight_pair for many weights in ONE launch.  outs: per weight the (wp, wtp) tensors to fill (None =
     allocate).  Returns the list of (wp, wtp).  The device-side table of pointers is cached per pointer set."""
@@ -432,13 +436,29 @@ def pack_conv_weight_pairs(weights, outs):
         tab = (key, items, starts)
         _PACK_TABLES[dev] = tab
     _check(lib().sf_pack_conv_weights(_ptr(tab[1]), _ptr(tab[2]), len(recs), nb, _stream()), "sf_pack_conv_weights")
-    for o in res:  # packed weights overwritten in place: their bf16 piece planes (conv_bx.hip) follow
+    # packed weights overwritten in place: their bf16 piece planes (conv_bx.hip) follow, all in ONE launch
+    recs, blk0, nb = [], [0], 0
+    for o in res:
         for t in o:
             pl = t.__dict__.get("_sf_bx")
             if pl is not None:
-                _check(lib().sf_bx_split(_ptr(t), t.shape[1] * t.shape[2], 0, t.shape[0], t.shape[1] * t.shape[2],
-                                         _ptr(pl), _stream()), "sf_bx_split")
+                rows, c = t.shape[0], t.shape[1] * t.shape[2]
+                recs.append((t.data_ptr(), pl.data_ptr(), rows, c, 0))
+                nb += ((rows + 1) * (c // 8) + 255) // 256
+                blk0.append(nb)
             t.__dict__.pop("_sf_classes", None)  # tap-subset copies of the previous contents (strided data gradients)
+    if len(recs) == 1:
+        r = recs[0]
+        _check(lib().sf_bx_split(r[0], r[3], 0, r[2], r[3], r[1], _stream()), "sf_bx_split")
+    elif recs:
+        key = tuple(recs)
+        tab = _SPLIT_TABLES.get(dev)
+        if tab is None or tab[0] != key:
+            raw = b"".join(struct.pack("<QQqii", *r) for r in recs)
+            tab = (key, torch.from_numpy(np.frombuffer(raw, dtype=np.uint8).copy()).to(dev),
+                   torch.tensor(blk0, dtype=torch.int32).to(dev))
+            _SPLIT_TABLES[dev] = tab
+        _check(lib().sf_bx_split_batched(_ptr(tab[1]), _ptr(tab[2]), len(recs), nb, _stream()), "sf_bx_split_batched")
     return res
 
 

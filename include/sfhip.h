@@ -114,6 +114,11 @@ int sf_conv_tune(int knob, int value);
  *   ws).  ws: sf_conv_bx_ws_floats(d, have_in_planes, have_w_planes) floats; 0 = the shape is not served (SF_EINVAL). */
 long sf_bx_planes_elems(long rows, int C);
 int sf_bx_split(const float* x, int cs, int coff, long rows, int C, unsigned short* planes, void* stream);
+/* sf_bx_split of n DENSE tensors (pitch = C) in one launch — the packed weights of every bf16-piece layer after an
+ * optimizer step (models/optimizer.py step -> every nn.Conv3d weight of resnet_helper.py:182-223 changes).  items: n
+ * records {const float* x; uint16_t* planes; int64_t rows; int32_t C; int32_t 0}; blk0[i] = first workgroup of item i
+ * (a workgroup = 256 elements of 8 channels over (rows + 1) * C / 8), blk0[n] = nblocks.                           */
+int sf_bx_split_batched(const void* items, const int* blk0, int n, int nblocks, void* stream);
 long sf_conv_bx_ws_floats(const sf_conv_desc* d, int have_in_planes, int have_w_planes);
 int sf_conv_fwd_bx(const sf_conv_desc* d, const float* in, const unsigned short* in_planes, const float* w_packed,
                    const unsigned short* w_planes, const float* scale, const float* bias, const float* res, float* out,
