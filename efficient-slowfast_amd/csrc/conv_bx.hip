@@ -47,6 +47,9 @@ struct BxArgs {
   unsigned a_rows, a_bytes, b_bytes;      // rows of a plane (the zero row's index), bytes of all three planes
   unsigned a_plane, b_plane;              // bytes per plane
   unsigned wo_mul, wo_sh, ho_mul, ho_sh, to_mul, to_sh;
+  const float* xf;           // AREG (pointwise layers): the fp32 activation rows themselves, split in registers
+  unsigned xf_bytes;
+  float* stats;              // AREG + DIRECT: per-tile channel statistics of the stored outputs (conv_wave's records)
 };
 
 __device__ __forceinline__ unsigned mdiv(unsigned n, unsigned mul, unsigned sh) {
@@ -265,6 +268,200 @@ __global__ __launch_bounds__(512, 2) void conv_bx_kernel(const BxArgs p) {
         if (m < p.M && n < d.Cout) wsp[(long)m * d.Cout + n] = acc[i][j][e];
       }
     }
+}
+
+// ---- pointwise layers ------------------------------------------------------------------------------------------------
+// 1x1x1 stride-1 convs (and their data gradients: the same GEMM on the transposed packed weight) with 64..2048 channels
+// on both sides — conv_a / conv_c of every bottleneck, resnet_helper.py:182-223.  Here the activation operand is used
+// ONCE per output column block, so writing it out as piece planes first (4 B read + 6 B written per element, then 6 B
+// read) costs more than the f32 MFMA it replaces.  Instead the step's fp32 rows themselves ([256][16 channels], 16 KB)
+// arrive in LDS by LDS-DMA next to the weights' piece planes (three stages, one barrier per step, rows past M read as
+// zeros), a lane reads the 32 bytes of its MFMA A fragment (channels 16 c + 8 h .. + 7 of row r) with two
+// ds_read_b128 and splits them into the three bf16 pieces IN REGISTERS (bx.h split_pair, 11 vector instructions per
+// pair, in the shadow of the bf16 MFMAs).  (Register loads for the rows instead — no LDS for A — were slower: mixed
+// with LDS-DMA loads the compiler waits for vmcnt(0) at every use, and the prefetch is lost.)  Tile 256 x BN, 8 wavefronts of 64 x BN/2, direct epilogue (scale, bias,
+// residual, activation) and, for training-mode forward convs, the BN batch statistics of what was stored, in
+// conv_wave.hip's record format [part = M tile][C / 4][count, K, S1, S2][4] (K = the tile's first row).
+template <int BN>
+__global__ __launch_bounds__(512, 2) void conv_pw_bx_kernel(const BxArgs p) {
+  constexpr int A_STAGE = BXC_BM * 64;            // fp32 rows of a step: 256 x 16 channels x 4 B
+  constexpr int B_STAGE = 3 * BN * BXC_ROWB;
+  constexpr int STAGE = A_STAGE + B_STAGE;
+  constexpr int NT = BN / 64;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const sf_conv_desc& d = p.d;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave & 3, wn = wave >> 2;
+  const int bid = xcd_remap(blockIdx.x, p.tiles);
+  const int tile_m = bid / p.nb_n, tile_n = bid - tile_m * p.nb_n;
+  const int m0 = tile_m * BXC_BM, n0 = tile_n * BN;
+  const int nsteps = p.nk;
+
+  // B loader (as conv_bx_kernel): BN = 256: wave w brings rows 32w .. 32w+31; BN = 128: waves 0..3 only
+  const int lrow = lane >> 1;
+  const unsigned lchunk = (unsigned)((lane & 1) ^ ((lrow >> 4) & 1)) * 16u;
+  const bool b_loader = BN == 256 || wave < 4;
+  const int bn = n0 + 32 * wave + lrow;
+  const unsigned kbytes = (unsigned)p.nk * (unsigned)BXC_ROWB;
+  const unsigned b_voff = (unsigned)((b_loader && bn < d.Cout) ? bn : d.Cout) * kbytes + lchunk;
+  const __amdgpu_buffer_rsrc_t b_rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.bp, 0, p.b_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t x_rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.xf, 0, p.xf_bytes, 0x00020000);
+  // A loader: the step's fp32 rows [256][16 channels] as they lie in memory, by LDS-DMA (every load of this kernel is
+  // an LDS-DMA: mixed with register loads the compiler drains the whole queue at every use).  Wave w, piece u brings
+  // rows 32 w + 16 u .. + 15: lane = (row, 16-byte slot); slot s of row r holds source chunk s ^ ((r >> 2) & 3), which
+  // puts the 16 rows a quarter-wave reads (64 B apart) on 16 different 16-byte bank groups.
+  unsigned a_lvoff[2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int r = 32 * wave + 16 * u + (lane >> 2);
+    const int m = m0 + r;
+    const unsigned chunk = (unsigned)((lane & 3) ^ ((r >> 2) & 3));
+    a_lvoff[u] = m < p.M ? ((unsigned)m * (unsigned)d.in_cs + (unsigned)d.in_coff) * 4u + chunk * 16u : 0x80000000u;
+  }
+  auto issue = [&](int step) {
+    char* const st = smem + (step % BXC_STAGES) * STAGE;
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rs, (lds_void*)(st + wave * 2048 + u * 1024), 16, a_lvoff[u],
+                                               (unsigned)step * 64u, 0, 0);
+    if (b_loader) {
+      char* const sb = st + A_STAGE + wave * 1024;
+#pragma unroll
+      for (int g = 0; g < 3; ++g)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(b_rs, (lds_void*)(sb + g * (BN * BXC_ROWB)), 16, b_voff,
+                                                 (unsigned)step * (unsigned)BXC_ROWB + (unsigned)g * p.b_plane, 0, 0);
+    }
+  };
+  // fragment addresses.  A: lane (r = lane & 31, h = lane >> 5) of tile i reads channels 8 h .. 8 h + 7 of row
+  // 64 wm + 32 i + r: source chunks 2 h and 2 h + 1, each at slot chunk ^ ((row >> 2) & 3)
+  unsigned a_frag[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int r = wm * 64 + i * 32 + (lane & 31);
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+      a_frag[i][q] = (unsigned)r * 64u + (unsigned)(((2 * (lane >> 5) + q) ^ ((r >> 2) & 3)) * 16);
+  }
+  const unsigned frag_lane = (unsigned)(lane & 31) * BXC_ROWB + (unsigned)(((lane >> 5) ^ ((lane >> 4) & 1)) * 16);
+  const unsigned b_frag = A_STAGE + (unsigned)(wn * (BN / 2)) * BXC_ROWB + frag_lane;
+
+  f32x16 acc[2][NT];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  if (nsteps > 0) issue(0);
+  if (nsteps > 1) issue(1);
+  for (int it = 0; it < nsteps; ++it) {
+    if (it + 1 < nsteps) {  // this wave's loads of step `it` have landed once at most those of step it + 1 are outstanding
+      if (b_loader) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    if (it + 2 < nsteps) issue(it + 2);
+    const char* const st = smem + (it % BXC_STAGES) * STAGE;
+    u32x4 af[2][3], bf[NT][3];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const f32x4 lo = *reinterpret_cast<const f32x4*>(st + a_frag[i][0]);
+      const f32x4 hi = *reinterpret_cast<const f32x4*>(st + a_frag[i][1]);
+      split_pair(lo[0], lo[1], af[i], 0);
+      split_pair(lo[2], lo[3], af[i], 1);
+      split_pair(hi[0], hi[1], af[i], 2);
+      split_pair(hi[2], hi[3], af[i], 3);
+    }
+#pragma unroll
+    for (int pc = 0; pc < 3; ++pc)
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+        bf[j][pc] = *reinterpret_cast<const u32x4*>(st + b_frag + pc * (BN * BXC_ROWB) + j * (32 * BXC_ROWB));
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) acc[i][j] = mfma_split(af[i], bf[j], acc[i][j]);
+  }
+
+  // ---- epilogue: register e of a lane = column lane & 31, rows (e & 3) + 8 (e >> 2) + 4 (lane >> 5) of its tiles
+  const int col = lane & 31, rsub = 4 * (lane >> 5);
+  const bool want_stats = p.stats != nullptr;
+  float* const kred = reinterpret_cast<float*>(smem);  // [BN] shift values, then [4][BN][2] sums (the B stages are free)
+  if (want_stats) __syncthreads();
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int cl = wn * (BN / 2) + j * 32 + col;  // column within the tile
+    const int n = n0 + cl;
+    const bool n_ok = n < d.Cout;
+    const float sc = (p.scale && n_ok) ? p.scale[n] : 1.f;
+    const float bi = (p.bias && n_ok) ? p.bias[n] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      float r[16];
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int m = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + rsub;
+        r[e] = (p.res && m < p.M && n_ok) ? p.res[(long)m * d.res_cs + d.res_coff + n] : 0.f;
+      }
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int m = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + rsub;
+        const float v = sf_act(acc[i][j][e] * sc + bi + r[e], d.act);
+        acc[i][j][e] = v;
+        if (m < p.M && n_ok) p.out[(long)m * d.out_cs + d.out_coff + n] = v;
+      }
+    }
+    if (want_stats && wm == 0 && rsub == 0) kred[cl] = acc[0][j][0];  // the tile's first row (always a valid row)
+  }
+  if (!want_stats) return;
+  __syncthreads();
+  float* const sred = kred + BN;
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int cl = wn * (BN / 2) + j * 32 + col;
+    const float k0 = kred[cl];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int m = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + rsub;
+        if (m < p.M) {
+          const float dv = acc[i][j][e] - k0;
+          s1 += dv;
+          s2 += dv * dv;
+        }
+      }
+    s1 += __shfl_xor(s1, 32, 64);
+    s2 += __shfl_xor(s2, 32, 64);
+    if (rsub == 0) {
+      sred[(wm * BN + cl) * 2] = s1;
+      sred[(wm * BN + cl) * 2 + 1] = s2;
+    }
+  }
+  __syncthreads();
+  if (tid < BN) {
+    const int n = n0 + tid;
+    if (n < d.Cout) {
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        s1 += sred[(w * BN + tid) * 2];
+        s2 += sred[(w * BN + tid) * 2 + 1];
+      }
+      const int left = p.M - m0;
+      const float cnt = (float)(left < BXC_BM ? left : BXC_BM);
+      float* const o = p.stats + ((long)tile_m * (d.Cout >> 2) + (n >> 2)) * 16 + (n & 3);
+      o[0] = cnt;
+      o[4] = kred[tid];
+      o[8] = s1;
+      o[12] = s2;
+    }
+  }
 }
 
 // ---- weight gradient ---------------------------------------------------------------------------------------------------
@@ -583,6 +780,51 @@ bool bx_plan(const sf_conv_desc* d, BxPlan* pl, bool gate = true) {
   return true;
 }
 
+
+// ---- pointwise plan ---------------------------------------------------------------------------------------------------
+int g_pw_enable = 1;  // sf_conv_tune(21, e): 0 off, 1 where the time model says it wins, 2 every shape it covers
+
+struct PwPlan { int bn, nb_n, tiles, nk; };
+
+bool pw_plan(const sf_conv_desc* d, PwPlan* pl, bool gate = true) {
+  static const int env_on = [] { const char* e = getenv("SF_CONV_PW"); return e ? atoi(e) : 1; }();
+  if (!bx_enabled() || !env_on || !g_pw_enable) return false;
+  if (d->kT != 1 || d->kH != 1 || d->kW != 1 || d->sT != 1 || d->sH != 1 || d->sW != 1 || d->pT || d->pH || d->pW)
+    return false;
+  if (d->To != d->Ti || d->Ho != d->Hi || d->Wo != d->Wi) return false;
+  if (d->os_T > 1 || d->os_H > 1 || d->os_W > 1 || d->out_cmul != 1) return false;
+  if ((d->Cin % 16) || d->cin_pad != d->Cin || (d->in_cs % 4) || (d->in_coff % 4)) return false;
+  if (d->Cin < 64 || d->Cout < 64 || (d->Cout % 4)) return false;
+  const long M = (long)d->N * d->To * d->Ho * d->Wo;
+  if (M < 2048 || M > 0x3fffffffL) return false;
+  if (((M - 1) * d->in_cs + d->in_coff + d->Cin) * 4L >= 0x7fffffffL) return false;
+  pl->nk = d->Cin / BXC_BK;
+  if (3L * (d->Cout + 1) * pl->nk * BXC_ROWB > 0xfffffff0L) return false;
+  pl->bn = d->Cout >= 256 ? 256 : 128;
+  pl->nb_n = sf_cdiv(d->Cout, pl->bn);
+  pl->tiles = sf_cdiv(M, BXC_BM) * pl->nb_n;
+  if (gate && g_pw_enable < 2 && g_bx_enable < 2) {
+    // Measured (tools/microbench/conv_pw_bench.py, hot and cold alike): every workgroup-step moves 16 KB of rows + 24
+    // (12) KB of weight pieces into LDS and the chip delivers ~2.3-3 TB/s of that whatever the shape, so a bottleneck
+    // layer (6.6 GFLOP) takes 55-60 us against 70-85 on the f32 kernels — where the f32 kernels are not HBM-bound
+    // themselves (res2: 200 704 rows), the reduction is not too short to amortise the pipeline (Cin >= 128) and the
+    // tiles fill the chip (res5: 13 row tiles).
+    if (d->Cin < 128 || d->Cout < 128 || M < 8192 || M > 65536) return false;
+  }
+  return true;
+}
+
+template <int BN>
+int launch_pw(const BxArgs& a, int grid, hipStream_t stream) {
+  constexpr int lds = BXC_STAGES * (BXC_BM * 64 + 3 * BN * BXC_ROWB);
+  static_assert(lds >= (BN + 4 * BN * 2) * 4, "the statistics scratch lives in the stages");
+  static SfLdsAttr at;
+  if (!sf_ensure_dyn_lds(at, reinterpret_cast<const void*>(conv_pw_bx_kernel<BN>), lds)) return SF_ELAUNCH;
+  hipLaunchKernelGGL((conv_pw_bx_kernel<BN>), dim3(grid), dim3(512), lds, stream, a);
+  SF_CHECK_LAUNCH();
+  return SF_OK;
+}
+
 long align4(long floats) { return (floats + 3) & ~3L; }
 long a_plane_floats(const sf_conv_desc* d, long a_rows) { return align4((3 * (a_rows + 1) * d->Cin + 1) / 2); }
 long b_plane_floats(const sf_conv_desc* d, int nk) { return align4((3L * (d->Cout + 1) * nk * BXC_BK + 1) / 2); }
@@ -652,6 +894,71 @@ extern "C" int sf_bx_split_batched(const void* items, const int* blk0, int n, in
                      reinterpret_cast<const BxSplitItem*>(items), blk0, n);
   SF_CHECK_LAUNCH();
   return SF_OK;
+}
+
+int sf_conv_pw_tune(int value) { g_pw_enable = value; return SF_OK; }
+
+int sf_conv_pw_takes(const sf_conv_desc* d) {
+  PwPlan pl;
+  return pw_plan(d, &pl) ? 1 : 0;
+}
+
+// Workspace floats of sf_conv_fwd_pw (0: shape not served): the weight planes unless handed in (+ a non-zero token).
+extern "C" long sf_conv_pw_ws_floats(const sf_conv_desc* d, int have_w_planes) {
+  PwPlan pl;
+  if (!d || !pw_plan(d, &pl)) return 0;
+  return 4 + (have_w_planes ? 0 : b_plane_floats(d, pl.nk));
+}
+
+// Floats of the statistics scratch of sf_conv_fwd_pw (one record row per 256-position tile and 4 channels), 0: the shape
+// is not served or leaves no statistics (an epilogue with scale / residual / activation).
+extern "C" long sf_conv_pw_stats_floats(const sf_conv_desc* d) {
+  PwPlan pl;
+  if (!d || d->transposed || d->act != SF_ACT_NONE || !pw_plan(d, &pl)) return 0;
+  const long M = (long)d->N * d->To * d->Ho * d->Wo;
+  return (long)sf_cdiv(M, BXC_BM) * 4 * d->Cout;
+}
+
+// 1 = not taken.  stats != NULL (with parts): BN batch statistics of the stored outputs, *parts = record rows per channel.
+int sf_conv_pw_try(const sf_conv_desc* d, const float* in, const float* w_packed, const unsigned short* w_planes,
+                   const float* scale, const float* bias, const float* res, float* out, float* ws, float* stats,
+                   int* parts, hipStream_t stream) {
+  PwPlan pl;
+  if (parts) *parts = 0;
+  if (!ws || !pw_plan(d, &pl)) return 1;
+  if (!sf_aligned16(in) || !sf_aligned16(w_packed) || !sf_aligned16(ws)) return 1;
+  if (w_planes && !sf_aligned16(w_planes)) return SF_EALIGN;
+  if (stats && (scale || res || d->act != SF_ACT_NONE || !parts || !sf_aligned16(stats))) return 1;
+  const long M = (long)d->N * d->To * d->Ho * d->Wo;
+  if (!w_planes) {
+    unsigned short* const bp = reinterpret_cast<unsigned short*>(ws + 4);
+    const int rc = sf_bx_split_rows(w_packed, pl.nk * BXC_BK, 0, d->Cout, pl.nk * BXC_BK, bp, stream);
+    if (rc != SF_OK) return rc;
+    w_planes = bp;
+  }
+  BxArgs a = {};
+  a.d = *d;
+  a.bp = w_planes;
+  a.scale = scale; a.bias = bias; a.res = res; a.out = out;
+  a.M = (int)M;
+  a.ntaps = 1; a.cpk = pl.nk; a.nk = pl.nk; a.S = 1; a.nk_per = pl.nk; a.nb_n = pl.nb_n; a.tiles = pl.tiles;
+  a.b_plane = (unsigned)((long)(d->Cout + 1) * pl.nk * BXC_ROWB);
+  a.b_bytes = 3u * a.b_plane;
+  a.xf = in;
+  a.xf_bytes = (unsigned)(((M - 1) * d->in_cs + d->in_coff + d->Cin) * 4L);
+  a.stats = stats;
+  if (stats) *parts = (int)sf_cdiv(M, BXC_BM);
+  return pl.bn == 256 ? launch_pw<256>(a, pl.tiles, stream) : launch_pw<128>(a, pl.tiles, stream);
+}
+
+// sf_conv_fwd_ws for the pointwise shapes sf_conv_pw_ws_floats accepts, with the weight planes handed in (or NULL: made
+// in ws) and, optionally, the training-mode BN statistics of the output (stats / parts as sf_conv_fwd_stats).
+extern "C" int sf_conv_fwd_pw(const sf_conv_desc* d, const float* in, const float* w_packed,
+                              const unsigned short* w_planes, const float* scale, const float* bias, const float* res,
+                              float* out, float* ws, float* stats, int* parts, void* stream) {
+  if (!d || !in || !w_packed || !out || !ws) return SF_EINVAL;
+  const int rc = sf_conv_pw_try(d, in, w_packed, w_planes, scale, bias, res, out, ws, stats, parts, (hipStream_t)stream);
+  return rc == 1 ? SF_EINVAL : rc;
 }
 
 // workspace floats of sf_conv_fwd_bx: the planes the call has to make itself + the S partial tiles (0: shape not served)

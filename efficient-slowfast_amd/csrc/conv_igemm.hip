@@ -521,6 +521,11 @@ int sf_conv_splitk_finish(const sf_conv_desc* d, const float* ws, int S, const f
 }
 
 int sf_conv_bx_takes(const sf_conv_desc* d);                                                  // conv_bx.hip
+int sf_conv_pw_takes(const sf_conv_desc* d);                                                  // conv_bx.hip
+extern "C" long sf_conv_pw_ws_floats(const sf_conv_desc* d, int have_w_planes);               // conv_bx.hip
+int sf_conv_pw_try(const sf_conv_desc* d, const float* in, const float* w_packed, const unsigned short* w_planes,
+                   const float* scale, const float* bias, const float* res, float* out, float* ws, float* stats,
+                   int* parts, hipStream_t stream);
 extern "C" long sf_conv_bx_ws_floats(const sf_conv_desc* d, int have_in_planes, int have_w_planes);  // conv_bx.hip
 int sf_conv_bx_try(const sf_conv_desc* d, const float* in, const unsigned short* in_planes, const float* w,
                    const unsigned short* w_planes, const float* scale, const float* bias, const float* res, float* out,
@@ -535,6 +540,7 @@ extern "C" long sf_conv_fwd_ws_floats(const sf_conv_desc* d) {
   if (!d) return 0;
   const long M = (long)d->N * d->To * d->Ho * d->Wo;
   if (M <= 0 || d->Cout <= 0 || d->cin_pad <= 0) return 0;
+  if (sf_conv_pw_takes(d)) return sf_conv_pw_ws_floats(d, 0);     // pointwise layers: the weight planes
   if (sf_conv_bx_takes(d)) return sf_conv_bx_ws_floats(d, 0, 0);  // operand planes + split-K partial tiles
   if (sf_conv_wave_takes(d)) return 0;  // conv_wave.hip splits long reductions inside the workgroup
   const int S = splitk_factor(d, M);
@@ -571,6 +577,11 @@ static int conv_fwd_impl(const sf_conv_desc* d, const float* in, const float* w_
   }
   {  // the tiniest channel counts (8 -> 8 spatial layers of the Fast pathway): LDS-staged input, scalar-register weights, vector FMAs
     const int rc = sf_conv_small_try(d, in, w_packed, scale, bias, res, out, (hipStream_t)stream, stats, stat_parts);
+    if (rc != 1) return rc;
+  }
+  if (ws && !stats) {  // pointwise layers on the bf16 matrix pipe, activations split in registers (conv_bx.hip)
+    const int rc = sf_conv_pw_try(d, in, w_packed, nullptr, scale, bias, res, out, ws, nullptr, nullptr,
+                                  (hipStream_t)stream);
     if (rc != 1) return rc;
   }
   if (ws && !stats) {  // long reductions on the bf16 matrix pipe (fp32-exact operand pieces), conv_bx.hip
@@ -630,6 +641,7 @@ extern "C" int sf_conv_fwd_ws(const sf_conv_desc* d, const float* in, const floa
 // S2] rows per channel it left in stats_ws (0: none were produced — run sf_bn_train_stats on the output instead).
 extern "C" long sf_conv_stats_ws_floats(const sf_conv_desc* d) {
   if (!d || !sf_conv_wave_takes(d) || d->transposed) return 0;
+  if (sf_conv_pw_takes(d)) return 0;  // statistics of these come from sf_conv_fwd_pw (sf_conv_pw_stats_floats)
   if (sf_conv_bx_takes(d)) return 0;  // conv_bx.hip leaves no statistics: the caller's statistics pass runs
   const long M = (long)d->N * d->To * d->Ho * d->Wo;
   return sf_conv_wave_max_parts(M) * 4 * d->Cout;

@@ -55,7 +55,7 @@ EXPORTS = [
     "sf_conv_fwd_ws", "sf_attn_fwd_ws_floats", "sf_attn_fwd_ws", "sf_affine_fwd_mask", "sf_bn_bwd_apply_first", "sf_maxpool_bwd_first",
     "sf_conv_tune", "sf_conv_stats_ws_floats", "sf_conv_fwd_stats", "sf_bn_train_stats_merge",
     "sf_attn_products_per_fp32", "sf_pack_conv_weights", "sf_attn_bwd_variant", "sf_attn_tune",
-    "sf_bx_planes_elems", "sf_bx_split", "sf_bx_split_batched", "sf_conv_bx_ws_floats", "sf_conv_fwd_bx", "sf_conv_wgrad_bx_splits",
+    "sf_bx_planes_elems", "sf_bx_split", "sf_bx_split_batched", "sf_conv_pw_ws_floats", "sf_conv_pw_stats_floats", "sf_conv_fwd_pw", "sf_conv_bx_ws_floats", "sf_conv_fwd_bx", "sf_conv_wgrad_bx_splits",
     "sf_conv_wgrad_bx_ws_floats", "sf_conv_wgrad_bx",
 ]
 _LONG_RET = ("sf_tmax_mean_ws_floats", "sf_channel_stats_ws_floats", "sf_bn_bwd_ws_floats",
@@ -146,6 +146,11 @@ def lib():
         L.sf_bx_planes_elems.restype = cl
         L.sf_bx_split.argtypes = [vp, ci, ci, cl, ci, vp, vp]
         L.sf_bx_split_batched.argtypes = [vp, vp, ci, ci, vp]
+        L.sf_conv_pw_ws_floats.argtypes = [ctypes.POINTER(ConvDesc), ci]
+        L.sf_conv_pw_ws_floats.restype = cl
+        L.sf_conv_pw_stats_floats.argtypes = [ctypes.POINTER(ConvDesc)]
+        L.sf_conv_pw_stats_floats.restype = cl
+        L.sf_conv_fwd_pw.argtypes = [ctypes.POINTER(ConvDesc)] + [vp] * 9 + [ctypes.POINTER(ctypes.c_int), vp]
         L.sf_conv_bx_ws_floats.argtypes = [ctypes.POINTER(ConvDesc), ci, ci]
         L.sf_conv_bx_ws_floats.restype = cl
         L.sf_conv_fwd_bx.argtypes = [ctypes.POINTER(ConvDesc)] + [vp] * 10
@@ -358,6 +363,13 @@ def _conv_launch(d, x_ptr, w_ptr, scale, bias, res_ptr, out_ptr, device, what, w
     call makes are left in keep["x"] for the layer's weight gradient."""
     tag = ("conv", d.N * d.To * d.Ho * d.Wo, d.kT * d.kH * d.kW * d.Cin, d.Cout)
     if SPLIT_K and w_tensor is not None and w_tensor.shape[2] == d.Cin:
+        n = lib().sf_conv_pw_ws_floats(ctypes.byref(d), 1)
+        if n > 0:  # pointwise layers: activations split in registers, only the weight's planes are kept
+            planes = _weight_planes(w_tensor)
+            ws = torch.empty((n,), dtype=torch.float32, device=device)
+            _check(_traced(tag, lambda: lib().sf_conv_fwd_pw(ctypes.byref(d), x_ptr, w_ptr, _ptr(planes), scale, bias,
+                                                             res_ptr, out_ptr, _ptr(ws), None, None, _stream())), what)
+            return
         if in_planes is None and keep is not None and x_act is not None and \
                 lib().sf_conv_bx_ws_floats(ctypes.byref(d), 1, 1) > 0:
             in_planes = keep["x"] = act_planes(x_act)
@@ -499,6 +511,19 @@ def conv(x, wp, kernel, stride=(1, 1, 1), padding=(0, 0, 0), dilation=(1, 1, 1),
                  res.cs if res is not None else 0, res.coff if res is not None else 0, 0)
     if res is not None:
         assert res.rows == out.rows and res.C == cout
+    if stats and CONV_STATS and SPLIT_K and scale is None and res is None and not relu and out_cmul == 1 and \
+            wp.shape[2] == cin:
+        n = lib().sf_conv_pw_stats_floats(ctypes.byref(d))
+        if n > 0:  # pointwise layer on the bf16 pipe, statistics from its epilogue
+            planes = _weight_planes(wp)
+            ws = torch.empty((lib().sf_conv_pw_ws_floats(ctypes.byref(d), 1),), dtype=torch.float32, device=x.buf.device)
+            st = torch.empty((n,), dtype=torch.float32, device=x.buf.device)
+            parts = ctypes.c_int(0)
+            tag = ("conv", d.N * d.To * d.Ho * d.Wo, d.Cin, d.Cout)
+            _check(_traced(tag, lambda: lib().sf_conv_fwd_pw(ctypes.byref(d), x.ptr(), _ptr(wp), _ptr(planes), None,
+                                                             _ptr(bias), None, out.ptr(), _ptr(ws), _ptr(st),
+                                                             ctypes.byref(parts), _stream())), "sf_conv_fwd_pw")
+            return out, ((st, parts.value) if parts.value > 0 else None)
     if stats:
         n = lib().sf_conv_stats_ws_floats(ctypes.byref(d)) if (CONV_STATS and scale is None and res is None
                                                               and not relu and out_cmul == 1) else 0

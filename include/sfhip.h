@@ -119,6 +119,19 @@ int sf_bx_split(const float* x, int cs, int coff, long rows, int C, unsigned sho
  * records {const float* x; uint16_t* planes; int64_t rows; int32_t C; int32_t 0}; blk0[i] = first workgroup of item i
  * (a workgroup = 256 elements of 8 channels over (rows + 1) * C / 8), blk0[n] = nblocks.                           */
 int sf_bx_split_batched(const void* items, const int* blk0, int n, int nblocks, void* stream);
+/* Pointwise layers — 1x1x1 stride-1 convs with >= 64 channels on both sides, forward and (desc.transposed) data
+ * gradient: nn.Conv3d branch2a / branch2c of resnet_helper.py:182-223 — on the bf16 matrix pipe with the ACTIVATIONS
+ * split in registers (no activation planes; conv_bx.hip conv_pw_bx_kernel).  sf_conv_pw_ws_floats: workspace floats
+ * (0: the shape is not served, or the launcher's time model leaves it to the f32 kernels); w_planes = sf_bx_split of the
+ * packed weight ([Cout][Cin]) or NULL (made in ws).  stats != NULL (a buffer of sf_conv_pw_stats_floats(d) floats,
+ * only without scale / res / activation): the training-mode BN statistics of the stored outputs as sf_conv_fwd_stats
+ * leaves them — *parts record rows per channel for sf_bn_train_stats_merge.  sf_conv_fwd_ws routes here by itself
+ * (sf_conv_fwd_ws_floats covers it); sf_conv_tune(21, 0 | 1 | 2) = off / by model / every shape it covers.            */
+long sf_conv_pw_ws_floats(const sf_conv_desc* d, int have_w_planes);
+long sf_conv_pw_stats_floats(const sf_conv_desc* d);
+int sf_conv_fwd_pw(const sf_conv_desc* d, const float* in, const float* w_packed, const unsigned short* w_planes,
+                   const float* scale, const float* bias, const float* res, float* out, float* ws, float* stats,
+                   int* parts, void* stream);
 long sf_conv_bx_ws_floats(const sf_conv_desc* d, int have_in_planes, int have_w_planes);
 int sf_conv_fwd_bx(const sf_conv_desc* d, const float* in, const unsigned short* in_planes, const float* w_packed,
                    const unsigned short* w_planes, const float* scale, const float* bias, const float* res, float* out,

@@ -35,7 +35,7 @@ def tune():
     L = sfhip.lib()
     yield L
     for knob, v in ((0, 1), (1, -1), (2, 0), (3, 0), (4, 1), (5, 0), (6, 1), (7, 1), (8, 0), (9, 1), (10, 1), (11, -1),
-                    (12, 0), (20, 1)):
+                    (12, 0), (20, 1), (21, 1)):
         L.sf_conv_tune(knob, v)
 
 
@@ -314,3 +314,67 @@ def test_small_channel_wgrad_rows_kernel(shape, sliced, tune):
     dwp0 = sfhip.conv_wgrad(xa, dya, cout, k, (1, 1, 1), p)
     assert _rel(sfhip.unpack_conv_weight_grad(dwp0, wt.shape), wd.grad) < 2e-6, name
     assert (s_on, s_off) != (0, 0)
+
+
+# ---- conv_pw_bx_kernel: pointwise layers on the bf16 pipe with the activations split in registers (sf_conv_tune(21, 2)
+# forces it onto every shape it covers).  Ragged row counts (M tiles with rows past M), channel counts that fill a
+# 256- / 128-wide column block partly, K from 4 to 64 steps, a channel-slice input.
+PW_SHAPES = [
+    ("pw_64_256", 64, 256, (3, 2, 23, 21)),
+    ("pw_256_64", 256, 64, (2, 4, 19, 17)),
+    ("pw_128_192", 128, 192, (3, 5, 13, 11)),
+    ("pw_512_320", 512, 320, (3, 4, 14, 14)),
+    ("pw_1024_256", 1024, 256, (3, 4, 14, 13)),
+    ("pw_80_72", 80, 72, (3, 3, 17, 19)),
+]
+
+
+@pytest.mark.parametrize("shape", PW_SHAPES, ids=[s[0] for s in PW_SHAPES])
+def test_pointwise_bf16_piece_conv(shape, tune):
+    """Forward (bias; training-mode statistics from the epilogue; eval epilogue with scale / bias / residual / ReLU),
+    data gradient written and accumulated, all against fp64 at the fp32-level bound of the other bf16-piece kernels;
+    and the launcher's route: sf_conv_pw_ws_floats > 0 exactly when forced on / 0 when switched off."""
+    import ctypes
+    import sfhip
+    name, cin, cout, (n, t, h, w) = shape
+    dev = _dev()
+    k, p1 = (1, 1, 1), (0, 0, 0)
+    g = torch.Generator().manual_seed(cin + 3 * cout)
+    x = torch.randn(n, cin, t, h, w, generator=g).to(dev)
+    wt = (torch.randn(cout, cin, 1, 1, 1, generator=g) / np.sqrt(cin)).to(dev)
+    bias = (torch.randn(cout, generator=g) * 0.1).to(dev)
+    scale = (torch.rand(cout, generator=g) + 0.5).to(dev)
+    res = torch.randn(n, cout, t, h, w, generator=g).to(dev)
+    dy = torch.randn(n, cout, t, h, w, generator=g).to(dev)
+    assert tune.sf_conv_tune(21, 2) == 0
+    wp, wtp = sfhip.pack_conv_weight_pair(wt)
+    xa = _act(x)
+    wide = sfhip.Act(torch.randn(xa.buf.shape[:-1] + (cin + 24,), device=dev), 16, cin)  # slice of a wider buffer
+    wide.buf[..., 16:16 + cin] = xa.buf
+    d = sfhip.ConvDesc(xa.N, xa.T, xa.H, xa.W, cin, xa.cs, xa.coff, xa.T, xa.H, xa.W, cout, cout, 0, 1, 1, 1, 1, 1, 1, 1,
+                       0, 0, 0, 1, 1, 1, cin, 0, 0, 0, 0)
+    assert tune.sf_conv_pw_ws_floats(ctypes.byref(d), 1) > 0
+    ref = F.conv3d(x.double(), wt.double(), bias.double())
+    for a in (xa, wide):
+        z, st = sfhip.conv(a, wp, k, bias=bias, stats=True)
+        assert _rel(_ncthw(z), ref) < BX_TOL, name
+        assert st is not None, "pointwise layers leave their statistics from the epilogue"
+        ones = torch.ones(cout, device=dev)
+        mean, invstd, _, _ = sfhip.bn_train_stats_merge(st, cout, ones, ones, 1e-5, 0.1, None, None)
+        flat = ref.transpose(0, 1).reshape(cout, -1)
+        assert float((mean.double() - flat.mean(1)).abs().max()) < 1e-5 * float(flat.std() + flat.mean(1).abs().max())
+        assert _rel(invstd, torch.rsqrt(flat.var(1, unbiased=False) + 1e-5)) < 1e-4
+    y = sfhip.conv(xa, wp, k, scale=scale, bias=bias, relu=True, res=_act(res))
+    ref2 = torch.relu(F.conv3d(x.double(), wt.double()) * scale.double().view(1, -1, 1, 1, 1) +
+                      bias.double().view(1, -1, 1, 1, 1) + res.double())
+    assert _rel(_ncthw(y), ref2) < BX_TOL, name
+    xd = x.double().requires_grad_(True)
+    F.conv3d(xd, wt.double()).backward(dy.double())
+    dxa = sfhip.conv_dgrad(_act(dy), wtp, xa, k)
+    assert _rel(_ncthw(dxa), xd.grad) < BX_TOL, name
+    sfhip.conv_dgrad(_act(dy), wtp, xa, k, out=dxa, accumulate=True)
+    assert _rel(_ncthw(dxa), 2 * xd.grad) < BX_TOL, name
+    assert tune.sf_conv_tune(21, 0) == 0
+    assert tune.sf_conv_pw_ws_floats(ctypes.byref(d), 1) == 0
+    z0 = sfhip.conv(xa, wp, k, bias=bias)
+    assert _rel(_ncthw(z0), ref) < TOL, name
