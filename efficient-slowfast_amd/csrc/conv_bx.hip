@@ -60,8 +60,12 @@ typedef __attribute__((address_space(3))) void lds_void;
 
 template <int BN, bool DIRECT, int VAR>
 __global__ __launch_bounds__(512, 2) void conv_bx_kernel(const BxArgs p) {
+  // VAR & 32 (AF32): the A operand arrives as the fp32 rows themselves (16 KB per step instead of 24 KB of pieces, and
+  // no activation planes) and is split into its three pieces after the fragment read — conv_pw_bx_kernel's A path.
+  constexpr bool AF32 = (VAR & 32) != 0;
+  constexpr int A_ST = AF32 ? BXC_BM * 64 : BXC_A_STAGE;
   constexpr int B_STAGE = 3 * BN * BXC_ROWB;
-  constexpr int STAGE = BXC_A_STAGE + B_STAGE;
+  constexpr int STAGE = A_ST + B_STAGE;
   constexpr int NT = BN / 64;  // 32-column MFMA tiles per wavefront
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const sf_conv_desc& d = p.d;
@@ -96,6 +100,40 @@ __global__ __launch_bounds__(512, 2) void conv_bx_kernel(const BxArgs p) {
     h0 = d.transposed ? (int)ho + d.pH : (int)ho * d.sH - d.pH;
     w0 = d.transposed ? (int)wo + d.pW : (int)wo * d.sW - d.pW;
   }
+  // AF32 loader: wave w, piece u brings rows 32 w + 16 u + (lane >> 2), 16-byte slot lane & 3 = source chunk
+  // slot ^ ((row >> 2) & 3) (conflict-free fragment reads, see conv_pw_bx_kernel)
+  int f_t0[2], f_h0[2], f_w0[2], f_n[2];
+  bool f_ok[2];
+  unsigned f_chunk[2];
+  if constexpr (AF32) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int r = 32 * wave + 16 * u + (lane >> 2);
+      const int fm = m0 + r;
+      f_ok[u] = fm < p.M;
+      f_chunk[u] = (unsigned)((lane & 3) ^ ((r >> 2) & 3)) * 16u;
+      const unsigned mm = f_ok[u] ? (unsigned)fm : 0u;
+      const unsigned q1 = mdiv(mm, p.wo_mul, p.wo_sh);
+      const unsigned wo = mm - q1 * (unsigned)d.Wo;
+      const unsigned q2 = mdiv(q1, p.ho_mul, p.ho_sh);
+      const unsigned ho = q1 - q2 * (unsigned)d.Ho;
+      const unsigned q3 = mdiv(q2, p.to_mul, p.to_sh);
+      const unsigned to = q2 - q3 * (unsigned)d.To;
+      f_n[u] = (int)q3;
+      f_t0[u] = d.transposed ? (int)to + d.pT : (int)to * d.sT - d.pT;
+      f_h0[u] = d.transposed ? (int)ho + d.pH : (int)ho * d.sH - d.pH;
+      f_w0[u] = d.transposed ? (int)wo + d.pW : (int)wo * d.sW - d.pW;
+    }
+  }
+  auto f_voff = [&](int u, int kt, int kh, int kw) -> unsigned {  // byte offset of the row's chunk in the fp32 tensor
+    const int ti = d.transposed ? f_t0[u] - kt * d.dT : f_t0[u] + kt * d.dT;
+    const int hi = d.transposed ? f_h0[u] - kh * d.dH : f_h0[u] + kh * d.dH;
+    const int wi = d.transposed ? f_w0[u] - kw * d.dW : f_w0[u] + kw * d.dW;
+    const bool ok = f_ok[u] && (unsigned)ti < (unsigned)d.Ti && (unsigned)hi < (unsigned)d.Hi && (unsigned)wi < (unsigned)d.Wi;
+    if (!ok) return 0x80000000u;  // past the buffer: the DMA writes zeros
+    const unsigned r = (unsigned)(((f_n[u] * d.Ti + ti) * d.Hi + hi) * d.Wi + wi);
+    return (r * (unsigned)d.in_cs + (unsigned)d.in_coff) * 4u + f_chunk[u];
+  };
   const unsigned row_bytes = (unsigned)d.Cin * 2u;
   auto a_voff = [&](int kt, int kh, int kw) -> unsigned {  // byte offset of this lane's row for a tap (or the zero row)
     const int ti = d.transposed ? t0 - kt * d.dT : t0 + kt * d.dT;
@@ -113,6 +151,7 @@ __global__ __launch_bounds__(512, 2) void conv_bx_kernel(const BxArgs p) {
 
   const __amdgpu_buffer_rsrc_t a_rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.ap, 0, p.a_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t b_rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.bp, 0, p.b_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t x_rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.xf, 0, AF32 ? p.xf_bytes : 0u, 0x00020000);
 
   // ---- K iteration state of the loader (runs two steps ahead of the MFMAs).  K order: 16-channel chunk OUTER, tap
   // INNER — consecutive steps read the same input rows shifted by one tap, so a workgroup's share of the K steps
@@ -124,19 +163,31 @@ __global__ __launch_bounds__(512, 2) void conv_bx_kernel(const BxArgs p) {
   int l_kw = l_tap % d.kW, l_kh = (l_tap / d.kW) % d.kH, l_kt = l_tap / (d.kW * d.kH);
   // one step's loads = 6 LDS-DMA pieces per wave (3 A planes, 3 B planes): `piece(stage, g)` issues piece g of the
   // loader's current step, `advance()` moves the loader to the next step
-  unsigned cur_voff = 0, cur_aso = 0, cur_bso = 0;
+  unsigned cur_voff = 0, cur_aso = 0, cur_bso = 0, cur_f[2] = {0, 0};
   auto prepare = [&]() {
-    cur_voff = a_voff(l_kt, l_kh, l_kw);
-    cur_aso = (unsigned)l_c * (unsigned)BXC_ROWB;
+    if constexpr (AF32) {
+      cur_f[0] = f_voff(0, l_kt, l_kh, l_kw);
+      cur_f[1] = f_voff(1, l_kt, l_kh, l_kw);
+      cur_aso = (unsigned)l_c * 64u;
+    } else {
+      cur_voff = a_voff(l_kt, l_kh, l_kw);
+      cur_aso = (unsigned)l_c * (unsigned)BXC_ROWB;
+    }
     cur_bso = (unsigned)(l_tap * p.cpk + l_c) * (unsigned)BXC_ROWB;
   };
   auto piece = [&](int stage, int g) {
     if (g < 3) {
-      char* const sa = smem + stage * STAGE + wave * 1024;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rs, (lds_void*)(sa + g * (BXC_BM * BXC_ROWB)), 16, cur_voff,
-                                               cur_aso + (unsigned)g * p.a_plane, 0, 0);
+      if constexpr (AF32) {
+        if (g < 2)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rs, (lds_void*)(smem + stage * STAGE + wave * 2048 + g * 1024), 16,
+                                                   cur_f[g], cur_aso, 0, 0);
+      } else {
+        char* const sa = smem + stage * STAGE + wave * 1024;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rs, (lds_void*)(sa + g * (BXC_BM * BXC_ROWB)), 16, cur_voff,
+                                                 cur_aso + (unsigned)g * p.a_plane, 0, 0);
+      }
     } else if (b_loader) {
-      char* const sb = smem + stage * STAGE + BXC_A_STAGE + wave * 1024;
+      char* const sb = smem + stage * STAGE + A_ST + wave * 1024;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(b_rs, (lds_void*)(sb + (g - 3) * (BN * BXC_ROWB)), 16, b_voff,
                                                cur_bso + (unsigned)(g - 3) * p.b_plane, 0, 0);
     }
@@ -172,7 +223,16 @@ __global__ __launch_bounds__(512, 2) void conv_bx_kernel(const BxArgs p) {
   // ---- fragment addresses: lane (r = lane & 31, h = lane >> 5) reads 16 bytes of row r, k = 8h .. 8h+7
   const unsigned frag_lane = (unsigned)(lane & 31) * BXC_ROWB + (unsigned)(((lane >> 5) ^ ((lane >> 4) & 1)) * 16);
   const unsigned a_frag = (unsigned)(wm * 64) * BXC_ROWB + frag_lane;
-  const unsigned b_frag = BXC_A_STAGE + (unsigned)(wn * (BN / 2)) * BXC_ROWB + frag_lane;
+  const unsigned b_frag = A_ST + (unsigned)(wn * (BN / 2)) * BXC_ROWB + frag_lane;
+  unsigned f_frag[2][2] = {{0, 0}, {0, 0}};
+  if constexpr (AF32) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int r = wm * 64 + i * 32 + (lane & 31);
+#pragma unroll
+      for (int q = 0; q < 2; ++q) f_frag[i][q] = (unsigned)r * 64u + (unsigned)(((2 * (lane >> 5) + q) ^ ((r >> 2) & 3)) * 16);
+    }
+  }
 
   f32x16 acc[2][NT];
 #pragma unroll
@@ -187,8 +247,13 @@ __global__ __launch_bounds__(512, 2) void conv_bx_kernel(const BxArgs p) {
   for (int it = 0; it < nsteps; ++it) {
     // this wave's loads of step `it` have landed once at most the loads of step it + 1 are outstanding
     if (it + 1 < nsteps) {
-      if (b_loader) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+      if constexpr (AF32) {
+        if (b_loader) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+      } else {
+        if (b_loader) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+      }
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
@@ -196,11 +261,24 @@ __global__ __launch_bounds__(512, 2) void conv_bx_kernel(const BxArgs p) {
     if (!(VAR & 16) && it + 2 < nsteps) issue((it + 2) % BXC_STAGES);
     const char* const st = smem + (it % BXC_STAGES) * STAGE;
     u32x4 af[2][3], bf[NT][3];
+    if constexpr (AF32) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const f32x4 lo = *reinterpret_cast<const f32x4*>(st + f_frag[i][0]);
+        const f32x4 hi = *reinterpret_cast<const f32x4*>(st + f_frag[i][1]);
+        split_pair(lo[0], lo[1], af[i], 0);
+        split_pair(lo[2], lo[3], af[i], 1);
+        split_pair(hi[0], hi[1], af[i], 2);
+        split_pair(hi[2], hi[3], af[i], 3);
+      }
+    }
 #pragma unroll
     for (int pc = 0; pc < 3; ++pc) {
+      if constexpr (!AF32) {
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
-        af[i][pc] = *reinterpret_cast<const u32x4*>(st + a_frag + pc * (BXC_BM * BXC_ROWB) + i * (32 * BXC_ROWB));
+        for (int i = 0; i < 2; ++i)
+          af[i][pc] = *reinterpret_cast<const u32x4*>(st + a_frag + pc * (BXC_BM * BXC_ROWB) + i * (32 * BXC_ROWB));
+      }
 #pragma unroll
       for (int j = 0; j < NT; ++j)
         bf[j][pc] = *reinterpret_cast<const u32x4*>(st + b_frag + pc * (BN * BXC_ROWB) + j * (32 * BXC_ROWB));
@@ -728,6 +806,8 @@ struct BxPlan { int bn, S, nk, nk_per, nb_n, tiles, direct; long a_rows; };
 // Which shapes run here: long reductions (>= 32 K steps = 512 channel-taps) into >= 128 output channels over >= 2048
 // positions — the 1x3x3 / 3x1x1 layers of res3..res5 and the 1x1x1 layers over >= 512 channels.  `gate`: also apply
 // the measured win / lose rule (tools/microbench/conv_bx_bench.py); the shape rules alone decide what the kernel CAN run.
+bool bx_af32(const sf_conv_desc* d);
+
 bool bx_plan(const sf_conv_desc* d, BxPlan* pl, bool gate = true) {
   if (!bx_enabled()) return false;
   const long M = (long)d->N * d->To * d->Ho * d->Wo;
@@ -774,7 +854,8 @@ bool bx_plan(const sf_conv_desc* d, BxPlan* pl, bool gate = true) {
     // against conv_wave.hip at ~100 TFLOP/s (x 0.9 for the short reductions) plus this path's activation split
     const double flop = 2.0 * M * (double)nk * BXC_BK * d->Cout;
     const double wave_us = flop / (nk >= 64 ? 100e6 : 90e6);
-    const double split_us = 4.0 + (double)a_rows * d->Cin * 10e-6 / 3.0;  // 10 B per element at ~3 TB/s
+    // (plane-fed mode only: fp32-row launches have no activation split)
+    const double split_us = bx_af32(d) ? 0.0 : 4.0 + (double)a_rows * d->Cin * 10e-6 / 3.0;  // 10 B per element at ~3 TB/s
     if (best_t + split_us > 0.93 * wave_us) return false;
   }
   return true;
@@ -825,13 +906,21 @@ int launch_pw(const BxArgs& a, int grid, hipStream_t stream) {
   return SF_OK;
 }
 
+// SF_CONV_BX_AF32 (default 1): forward / data-gradient launches take their activation operand as fp32 rows (no planes)
+bool bx_af32(const sf_conv_desc* d) {
+  static const int on = [] { const char* e = getenv("SF_CONV_BX_AF32"); return e ? atoi(e) : 1; }();
+  if (!on) return false;
+  const long rows = (long)d->N * d->Ti * d->Hi * d->Wi;
+  return ((rows - 1) * d->in_cs + d->in_coff + d->Cin) * 4L < 0x7fffffffL;
+}
+
 long align4(long floats) { return (floats + 3) & ~3L; }
 long a_plane_floats(const sf_conv_desc* d, long a_rows) { return align4((3 * (a_rows + 1) * d->Cin + 1) / 2); }
 long b_plane_floats(const sf_conv_desc* d, int nk) { return align4((3L * (d->Cout + 1) * nk * BXC_BK + 1) / 2); }
 
 template <int BN, bool DIRECT, int VAR>
 int launch_bx_v(const BxArgs& a, int grid, hipStream_t stream) {
-  constexpr int lds = BXC_STAGES * (BXC_A_STAGE + 3 * BN * BXC_ROWB);
+  constexpr int lds = BXC_STAGES * (((VAR & 32) ? BXC_BM * 64 : BXC_A_STAGE) + 3 * BN * BXC_ROWB);
   static SfLdsAttr at;
   if (!sf_ensure_dyn_lds(at, reinterpret_cast<const void*>(conv_bx_kernel<BN, DIRECT, VAR>), lds)) return SF_ELAUNCH;
   hipLaunchKernelGGL((conv_bx_kernel<BN, DIRECT, VAR>), dim3(grid), dim3(512), lds, stream, a);
@@ -847,6 +936,7 @@ int launch_bx(const BxArgs& a, int grid, hipStream_t stream) {
   // operand pieces arrive in LDS, not by the matrix pipe.  Tried without gain: the loads behind the fragment reads,
   // s_setprio around the MFMAs, one LDS-DMA piece per MFMA group instead of a burst behind the barrier, tap-major K order.
   static const int var = [] { const char* e = getenv("SF_CONV_BX_VAR"); return e ? atoi(e) : 0; }();
+  if (a.xf) return launch_bx_v<BN, DIRECT, 32>(a, grid, stream);  // fp32 rows, split after the fragment read
   switch (var) {
     case 4: return launch_bx_v<BN, DIRECT, 4>(a, grid, stream);
     case 12: return launch_bx_v<BN, DIRECT, 12>(a, grid, stream);
@@ -966,8 +1056,8 @@ extern "C" long sf_conv_bx_ws_floats(const sf_conv_desc* d, int have_in_planes, 
   BxPlan pl;
   if (!d || !bx_plan(d, &pl)) return 0;
   const long M = (long)d->N * d->To * d->Ho * d->Wo;
-  return 4 + (have_in_planes ? 0 : a_plane_floats(d, pl.a_rows)) + (have_w_planes ? 0 : b_plane_floats(d, pl.nk)) +
-         (pl.direct ? 0 : (long)pl.S * M * d->Cout);
+  return 4 + ((have_in_planes || bx_af32(d)) ? 0 : a_plane_floats(d, pl.a_rows)) +
+         (have_w_planes ? 0 : b_plane_floats(d, pl.nk)) + (pl.direct ? 0 : (long)pl.S * M * d->Cout);
 }
 
 int sf_conv_splitk_finish(const sf_conv_desc* d, const float* ws, int S, const float* scale, const float* bias,
@@ -985,7 +1075,8 @@ int sf_conv_bx_try(const sf_conv_desc* d, const float* in, const unsigned short*
   const long M = (long)d->N * d->To * d->Ho * d->Wo;
   float* cur = ws;
   int rc = SF_OK;
-  if (!in_planes) {
+  const bool af32 = bx_af32(d);
+  if (!in_planes && !af32) {
     unsigned short* const ap = reinterpret_cast<unsigned short*>(cur);
     cur += a_plane_floats(d, pl.a_rows);
     if (!(g_bx_dbg & 1)) rc = sf_bx_split_rows(in, d->in_cs, d->in_coff, pl.a_rows, d->Cin, ap, stream);
@@ -999,9 +1090,13 @@ int sf_conv_bx_try(const sf_conv_desc* d, const float* in, const unsigned short*
     if (rc != SF_OK) return rc;
     w_planes = bp;
   }
-  BxArgs a;
+  BxArgs a = {};
   a.d = *d;
   a.ap = in_planes; a.bp = w_planes; a.ws = cur;
+  if (af32) {
+    a.xf = in;
+    a.xf_bytes = (unsigned)(((pl.a_rows - 1) * d->in_cs + d->in_coff + d->Cin) * 4L);
+  }
   a.scale = scale; a.bias = bias; a.res = res; a.out = out;
   a.M = (int)M;
   a.ntaps = d->kT * d->kH * d->kW;

@@ -370,7 +370,7 @@ def _conv_launch(d, x_ptr, w_ptr, scale, bias, res_ptr, out_ptr, device, what, w
             _check(_traced(tag, lambda: lib().sf_conv_fwd_pw(ctypes.byref(d), x_ptr, w_ptr, _ptr(planes), scale, bias,
                                                              res_ptr, out_ptr, _ptr(ws), None, None, _stream())), what)
             return
-        if in_planes is None and keep is not None and x_act is not None and \
+        if in_planes is None and keep is not None and x_act is not None and not BX_AF32 and \
                 lib().sf_conv_bx_ws_floats(ctypes.byref(d), 1, 1) > 0:
             in_planes = keep["x"] = act_planes(x_act)
         n = lib().sf_conv_bx_ws_floats(ctypes.byref(d), 1 if in_planes is not None else 0, 1)
@@ -791,10 +791,19 @@ def _conv_dgrad_strided(dz, wt_packed, out, kernel, stride, padding, accumulate,
 
 
 # ------------------------------------------------------------------------------------------------ backward
+# SF_CONV_BX_AF32 (default 1, read by conv_bx.hip too): forward / data-gradient launches of conv_bx.hip take their
+# activation operand as fp32 rows and split it after the LDS fragment read — no activation planes on those paths; the
+# weight gradient (whose transposing LDS reads need 16-bit elements) makes the planes of x and dz itself, inside its
+# own launch sequence on the companion stream.  0: planes made once per tensor on the pathway's stream and shared.
+BX_AF32 = os.environ.get("SF_CONV_BX_AF32", "1") != "0"
+
+
 def bx_backward_wants_dz_planes(x, dz, cout, kernel, stride, padding, dilation, cin=None, cin_pad=None,
                                 dgrad=True):
-    """True when the layer's weight gradient or (stride-1) data gradient runs on conv_bx.hip: the caller then makes
-    dz's planes ONCE (act_planes) and hands them to both."""
+    """True when the layer's weight gradient or (stride-1) data gradient runs on conv_bx.hip AND takes planes from the
+    caller (SF_CONV_BX_AF32=0): the caller then makes dz's planes ONCE (act_planes) and hands them to both."""
+    if BX_AF32:
+        return False
     cin = x.C if cin is None else cin
     cin_pad = (cin + 15) // 16 * 16 if cin_pad is None else cin_pad
     if cin_pad != cin or not SPLIT_K:

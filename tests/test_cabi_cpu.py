@@ -104,29 +104,21 @@ def test_launch_planning_queries_are_host_only_and_fill_the_chip():
     wg = 9 * S
     assert 512 <= wg <= 1024 and wg / (-(-wg // 256) * 256) >= 0.94, (S, wg)
     assert L.sf_conv_fwd_ws_floats(ctypes.byref(d)) == 0                       # 1568 tiles: no split-K
-    # res4 3x1x1 1024->256 at M = 12544 (K = 3072) on the bf16-piece kernel (conv_bx.hip, forced: sf_conv_tune(7, 2)) —
-    # 49 tiles of 256 x 256 share their K steps between S workgroups that together fill the chip; workspace = the
-    # activation planes [3][rows + 1][1024] bf16 (+ the weight planes unless handed in) + S partial tiles.  The
-    # launcher's time model (cold-operand fit) leaves THIS layer to the per-wavefront kernel, which splits K inside the
-    # workgroup (no workspace), and takes res5a's 3x1x1 1152 -> 512 at the same M; the LDS-tiled fallback
-    # (sf_conv_tune(0, 0)): 196 tiles, 192 K steps -> split-K with a [S][M][Cout] workspace
+    # res4 3x1x1 1024->256 at M = 12544 (K = 3072) on the bf16-piece kernel (conv_bx.hip): 49 tiles of 256 x 256 share
+    # their K steps between S workgroups that together fill the chip.  Default mode (SF_CONV_BX_AF32=1): the activation
+    # operand travels as fp32 rows, so the workspace = the weight planes (unless handed in) + S partial tiles — no
+    # activation planes whether or not the caller has them.  sf_conv_tune(7, 0): the per-wavefront kernel splits K inside
+    # the workgroup (no workspace); the LDS-tiled fallback (sf_conv_tune(0, 0)): 196 tiles, 192 K steps -> split-K with a
+    # [S][M][Cout] workspace.  res3's 1x3x3 128 -> 128 (196 tiles of 256 x 128 = 0.77 of a round) stays on conv_wave
     d4 = _conv_desc(8, 8, 14, 14, 1024, 256, (3, 1, 1))
-    d5a = _conv_desc(8, 8, 14, 14, 1152, 512, (3, 1, 1))
-    a_planes = -(-(3 * (12544 + 1) * 1024 // 2) // 4) * 4
     w_planes = -(-(3 * (256 + 1) * 3072 // 2) // 4) * 4
-    assert L.sf_conv_bx_ws_floats(ctypes.byref(d4), 0, 1) == 0 and L.sf_conv_fwd_ws_floats(ctypes.byref(d4)) == 0
-    assert L.sf_conv_bx_ws_floats(ctypes.byref(d5a), 0, 1) > 0
-    assert L.sf_conv_fwd_ws_floats(ctypes.byref(d5a)) > L.sf_conv_bx_ws_floats(ctypes.byref(d5a), 0, 1)
-    assert L.sf_conv_tune(7, 2) == 0
-    try:
-        n_bx = L.sf_conv_bx_ws_floats(ctypes.byref(d4), 0, 1)
-        S = (n_bx - 4 - a_planes) // (12544 * 256)
-        assert n_bx == 4 + a_planes + S * 12544 * 256 and 200 <= 49 * S <= 256, (n_bx, S)
-        assert L.sf_conv_bx_ws_floats(ctypes.byref(d4), 0, 0) == n_bx + w_planes
-        assert L.sf_conv_bx_ws_floats(ctypes.byref(d4), 1, 1) == n_bx - a_planes
-        assert L.sf_conv_fwd_ws_floats(ctypes.byref(d4)) == n_bx + w_planes
-    finally:
-        L.sf_conv_tune(7, 1)
+    n_bx = L.sf_conv_bx_ws_floats(ctypes.byref(d4), 0, 1)
+    S = (n_bx - 4) // (12544 * 256)
+    assert n_bx == 4 + S * 12544 * 256 and 200 <= 49 * S <= 256, (n_bx, S)
+    assert L.sf_conv_bx_ws_floats(ctypes.byref(d4), 1, 1) == n_bx          # fp32 rows: no activation planes either way
+    assert L.sf_conv_bx_ws_floats(ctypes.byref(d4), 0, 0) == n_bx + w_planes
+    assert L.sf_conv_fwd_ws_floats(ctypes.byref(d4)) == n_bx + w_planes
+    assert L.sf_conv_bx_ws_floats(ctypes.byref(_conv_desc(8, 8, 28, 28, 128, 128, (1, 3, 3))), 1, 1) == 0
     assert L.sf_bx_planes_elems(12544, 1024) == 3 * 12545 * 1024
     assert L.sf_conv_bx_ws_floats(ctypes.byref(d), 0, 0) == 0                  # res2 3x3 64 -> 64: not a bx shape
     assert L.sf_conv_tune(7, 0) == 0

@@ -235,7 +235,7 @@ def test_bf16_piece_conv_forward_dgrad_wgrad(shape, tune):
         sc = torch.rand(cout, device=dev) + 0.5
         keep = {}
         y = sfhip.conv(xa, wp, k, s, p, dl, scale=sc, bias=bias, relu=True, res=_act(res), keep=keep)
-        assert "x" in keep
+        assert sfhip.BX_AF32 or name.startswith("plain") or "x" in keep  # planes are kept only in the plane-fed mode
         ref2 = F.relu(F.conv3d(x.double(), wt.double(), None, s, p, dl) * sc.double().view(1, -1, 1, 1, 1) +
                       bias.double().view(1, -1, 1, 1, 1) + res.double())
         assert _rel(_ncthw(y), ref2) < BX_TOL, name
@@ -249,7 +249,7 @@ def test_bf16_piece_conv_forward_dgrad_wgrad(shape, tune):
         assert _rel(_ncthw(dxa), xd.grad) < BX_TOL, name
         sfhip.conv_dgrad(dya, wtp, xa, k, s, p, dl, out=dxa, accumulate=True)     # planes made inside this time
         assert _rel(_ncthw(dxa), 2 * xd.grad) < BX_TOL, name
-        dwp = sfhip.conv_wgrad(xa, dya, cout, k, s, p, dl, x_planes=keep["x"], dz_planes=zp)
+        dwp = sfhip.conv_wgrad(xa, dya, cout, k, s, p, dl, x_planes=keep.get("x"), dz_planes=zp)
         assert _rel(sfhip.unpack_conv_weight_grad(dwp, wt.shape), wd.grad) < BX_TOL, name
         acc = torch.ones_like(wt)
         sfhip.conv_wgrad(xa, dya, cout, k, s, p, dl, finish_into=(acc, cin, 0))  # planes made inside
