@@ -1,7 +1,6 @@
 # round 4 evidence set -> gpurun_out/final_r4 (copy what is to be judged into profiles/ as r04_*).
 # gpurun -- bash tools/final_profiles_r4.sh
 cd /tmp && export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/final_r4; mkdir -p $O
-cd $R; timeout 1800 python -m pytest tests -m gpu -q > $O/pytest_gpu.log 2>&1; tail -3 $O/pytest_gpu.log
 cd /tmp
 timeout 500 rocprofv3 --kernel-trace --stats -d $O/default --output-format csv -- python3 $R/bench.py --no-cpu-baseline > $O/default.log 2>&1
 cp $(find $O/default -name "*kernel_stats.csv" | head -1) $O/bench_default_kernel_stats.csv; rm -rf $O/default
@@ -17,6 +16,7 @@ timeout 400 python tools/prof_convs.py dual > $O/conv_per_shape.txt 2>&1
 timeout 300 python tools/microbench/conv_bx_bench.py > $O/conv_bx_ab.txt 2>&1
 timeout 300 python tools/microbench/wgrad_bx_bench.py > $O/wgrad_bx_ab.txt 2>&1
 (echo "conv_wgrad_rows.hip + flat finish (default)"; timeout 200 python tools/microbench/wgrad_small_bench.py; echo; echo "SF_WGRAD_ROWS=0 (conv_wgrad_small_kernel)"; SF_WGRAD_ROWS=0 timeout 200 python tools/microbench/wgrad_small_bench.py) 2>&1 | grep -v "amdgpu.ids" > $O/wgrad_small_ab.txt
+timeout 300 python tools/microbench/conv_pw_bench.py > $O/conv_pw_ab.txt 2>&1
 timeout 600 python tools/whatif_skip.py > $O/whatif_skip.txt 2>&1
 timeout 300 python tools/host_lead.py > $O/host_lead.txt 2>&1
 timeout 700 python bench.py > $O/bench_dual.json 2> $O/bench_dual.err
