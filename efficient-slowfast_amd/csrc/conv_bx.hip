@@ -890,7 +890,11 @@ bool pw_plan(const sf_conv_desc* d, PwPlan* pl, bool gate = true) {
     // layer (6.6 GFLOP) takes 55-60 us against 70-85 on the f32 kernels — where the f32 kernels are not HBM-bound
     // themselves (res2: 200 704 rows), the reduction is not too short to amortise the pipeline (Cin >= 128) and the
     // tiles fill the chip (res5: 13 row tiles).
-    if (d->Cin < 128 || d->Cout < 128 || M < 8192 || M > 65536) return false;
+    // In the training step (profiles/r04_conv_per_shape.txt before / after): 512 -> 128 at 50 176 rows 77 -> 58 us,
+    // 256 -> 1024 at 12 544 rows 72 -> 68 us; a reduction of 8 steps (Cin = 128) does not amortise the pipeline and
+    // the statistics epilogue (83 -> 97 us), and 49 tiles (1024 -> 256 at 12 544 rows) leave 4/5 of the chip idle
+    // (66 -> 141 us): at least 16 K steps and 150 tiles.
+    if (d->Cin < 256 || d->Cout < 128 || M < 8192 || M > 65536 || pl->tiles < 150) return false;
   }
   return true;
 }
