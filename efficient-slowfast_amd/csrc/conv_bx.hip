@@ -856,7 +856,10 @@ bool bx_plan(const sf_conv_desc* d, BxPlan* pl, bool gate = true) {
     const double wave_us = flop / (nk >= 64 ? 100e6 : 90e6);
     // (plane-fed mode only: fp32-row launches have no activation split)
     const double split_us = bx_af32(d) ? 0.0 : 4.0 + (double)a_rows * d->Cin * 10e-6 / 3.0;  // 10 B per element at ~3 TB/s
-    if (best_t + split_us > 0.93 * wave_us) return false;
+    // column blocks that are partly padding cost as much as full ones (576 outputs = 2.25 blocks of 256: the 3x1x1
+    // data gradient 256 -> 576 ran 0.46 ms here against 0.35 on conv_wave)
+    const double pad = (double)(pl->nb_n * pl->bn) / (double)d->Cout;
+    if (best_t * pad + split_us > 0.93 * wave_us) return false;
   }
   return true;
 }
