@@ -360,8 +360,11 @@ __global__ __launch_bounds__(512, 2) void conv_bx_kernel(const BxArgs p) {
 // with LDS-DMA loads the compiler waits for vmcnt(0) at every use, and the prefetch is lost.)  Tile 256 x BN, 8 wavefronts of 64 x BN/2, direct epilogue (scale, bias,
 // residual, activation) and, for training-mode forward convs, the BN batch statistics of what was stored, in
 // conv_wave.hip's record format [part = M tile][C / 4][count, K, S1, S2][4] (K = the tile's first row).
-template <int BN>
-__global__ __launch_bounds__(512, 2) void conv_pw_bx_kernel(const BxArgs p) {
+// ST = 3: three LDS stages, one workgroup per CU (two wavefronts per SIMD).  ST = 2 (BN = 128 only, <= 128 registers):
+// two stages = 56 KB, so TWO workgroups share a CU — four wavefronts per SIMD, and while one workgroup sits in its
+// barrier / load-issue / fragment-read phase the other one's MFMAs keep the matrix pipe busy.
+template <int BN, int ST>
+__global__ __launch_bounds__(512, ST == 2 ? 4 : 2) void conv_pw_bx_kernel(const BxArgs p) {
   constexpr int A_STAGE = BXC_BM * 64;            // fp32 rows of a step: 256 x 16 channels x 4 B
   constexpr int B_STAGE = 3 * BN * BXC_ROWB;
   constexpr int STAGE = A_STAGE + B_STAGE;
@@ -398,7 +401,7 @@ __global__ __launch_bounds__(512, 2) void conv_pw_bx_kernel(const BxArgs p) {
     a_lvoff[u] = m < p.M ? ((unsigned)m * (unsigned)d.in_cs + (unsigned)d.in_coff) * 4u + chunk * 16u : 0x80000000u;
   }
   auto issue = [&](int step) {
-    char* const st = smem + (step % BXC_STAGES) * STAGE;
+    char* const st = smem + (step % ST) * STAGE;
 #pragma unroll
     for (int u = 0; u < 2; ++u)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rs, (lds_void*)(st + wave * 2048 + u * 1024), 16, a_lvoff[u],
@@ -433,17 +436,17 @@ __global__ __launch_bounds__(512, 2) void conv_pw_bx_kernel(const BxArgs p) {
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
   if (nsteps > 0) issue(0);
-  if (nsteps > 1) issue(1);
+  if (ST == 3 && nsteps > 1) issue(1);
   for (int it = 0; it < nsteps; ++it) {
-    if (it + 1 < nsteps) {  // this wave's loads of step `it` have landed once at most those of step it + 1 are outstanding
+    if (ST == 3 && it + 1 < nsteps) {  // this wave's loads of step `it` have landed once at most those of step it + 1 are outstanding
       if (b_loader) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __builtin_amdgcn_s_barrier();
-    if (it + 2 < nsteps) issue(it + 2);
-    const char* const st = smem + (it % BXC_STAGES) * STAGE;
+    if (it + ST - 1 < nsteps) issue(it + ST - 1);
+    const char* const st = smem + (it % ST) * STAGE;
     u32x4 af[2][3], bf[NT][3];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -884,7 +887,9 @@ bool pw_plan(const sf_conv_desc* d, PwPlan* pl, bool gate = true) {
   if (((M - 1) * d->in_cs + d->in_coff + d->Cin) * 4L >= 0x7fffffffL) return false;
   pl->nk = d->Cin / BXC_BK;
   if (3L * (d->Cout + 1) * pl->nk * BXC_ROWB > 0xfffffff0L) return false;
-  pl->bn = d->Cout >= 256 ? 256 : 128;
+  // 256 x 128 tiles on two LDS stages, two workgroups per CU (SF_PW_WIDE=1: 256 x 256 on three stages, one per CU)
+  static const int wide = [] { const char* e = getenv("SF_PW_WIDE"); return e ? atoi(e) : 0; }();
+  pl->bn = (d->Cout >= 256 && wide) ? 256 : 128;
   pl->nb_n = sf_cdiv(d->Cout, pl->bn);
   pl->tiles = sf_cdiv(M, BXC_BM) * pl->nb_n;
   if (gate && g_pw_enable < 2 && g_bx_enable < 2) {
@@ -893,22 +898,28 @@ bool pw_plan(const sf_conv_desc* d, PwPlan* pl, bool gate = true) {
     // layer (6.6 GFLOP) takes 55-60 us against 70-85 on the f32 kernels — where the f32 kernels are not HBM-bound
     // themselves (res2: 200 704 rows), the reduction is not too short to amortise the pipeline (Cin >= 128) and the
     // tiles fill the chip (res5: 13 row tiles).
-    // In the training step (profiles/r04_conv_per_shape.txt before / after): 512 -> 128 at 50 176 rows 77 -> 58 us,
-    // 256 -> 1024 at 12 544 rows 72 -> 68 us; a reduction of 8 steps (Cin = 128) does not amortise the pipeline and
-    // the statistics epilogue (83 -> 97 us), and 49 tiles (1024 -> 256 at 12 544 rows) leave 4/5 of the chip idle
-    // (66 -> 141 us): at least 16 K steps and 150 tiles.
-    if (d->Cin < 256 || d->Cout < 128 || M < 8192 || M > 65536 || pl->tiles < 150) return false;
+    // Time model (us) fitted on the training step's per-shape table (tools/prof_convs.py, two workgroups per CU): a
+    // resident set of up to 256 tiles advances one K step in ~1.5 us (a workgroup's step is a DMA round trip on two
+    // stages — there is no split-K here, so few tiles with a long reduction lose: 1024 -> 256 at 12 544 rows, 98
+    // tiles x 64 steps, 66 -> 88 us), never faster than its operands at ~4.5 TB/s; the f32 kernels run these layers
+    // at ~95 TFLOP/s with half of their HBM time beside it.  64-wide outputs fill half a column block: left out.
+    if (d->Cout < 128) return false;
+    const double mb = (double)M * (d->Cin + d->Cout) * 4e-6;
+    double t_pw = 6.0 + (double)sf_cdiv(pl->tiles, 256) * pl->nk * 1.5;
+    if (t_pw < mb / 4.5) t_pw = mb / 4.5;
+    const double t_f32 = 6.0 + 2.0 * M * (double)d->Cin * d->Cout / 95e6 + 0.5 * mb / 4.5;
+    if (t_pw > 0.85 * t_f32) return false;
   }
   return true;
 }
 
-template <int BN>
+template <int BN, int ST>
 int launch_pw(const BxArgs& a, int grid, hipStream_t stream) {
-  constexpr int lds = BXC_STAGES * (BXC_BM * 64 + 3 * BN * BXC_ROWB);
+  constexpr int lds = ST * (BXC_BM * 64 + 3 * BN * BXC_ROWB);
   static_assert(lds >= (BN + 4 * BN * 2) * 4, "the statistics scratch lives in the stages");
   static SfLdsAttr at;
-  if (!sf_ensure_dyn_lds(at, reinterpret_cast<const void*>(conv_pw_bx_kernel<BN>), lds)) return SF_ELAUNCH;
-  hipLaunchKernelGGL((conv_pw_bx_kernel<BN>), dim3(grid), dim3(512), lds, stream, a);
+  if (!sf_ensure_dyn_lds(at, reinterpret_cast<const void*>(conv_pw_bx_kernel<BN, ST>), lds)) return SF_ELAUNCH;
+  hipLaunchKernelGGL((conv_pw_bx_kernel<BN, ST>), dim3(grid), dim3(512), lds, stream, a);
   SF_CHECK_LAUNCH();
   return SF_OK;
 }
@@ -1045,7 +1056,8 @@ int sf_conv_pw_try(const sf_conv_desc* d, const float* in, const float* w_packed
   a.xf_bytes = (unsigned)(((M - 1) * d->in_cs + d->in_coff + d->Cin) * 4L);
   a.stats = stats;
   if (stats) *parts = (int)sf_cdiv(M, BXC_BM);
-  return pl.bn == 256 ? launch_pw<256>(a, pl.tiles, stream) : launch_pw<128>(a, pl.tiles, stream);
+  if (pl.bn == 256) return launch_pw<256, 3>(a, pl.tiles, stream);
+  return launch_pw<128, 2>(a, pl.tiles, stream);
 }
 
 // sf_conv_fwd_ws for the pointwise shapes sf_conv_pw_ws_floats accepts, with the weight planes handed in (or NULL: made

@@ -134,16 +134,19 @@ def test_launch_planning_queries_are_host_only_and_fill_the_chip():
         L.sf_conv_tune(7, 1)
     assert n > 0 and n % (12544 * 256) == 0 and 2 <= n // (12544 * 256) <= 12
     # pointwise layers (conv_pw_bx_kernel): res4's 256 -> 1024 at M = 12 544 goes to the bf16 pipe with ONLY the weight
-    # planes as workspace (the rows are split in registers) and leaves its BN statistics itself, one record row per
-    # 256-position tile; res2's 64 -> 256 at 200 704 rows (HBM-bound on the f32 kernels already) and res5's 13 row tiles
-    # stay where they were; sf_conv_tune(21, 0) switches the path off
+    # planes as workspace (the rows are split after the LDS read) and leaves its BN statistics itself, one record row
+    # per 256-position tile; 64-wide outputs (res2's 256 -> 64) and few tiles under a long reduction (the data gradient
+    # 1024 -> 256 at 12 544 rows: 98 tiles x 64 steps, no split-K) stay on the f32 kernels; sf_conv_tune(21, 0) = off
     dp = _conv_desc(8, 8, 14, 14, 256, 1024, (1, 1, 1))
     wpl = -(-(3 * (1024 + 1) * 256 // 2) // 4) * 4
     assert L.sf_conv_pw_ws_floats(ctypes.byref(dp), 1) == 4 and L.sf_conv_pw_ws_floats(ctypes.byref(dp), 0) == 4 + wpl
     assert L.sf_conv_fwd_ws_floats(ctypes.byref(dp)) == 4 + wpl
     assert L.sf_conv_pw_stats_floats(ctypes.byref(dp)) == 49 * 4 * 1024 and L.sf_conv_stats_ws_floats(ctypes.byref(dp)) == 0
-    assert L.sf_conv_pw_ws_floats(ctypes.byref(_conv_desc(8, 8, 56, 56, 64, 256, (1, 1, 1))), 1) == 0
-    assert L.sf_conv_pw_ws_floats(ctypes.byref(_conv_desc(8, 8, 7, 7, 512, 2048, (1, 1, 1))), 1) == 0
+    assert L.sf_conv_pw_ws_floats(ctypes.byref(_conv_desc(8, 8, 56, 56, 256, 64, (1, 1, 1))), 1) == 0
+    dt = _conv_desc(8, 8, 14, 14, 1024, 256, (1, 1, 1))
+    dt.transposed = 1
+    assert L.sf_conv_pw_ws_floats(ctypes.byref(dt), 1) == 0
+    assert L.sf_conv_pw_ws_floats(ctypes.byref(_conv_desc(8, 8, 56, 56, 64, 256, (1, 1, 1))), 1) == 4
     assert L.sf_conv_tune(21, 0) == 0
     try:
         assert L.sf_conv_pw_ws_floats(ctypes.byref(dp), 1) == 0 and L.sf_conv_stats_ws_floats(ctypes.byref(dp)) > 0
