@@ -751,9 +751,18 @@ def main():
                                  "the HIP forward's ReLU masks / max-pool winners (tests/_masks.py); gradients that are zero " \
                                  "in exact arithmetic (tests/_zero_grads.py) are bounded absolutely: bwd_zero_class_*; " \
                                  "8-clip parity: tests/test_fullsize_gpu.py (eval rows vs 8 oracle forwards, 3-clip train step)"
-        print(json.dumps(res))
     if dist.is_initialized():
         dist.destroy_process_group()
+    if rank == 0:
+        # the JSON line is the LAST line of stdout: RCCL's version banner sits in C stdio's buffer since the group was
+        # created and would otherwise be flushed behind it at exit (stdout redirected to a file or a pipe)
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except OSError:
+            pass
+        sys.stdout.flush()
+        print(json.dumps(res), flush=True)
 
 
 if __name__ == "__main__":
