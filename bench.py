@@ -200,6 +200,46 @@ def cpu_baseline(workload, cfg, model, train, device=None, hip_train_step=None):
              "sample": "oracle (torch CPU restatement of the reference), same model / clip shape: " + sample}, parity)
 
 
+def make_train_step(model, clips, labels, overlap_allreduce=True, lr=1e-3):
+    """The benchmark's training step (the reference loop: tools/train_net.py:78-96) as a closure over resident clips:
+    zero the flat gradient buffer, train-mode forward, cross-entropy, backward through the tape (parameter gradients
+    accumulated by the kernels straight into the flat buffer), ONE all-reduce of that buffer, torch.optim.SGD step.
+    Returns (step, flat, opt); step() returns the loss tensor.  tests/test_graph_train_gpu.py replays exactly this
+    closure from a hipGraph against its eager form."""
+    from slowfast.models import engine
+    from slowfast.utils.distributed import FlatGradients
+    model.train()
+    flat = FlatGradients(model.parameters())
+    engine.set_grad_sink(os.environ.get("SF_NO_GRAD_SINK") != "1")  # backward kernels accumulate straight into the flat gradient buffer
+    if overlap_allreduce:
+        # res5 + head, then res4 (+ s4_fuse): 85 % of the gradient bytes, final ~10 ms into the backward pass —
+        # their all-reduce runs on its own stream under the rest of the backward; the remainder after it
+        flat.overlap_with_backward(model, boundaries=("s5", "s4"))
+    # torch's SGD (the reference: models/optimizer.py:53-60 torch.optim.SGD with momentum + weight decay); fused=True is
+    # torch's single multi-tensor kernel per step instead of its four foreach passes (SF_SGD_FUSED=0: the foreach form)
+    sgd = dict(lr=lr, momentum=0.9, weight_decay=1e-4)
+    opt = None
+    if os.environ.get("SF_SGD_FUSED", "1") != "0":
+        try:
+            opt = torch.optim.SGD(model.parameters(), fused=True, **sgd)
+        except (TypeError, RuntimeError):
+            opt = None
+    if opt is None:
+        opt = torch.optim.SGD(model.parameters(), **sgd)  # torch's default: the foreach implementation
+
+    def step():
+        flat.zero()
+        logits = model([clips[0], clips[1]])
+        loss = torch.nn.functional.cross_entropy(logits, labels)
+        loss.backward()
+        flat.all_reduce_mean()      # ONE collective per step over RCCL / xGMI (no-op at world 1)
+        opt.step()
+        flat.rebind()
+        return loss
+
+    return step, flat, opt
+
+
 def _free_port():
     import socket
     s = socket.socket()
@@ -378,45 +418,47 @@ def main():
     side = torch.cuda.Stream(priority=int(os.environ.get("SF_PRIO_MAIN", "0")))
 
     if train:
-        model.train()
-        flat = FlatGradients(model.parameters())
-        from slowfast.models import engine
-        engine.set_grad_sink(os.environ.get("SF_NO_GRAD_SINK") != "1")  # backward kernels accumulate straight into the flat gradient buffer
-        if not args.no_overlap_allreduce:
-            # res5 + head, then res4 (+ s4_fuse): 85 % of the gradient bytes, final ~10 ms into the backward pass —
-            # their all-reduce runs on its own stream under the rest of the backward; the remainder after it
-            flat.overlap_with_backward(model, boundaries=("s5", "s4"))
-        # torch's SGD (the reference: models/optimizer.py:53-60 torch.optim.SGD with momentum + weight decay); fused=True is
-        # torch's single multi-tensor kernel per step instead of its four foreach passes (SF_SGD_FUSED=0: the foreach form)
-        sgd = dict(lr=1e-3, momentum=0.9, weight_decay=1e-4)
-        opt = None
-        if os.environ.get("SF_SGD_FUSED", "1") != "0":
-            try:
-                opt = torch.optim.SGD(model.parameters(), fused=True, **sgd)
-            except (TypeError, RuntimeError):
-                opt = None
-        if opt is None:
-            opt = torch.optim.SGD(model.parameters(), **sgd)  # torch's default: the foreach implementation
-
-        def step():
-            flat.zero()
-            logits = model([clips[0], clips[1]])
-            loss = torch.nn.functional.cross_entropy(logits, labels)
-            loss.backward()
-            flat.all_reduce_mean()      # ONE collective per step over RCCL / xGMI (no-op at world 1)
-            opt.step()
-            flat.rebind()
-            return loss
+        step, flat, opt = make_train_step(model, clips, labels, overlap_allreduce=not args.no_overlap_allreduce)
     else:
         def step():
             with torch.no_grad():
                 return model([clips[0], clips[1]])
 
-    # ---- warm-up (also builds the packed-weight / folded-BN caches), optional hipGraph capture (eval)
+    # ---- warm-up (also builds the packed-weight / folded-BN caches): the W steps asked for, then on to a STEADY state
+    #      whatever W was — groups of 4 steps until two successive groups agree within 2 % (at most 40 more steps).  As
+    #      the first GPU process of a fresh box the first 2-3 s of steps carry one-off host stalls (runtime pools
+    #      growing, code objects loading, allocator growth: tools/cold_start.py), and round 4's driver run (--warmup 5)
+    #      decided the launch form on exactly those steps.  Nothing here is timed for the result.
     with torch.cuda.stream(side):
         for _ in range(max(args.warmup, 1)):
             out = step()
     torch.cuda.synchronize()
+
+    def ms_per(fn, n):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        with torch.cuda.stream(side):
+            for _ in range(n):
+                fn()
+        t_issue = time.perf_counter() - t0
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n * 1e3, t_issue / n * 1e3
+
+    def settle(fn, cap=40, group=4, tol=0.02):
+        """run fn in groups until two successive groups take the same time within tol; -> (ms, issue ms, steps run)"""
+        prev, n = None, 0
+        while True:
+            cur = ms_per(fn, group)
+            n += group
+            if prev is not None and abs(cur[0] - prev[0]) <= tol * min(cur[0], prev[0]):
+                return min(cur, prev), n
+            if n >= cap:
+                return cur, n
+            prev = cur
+
+    (eager_ms, issue_ms), settle_steps = settle(step)
+    launch_probe = {"steady_state_steps": settle_steps, "eager_ms": round(eager_ms, 3),
+                    "host_issue_ms": round(issue_ms, 3)}
     graph = None
     graph_note = None
 
@@ -433,55 +475,49 @@ def main():
         torch.cuda.synchronize()
         return g, o
 
-    def ms_per(fn, n):
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        with torch.cuda.stream(side):
-            for _ in range(n):
-                fn()
-        t_issue = time.perf_counter() - t0
-        torch.cuda.synchronize()
-        return (time.perf_counter() - t0) / n * 1e3, t_issue / n * 1e3
-
     want_graph = (not train and not args.no_graph) or (train and args.graph_train)
-    auto = None
+    auto = False
     if train and not args.graph_train and not args.no_graph and world == 1 and not dist.is_initialized():
         # Launch-bound training steps (cfg #1: ~1500 launches of a 0.007 GMAC model): when the Python thread needs as
-        # long to ISSUE a step as the GPU needs to run it, the step is captured into one hipGraph and the faster of
-        # the two forms is timed.  For cfg #2 / #3 the host is 2x ahead (34 of 68 ms) and nothing is captured: their
-        # graph replays slower than the eager streams.  Not with a process group up: the step then holds
-        # RCCL collectives on a comm stream, which stay eager.
-        eager_ms, issue_ms = ms_per(step, 6)
+        # long to ISSUE a warm step as the GPU needs to run it, the step is also captured into one hipGraph, BOTH forms
+        # are timed warm, and the faster one is what the timed region runs.  For cfg #2 / #3 the warm host is 1.4-2x
+        # ahead and nothing is captured.  Not with a process group up: the step then holds RCCL collectives on a comm
+        # stream, which stay eager.
         if issue_ms > 0.85 * eager_ms:
-            want_graph = True
-            auto = {"eager_ms": round(eager_ms, 3), "host_issue_ms": round(issue_ms, 3)}
+            want_graph = auto = True
     if want_graph:
         # eval forward: one hipGraph.  The train step (forward, backward with the tape's streams as graph branches,
         # SGD) also captures (the capture runs right after an optimizer step, so every conv's weight re-packing is part
         # of the graph).
         try:
             graph, out = capture()
-            if auto is not None:
-                graph_ms, _ = ms_per(graph.replay, 6)
-                auto["graph_ms"] = round(graph_ms, 3)
-                if graph_ms >= auto["eager_ms"]:
+            if auto:
+                (graph_ms, _), _n = settle(graph.replay, cap=24)
+                launch_probe["graph_ms"] = round(graph_ms, 3)
+                # torch.cuda.graph() emptied the allocator's cache before capturing: the first eager steps after it
+                # re-allocate every block of the step (measured: 82 ms per step over the next 20 instead of 59) — the
+                # eager form is warmed up again and RE-TIMED before the two warm figures are compared
+                (eager_ms, issue_ms), _n = settle(step, cap=24)
+                launch_probe["eager_ms_after_capture"] = round(eager_ms, 3)
+                launch_probe["host_issue_ms_after_capture"] = round(issue_ms, 3)
+                if graph_ms >= min(eager_ms, launch_probe["eager_ms"]):
                     graph = None  # drops the graph and its private memory pool
-                    graph_note = "eager (host-bound, but the hipGraph replay was not faster: %s)" % json.dumps(auto)
-                    # torch.cuda.graph() emptied the allocator's cache before capturing: the first eager steps after it
-                    # re-allocate every block of the step (measured: 82 ms per step over the next 20 instead of 59) —
-                    # warm the eager path up again before anything is timed
-                    torch.cuda.synchronize()
-                    with torch.cuda.stream(side):
-                        for _ in range(3):
-                            out = step()
-                    torch.cuda.synchronize()
+                    graph_note = "eager (host-bound, but the warm hipGraph replay was not faster)"
+                    settle(step, cap=12)
+                launch_probe["timed"] = "eager" if graph is None else "hipGraph replay"
         except Exception as e:  # noqa: BLE001 — fall back to eager launches and say so in the JSON line
             graph, graph_note = None, "hipGraph capture failed (%s: %s); eager launches" % (type(e).__name__, str(e)[:120])
             torch.cuda.synchronize()
-            with torch.cuda.stream(side):
-                out = step()
-            torch.cuda.synchronize()
+            settle(step, cap=12)
+    if graph is None:
+        with torch.cuda.stream(side):
+            out = step()  # the tensor the finiteness check reads belongs to the form that is timed
+        torch.cuda.synchronize()
+    else:
+        graph.replay()  # `out` is the capture's static output: rewritten by every replay
+        torch.cuda.synchronize()
     assert bool(torch.isfinite(out).all()), "non-finite model output"
+    launch_probe.setdefault("timed", "eager" if graph is None else "hipGraph replay")
 
     def barrier():
         if dist.is_initialized():
@@ -510,6 +546,10 @@ def main():
     elapsed = time.perf_counter() - t0
     barrier()
     elapsed = max_over_ranks(elapsed, device)
+    # the LAST timed step's own result (eager: the tensor it returned; replay: the capture's static output, which every
+    # replay rewrites): train = the loss, eval = the probabilities
+    assert bool(torch.isfinite(out).all()), "non-finite result in the timed region"
+    last_loss = float(out) if train else None
 
     # ---- secondary: eval-mode forward (inference) clips/s of the same model, hipGraph replay
     eval_fwd = None
@@ -596,7 +636,8 @@ def main():
                                            "backward, dQ/dK/dV in one sweep)"}[kind]
                 traffic, traffic_src = None, None  # HBM bytes per launch: rocprofv3 PMC passes cannot run inside bench.py
                 try:
-                    tfile = next(f for f in ("r03b_attention_hbm_traffic.json", "r03_attention_hbm_traffic.json",
+                    tfile = next(f for f in ("r05_attention_hbm_traffic.json", "r04_attention_hbm_traffic.json",
+                                             "r03b_attention_hbm_traffic.json", "r03_attention_hbm_traffic.json",
                                              "r02b_attention_hbm_traffic.json")
                                  if os.path.exists(os.path.join(ROOT, "profiles", f)))
                     tj = json.load(open(os.path.join(ROOT, "profiles", tfile)))["kernels"]
@@ -679,8 +720,9 @@ def main():
                                      "v_mfma_f32_32x32x16_bf16 per fp32 product (fp32-level results: DESIGN 6a-4, 6a-5)"
                        if sfhip.lib().sf_attn_products_per_fp32(32) == 6 else "fp32 (v_mfma_f32_*_f32)",
                        "launch": (graph_note or "eager") if graph is None else (
-                           "hipGraph replay" if auto is None else
-                           "hipGraph replay (chosen at warm-up: the eager step is host-bound, %s)" % json.dumps(auto)),
+                           "hipGraph replay" if not auto else
+                           "hipGraph replay (the warm eager step is host-bound and the warm replay is faster)"),
+                       "launch_probe": launch_probe,
                        "parallelism": "dp%d (clip-sharded replicas; %s)" % (
                            world, "one RCCL all-reduce of the flat fp32 gradient per step" if train
                            else "no data-path collective in forward")},
@@ -702,6 +744,8 @@ def main():
             res["roofline"] = roofline
             res["kernel_family_ms_per_step"] = family_ms
         res["n_ranks_seen"] = n_ranks_seen
+        if last_loss is not None:
+            res["last_timed_step_loss"] = round(last_loss, 6)
         if affinity is not None:
             res["rank0_cpu_affinity"] = affinity
         if train:

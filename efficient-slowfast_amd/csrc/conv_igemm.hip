@@ -598,7 +598,11 @@ static int conv_fwd_impl(const sf_conv_desc* d, const float* in, const float* w_
   a.M = (int)M;
   a.ntaps = d->kT * d->kH * d->kW;
   a.nb_n = 0; a.nblocks = 0; a.vec_epi = 0;
-  a.ksplit = ws ? splitk_factor(d, M) : 1;
+  // split-K partial tiles need S * M * Cout floats of workspace: sf_conv_fwd_ws_floats sizes it for that ONLY for shapes
+  // none of the pw / bx / wave paths takes by shape.  A shape they take by shape but refused at run time (an operand
+  // pointer that is not 16-byte aligned) arrives here with a workspace sized for weight planes: one pass, no partials.
+  const bool ws_is_for_splitk = ws && !sf_conv_pw_takes(d) && !sf_conv_bx_takes(d) && !sf_conv_wave_takes(d);
+  a.ksplit = ws_is_for_splitk ? splitk_factor(d, M) : 1;
   a.ws = ws;
   const bool vec4 = (d->Cin % 4 == 0) && (d->in_cs % 4 == 0) && (d->in_coff % 4 == 0) && sf_aligned16(in);
   a.vec_epi = (d->out_cmul == 1) && (d->Cout % 4 == 0) && (d->out_cs % 4 == 0) && (d->out_coff % 4 == 0) &&

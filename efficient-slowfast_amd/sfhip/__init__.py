@@ -22,6 +22,7 @@ ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_SOFTMAX, ACT_HSIGMOID, ACT_RELU6 = 0, 1, 2,
 def _act(relu):
     """relu: False/True (ReLU) or 6 (ReLU6)."""
     return ACT_RELU6 if relu == 6 else (ACT_RELU if relu else ACT_NONE)
+SF_EINVAL, SF_EALIGN, SF_ELAUNCH = -1, -2, -3
 _ERR = {-1: "SF_EINVAL (inconsistent descriptor)", -2: "SF_EALIGN", -3: "SF_ELAUNCH (hip launch failed)"}
 
 
@@ -343,9 +344,16 @@ def _weight_planes(wp):
     """Planes of a packed conv weight [Cout][taps][cin_pad], cached ON the tensor object (pack_conv_weight_pairs
     refreshes them when it overwrites the packed weight in place)."""
     pl = wp.__dict__.get("_sf_bx")
-    if pl is None:
-        pl = bx_planes(wp, wp.shape[0], wp.shape[1] * wp.shape[2])
+    # torch's version counter of the packed tensor: the library's own in-place re-pack (a raw kernel launch) does not
+    # move it and refreshes the planes itself; any OTHER in-place write (wp.copy_(...)) does, and the planes are re-made
+    if pl is None or wp.__dict__.get("_sf_bx_ver") != wp._version:
+        if pl is None:
+            pl = bx_planes(wp, wp.shape[0], wp.shape[1] * wp.shape[2])
+        else:  # same storage: pack_conv_weight_pairs' device-side tables keep pointing at it
+            _check(lib().sf_bx_split(_ptr(wp), wp.shape[1] * wp.shape[2], 0, wp.shape[0], wp.shape[1] * wp.shape[2],
+                                     _ptr(pl), _stream()), "sf_bx_split")
         wp.__dict__["_sf_bx"] = pl
+        wp.__dict__["_sf_bx_ver"] = wp._version
     return pl
 
 
@@ -367,9 +375,11 @@ def _conv_launch(d, x_ptr, w_ptr, scale, bias, res_ptr, out_ptr, device, what, w
         if n > 0:  # pointwise layers: activations split in registers, only the weight's planes are kept
             planes = _weight_planes(w_tensor)
             ws = torch.empty((n,), dtype=torch.float32, device=device)
-            _check(_traced(tag, lambda: lib().sf_conv_fwd_pw(ctypes.byref(d), x_ptr, w_ptr, _ptr(planes), scale, bias,
-                                                             res_ptr, out_ptr, _ptr(ws), None, None, _stream())), what)
-            return
+            rc = _traced(tag, lambda: lib().sf_conv_fwd_pw(ctypes.byref(d), x_ptr, w_ptr, _ptr(planes), scale, bias,
+                                                           res_ptr, out_ptr, _ptr(ws), None, None, _stream()))
+            if rc not in (SF_EALIGN, SF_EINVAL):  # those two: refused before any launch -> the f32 kernels below
+                _check(rc, what)
+                return
         if in_planes is None and keep is not None and x_act is not None and not BX_AF32 and \
                 lib().sf_conv_bx_ws_floats(ctypes.byref(d), 1, 1) > 0:
             in_planes = keep["x"] = act_planes(x_act)
@@ -377,10 +387,12 @@ def _conv_launch(d, x_ptr, w_ptr, scale, bias, res_ptr, out_ptr, device, what, w
         if n > 0:
             planes = _weight_planes(w_tensor)
             ws = torch.empty((n,), dtype=torch.float32, device=device)
-            _check(_traced(tag, lambda: lib().sf_conv_fwd_bx(ctypes.byref(d), x_ptr, _ptr(in_planes), w_ptr,
-                                                             _ptr(planes), scale, bias, res_ptr, out_ptr, _ptr(ws),
-                                                             _stream())), what)
-            return
+            rc = _traced(tag, lambda: lib().sf_conv_fwd_bx(ctypes.byref(d), x_ptr, _ptr(in_planes), w_ptr,
+                                                           _ptr(planes), scale, bias, res_ptr, out_ptr, _ptr(ws),
+                                                           _stream()))
+            if rc not in (SF_EALIGN, SF_EINVAL):
+                _check(rc, what)
+                return
     n = lib().sf_conv_fwd_ws_floats(ctypes.byref(d)) if SPLIT_K else 0
     if n > 0:
         ws = torch.empty((n,), dtype=torch.float32, device=device)
@@ -840,10 +852,14 @@ def conv_wgrad(x, dz, cout, kernel, stride=(1, 1, 1), padding=(0, 0, 0), dilatio
         S = lib().sf_conv_wgrad_bx_splits(ctypes.byref(d))
         part = torch.empty((S, cout, kT * kH * kW, cin_pad), dtype=torch.float32, device=x.buf.device)
         ws = torch.empty((nws,), dtype=torch.float32, device=x.buf.device)
-        _check(_traced(("conv", dz.rows, kT * kH * kW * cin, cout), lambda: lib().sf_conv_wgrad_bx(
+        rc = _traced(("conv", dz.rows, kT * kH * kW * cin, cout), lambda: lib().sf_conv_wgrad_bx(
             ctypes.byref(d), x.ptr(), _ptr(x_planes), dz.ptr(), dz.cs, dz.coff, _ptr(dz_planes), _ptr(part), _ptr(ws),
-            _stream())), "sf_conv_wgrad_bx")
-    else:
+            _stream()))
+        if rc in (SF_EALIGN, SF_EINVAL):  # a dz view the shape-only plan cannot see (odd channel offset / pitch)
+            nws = 0
+        else:
+            _check(rc, "sf_conv_wgrad_bx")
+    if nws <= 0:
         S = lib().sf_conv_wgrad_splits(ctypes.byref(d))
         part = torch.empty((S, cout, kT * kH * kW, cin_pad), dtype=torch.float32, device=x.buf.device)
         _check(_traced(("conv", dz.rows, kT * kH * kW * cin, cout), lambda: lib().sf_conv_wgrad(

@@ -378,3 +378,46 @@ def test_pointwise_bf16_piece_conv(shape, tune):
     assert tune.sf_conv_pw_ws_floats(ctypes.byref(d), 1) == 0
     z0 = sfhip.conv(xa, wp, k, bias=bias)
     assert _rel(_ncthw(z0), ref) < TOL, name
+
+
+# ---- the C-ABI's own workspace rule with operands the bf16-piece paths refuse at run time (round-4 advisor finding):
+# sf_conv_fwd_ws_floats sizes the workspace from the SHAPE (weight planes for pointwise layers, planes + partial tiles
+# for the long-reduction kernel); an input that is not 16-byte aligned is refused by those paths at run time and the
+# call falls through to the generic implicit GEMM, which must then not run split-K into a workspace sized for planes.
+@pytest.mark.parametrize("shape", [
+    ("pw_256_1024", 256, 1024, (1, 1, 1), (0, 0, 0), (1, 2, 7, 7)),       # pointwise layer: ws = weight planes only
+    ("bx_512_512_s3", 512, 512, (1, 3, 3), (0, 1, 1), (2, 8, 14, 14)),    # long reduction: ws = planes + partial tiles
+], ids=["pw", "bx"])
+def test_cabi_workspace_rule_with_misaligned_input(shape, tune):
+    import ctypes
+    import sfhip
+    name, cin, cout, k, p, (n, t, h, w) = shape
+    dev = _dev()
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(n, t, h, w, cin, generator=g).to(dev)
+    wt = (torch.randn(cout, cin, *k, generator=g) / np.sqrt(cin * k[0] * k[1] * k[2])).to(dev)
+    wp, _ = sfhip.pack_conv_weight_pair(wt)
+    tune.sf_conv_tune(7, 2)   # every shape the bf16-piece kernels cover: the sizing rule answers for them
+    tune.sf_conv_tune(21, 2)
+    d = sfhip.ConvDesc(n, t, h, w, cin, cin, 0, t, h, w, cout, cout, 0, 1, k[0], k[1], k[2], 1, 1, 1, p[0], p[1], p[2],
+                       1, 1, 1, cin, 0, 0, 0, 0)
+    nws = tune.sf_conv_fwd_ws_floats(ctypes.byref(d))
+    assert nws > 0
+    CANARY = 4096
+    ws = torch.full((nws + CANARY,), 7.25, device=dev)
+    # the same rows 4 bytes further: x.data_ptr() + 4 is not 16-byte aligned
+    shifted = torch.empty(x.numel() + 1, device=dev)
+    shifted[1:] = x.reshape(-1)
+    out = torch.empty(n, t, h, w, cout, device=dev)
+    rc = tune.sf_conv_fwd_ws(ctypes.byref(d), ctypes.c_void_p(shifted.data_ptr() + 4), ctypes.c_void_p(wp.data_ptr()),
+                             None, None, None, ctypes.c_void_p(out.data_ptr()), ctypes.c_void_p(ws.data_ptr()),
+                             ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    assert rc == 0, rc
+    assert bool((ws[nws:] == 7.25).all()), "write past the workspace the header's sizing rule asked for"
+    ref = F.conv3d(x.permute(0, 4, 1, 2, 3).double(), wt.double(), None, 1, p)
+    assert _rel(out.permute(0, 4, 1, 2, 3), ref) < TOL
+    # and through the Python binding: the run-time refusal falls back to the f32 kernels instead of raising
+    xa = sfhip.Act(shifted[1:].view(n, t, h, w, cin))
+    z = sfhip.conv(xa, wp, k, (1, 1, 1), p)
+    assert _rel(_ncthw(z), ref) < TOL
