@@ -376,8 +376,32 @@ def _cached_t(tensor, slot, key, make):
     return c[1]
 
 
+# Everything derived from parameters (packed conv weights and their bf16 planes, folded BN affines, q/k/v stacks, ...)
+# is cached per (address, torch version counter) of its sources.  torch's FUSED optimizers (torch.optim.SGD / Adam
+# with fused=True: one multi-tensor kernel, torch._fused_sgd_) update the parameters WITHOUT moving their version
+# counters, so the counter alone would leave every cache on the pre-update weights — silently: the step still runs,
+# on frozen packed weights (found by tests/test_graph_train_gpu.py in round 5: the replayed graph, whose re-pack is a
+# captured launch, disagreed with eager steps that skipped it).  Every optimizer step of the process therefore bumps
+# an epoch that is part of every cache key (a global post-step hook: fires for any torch.optim.Optimizer, fused or
+# not); code that writes parameters through raw pointers calls parameters_changed() itself.
+_PARAM_EPOCH = 0
+
+
+def parameters_changed(*_unused):
+    """Invalidate every parameter-derived cache of the HIP path (packed weights, folded BN, ...)."""
+    global _PARAM_EPOCH
+    _PARAM_EPOCH += 1
+
+
+try:
+    from torch.optim.optimizer import register_optimizer_step_post_hook as _register_step_hook
+    _STEP_HOOK = _register_step_hook(lambda optimizer, args, kwargs: parameters_changed())
+except ImportError:  # pragma: no cover — torch without global optimizer hooks
+    _STEP_HOOK = None
+
+
 def _key(*tensors):
-    return tuple((t.data_ptr(), t._version) for t in tensors if t is not None)
+    return (_PARAM_EPOCH,) + tuple((t.data_ptr(), t._version) for t in tensors if t is not None)
 
 
 def _cached(mod, slot, key, make):

@@ -385,7 +385,7 @@ def test_pointwise_bf16_piece_conv(shape, tune):
 # for the long-reduction kernel); an input that is not 16-byte aligned is refused by those paths at run time and the
 # call falls through to the generic implicit GEMM, which must then not run split-K into a workspace sized for planes.
 @pytest.mark.parametrize("shape", [
-    ("pw_256_1024", 256, 1024, (1, 1, 1), (0, 0, 0), (1, 2, 7, 7)),       # pointwise layer: ws = weight planes only
+    ("pw_256_1024", 256, 1024, (1, 1, 1), (0, 0, 0), (2, 4, 16, 17)),     # pointwise layer: ws = weight planes only
     ("bx_512_512_s3", 512, 512, (1, 3, 3), (0, 1, 1), (2, 8, 14, 14)),    # long reduction: ws = planes + partial tiles
 ], ids=["pw", "bx"])
 def test_cabi_workspace_rule_with_misaligned_input(shape, tune):

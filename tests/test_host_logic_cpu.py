@@ -125,3 +125,32 @@ def test_fresh_init_is_bit_identical_to_the_reference(name):
            if hashlib.sha256(v.detach().cpu().contiguous().numpy().tobytes()).hexdigest()[:16] != ref[k]]
     assert not bad, bad[:8]
     assert nxt == ref["__next_rand__"]
+
+
+def test_cache_keys_follow_fused_optimizer_steps():
+    """torch's fused optimizers (torch._fused_sgd_) update parameters without moving their version counters; the
+    engine's caches (packed conv weights, folded BN, ...) must still see the update: every optimizer step of the
+    process bumps an epoch that is part of every cache key (engine._key) — round 5: eager training steps behind
+    torch.optim.SGD(fused=True) ran on frozen packed weights until this was keyed in."""
+    import torch
+    from slowfast.models import engine
+    p = torch.nn.Parameter(torch.randn(16))
+    p.grad = torch.randn(16)
+    for it, kwargs in enumerate(({"fused": True}, {"foreach": True}, {})):
+        slot = "_t_slot%d" % it
+        try:
+            opt = torch.optim.SGD([p], lr=0.1, momentum=0.9, **kwargs)
+        except (TypeError, RuntimeError):
+            continue
+        made = []
+        engine._cached_t(p, slot, engine._key(p), lambda: made.append(1) or p.detach().clone())
+        engine._cached_t(p, slot, engine._key(p), lambda: made.append(1) or p.detach().clone())
+        assert len(made) == 1                      # unchanged parameter: the cached copy is reused
+        before = p.detach().clone()
+        opt.step()
+        assert not torch.equal(before, p.detach())
+        got = engine._cached_t(p, slot, engine._key(p), lambda: made.append(1) or p.detach().clone())
+        assert len(made) == 2 and torch.equal(got, p.detach()), kwargs   # re-made from the updated values
+    k = engine._key(p)
+    engine.parameters_changed()
+    assert engine._key(p) != k
