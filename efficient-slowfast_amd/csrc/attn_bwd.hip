@@ -15,6 +15,7 @@
 #include "attn_args.h"
 #include "attn_bx.h"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace {
 
@@ -639,6 +640,14 @@ __device__ __forceinline__ f32x16 bxb_mfma(const u32x4 (&a)[3], const u32x4 (&b)
   if constexpr (DBG & 4) return mfma_bf(a[0], b[0], c);
   return mfma_split(a, b, c);
 }
+// A workgroup barrier for LDS hand-overs only (__syncthreads() also drains vmcnt — here that would wait for the dQ plane
+// store's acknowledgement once per tile): every LDS access of this wavefront has landed / been served, then the workgroup barrier; vmcnt is left alone
+#define PP_BARRIER()                                                  \
+  do {                                                                \
+    __builtin_amdgcn_sched_barrier(0);                                \
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); \
+    __builtin_amdgcn_sched_barrier(0);                                \
+  } while (0)
 constexpr int bxb_lds_bytes(int nw) { return 6 * BXB_PL * 2 + 2 * BXB_QT * 4 + nw * BXB_QT * 32 * 4; }
 template <int DBG, int NW>
 __global__ __launch_bounds__(64 * NW, 8 / NW) void attn_bwd_bx_kernel(const BwdArgs p, float* __restrict__ ws,
@@ -753,8 +762,10 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void attn_bwd_bx_kernel(const BwdA
     store_tile();
   }
   __syncthreads();
+  unsigned long long st_acc[5] = {0, 0, 0, 0, 0}, st0 = 0, st1 = 0, st2 = 0, st3 = 0, st4 = 0;  // DBG & 8: s_memtime per phase
   for (int t = t0; t < ntiles; ++t) {
     const bool more = (t + 1) < ntiles;
+    if constexpr (DBG & 8) { __builtin_amdgcn_sched_barrier(0); st0 = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
     if (more) load_tile(t + 1);
     f32x16 dqp[2];
 #pragma unroll
@@ -855,11 +866,14 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void attn_bwd_bx_kernel(const BwdA
       __builtin_amdgcn_wave_barrier();  // the image is rewritten by the next block
     }
     // this wavefront's partial [QT][CP] into its slot (rows kappa(r,lh), channel on the lane)
+    if constexpr (DBG & 8) { __builtin_amdgcn_sched_barrier(0); st1 = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
       for (int r = 0; r < 16; ++r) myslot[(sub * 32 + kappa(r, lh)) * CP + li] = dqp[sub][r];
-    __syncthreads();  // every wavefront is done with the tile and has its partial in place
+    if constexpr (DBG & 8) { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_waitcnt(0xc07f); st2 = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
+    PP_BARRIER();  // every wavefront is done with the tile and has its partial in place
+    if constexpr (DBG & 8) { __builtin_amdgcn_sched_barrier(0); st3 = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
     if (more) store_tile();
     for (int e0 = tid * 4; e0 < SLOT; e0 += NT * 4) {  // fixed-order sum of the NW partials to the plane
       f32x4 v = *reinterpret_cast<const f32x4*>(slots + e0);
@@ -867,7 +881,451 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void attn_bwd_bx_kernel(const BwdA
       for (int w = 1; w < NW; ++w) v += *reinterpret_cast<const f32x4*>(slots + w * SLOT + e0);
       *reinterpret_cast<f32x4*>(ws + ((((long)b * nq + t) * p.nt + kb) * (long)SLOT) + e0) = v;  // rows >= N: never read
     }
-    __syncthreads();
+    if constexpr (DBG & 8) { __builtin_amdgcn_sched_barrier(0); st4 = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
+    PP_BARRIER();
+    if constexpr (DBG & 8) {
+      __builtin_amdgcn_sched_barrier(0);
+      const unsigned long long st5 = __builtin_amdgcn_s_memtime();
+      st_acc[0] += st1 - st0; st_acc[1] += st2 - st1; st_acc[2] += st3 - st2; st_acc[3] += st4 - st3; st_acc[4] += st5 - st4;
+    }
+  }
+  if constexpr (DBG & 8) {
+    if ((blockIdx.x == 7 || blockIdx.x == 2000) && lane == 0 && (wave == 0 || wave == 5) && ntiles > t0) {
+      const unsigned long long n = ntiles - t0;
+      printf("bwd_bx stamps (workgroup %d wave %d, %llu tiles): per tile  compute %llu  slot writes %llu  barrier-1 wait %llu  "
+             "stage + slot sum %llu  barrier-2 wait %llu  = %llu cycles\n", (int)blockIdx.x, wave, n, st_acc[0] / n,
+             st_acc[1] / n, st_acc[2] / n, st_acc[3] / n, st_acc[4] / n,
+             (st_acc[0] + st_acc[1] + st_acc[2] + st_acc[3] + st_acc[4]) / n);
+    }
+  }
+  if (!jok) return;
+  float* okp;
+  float* ovp;
+  if (p.zs > 1) {  // this query part's share of dK / dV; attn_dq_reduce_kernel adds the parts in order
+    okp = p.dkp + ((long)bz * N + jrow) * CP;
+    ovp = p.dvp + ((long)bz * N + jrow) * CP;
+  } else {
+    okp = p.dk + (brow + jrow) * p.dk_cs;
+    ovp = p.dv + (brow + jrow) * p.dv_cs;
+  }
+#pragma unroll
+  for (int r = 0; r < 16; r += 4) {
+    const int c = 8 * (r >> 2) + 4 * lh;
+    if (p.zs > 1 || c < C) {  // C % 4 == 0 on this path
+      *reinterpret_cast<f32x4*>(okp + c) = (f32x4){dk[r], dk[r + 1], dk[r + 2], dk[r + 3]};
+      *reinterpret_cast<f32x4*>(ovp + c) = (f32x4){dv[r], dv[r + 1], dv[r + 2], dv[r + 3]};
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------- fused, bf16 pieces, ping-pong
+// attn_bwd_bx_kernel<., 8> re-scheduled (round 5).  Its stamps (SF_ATTN_BX_DBG=8) show where a 64-query tile's 12 850
+// cycles go: the two wavefronts of a SIMD need 11 100 for 2 x 120 MFMAs = 7 680 cycles of the matrix pipe — every
+// product waits for its fragment reads right in front of it, every exp2 / split for its product, and the older
+// wavefront wins both pipes whenever it can issue — and 1 750 go to the dQ hand-over (slot stores, two barriers, the
+// sum) with no MFMA in flight.  tools/microbench/mfma_pingpong.hip: a wavefront that alternates a pure MFMA segment
+// with a pure vector segment, its SIMD partner one segment behind and s_setprio 1 inside MFMA segments, keeps the
+// pipe 95-99 % busy.  So here the loop is cut into such segments, software-pipelined by one 32-query SUB-block k:
+//   M(k):  back(k-1)  dV^T += dO^T P, dK^T += Q^T dS, dQ(k-1) = dS K   (36 MFMAs; P / dS pieces from registers, dS^T
+//                     from the wavefront's LDS image), then
+//          front(k)   S' = Q K'^T - LSE, dP = dO V^T - D                (24 MFMAs) — all fragment reads, no vector work;
+//   V(k):  dQ(k-1) partial -> slot, P = exp2(S'), split, dS = P dP, split, dS pieces -> image; wavefronts 0-3 also sum
+//          the eight slots of sub-block k-2 into the dQ plane, wavefronts 4-7 issue the LDS-DMA loads of sub-block k+2's Q / dO pieces.
+// Wavefronts 4-7 (the SIMD partners of 0-3) run one segment behind; EVERY segment ends in one raw s_barrier (LDS
+// counters drained, global loads / stores stay in flight), which is all the synchronisation there is: sub-block
+// buffers are a ring of three (sub-block j is read in intervals 2j .. 2j+3 and refilled in 2j+4), slots alternate by
+// sub-block parity, the image is private to its wavefront.  Same products, same accumulation order, same slot-sum
+// order as attn_bwd_bx_kernel: the results are bit-identical to it (tests/test_attention_bx_gpu.py).
+// Sub-block buffers are unpadded [piece 6][row 32][32 channels] with the 16-byte chunk index XORed by (row >> 2) & 3:
+// conflict-free for the row reads (ds_read_b128), the transposing reads and the staging stores.
+constexpr int PP_SUB = 32;                      // queries per sub-block
+constexpr int PP_PIECE = PP_SUB * 32;           // one piece of one sub-block (bf16 elements; 2 KB)
+constexpr int PP_TILE = 6 * PP_PIECE;           // Q pieces 0..2, dO pieces 3..5
+constexpr int PP_IMG = 3 * 32 * BXB_TP;         // one wavefront's dS image (bf16 elements)
+constexpr int PP_SLOT = PP_SUB * 32;            // one wavefront's dQ partial of a sub-block (floats)
+constexpr int PP_LDS_BYTES = 3 * PP_TILE * 2 + 8 * PP_IMG * 2 + 8 * 2 * PP_SLOT * 4 + 3 * 2 * PP_SUB * 4;
+static_assert(PP_LDS_BYTES <= 160 * 1024, "one workgroup per CU");
+// (a barrier that also drains vmcnt: the prologue's)
+#define PP_BARRIER_VM()                                                          \
+  do {                                                                           \
+    __builtin_amdgcn_sched_barrier(0);                                           \
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");   \
+    __builtin_amdgcn_sched_barrier(0);                                           \
+  } while (0)
+typedef __attribute__((address_space(3))) void lds_void;
+template <int DBG>
+__global__ __launch_bounds__(512, 1) void attn_bwd_bxpp_kernel(const BwdArgs p, float* __restrict__ ws,
+                                                               const unsigned short* __restrict__ qb,
+                                                               const unsigned short* __restrict__ db, int n64) {
+  constexpr int CP = 32, TP = BXB_TP;
+  extern __shared__ __attribute__((aligned(16))) unsigned short pp_smem[];
+  unsigned short* const tiles = pp_smem;                                  // ring of 3 sub-block buffers
+  unsigned short* const imgs = tiles + 3 * PP_TILE;                       // [wave][piece][key 32][TP]
+  float* const slots = reinterpret_cast<float*>(imgs + 8 * PP_IMG);       // [wave][parity][PP_SLOT]
+  float* const lsd = slots + 8 * 2 * PP_SLOT;                             // [buffer][-LSE 32 | -D 32]
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = wave >> 2;  // 0: wavefronts 0-3, 1: their SIMD partners, one segment behind
+  const int li = lane & 31, lh = lane >> 5;
+  const int bz = blockIdx.x / p.nt;  // workgroup -> (clip b, query part z, key block kb)
+  const int kb = blockIdx.x - bz * p.nt;
+  const int b = bz / p.zs, z = bz - b * p.zs;
+  const int j0 = kb * 256 + wave * 32;
+  const int N = p.N, C = p.C;
+  const long brow = (long)b * N;
+  const float gamma = p.gamma[0];
+  float* const myslot = slots + wave * 2 * PP_SLOT;
+  unsigned short* const img = imgs + wave * PP_IMG;
+
+  // ---- this wavefront's keys: K' = K log2(e) and V as B operands [k = channel][col = key], K as [k = key][col = channel]
+  u32x4 kfb[2][3], vfb[2][3], kbr[2][3];
+  const int jrow = j0 + li;
+  const bool jok = jrow < N;
+  {
+    const float* kp = p.k + (brow + (jok ? jrow : 0)) * p.k_cs + 8 * lh;
+    const float* vp = p.v + (brow + (jok ? jrow : 0)) * p.v_cs + 8 * lh;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      f32x4 k0 = {0.f, 0.f, 0.f, 0.f}, k1 = k0, v0 = k0, v1 = k0;
+      if (jok && 16 * c + 8 * lh < C) {
+        k0 = *reinterpret_cast<const f32x4*>(kp + 16 * c);
+        v0 = *reinterpret_cast<const f32x4*>(vp + 16 * c);
+      }
+      if (jok && 16 * c + 8 * lh + 4 < C) {
+        k1 = *reinterpret_cast<const f32x4*>(kp + 16 * c + 4);
+        v1 = *reinterpret_cast<const f32x4*>(vp + 16 * c + 4);
+      }
+      k0 *= LOG2E;
+      k1 *= LOG2E;
+      split_pair(k0[0], k0[1], kfb[c], 0);
+      split_pair(k0[2], k0[3], kfb[c], 1);
+      split_pair(k1[0], k1[1], kfb[c], 2);
+      split_pair(k1[2], k1[3], kfb[c], 3);
+      split_pair(v0[0], v0[1], vfb[c], 0);
+      split_pair(v0[2], v0[3], vfb[c], 1);
+      split_pair(v1[0], v1[1], vfb[c], 2);
+      split_pair(v1[2], v1[3], vfb[c], 3);
+    }
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      float kv[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int key = j0 + 16 * m + 8 * lh + e;
+        kv[e] = (key < N && li < C) ? p.k[(brow + key) * p.k_cs + li] : 0.f;
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) split_pair(kv[2 * e], kv[2 * e + 1], kbr[m], e);
+    }
+  }
+  f32x16 dk, dv;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { dk[r] = 0.f; dv[r] = 0.f; }
+
+  // ---- the sub-blocks of this workgroup's query part
+  const int nq = (N + 63) / 64;
+  const int tz = (nq + p.zs - 1) / p.zs;  // 64-query tiles per part
+  const int t0 = z * tz;
+  const int ntiles = min(nq, t0 + tz);
+  const int NS = t0 < ntiles ? 2 * (ntiles - t0) : 0;  // sub-blocks; sub-block j is rows (2 t0 + j) * 32 ..
+  const int S0 = 2 * t0;
+
+  // ---- staging by wavefronts 0-3 (256 threads; thread st -> Q or dO pieces, row st_r, 16-byte chunk st_c): global
+  // loads into three registers at the start of M(k-1), LDS stores at the start of M(k) — two intervals to land, and
+  // both ends sit in MFMA segments, whose issue slots are free.  (Direct-to-LDS loads were built first: hipcc waits for
+  // vmcnt(0) in front of the first LDS access behind an LDS-DMA instruction — it cannot tell the ring slots apart — and
+  // that put a whole memory latency into the segment that issued them.)
+  const long plane = (long)n64 * 64 * 32;
+  const int st = tid & 255;
+  const int st_r = (st & 127) >> 2, st_c = st & 3;
+  const unsigned short* const sg = ((st >> 7) ? db : qb) + (long)b * 3 * plane + st_r * 32 + st_c * 8;
+  const int st_off = ((st >> 7) ? 3 * PP_PIECE : 0) + st_r * 32 + ((st_c ^ ((st_r >> 2) & 3)) << 3);
+  u32x4 rq[3];
+  auto stage_load = [&](int j) {
+#pragma unroll
+    for (int pc = 0; pc < 3; ++pc)
+      rq[pc] = *reinterpret_cast<const u32x4*>(sg + pc * plane + (long)(S0 + j) * (PP_SUB * 32));
+  };
+  auto stage_store = [&](int buf) {
+#pragma unroll
+    for (int pc = 0; pc < 3; ++pc) *reinterpret_cast<u32x4*>(tiles + buf * PP_TILE + pc * PP_PIECE + st_off) = rq[pc];
+  };
+  // -LSE / -D of the sub-block's queries: lanes 0..31 of ONE wavefront — loaded in M (raw: nothing there may wait for
+  // the loads), negated / scaled and stored in V
+  float rl = 0.f, rD = 0.f;
+  auto lsd_load = [&](int j) {
+    const int i = (S0 + j) * PP_SUB + li;
+    const long src = brow + (i < N ? i : 0);
+    rl = p.lse[src];
+    rD = p.dvec[src];
+  };
+  auto lsd_store = [&](int j, int buf) {
+    if (lane < PP_SUB) {
+      const bool ok = (S0 + j) * PP_SUB + li < N;
+      lsd[buf * 64 + lane] = ok ? -rl : -POS_BIG;  // P = 2^(s - BIG) = 0 for padded queries
+      lsd[buf * 64 + 32 + lane] = ok ? -rD * gamma : 0.f;
+    }
+  };
+  // fragment addresses (bf16 elements inside a sub-block buffer)
+  const int row_off0 = li * 32 + (((0 + lh) ^ ((li >> 2) & 3)) << 3);  // row fragment of channel chunk c = 0
+  const int row_off1 = li * 32 + (((2 + lh) ^ ((li >> 2) & 3)) << 3);  //                              c = 1
+  // transposing reads: lane 4q+p of a 16-lane group addresses row q, columns 4p..4p+3 of the block
+  const int tr_row = (lane & 15) >> 2, tr_col = 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+  // rows 16 m + 4 lh + tr_row (+ 8): (row >> 2) & 3 = lh (lh + 2)
+  const int col_lo = (4 * lh + tr_row) * 32 + ((((tr_col >> 3) ^ lh) << 3) | (tr_col & 7));
+  const int col_hi = (8 + 4 * lh + tr_row) * 32 + ((((tr_col >> 3) ^ (lh + 2)) << 3) | (tr_col & 7));
+  const unsigned short* const imgp = img + (8 * lh + tr_row) * TP + tr_col;
+
+  unsigned long long st_acc[7] = {0, 0, 0, 0, 0, 0, 0}, sa = 0, sb = 0;  // DBG & 8: cycles in M, barrier, V, barrier; M's parts
+  f32x16 s, dp, dqp;
+  u32x4 pf[2][3], sf[2][3];
+  typedef std::integral_constant<bool, true> yes_t;
+  typedef std::integral_constant<bool, false> no_t;
+
+  // ================================================================ M(k): back(k-1), then front(k); no vector work
+  // Eight chains of 6 (12) MFMAs; the fragment reads of chain i+1 are issued in front of chain i's MFMAs and pinned there
+  // (sched_barrier): the compiler's own order reads each chain's fragments right in front of it and waits for them
+  // (~100-200 cycles of idle matrix pipe per chain — the partner wavefront is in its vector segment and cannot fill it).
+#define PP_PIN() __builtin_amdgcn_sched_barrier(0)
+  auto cols = [&](const unsigned short* base, int m, u32x4 (&a)[3]) {  // transposed reads: A = columns of a sub-block
+    if constexpr (DBG & 128) return;  // timing ablation: no fragment reads
+#pragma unroll
+    for (int pc = 0; pc < 3; ++pc) {
+      const u32x2 lo = lds_read_tr(base + pc * PP_PIECE + 512 * m + col_lo);
+      const u32x2 hi = lds_read_tr(base + pc * PP_PIECE + 512 * m + col_hi);
+      a[pc] = (u32x4){lo[0], lo[1], hi[0], hi[1]};
+    }
+  };
+  auto imgf = [&](int m, u32x4 (&a)[3]) {  // transposed reads of this wavefront's dS image: A = dS, query on the lane
+    if constexpr (DBG & 128) return;
+#pragma unroll
+    for (int pc = 0; pc < 3; ++pc) {
+      const u32x2 lo = lds_read_tr(imgp + (pc * 32 + 16 * m) * TP);
+      const u32x2 hi = lds_read_tr(imgp + (pc * 32 + 16 * m + 4) * TP);
+      a[pc] = (u32x4){lo[0], lo[1], hi[0], hi[1]};
+    }
+  };
+  auto rows = [&](const unsigned short* tf, int c, u32x4 (&qa)[3], u32x4 (&da)[3]) {
+    if constexpr (DBG & 128) return;
+    const int ro = c ? row_off1 : row_off0;
+#pragma unroll
+    for (int pc = 0; pc < 3; ++pc) {
+      qa[pc] = *reinterpret_cast<const u32x4*>(tf + pc * PP_PIECE + ro);
+      da[pc] = *reinterpret_cast<const u32x4*>(tf + (3 + pc) * PP_PIECE + ro);
+    }
+  };
+  auto init_acc = [&](int bf) {  // -LSE and -D are the initial accumulators of S' and dP
+    if constexpr (DBG & 1024) return;
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {
+      const f32x4 l4 = *reinterpret_cast<const f32x4*>(lsd + bf * 64 + 8 * g4 + 4 * lh);
+      const f32x4 d4 = *reinterpret_cast<const f32x4*>(lsd + bf * 64 + 32 + 8 * g4 + 4 * lh);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        s[4 * g4 + e] = l4[e];
+        dp[4 * g4 + e] = d4[e];
+      }
+    }
+  };
+  auto mm = [&](const u32x4 (&a)[3], const u32x4 (&bb)[3], f32x16 c) -> f32x16 {
+    if constexpr (DBG & 64) {  // timing ablation: no MFMAs (the fragments are still read)
+      c[0] += __builtin_bit_cast(float, a[0][0] ^ a[1][1] ^ a[2][2] ^ a[0][3] ^ bb[0][0]);
+      return c;
+    } else {
+      return mfma_split(a, bb, c);
+    }
+  };
+  // dQ plane rows of sub-block j = fixed-order sum of the eight wavefronts' partials (256 threads, one float4 each)
+  const int stid = tid & 255;
+  f32x4 sum_v;
+  auto sum_read = [&](int par, int w0, int w1) {
+    const float* const sl = slots + par * PP_SLOT + stid * 4;
+#pragma unroll
+    for (int w = 0; w < 8; ++w)
+      if (w >= w0 && w < w1) {
+        const f32x4 x = *reinterpret_cast<const f32x4*>(sl + w * 2 * PP_SLOT);
+        sum_v = (w == 0) ? x : sum_v + x;
+      }
+  };
+  auto sum_store = [&](int j) {  // absolute sub-block S0 + j: tile >> 1, rows (& 1) * 32 ..
+    const int a = S0 + j;
+    *reinterpret_cast<f32x4*>(ws + ((((long)b * nq + (a >> 1)) * p.nt + kb) * (long)(2 * PP_SLOT)) + (a & 1) * PP_SLOT +
+                              stid * 4) = sum_v;  // rows >= N: never read
+  };
+  auto seg_m = [&](const int k, auto has_back, auto has_front) {
+    constexpr bool BACK = decltype(has_back)::value, FRONT = decltype(has_front)::value;
+    if constexpr (DBG & 8) { __builtin_amdgcn_sched_barrier(0); sa = __builtin_amdgcn_s_memtime(); }
+    // Bookkeeping rides in the gaps of this segment's MFMAs (the V segment is the longer one):
+    //   wavefronts 0-3: sub-block k+1's pieces (in registers since M(k-1)) into the ring slot sub-block k-2 left (dead
+    //   since interval 2k-1; first read in interval 2k+2), then the global loads of sub-block k+2's; wavefront 0 the
+    //   same for -LSE / -D;
+    //   wavefronts 4-7: the sum of sub-block k-2's eight dQ partials (complete since their own V(k-1)).
+    if (grp == 0 && !(DBG & 512)) {
+      if (k + 1 < NS) {  // loaded at the start of M(k-1) (sub-block 1: in the prologue)
+        stage_store((k + 1) % 3);
+        if constexpr (DBG & 8) { __builtin_amdgcn_sched_barrier(0); st_acc[6] += __builtin_amdgcn_s_memtime() - sa; __builtin_amdgcn_sched_barrier(0); }
+        if (wave == 0) lsd_store(k + 1, (k + 1) % 3);
+      }
+      if (k + 2 < NS) {
+        stage_load(k + 2);
+        if (wave == 0) lsd_load(k + 2);
+      }
+    }
+    const bool summer = BACK && grp == 1 && k >= 2 && !(DBG & 512);
+    if constexpr (DBG & 8) { __builtin_amdgcn_sched_barrier(0); st_acc[4] += __builtin_amdgcn_s_memtime() - sa; }
+    if constexpr (!(DBG & 16)) __builtin_amdgcn_s_setprio(1);
+    const unsigned short* const tb = tiles + ((k + 2) % 3) * PP_TILE;  // sub-block k-1
+    const int bf = k % 3;
+    const unsigned short* const tf = tiles + bf * PP_TILE;             // sub-block k
+    u32x4 a0[3] = {}, a1[3] = {}, qa0[3] = {}, da0[3] = {}, qa1[3] = {}, da1[3] = {};
+    if constexpr (BACK) {
+      cols(tb + 3 * PP_PIECE, 0, a0);                                                  // dO columns, k-step 0
+      PP_PIN();
+      cols(tb + 3 * PP_PIECE, 1, a1); PP_PIN(); dv = mm(a0, pf[0], dv); PP_PIN();  // dV^T += dO^T P
+      if (summer) sum_read(k & 1, 0, 4);
+      cols(tb, 0, a0);                PP_PIN(); dv = mm(a1, pf[1], dv); PP_PIN();
+      if (summer) sum_read(k & 1, 4, 8);
+      cols(tb, 1, a1);                PP_PIN(); dk = mm(a0, sf[0], dk); PP_PIN();  // dK^T += Q^T dS
+      if (summer) sum_store(k - 2);
+      imgf(0, a0);                    PP_PIN(); dk = mm(a1, sf[1], dk); PP_PIN();
+      if constexpr (!(DBG & 1024)) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dqp[r] = 0.f;
+      }
+      imgf(1, a1);                    PP_PIN(); dqp = mm(a0, kbr[0], dqp); PP_PIN();  // dQ(k-1) = dS K
+      if constexpr (FRONT) {
+        init_acc(bf);
+        rows(tf, 0, qa0, da0);
+      }
+      PP_PIN();
+      dqp = mm(a1, kbr[1], dqp);
+      PP_PIN();
+      if constexpr (DBG & 8) { st_acc[5] += __builtin_amdgcn_s_memtime() - sa; __builtin_amdgcn_sched_barrier(0); }
+    } else {
+      init_acc(bf);
+      rows(tf, 0, qa0, da0);
+      PP_PIN();
+    }
+    if constexpr (FRONT) {  // S' = Q K'^T - LSE,  dP = dO V^T - D   (queries in registers, key on the lane)
+      rows(tf, 1, qa1, da1);
+      PP_PIN();
+      s = mm(qa0, kfb[0], s);
+      dp = mm(da0, vfb[0], dp);
+      PP_PIN();
+      s = mm(qa1, kfb[1], s);
+      dp = mm(da1, vfb[1], dp);
+    }
+    if constexpr (!(DBG & 16)) __builtin_amdgcn_s_setprio(0);
+    if constexpr (DBG & 8) { __builtin_amdgcn_sched_barrier(0); sb = __builtin_amdgcn_s_memtime(); st_acc[0] += sb - sa; }
+  };
+  // ================================================================ V(k): everything that is not an MFMA
+  auto seg_v = [&](const int k, auto has_back, auto has_front) {
+    if constexpr (DBG & 8) { __builtin_amdgcn_sched_barrier(0); sa = __builtin_amdgcn_s_memtime(); st_acc[1] += sa - sb; }
+    if constexpr (decltype(has_back)::value) {  // dQ(k-1) partial [32 queries][CP] -> this wavefront's slot
+      float* const sl = myslot + ((k - 1) & 1) * PP_SLOT;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sl[kappa(r, lh) * CP + li] = dqp[r];
+    }
+    if constexpr (decltype(has_front)::value && (DBG & 256)) {  // timing ablation: the probe's vector segment instead
+      float f[8];
+      for (int i = 0; i < 8; ++i) f[i] = s[i];
+      const float bb = dp[0];
+#pragma unroll
+      for (int q = 0; q < 16; ++q) asm volatile("v_exp_f32 %0, %0" : "+v"(f[q & 7]));
+#pragma unroll
+      for (int q = 0; q < 48; ++q) asm volatile("v_cvt_pk_bf16_f32 %0, %0, %1" : "+v"(f[q & 7]) : "v"(bb));
+#pragma unroll
+      for (int q = 0; q < 150; ++q) asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(f[q & 7]) : "v"(bb));
+      for (int i = 0; i < 8; ++i) pf[0][0][i & 3] ^= __builtin_bit_cast(unsigned, f[i]);
+    }
+    if constexpr (decltype(has_front)::value && !(DBG & 32) && !(DBG & 256)) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[r] = __builtin_amdgcn_exp2f(s[r]);  // P
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dp[r] *= s[r];  // dS = P dP
+      // Both three-way splits STAGE by stage over all 16 pairs (in place: s and dp end as the third residuals): the
+      // partner wavefront is in its MFMA segment and covers nothing, so a pair's own chain (convert -> expand ->
+      // subtract -> convert ...: seven dependent steps) must not be what the vector pipe waits for — the compiler's
+      // order interleaved two pairs and the segment took 1 900 cycles with the matrix pipe idle beside it.
+#pragma unroll
+      for (int st = 0; st < 3; ++st) {
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            pf[m][st][e] = cvt_pk_bf16(s[8 * m + 2 * e], s[8 * m + 2 * e + 1]);
+            sf[m][st][e] = cvt_pk_bf16(dp[8 * m + 2 * e], dp[8 * m + 2 * e + 1]);
+          }
+        PP_PIN();
+        if (st < 2) {
+#pragma unroll
+          for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              s[8 * m + 2 * e] -= __builtin_bit_cast(float, pf[m][st][e] << 16);
+              s[8 * m + 2 * e + 1] -= __builtin_bit_cast(float, pf[m][st][e] & 0xffff0000u);
+              dp[8 * m + 2 * e] -= __builtin_bit_cast(float, sf[m][st][e] << 16);
+              dp[8 * m + 2 * e + 1] -= __builtin_bit_cast(float, sf[m][st][e] & 0xffff0000u);
+            }
+          PP_PIN();
+        }
+      }
+      // dS pieces -> [key][query] image (registers 4g..4g+3 = queries 8g + 4h .. +3 of this lane's key)
+#pragma unroll
+      for (int pc = 0; pc < 3; ++pc)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          *reinterpret_cast<u32x2*>(img + (pc * 32 + li) * TP + 8 * g + 4 * lh) =
+              (u32x2){sf[g >> 1][pc][2 * (g & 1)], sf[g >> 1][pc][2 * (g & 1) + 1]};
+    }
+    if constexpr (DBG & 8) { __builtin_amdgcn_sched_barrier(0); sb = __builtin_amdgcn_s_memtime(); st_acc[2] += sb - sa; }
+  };
+  auto sync = [&]() {
+    PP_BARRIER();
+    if constexpr (DBG & 8) { sa = __builtin_amdgcn_s_memtime(); st_acc[3] += sa - sb; sb = sa; }
+  };
+
+  if (NS > 0) {  // (every wavefront of the workgroup has the same NS: the barrier counts agree)
+    if (grp == 0) {  // prologue: sub-block 0 into the ring, sub-block 1 into the registers (M(k) stores k+1, loads k+2)
+      stage_load(0);
+      if (wave == 0) lsd_load(0);
+      stage_store(0);
+      if (wave == 0) lsd_store(0, 0);
+      stage_load(1);  // NS >= 2
+      if (wave == 0) lsd_load(1);
+    }
+    PP_BARRIER_VM();
+    if (grp == 1) PP_BARRIER();  // one segment behind
+    seg_m(0, no_t(), yes_t());
+    PP_BARRIER();
+    seg_v(0, no_t(), yes_t());
+    sync();
+    for (int k = 1; k < NS; ++k) {
+      seg_m(k, yes_t(), yes_t());
+      PP_BARRIER();
+      seg_v(k, yes_t(), yes_t());
+      sync();
+    }
+    seg_m(NS, yes_t(), no_t());
+    PP_BARRIER();
+    seg_v(NS, yes_t(), no_t());
+    sync();
+    if (grp == 0) {
+      PP_BARRIER();
+      // the last sub-block's partials (written in V(NS))
+      sum_read((NS - 1) & 1, 0, 8);
+      sum_store(NS - 1);
+    }
+  }
+  if constexpr (DBG & 8) {
+    if ((blockIdx.x == 7 || blockIdx.x == 2000) && lane == 0 && (wave == 0 || wave == 5) && NS > 0) {
+      const unsigned long long n = NS + 1;
+      printf("bwd_bxpp stamps (workgroup %d wave %d, %d sub-blocks): per sub-block  M %llu (staging stores until %llu, bookkeeping until %llu, back "
+             "until %llu)  barrier %llu  V %llu  barrier %llu  = %llu cycles\n", (int)blockIdx.x, wave, NS, st_acc[0] / n,
+             st_acc[6] / n, st_acc[4] / n, st_acc[5] / n, st_acc[1] / n, st_acc[2] / n, st_acc[3] / n,
+             (st_acc[0] + st_acc[1] + st_acc[2] + st_acc[3]) / n);
+    }
   }
   if (!jok) return;
   float* okp;
@@ -1482,9 +1940,14 @@ int sf_attn_dq_reduce(const float* ws, float* dq, int dq_cs, int B, int N, int C
 static int g_attn_nw = [] { const char* e = getenv("SF_ATTN_BX_NW"); return e ? atoi(e) : 0; }();
 static int g_sweep_parts = [] { const char* e = getenv("SF_SWEEP_PARTS"); return e ? atoi(e) : 0; }();
 
+// SF_ATTN_BX_PP / sf_attn_tune(2, .): the 8-wavefront bf16-piece backward as the ping-pong schedule
+// (attn_bwd_bxpp_kernel) or as the free-running sweep (attn_bwd_bx_kernel<., 8>)
+static int g_attn_pp = [] { const char* e = getenv("SF_ATTN_BX_PP"); return e ? atoi(e) : 0; }();
+
 extern "C" int sf_attn_tune(int knob, int value) {
   if (knob == 0 && (value == 0 || value == 4 || value == 8)) g_attn_nw = value;
   else if (knob == 1 && value >= 0 && value <= SF_SWEEP_PARTS_MAX) g_sweep_parts = value;
+  else if (knob == 2 && (value == 0 || value == 1)) g_attn_pp = value;
   else return SF_EINVAL;
   return SF_OK;
 }
@@ -1551,7 +2014,7 @@ int launch_fused_bx(BwdArgs a, float* ws, float* bx_ws, hipStream_t s) {
   static const Kern kern = [] {  // SF_ATTN_BX_DBG: timing ablations (see the kernel)
     const char* e = getenv("SF_ATTN_BX_DBG");
     const int dbg = e ? atoi(e) : 0;
-    if (NW == 8) return dbg == 2 ? (Kern)attn_bwd_bx_kernel<2, 8> : (Kern)attn_bwd_bx_kernel<0, 8>;
+    if (NW == 8) return dbg == 2 ? (Kern)attn_bwd_bx_kernel<2, 8> : dbg == 8 ? (Kern)attn_bwd_bx_kernel<8, 8> : (Kern)attn_bwd_bx_kernel<0, 8>;
     switch (dbg) {
       case 1: return (Kern)attn_bwd_bx_kernel<1, 4>;
       case 2: return (Kern)attn_bwd_bx_kernel<2, 4>;
@@ -1562,10 +2025,35 @@ int launch_fused_bx(BwdArgs a, float* ws, float* bx_ws, hipStream_t s) {
     }
   }();
   static const int pad = [] { const char* e = getenv("SF_ATTN_BX_PADLDS"); return e ? atoi(e) : 0; }();  // occupancy probe
-  static SfLdsAttr lds_attr;
-  if (!sf_ensure_dyn_lds(lds_attr, reinterpret_cast<const void*>(kern), bxb_lds_bytes(NW) + pad)) return SF_ELAUNCH;
-  hipLaunchKernelGGL(kern, dim3(a.B * a.zs * a.nt), dim3(64 * NW), bxb_lds_bytes(NW) + pad, s, a, ws, qb, db,
-                     sf_cdiv(a.N, qt));
+  if (NW == 8 && g_attn_pp) {  // the ping-pong schedule of the same sweep
+    static const Kern pp = [] {
+      const char* e = getenv("SF_ATTN_BX_DBG");
+      switch (e ? atoi(e) : 0) {
+        case 8: return (Kern)attn_bwd_bxpp_kernel<8>;
+        case 16: return (Kern)attn_bwd_bxpp_kernel<16>;    // no s_setprio
+        case 32: return (Kern)attn_bwd_bxpp_kernel<32>;    // V segments without exp2 / splits / image (results invalid)
+        case 64: return (Kern)attn_bwd_bxpp_kernel<64>;    // M segments without MFMAs (results invalid)
+        case 40: return (Kern)attn_bwd_bxpp_kernel<40>;
+        case 72: return (Kern)attn_bwd_bxpp_kernel<72>;
+        case 136: return (Kern)attn_bwd_bxpp_kernel<136>;
+        case 264: return (Kern)attn_bwd_bxpp_kernel<264>;
+        case 392: return (Kern)attn_bwd_bxpp_kernel<392>;    // 264 + no fragment reads
+        case 904: return (Kern)attn_bwd_bxpp_kernel<904>;    // 392 + no staging / slot sums
+        case 1928: return (Kern)attn_bwd_bxpp_kernel<1928>;  // 904 + no accumulator initialisation
+        case 776: return (Kern)attn_bwd_bxpp_kernel<776>;    // 264 + no staging / slot sums
+        case 520: return (Kern)attn_bwd_bxpp_kernel<520>;    // real V, no staging / slot sums  // V segments with the probe's register-only vector work, stamps  // M segments without fragment reads (results invalid), stamps
+        default: return (Kern)attn_bwd_bxpp_kernel<0>;
+      }
+    }();
+    static SfLdsAttr pp_attr;
+    if (!sf_ensure_dyn_lds(pp_attr, reinterpret_cast<const void*>(pp), PP_LDS_BYTES)) return SF_ELAUNCH;
+    hipLaunchKernelGGL(pp, dim3(a.B * a.zs * a.nt), dim3(512), PP_LDS_BYTES, s, a, ws, qb, db, sf_cdiv(a.N, qt));
+  } else {
+    static SfLdsAttr lds_attr;
+    if (!sf_ensure_dyn_lds(lds_attr, reinterpret_cast<const void*>(kern), bxb_lds_bytes(NW) + pad)) return SF_ELAUNCH;
+    hipLaunchKernelGGL(kern, dim3(a.B * a.zs * a.nt), dim3(64 * NW), bxb_lds_bytes(NW) + pad, s, a, ws, qb, db,
+                       sf_cdiv(a.N, qt));
+  }
   SF_CHECK_LAUNCH();
   if (a.zs > 1) {
     rc = sf_attn_dq_reduce(a.dkp, a.dk, a.dk_cs, a.B, a.N, a.C, CP, a.zs, s);
