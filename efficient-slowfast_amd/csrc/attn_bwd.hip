@@ -945,7 +945,8 @@ constexpr int PP_IMG = 3 * 32 * BXB_TP;         // one wavefront's dS image (bf1
 constexpr int PP_SLOT = PP_SUB * 32;            // one wavefront's dQ partial of a sub-block (floats)
 constexpr int PP_LDS_BYTES = 3 * PP_TILE * 2 + 8 * PP_IMG * 2 + 8 * 2 * PP_SLOT * 4 + 3 * 2 * PP_SUB * 4;
 static_assert(PP_LDS_BYTES <= 160 * 1024, "one workgroup per CU");
-// (a barrier that also drains vmcnt: the prologue's)
+// the barrier behind an M segment also drains vmcnt: the LDS-DMA pieces this wavefront issued at the start of its V
+// segment, an interval ago, have landed before anybody reads their ring slot
 #define PP_BARRIER_VM()                                                          \
   do {                                                                           \
     __builtin_amdgcn_sched_barrier(0);                                           \
@@ -958,11 +959,14 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_bxpp_kernel(const BwdArgs p, 
                                                                const unsigned short* __restrict__ qb,
                                                                const unsigned short* __restrict__ db, int n64) {
   constexpr int CP = 32, TP = BXB_TP;
-  extern __shared__ __attribute__((aligned(16))) unsigned short pp_smem[];
-  unsigned short* const tiles = pp_smem;                                  // ring of 3 sub-block buffers
-  unsigned short* const imgs = tiles + 3 * PP_TILE;                       // [wave][piece][key 32][TP]
-  float* const slots = reinterpret_cast<float*>(imgs + 8 * PP_IMG);       // [wave][parity][PP_SLOT]
-  float* const lsd = slots + 8 * 2 * PP_SLOT;                             // [buffer][-LSE 32 | -D 32]
+  // FOUR LDS objects, not one carved buffer: the ring is filled by LDS-DMA (buffer_load ... lds), whose completion is a
+  // vmcnt event, and hipcc puts s_waitcnt vmcnt(0) in front of every LDS access that MAY touch what an outstanding
+  // LDS-DMA writes — with one buffer that is every image / slot store of the segment that issued the loads (a whole
+  // memory latency in the middle of it); distinct objects cannot alias.
+  __shared__ __attribute__((aligned(16))) unsigned short tiles[3 * PP_TILE];     // ring of 3 sub-block buffers
+  __shared__ __attribute__((aligned(16))) unsigned short imgs[8 * PP_IMG];       // [wave][piece][key 32][TP]
+  __shared__ __attribute__((aligned(16))) float slots[8 * 2 * PP_SLOT];          // [wave][parity][PP_SLOT]
+  __shared__ __attribute__((aligned(16))) float lsd[3 * 2 * PP_SUB];             // [buffer][-LSE 32 | -D 32]
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1031,25 +1035,29 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_bxpp_kernel(const BwdArgs p, 
   const int NS = t0 < ntiles ? 2 * (ntiles - t0) : 0;  // sub-blocks; sub-block j is rows (2 t0 + j) * 32 ..
   const int S0 = 2 * t0;
 
-  // ---- staging by wavefronts 0-3 (256 threads; thread st -> Q or dO pieces, row st_r, 16-byte chunk st_c): global
-  // loads into three registers at the start of M(k-1), LDS stores at the start of M(k) — two intervals to land, and
-  // both ends sit in MFMA segments, whose issue slots are free.  (Direct-to-LDS loads were built first: hipcc waits for
-  // vmcnt(0) in front of the first LDS access behind an LDS-DMA instruction — it cannot tell the ring slots apart — and
-  // that put a whole memory latency into the segment that issued them.)
+  // ---- staging: a sub-block is 6 pieces x 2 KB = twelve 1 KB LDS-DMA wave-instructions (buffer_load_dwordx4 ... lds:
+  // no staging registers, no LDS stores), three per wavefront 4-7 at the start of V(k) for sub-block k+2: its ring slot
+  // held sub-block k-1, last read in the interval before; the first reader comes two intervals later, behind the
+  // vmcnt(0) barrier that ends the issuing wavefront's next M segment.  An LDS-DMA image is lane-linear, so the chunk
+  // swizzle sits on the SOURCE address: lane l fills position (row l >> 2, chunk l & 3) of its 16 rows with source
+  // chunk (l & 3) ^ ((row >> 2) & 3).
   const long plane = (long)n64 * 64 * 32;
-  const int st = tid & 255;
-  const int st_r = (st & 127) >> 2, st_c = st & 3;
-  const unsigned short* const sg = ((st >> 7) ? db : qb) + (long)b * 3 * plane + st_r * 32 + st_c * 8;
-  const int st_off = ((st >> 7) ? 3 * PP_PIECE : 0) + st_r * 32 + ((st_c ^ ((st_r >> 2) & 3)) << 3);
-  u32x4 rq[3];
-  auto stage_load = [&](int j) {
-#pragma unroll
-    for (int pc = 0; pc < 3; ++pc)
-      rq[pc] = *reinterpret_cast<const u32x4*>(sg + pc * plane + (long)(S0 + j) * (PP_SUB * 32));
-  };
-  auto stage_store = [&](int buf) {
-#pragma unroll
-    for (int pc = 0; pc < 3; ++pc) *reinterpret_cast<u32x4*>(tiles + buf * PP_TILE + pc * PP_PIECE + st_off) = rq[pc];
+  const __amdgpu_buffer_rsrc_t q_rs =
+      __builtin_amdgcn_make_buffer_rsrc((void*)(qb + (long)b * 3 * plane), 0, (unsigned)(3 * plane * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t d_rs =
+      __builtin_amdgcn_make_buffer_rsrc((void*)(db + (long)b * 3 * plane), 0, (unsigned)(3 * plane * 2), 0x00020000);
+  const unsigned dma_voff[2] = {  // halves: rows 0..15, 16..31
+      (unsigned)((lane >> 2) * 64 + (((lane & 3) ^ ((lane >> 4) & 3)) << 4)),
+      (unsigned)((16 + (lane >> 2)) * 64 + (((lane & 3) ^ ((lane >> 4) & 3)) << 4))};
+  // piece `id` (0..11: Q pieces x halves, then dO pieces x halves) of sub-block j into ring buffer buf
+  auto stage_piece = [&](int j, int buf, int id) {
+    const int which = id >= 6, pc = (id % 6) >> 1, half = id & 1;
+    const unsigned so = (unsigned)(((long)pc * plane + (long)(S0 + j) * (PP_SUB * 32)) * 2);
+    unsigned short* const dst = tiles + buf * PP_TILE + (which * 3 + pc) * PP_PIECE + half * 512;
+    if (which)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(d_rs, (lds_void*)dst, 16, dma_voff[half], so, 0, 0);
+    else
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(q_rs, (lds_void*)dst, 16, dma_voff[half], so, 0, 0);
   };
   // -LSE / -D of the sub-block's queries: lanes 0..31 of ONE wavefront — loaded in M (raw: nothing there may wait for
   // the loads), negated / scaled and stored in V
@@ -1156,23 +1164,7 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_bxpp_kernel(const BwdArgs p, 
   auto seg_m = [&](const int k, auto has_back, auto has_front) {
     constexpr bool BACK = decltype(has_back)::value, FRONT = decltype(has_front)::value;
     if constexpr (DBG & 8) { __builtin_amdgcn_sched_barrier(0); sa = __builtin_amdgcn_s_memtime(); }
-    // Bookkeeping rides in the gaps of this segment's MFMAs (the V segment is the longer one):
-    //   wavefronts 0-3: sub-block k+1's pieces (in registers since M(k-1)) into the ring slot sub-block k-2 left (dead
-    //   since interval 2k-1; first read in interval 2k+2), then the global loads of sub-block k+2's; wavefront 0 the
-    //   same for -LSE / -D;
-    //   wavefronts 4-7: the sum of sub-block k-2's eight dQ partials (complete since their own V(k-1)).
-    if (grp == 0 && !(DBG & 512)) {
-      if (k + 1 < NS) {  // loaded at the start of M(k-1) (sub-block 1: in the prologue)
-        stage_store((k + 1) % 3);
-        if constexpr (DBG & 8) { __builtin_amdgcn_sched_barrier(0); st_acc[6] += __builtin_amdgcn_s_memtime() - sa; __builtin_amdgcn_sched_barrier(0); }
-        if (wave == 0) lsd_store(k + 1, (k + 1) % 3);
-      }
-      if (k + 2 < NS) {
-        stage_load(k + 2);
-        if (wave == 0) lsd_load(k + 2);
-      }
-    }
-    const bool summer = BACK && grp == 1 && k >= 2 && !(DBG & 512);
+    if (wave == 4 && k + 2 < NS && !(DBG & 512)) lsd_load(k + 2);  // raw; stored at the start of V(k)
     if constexpr (DBG & 8) { __builtin_amdgcn_sched_barrier(0); st_acc[4] += __builtin_amdgcn_s_memtime() - sa; }
     if constexpr (!(DBG & 16)) __builtin_amdgcn_s_setprio(1);
     const unsigned short* const tb = tiles + ((k + 2) % 3) * PP_TILE;  // sub-block k-1
@@ -1183,11 +1175,8 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_bxpp_kernel(const BwdArgs p, 
       cols(tb + 3 * PP_PIECE, 0, a0);                                                  // dO columns, k-step 0
       PP_PIN();
       cols(tb + 3 * PP_PIECE, 1, a1); PP_PIN(); dv = mm(a0, pf[0], dv); PP_PIN();  // dV^T += dO^T P
-      if (summer) sum_read(k & 1, 0, 4);
       cols(tb, 0, a0);                PP_PIN(); dv = mm(a1, pf[1], dv); PP_PIN();
-      if (summer) sum_read(k & 1, 4, 8);
       cols(tb, 1, a1);                PP_PIN(); dk = mm(a0, sf[0], dk); PP_PIN();  // dK^T += Q^T dS
-      if (summer) sum_store(k - 2);
       imgf(0, a0);                    PP_PIN(); dk = mm(a1, sf[1], dk); PP_PIN();
       if constexpr (!(DBG & 1024)) {
 #pragma unroll
@@ -1222,6 +1211,13 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_bxpp_kernel(const BwdArgs p, 
   // ================================================================ V(k): everything that is not an MFMA
   auto seg_v = [&](const int k, auto has_back, auto has_front) {
     if constexpr (DBG & 8) { __builtin_amdgcn_sched_barrier(0); sa = __builtin_amdgcn_s_memtime(); st_acc[1] += sa - sb; }
+    if (grp == 1 && k + 2 < NS && !(DBG & 512)) {  // sub-block k+2 into the ring (global work first: it has this whole
+      const int buf = (k + 2) % 3;                  // segment and the next to land)
+      if (wave == 4) lsd_store(k + 2, buf);  // BEFORE the pieces: vmcnt counts in order, and its loads are an interval old
+      PP_PIN();
+#pragma unroll
+      for (int u = 0; u < 3; ++u) stage_piece(k + 2, buf, (wave - 4) * 3 + u);
+    }
     if constexpr (decltype(has_back)::value) {  // dQ(k-1) partial [32 queries][CP] -> this wavefront's slot
       float* const sl = myslot + ((k - 1) & 1) * PP_SLOT;
 #pragma unroll
@@ -1279,6 +1275,10 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_bxpp_kernel(const BwdArgs p, 
           *reinterpret_cast<u32x2*>(img + (pc * 32 + li) * TP + 8 * g + 4 * lh) =
               (u32x2){sf[g >> 1][pc][2 * (g & 1)], sf[g >> 1][pc][2 * (g & 1) + 1]};
     }
+    if (grp == 0 && k >= 2 && !(DBG & 512)) {  // sub-block k-2's eight dQ partials (complete since the barrier before this
+      sum_read(k & 1, 0, 8);                   // segment) -> its rows of the dQ plane
+      sum_store(k - 2);
+    }
     if constexpr (DBG & 8) { __builtin_amdgcn_sched_barrier(0); sb = __builtin_amdgcn_s_memtime(); st_acc[2] += sb - sa; }
   };
   auto sync = [&]() {
@@ -1287,28 +1287,31 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_bxpp_kernel(const BwdArgs p, 
   };
 
   if (NS > 0) {  // (every wavefront of the workgroup has the same NS: the barrier counts agree)
-    if (grp == 0) {  // prologue: sub-block 0 into the ring, sub-block 1 into the registers (M(k) stores k+1, loads k+2)
-      stage_load(0);
-      if (wave == 0) lsd_load(0);
-      stage_store(0);
-      if (wave == 0) lsd_store(0, 0);
-      stage_load(1);  // NS >= 2
-      if (wave == 0) lsd_load(1);
+    {  // prologue: sub-blocks 0 and 1 (twelve pieces each, three per wavefront)
+#pragma unroll
+      for (int u = 0; u < 3; ++u) {
+        const int id = wave * 3 + u;  // 0..23
+        stage_piece(id / 12, id / 12, id % 12);
+      }
+      if (wave < 2) {
+        lsd_load(wave);
+        lsd_store(wave, wave);
+      }
     }
     PP_BARRIER_VM();
     if (grp == 1) PP_BARRIER();  // one segment behind
     seg_m(0, no_t(), yes_t());
-    PP_BARRIER();
+    PP_BARRIER_VM();
     seg_v(0, no_t(), yes_t());
     sync();
     for (int k = 1; k < NS; ++k) {
       seg_m(k, yes_t(), yes_t());
-      PP_BARRIER();
+      PP_BARRIER_VM();
       seg_v(k, yes_t(), yes_t());
       sync();
     }
     seg_m(NS, yes_t(), no_t());
-    PP_BARRIER();
+    PP_BARRIER_VM();
     seg_v(NS, yes_t(), no_t());
     sync();
     if (grp == 0) {
@@ -2045,9 +2048,7 @@ int launch_fused_bx(BwdArgs a, float* ws, float* bx_ws, hipStream_t s) {
         default: return (Kern)attn_bwd_bxpp_kernel<0>;
       }
     }();
-    static SfLdsAttr pp_attr;
-    if (!sf_ensure_dyn_lds(pp_attr, reinterpret_cast<const void*>(pp), PP_LDS_BYTES)) return SF_ELAUNCH;
-    hipLaunchKernelGGL(pp, dim3(a.B * a.zs * a.nt), dim3(512), PP_LDS_BYTES, s, a, ws, qb, db, sf_cdiv(a.N, qt));
+    hipLaunchKernelGGL(pp, dim3(a.B * a.zs * a.nt), dim3(512), 0, s, a, ws, qb, db, sf_cdiv(a.N, qt));  // static LDS
   } else {
     static SfLdsAttr lds_attr;
     if (!sf_ensure_dyn_lds(lds_attr, reinterpret_cast<const void*>(kern), bxb_lds_bytes(NW) + pad)) return SF_ELAUNCH;
