@@ -700,6 +700,21 @@ def main():
                                           "frac": round(by / fam["dwconv"] / 1e9 / 8000.0, 4),
                                           "ms_per_step": family_ms["dwconv"]}
 
+    # ---- the gradient buffer as ONE integer, on a canonical state: seeded parameters / BN buffers, seeded generator
+    #      (dropout), one more step.  Every kernel and RCCL's reduction order are deterministic, so the chunked and the
+    #      single-collective schedule must agree on it bit for bit (tests/test_multigpu_gpu.py) — the number of steps a
+    #      run took to reach its steady state must not enter.  Every rank runs the step (it carries the collective).
+    ghash = None
+    if train:
+        from paramgen import fill_state_dict
+        with torch.no_grad():
+            fill_state_dict(model.state_dict(), PARAM_SEED)
+        torch.manual_seed(20250 + rank)
+        with torch.cuda.stream(side):
+            step()
+        torch.cuda.synchronize()
+        ghash = int(flat.flat.view(torch.int32).to(torch.int64).sum().item()) & 0xffffffffffff
+
     if rank == 0:
         clips_total = batch * world * args.steps
         res = {
@@ -749,9 +764,6 @@ def main():
         if affinity is not None:
             res["rank0_cpu_affinity"] = affinity
         if train:
-            # the flat gradient buffer of the last timed step as one integer (every kernel and RCCL's reduction order are
-            # deterministic: the chunked and the single-collective schedule must agree on it bit for bit)
-            ghash = int(flat.flat.view(torch.int32).to(torch.int64).sum().item()) & 0xffffffffffff
             res["allreduce"] = {"chunks_per_step": flat.chunks_last_step, "grad_hash": ghash,
                                 "schedule": "one collective after the backward" if args.no_overlap_allreduce else
                                 "flat fp32 gradient in chunks [s5+head | s4+s4_fuse | rest] on a comm stream, each issued "

@@ -483,7 +483,13 @@ static int bn_bwd_reduce_launch(const float* dy, int dy_cs, int dy_coff, const f
   int CB, P;
   // the ticket ring is allocated on first use; while a stream capture is under way before that, the two-launch form runs
   const bool ring = sf_ticket_ring_ready((hipStream_t)stream);
-  const bool few = ring && sf_tickets_level() == 2 && S == 1 && vec4 && C >= 256;  // short last-arriver walk: <= 64 partials
+  // short last-arriver walk: <= 64 partials.  That is also at most 64 x C/64 workgroups, which streams the big early
+  // tensors at a third of the bandwidth when the kernel runs ALONE (round 5, tools/microbench/bn_passes.py: 200 704 rows
+  // x 256 channels 317 us with tickets, 123 us as partial + final launches) — but in the step these launches run beside
+  // the other pathway's kernels, and restricting the tickets to <= 16 384 rows measured 54.47-54.55 ms against
+  // 54.26-54.54 with them everywhere (three alternations on one box): the thin launch leaves the chip to its neighbour
+  // and the final launch it saves is on the stream's critical path.  Kept as it was.
+  const bool few = ring && sf_tickets_level() == 2 && S == 1 && vec4 && C >= 256;
   const bool fused = (ring && sf_tickets_enabled()) || few;
   red_geometry(group_rows, C, vec4 ? 4 : 1, &CB, &P);
   const int max_p = few ? 64 : (fused ? 512 : MAX_P);

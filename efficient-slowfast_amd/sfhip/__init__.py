@@ -13,7 +13,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "libsfhip.so")
+# SF_LIB: an alternative build of the library (A/B runs of compiler flags inside one GPU lease; default: the in-tree build)
+_LIB_PATH = os.environ.get("SF_LIB") or os.path.join(_HERE, "libsfhip.so")
 _lib = None
 
 ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_SOFTMAX, ACT_HSIGMOID, ACT_RELU6 = 0, 1, 2, 3, 4, 5

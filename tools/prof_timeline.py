@@ -82,8 +82,8 @@ print("idle per 5 ms slice:", " ".join("%d:%.1f" % (k * 5, v / 1e6) for k, v in 
 
 # ---- time with NO MFMA-bound kernel in flight (convolutions, attention sweeps): what runs then is what the two-stream
 #      schedule fails to hide behind the matrix pipes
-MFMA_KEYS = ("conv_wave", "conv_wgrad", "conv_stem", "conv_igemm", "conv_kernel", "attn_fwd_kernel", "attn_bwd",
-             "attn_small", "attn_lane")
+MFMA_KEYS = ("conv_wave", "conv_wgrad", "conv_stem", "conv_igemm", "conv_kernel", "conv_bx", "conv_pw_bx", "conv_small",
+             "attn_fwd", "attn_bwd", "attn_small", "attn_lane")
 
 
 def is_mfma(name):
