@@ -1123,18 +1123,11 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_bxpp_kernel(const BwdArgs p, 
       da[pc] = *reinterpret_cast<const u32x4*>(tf + (3 + pc) * PP_PIECE + ro);
     }
   };
-  auto init_acc = [&](int bf) {  // -LSE and -D are the initial accumulators of S' and dP
-    if constexpr (DBG & 1024) return;
+  // S' and dP start from zero; -LSE and -D are added in V(k), which reads them there (eight 16-byte LDS reads that carry
+  // 256 bytes of distinct data: in M they queued in front of the fragment reads the MFMAs wait for)
+  auto init_acc = [&](int) {
 #pragma unroll
-    for (int g4 = 0; g4 < 4; ++g4) {
-      const f32x4 l4 = *reinterpret_cast<const f32x4*>(lsd + bf * 64 + 8 * g4 + 4 * lh);
-      const f32x4 d4 = *reinterpret_cast<const f32x4*>(lsd + bf * 64 + 32 + 8 * g4 + 4 * lh);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        s[4 * g4 + e] = l4[e];
-        dp[4 * g4 + e] = d4[e];
-      }
-    }
+    for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
   };
   auto mm = [&](const u32x4 (&a)[3], const u32x4 (&bb)[3], f32x16 c) -> f32x16 {
     if constexpr (DBG & 64) {  // timing ablation: no MFMAs (the fragments are still read)
@@ -1164,41 +1157,54 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_bxpp_kernel(const BwdArgs p, 
   auto seg_m = [&](const int k, auto has_back, auto has_front) {
     constexpr bool BACK = decltype(has_back)::value, FRONT = decltype(has_front)::value;
     if constexpr (DBG & 8) { __builtin_amdgcn_sched_barrier(0); sa = __builtin_amdgcn_s_memtime(); }
-    if (wave == 4 && k + 2 < NS && !(DBG & 512)) lsd_load(k + 2);  // raw; stored at the start of V(k)
+    if (wave == 4 && k + 2 < NS && !(DBG & 512) && !(DBG & 4096)) lsd_load(k + 2);  // raw; stored at the start of V(k)
     if constexpr (DBG & 8) { __builtin_amdgcn_sched_barrier(0); st_acc[4] += __builtin_amdgcn_s_memtime() - sa; }
     if constexpr (!(DBG & 16)) __builtin_amdgcn_s_setprio(1);
     const unsigned short* const tb = tiles + ((k + 2) % 3) * PP_TILE;  // sub-block k-1
     const int bf = k % 3;
     const unsigned short* const tf = tiles + bf * PP_TILE;             // sub-block k
-    u32x4 a0[3] = {}, a1[3] = {}, qa0[3] = {}, da0[3] = {}, qa1[3] = {}, da1[3] = {};
+    u32x4 a0[3] = {}, a1[3] = {}, a2[3] = {}, qa0[3] = {}, da0[3] = {}, qa1[3] = {}, da1[3] = {};
+    // fragment reads run TWO chains (384 matrix-pipe cycles) ahead of the MFMAs that take them: with the partner's vector
+    // segment and the LDS stores of four other wavefronts in flight a read needs ~300 cycles, and one chain ahead left
+    // every chain waiting (SF_ATTN_BX_DBG=128, no fragment reads: 9.1 -> 6.7 ms)
+    // ... and they are dealt ONE per MFMA gap (sched_group_barrier: MFMA, LDS read, MFMA, LDS read ...): six reads in a
+    // row in front of a chain hold the wavefront's issue past the previous MFMA's 32-cycle shadow
+#define PP_MIX(n)                                              \
+  do {                                                         \
+    _Pragma("unroll") for (int i_ = 0; i_ < (n); ++i_) {       \
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);       \
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);       \
+    }                                                          \
+    __builtin_amdgcn_sched_barrier(0);                         \
+  } while (0)
     if constexpr (BACK) {
-      cols(tb + 3 * PP_PIECE, 0, a0);                                                  // dO columns, k-step 0
+      cols(tb + 3 * PP_PIECE, 0, a0);                                                     // dO columns, k-step 0
+      cols(tb + 3 * PP_PIECE, 1, a1);                                                     //             k-step 1
       PP_PIN();
-      cols(tb + 3 * PP_PIECE, 1, a1); PP_PIN(); dv = mm(a0, pf[0], dv); PP_PIN();  // dV^T += dO^T P
-      cols(tb, 0, a0);                PP_PIN(); dv = mm(a1, pf[1], dv); PP_PIN();
-      cols(tb, 1, a1);                PP_PIN(); dk = mm(a0, sf[0], dk); PP_PIN();  // dK^T += Q^T dS
-      imgf(0, a0);                    PP_PIN(); dk = mm(a1, sf[1], dk); PP_PIN();
+      cols(tb, 0, a2); dv = mm(a0, pf[0], dv); PP_MIX(6);                                  // dV^T += dO^T P
+      cols(tb, 1, a0); dv = mm(a1, pf[1], dv); PP_MIX(6);
+      imgf(0, a1);     dk = mm(a2, sf[0], dk); PP_MIX(6);                                  // dK^T += Q^T dS
+      imgf(1, a2);     dk = mm(a0, sf[1], dk); PP_MIX(6);
       if constexpr (!(DBG & 1024)) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) dqp[r] = 0.f;
       }
-      imgf(1, a1);                    PP_PIN(); dqp = mm(a0, kbr[0], dqp); PP_PIN();  // dQ(k-1) = dS K
+      if constexpr (FRONT) rows(tf, 0, qa0, da0);
+      dqp = mm(a1, kbr[0], dqp);                                                          // dQ(k-1) = dS K
+      PP_MIX(6);
       if constexpr (FRONT) {
         init_acc(bf);
-        rows(tf, 0, qa0, da0);
+        rows(tf, 1, qa1, da1);
       }
-      PP_PIN();
-      dqp = mm(a1, kbr[1], dqp);
-      PP_PIN();
-      if constexpr (DBG & 8) { st_acc[5] += __builtin_amdgcn_s_memtime() - sa; __builtin_amdgcn_sched_barrier(0); }
+      dqp = mm(a2, kbr[1], dqp);
+      PP_MIX(6);
     } else {
       init_acc(bf);
       rows(tf, 0, qa0, da0);
-      PP_PIN();
-    }
-    if constexpr (FRONT) {  // S' = Q K'^T - LSE,  dP = dO V^T - D   (queries in registers, key on the lane)
       rows(tf, 1, qa1, da1);
       PP_PIN();
+    }
+    if constexpr (FRONT) {  // S' = Q K'^T,  dP = dO V^T   (queries in registers, key on the lane)
       s = mm(qa0, kfb[0], s);
       dp = mm(da0, vfb[0], dp);
       PP_PIN();
@@ -1211,7 +1217,7 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_bxpp_kernel(const BwdArgs p, 
   // ================================================================ V(k): everything that is not an MFMA
   auto seg_v = [&](const int k, auto has_back, auto has_front) {
     if constexpr (DBG & 8) { __builtin_amdgcn_sched_barrier(0); sa = __builtin_amdgcn_s_memtime(); st_acc[1] += sa - sb; }
-    if (grp == 1 && k + 2 < NS && !(DBG & 512)) {  // sub-block k+2 into the ring (global work first: it has this whole
+    if (grp == 1 && k + 2 < NS && !(DBG & 512) && !(DBG & 4096)) {  // sub-block k+2 into the ring (global work first: it has this whole
       const int buf = (k + 2) % 3;                  // segment and the next to land)
       if (wave == 4) lsd_store(k + 2, buf);  // BEFORE the pieces: vmcnt counts in order, and its loads are an interval old
       PP_PIN();
@@ -1236,10 +1242,19 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_bxpp_kernel(const BwdArgs p, 
       for (int i = 0; i < 8; ++i) pf[0][0][i & 3] ^= __builtin_bit_cast(unsigned, f[i]);
     }
     if constexpr (decltype(has_front)::value && !(DBG & 32) && !(DBG & 256)) {
+      {
+        const int bf = k % 3;
+        f32x4 l4[4], d4[4];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) s[r] = __builtin_amdgcn_exp2f(s[r]);  // P
+        for (int g4 = 0; g4 < 4; ++g4) {
+          l4[g4] = *reinterpret_cast<const f32x4*>(lsd + bf * 64 + 8 * g4 + 4 * lh);
+          d4[g4] = *reinterpret_cast<const f32x4*>(lsd + bf * 64 + 32 + 8 * g4 + 4 * lh);
+        }
 #pragma unroll
-      for (int r = 0; r < 16; ++r) dp[r] *= s[r];  // dS = P dP
+        for (int r = 0; r < 16; ++r) s[r] = __builtin_amdgcn_exp2f(s[r] + l4[r >> 2][r & 3]);  // P = 2^(S' - LSE)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dp[r] = (dp[r] + d4[r >> 2][r & 3]) * s[r];  // dS = P (dP - D)
+      }
       // Both three-way splits STAGE by stage over all 16 pairs (in place: s and dp end as the third residuals): the
       // partner wavefront is in its MFMA segment and covers nothing, so a pair's own chain (convert -> expand ->
       // subtract -> convert ...: seven dependent steps) must not be what the vector pipe waits for — the compiler's
@@ -1275,7 +1290,7 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_bxpp_kernel(const BwdArgs p, 
           *reinterpret_cast<u32x2*>(img + (pc * 32 + li) * TP + 8 * g + 4 * lh) =
               (u32x2){sf[g >> 1][pc][2 * (g & 1)], sf[g >> 1][pc][2 * (g & 1) + 1]};
     }
-    if (grp == 0 && k >= 2 && !(DBG & 512)) {  // sub-block k-2's eight dQ partials (complete since the barrier before this
+    if (grp == 0 && k >= 2 && !(DBG & 512) && !(DBG & 2048)) {  // sub-block k-2's eight dQ partials (complete since the barrier before this
       sum_read(k & 1, 0, 8);                   // segment) -> its rows of the dQ plane
       sum_store(k - 2);
     }
@@ -2044,7 +2059,16 @@ int launch_fused_bx(BwdArgs a, float* ws, float* bx_ws, hipStream_t s) {
         case 904: return (Kern)attn_bwd_bxpp_kernel<904>;    // 392 + no staging / slot sums
         case 1928: return (Kern)attn_bwd_bxpp_kernel<1928>;  // 904 + no accumulator initialisation
         case 776: return (Kern)attn_bwd_bxpp_kernel<776>;    // 264 + no staging / slot sums
-        case 520: return (Kern)attn_bwd_bxpp_kernel<520>;    // real V, no staging / slot sums  // V segments with the probe's register-only vector work, stamps  // M segments without fragment reads (results invalid), stamps
+        case 520: return (Kern)attn_bwd_bxpp_kernel<520>;    // real V, no staging / slot sums
+        case 256: return (Kern)attn_bwd_bxpp_kernel<256>;    // (no stamps: a stamp's s_memtime drains lgkmcnt)
+        case 384: return (Kern)attn_bwd_bxpp_kernel<384>;
+        case 896: return (Kern)attn_bwd_bxpp_kernel<896>;
+        case 1920: return (Kern)attn_bwd_bxpp_kernel<1920>;
+        case 512: return (Kern)attn_bwd_bxpp_kernel<512>;
+        case 128: return (Kern)attn_bwd_bxpp_kernel<128>;
+        case 640: return (Kern)attn_bwd_bxpp_kernel<640>;
+        case 2048: return (Kern)attn_bwd_bxpp_kernel<2048>;  // no slot sums (results invalid)
+        case 4096: return (Kern)attn_bwd_bxpp_kernel<4096>;  // no staging (results invalid)  // V segments with the probe's register-only vector work, stamps  // M segments without fragment reads (results invalid), stamps
         default: return (Kern)attn_bwd_bxpp_kernel<0>;
       }
     }();
