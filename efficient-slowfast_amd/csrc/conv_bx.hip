@@ -102,37 +102,41 @@ __global__ __launch_bounds__(512, 2) void conv_bx_kernel(const BxArgs p) {
   }
   // AF32 loader: wave w, piece u brings rows 32 w + 16 u + (lane >> 2), 16-byte slot lane & 3 = source chunk
   // slot ^ ((row >> 2) & 3) (conflict-free fragment reads, see conv_pw_bx_kernel)
-  int f_t0[2], f_h0[2], f_w0[2], f_n[2];
-  bool f_ok[2];
-  unsigned f_chunk[2];
+  // (plain structs, not arrays indexed by u: hipcc kept the arrays in SCRATCH — 40 bytes per lane, re-read by every K
+  // step's address computation with a memory latency each and counted in the same vmcnt as the LDS-DMA pieces)
+  struct FRow { int t0, h0, w0, n; bool ok; unsigned chunk; };
+  FRow fr0 = {0, 0, 0, 0, false, 0u}, fr1 = fr0;
   if constexpr (AF32) {
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
+    auto frow = [&](int u) -> FRow {
+      FRow f;
       const int r = 32 * wave + 16 * u + (lane >> 2);
       const int fm = m0 + r;
-      f_ok[u] = fm < p.M;
-      f_chunk[u] = (unsigned)((lane & 3) ^ ((r >> 2) & 3)) * 16u;
-      const unsigned mm = f_ok[u] ? (unsigned)fm : 0u;
+      f.ok = fm < p.M;
+      f.chunk = (unsigned)((lane & 3) ^ ((r >> 2) & 3)) * 16u;
+      const unsigned mm = f.ok ? (unsigned)fm : 0u;
       const unsigned q1 = mdiv(mm, p.wo_mul, p.wo_sh);
       const unsigned wo = mm - q1 * (unsigned)d.Wo;
       const unsigned q2 = mdiv(q1, p.ho_mul, p.ho_sh);
       const unsigned ho = q1 - q2 * (unsigned)d.Ho;
       const unsigned q3 = mdiv(q2, p.to_mul, p.to_sh);
       const unsigned to = q2 - q3 * (unsigned)d.To;
-      f_n[u] = (int)q3;
-      f_t0[u] = d.transposed ? (int)to + d.pT : (int)to * d.sT - d.pT;
-      f_h0[u] = d.transposed ? (int)ho + d.pH : (int)ho * d.sH - d.pH;
-      f_w0[u] = d.transposed ? (int)wo + d.pW : (int)wo * d.sW - d.pW;
-    }
+      f.n = (int)q3;
+      f.t0 = d.transposed ? (int)to + d.pT : (int)to * d.sT - d.pT;
+      f.h0 = d.transposed ? (int)ho + d.pH : (int)ho * d.sH - d.pH;
+      f.w0 = d.transposed ? (int)wo + d.pW : (int)wo * d.sW - d.pW;
+      return f;
+    };
+    fr0 = frow(0);
+    fr1 = frow(1);
   }
-  auto f_voff = [&](int u, int kt, int kh, int kw) -> unsigned {  // byte offset of the row's chunk in the fp32 tensor
-    const int ti = d.transposed ? f_t0[u] - kt * d.dT : f_t0[u] + kt * d.dT;
-    const int hi = d.transposed ? f_h0[u] - kh * d.dH : f_h0[u] + kh * d.dH;
-    const int wi = d.transposed ? f_w0[u] - kw * d.dW : f_w0[u] + kw * d.dW;
-    const bool ok = f_ok[u] && (unsigned)ti < (unsigned)d.Ti && (unsigned)hi < (unsigned)d.Hi && (unsigned)wi < (unsigned)d.Wi;
+  auto f_voff = [&](const FRow f, int kt, int kh, int kw) -> unsigned {  // byte offset of the row's chunk in the fp32 tensor
+    const int ti = d.transposed ? f.t0 - kt * d.dT : f.t0 + kt * d.dT;
+    const int hi = d.transposed ? f.h0 - kh * d.dH : f.h0 + kh * d.dH;
+    const int wi = d.transposed ? f.w0 - kw * d.dW : f.w0 + kw * d.dW;
+    const bool ok = f.ok && (unsigned)ti < (unsigned)d.Ti && (unsigned)hi < (unsigned)d.Hi && (unsigned)wi < (unsigned)d.Wi;
     if (!ok) return 0x80000000u;  // past the buffer: the DMA writes zeros
-    const unsigned r = (unsigned)(((f_n[u] * d.Ti + ti) * d.Hi + hi) * d.Wi + wi);
-    return (r * (unsigned)d.in_cs + (unsigned)d.in_coff) * 4u + f_chunk[u];
+    const unsigned r = (unsigned)(((f.n * d.Ti + ti) * d.Hi + hi) * d.Wi + wi);
+    return (r * (unsigned)d.in_cs + (unsigned)d.in_coff) * 4u + f.chunk;
   };
   const unsigned row_bytes = (unsigned)d.Cin * 2u;
   auto a_voff = [&](int kt, int kh, int kw) -> unsigned {  // byte offset of this lane's row for a tap (or the zero row)
@@ -158,66 +162,84 @@ __global__ __launch_bounds__(512, 2) void conv_bx_kernel(const BxArgs p) {
   // touches (rows + halo) x (its few channel chunks) and the taps' re-reads hit L1 / L2; tap-major order streamed
   // whole rows of all channels once per tap.  Strided layers (whose taps' rows do not overlap) keep the tap-major order:
   // measured 171 vs 135 TFLOP/s on the 1x3x3 stride-2 layer; the stride-1 layers are within noise either way.
-  int l_c = p.tap_major ? ks0 % p.cpk : ks0 / p.ntaps;          // 16-channel chunk
-  int l_tap = p.tap_major ? ks0 / p.cpk : ks0 - l_c * p.ntaps;
-  int l_kw = l_tap % d.kW, l_kh = (l_tap / d.kW) % d.kH, l_kt = l_tap / (d.kW * d.kH);
-  // one step's loads = 6 LDS-DMA pieces per wave (3 A planes, 3 B planes): `piece(stage, g)` issues piece g of the
-  // loader's current step, `advance()` moves the loader to the next step
-  unsigned cur_voff = 0, cur_aso = 0, cur_bso = 0, cur_f[2] = {0, 0};
-  auto prepare = [&]() {
-    if constexpr (AF32) {
-      cur_f[0] = f_voff(0, l_kt, l_kh, l_kw);
-      cur_f[1] = f_voff(1, l_kt, l_kh, l_kw);
-      cur_aso = (unsigned)l_c * 64u;
-    } else {
-      cur_voff = a_voff(l_kt, l_kh, l_kw);
-      cur_aso = (unsigned)l_c * (unsigned)BXC_ROWB;
+  // The loader's K position is a VALUE (struct LS, advanced by a pure function), wave-uniform and said so
+  // (readfirstlane: the integer divisions run on the vector ALU).  As five int locals advanced inside [&] lambdas by
+  // `if (++x == n) { x = 0; ++y; }` ladders it stayed in 40 bytes of SCRATCH: hipcc merged the ladders' `++l_kt` /
+  // `++l_c` into one increment through a pointer to either, which defeated scalar replacement for all ten loader
+  // variables — ~15 scratch loads / stores per K step, each a memory latency in front of the next step's DMA addresses
+  // and each counted by the same vmcnt as the LDS-DMA pieces, and on every tap wrap a flat_load behind
+  // s_waitcnt vmcnt(0) lgkmcnt(0): a full drain of the three-stage pipeline (round 5; hipcc -S:
+  // private_segment_fixed_size 40 -> 0).
+  struct LS { int c, tap, kw, kh, kt; };
+  LS ls;
+  ls.c = __builtin_amdgcn_readfirstlane(p.tap_major ? ks0 % p.cpk : ks0 / p.ntaps);          // 16-channel chunk
+  ls.tap = __builtin_amdgcn_readfirstlane(p.tap_major ? ks0 / p.cpk : ks0 - ls.c * p.ntaps);
+  ls.kw = __builtin_amdgcn_readfirstlane(ls.tap % d.kW);
+  ls.kh = __builtin_amdgcn_readfirstlane((ls.tap / d.kW) % d.kH);
+  ls.kt = __builtin_amdgcn_readfirstlane(ls.tap / (d.kW * d.kH));
+  const int tap_major = p.tap_major, cpk = p.cpk, kW = d.kW, kH = d.kH, kT = d.kT;
+  auto next = [=](const LS o) -> LS {
+    LS n;
+    if (tap_major) {
+      const int c1 = o.c + 1;
+      const bool wc = c1 == cpk;
+      n.c = wc ? 0 : c1;
+      n.tap = o.tap + (wc ? 1 : 0);
+      const int w1 = o.kw + (wc ? 1 : 0);
+      const bool ww = w1 == kW;
+      n.kw = ww ? 0 : w1;
+      const int h1 = o.kh + (ww ? 1 : 0);
+      const bool wh = h1 == kH;
+      n.kh = wh ? 0 : h1;
+      n.kt = o.kt + (wh ? 1 : 0);
+      return n;
     }
-    cur_bso = (unsigned)(l_tap * p.cpk + l_c) * (unsigned)BXC_ROWB;
+    const int w1 = o.kw + 1;
+    const bool ww = w1 == kW;
+    n.kw = ww ? 0 : w1;
+    const int h1 = o.kh + (ww ? 1 : 0);
+    const bool wh = h1 == kH;
+    n.kh = wh ? 0 : h1;
+    const int t1 = o.kt + (wh ? 1 : 0);
+    const bool wt = t1 == kT;  // next channel chunk
+    n.kt = wt ? 0 : t1;
+    n.tap = wt ? 0 : o.tap + 1;
+    n.c = o.c + (wt ? 1 : 0);
+    return n;
   };
-  auto piece = [&](int stage, int g) {
-    if (g < 3) {
-      if constexpr (AF32) {
-        if (g < 2)
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rs, (lds_void*)(smem + stage * STAGE + wave * 2048 + g * 1024), 16,
-                                                   cur_f[g], cur_aso, 0, 0);
-      } else {
-        char* const sa = smem + stage * STAGE + wave * 1024;
+  // one step's loads = 6 LDS-DMA pieces per wave (3 A planes, 3 B planes; fp32 rows: 2 + 3)
+  auto issue = [&](int stage) {
+    const LS l = ls;
+    unsigned cur_voff = 0, cur_aso, cur_f0 = 0, cur_f1 = 0;
+    if constexpr (AF32) {
+      cur_f0 = f_voff(fr0, l.kt, l.kh, l.kw);
+      cur_f1 = f_voff(fr1, l.kt, l.kh, l.kw);
+      cur_aso = (unsigned)l.c * 64u;
+    } else {
+      cur_voff = a_voff(l.kt, l.kh, l.kw);
+      cur_aso = (unsigned)l.c * (unsigned)BXC_ROWB;
+    }
+    const unsigned cur_bso = (unsigned)(l.tap * p.cpk + l.c) * (unsigned)BXC_ROWB;
+    if constexpr (AF32) {
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rs, (lds_void*)(smem + stage * STAGE + wave * 2048), 16, cur_f0, cur_aso,
+                                               0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rs, (lds_void*)(smem + stage * STAGE + wave * 2048 + 1024), 16, cur_f1,
+                                               cur_aso, 0, 0);
+    } else {
+      char* const sa = smem + stage * STAGE + wave * 1024;
+#pragma unroll
+      for (int g = 0; g < 3; ++g)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rs, (lds_void*)(sa + g * (BXC_BM * BXC_ROWB)), 16, cur_voff,
                                                  cur_aso + (unsigned)g * p.a_plane, 0, 0);
-      }
-    } else if (b_loader) {
+    }
+    if (b_loader) {
       char* const sb = smem + stage * STAGE + A_ST + wave * 1024;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(b_rs, (lds_void*)(sb + (g - 3) * (BN * BXC_ROWB)), 16, b_voff,
-                                               cur_bso + (unsigned)(g - 3) * p.b_plane, 0, 0);
-    }
-  };
-  auto advance = [&]() {
-    if (p.tap_major) {
-      if (++l_c == p.cpk) {
-        l_c = 0;
-        ++l_tap;
-        if (++l_kw == d.kW) {
-          l_kw = 0;
-          if (++l_kh == d.kH) { l_kh = 0; ++l_kt; }
-        }
-      }
-      return;
-    }
-    ++l_tap;
-    if (++l_kw == d.kW) {
-      l_kw = 0;
-      if (++l_kh == d.kH) {
-        l_kh = 0;
-        if (++l_kt == d.kT) { l_kt = 0; l_tap = 0; ++l_c; }  // next channel chunk
-      }
-    }
-  };
-  auto issue = [&](int stage) {
-    prepare();
 #pragma unroll
-    for (int g = 0; g < 6; ++g) piece(stage, g);
-    advance();
+      for (int g = 0; g < 3; ++g)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(b_rs, (lds_void*)(sb + g * (BN * BXC_ROWB)), 16, b_voff,
+                                                 cur_bso + (unsigned)g * p.b_plane, 0, 0);
+    }
+    ls = next(l);
   };
 
   // ---- fragment addresses: lane (r = lane & 31, h = lane >> 5) reads 16 bytes of row r, k = 8h .. 8h+7
@@ -830,12 +852,12 @@ bool bx_plan(const sf_conv_desc* d, BxPlan* pl, bool gate = true) {
   pl->a_rows = a_rows;
   // Time model in microseconds, fitted on MI355X with COLD operands (conv_bx_bench.py flushes the Infinity Cache in
   // front of every timed call, as inside a training step; back-to-back calls read 20-30 % faster): a workgroup needs
-  // ~2.4 us per K step of a 256-wide tile and ~1.85 of a 128-wide one — the loop is bound by the arrival of the
+  // ~2.05 us per K step of a 256-wide tile and ~1.6 of a 128-wide one — the loop is bound by the arrival of the
   // operand pieces in LDS, so the narrow tile is not half the wide one; the launch ends with its busiest CU; S > 1
   // writes S partial tiles and the finish kernel reads them back (~4 TB/s each way) — one workgroup per tile stores the
   // finished outputs itself.
   const bool scatter = d->os_T > 1 || d->os_H > 1 || d->os_W > 1;
-  const double step_us = pl->bn == 256 ? 2.4 : 1.85;
+  const double step_us = pl->bn == 256 ? 2.05 : 1.6;  // round 5 (loader state out of scratch): 2.4 / 1.85 before
   const double out_mb = (double)M * d->Cout * 4e-6;
   int best = 1;
   double best_t = 1e30;
