@@ -591,6 +591,15 @@ struct BxwArgs {
 __device__ __forceinline__ u32x2 lds_tr(const char* p) {
   return lds_read_tr(reinterpret_cast<const unsigned short*>(p));
 }
+// The same read as an instruction the compiler does not look into: its waitcnt pass puts s_waitcnt vmcnt(0) in front of
+// the ds_read_tr intrinsic whenever an LDS-DMA load is outstanding (no memory operand: it may read what the DMA
+// writes), which turns a three-stage LDS-DMA ring into one round trip per step.  The caller owns both counters: LDS
+// address = byte offset in the workgroup's LDS, and the data is there after bxw_lgkm_drain().
+__device__ __forceinline__ u32x2 lds_tr_raw(unsigned lds_byte_addr) {
+  u32x2 r;
+  asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(r) : "v"(lds_byte_addr));
+  return r;
+}
 
 template <int BCO>
 __global__ __launch_bounds__(512, 2) void conv_bx_wgrad_kernel(const BxwArgs p) {
@@ -693,6 +702,7 @@ __global__ __launch_bounds__(512, 2) void conv_bx_wgrad_kernel(const BxwArgs p) 
     for (int j = 0; j < NT; ++j)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
 
   if (nsteps > 0) issue(0);
   if (nsteps > 1) issue(1);
@@ -704,21 +714,35 @@ __global__ __launch_bounds__(512, 2) void conv_bx_wgrad_kernel(const BxwArgs p) 
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __builtin_amdgcn_s_barrier();
-    if (it + 2 < nsteps) issue((it + 2) % BXC_STAGES);
-    const char* const st = smem + (it % BXC_STAGES) * STAGE;
+    // This step's fragments by raw transposing reads (see lds_tr_raw: the intrinsic form made hipcc drain vmcnt in front
+    // of them every step — round 4's kernel ran one DMA round trip per K step, not three stages in flight), the loads
+    // of step it+2 behind them, one explicit LDS drain in front of the MFMAs.
+    const unsigned st = lds_base + (unsigned)((it % BXC_STAGES) * STAGE);
     u32x4 af[2][3], bf[NT][3];
 #pragma unroll
     for (int pc = 0; pc < 3; ++pc) {
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        const u32x2 lo = lds_tr(st + a_addr[i] + pc * PL_A), hi = lds_tr(st + a_addr[i] + pc * PL_A + 4 * ROW_A);
+        const u32x2 lo = lds_tr_raw(st + a_addr[i] + pc * PL_A), hi = lds_tr_raw(st + a_addr[i] + pc * PL_A + 4 * ROW_A);
         af[i][pc] = (u32x4){lo[0], lo[1], hi[0], hi[1]};
       }
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
-        const u32x2 lo = lds_tr(st + b_addr[j] + pc * PL_B), hi = lds_tr(st + b_addr[j] + pc * PL_B + 4 * ROW_B);
+        const u32x2 lo = lds_tr_raw(st + b_addr[j] + pc * PL_B), hi = lds_tr_raw(st + b_addr[j] + pc * PL_B + 4 * ROW_B);
         bf[j][pc] = (u32x4){lo[0], lo[1], hi[0], hi[1]};
       }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (it + 2 < nsteps) issue((it + 2) % BXC_STAGES);
+    __builtin_amdgcn_sched_barrier(0);
+    // every fragment register is an operand of the drain, so no MFMA can be scheduled in front of it
+#pragma unroll
+    for (int pc = 0; pc < 3; ++pc) {
+      if constexpr (NT == 4)
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(af[0][pc]), "+v"(af[1][pc]), "+v"(bf[0][pc]), "+v"(bf[1][pc]), "+v"(bf[2][pc]), "+v"(bf[3][pc]));
+      else
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(af[0][pc]), "+v"(af[1][pc]), "+v"(bf[0][pc]), "+v"(bf[1][pc]));
     }
 #pragma unroll
     for (int i = 0; i < 2; ++i)
