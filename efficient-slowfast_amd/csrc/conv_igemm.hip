@@ -391,12 +391,26 @@ __global__ void conv_splitk_finish4_kernel(const ConvArgs p) {
   const int c4 = d.Cout >> 2;
   const long total4 = (long)p.M * c4;
   if (idx >= total4) return;
-  const long m = idx / c4;
+  // (M * Cout / 4 < 2^31 for every launch of this library: one 32-bit division instead of a 64-bit one per thread)
+  const long m = total4 < 0x7fffffffL ? (long)((unsigned)idx / (unsigned)c4) : idx / c4;
   const int n = (int)(idx - m * c4) * 4;
   const long stride = (long)p.M * d.Cout;
   const float* src = p.ws + m * d.Cout + n;
+  // the S partials summed in split order (bit-reproducible), four loads in flight at a time (measured neutral: the
+  // ~28 us this launch costs a res4 3x3 layer — 77 MB at 2.8 TB/s, a quarter of the layer — are not load latency)
   f32x4 v = *reinterpret_cast<const f32x4*>(src);
-  for (int s = 1; s < p.ksplit; ++s) v += *reinterpret_cast<const f32x4*>(src + (long)s * stride);
+  int s = 1;
+  for (; s + 3 < p.ksplit; s += 4) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(src + (long)s * stride);
+    const f32x4 b = *reinterpret_cast<const f32x4*>(src + (long)(s + 1) * stride);
+    const f32x4 c = *reinterpret_cast<const f32x4*>(src + (long)(s + 2) * stride);
+    const f32x4 e = *reinterpret_cast<const f32x4*>(src + (long)(s + 3) * stride);
+    v += a;
+    v += b;
+    v += c;
+    v += e;
+  }
+  for (; s < p.ksplit; ++s) v += *reinterpret_cast<const f32x4*>(src + (long)s * stride);
   if (p.scale) v *= *reinterpret_cast<const f32x4*>(p.scale + n);
   if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
   if (p.res) v += *reinterpret_cast<const f32x4*>(p.res + m * d.res_cs + d.res_coff + n);
