@@ -31,6 +31,7 @@ struct BwdArgs {
   int zs;                                            // fused kernels: the swept (query) range is cut into zs parts
   float* dkp; float* dvp;                            // zs > 1: dK / dV partials [B][zs][N][CP], summed afterwards
   float* dqp;                                        // two-kernel form with zs > 1: dQ partials [B][zs][N][CP]
+  int stagger;                                       // bf16-piece sweeps: s_sleep units the OLDER wavefront of each SIMD waits per tile
 };
 
 constexpr float POS_BIG = 3.0e38f;
@@ -727,16 +728,18 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void attn_bwd_bx_kernel(const BwdA
   const int st_off = (st >> 2) * KP + (st & 3) * 8 + ((NW == 8 && tid >= 256) ? 3 * PL : 0);
   u32x4 rq[3], rd[NW == 8 ? 1 : 3];
   float rl = 0.f, rD = 0.f;
+  bool ld_ok = false;
   auto load_tile = [&](int t) {
 #pragma unroll
     for (int pc = 0; pc < 3; ++pc) {
       rq[pc] = *reinterpret_cast<const u32x4*>(qg + pc * plane + (long)t * (QT * 32));
       if constexpr (NW == 4) rd[pc] = *reinterpret_cast<const u32x4*>(dg + pc * plane + (long)t * (QT * 32));
     }
-    if (tid < QT) {
-      const int i = t * QT + tid;
-      rl = (i < N) ? -p.lse[brow + i] : -POS_BIG;  // P = 2^(s - BIG) = 0 for padded queries
-      rD = (i < N) ? -p.dvec[brow + i] * gamma : 0.f;
+    if (tid < QT) {  // raw loads only: a negation here made hipcc wait for vmcnt(0) — these loads, the tile's pieces and the
+      const int i = t * QT + tid;  // previous tile's plane store — at the top of every tile (wavefront 0)
+      ld_ok = i < N;
+      rl = p.lse[brow + (ld_ok ? i : 0)];
+      rD = p.dvec[brow + (ld_ok ? i : 0)];
     }
   };
   auto store_tile = [&]() {
@@ -746,8 +749,8 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void attn_bwd_bx_kernel(const BwdA
       if constexpr (NW == 4) *reinterpret_cast<u32x4*>(tile + (3 + pc) * PL + st_off) = rd[pc];
     }
     if (tid < QT) {
-      lsd[tid] = rl;
-      lsd[QT + tid] = rD;
+      lsd[tid] = ld_ok ? -rl : -POS_BIG;  // P = 2^(s - BIG) = 0 for padded queries
+      lsd[QT + tid] = ld_ok ? -rD * gamma : 0.f;
     }
   };
   // transposing reads: lane 4q+p of a 16-lane group addresses row q, columns 4p..4p+3 of the block
@@ -767,6 +770,12 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void attn_bwd_bx_kernel(const BwdA
     const bool more = (t + 1) < ntiles;
     if constexpr (DBG & 8) { __builtin_amdgcn_sched_barrier(0); st0 = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
     if (more) load_tile(t + 1);
+    // Both wavefronts of a SIMD leave the tile's barrier in the same phase (MFMAs of S' / dP first) and then fight for
+    // the matrix pipe and the vector port in lock step; letting the older one (which wins every arbitration) start a
+    // little later puts the pair in anti-phase: one in its MFMA stretch while the other splits / exponentiates.
+    if (NW == 8 && wave < 4 && p.stagger > 0) {
+      for (int i = 0; i < p.stagger; ++i) __builtin_amdgcn_s_sleep(16);  // 16 x 64 cycles each
+    }
     f32x16 dqp[2];
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub) {
@@ -1453,6 +1462,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_bx2_kernel(const BwdArgs p, f
   const int st_off = (tid >> 2) * KP + (tid & 3) * 8;
   u32x4 rq[2][3], rd[2][3];
   float rl = 0.f, rD = 0.f;
+  bool ld_ok = false;
   auto load_tile = [&](int t) {
 #pragma unroll
     for (int blk = 0; blk < 2; ++blk)
@@ -1461,10 +1471,11 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_bx2_kernel(const BwdArgs p, f
         rq[blk][pc] = *reinterpret_cast<const u32x4*>(qg + blk * blk_elems + pc * plane + (long)t * (QT * 32));
         rd[blk][pc] = *reinterpret_cast<const u32x4*>(dg + blk * blk_elems + pc * plane + (long)t * (QT * 32));
       }
-    if (tid < QT) {
+    if (tid < QT) {  // raw loads only (no arithmetic on them here: see attn_bwd_bx_kernel)
       const int i = t * QT + tid;
-      rl = (i < N) ? -p.lse[brow + i] : -POS_BIG;
-      rD = (i < N) ? -p.dvec[brow + i] * gamma : 0.f;
+      ld_ok = i < N;
+      rl = p.lse[brow + (ld_ok ? i : 0)];
+      rD = p.dvec[brow + (ld_ok ? i : 0)];
     }
   };
   auto store_tile = [&]() {
@@ -1476,8 +1487,8 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_bx2_kernel(const BwdArgs p, f
         *reinterpret_cast<u32x4*>(tile + (blk * 6 + 3 + pc) * PL + st_off) = rd[blk][pc];
       }
     if (tid < QT) {
-      lsd[tid] = rl;
-      lsd[QT + tid] = rD;
+      lsd[tid] = ld_ok ? -rl : -POS_BIG;  // P = 2^(s - BIG) = 0 for padded queries
+      lsd[QT + tid] = ld_ok ? -rD * gamma : 0.f;
     }
   };
   const int tr_row = (lane & 15) >> 2, tr_col = 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
@@ -1724,21 +1735,23 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void attn_bwd_bxp_kernel(const Bwd
   const int st_off = (st >> 2) * KP + (st & 3) * 8 + (st_d ? PL : 0);
   u32x4 rq, rd;
   float rl = 0.f, rD = 0.f;
+  bool ld_ok = false;
   auto load_tile = [&](int t) {
     rq = *reinterpret_cast<const u32x4*>(qg + (long)t * (QT * 32));
     if constexpr (NW == 4) rd = *reinterpret_cast<const u32x4*>(dg + (long)t * (QT * 32));
-    if (tid < QT) {
+    if (tid < QT) {  // raw loads only (no arithmetic on them here: see attn_bwd_bx_kernel)
       const int i = t * QT + tid;
-      rl = (i < N) ? -p.lse[brow + i] : -POS_BIG;
-      rD = (i < N) ? -p.dvec[brow + i] * gamma : 0.f;
+      ld_ok = i < N;
+      rl = p.lse[brow + (ld_ok ? i : 0)];
+      rD = p.dvec[brow + (ld_ok ? i : 0)];
     }
   };
   auto store_tile = [&]() {
     *reinterpret_cast<u32x4*>(tile + st_off) = rq;
     if constexpr (NW == 4) *reinterpret_cast<u32x4*>(tile + PL + st_off) = rd;
     if (tid < QT) {
-      lsd[tid] = rl;
-      lsd[QT + tid] = rD;
+      lsd[tid] = ld_ok ? -rl : -POS_BIG;  // P = 2^(s - BIG) = 0 for padded queries
+      lsd[QT + tid] = ld_ok ? -rD * gamma : 0.f;
     }
   };
   const int tr_row = (lane & 15) >> 2, tr_col = 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
@@ -2025,6 +2038,8 @@ int launch_fused_bx(BwdArgs a, float* ws, float* bx_ws, hipStream_t s) {
   a.dvp = a.dkp + part;
   unsigned short* qb = reinterpret_cast<unsigned short*>(bx_ws);
   unsigned short* db = qb + sf_attn_bx_plane_elems(a.B, a.N);
+  static const int stagger = [] { const char* e = getenv("SF_ATTN_STAGGER"); return e ? atoi(e) : 0; }();
+  a.stagger = stagger;
   int rc = sf_attn_bx_split(a.q, a.q_cs, nullptr, a.B, a.N, a.C, qb, nullptr, s);
   if (rc == SF_OK) rc = sf_attn_bx_split(a.dz, a.dz_cs, a.gamma, a.B, a.N, a.C, db, nullptr, s);
   if (rc != SF_OK) return rc;
@@ -2189,7 +2204,7 @@ extern "C" int sf_attn_bwd(const float* q, int q_cs, const float* k, int k_cs, c
   a.dq = dq; a.dk = dk; a.dv = dv;
   a.q_cs = q_cs; a.k_cs = k_cs; a.v_cs = v_cs; a.dz_cs = dz_cs; a.dq_cs = dq_cs; a.dk_cs = dk_cs; a.dv_cs = dv_cs;
   a.B = B; a.C = C; a.N = N; a.nt = sf_cdiv(N, 128);
-  a.zs = 1; a.dkp = a.dvp = a.dqp = nullptr;
+  a.zs = 1; a.dkp = a.dvp = a.dqp = nullptr; a.stagger = 0;
   hipStream_t s = (hipStream_t)stream;
   if (C <= 16)  // 16x16x4 tiles: no padded rows
     return sf_attn_small_bwd_dispatch(q, q_cs, k, k_cs, v, v_cs, dz, dz_cs, lse, dvec, gamma, dq, dq_cs, dk, dk_cs,
@@ -2258,7 +2273,7 @@ extern "C" int sf_attn_bwd_fused(const float* q, int q_cs, const float* k, int k
     a.q = q; a.k = k; a.v = v; a.dz = dz; a.lse = lse; a.dvec = dvec; a.gamma = gamma;
     a.dq = dq; a.dk = dk; a.dv = dv;
     a.q_cs = q_cs; a.k_cs = k_cs; a.v_cs = v_cs; a.dz_cs = dz_cs; a.dq_cs = dq_cs; a.dk_cs = dk_cs; a.dv_cs = dv_cs;
-    a.B = B; a.C = C; a.N = N; a.dqp = nullptr;
+    a.B = B; a.C = C; a.N = N; a.dqp = nullptr; a.stagger = 0;
     // 128 keys per workgroup: the dQ planes are a quarter of the d = 32 ones, and 8-wavefront barriers cost more than
     // halving them saves (N = 25 088, B = 8: 5.00 ms against 5.26).  SF_ATTN_BX_NW=8 forces the wide form.
     const bool wide = g_attn_nw == 8;
@@ -2275,6 +2290,7 @@ extern "C" int sf_attn_bwd_fused(const float* q, int q_cs, const float* k, int k
   a.q_cs = q_cs; a.k_cs = k_cs; a.v_cs = v_cs; a.dz_cs = dz_cs; a.dq_cs = dq_cs; a.dk_cs = dk_cs; a.dv_cs = dv_cs;
   a.B = B; a.C = C; a.N = N; a.nt = sf_cdiv(N, 128);
   a.dqp = nullptr;
+  a.stagger = 0;
   if (C > 64) {  // d = 128: both kernels of the two-kernel form, their sweeps cut into parts so that B * N/128 < 2 x 256
     hipStream_t st = (hipStream_t)stream;  // workgroups become B * N/128 * z; the parts are summed in part order
     a.zs = sf_sweep_parts((long)B * a.nt, sf_cdiv(N, 32));
