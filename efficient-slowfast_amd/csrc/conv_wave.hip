@@ -46,7 +46,8 @@ struct WaveArgs {
   int nk;              // K steps of 16 = ntaps * cin_pad / 16
   int cpk;             // K steps per tap = cin_pad / 16
   unsigned in_bytes, w_bytes;
-  unsigned out_bytes, res_bytes;  // persistent form: extents of the output / residual buffers (buffer_store bounds)
+  unsigned out_bytes, res_bytes;  // extents of the output / residual buffers (buffer load / store bounds)
+  int res_buf;                    // output and residual fit 32-bit buffer addressing: the one-pass epilogue's branch-free form
   int dbg;             // sf_conv_tune(5, mask), microbenchmarks only: 1 = drop the stores, 2 = every A row reads row 0
   int plain;           // 1: 1x1x1 kernel, stride 1, no padding, same extents -> input row == output row
   float* stats;        // != NULL: [part][Cout / 4][count, K, sum(v - K), sum((v - K)^2)][4 channels] of the stored outputs
@@ -244,6 +245,10 @@ __global__ __launch_bounds__(256) void conv_wave_kernel(const WaveArgs p) {
   constexpr int PER = (NV + KS * 64 - 1) / (KS * 64);
   float* const slab = smem + wave * (R * 16 * EP);
   const float* const slab0 = smem + (tslot * KS) * (R * 16 * EP);
+  typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+  const __amdgpu_buffer_rsrc_t res_rs =
+      __builtin_amdgcn_make_buffer_rsrc((void*)(p.res ? p.res : p.out), 0, (int)p.res_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t out_rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.out, 0, (int)p.out_bytes, 0x00020000);
   // Training-mode BN statistics of the outputs, taken where they are stored (removes the statistics kernel's read
   // pass over z): a lane always handles the same 4 channels (c4 = 4 * (lane % LPR)), so it keeps shifted sums
   // sum(v - K), sum((v - K)^2) with K = the tile's first row; lanes, then the tile's KS wavefronts, are combined at
@@ -251,6 +256,15 @@ __global__ __launch_bounds__(256) void conv_wave_kernel(const WaveArgs p) {
   // stats_merge_kernel with Chan's formula, so the shift may differ from tile to tile).
   const bool want_stats = p.stats != nullptr;
   f32x4 st_k = {0.f, 0.f, 0.f, 0.f}, st_1 = {0.f, 0.f, 0.f, 0.f}, st_2 = {0.f, 0.f, 0.f, 0.f};
+  // a lane handles the same four channels in every element of every round (64 % LPR == 0): its scale / bias once, not a
+  // load + s_waitcnt vmcnt(0) per element between the stores
+  static_assert(64 % LPR == 0, "lane -> channel group is fixed");
+  f32x4 sc4 = {1.f, 1.f, 1.f, 1.f}, bi4 = {0.f, 0.f, 0.f, 0.f};
+  {
+    const int n = n0 + (lane % LPR) * 4;
+    if (p.scale && n < d.Cout) sc4 = *reinterpret_cast<const f32x4*>(p.scale + n);
+    if (p.bias && n < d.Cout) bi4 = *reinterpret_cast<const f32x4*>(p.bias + n);
+  }
 #pragma unroll
   for (int i0 = 0; i0 < TM; i0 += R) {
 #pragma unroll
@@ -270,6 +284,15 @@ __global__ __launch_bounds__(256) void conv_wave_kernel(const WaveArgs p) {
       for (int s = 1; s < KS; ++s) st_k += *reinterpret_cast<const f32x4*>(slab0 + s * (R * 16 * EP) + c4);
       if (p.bias && n0 + c4 < d.Cout) st_k += *reinterpret_cast<const f32x4*>(p.bias + n0 + c4);
     }
+    // The round's residual loads FIRST, branch-free (buffer loads: an invalid element's offset is past the buffer and
+    // reads zeros), then the slab reads, sums and stores.  With the load inside the per-element `if` (rounds 2-4) every
+    // element was load -> s_waitcnt vmcnt(0) -> store: PER memory round trips in a row per round, and vmcnt(0) also
+    // waits for the previous element's STORE to be acknowledged — every accumulating data gradient on this kernel paid
+    // that (8 per round x 4 rounds per 112 x 64 tile).
+    bool okq[PER];
+    unsigned ooff[PER], roff[PER];  // byte offsets of the element's float4 in the output / residual buffer, or past them
+    long orowq[PER];
+    f32x4 resq[PER];
 #pragma unroll
     for (int q = 0; q < PER; ++q) {
       const int idx = (q * KS + ksub) * 64 + lane;
@@ -278,33 +301,84 @@ __global__ __launch_bounds__(256) void conv_wave_kernel(const WaveArgs p) {
       const int rr = i0 * 16 + row;
       const int m = m0 + rr;
       const int n = n0 + c4;
-      if (idx < NV && rr < TM * 16 && live && rr < p.rows && m < p.M && n < d.Cout) {
+      okq[q] = idx < NV && rr < TM * 16 && live && rr < p.rows && m < p.M && n < d.Cout;
+      long orow = m;
+      if (scatter) {
+        const unsigned mu = okq[q] ? (unsigned)m : 0u;
+        const unsigned q1 = fast_div(mu, p.wo_mul, p.wo_sh);
+        const int wo = (int)mu - (int)q1 * d.Wo;
+        const unsigned q2 = fast_div(q1, p.ho_mul, p.ho_sh);
+        const int ho = (int)q1 - (int)q2 * d.Ho;
+        const unsigned q3 = fast_div(q2, p.to_mul, p.to_sh);
+        const int to = (int)q2 - (int)q3 * d.To;
+        const int st = d.os_T > 1 ? d.os_T : 1, sh = d.os_H > 1 ? d.os_H : 1, sw = d.os_W > 1 ? d.os_W : 1;
+        orow = (((long)q3 * d.ob_T + to * st + d.oo_T) * d.ob_H + ho * sh + d.oo_H) * d.ob_W + wo * sw + d.oo_W;
+      }
+      orowq[q] = orow;
+      ooff[q] = okq[q] ? (unsigned)((orow * d.out_cs + d.out_coff + n) * 4) : 0x80000000u;
+      roff[q] = okq[q] ? (unsigned)((orow * d.res_cs + d.res_coff + n) * 4) : 0x80000000u;
+      resq[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    if (p.res && p.res_buf) {  // (the uniform tests OUTSIDE the element loop: inside it every load met a merge point —
+#pragma unroll                 // and a wait — right behind it)
+      for (int q = 0; q < PER; ++q)
+        resq[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(res_rs, roff[q], 0, 0));
+    } else if (p.res) {
+#pragma unroll
+      for (int q = 0; q < PER; ++q) {
+        const int idx = (q * KS + ksub) * 64 + lane;
+        const int n = n0 + (idx - (idx / LPR) * LPR) * 4;
+        if (okq[q]) resq[q] = *reinterpret_cast<const f32x4*>(p.res + orowq[q] * d.res_cs + d.res_coff + n);
+      }
+    }
+    if (p.res_buf) {  // straight-line: buffer stores drop what lies past the buffer, so the waits stay counted
+#pragma unroll
+      for (int q = 0; q < PER; ++q) {
+        const int idx = (q * KS + ksub) * 64 + lane;
+        const int row = idx < NV ? idx / LPR : 0;
+        const int c4 = idx < NV ? (idx - row * LPR) * 4 : 0;
+        const int n = n0 + c4 < d.Cout ? n0 + c4 : 0;
         f32x4 v = *reinterpret_cast<const f32x4*>(slab0 + row * EP + c4);
 #pragma unroll
         for (int s = 1; s < KS; ++s) v += *reinterpret_cast<const f32x4*>(slab0 + s * (R * 16 * EP) + row * EP + c4);
-        long orow = m;
-        if (scatter) {
-          const unsigned q1 = fast_div((unsigned)m, p.wo_mul, p.wo_sh);
-          const int wo = m - (int)q1 * d.Wo;
-          const unsigned q2 = fast_div(q1, p.ho_mul, p.ho_sh);
-          const int ho = (int)q1 - (int)q2 * d.Ho;
-          const unsigned q3 = fast_div(q2, p.to_mul, p.to_sh);
-          const int to = (int)q2 - (int)q3 * d.To;
-          const int st = d.os_T > 1 ? d.os_T : 1, sh = d.os_H > 1 ? d.os_H : 1, sw = d.os_W > 1 ? d.os_W : 1;
-          orow = (((long)q3 * d.ob_T + to * st + d.oo_T) * d.ob_H + ho * sh + d.oo_H) * d.ob_W + wo * sw + d.oo_W;
-        }
-        if (p.scale) v *= *reinterpret_cast<const f32x4*>(p.scale + n);
-        if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
-        if (p.res) v += *reinterpret_cast<const f32x4*>(p.res + orow * d.res_cs + d.res_coff + n);
+        v = v * sc4 + bi4;
+        v += resq[q];
         if (relu) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = fminf(fmaxf(v[e], 0.f), hi);
         }
-        *reinterpret_cast<f32x4*>(p.out + orow * d.out_cs + d.out_coff + n) = v;
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), out_rs, ooff[q], 0, 0);
         if (want_stats) {
           const f32x4 dv = v - st_k;
-          st_1 += dv;
-          st_2 += dv * dv;
+          const float keep = okq[q] ? 1.f : 0.f;
+          st_1 += dv * keep;
+          st_2 += dv * dv * keep;
+        }
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < PER; ++q) {
+        const int idx = (q * KS + ksub) * 64 + lane;
+        const int row = idx / LPR;
+        const int c4 = (idx - row * LPR) * 4;
+        const int n = n0 + c4;
+        if (okq[q]) {
+          f32x4 v = *reinterpret_cast<const f32x4*>(slab0 + row * EP + c4);
+#pragma unroll
+          for (int s = 1; s < KS; ++s) v += *reinterpret_cast<const f32x4*>(slab0 + s * (R * 16 * EP) + row * EP + c4);
+          const long orow = orowq[q];
+          v = v * sc4 + bi4;
+          v += resq[q];
+          if (relu) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fminf(fmaxf(v[e], 0.f), hi);
+          }
+          *reinterpret_cast<f32x4*>(p.out + orow * d.out_cs + d.out_coff + n) = v;
+          if (want_stats) {
+            const f32x4 dv = v - st_k;
+            st_1 += dv;
+            st_2 += dv * dv;
+          }
         }
       }
     }
@@ -928,6 +1002,7 @@ int sf_conv_wave_try(const sf_conv_desc* d, const float* in, const float* w_pack
   a.dbg = g_dbg;
   a.out_bytes = (unsigned)out_b;
   a.res_bytes = (unsigned)res_b;
+  a.res_buf = (out_b > 0 && out_b < 0x7ffffff0L && res_b < 0x7ffffff0L) ? 1 : 0;
   // Where the persistent form pays (tools/microbench/conv_pw_probe.py, MI355X): plain layers with at most 4 K steps
   // (K <= 64: 64 -> 256 at 56^2 79 us on 7x2 tiles against 86-94 us one-pass on any tile; the C <= 32 Fast-pathway
   // projections 10-25 % faster) — a tile there is ~7 k MFMA cycles, as long as the one-pass kernel's fixed part.  From
