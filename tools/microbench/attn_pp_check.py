@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
-"""attn_bwd_bxpp_kernel (ping-pong schedule) against attn_bwd_bx_kernel<., 8> (free-running sweep): same products in the
-same order, so dq / dk / dv must agree BIT FOR BIT; then the time of both at the production shape.
+"""attn_bwd_bxpp_kernel (ping-pong schedule) against attn_bwd_bx_kernel<., 8> (free-running sweep): the same products in
+the same order — bit-identical while both started S' / dP from -LSE / -D; since the ping-pong kernel adds them in its
+vector segment the two differ by fp32 rounding of that one addition (bound here: 5e-6 of the tensor's max) — then the
+time of both at the production shape.
 usage: tools/microbench/attn_pp_check.py"""
 import os
 import sys
@@ -52,9 +54,10 @@ for B, thw, c in [(2, (1, 8, 8), 32), (3, (3, 25, 33), 32), (2, (2, 17, 19), 20)
     a, ta = run(B, thw, c, 0, 5 if big else 0)
     b, tb = run(B, thw, c, 1, 5 if big else 0)
     same = torch.equal(a, b)
-    ok &= same
+    rel = float((a - b).abs().max() / a.abs().max())
+    ok &= rel < 5e-6
     n = thw[0] * thw[1] * thw[2]
-    print("B=%d N=%d d=%d: ping-pong == free-running bit for bit: %s  (max |diff| %.3e, |ref| %.3e)%s" % (
-        B, n, c, same, float((a - b).abs().max()), float(a.abs().max()),
+    print("B=%d N=%d d=%d: ping-pong vs free-running: bit-identical %s, max |diff| / max |ref| %.2e (max |diff| %.3e, |ref| %.3e)%s" % (
+        B, n, c, same, rel, float((a - b).abs().max()), float(a.abs().max()),
         "   free-running %.3f ms, ping-pong %.3f ms" % (ta, tb) if big else ""))
-print("ALL EQUAL" if ok else "MISMATCH")
+print("ALL WITHIN 5e-6" if ok else "MISMATCH")
