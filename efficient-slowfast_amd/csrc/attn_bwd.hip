@@ -2066,19 +2066,7 @@ int launch_fused_bx(BwdArgs a, float* ws, float* bx_ws, hipStream_t s) {
         case 16: return (Kern)attn_bwd_bxpp_kernel<16>;    // no s_setprio
         case 32: return (Kern)attn_bwd_bxpp_kernel<32>;    // V segments without exp2 / splits / image (results invalid)
         case 64: return (Kern)attn_bwd_bxpp_kernel<64>;    // M segments without MFMAs (results invalid)
-        case 40: return (Kern)attn_bwd_bxpp_kernel<40>;
-        case 72: return (Kern)attn_bwd_bxpp_kernel<72>;
-        case 136: return (Kern)attn_bwd_bxpp_kernel<136>;
-        case 264: return (Kern)attn_bwd_bxpp_kernel<264>;
-        case 392: return (Kern)attn_bwd_bxpp_kernel<392>;    // 264 + no fragment reads
-        case 904: return (Kern)attn_bwd_bxpp_kernel<904>;    // 392 + no staging / slot sums
-        case 1928: return (Kern)attn_bwd_bxpp_kernel<1928>;  // 904 + no accumulator initialisation
-        case 776: return (Kern)attn_bwd_bxpp_kernel<776>;    // 264 + no staging / slot sums
-        case 520: return (Kern)attn_bwd_bxpp_kernel<520>;    // real V, no staging / slot sums
         case 256: return (Kern)attn_bwd_bxpp_kernel<256>;    // (no stamps: a stamp's s_memtime drains lgkmcnt)
-        case 384: return (Kern)attn_bwd_bxpp_kernel<384>;
-        case 896: return (Kern)attn_bwd_bxpp_kernel<896>;
-        case 1920: return (Kern)attn_bwd_bxpp_kernel<1920>;
         case 512: return (Kern)attn_bwd_bxpp_kernel<512>;
         case 128: return (Kern)attn_bwd_bxpp_kernel<128>;
         case 640: return (Kern)attn_bwd_bxpp_kernel<640>;
