@@ -109,7 +109,8 @@ def test_launch_planning_queries_are_host_only_and_fill_the_chip():
     # operand travels as fp32 rows, so the workspace = the weight planes (unless handed in) + S partial tiles — no
     # activation planes whether or not the caller has them.  sf_conv_tune(7, 0): the per-wavefront kernel splits K inside
     # the workgroup (no workspace); the LDS-tiled fallback (sf_conv_tune(0, 0)): 196 tiles, 192 K steps -> split-K with a
-    # [S][M][Cout] workspace.  res3's 1x3x3 128 -> 128 (196 tiles of 256 x 128 = 0.77 of a round) stays on conv_wave
+    # [S][M][Cout] workspace.  res3's 1x3x3 128 -> 128 (196 tiles of 256 x 128 = 0.77 of a round): on conv_wave until
+    # round 5 (97 TFLOP/s there against 87 here), on conv_bx since its loader state left scratch (112 in the step)
     d4 = _conv_desc(8, 8, 14, 14, 1024, 256, (3, 1, 1))
     w_planes = -(-(3 * (256 + 1) * 3072 // 2) // 4) * 4
     n_bx = L.sf_conv_bx_ws_floats(ctypes.byref(d4), 0, 1)
@@ -118,7 +119,7 @@ def test_launch_planning_queries_are_host_only_and_fill_the_chip():
     assert L.sf_conv_bx_ws_floats(ctypes.byref(d4), 1, 1) == n_bx          # fp32 rows: no activation planes either way
     assert L.sf_conv_bx_ws_floats(ctypes.byref(d4), 0, 0) == n_bx + w_planes
     assert L.sf_conv_fwd_ws_floats(ctypes.byref(d4)) == n_bx + w_planes
-    assert L.sf_conv_bx_ws_floats(ctypes.byref(_conv_desc(8, 8, 28, 28, 128, 128, (1, 3, 3))), 1, 1) == 0
+    assert L.sf_conv_bx_ws_floats(ctypes.byref(_conv_desc(8, 8, 28, 28, 128, 128, (1, 3, 3))), 1, 1) > 0
     assert L.sf_bx_planes_elems(12544, 1024) == 3 * 12545 * 1024
     assert L.sf_conv_bx_ws_floats(ctypes.byref(d), 0, 0) == 0                  # res2 3x3 64 -> 64: not a bx shape
     assert L.sf_conv_tune(7, 0) == 0
