@@ -37,6 +37,14 @@ struct ConvArgs {
   int vec_epi;  // 1: outputs/residual are 16-byte addressable -> LDS-transposed float4 epilogue
   int ksplit;   // > 1: blockIdx.y takes a contiguous share of the K steps and stores a raw partial tile to ws
   float* ws;    // [ksplit][M][Cout] partials (split-K), finished by conv_splitk_finish_kernel
+  // grouped convolution (sf_conv_fwd_grouped): blockIdx.z = group; d.Cin / d.Cout are ONE group's widths and the group
+  // index moves the channel windows and the weight / scale / bias rows.  All zero for a dense launch (gridDim.z == 1).
+  int g_in = 0;     // input channels per group  (in_coff  += g * g_in)
+  int g_out = 0;    // output channel step       (out_coff += g * g_out: Cout per group, or 1 for a shuffled store)
+  int g_res = 0;    // residual channel step     (res_coff += g * g_res)
+  int g_sb = 0;     // scale / bias rows per group
+  long g_w = 0;     // packed weight floats per group = Cout_g * taps * cin_pad
+  int groups = 1;   // gridDim.z
 };
 
 constexpr int BK = 16;
@@ -63,6 +71,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
   const int tile_n = bid - tile_m * p.nb_n;
   const int m0 = tile_m * BM;
   const int n0 = tile_n * BN;
+  const int grp = (int)blockIdx.z;   // 0 for a dense conv
+  const int g_in_coff = d.in_coff + grp * p.g_in;
+  const float* const g_w = p.w + (long)grp * p.g_w;
 
   // ---- staging role: thread owns float4 column lc of rows lr + 64*i
   const int lr = tid >> 2;
@@ -94,7 +105,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
     const int rn = lr + 64 * j;
     const int n = n0 + rn;
     b_ok[j] = (rn < BN) && (n < d.Cout);
-    b_ptr[j] = p.w + (long)(b_ok[j] ? n : 0) * kpad + lc;
+    b_ptr[j] = g_w + (long)(b_ok[j] ? n : 0) * kpad + lc;
   }
 
   // ---- K iteration state: tap (kt,kh,kw) outer, 16-channel chunk inner; a split-K workgroup starts at its share
@@ -127,7 +138,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
       }
       a_v[i] = ok && (unsigned)ti < (unsigned)d.Ti && (unsigned)hi < (unsigned)d.Hi &&
                (unsigned)wi < (unsigned)d.Wi;
-      a_off[i] = ((((long)a_n[i] * d.Ti + ti) * d.Hi + hi) * d.Wi + wi) * d.in_cs + d.in_coff + lc;
+      a_off[i] = ((((long)a_n[i] * d.Ti + ti) * d.Hi + hi) * d.Wi + wi) * d.in_cs + g_in_coff + lc;
     }
   };
   set_tap();
@@ -228,11 +239,12 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
   // Scattered stores (strided data-gradient classes): output position (n,t,h,w) of this launch lands at
   // (t*os_T + oo_T, h*os_H + oo_H, w*os_W + oo_W) of a destination of dims ob_T x ob_H x ob_W.
   const bool split = p.ksplit > 1;  // raw partial tile to the workspace; the finish kernel applies the epilogue
-  const float* const e_scale = split ? nullptr : p.scale;
-  const float* const e_bias = split ? nullptr : p.bias;
+  const float* const e_scale = (split || !p.scale) ? nullptr : p.scale + grp * p.g_sb;
+  const float* const e_bias = (split || !p.bias) ? nullptr : p.bias + grp * p.g_sb;
   const float* const e_res = split ? nullptr : p.res;
+  const int e_res_coff = d.res_coff + grp * p.g_res;
   float* const e_out = split ? p.ws + (long)blockIdx.y * p.M * d.Cout : p.out;
-  const int e_out_cs = split ? d.Cout : d.out_cs, e_out_coff = split ? 0 : d.out_coff;
+  const int e_out_cs = split ? d.Cout : d.out_cs, e_out_coff = split ? 0 : d.out_coff + grp * p.g_out;
   const int e_out_cmul = split ? 1 : d.out_cmul;
   const bool scatter = !split && (d.os_T > 1 || d.os_H > 1 || d.os_W > 1);
   auto out_row = [&](int m) -> long {
@@ -281,7 +293,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
           const long orow = out_row(m);
           f32x4 v = *reinterpret_cast<const f32x4*>(slab + row * EP + c4);
           v = v * sc + bi;
-          if (has_res) v += *reinterpret_cast<const f32x4*>(e_res + orow * d.res_cs + d.res_coff + n);
+          if (has_res) v += *reinterpret_cast<const f32x4*>(e_res + orow * d.res_cs + e_res_coff + n);
           if (relu) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = fminf(fmaxf(v[e], 0.f), hi);
@@ -308,7 +320,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
         if (m >= p.M) continue;
         const long orow = out_row(m);
         float v = acc[i][j][r] * sc + bi;
-        if (has_res) v += e_res[orow * d.res_cs + d.res_coff + n];
+        if (has_res) v += e_res[orow * d.res_cs + e_res_coff + n];
         v = relu ? fminf(fmaxf(v, 0.f), hi) : v;
         e_out[orow * e_out_cs + e_out_coff + (long)n * e_out_cmul] = v;
       }
@@ -424,7 +436,7 @@ int launch(const ConvArgs& a, bool vec4, hipStream_t s) {
   ConvArgs p = a;
   p.nb_n = sf_cdiv(p.d.Cout, BN);
   p.nblocks = sf_cdiv(p.M, BM) * p.nb_n;
-  const dim3 grid(p.nblocks, p.ksplit);
+  const dim3 grid(p.nblocks, p.ksplit, p.groups);
   if (vec4)
     hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, 4>), grid, dim3(256), 0, s, p);
   else
@@ -652,6 +664,60 @@ extern "C" int sf_conv_fwd_ws(const sf_conv_desc* d, const float* in, const floa
                               const float* bias, const float* res, float* out, float* ws, void* stream) {
   if (ws && !sf_aligned16(ws)) return SF_EALIGN;
   return conv_fwd_impl(d, in, w_packed, scale, bias, res, out, ws, stream);
+}
+
+// nn.Conv3d(groups = G), 1 < G < channels, as ONE launch of the LDS-tiled kernel: the block-diagonal GEMM's group is the
+// grid's z index.  `d` carries the WHOLE layer (Cin, Cout = all groups; cin_pad = the packed width of ONE group's
+// Cin / G channels); w_packed = [Cout][taps][cin_pad], which is the G per-group packs one after the other (forward), or
+// with d->transposed the G transposed packs [Cin_fwd][taps][pad(Cout_fwd / G)] (data gradient: d->Cin = forward Cout).
+// shuffle != 0: group g's channel j is stored at channel j * G + g (channel_shuffle(., G) in the store index).
+extern "C" int sf_conv_fwd_grouped(const sf_conv_desc* d, int groups, int shuffle, const float* in,
+                                   const float* w_packed, const float* scale, const float* bias, const float* res,
+                                   float* out, void* stream) {
+  if (!d || groups < 1) return SF_EINVAL;
+  if (groups == 1 && !shuffle) return conv_fwd_impl(d, in, w_packed, scale, bias, res, out, nullptr, stream);
+  if (!in || !w_packed || !out) return SF_EINVAL;
+  if (d->Cin <= 0 || d->Cout <= 0 || d->Cin % groups || d->Cout % groups) return SF_EINVAL;
+  const int cin_g = d->Cin / groups, cout_g = d->Cout / groups;
+  if (d->cin_pad < cin_g || (d->cin_pad % BK) != 0) return SF_EINVAL;
+  if (d->kT <= 0 || d->kH <= 0 || d->kW <= 0 || d->sT <= 0 || d->sH <= 0 || d->sW <= 0) return SF_EINVAL;
+  if (d->out_cmul != 1) return SF_EINVAL;   // the shuffle owns the channel multiplier
+  if (d->act != SF_ACT_NONE && d->act != SF_ACT_RELU && d->act != SF_ACT_RELU6) return SF_EINVAL;
+  if (d->os_T > 1 || d->os_H > 1 || d->os_W > 1) return SF_EINVAL;
+  if (!sf_aligned16(w_packed)) return SF_EALIGN;
+  const long M = (long)d->N * d->To * d->Ho * d->Wo;
+  if (M <= 0 || M > 0x7fffffffL || groups > 65535) return SF_EINVAL;
+  ConvArgs a;
+  a.d = *d;
+  a.d.Cin = cin_g;
+  a.d.Cout = cout_g;
+  a.d.out_cmul = shuffle ? groups : 1;
+  a.in = in; a.w = w_packed; a.scale = scale; a.bias = bias; a.res = res; a.out = out;
+  a.M = (int)M;
+  a.ntaps = d->kT * d->kH * d->kW;
+  a.nb_n = 0; a.nblocks = 0;
+  a.ksplit = 1;
+  a.ws = nullptr;
+  a.groups = groups;
+  a.g_in = cin_g;
+  a.g_out = shuffle ? 1 : cout_g;
+  a.g_res = cout_g;
+  a.g_sb = cout_g;
+  a.g_w = (long)cout_g * a.ntaps * d->cin_pad;
+  // 16-byte forms only when every group's window starts on a 16-byte boundary
+  const bool vec4 = (cin_g % 4 == 0) && (d->in_cs % 4 == 0) && (d->in_coff % 4 == 0) && sf_aligned16(in);
+  a.vec_epi = !shuffle && (cout_g % 4 == 0) && (d->out_cs % 4 == 0) && (d->out_coff % 4 == 0) && sf_aligned16(out) &&
+              (!scale || sf_aligned16(scale)) && (!bias || sf_aligned16(bias)) &&
+              (!res || ((d->res_cs % 4 == 0) && (d->res_coff % 4 == 0) && sf_aligned16(res)));
+  hipStream_t s = (hipStream_t)stream;
+  // tiles sized for ONE group's GEMM; the G groups multiply the workgroup count
+  if (cout_g <= 16) return launch<256, 16, 4, 1>(a, vec4, s);
+  if (cout_g <= 32) return launch<256, 32, 4, 1>(a, vec4, s);
+  if (cout_g <= 64 || (long)sf_cdiv(M, 128) * sf_cdiv(cout_g, 128) * groups < 256) {
+    if ((long)sf_cdiv(M, 128) * sf_cdiv(cout_g, 64) * groups < 256) return launch<64, 64, 2, 2>(a, vec4, s);
+    return launch<128, 64, 2, 2>(a, vec4, s);
+  }
+  return launch<128, 128, 2, 2>(a, vec4, s);
 }
 
 // Training-mode BN statistics out of the conv's epilogue (conv_wave.hip): sf_conv_stats_ws_floats(d) floats of scratch

@@ -24,6 +24,9 @@ struct WgradArgs {
   int dz_cs, dz_coff;
   int M, ntaps, S, nb_co, nb_ci;
   long chunk;          // positions per split (multiple of 32)
+  // grouped convolution (sf_conv_wgrad_grouped): blockIdx.z = group, d.Cin / d.Cout are ONE group's widths; the group
+  // index moves both channel windows and the row block of the partial [S][G * Cout][ntaps][cin_pad].  Dense: 1, 0, 0.
+  int groups = 1, g_ci = 0, g_co = 0;
 };
 
 constexpr int BM = 16;    // positions per stage
@@ -48,6 +51,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs p) {
   const int tco = tile / p.nb_ci;
   const int co0 = tco * BCO, ci0 = tci * BCI;
   const int split = blockIdx.y;
+  const int grp = (int)blockIdx.z;   // 0 for a dense conv
+  const int g_dz_coff = p.dz_coff + grp * p.g_co, g_in_coff = d.in_coff + grp * p.g_ci;
   const long m_begin = (long)split * p.chunk;
   const long m_end = (m_begin + p.chunk < p.M) ? m_begin + p.chunk : p.M;
 
@@ -77,7 +82,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs p) {
       const long m = mb + lr;
       f32x4 vz = {0.f, 0.f, 0.f, 0.f};
       if (f < BM * ZF && m < m_end) {
-        const float* zp = p.dz + m * p.dz_cs + p.dz_coff + co0 + lc;
+        const float* zp = p.dz + m * p.dz_cs + g_dz_coff + co0 + lc;
         if (VEC == 4) {
           if (co0 + lc < d.Cout) vz = *reinterpret_cast<const f32x4*>(zp);
         } else {
@@ -100,7 +105,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs p) {
         const int hi = pos_h[i] * d.sH - d.pH + kh * d.dH;
         const int wi = pos_w[i] * d.sW - d.pW + kw * d.dW;
         if ((unsigned)ti < (unsigned)d.Ti && (unsigned)hi < (unsigned)d.Hi && (unsigned)wi < (unsigned)d.Wi) {
-          const float* xp = p.x + ((((long)n * d.Ti + ti) * d.Hi + hi) * d.Wi + wi) * d.in_cs + d.in_coff + ci0 + lc;
+          const float* xp = p.x + ((((long)n * d.Ti + ti) * d.Hi + hi) * d.Wi + wi) * d.in_cs + g_in_coff + ci0 + lc;
           if (VEC == 4) {
             if (ci0 + lc < d.Cin) vx = *reinterpret_cast<const f32x4*>(xp);
           } else {
@@ -180,7 +185,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs p) {
   }
 
   // partial tile: rows co = .. + 4*fg + r, cols ci = .. + fr
-  float* const base = p.part + (long)split * d.Cout * p.ntaps * d.cin_pad;
+  float* const base = p.part + ((long)split * p.groups + grp) * d.Cout * p.ntaps * d.cin_pad;
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -222,6 +227,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_small_kernel(const WgradArgs p
   const int tco = tile / p.nb_ci;
   const int co0 = tco * BCO, ci0 = tci * BCI;
   const int split = blockIdx.y;
+  const int grp = (int)blockIdx.z;   // 0 for a dense conv
+  const int g_dz_coff = p.dz_coff + grp * p.g_co, g_in_coff = d.in_coff + grp * p.g_ci;
   const long m_begin = (long)split * p.chunk;
   const long m_end = (m_begin + p.chunk < p.M) ? m_begin + p.chunk : p.M;
   const int kw = tap % d.kW;
@@ -250,7 +257,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_small_kernel(const WgradArgs p
       const long m = mb + lr;
       f32x4 vz = {0.f, 0.f, 0.f, 0.f};
       if (f < BMS * ZF && m < m_end) {
-        const float* zp = p.dz + m * p.dz_cs + p.dz_coff + co0 + lc;
+        const float* zp = p.dz + m * p.dz_cs + g_dz_coff + co0 + lc;
         if (VEC == 4) {
           if (co0 + lc < d.Cout) vz = *reinterpret_cast<const f32x4*>(zp);
         } else {
@@ -273,7 +280,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_small_kernel(const WgradArgs p
         const int hi = pos_h[i] * d.sH - d.pH + kh * d.dH;
         const int wi = pos_w[i] * d.sW - d.pW + kw * d.dW;
         if ((unsigned)ti < (unsigned)d.Ti && (unsigned)hi < (unsigned)d.Hi && (unsigned)wi < (unsigned)d.Wi) {
-          const float* xp = p.x + ((((long)n * d.Ti + ti) * d.Hi + hi) * d.Wi + wi) * d.in_cs + d.in_coff + ci0 + lc;
+          const float* xp = p.x + ((((long)n * d.Ti + ti) * d.Hi + hi) * d.Wi + wi) * d.in_cs + g_in_coff + ci0 + lc;
           if (VEC == 4) {
             if (ci0 + lc < d.Cin) vx = *reinterpret_cast<const f32x4*>(xp);
           } else {
@@ -359,7 +366,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_small_kernel(const WgradArgs p
 #pragma unroll
       for (int r = 0; r < 4; ++r) red[(wave * BCO + 16 * i + 4 * fg + r) * BCI + 16 * j + fr] = acc[i][j][r];
   __syncthreads();
-  float* const base = p.part + (long)split * d.Cout * p.ntaps * d.cin_pad;
+  float* const base = p.part + ((long)split * p.groups + grp) * d.Cout * p.ntaps * d.cin_pad;
   for (int e = tid; e < BCO * BCI; e += 256) {
     const int co = co0 + e / BCI, ci = ci0 + e % BCI;
     if (co < d.Cout && ci < d.cin_pad) {
@@ -748,7 +755,7 @@ template <int BCO, int BCI>
 static int launch_wgrad_small(WgradArgs a, bool vec4, hipStream_t s) {
   a.nb_co = sf_cdiv(a.d.Cout, BCO);
   a.nb_ci = sf_cdiv(a.d.cin_pad, BCI);   // cover the zero-padded packed width too
-  dim3 grid(a.nb_co * a.nb_ci * a.ntaps, a.S);
+  dim3 grid(a.nb_co * a.nb_ci * a.ntaps, a.S, a.groups);
   if (vec4)
     hipLaunchKernelGGL((conv_wgrad_small_kernel<BCO, BCI, 4>), grid, dim3(256), 0, s, a);
   else
@@ -761,7 +768,7 @@ template <int BCO, int BCI>
 static int launch_wgrad(WgradArgs a, bool vec4, hipStream_t s) {
   a.nb_co = sf_cdiv(a.d.Cout, BCO);
   a.nb_ci = sf_cdiv(a.d.Cin, BCI);
-  dim3 grid(a.nb_co * a.nb_ci * a.ntaps, a.S);
+  dim3 grid(a.nb_co * a.nb_ci * a.ntaps, a.S, a.groups);
   if (vec4)
     hipLaunchKernelGGL((conv_wgrad_kernel<BCO, BCI, 4>), grid, dim3(256), 0, s, a);
   else
@@ -906,24 +913,13 @@ int sf_wgrad_wave_splits(const sf_conv_desc* d);  // conv_wgrad_wave.hip
 int sf_wgrad_wave_try(const sf_conv_desc* d, const float* x, const float* dz, int dz_cs, int dz_coff, float* partial,
                       hipStream_t stream);
 
-// Number of position splits the kernel will use for this problem (the caller sizes the workspace with it).
-extern "C" int sf_conv_wgrad_splits(const sf_conv_desc* d) {
-  if (!d) return 0;
-  StemArgs sq;
-  if (stem_plan(d, 0, &sq)) return stem_workgroups(sq);
-  {
-    const int s = sf_wgrad_rows_splits(d);  // small-channel stride-1 "same" layers: the rows kernel's plan
-    if (s > 0) return s;
-  }
-  {
-    const int s = sf_wgrad_wave_splits(d);  // >= 64 channels on both sides: the per-wavefront kernel's own plan
-    if (s > 0) return s;
-  }
+// Position splits of the LDS-tiled kernels above for a problem of `groups` block-diagonal GEMMs of d's widths each.
+static int tiled_wgrad_splits(const sf_conv_desc* d, int groups) {
   int bco, bci;
   wgrad_tile(d, &bco, &bci);
   const long M = (long)d->N * d->To * d->Ho * d->Wo;
   const long tiles = (long)sf_cdiv(d->Cout, bco) * sf_cdiv(bco <= 32 ? d->cin_pad : d->Cin, bci) * d->kT * d->kH *
-                     d->kW;
+                     d->kW * groups;
   static const long target = [] {
     const char* e = getenv("SF_WGRAD_WGS");  // tuning aid
     return e ? atol(e) : 768L;
@@ -947,6 +943,76 @@ extern "C" int sf_conv_wgrad_splits(const sf_conv_desc* d) {
     if (fill >= best_fill - 1e-12) { best_fill = fill; best = c; }
   }
   return (int)best;
+}
+
+// Number of position splits the kernel will use for this problem (the caller sizes the workspace with it).
+extern "C" int sf_conv_wgrad_splits(const sf_conv_desc* d) {
+  if (!d) return 0;
+  StemArgs sq;
+  if (stem_plan(d, 0, &sq)) return stem_workgroups(sq);
+  {
+    const int s = sf_wgrad_rows_splits(d);  // small-channel stride-1 "same" layers: the rows kernel's plan
+    if (s > 0) return s;
+  }
+  {
+    const int s = sf_wgrad_wave_splits(d);  // >= 64 channels on both sides: the per-wavefront kernel's own plan
+    if (s > 0) return s;
+  }
+  return tiled_wgrad_splits(d, 1);
+}
+
+static bool grouped_desc(const sf_conv_desc* d, int groups, sf_conv_desc* g) {
+  if (!d || groups < 1 || groups > 65535 || d->Cin <= 0 || d->Cout <= 0 || d->Cin % groups || d->Cout % groups)
+    return false;
+  *g = *d;
+  g->Cin = d->Cin / groups;
+  g->Cout = d->Cout / groups;
+  return g->cin_pad >= g->Cin;
+}
+
+// Weight gradient of nn.Conv3d(groups = G) as ONE launch: group = grid z.  `d` is the forward descriptor of the WHOLE
+// layer (cin_pad = the packed width of one group's Cin / G channels); partial [S][Cout][taps][cin_pad] holds group g's
+// rows at [g * Cout / G, (g + 1) * Cout / G), i.e. sf_conv_wgrad_finish(partial, S, Cout, taps, cin_pad, Cin / G, ...)
+// stores the gradient in nn.Conv3d's own grouped layout [Cout][Cin / G][kT][kH][kW].
+extern "C" int sf_conv_wgrad_grouped_splits(const sf_conv_desc* d, int groups) {
+  sf_conv_desc g;
+  if (!grouped_desc(d, groups, &g)) return 0;
+  return groups == 1 ? sf_conv_wgrad_splits(d) : tiled_wgrad_splits(&g, groups);
+}
+
+extern "C" int sf_conv_wgrad_grouped(const sf_conv_desc* d, int groups, const float* x, const float* dz, int dz_cs,
+                                     int dz_coff, float* partial, void* stream) {
+  if (groups == 1) return sf_conv_wgrad(d, x, dz, dz_cs, dz_coff, partial, stream);
+  sf_conv_desc g;
+  if (!x || !dz || !partial || !grouped_desc(d, groups, &g)) return SF_EINVAL;
+  const long M = (long)d->N * d->To * d->Ho * d->Wo;
+  if (M <= 0 || M > 0x7fffffffL) return SF_EINVAL;
+  WgradArgs a;
+  a.d = g;
+  a.x = x; a.dz = dz; a.part = partial; a.dz_cs = dz_cs; a.dz_coff = dz_coff;
+  a.M = (int)M;
+  a.ntaps = d->kT * d->kH * d->kW;
+  a.S = tiled_wgrad_splits(&g, groups);
+  a.nb_co = a.nb_ci = 0;
+  a.groups = groups;
+  a.g_ci = g.Cin;
+  a.g_co = g.Cout;
+  a.chunk = ((M + a.S - 1) / a.S + BMS - 1) / BMS * BMS;
+  const bool vec4 = (g.Cin % 4 == 0) && (d->in_cs % 4 == 0) && (d->in_coff % 4 == 0) && sf_aligned16(x) &&
+                    (g.Cout % 4 == 0) && (dz_cs % 4 == 0) && (dz_coff % 4 == 0) && sf_aligned16(dz);
+  int bco, bci;
+  wgrad_tile(&g, &bco, &bci);
+  hipStream_t s = (hipStream_t)stream;
+  if (bco <= 32) {
+    if (bco == 16 && bci == 16) return launch_wgrad_small<16, 16>(a, vec4, s);
+    if (bco == 16) return launch_wgrad_small<16, 32>(a, vec4, s);
+    if (bci == 16) return launch_wgrad_small<32, 16>(a, vec4, s);
+    return launch_wgrad_small<32, 32>(a, vec4, s);
+  }
+  if (bco == 128 && bci == 128) return launch_wgrad<128, 128>(a, vec4, s);
+  if (bco == 128) return launch_wgrad<128, 64>(a, vec4, s);
+  if (bci == 128) return launch_wgrad<64, 128>(a, vec4, s);
+  return launch_wgrad<64, 64>(a, vec4, s);
 }
 
 extern "C" int sf_conv_wgrad(const sf_conv_desc* d, const float* x, const float* dz, int dz_cs, int dz_coff,

@@ -393,6 +393,19 @@ __global__ void copy_channels_kernel(const float* __restrict__ in, int in_cs, in
   out[r * out_cs + out_coff + (long)c * out_cmul] = in[r * in_cs + in_coff + c];
 }
 
+// channel_shuffle(x, G): out[.., c] (+)= in[.., (c % G) * (C / G) + c / G] — one thread per OUTPUT element (coalesced
+// stores; the reads stay inside the row's C * 4 bytes).  The inverse permutation is the same kernel with G' = C / G.
+__global__ void channel_shuffle_kernel(const float* __restrict__ in, int in_cs, int in_coff, float* __restrict__ out,
+                                       int out_cs, int out_coff, int G, int C, int accumulate, long total) {
+  const long idx = (long)blockIdx.x * TPB + threadIdx.x;
+  if (idx >= total) return;
+  const int c = (int)(idx % C);
+  const long r = idx / C;
+  const float v = in[r * in_cs + in_coff + (c % G) * (C / G) + c / G];
+  float* const o = out + r * out_cs + out_coff + c;
+  *o = accumulate ? *o + v : v;
+}
+
 
 // ------------------------------------------------------------------------------------------------
 // Training-mode BN statistics: partial[blk][{sum,sumsq}][c] over the block's rows (fp32), combined in fp64.
@@ -1208,6 +1221,16 @@ extern "C" int sf_row_softmax_bwd(const float* p, int p_cs, int p_coff, float* d
 extern "C" int sf_head_act_mean(const float* logits, int B, int P, int K, int act, float* out, void* stream) {
   if (!logits || !out || B <= 0 || P <= 0 || K <= 0) return SF_EINVAL;
   hipLaunchKernelGGL(head_act_mean_kernel, dim3(B), dim3(TPB), 0, (hipStream_t)stream, logits, P, K, act, out);
+  SF_CHECK_LAUNCH();
+  return SF_OK;
+}
+
+extern "C" int sf_channel_shuffle(const float* in, int in_cs, int in_coff, float* out, int out_cs, int out_coff,
+                                  int groups, long rows, int C, int accumulate, void* stream) {
+  if (!in || !out || rows <= 0 || C <= 0 || groups <= 0 || C % groups) return SF_EINVAL;
+  const long total = rows * C;
+  hipLaunchKernelGGL(channel_shuffle_kernel, dim3(sf_cdiv(total, TPB)), dim3(TPB), 0, (hipStream_t)stream, in, in_cs,
+                     in_coff, out, out_cs, out_coff, groups, C, accumulate, total);
   SF_CHECK_LAUNCH();
   return SF_OK;
 }

@@ -59,6 +59,7 @@ EXPORTS = [
     "sf_attn_products_per_fp32", "sf_pack_conv_weights", "sf_attn_bwd_variant", "sf_attn_tune",
     "sf_bx_planes_elems", "sf_bx_split", "sf_bx_split_batched", "sf_conv_pw_ws_floats", "sf_conv_pw_stats_floats", "sf_conv_fwd_pw", "sf_conv_bx_ws_floats", "sf_conv_fwd_bx", "sf_conv_wgrad_bx_splits",
     "sf_conv_wgrad_bx_ws_floats", "sf_conv_wgrad_bx",
+    "sf_conv_fwd_grouped", "sf_conv_wgrad_grouped_splits", "sf_conv_wgrad_grouped", "sf_channel_shuffle",
 ]
 _LONG_RET = ("sf_tmax_mean_ws_floats", "sf_channel_stats_ws_floats", "sf_bn_bwd_ws_floats",
              "sf_dwconv_wgrad_ws_floats", "sf_attn_bwd_fused_ws_floats", "sf_conv_fwd_ws_floats",
@@ -101,6 +102,7 @@ def lib():
         L.sf_attn_bwd.argtypes = [vp, ci, vp, ci, vp, ci, vp, ci, vp, vp, vp, vp, ci, vp, ci, vp, ci, ci, ci, ci, ci, vp]
         L.sf_head_act_mean.argtypes = [vp, ci, ci, ci, ci, vp, vp]
         L.sf_copy_channels.argtypes = [vp, ci, ci, vp, ci, ci, ci, cl, ci, vp]
+        L.sf_channel_shuffle.argtypes = [vp, ci, ci, vp, ci, ci, ci, cl, ci, ci, vp]
         L.sf_channel_stats_ws_floats.argtypes = [ci]
         L.sf_channel_stats_ws_floats.restype = cl
         L.sf_channel_stats.argtypes = [vp, ci, ci, cl, ci, vp, vp, vp, vp]
@@ -109,6 +111,9 @@ def lib():
         cf = ctypes.c_float
         L.sf_conv_wgrad_splits.argtypes = [ctypes.POINTER(ConvDesc)]
         L.sf_conv_wgrad.argtypes = [ctypes.POINTER(ConvDesc), vp, vp, ci, ci, vp, vp]
+        L.sf_conv_fwd_grouped.argtypes = [ctypes.POINTER(ConvDesc), ci, ci] + [vp] * 7
+        L.sf_conv_wgrad_grouped_splits.argtypes = [ctypes.POINTER(ConvDesc), ci]
+        L.sf_conv_wgrad_grouped.argtypes = [ctypes.POINTER(ConvDesc), ci, vp, vp, ci, ci, vp, vp]
         L.sf_bn_bwd_ws_floats.argtypes = [ci]
         L.sf_bn_bwd_ws_floats.restype = cl
         L.sf_bn_bwd_reduce.argtypes = [vp, ci, ci, vp, ci, ci, vp, ci, ci] + [ci] * 7 + [vp] * 5 + [vp]
@@ -421,6 +426,27 @@ def pack_conv_weight_pair(w):
     return wp, wtp
 
 
+def pack_grouped_weight_pair(w, groups):
+    """Packed weights of nn.Conv3d(groups = G) for sf_conv_fwd_grouped: (wp [Cout][taps][pad(Cin / G)], wtp
+    [Cin][taps][pad(Cout / G)]) = the G per-group (forward, transposed) packs one after the other, written in place
+    into two tensors (one sf_pack_conv_weight launch per group, once per parameter version)."""
+    _require_gpu(w, "pack_grouped_weight_pair")
+    w = w.detach().contiguous()
+    cout, cin_g = w.shape[0], w.shape[1]
+    assert cout % groups == 0, (w.shape, groups)
+    cout_g = cout // groups
+    taps = w.shape[2] * w.shape[3] * w.shape[4]
+    cin_pad, cout_pad = (cin_g + 15) // 16 * 16, (cout_g + 15) // 16 * 16
+    wp = torch.empty((cout, taps, cin_pad), dtype=torch.float32, device=w.device)
+    wtp = torch.empty((cin_g * groups, taps, cout_pad), dtype=torch.float32, device=w.device)
+    for g in range(groups):
+        _check(lib().sf_pack_conv_weight(_ptr(w[g * cout_g:(g + 1) * cout_g]), cout_g, cin_g, taps,
+                                         _ptr(wp[g * cout_g:(g + 1) * cout_g]), cin_pad,
+                                         _ptr(wtp[g * cin_g:(g + 1) * cin_g]), cout_pad, _stream()),
+               "sf_pack_conv_weight")
+    return wp, wtp
+
+
 _PACK_TABLES = {}
 
 
@@ -671,6 +697,14 @@ def copy_channels(x, out, out_cmul=1):
     return out
 
 
+def channel_shuffle(x, out, groups, accumulate=False):
+    """out[.., j*G + g] (+)= x[.., g*(C/G) + j] in one launch (sf_channel_shuffle); groups = C/G inverts it."""
+    assert x.rows == out.rows and x.C == out.C and x.C % groups == 0
+    _check(lib().sf_channel_shuffle(x.ptr(), x.cs, x.coff, out.ptr(), out.cs, out.coff, groups, x.rows, x.C,
+                                    1 if accumulate else 0, _stream()), "sf_channel_shuffle")
+    return out
+
+
 def channel_stats(x):
     """Per-channel (mean, biased variance) over all N*T*H*W rows of the view -> two torch [C] tensors."""
     _require_gpu(x.buf, "channel_stats")
@@ -872,6 +906,86 @@ def conv_wgrad(x, dz, cout, kernel, stride=(1, 1, 1), padding=(0, 0, 0), dilatio
             part, S = part.sum(0, keepdim=True), 1  # in the shipped models): a parallel tree sum first
         assert dst.numel() == cout * real_cin * kT * kH * kW * max(fold_kw, 1), (dst.shape, cout, real_cin, kernel)
         _check(lib().sf_conv_wgrad_finish(_ptr(part), S, cout, kT * kH * kW, cin_pad, real_cin, fold_kw, _ptr(dst), 1,
+                                          _stream()), "sf_conv_wgrad_finish")
+        return None
+    return part.sum(0) if S > 1 else part[0]
+
+
+# ------------------------------------------------------------------------------------------------ grouped convs
+def conv_grouped(x, wp, groups, kernel, stride=(1, 1, 1), padding=(0, 0, 0), dilation=(1, 1, 1), scale=None,
+                 bias=None, relu=False, res=None, out=None, shuffle=False, out_reserve=(0, 0)):
+    """nn.Conv3d(groups = G), 1 < G < channels, as ONE launch (sf_conv_fwd_grouped: group = grid z of the LDS-tiled
+    kernel).  wp = the packed weight [Cout][taps][pad(Cin / G)] (pack_conv_weight_pair of the grouped parameter: the G
+    per-group packs one after the other).  shuffle: group g's channel j is stored at channel j*G + g."""
+    _require_gpu(x.buf, "conv_grouped")
+    cout, taps, cin_pad = wp.shape
+    kT, kH, kW = kernel
+    To = _out_dim(x.T, kT, stride[0], padding[0], dilation[0])
+    Ho = _out_dim(x.H, kH, stride[1], padding[1], dilation[1])
+    Wo = _out_dim(x.W, kW, stride[2], padding[2], dilation[2])
+    if out is None:
+        out = new_act(x, x.N, To, Ho, Wo, cout, out_reserve[0], out_reserve[1])
+    assert (out.N, out.T, out.H, out.W, out.C) == (x.N, To, Ho, Wo, cout), (out, (x.N, To, Ho, Wo, cout))
+    assert x.C % groups == 0 and cout % groups == 0 and cin_pad >= x.C // groups, (x, wp.shape, groups)
+    d = ConvDesc(x.N, x.T, x.H, x.W, x.C, x.cs, x.coff, To, Ho, Wo, cout, out.cs, out.coff, 1,
+                 kT, kH, kW, stride[0], stride[1], stride[2], padding[0], padding[1], padding[2],
+                 dilation[0], dilation[1], dilation[2], cin_pad, _act(relu),
+                 res.cs if res is not None else 0, res.coff if res is not None else 0, 0)
+    if res is not None:
+        assert res.rows == out.rows and res.C == cout
+    tag = ("conv", d.N * d.To * d.Ho * d.Wo, taps * (x.C // groups), cout)
+    _check(_traced(tag, lambda: lib().sf_conv_fwd_grouped(
+        ctypes.byref(d), groups, 1 if shuffle else 0, x.ptr(), _ptr(wp), _ptr(scale), _ptr(bias),
+        res.ptr() if res is not None else None, out.ptr(), _stream())), "sf_conv_fwd_grouped")
+    return out
+
+
+def conv_dgrad_grouped(dz, wtp, groups, x_like, kernel, stride=(1, 1, 1), padding=(0, 0, 0), dilation=(1, 1, 1),
+                       out=None, accumulate=False):
+    """Data gradient of a grouped conv in ONE launch: wtp = [Cin][taps][pad(Cout / G)], the G transposed per-group
+    packs one after the other (group g: rows [g*Cin/G, (g+1)*Cin/G), reading dz channels [g*Cout/G, (g+1)*Cout/G)).
+    Strided layers run the transposed gather with its taps predicated (no residue-class launches)."""
+    _require_gpu(dz.buf, "conv_dgrad_grouped")
+    cin, taps, cout_pad = wtp.shape
+    if out is None:
+        out = new_act(dz, x_like.N, x_like.T, x_like.H, x_like.W, cin)
+        accumulate = False
+    assert (out.N, out.T, out.H, out.W, out.C) == (x_like.N, x_like.T, x_like.H, x_like.W, cin), (out, x_like)
+    assert dz.C % groups == 0 and cin % groups == 0 and cout_pad >= dz.C // groups
+    d = ConvDesc(dz.N, dz.T, dz.H, dz.W, dz.C, dz.cs, dz.coff, out.T, out.H, out.W, cin, out.cs, out.coff, 1,
+                 kernel[0], kernel[1], kernel[2], stride[0], stride[1], stride[2], padding[0], padding[1],
+                 padding[2], dilation[0], dilation[1], dilation[2], cout_pad, ACT_NONE,
+                 out.cs if accumulate else 0, out.coff if accumulate else 0, 1)
+    tag = ("conv", dz.rows, taps * (dz.C // groups), cin)
+    _check(_traced(tag, lambda: lib().sf_conv_fwd_grouped(
+        ctypes.byref(d), groups, 0, dz.ptr(), _ptr(wtp), None, None, out.ptr() if accumulate else None, out.ptr(),
+        _stream())), "sf_conv_fwd_grouped(transposed)")
+    return out
+
+
+def conv_wgrad_grouped(x, dz, groups, kernel, stride=(1, 1, 1), padding=(0, 0, 0), dilation=(1, 1, 1),
+                       cin_pad=None, finish_into=None):
+    """Weight gradient of a grouped conv in ONE launch (+ the finish): packed [Cout][taps][cin_pad] with cin_pad =
+    pad(Cin / G), or accumulated into finish_into = a contiguous tensor in nn.Conv3d's grouped layout
+    [Cout][Cin / G][kT][kH][kW] (the parameter's gradient)."""
+    _require_gpu(x.buf, "conv_wgrad_grouped")
+    cin_g, cout = x.C // groups, dz.C
+    assert x.C % groups == 0 and cout % groups == 0
+    cin_pad = (cin_g + 15) // 16 * 16 if cin_pad is None else cin_pad
+    kT, kH, kW = kernel
+    d = ConvDesc(x.N, x.T, x.H, x.W, x.C, x.cs, x.coff, dz.T, dz.H, dz.W, cout, 0, 0, 1,
+                 kT, kH, kW, stride[0], stride[1], stride[2], padding[0], padding[1], padding[2],
+                 dilation[0], dilation[1], dilation[2], cin_pad, ACT_NONE, 0, 0, 0)
+    S = lib().sf_conv_wgrad_grouped_splits(ctypes.byref(d), groups)
+    if S <= 0:
+        raise SfhipError("sf_conv_wgrad_grouped_splits: %d -> %d channels in %d groups" % (x.C, cout, groups))
+    part = torch.empty((S, cout, kT * kH * kW, cin_pad), dtype=torch.float32, device=x.buf.device)
+    _check(_traced(("conv", dz.rows, kT * kH * kW * cin_g, cout), lambda: lib().sf_conv_wgrad_grouped(
+        ctypes.byref(d), groups, x.ptr(), dz.ptr(), dz.cs, dz.coff, _ptr(part), _stream())), "sf_conv_wgrad_grouped")
+    if finish_into is not None:
+        dst = finish_into
+        assert dst.is_contiguous() and dst.dtype == torch.float32 and dst.numel() == cout * cin_g * kT * kH * kW
+        _check(lib().sf_conv_wgrad_finish(_ptr(part), S, cout, kT * kH * kW, cin_pad, cin_g, 0, _ptr(dst), 1,
                                           _stream()), "sf_conv_wgrad_finish")
         return None
     return part.sum(0) if S > 1 else part[0]

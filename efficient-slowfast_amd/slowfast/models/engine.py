@@ -640,73 +640,50 @@ def packed_weight(conv):
 
 
 def _group_pairs(conv):
-    """Per-group (forward, data-gradient) packed weights of a grouped conv (1 < groups < channels), cached per
-    parameter version: group g owns output channels [g*Cout/G, (g+1)*Cout/G) and reads input channels
-    [g*Cin/G, (g+1)*Cin/G) — nn.Conv3d(groups=G), shufflenet_helper.py:48-63 / resnet_helper.py:196-205."""
+    """(forward, data-gradient) packed weights of a grouped conv (1 < groups < channels) for the one-launch grouped
+    kernels, cached per parameter version: wp [Cout][taps][pad(Cin/G)], wtp [Cin][taps][pad(Cout/G)] — group g owns
+    output channels [g*Cout/G, (g+1)*Cout/G) and reads input channels [g*Cin/G, (g+1)*Cin/G): nn.Conv3d(groups=G),
+    shufflenet_helper.py:48-63 / resnet_helper.py:196-205."""
     w, G = conv.weight, conv.groups
     if conv.in_channels % G or conv.out_channels % G:
         raise ValueError("grouped conv: %d -> %d channels are not divisible by %d groups" % (
             conv.in_channels, conv.out_channels, G))
-
-    def make():
-        cg = w.shape[0] // G
-        return [sfhip.pack_conv_weight_pair(w.detach()[g * cg:(g + 1) * cg]) for g in range(G)]
-
-    return _cached_t(w, "_sf_wgroups", _key(w), make)
+    return _cached_t(w, "_sf_wgroups", _key(w), lambda: sfhip.pack_grouped_weight_pair(w, G))
 
 
 def grouped_conv(x, conv, scale=None, bias=None, relu=False, res=None, out=None, out_reserve=(0, 0), shuffle=False):
-    """nn.Conv3d with 1 < groups < channels as a block-diagonal GEMM: one launch of the dense kernels per group on
-    channel slices of the same NDHWC buffers (input slice g -> output slice g; no tensor is split or concatenated).
-    shuffle: the output is stored channel-shuffled — group g's channel j lands at j*G + g, channel_shuffle(., G) of
-    shufflenet_helper.py:22-29 as index math of the stores (eval mode; the taped path shuffles after the BN)."""
-    G = conv.groups
-    pairs = _group_pairs(conv)
-    cin_g, cout_g = conv.in_channels // G, conv.out_channels // G
+    """nn.Conv3d with 1 < groups < channels as a block-diagonal GEMM in ONE launch (sfhip.conv_grouped: the group is
+    the grid's z index; input window g -> output window g of the same NDHWC buffers, no tensor is split or
+    concatenated).  shuffle: the output is stored channel-shuffled — group g's channel j lands at j*G + g,
+    channel_shuffle(., G) of shufflenet_helper.py:22-29 as index math of the stores (eval mode; the taped path shuffles
+    after the BN)."""
     k, s, p, d = conv.kernel_size, conv.stride, conv.padding, conv.dilation
-    if out is None:
-        To = sfhip._out_dim(x.T, k[0], s[0], p[0], d[0])
-        Ho = sfhip._out_dim(x.H, k[1], s[1], p[1], d[1])
-        Wo = sfhip._out_dim(x.W, k[2], s[2], p[2], d[2])
-        out = sfhip.new_act(x, x.N, To, Ho, Wo, conv.out_channels, out_reserve[0], out_reserve[1])
-    assert out.C == conv.out_channels and x.C == conv.in_channels, (x, out, conv)
-    for g in range(G):
-        sl = slice(g * cout_g, (g + 1) * cout_g)
-        og = Act(out.buf, out.coff + g, cout_g) if shuffle else out.slice(g * cout_g, cout_g)
-        sfhip.conv(x.slice(g * cin_g, cin_g), pairs[g][0], k, s, p, d,
-                   scale=None if scale is None else scale[sl].contiguous(),
-                   bias=None if bias is None else bias[sl].contiguous(), relu=relu,
-                   res=None if res is None else res.slice(g * cout_g, cout_g), out=og, out_cmul=G if shuffle else 1)
-    return out
+    assert x.C == conv.in_channels, (x, conv)
+    return sfhip.conv_grouped(x, _group_pairs(conv)[0], conv.groups, k, s, p, d,
+                              scale=None if scale is None else scale.contiguous(),
+                              bias=None if bias is None else bias.contiguous(), relu=relu, res=res, out=out,
+                              shuffle=shuffle, out_reserve=out_reserve)
 
 
 def _record_grouped_conv(x, conv, gsrc):
-    """Backward of grouped_conv (un-shuffled output): per group, the dense weight-gradient / data-gradient kernels on
-    the group's channel slices; the weight gradient of group g is rows [g*Cout/G, (g+1)*Cout/G) of the parameter's."""
+    """Backward of grouped_conv (un-shuffled output): ONE weight-gradient launch (+ its finish, straight into the
+    parameter's gradient in nn.Conv3d's grouped layout [Cout][Cin/G][k]) and ONE data-gradient launch for all groups."""
     t = tape()
     if t is None:
         return
     G = conv.groups
-    cin_g, cout_g = conv.in_channels // G, conv.out_channels // G
     k, s, p, d = conv.kernel_size, conv.stride, conv.padding, conv.dilation
 
     def bwd():
         g_all = gsrc() if callable(gsrc) else gsrc
-        pairs = _group_pairs(conv)
+        wp, wtp = _group_pairs(conv)
         tgt = t.pgrad_target(conv.weight)
-        dws = []
-        dx = t.grad_of(x)
-        for g in range(G):
-            xg, gg = x.slice(g * cin_g, cin_g), g_all.slice(g * cout_g, cout_g)
-            if tgt is not None:
-                sfhip.conv_wgrad(xg, gg, cout_g, k, s, p, d, cin_pad=pairs[g][0].shape[2],
-                                 finish_into=(tgt[g * cout_g:(g + 1) * cout_g], cin_g, 0))
-            else:
-                dwp = sfhip.conv_wgrad(xg, gg, cout_g, k, s, p, d, cin_pad=pairs[g][0].shape[2])
-                dws.append(sfhip.unpack_conv_weight_grad(dwp, (cout_g, cin_g) + tuple(k)))
-            sfhip.conv_dgrad(gg, pairs[g][1], xg, k, s, p, d, out=dx.slice(g * cin_g, cin_g), accumulate=True)
-        if dws:
-            t.add_pgrad(conv.weight, torch.cat(dws, 0))
+        if tgt is not None:
+            sfhip.conv_wgrad_grouped(x, g_all, G, k, s, p, d, cin_pad=wp.shape[2], finish_into=tgt)
+        else:
+            dwp = sfhip.conv_wgrad_grouped(x, g_all, G, k, s, p, d, cin_pad=wp.shape[2])
+            t.add_pgrad(conv.weight, sfhip.unpack_conv_weight_grad(dwp, tuple(conv.weight.shape)))
+        sfhip.conv_dgrad_grouped(g_all, wtp, G, x, k, s, p, d, out=t.grad_of(x), accumulate=True)
         if conv.bias is not None:
             t.add_pgrad(conv.bias, _colsum(g_all))
 
@@ -714,15 +691,17 @@ def _record_grouped_conv(x, conv, gsrc):
 
 
 def channel_shuffle(x, groups, out=None, out_reserve=(0, 0)):
-    """channel_shuffle(x, G) (shufflenet_helper.py:22-29): channel g*C/G + j -> j*G + g, as G strided channel copies
-    (taped: the gathers run in the backward).  The eval path never calls it: grouped_conv(shuffle=True) stores so."""
+    """channel_shuffle(x, G) (shufflenet_helper.py:22-29): channel g*C/G + j -> j*G + g, one launch (taped: the inverse
+    permutation — the same kernel with C/G groups — accumulates the gradient in the backward).  The eval path never
+    calls it: grouped_conv(shuffle=True) stores so."""
     if groups == 1:
         return x
-    cg = x.C // groups
     if out is None:
         out = sfhip.new_act(x, x.N, x.T, x.H, x.W, x.C, out_reserve[0], out_reserve[1])
-    for g in range(groups):
-        copy_channels(x.slice(g * cg, cg), Act(out.buf, out.coff + g, cg), out_cmul=groups)
+    sfhip.channel_shuffle(x, out, groups)
+    t = tape()
+    if t is not None:
+        t.record(lambda: sfhip.channel_shuffle(t.grad_of(out), t.grad_of(x), x.C // groups, accumulate=True))
     return out
 
 

@@ -1,8 +1,8 @@
 """ShuffleNet v1 stages (reference shufflenet_helper.py).  SLOWFAST.GROUPS = 1 (the shipped YAML): the 1x1 convs are
 plain GEMMs and channel_shuffle(x, 1) is the identity.  GROUPS > 1 (the published w2.0 / g3 model, README.md:260,
-wdf_all_run_scripts/run_shufflenet_w2_g3.sh): the 1x1 convs are block-diagonal GEMMs — one launch per group on channel
-slices of the same buffers (engine.grouped_conv) — and channel_shuffle is index math of conv1's stores in eval mode,
-G strided channel copies behind the batch-statistics BN in training mode.  The stride-2 shortcut
+wdf_all_run_scripts/run_shufflenet_w2_g3.sh): the 1x1 convs are block-diagonal GEMMs — ONE launch per layer, the group on
+the grid's z index, on channel windows of the same buffers (engine.grouped_conv) — and channel_shuffle is index math of
+conv1's stores in eval mode, one sf_channel_shuffle launch behind the batch-statistics BN in training mode.  The stride-2 shortcut
 conv1x1 -> AvgPool3d((1,3,3),(1,2,2),(0,1,1)) is evaluated as pool -> conv1x1 (both linear, no bias: same
 result, a quarter of the GEMM), and its ReLU and the concat are the GEMM's epilogue and store slice."""
 import torch.nn as nn

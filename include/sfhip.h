@@ -81,6 +81,19 @@ int sf_conv_fwd(const sf_conv_desc* d, const float* in, const float* w_packed, c
 long sf_conv_fwd_ws_floats(const sf_conv_desc* d);
 int sf_conv_fwd_ws(const sf_conv_desc* d, const float* in, const float* w_packed, const float* scale,
                    const float* bias, const float* res, float* out, float* ws, void* stream);
+/* nn.Conv3d(groups = G) with 1 < G < channels — the grouped 1x1x1 convs of ShuffleUnit (shufflenet_helper.py:48-63,
+ * conv1x1x1(groups) :36-45, followed by channel_shuffle :22-34) and the grouped 1x3x3 of BottleneckTransform when
+ * RESNET.NUM_GROUPS > 1 (resnet_helper.py:196-205) — as ONE launch: the block-diagonal GEMM's group is the grid's z
+ * index of the LDS-tiled kernel (conv_igemm.hip).  `d` describes the WHOLE layer: Cin / Cout = all groups' channels,
+ * cin_pad = the packed width of ONE group's Cin / G input channels; w_packed = [Cout][taps][cin_pad] = the G per-group
+ * packs one after the other (sf_pack_conv_weight of the grouped parameter [Cout][Cin / G][kT][kH][kW]).  Group g reads
+ * input channels [g Cin / G, (g + 1) Cin / G) and owns output channels, scale / bias / residual entries
+ * [g Cout / G, (g + 1) Cout / G).  shuffle != 0: its channel j is STORED at channel j * G + g — channel_shuffle(., G)
+ * as index math of the stores.  d->transposed = 1: the data gradient (d->Cin = the forward Cout, w_packed = the G
+ * transposed packs [Cin_fwd][taps][pad(Cout_fwd / G)]; strided layers predicate the taps, os_* must be <= 1).
+ * d->out_cmul must be 1.  groups == 1 && !shuffle: sf_conv_fwd.                                                   */
+int sf_conv_fwd_grouped(const sf_conv_desc* d, int groups, int shuffle, const float* in, const float* w_packed,
+                        const float* scale, const float* bias, const float* res, float* out, void* stream);
 /* Training-mode BN statistics out of the conv's epilogue (Conv3d -> BatchNorm3d of stem_helper.py:239-254,
  * resnet_helper.py:150-215 in train mode): the per-wavefront conv kernels keep shifted sums of the outputs they store
  * and leave [count, K, sum(v - K), sum((v - K)^2)] x 4 channels per (part, channel quad) in stats_ws
@@ -277,6 +290,11 @@ int sf_head_act_mean(const float* logits, int B, int P, int K, int act, float* o
  * shufflenetv2_helper.py:100-107): out[.., out_coff + c*out_cmul] = in[.., in_coff + c].          */
 int sf_copy_channels(const float* in, int in_cs, int in_coff, float* out, int out_cs, int out_coff,
                      int out_cmul, long rows, int C, void* stream);
+/* channel_shuffle(x, groups) of shufflenet_helper.py:22-34 (view [B, G, C/G, ...] -> transpose(1, 2) -> flatten) in
+ * one launch: out[.., out_coff + j*G + g] (+)= in[.., in_coff + g*(C/G) + j]  (accumulate != 0 adds).  Its inverse —
+ * the backward's gather — is the same call with groups = C / G.                                               */
+int sf_channel_shuffle(const float* in, int in_cs, int in_coff, float* out, int out_cs, int out_coff, int groups,
+                       long rows, int C, int accumulate, void* stream);
 
 /* ================================ backward (training) ============================================
  * Gradients of the ops above.  Activation gradients live in NDHWC buffers shaped like their forward
@@ -300,6 +318,14 @@ int sf_conv_wgrad_bx(const sf_conv_desc* d, const float* x, const unsigned short
                      int dz_coff, const unsigned short* dz_planes, float* partial, float* ws, void* stream);
 int sf_conv_wgrad(const sf_conv_desc* d, const float* x, const float* dz, int dz_cs, int dz_coff,
                   float* partial, void* stream);
+/* Weight gradient of the grouped convs of sf_conv_fwd_grouped in ONE launch (group = grid z of conv_wgrad.hip's
+ * LDS-tiled kernels): `d` = the forward descriptor of the whole layer, partial [S][Cout][taps][cin_pad] with S =
+ * sf_conv_wgrad_grouped_splits(d, groups) (0: channels not divisible by groups); group g's rows are
+ * [g Cout / G, (g + 1) Cout / G), so sf_conv_wgrad_finish(partial, S, Cout, taps, cin_pad, Cin / G, 0, dst, ...)
+ * leaves nn.Conv3d's grouped parameter layout [Cout][Cin / G][kT][kH][kW].                                          */
+int sf_conv_wgrad_grouped_splits(const sf_conv_desc* d, int groups);
+int sf_conv_wgrad_grouped(const sf_conv_desc* d, int groups, const float* x, const float* dz, int dz_cs, int dz_coff,
+                          float* partial, void* stream);
 /* Sum the S split partials [S][Cout][packed_taps][cin_pad] in a fixed order and store / accumulate them in
  * nn.Conv3d's own layout dst[Cout][Cin][kT][kH][kW] (one pass, so the gradient can land directly in the
  * parameter's .grad).  fold_kw > 0: the stem layout, where a packed tap is (kt,kh) and a packed channel is

@@ -1,5 +1,6 @@
-"""Grouped convolutions (1 < groups < channels) on the HIP path — engine.grouped_conv: one launch of the dense kernels
-per group on channel slices — against torch's nn.Conv3d(groups=G) on the same parameters: ShuffleNet-v1's grouped
+"""Grouped convolutions (1 < groups < channels) on the HIP path — engine.grouped_conv: ONE launch per layer and kind
+(sf_conv_fwd_grouped / sf_conv_wgrad_grouped: the block-diagonal GEMM's group is the grid's z index) on channel windows
+of the same buffers — against torch's nn.Conv3d(groups=G) on the same parameters: ShuffleNet-v1's grouped
 1x1x1 convs with channel_shuffle folded into the stores (shufflenet_helper.py:22-34, 48-63, 73) and ResNeXt's grouped
 1x3x3 (resnet_helper.py:196-205, RESNET.NUM_GROUPS > 1).  Eval (folded BN epilogue) and the taped training path
 (batch-statistics BN, gradients of input / weight / BN)."""
@@ -76,6 +77,101 @@ def test_grouped_conv_eval_and_train(case):
     assert _rel(t_.pgrads[conv.weight], wd.grad) < 5e-4, name
     assert _rel(t_.pgrads[bn.weight], gam.grad) < 5e-4 and _rel(t_.pgrads[bn.bias], bet.grad) < 5e-4, name
     assert _rel(dx, xd.grad) < 5e-4, name
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
+def test_grouped_entry_points_through_the_c_abi(case):
+    """sf_conv_fwd_grouped with the full epilogue (scale, bias, residual, ReLU; shuffled stores), its transposed form
+    accumulating into an existing gradient, and sf_conv_wgrad_grouped + sf_conv_wgrad_finish accumulating into a tensor
+    in nn.Conv3d's grouped layout — each ONE C-ABI call — against fp64 torch."""
+    import sfhip
+    name, cin, cout, G, k, s, p, (n, t, h, w), shuffle = case
+    dev = torch.device("cuda:0")
+    torch.manual_seed(100 + len(name))
+    wt = torch.randn(cout, cin // G, *k, device=dev) * 0.2
+    x = torch.randn(n, cin, t, h, w, device=dev)
+    scale, bias = torch.rand(cout, device=dev) + 0.5, torch.randn(cout, device=dev)
+    wp, wtp = sfhip.pack_grouped_weight_pair(wt, G)
+    assert tuple(wp.shape) == (cout, k[0] * k[1] * k[2], (cin // G + 15) // 16 * 16)
+    assert tuple(wtp.shape) == (cin, k[0] * k[1] * k[2], (cout // G + 15) // 16 * 16)
+    z = F.conv3d(x.double(), wt.double(), None, s, p, 1, G)
+    res = torch.randn(z.shape, device=dev)
+    xa = sfhip.from_ncthw(x)
+    sfhip.EVENT_TRACE = []
+    try:
+        # ---- forward, un-shuffled, whole epilogue
+        y = sfhip.conv_grouped(xa, wp, G, k, s, p, scale=scale, bias=bias, relu=True, res=sfhip.from_ncthw(res))
+        ref = F.relu(z * scale.double().view(1, -1, 1, 1, 1) + bias.double().view(1, -1, 1, 1, 1) + res.double())
+        assert _rel(sfhip.to_ncthw(y), ref) < 2e-5, name
+        # ---- forward, shuffled stores (no residual: shufflenet_helper.py:73 shuffles conv1's BN-ReLU output)
+        y = sfhip.conv_grouped(xa, wp, G, k, s, p, scale=scale, bias=bias, relu=True, shuffle=True)
+        ref = _shuffle(F.relu(z * scale.double().view(1, -1, 1, 1, 1) + bias.double().view(1, -1, 1, 1, 1)), G)
+        assert _rel(sfhip.to_ncthw(y), ref) < 2e-5, name
+        # ---- data gradient accumulated over an existing gradient, weight gradient accumulated into the parameter's
+        dz = torch.randn(z.shape, device=dev)
+        dza = sfhip.from_ncthw(dz)
+        dx0 = torch.randn_like(x)
+        dxa = sfhip.from_ncthw(dx0)
+        sfhip.conv_dgrad_grouped(dza, wtp, G, xa, k, s, p, out=dxa, accumulate=True)
+        dw0 = torch.randn_like(wt)
+        dw = dw0.clone()
+        sfhip.conv_wgrad_grouped(xa, dza, G, k, s, p, cin_pad=wp.shape[2], finish_into=dw)
+        calls = len(sfhip.EVENT_TRACE)
+    finally:
+        sfhip.EVENT_TRACE = None
+    assert calls == 4, calls   # one C-ABI call per conv launch (the finish is not traced)
+    xd = x.double().requires_grad_(True)
+    wd = wt.double().requires_grad_(True)
+    (F.conv3d(xd, wd, None, s, p, 1, G) * dz.double()).sum().backward()
+    assert _rel(sfhip.to_ncthw(dxa) - dx0, xd.grad) < 2e-5, name
+    assert _rel(dw - dw0, wd.grad) < 2e-5, name
+    # packed return form == the finished one
+    dwp = sfhip.conv_wgrad_grouped(xa, dza, G, k, s, p, cin_pad=wp.shape[2])
+    assert _rel(sfhip.unpack_conv_weight_grad(dwp, tuple(wt.shape)), wd.grad) < 2e-5, name
+
+
+def test_grouped_entry_points_reject_what_they_cannot_run():
+    import ctypes
+    import sfhip
+    dev = torch.device("cuda:0")
+    x = sfhip.from_ncthw(torch.randn(1, 12, 2, 4, 4, device=dev))
+    wp, _ = sfhip.pack_grouped_weight_pair(torch.randn(30, 4, 1, 1, 1, device=dev), 3)
+    with pytest.raises(sfhip.SfhipError):     # 12 input channels are not divisible by 5 groups
+        _raw_grouped(sfhip, x, wp, 5)
+    _raw_grouped(sfhip, x, wp, 3)             # the same call with a divisor is accepted
+    d = sfhip.ConvDesc(1, 2, 4, 4, 12, 12, 0, 2, 4, 4, 30, 30, 0, 1, 1, 1, 1, 1, 1, 1, 0, 0, 0, 1, 1, 1, 16, 0, 0, 0, 0)
+    assert sfhip.lib().sf_conv_wgrad_grouped_splits(ctypes.byref(d), 5) == 0
+    assert sfhip.lib().sf_conv_wgrad_grouped_splits(ctypes.byref(d), 3) > 0
+
+
+def _raw_grouped(sfhip, x, wp, groups):
+    import ctypes
+    out = sfhip.new_act(x, x.N, x.T, x.H, x.W, wp.shape[0])
+    d = sfhip.ConvDesc(x.N, x.T, x.H, x.W, x.C, x.cs, x.coff, x.T, x.H, x.W, wp.shape[0], out.cs, out.coff, 1,
+                       1, 1, 1, 1, 1, 1, 0, 0, 0, 1, 1, 1, wp.shape[2], 0, 0, 0, 0)
+    sfhip._check(sfhip.lib().sf_conv_fwd_grouped(ctypes.byref(d), groups, 0, x.ptr(), sfhip._ptr(wp), None, None, None,
+                                                 out.ptr(), sfhip._stream()), "sf_conv_fwd_grouped")
+
+
+@pytest.mark.parametrize("c,g,coff", [(240, 3, 0), (24, 4, 0), (30, 3, 6)])
+def test_channel_shuffle_one_launch_and_its_inverse(c, g, coff):
+    """sf_channel_shuffle == shufflenet_helper.py:22-34's view / transpose / flatten; groups = C/G undoes it (the
+    backward's gather, accumulating)."""
+    import sfhip
+    dev = torch.device("cuda:0")
+    torch.manual_seed(c)
+    x = torch.randn(2, c, 3, 5, 7, device=dev)
+    xa = sfhip.from_ncthw(x)
+    wide = torch.zeros(2, 3, 5, 7, c + coff + 2, device=dev)
+    out = sfhip.Act(wide, coff, c)
+    sfhip.channel_shuffle(xa, out, g)
+    got = wide[..., coff:coff + c].permute(0, 4, 1, 2, 3)
+    assert torch.equal(got, _shuffle(x, g))
+    assert float(wide[..., :coff].abs().sum()) == 0 and float(wide[..., coff + c:].abs().sum()) == 0
+    back0 = torch.randn_like(x)
+    back = sfhip.from_ncthw(back0)
+    sfhip.channel_shuffle(out, back, c // g, accumulate=True)
+    assert torch.equal(sfhip.to_ncthw(back), back0 + x)
 
 
 @pytest.mark.parametrize("c,red,thw", [(240, 1, (4, 2, 2)), (144, 1, (2, 5, 7)), (256, 8, (2, 4, 4))])
