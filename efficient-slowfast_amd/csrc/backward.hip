@@ -1066,9 +1066,18 @@ __global__ void gather_add_kernel(const float* __restrict__ in, int in_cs, int i
 
 }  // namespace
 
+int sf_dwm_dgrad_try(const sf_conv_desc* d, const float* dz, int dz_cs, int dz_coff, const float* w, float* dx,
+                     int dx_cs, int dx_coff, int C, int accumulate, hipStream_t s);  // dwconv_march.hip
+int sf_dwm_wgrad_try(const sf_conv_desc* d, const float* x, const float* dz, int dz_cs, int dz_coff, int C, float* ws,
+                     int max_blk, int* nblk, hipStream_t s);
+
 extern "C" int sf_dwconv_dgrad(const sf_conv_desc* d, const float* dz, int dz_cs, int dz_coff, const float* w_packed,
                                float* dx, int dx_cs, int dx_coff, int C, void* stream) {
   if (!d || !dz || !w_packed || !dx || C <= 0) return SF_EINVAL;
+  {  // kT x 3 x 3 stride-1 "same" layers: the row-march kernel with mirrored taps
+    const int rc = sf_dwm_dgrad_try(d, dz, dz_cs, dz_coff, w_packed, dx, dx_cs, dx_coff, C, 1, (hipStream_t)stream);
+    if (rc != 1) return rc;
+  }
   const long total = (long)d->N * d->Ti * d->Hi * d->Wi * C;
   if (C % 4 == 0 && dz_cs % 4 == 0 && dz_coff % 4 == 0 && dx_cs % 4 == 0 && dx_coff % 4 == 0 && d->cin_pad % 4 == 0 &&
       sf_aligned16(dz) && sf_aligned16(dx) && sf_aligned16(w_packed) && total / 4 < 0x7fffffffL) {
@@ -1099,7 +1108,11 @@ extern "C" int sf_dwconv_wgrad(const sf_conv_desc* d, const float* x, const floa
   const bool vec4 = (C % 4 == 0) && (d->in_cs % 4 == 0) && (d->in_coff % 4 == 0) && (dz_cs % 4 == 0) &&
                     (dz_coff % 4 == 0) && sf_aligned16(x) && sf_aligned16(dz) && sf_aligned16(ws);
   int nblk = DW_P;
-  if (rows < 0x7fffffffL && ntaps <= 27) {                   // one pass over the rows, all taps in registers
+  const int march = sf_dwm_wgrad_try(d, x, dz, dz_cs, dz_coff, C, ws, dw_row_blocks(C, rows) > DW_P ? dw_row_blocks(C, rows) : DW_P,
+                                     &nblk, (hipStream_t)stream);
+  if (march != 1) {                                          // kT x 3 x 3 stride-1 "same": the row-march kernel
+    if (march != SF_OK) return march;
+  } else if (rows < 0x7fffffffL && ntaps <= 27) {            // one pass over the rows, all taps in registers
     const int nq = (C % 4 == 0) ? C / 4 : C;                 // (the row-block count follows C % 4 alone: see ws_floats)
     const int CQ = dw_quads_per_block(nq);
     nblk = dw_row_blocks(C, rows);

@@ -901,11 +901,18 @@ extern "C" int sf_maxpool_bwd_arg(const sf_pool_desc* d, const unsigned char* ar
   return SF_OK;
 }
 
+int sf_dwm_fwd_try(const sf_conv_desc* d, const float* in, const float* w, const float* scale, const float* bias,
+                   const float* res, float* out, hipStream_t s);  // dwconv_march.hip
+
 extern "C" int sf_dwconv_fwd(const sf_conv_desc* d, const float* in, const float* w_packed, const float* scale,
                              const float* bias, const float* res, float* out, void* stream) {
   if (!d || !in || !w_packed || !out || d->Cout <= 0 || d->Cout > d->Cin || d->cin_pad < d->Cin) return SF_EINVAL;
   if ((scale == nullptr) != (bias == nullptr)) return SF_EINVAL;
   if (d->act != SF_ACT_NONE && d->act != SF_ACT_RELU && d->act != SF_ACT_RELU6) return SF_EINVAL;
+  {  // kT x 3 x 3 stride-1 "same" layers: the row-march kernels
+    const int rc = sf_dwm_fwd_try(d, in, w_packed, scale, bias, res, out, (hipStream_t)stream);
+    if (rc != 1) return rc;
+  }
   const bool vec4 = (d->Cout % 4 == 0) && (d->in_cs % 4 == 0) && (d->in_coff % 4 == 0) && (d->cin_pad % 4 == 0) &&
                     sf_aligned16(in) && sf_aligned16(w_packed);
   const long pos = (long)d->N * d->To * d->Ho * d->Wo;

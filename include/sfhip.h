@@ -112,7 +112,8 @@ int sf_conv_fwd_stats(const sf_conv_desc* d, const float* in, const float* w_pac
  * 2 plain layers, 3 plain layers with <= 5 K steps); knob 6: conv_small.hip (bit 0 enable); knob 7: conv_bx.hip (0 off,
  * 1 where it wins, 2 every shape it covers); knob 8: its timing ablations; knobs 10 / 11 / 12: the weight-gradient kernels of
  * conv_wgrad_wave.hip — 10: value 0 routes every weight gradient to conv_wgrad.hip, 11: force the blocks per
- * wavefront (-1: planner), 12: workgroups to aim at (0: default).  Returns SF_EINVAL for an unknown knob.      */
+ * wavefront (-1: planner), 12: workgroups to aim at (0: default); knob 30: the row-march depthwise kernels
+ * (dwconv_march.hip) off / on.  Returns SF_EINVAL for an unknown knob.                                           */
 int sf_conv_tune(int knob, int value);
 /* ---- long reductions on the bf16 matrix pipe with fp32-exact operands (conv_bx.hip) --------------------------------
  * gfx950's f32-input MFMA runs at the vector rate, its bf16 MFMA at 16x that.  Every fp32 value is the EXACT sum of
@@ -162,7 +163,10 @@ int sf_pack_conv_weights(const void* items, const int* blk0, int n, int nblocks,
 /* ---- depthwise convolution (groups == channels) ----------------------------------------------
  * ghostnet_helper.py:88-90,114-120,137-143; shufflenetv2_helper.py:62-64,74-75,89-91.
  * Weights packed [kT*kH*kW][C].  `Cout` <= C output channels are produced (GhostModule's
- * out[:, :oup] slice, ghostnet_helper.py:99).                                                  */
+ * out[:, :oup] slice, ghostnet_helper.py:99).  kT x 3 x 3 (kT = 1 | 3) stride-1 "same" layers — the cheap operations
+ * and stride-1 conv_dw of ghostnet_helper.py, the branch convs of shufflenetv2_helper.py — run as row marches
+ * (dwconv_march.hip: a thread walks a column of rows with the 3 x 3 x kT window in registers), forward, data and weight
+ * gradient; every other shape on the position-per-thread kernels.  Same results either way (fp32 sums in tap order). */
 int sf_dwconv_fwd(const sf_conv_desc* d, const float* in, const float* w_packed, const float* scale,
                   const float* bias, const float* res, float* out, void* stream);
 
