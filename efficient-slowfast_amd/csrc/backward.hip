@@ -1018,7 +1018,8 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_partial4_kernel(const sf_con
   }
 }
 
-__global__ void dwconv_wgrad_final_kernel(const float* __restrict__ partial, int n, int nblk, float* __restrict__ out) {
+__global__ void dwconv_wgrad_final_kernel(const float* __restrict__ partial, int n, int nblk, float* __restrict__ out,
+                                          int C, int ntaps, int to_param, int accumulate) {
   const int i = blockIdx.x * TPB + threadIdx.x;  // i over ntaps*C
   if (i >= n) return;
   double s = 0.0;
@@ -1031,7 +1032,9 @@ __global__ void dwconv_wgrad_final_kernel(const float* __restrict__ partial, int
     for (int u = 0; u < 8; ++u) s += (double)v[u];
   }
   for (; b < nblk; ++b) s += (double)partial[(long)b * n + i];
-  out[i] = (float)s;
+  // to_param: nn.Conv3d's own depthwise layout [C][1][kT][kH][kW] = [c][tap] instead of the packed [tap][c]
+  float* const o = out + (to_param ? (long)(i % C) * ntaps + i / C : (long)i);
+  *o = accumulate ? *o + (float)s : (float)s;
 }
 
 // Row blocks of the one-pass kernel: enough workgroups to fill the chip when the layer has few channel blocks
@@ -1099,8 +1102,8 @@ extern "C" long sf_dwconv_wgrad_ws_floats(const sf_conv_desc* d, int C) {
   return (long)(nb > DW_P ? nb : DW_P) * d->kT * d->kH * d->kW * C;
 }
 
-extern "C" int sf_dwconv_wgrad(const sf_conv_desc* d, const float* x, const float* dz, int dz_cs, int dz_coff, int C,
-                               float* dw /* [taps][C] */, float* ws, void* stream) {
+static int dwconv_wgrad_impl(const sf_conv_desc* d, const float* x, const float* dz, int dz_cs, int dz_coff, int C,
+                             float* dw, float* ws, int to_param, int accumulate, void* stream) {
   if (!d || !x || !dz || !dw || !ws || C <= 0) return SF_EINVAL;
   const long rows = (long)d->N * d->To * d->Ho * d->Wo;
   const int CB = pow2ceil_b(C) < TPB ? pow2ceil_b(C) : TPB;
@@ -1135,9 +1138,21 @@ extern "C" int sf_dwconv_wgrad(const sf_conv_desc* d, const float* x, const floa
     hipLaunchKernelGGL(dwconv_wgrad_partial_kernel, dim3(DW_P, sf_cdiv(C, CB)), dim3(TPB), 0, (hipStream_t)stream, *d, x,
                        dz, dz_cs, dz_coff, C, CB, rows, ws);
   hipLaunchKernelGGL(dwconv_wgrad_final_kernel, dim3(sf_cdiv(ntaps * C, TPB)), dim3(TPB), 0, (hipStream_t)stream, ws,
-                     ntaps * C, nblk, dw);
+                     ntaps * C, nblk, dw, C, ntaps, to_param, accumulate);
   SF_CHECK_LAUNCH();
   return SF_OK;
+}
+
+extern "C" int sf_dwconv_wgrad(const sf_conv_desc* d, const float* x, const float* dz, int dz_cs, int dz_coff, int C,
+                               float* dw /* [taps][C] */, float* ws, void* stream) {
+  return dwconv_wgrad_impl(d, x, dz, dz_cs, dz_coff, C, dw, ws, 0, 0, stream);
+}
+
+// The same with the result stored (accumulate == 0) or accumulated in nn.Conv3d's own layout [C][1][kT][kH][kW]: the
+// gradient lands in the parameter's .grad without a transpose and an add.
+extern "C" int sf_dwconv_wgrad_param(const sf_conv_desc* d, const float* x, const float* dz, int dz_cs, int dz_coff,
+                                     int C, float* dw_param, int accumulate, float* ws, void* stream) {
+  return dwconv_wgrad_impl(d, x, dz, dz_cs, dz_coff, C, dw_param, ws, 1, accumulate, stream);
 }
 
 extern "C" int sf_gather_add(const float* in, int in_cs, int in_coff, int in_cmul, float* out, int out_cs,

@@ -60,6 +60,7 @@ EXPORTS = [
     "sf_bx_planes_elems", "sf_bx_split", "sf_bx_split_batched", "sf_conv_pw_ws_floats", "sf_conv_pw_stats_floats", "sf_conv_fwd_pw", "sf_conv_bx_ws_floats", "sf_conv_fwd_bx", "sf_conv_wgrad_bx_splits",
     "sf_conv_wgrad_bx_ws_floats", "sf_conv_wgrad_bx",
     "sf_conv_fwd_grouped", "sf_conv_wgrad_grouped_splits", "sf_conv_wgrad_grouped", "sf_channel_shuffle",
+    "sf_dwconv_wgrad_param",
 ]
 _LONG_RET = ("sf_tmax_mean_ws_floats", "sf_channel_stats_ws_floats", "sf_bn_bwd_ws_floats",
              "sf_dwconv_wgrad_ws_floats", "sf_attn_bwd_fused_ws_floats", "sf_conv_fwd_ws_floats",
@@ -133,6 +134,7 @@ def lib():
         L.sf_dwconv_wgrad_ws_floats.argtypes = [ctypes.POINTER(ConvDesc), ci]
         L.sf_dwconv_wgrad_ws_floats.restype = cl
         L.sf_dwconv_wgrad.argtypes = [ctypes.POINTER(ConvDesc), vp, vp, ci, ci, ci, vp, vp, vp]
+        L.sf_dwconv_wgrad_param.argtypes = [ctypes.POINTER(ConvDesc), vp, vp, ci, ci, ci, vp, ci, vp, vp]
         L.sf_gather_add.argtypes = [vp, ci, ci, ci, vp, ci, ci, cl, ci, ci, vp]
         L.sf_clip_prologue.argtypes = [vp] + [ci] * 10 + [ctypes.POINTER(ctypes.c_float)] * 2 + [vp, ci, vp, ci, ci, ci, vp]
         L.sf_attn_bwd_fused_ws_floats.argtypes = [ci, ci, ci]
@@ -581,10 +583,12 @@ def conv(x, wp, kernel, stride=(1, 1, 1), padding=(0, 0, 0), dilation=(1, 1, 1),
 
 def dwconv(x, wp, kernel, stride=(1, 1, 1), padding=(0, 0, 0), scale=None, bias=None, relu=False, res=None,
            out=None, cout=None, out_cmul=1):
-    """Depthwise conv (sf_dwconv_fwd); wp = pack_dw_weight(...) [taps, C]."""
+    """Depthwise conv (sf_dwconv_fwd); wp = pack_dw_weight(...) [taps, C], or [taps, pitch >= C] (the transposed
+    half of pack_conv_weight_pair of the [C, 1, kT, kH, kW] parameter)."""
     _require_gpu(x.buf, "dwconv")
-    taps, c = wp.shape
-    assert c == x.C
+    taps, wpitch = wp.shape
+    c = x.C
+    assert wpitch >= c, (wp.shape, x)
     cout = c if cout is None else cout
     kT, kH, kW = kernel
     To = _out_dim(x.T, kT, stride[0], padding[0], 1)
@@ -596,7 +600,7 @@ def dwconv(x, wp, kernel, stride=(1, 1, 1), padding=(0, 0, 0), scale=None, bias=
         assert (out.N, out.T, out.H, out.W) == (x.N, To, Ho, Wo)
     d = ConvDesc(x.N, x.T, x.H, x.W, c, x.cs, x.coff, To, Ho, Wo, cout, out.cs, out.coff, out_cmul,
                  kT, kH, kW, stride[0], stride[1], stride[2], padding[0], padding[1], padding[2], 1, 1, 1,
-                 c, _act(relu),
+                 wpitch, _act(relu),
                  res.cs if res is not None else 0, res.coff if res is not None else 0, 0)
     # trace tag: ("dwconv", algorithmic HBM bytes = input + output (+ residual) rows once)
     nbytes = 4 * (x.rows * c + out.rows * cout * (2 if res is not None else 1))
@@ -1197,21 +1201,30 @@ def bn_train_stats_merge(parts, C, gamma, beta, eps, momentum, run_mean, run_var
     return o[0], o[2], o[3], o[4]
 
 
-def _dw_desc(x, dz, kernel, stride, padding):
+def _dw_desc(x, dz, kernel, stride, padding, wpitch=None):
     return ConvDesc(x.N, x.T, x.H, x.W, x.C, x.cs, x.coff, dz.T, dz.H, dz.W, x.C, 0, 0, 1,
                     kernel[0], kernel[1], kernel[2], stride[0], stride[1], stride[2], padding[0], padding[1],
-                    padding[2], 1, 1, 1, x.C, ACT_NONE, 0, 0, 0)
+                    padding[2], 1, 1, 1, x.C if wpitch is None else wpitch, ACT_NONE, 0, 0, 0)
 
 
-def dwconv_bwd(x, dz, wp, kernel, stride, padding, dx=None):
-    """Depthwise conv backward: returns dw [taps, C]; accumulates the data gradient into dx (if given)."""
-    d = _dw_desc(x, dz, kernel, stride, padding)
+def dwconv_bwd(x, dz, wp, kernel, stride, padding, dx=None, into=None):
+    """Depthwise conv backward: returns dw [taps, C]; accumulates the data gradient into dx (if given).
+    into: a contiguous tensor in the parameter's own layout [C, 1, kT, kH, kW] (its .grad) — the weight gradient is
+    ACCUMULATED there by the reduction's final step (sf_dwconv_wgrad_param) and None is returned."""
+    d = _dw_desc(x, dz, kernel, stride, padding, wp.shape[1])
     C = x.C
-    dw = torch.empty((kernel[0] * kernel[1] * kernel[2], C), dtype=torch.float32, device=x.buf.device)
     ws = torch.empty((lib().sf_dwconv_wgrad_ws_floats(ctypes.byref(d), C),), dtype=torch.float32,
                      device=x.buf.device)
-    _check(lib().sf_dwconv_wgrad(ctypes.byref(d), x.ptr(), dz.ptr(), dz.cs, dz.coff, C, _ptr(dw), _ptr(ws),
-                                 _stream()), "sf_dwconv_wgrad")
+    if into is not None:
+        assert into.is_contiguous() and into.dtype == torch.float32 and \
+            into.numel() == C * kernel[0] * kernel[1] * kernel[2], (into.shape, C, kernel)
+        dw = None
+        _check(lib().sf_dwconv_wgrad_param(ctypes.byref(d), x.ptr(), dz.ptr(), dz.cs, dz.coff, C, _ptr(into), 1,
+                                           _ptr(ws), _stream()), "sf_dwconv_wgrad_param")
+    else:
+        dw = torch.empty((kernel[0] * kernel[1] * kernel[2], C), dtype=torch.float32, device=x.buf.device)
+        _check(lib().sf_dwconv_wgrad(ctypes.byref(d), x.ptr(), dz.ptr(), dz.cs, dz.coff, C, _ptr(dw), _ptr(ws),
+                                     _stream()), "sf_dwconv_wgrad")
     if dx is not None:
         _check(lib().sf_dwconv_dgrad(ctypes.byref(d), dz.ptr(), dz.cs, dz.coff, _ptr(wp), dx.ptr(), dx.cs, dx.coff,
                                      C, _stream()), "sf_dwconv_dgrad")
@@ -1220,7 +1233,7 @@ def dwconv_bwd(x, dz, wp, kernel, stride, padding, dx=None):
 
 def dwconv_dgrad(x, dz, wp, kernel, stride, padding, dx):
     """dx += transposed depthwise conv of dz (data gradient only: constant-weight pooling)."""
-    d = _dw_desc(x, dz, kernel, stride, padding)
+    d = _dw_desc(x, dz, kernel, stride, padding, wp.shape[1])
     _check(lib().sf_dwconv_dgrad(ctypes.byref(d), dz.ptr(), dz.cs, dz.coff, _ptr(wp), dx.ptr(), dx.cs, dx.coff,
                                  x.C, _stream()), "sf_dwconv_dgrad")
     return dx

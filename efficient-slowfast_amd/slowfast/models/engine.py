@@ -63,6 +63,9 @@ class Tape(object):
         self.joins = set()  # companion streams with weight-gradient work in flight (joined at the end of backward)
         self.model = None   # the model whose forward this tape records (milestone hooks are bound to it)
         self.early = None   # backward: event a fusion region left for the next region's side stream (run_paths)
+        self.arena = None   # backward of a small model: ONE zero-filled tensor the gradient buffers are cut from
+        self.arena_off = 0
+        self.zero_floats = -1  # >= 0 while the backward runs: floats of zero-initialised buffers it has asked for
 
     def pgrad_target(self, param):
         """The tensor kernels may accumulate this parameter's gradient into directly, or None."""
@@ -75,7 +78,16 @@ class Tape(object):
         key = act.buf.data_ptr()
         g = self.gbuf.get(key)
         if g is None:
-            g = torch.zeros(act.buf.numel(), dtype=torch.float32, device=act.buf.device)
+            n = act.buf.numel()
+            nal = (n + 63) // 64 * 64
+            if self.zero_floats >= 0:
+                self.zero_floats += nal
+            if self.arena is not None and self.arena_off + nal <= self.arena.numel() and \
+                    self.arena.device == act.buf.device:
+                g = self.arena[self.arena_off:self.arena_off + n]
+                self.arena_off += nal
+            else:
+                g = torch.zeros(n, dtype=torch.float32, device=act.buf.device)
             self.gbuf[key] = g
         return Act(g.view(act.buf.shape), act.coff, act.C)
 
@@ -108,6 +120,7 @@ class Tape(object):
     def backward(self):
         """Replay in reverse.  Ops recorded inside run_paths on the side stream run there again; the region's
         join / fork markers become the backward pass's fork / join."""
+        self._open_arena()
         for fn, side in reversed(self.ops):
             if side is None:
                 fn()
@@ -118,7 +131,25 @@ class Tape(object):
             _sync_streams(wg, torch.cuda.current_stream(wg.device))
         self.joins = set()
         self.ops = []
+        if self.model is not None and self.zero_floats >= 0:
+            self.model.__dict__["_sf_arena_floats"] = self.zero_floats
+        self.zero_floats = -1
         self.gbuf = {}
+        self.arena = None
+
+    def _open_arena(self):
+        """Launch-bound models (cfg #1: ~115 gradient buffers of a few KB each): the zero-initialised gradient buffers of
+        one backward come out of ONE zero-filled tensor — one fill launch instead of one per buffer.  Sized by what the
+        previous backward of the same model asked for; made here, on the stream the backward starts on and before any
+        side stream is forked, so every later use is ordered behind the fill.  Large models keep one fill per buffer
+        (the fills then overlap with the backward's kernels instead of delaying its first one)."""
+        self.zero_floats = 0
+        if self.model is None or ARENA_MAX_FLOATS <= 0 or self.out_act is None:
+            return
+        want = self.model.__dict__.get("_sf_arena_floats", 0)
+        if 0 < want <= ARENA_MAX_FLOATS:
+            self.arena = torch.zeros(want, dtype=torch.float32, device=self.out_act.buf.device)
+            self.arena_off = 0
 
 
 def tape():
@@ -589,6 +620,7 @@ def norm_forward(bn, x):
     return leave([y])[0]
 
 
+ARENA_MAX_FLOATS = int(float(os.environ.get("SF_GRAD_ARENA_MB", "64")) * (1 << 18))  # 0: off
 _PAIR_WEIGHTS = {}  # id(weight) -> weakref of the dense conv weights that have been packed as a pair (tensors compare
 # elementwise, so no WeakSet): repack_all's candidates
 BATCHED_REPACK = os.environ.get("SF_BATCH_REPACK", "1") != "0"
@@ -635,6 +667,10 @@ def packed_weight(conv):
     if conv.groups == 1:
         return _packed_pair(conv.weight)[0]
     if conv.groups == conv.in_channels and conv.out_channels == conv.in_channels:
+        if conv.weight.is_cuda:
+            # [taps][pad16(C)]: the transposed half of the pair pack of the [C, 1, kT, kH, kW] parameter — depthwise
+            # weights are then re-packed after an optimizer step by repack_all's ONE launch, with the dense ones
+            return _packed_pair(conv.weight)[1][0]
         return _cached(conv, "_sf_wp", _key(conv.weight), lambda: sfhip.pack_dw_weight(conv.weight))
     return _group_pairs(conv)
 
@@ -747,8 +783,13 @@ def conv_bn_act(x, conv, bn=None, relu=False, res=None, out=None, out_reserve=(0
             t = tape()
             if t is not None:
                 def bwd_dw():  # z's buffer holds dL/dz after the BN backward
-                    dw = sfhip.dwconv_bwd(x, z, wp, k, s, p, dx=t.grad_of(x))
-                    t.add_pgrad(conv.weight, dw.t().contiguous())
+                    tgt = t.pgrad_target(conv.weight)
+                    wpk = packed_weight(conv)   # (this step's pack: the forward's may have been re-packed in place)
+                    if tgt is not None:  # the reduction's final step accumulates into the parameter's gradient
+                        sfhip.dwconv_bwd(x, z, wpk, k, s, p, dx=t.grad_of(x), into=tgt)
+                    else:
+                        dw = sfhip.dwconv_bwd(x, z, wpk, k, s, p, dx=t.grad_of(x))
+                        t.add_pgrad(conv.weight, dw[:, :x.C].t().contiguous())
                     if conv.bias is not None:
                         t.add_pgrad(conv.bias, _colsum(z))
 

@@ -403,6 +403,10 @@ int sf_dwconv_dgrad(const sf_conv_desc* d, const float* dz, int dz_cs, int dz_co
 long sf_dwconv_wgrad_ws_floats(const sf_conv_desc* d, int C);
 int sf_dwconv_wgrad(const sf_conv_desc* d, const float* x, const float* dz, int dz_cs, int dz_coff, int C,
                     float* dw, float* ws, void* stream);
+/* sf_dwconv_wgrad with the sum stored (accumulate == 0) or accumulated in the parameter's own layout
+ * dw_param[C][1][kT][kH][kW] (nn.Conv3d(C, C, k, groups = C).weight): the gradient reaches .grad in the same launch. */
+int sf_dwconv_wgrad_param(const sf_conv_desc* d, const float* x, const float* dz, int dz_cs, int dz_coff, int C,
+                          float* dw_param, int accumulate, float* ws, void* stream);
 /* out[r, c] (+)= in[r, in_coff + c*in_cmul]: backward of a channel-multiplier (shuffled) store.           */
 int sf_gather_add(const float* in, int in_cs, int in_coff, int in_cmul, float* out, int out_cs, int out_coff,
                   long rows, int C, int accumulate, void* stream);
