@@ -489,11 +489,14 @@ static int bn_bwd_reduce_launch(const float* dy, int dy_cs, int dy_coff, const f
   // the other pathway's kernels, and restricting the tickets to <= 16 384 rows measured 54.47-54.55 ms against
   // 54.26-54.54 with them everywhere (three alternations on one box): the thin launch leaves the chip to its neighbour
   // and the final launch it saves is on the stream's critical path.  Kept as it was.
-  const bool few = ring && sf_tickets_level() == 2 && S == 1 && vec4 && C >= 256;
-  const bool fused = (ring && sf_tickets_enabled()) || few;
   red_geometry(group_rows, C, vec4 ? 4 : 1, &CB, &P);
+  // small tensors (the launch-bound models): <= 16 row blocks in the natural geometry — the last arriver's walk is
+  // short and the final launch it replaces is a third of the reduction's launches
+  const bool small = ring && sf_tickets_level() >= 1 && S == 1 && P <= 16;
+  const bool few = !small && ring && sf_tickets_level() == 2 && S == 1 && vec4 && C >= 256;
+  const bool fused = (ring && sf_tickets_enabled()) || few || small;
   const int max_p = few ? 64 : (fused ? 512 : MAX_P);
-  if (fused && CB > 16) {  // <= 64 channels per channel group: the groups' last workgroups finish in parallel
+  if (fused && !small && CB > 16) {  // <= 64 channels per channel group: the groups' last workgroups finish in parallel
     CB = 16;
     long pp = group_rows / ((long)(TPB / CB) * 8);
     P = (int)(pp < 1 ? 1 : (pp > max_p ? max_p : pp));

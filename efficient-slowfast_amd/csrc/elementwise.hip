@@ -980,10 +980,16 @@ static int stats_launch(const float* x, int cs, int coff, int groups, long group
   if (groups > STAT_MAX_P || S <= 0 || groups % S != 0) return SF_EINVAL;
   const bool vec4 = (C % 4 == 0) && (cs % 4 == 0) && (coff % 4 == 0) && sf_aligned16(x);
   const int cv = sf_cdiv(C, vec4 ? 4 : 1);
-  const bool fused = sf_tickets_enabled() && sf_ticket_ring_ready(s);
-  // fused launch: <= 16 lanes (64 channels) per channel group, so that the group's last workgroup finishes few outputs
-  // while the groups finish in parallel, and <= 512 partials per output
-  const int cb_max = fused ? 16 : TPB;
+  const bool ring = sf_ticket_ring_ready(s);
+  // small tensors (the launch-bound models: cfg #1's 16 384 .. 32 rows): the natural geometry has <= 16 row blocks, the
+  // last arriver's walk is 16 partials per output at most and the final launch it replaces is a sixth of the layer's
+  // launches — fused whenever the tickets are not switched off (SF_BN_TICKET=0)
+  const bool small = ring && sf_tickets_level() >= 1 && S == 1 && groups == 1 &&
+                     group_rows / ((long)(TPB / (pow2ceil(cv) < TPB ? pow2ceil(cv) : TPB)) * 8) <= 16;
+  const bool fused = (sf_tickets_enabled() && ring) || small;
+  // fused launch of a LARGE tensor: <= 16 lanes (64 channels) per channel group, so that the group's last workgroup
+  // finishes few outputs while the groups finish in parallel, and <= 512 partials per output
+  const int cb_max = (fused && !small) ? 16 : TPB;
   const int CB = pow2ceil(cv) < cb_max ? pow2ceil(cv) : cb_max;
   const int rpi = TPB / CB;
   const int max_p = fused ? 512 : STAT_MAX_P;

@@ -17,10 +17,13 @@ ON = [False]
 
 
 def caller():
+    out = []
     for fr in reversed(traceback.extract_stack()[:-2]):
         if "/torch/" not in fr.filename and "count_torch_ops" not in fr.filename:
-            return os.path.basename(fr.filename), fr.lineno
-    return "?", 0
+            out.append("%s:%d" % (os.path.basename(fr.filename), fr.lineno))
+            if len(out) == 2:
+                break
+    return (" <- ".join(out) or "?",)
 
 
 def wrap(obj, name, pred=None):
@@ -60,4 +63,4 @@ ON[0] = False
 torch.cuda.synchronize()
 print("torch-level device ops in one step: %d" % sum(counts.values()))
 for k, v in counts.most_common(60):
-    print("%5d  %-14s %s:%d" % (v, k[0], k[1], k[2]))
+    print("%5d  %-14s %s" % (v, k[0], k[1]))
