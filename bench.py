@@ -46,6 +46,7 @@ for p in (ROOT, os.path.join(ROOT, "efficient-slowfast_amd"), os.path.join(ROOT,
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
 
 WORKLOADS = {
     "dual": ("SLOWFAST_DUAL_8x8_R50.yaml", 8, "SlowFastDualAttention 8x8 R50 + CMDA, 224^2, T=32 alpha=4"),
@@ -347,6 +348,26 @@ def spawn_selftest(rank, world):
         dist.destroy_process_group()
 
 
+def settle(measure, device, cap=40, group=4, tol=0.02):
+    """Run `measure(group)` -> (ms per step, host issue ms per step) until two successive groups take the same time
+    within tol (at most `cap` steps); -> ((ms, issue ms), steps run).  With a process group of more than one rank every
+    rank must run the SAME number of steps (each step holds collectives): the decision is taken on the slowest rank's
+    times, which all ranks see identically after one MAX all-reduce per group."""
+    prev, n = None, 0
+    while True:
+        cur = tuple(measure(group))
+        n += group
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            t = torch.tensor(cur, dtype=torch.float64, device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            cur = tuple(t.tolist())
+        if prev is not None and abs(cur[0] - prev[0]) <= tol * min(cur[0], prev[0]):
+            return min(cur, prev), n
+        if n >= cap:
+            return cur, n
+        prev = cur
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -444,19 +465,7 @@ def main():
         torch.cuda.synchronize()
         return (time.perf_counter() - t0) / n * 1e3, t_issue / n * 1e3
 
-    def settle(fn, cap=40, group=4, tol=0.02):
-        """run fn in groups until two successive groups take the same time within tol; -> (ms, issue ms, steps run)"""
-        prev, n = None, 0
-        while True:
-            cur = ms_per(fn, group)
-            n += group
-            if prev is not None and abs(cur[0] - prev[0]) <= tol * min(cur[0], prev[0]):
-                return min(cur, prev), n
-            if n >= cap:
-                return cur, n
-            prev = cur
-
-    (eager_ms, issue_ms), settle_steps = settle(step)
+    (eager_ms, issue_ms), settle_steps = settle(lambda n: ms_per(step, n), device)
     launch_probe = {"steady_state_steps": settle_steps, "eager_ms": round(eager_ms, 3),
                     "host_issue_ms": round(issue_ms, 3)}
     graph = None
@@ -492,23 +501,23 @@ def main():
         try:
             graph, out = capture()
             if auto:
-                (graph_ms, _), _n = settle(graph.replay, cap=24)
+                (graph_ms, _), _n = settle(lambda n: ms_per(graph.replay, n), device, cap=24)
                 launch_probe["graph_ms"] = round(graph_ms, 3)
                 # torch.cuda.graph() emptied the allocator's cache before capturing: the first eager steps after it
                 # re-allocate every block of the step (measured: 82 ms per step over the next 20 instead of 59) — the
                 # eager form is warmed up again and RE-TIMED before the two warm figures are compared
-                (eager_ms, issue_ms), _n = settle(step, cap=24)
+                (eager_ms, issue_ms), _n = settle(lambda n: ms_per(step, n), device, cap=24)
                 launch_probe["eager_ms_after_capture"] = round(eager_ms, 3)
                 launch_probe["host_issue_ms_after_capture"] = round(issue_ms, 3)
                 if graph_ms >= min(eager_ms, launch_probe["eager_ms"]):
                     graph = None  # drops the graph and its private memory pool
                     graph_note = "eager (host-bound, but the warm hipGraph replay was not faster)"
-                    settle(step, cap=12)
+                    settle(lambda n: ms_per(step, n), device, cap=12)
                 launch_probe["timed"] = "eager" if graph is None else "hipGraph replay"
         except Exception as e:  # noqa: BLE001 — fall back to eager launches and say so in the JSON line
             graph, graph_note = None, "hipGraph capture failed (%s: %s); eager launches" % (type(e).__name__, str(e)[:120])
             torch.cuda.synchronize()
-            settle(step, cap=12)
+            settle(lambda n: ms_per(step, n), device, cap=12)
     if graph is None:
         with torch.cuda.stream(side):
             out = step()  # the tensor the finiteness check reads belongs to the form that is timed

@@ -1,6 +1,7 @@
 """world_size-2 gloo tests (CPU) of the data-parallel path: flat-buffer gradient all-reduce == the mean of the
 per-rank gradients == single-process gradient of the concatenated batch; clip sharding; max-over-ranks."""
 import os
+import sys
 import socket
 
 import pytest
@@ -251,3 +252,35 @@ def test_bench_starts_its_own_ranks():
 def test_bench_launcher_reports_a_failed_rank():
     r = _run_bench(["--gpus", "2", "--spawn-selftest"], env={"SF_SELFTEST_FAIL_RANK": "1"})
     assert r.returncode == 3
+
+
+def _settle_worker(rank, world, port, out):
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    try:
+        # rank 0's own times agree at once (it would stop after 8 steps), rank 1's only from the fourth group on
+        series = {0: [10.0, 10.0, 10.0, 10.0, 10.0, 10.0], 1: [30.0, 20.0, 15.0, 15.0, 15.0, 15.0]}[rank]
+        calls = []
+
+        def measure(n):
+            calls.append(n)
+            dist.barrier()   # the measured steps hold collectives: a rank that ran more groups would hang here
+            return series[len(calls) - 1], 1.0
+
+        (ms, issue), steps = bench.settle(measure, torch.device("cpu"))
+        torch.save((ms, issue, steps, len(calls)), "%s.%d" % (out, rank))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_steady_state_warmup_runs_the_same_steps_on_every_rank(tmp_path):
+    """bench.settle decides on the slowest rank's times (one MAX all-reduce per group): both ranks stop after the same
+    group although rank 0's own times would have stopped two groups earlier — a rank-local decision would leave the
+    ranks with different numbers of all-reduce-carrying steps (SlowFast/tools/train_net.py:78-96 under DDP)."""
+    out = str(tmp_path / "settle")
+    mp.spawn(_settle_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    r0, r1 = torch.load(out + ".0"), torch.load(out + ".1")
+    assert r0 == r1
+    assert r0[2] == 16 and r0[3] == 4 and r0[0] == 15.0
