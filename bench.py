@@ -260,26 +260,94 @@ def _parse_cpulist(txt):
     return cpus
 
 
-def rank_cpu_sets(n):
-    """CPUs for each of n ranks of this node, WITHOUT touching the GPU: the CPUs of the NUMA node GPU r hangs off
-    (/sys/class/drm/renderD<128 + r>/device/numa_node) shared evenly between the ranks on that node; an even split of
-    the allowed CPUs where sysfs does not say.  The launcher threads of 8 ranks otherwise wander over one host."""
-    allowed = sorted(os.sched_getaffinity(0))
-    nodes = []
-    for r in range(n):
-        node = -1
+def _fmt_cpulist(cpus):
+    """[0, 1, 2, 3, 8, 9] -> '0-3,8-9'"""
+    out, i = [], 0
+    cpus = sorted(cpus)
+    while i < len(cpus):
+        j = i
+        while j + 1 < len(cpus) and cpus[j + 1] == cpus[j] + 1:
+            j += 1
+        out.append(str(cpus[i]) if i == j else "%d-%d" % (cpus[i], cpus[j]))
+        i = j + 1
+    return ",".join(out)
+
+
+def _visible_ordinals(n):
+    """Physical ordinal of HIP device r for r < n under HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES
+    / GPU_DEVICE_ORDINAL (numeric lists; they compose: ROCR filters what HIP then indexes), or None when a list is not
+    numeric (UUIDs) or too short — the caller then does not guess."""
+    phys = None
+    for var in ("ROCR_VISIBLE_DEVICES", "GPU_DEVICE_ORDINAL", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is None or v.strip() == "":
+            continue
         try:
-            with open("/sys/class/drm/renderD%d/device/numa_node" % (128 + r)) as f:
+            lst = [int(x) for x in v.split(",") if x.strip() != ""]
+        except ValueError:
+            return None
+        if phys is None:
+            phys = lst
+        else:
+            if any(k >= len(phys) or k < 0 for k in lst):
+                return None
+            phys = [phys[k] for k in lst]
+    if phys is None:
+        return list(range(n))
+    return phys[:n] if len(phys) >= n else None
+
+
+def gpu_numa_nodes(n, sysfs="/sys"):
+    """NUMA node of HIP devices 0 .. n-1 WITHOUT touching the GPU, or None per device where sysfs does not say.  HIP
+    enumerates the KFD topology's GPU nodes (simd_count > 0) in node order; a node's `domain` and `location_id`
+    (bus << 8 | device << 3 | function) are its PCI address, whose numa_node file names the host node.  (DRM render
+    minors are NOT used: they need not be contiguous or ordered like HIP ordinals, and a BMC's VGA device takes one.)"""
+    ords = _visible_ordinals(n)
+    if ords is None:
+        return [None] * n
+    gpus = []
+    top = os.path.join(sysfs, "class/kfd/kfd/topology/nodes")
+    try:
+        ids = sorted(int(d) for d in os.listdir(top) if d.isdigit())
+    except OSError:
+        return [None] * n
+    for d in ids:
+        props = {}
+        try:
+            with open(os.path.join(top, str(d), "properties")) as f:
+                for line in f:
+                    kv = line.split()
+                    if len(kv) == 2:
+                        props[kv[0]] = kv[1]
+            if int(props.get("simd_count", "0")) <= 0:
+                continue  # a CPU node
+            loc, dom = int(props["location_id"]), int(props.get("domain", "0"))
+        except (OSError, ValueError, KeyError):
+            gpus.append(None)
+            continue
+        addr = "%04x:%02x:%02x.%d" % (dom, (loc >> 8) & 0xff, (loc >> 3) & 0x1f, loc & 7)
+        try:
+            with open(os.path.join(sysfs, "bus/pci/devices", addr, "numa_node")) as f:
                 node = int(f.read().strip())
+            gpus.append(node if node >= 0 else None)
         except (OSError, ValueError):
-            pass
-        nodes.append(node)
+            gpus.append(None)
+    return [gpus[o] if 0 <= o < len(gpus) else None for o in ords]
+
+
+def rank_cpu_sets(n, sysfs="/sys"):
+    """CPUs for each of n ranks of this node, WITHOUT touching the GPU: the CPUs of the NUMA node GPU r hangs off
+    (gpu_numa_nodes) shared evenly between the ranks on that node; an even split of the allowed CPUs where sysfs does not
+    say or the visibility variables cannot be followed.  The launcher threads of 8 ranks otherwise wander over one
+    host.  -> [(node or -1, cpus)]"""
+    allowed = sorted(os.sched_getaffinity(0))
+    nodes = [-1 if k is None else k for k in gpu_numa_nodes(n, sysfs)]
     out = []
     for r in range(n):
         cpus = None
         if nodes[r] >= 0:
             try:
-                with open("/sys/devices/system/node/node%d/cpulist" % nodes[r]) as f:
+                with open(os.path.join(sysfs, "devices/system/node/node%d/cpulist" % nodes[r])) as f:
                     on_node = sorted(_parse_cpulist(f.read()) & set(allowed))
                 peers = [q for q in range(n) if nodes[q] == nodes[r]]
                 share = len(on_node) // len(peers)
@@ -291,6 +359,7 @@ def rank_cpu_sets(n):
         if not cpus:
             share = max(1, len(allowed) // n)
             cpus = allowed[r * share:(r + 1) * share] or allowed
+            nodes[r] = -1
         out.append((nodes[r], cpus))
     return out
 
@@ -304,6 +373,9 @@ def spawn_ranks(n, argv):
     port = _free_port()
     procs = []
     cpu_sets = rank_cpu_sets(n)
+    for r, (node, cpus) in enumerate(cpu_sets):
+        print("[bench] rank %d: %s, CPUs %s" % (r, "NUMA node %d" % node if node >= 0 else "no NUMA hint (even split)",
+                                               _fmt_cpulist(cpus)), file=sys.stderr)
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))

@@ -154,3 +154,64 @@ def test_cache_keys_follow_fused_optimizer_steps():
     k = engine._key(p)
     engine.parameters_changed()
     assert engine._key(p) != k
+
+
+def _fake_sysfs(root, gpus, cpu_nodes):
+    """a sysfs tree with the KFD topology (CPU nodes first, like a real host), PCI numa_node files and node cpulists"""
+    import os
+    nodes = os.path.join(root, "class/kfd/kfd/topology/nodes")
+    k = 0
+    for _ in cpu_nodes:
+        os.makedirs(os.path.join(nodes, str(k)))
+        with open(os.path.join(nodes, str(k), "properties"), "w") as f:
+            f.write("cpu_cores_count 64\nsimd_count 0\nlocation_id 0\ndomain 0\n")
+        k += 1
+    for dom, bus, dev, numa in gpus:
+        os.makedirs(os.path.join(nodes, str(k)))
+        with open(os.path.join(nodes, str(k), "properties"), "w") as f:
+            f.write("cpu_cores_count 0\nsimd_count 1024\nlocation_id %d\ndomain %d\n" % ((bus << 8) | (dev << 3), dom))
+        pci = os.path.join(root, "bus/pci/devices", "%04x:%02x:%02x.0" % (dom, bus, dev))
+        os.makedirs(pci)
+        with open(os.path.join(pci, "numa_node"), "w") as f:
+            f.write("%d\n" % numa)
+        k += 1
+    for node, cpulist in cpu_nodes.items():
+        d = os.path.join(root, "devices/system/node/node%d" % node)
+        os.makedirs(d)
+        with open(os.path.join(d, "cpulist"), "w") as f:
+            f.write(cpulist + "\n")
+
+
+def test_rank_cpu_sets_follow_the_pci_address_not_the_render_minor(tmp_path, monkeypatch):
+    """bench.py --gpus N pins rank r next to HIP device r: KFD topology order -> PCI address -> numa_node, composed with
+    the *_VISIBLE_DEVICES lists; no hint (even split) where sysfs or the lists cannot be followed."""
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    ncpu = 8
+    monkeypatch.setattr(os, "sched_getaffinity", lambda _pid: set(range(ncpu)))
+    for var in ("ROCR_VISIBLE_DEVICES", "GPU_DEVICE_ORDINAL", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        monkeypatch.delenv(var, raising=False)
+    sysfs = str(tmp_path / "sys")
+    # four GPUs: two on node 1, two on node 0 — in an order no render-minor rule would give
+    _fake_sysfs(sysfs, [(0, 0x85, 0, 1), (0, 0x05, 0, 0), (0, 0xc5, 0, 1), (1, 0x45, 0, 0)], {0: "0-3", 1: "4-7"})
+    assert bench.gpu_numa_nodes(4, sysfs) == [1, 0, 1, 0]
+    sets = bench.rank_cpu_sets(4, sysfs)
+    assert [n for n, _ in sets] == [1, 0, 1, 0]
+    assert [c for _, c in sets] == [[4, 5], [0, 1], [6, 7], [2, 3]]
+    # visibility lists compose: ROCR filters, HIP indexes what is left
+    monkeypatch.setenv("ROCR_VISIBLE_DEVICES", "1,2,3")
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "2,0")
+    assert bench.gpu_numa_nodes(2, sysfs) == [0, 0]          # physical 3, 1
+    assert [c for _, c in bench.rank_cpu_sets(2, sysfs)] == [[0, 1], [2, 3]]
+    # a UUID list cannot be followed: no hint, even split of the allowed CPUs
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "GPU-abcdef,GPU-123456")
+    assert bench.gpu_numa_nodes(2, sysfs) == [None, None]
+    assert bench.rank_cpu_sets(2, sysfs) == [(-1, [0, 1, 2, 3]), (-1, [4, 5, 6, 7])]
+    monkeypatch.delenv("HIP_VISIBLE_DEVICES")
+    monkeypatch.delenv("ROCR_VISIBLE_DEVICES")
+    # no KFD topology at all (this container): even split
+    assert bench.rank_cpu_sets(2, str(tmp_path / "nothing")) == [(-1, [0, 1, 2, 3]), (-1, [4, 5, 6, 7])]
+    assert bench._fmt_cpulist([0, 1, 2, 3, 8, 9, 12]) == "0-3,8-9,12"
