@@ -33,6 +33,9 @@ PATTERNS = [re.compile(p) for p in (
     r"\.shortcut\.1\.bias$", r"\.bn_dw\.bias$",
     r"^s5\..*\.(ghost2\.cheap_operation\.1|shortcut\.3)\.bias$",
 )]
+# how many parameters fall into the classes above at the BASELINE shapes (bench.py --workload <key>): a pattern that
+# starts to swallow real gradients — or a renamed module that drops out of the list — changes the count
+EXPECTED = {"dual": 12, "slowfast": 0, "ghostnet": 38, "shufflenetv2": 46}
 NOISE_REL = 1e-5     # |oracle gradient| below this fraction of the largest gradient norm ...
 ABS_BOUND = 2e-5     # ... and then |hip - oracle| must stay below this fraction of it
 

@@ -354,6 +354,9 @@ def test_fullsize_train_step_matches_oracle(workload, clips):
     # both sides, bounded absolutely against the model's largest parameter gradient
     noise, gmax = _zero_grads.split(ref)
     _zero_grads.check_noise(got, ref, noise, gmax)
+    # the class list takes exactly the parameters it is meant to: a pattern that starts to swallow real gradients, or a
+    # renamed module dropping out of it, changes the count
+    assert len(noise) == _zero_grads.EXPECTED[workload], (len(noise), sorted(noise)[:8])
     errs = sorted((l2(got[k], g), k) for k, g in ref.items() if k not in noise and float(g.norm()) > 0)
     e_in = [l2(a, b.grad) for a, b in zip(got_in, rx)]
     med, worst = errs[len(errs) // 2][0], errs[-1]
