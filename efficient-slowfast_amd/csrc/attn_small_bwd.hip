@@ -7,6 +7,7 @@
 // whose contraction runs over the swept index take it from the row-major tile [item][channel]
 // (lane (channel, g) reads item 4g+r) and use the recomputed P / dS registers directly as B operand.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -485,6 +486,239 @@ __global__ __launch_bounds__(256) void attn_small_fused_kernel(const BwdArgs p, 
     }
 }
 
+// ---------------------------------------------------------------------------------------------- fused, d <= 8: 4x4x1 MFMAs
+// The three products whose OUTPUT is the channels (dV = P^T dO, dK = dS^T Q, dQ = dS K) fill 4 (d = 4) or 8 of the 16
+// output columns of a 16x16x4 MFMA: 48 of the fused kernel's 56 MFMAs per stage run three quarters empty, and the
+// fp32 MFMA shares the vector ALUs, so the kernel is bound by exactly those cycles (1 792 MFMA cycles per 1 024
+// scores; measured 1.08e12 scores/s = that).  v_mfma_f32_4x4x1_16B_f32 is the same rate (512 FLOP in 8 cycles,
+// tools/microbench/mfma4x4_probe.hip) as sixteen independent 4x4 outer products: block b = lanes 4b .. 4b+3,
+// D[v][lane 4b+j] += A[lane 4b+v] * B[lane 4b+j].  With the four channels of a quad as the columns j nothing is empty:
+//   dV, dK: A = the P / dS register itself (block = (lane quarter lg, key quad): its four lanes hold four KEYS of one
+//           query), B = dO / Q[that query][4u + (lane & 3)] (one ds_read_b32): rows v = the quad's keys.  The four
+//           quarters see different queries: their sums are added once, after the sweep, through LDS.
+//   dQ:     the stage's dS goes through LDS once as a [64 queries][16 keys] tile (as before per 16x16 tile) and comes
+//           back with the QUERY on the lane; A = dS(query = lane, key k), B = K[key k][4u + (lane & 3)] from registers
+//           (the wavefront's 16 keys are fixed): rows v = the four queries of the block, complete over the 16 keys —
+//           no cross-lane sum.  The partial goes to the slot lane-linear ([u][v][lane]: conflict-free, and the summing
+//           thread's float4 over the channels is contiguous).
+// 8 + 48 MFMAs of 32 resp. 8 cycles = 640 cycles per stage instead of 1 792.
+template <int CP>
+__global__ __launch_bounds__(256) void attn_small_fused44_kernel(const BwdArgs p, float* __restrict__ ws) {
+  static_assert(CP == 4 || CP == 8, "one or two channel quads");
+  using G = Geo<CP>;
+  constexpr int QS = G::QS, RP = G::RP, F4 = G::F4, NLD = G::NLD;
+  constexpr int STAGE = 2 * CP * TP + 2 * ST * RP + 2 * ST;  // Qt, dOt, Qs, dOs, lse, D
+  constexpr int TT = 20;                                      // pitch of the dS^T tile
+  constexpr int SLOT = ST * TT;                               // [64 queries][16 keys]; then the dQ partial [QS*4][64]
+  static_assert(2 * STAGE >= 2 * 16 * 16 * CP, "the end-of-sweep reduction fits the stage buffers");
+  __shared__ __attribute__((aligned(16))) float smem[2 * STAGE + 4 * SLOT];
+  float* const slots = smem + 2 * STAGE;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, lg = lane >> 4, lc = lane & 3;
+  const int bz = blockIdx.x / p.nt;  // workgroup -> (clip b, query part z, key block kb)
+  const int kb = blockIdx.x - bz * p.nt;
+  const int b = bz / p.zs, z = bz - b * p.zs;
+  const int j0 = kb * 64 + wave * 16;
+  const int N = p.N, C = p.C;
+  const long brow = (long)b * N;
+  const float gamma = p.gamma[0];
+  float* const myslot = slots + wave * SLOT;
+
+  const int jrow = j0 + li;
+  const bool jok = jrow < N;
+  float kf[QS], vf[QS];
+  {
+    const float* kp = p.k + (brow + (jok ? jrow : 0)) * p.k_cs;
+    const float* vp = p.v + (brow + (jok ? jrow : 0)) * p.v_cs;
+#pragma unroll
+    for (int u = 0; u < QS; ++u) {
+      const int c = 4 * u + lg;
+      const bool ok = jok && c < C;
+      kf[u] = ok ? kp[c] * LOG2E : 0.f;
+      vf[u] = ok ? vp[c] : 0.f;
+    }
+  }
+  // K as B operand of dQ: every block multiplies by the SAME key k of this wavefront, lane & 3 picks the channel
+  float kq[16][QS];
+#pragma unroll
+  for (int k = 0; k < 16; ++k)
+#pragma unroll
+    for (int u = 0; u < QS; ++u) {
+      const int key = j0 + k, c = 4 * u + lc;
+      kq[k][u] = (key < N && c < C) ? p.k[(brow + key) * p.k_cs + c] : 0.f;
+    }
+  f32x4 dkq[QS], dvq[QS];
+#pragma unroll
+  for (int u = 0; u < QS; ++u) dkq[u] = dvq[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int srow = tid / F4;
+  const int sc4 = (tid - srow * F4) * 4;
+  f32x4 rq = {0.f, 0.f, 0.f, 0.f}, rd = {0.f, 0.f, 0.f, 0.f};
+  float rl = 0.f, rD = 0.f;
+  auto load_stage = [&](int i0) {
+    rq = (f32x4){0.f, 0.f, 0.f, 0.f};
+    rd = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int i = i0 + srow;
+    if (tid < NLD && i < N) {
+      const float* qp = p.q + (brow + i) * p.q_cs + sc4;
+      const float* dp = p.dz + (brow + i) * p.dz_cs + sc4;
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if ((sc4 + e) < C) {
+          rq[e] = qp[e];
+          rd[e] = dp[e] * gamma;
+        }
+    }
+    if (tid < ST) {
+      const int ii = i0 + tid;
+      rl = (ii < N) ? p.lse[brow + ii] : POS_BIG;
+      rD = (ii < N) ? p.dvec[brow + ii] * gamma : 0.f;
+    }
+  };
+  auto store_stage = [&](int buf) {
+    float* Qt = smem + buf * STAGE;
+    float* Dt = Qt + CP * TP;
+    float* Qs = Dt + CP * TP;
+    float* Ds = Qs + ST * RP;
+    float* Ls = Ds + ST * RP;
+    if (tid < NLD) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        Qt[(sc4 + e) * TP + srow] = rq[e];
+        Dt[(sc4 + e) * TP + srow] = rd[e];
+      }
+      *reinterpret_cast<f32x4*>(Qs + srow * RP + sc4) = rq;
+      *reinterpret_cast<f32x4*>(Ds + srow * RP + sc4) = rd;
+    }
+    if (tid < ST) {  // NEGATED: the score / dP tiles start from these as their C operand (S' - lse, dP - D)
+      Ls[tid] = -rl;
+      Ls[ST + tid] = -rD;
+    }
+  };
+
+  float* const plane = ws + ((long)b * p.nt + kb) * N * CP;
+  const int tz = ((N + ST - 1) / ST + p.zs - 1) / p.zs;  // stages per query part
+  const int t0 = z * tz;
+  const int nst = min((N + ST - 1) / ST, t0 + tz);
+  load_stage(t0 * ST);
+  store_stage(0);
+  __syncthreads();
+  for (int t = t0; t < nst; ++t) {
+    const int buf = (t - t0) & 1;
+    const bool more = (t + 1) < nst;
+    if (more) load_stage((t + 1) * ST);
+    const float* Qt = smem + buf * STAGE;
+    const float* Dt = Qt + CP * TP;
+    const float* Qs = Dt + CP * TP;
+    const float* Ds = Qs + ST * RP;
+    const float* Ls = Ds + ST * RP;
+    f32x4 s[4], dp[4];
+    const float* qb = Qt + lg * TP + li;
+    const float* db = Dt + lg * TP + li;
+#pragma unroll
+    for (int qt = 0; qt < 4; ++qt) {
+      s[qt] = *reinterpret_cast<const f32x4*>(Ls + qt * 16 + 4 * lg);
+      dp[qt] = *reinterpret_cast<const f32x4*>(Ls + ST + qt * 16 + 4 * lg);
+#pragma unroll
+      for (int u = 0; u < QS; ++u) {
+        s[qt] = __builtin_amdgcn_mfma_f32_16x16x4f32(qb[(4 * u) * TP + qt * 16], kf[u], s[qt], 0, 0, 0);    // S'
+        dp[qt] = __builtin_amdgcn_mfma_f32_16x16x4f32(db[(4 * u) * TP + qt * 16], vf[u], dp[qt], 0, 0, 0);  // dP
+      }
+    }
+    f32x4 pr[4];
+#pragma unroll
+    for (int qt = 0; qt < 4; ++qt) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) pr[qt][r] = __builtin_amdgcn_exp2f(s[qt][r]);
+      s[qt] = pr[qt] * dp[qt];  // dS = P (dP - D)
+    }
+    // dS^T tile: row = query 16 qt + 4 lg + r, column = key li (read back below with the query on the lane)
+#pragma unroll
+    for (int qt = 0; qt < 4; ++qt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) myslot[(qt * 16 + 4 * lg + r) * TT + li] = s[qt][r];
+    // dV, dK: rows = the four keys of this lane's quad, columns = the channels of quad u
+    const float* dB = Ds + (4 * lg) * RP + lc;
+    const float* qB = Qs + (4 * lg) * RP + lc;
+#pragma unroll
+    for (int qt = 0; qt < 4; ++qt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int u = 0; u < QS; ++u) {
+          dvq[u] = __builtin_amdgcn_mfma_f32_4x4x1f32(pr[qt][r], dB[(qt * 16 + r) * RP + 4 * u], dvq[u], 0, 0, 0);
+          dkq[u] = __builtin_amdgcn_mfma_f32_4x4x1f32(s[qt][r], qB[(qt * 16 + r) * RP + 4 * u], dkq[u], 0, 0, 0);
+        }
+    // dQ: A = dS(query = lane, key k)
+    f32x4 a[4];
+#pragma unroll
+    for (int k4 = 0; k4 < 4; ++k4) a[k4] = *reinterpret_cast<const f32x4*>(myslot + lane * TT + 4 * k4);
+    f32x4 dqq[QS];
+#pragma unroll
+    for (int u = 0; u < QS; ++u) dqq[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 16; ++k)
+#pragma unroll
+      for (int u = 0; u < QS; ++u)
+        dqq[u] = __builtin_amdgcn_mfma_f32_4x4x1f32(a[k >> 2][k & 3], kq[k][u], dqq[u], 0, 0, 0);
+    // partial of this wavefront's 16 keys: element (query 4 (lane / 4) + v, channel 4 u + (lane & 3)) at [u][v][lane]
+#pragma unroll
+    for (int u = 0; u < QS; ++u)
+#pragma unroll
+      for (int v = 0; v < 4; ++v) myslot[(u * 4 + v) * 64 + lane] = dqq[u][v];
+    if (more) store_stage(buf ^ 1);
+    __syncthreads();
+    if (tid < ST * CP / 4) {  // fixed-order sum of the four wavefronts' partials, one float4 (a channel quad) per thread
+      const int e0 = tid * 4;
+      const int ql = e0 / CP, u = (e0 % CP) >> 2;
+      const int off = (u * 4 + (ql & 3)) * 64 + (ql >> 2) * 4;
+      f32x4 v = *reinterpret_cast<const f32x4*>(slots + off);
+#pragma unroll
+      for (int w = 1; w < 4; ++w) v += *reinterpret_cast<const f32x4*>(slots + w * SLOT + off);
+      const int qi = t * ST + ql;
+      if (qi < N) *reinterpret_cast<f32x4*>(plane + (long)qi * CP + (e0 % CP)) = v;
+    }
+    __syncthreads();
+  }
+  // ---- the four lane quarters saw different queries: add them (quarter order) through LDS.  R[wave][lg][key][c],
+  //      dK then dV; a wavefront only reads what it wrote (LDS operations of a wavefront execute in order).
+  float* const R = smem + wave * (2 * 4 * 16 * CP);
+#pragma unroll
+  for (int u = 0; u < QS; ++u)
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const int o = (lg * 16 + 4 * (li >> 2) + v) * CP + 4 * u + lc;
+      R[o] = dkq[u][v];
+      R[4 * 16 * CP + o] = dvq[u][v];
+    }
+  const int c0 = 4 * lg;
+  f32x4 dkf = {0.f, 0.f, 0.f, 0.f}, dvf = dkf;
+  if (c0 < CP) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      dkf += *reinterpret_cast<const f32x4*>(R + (g * 16 + li) * CP + c0);
+      dvf += *reinterpret_cast<const f32x4*>(R + 4 * 16 * CP + (g * 16 + li) * CP + c0);
+    }
+  }
+  if (p.zs > 1) {  // this query part's share; attn_dq_reduce_kernel adds the parts in order
+    if (jok && c0 < CP) {
+      *reinterpret_cast<f32x4*>(p.dkp + ((long)bz * N + jrow) * CP + c0) = dkf;
+      *reinterpret_cast<f32x4*>(p.dvp + ((long)bz * N + jrow) * CP + c0) = dvf;
+    }
+    return;
+  }
+  if (!jok || c0 >= C) return;
+  float* okp = p.dk + (brow + jrow) * p.dk_cs + c0;
+  float* ovp = p.dv + (brow + jrow) * p.dv_cs + c0;
+#pragma unroll
+  for (int e = 0; e < 4; ++e)
+    if (c0 + e < C) {
+      okp[e] = dkf[e];
+      ovp[e] = dvf[e];
+    }
+}
+
 template <int CP>
 int launch(const BwdArgs& a, int which, hipStream_t s) {
   const int grid = a.B * a.nt;
@@ -528,12 +762,15 @@ int sf_attn_small_fused_dispatch(const float* q, int q_cs, const float* k, int k
   int cp = C <= 4 ? 4 : (C <= 8 ? 8 : 16);
   a.dkp = ws + (long)B * a.nt * N * cp;
   a.dvp = a.dkp + (long)B * a.zs * N * cp;
+  static const bool use44 = [] { const char* e = getenv("SF_ATTN_SMALL_44"); return !(e && e[0] == '0'); }();
   if (C <= 4) {
     cp = 4;
-    hipLaunchKernelGGL((attn_small_fused_kernel<4>), dim3(grid), dim3(256), 0, stream, a, ws);
+    if (use44) hipLaunchKernelGGL((attn_small_fused44_kernel<4>), dim3(grid), dim3(256), 0, stream, a, ws);
+    else hipLaunchKernelGGL((attn_small_fused_kernel<4>), dim3(grid), dim3(256), 0, stream, a, ws);
   } else if (C <= 8) {
     cp = 8;
-    hipLaunchKernelGGL((attn_small_fused_kernel<8>), dim3(grid), dim3(256), 0, stream, a, ws);
+    if (use44) hipLaunchKernelGGL((attn_small_fused44_kernel<8>), dim3(grid), dim3(256), 0, stream, a, ws);
+    else hipLaunchKernelGGL((attn_small_fused_kernel<8>), dim3(grid), dim3(256), 0, stream, a, ws);
   } else {
     cp = 16;
     hipLaunchKernelGGL((attn_small_fused_kernel<16>), dim3(grid), dim3(256), 0, stream, a, ws);

@@ -372,7 +372,9 @@ def test_small_helpers():
 
 
 ATTN_BWD = [(8, (2, 12, 12)), (32, (2, 14, 14)), (64, (4, 7, 7)), (128, (2, 7, 7)), (3, (4, 8, 8)), (28, (2, 9, 9)),
-            (32, (1, 3, 3))]
+            (32, (1, 3, 3)),
+            # d <= 8 off the packed-bf16 path: the 4x4x1-MFMA fused kernel (cfg #5's d = 4 / 6), ragged N, one quad and two
+            (4, (2, 9, 9)), (6, (3, 7, 9)), (7, (2, 8, 8)), (5, (1, 5, 13)), (4, (1, 4, 4))]
 
 
 @pytest.mark.parametrize("c,thw", ATTN_BWD, ids=["c%d_n%d" % (c, t * h * w) for c, (t, h, w) in ATTN_BWD])
