@@ -27,4 +27,16 @@ timeout 200 python tools/microbench/bn_passes.py 2>&1 | grep -v amdgpu > $O/bn_p
 timeout 300 python tools/host_lead.py > $O/host_lead.txt 2>&1
 timeout 700 python bench.py > $O/bench_dual.json 2> $O/bench_dual.err
 for w in slowfast ghostnet shufflenetv2; do timeout 900 python bench.py --workload $w >> $O/bench_lines_workloads.jsonl 2>> $O/bench_workloads.err; done
+# second half of the round: cfg #5 at 8 clips, the depthwise marches, the 4x4x1 attention backward, grouped convs
+timeout 600 python bench.py --workload ghostnet --batch 8 --no-cpu-baseline > $O/bench_line_ghostnet_b8.jsonl 2> $O/bench_ghostnet_b8.err
+(for on in 1 0; do echo "SF_ATTN_SMALL_44=$on"; SF_ATTN_SMALL_44=$on timeout 200 python tools/microbench/attn_small_bench.py; done) 2>&1 | grep -v amdgpu > $O/attn_small_44_ab.txt
+timeout 100 ./tools/microbench/build/mfma4x4_probe > $O/mfma4x4_probe.txt 2>&1
+timeout 200 python tools/microbench/grouped_conv_ab.py 2>&1 | grep -v amdgpu > $O/grouped_conv_ab.txt
+(echo "# SF_DW_MARCH=0 python tools/prof_dwconvs.py ghostnet 8"; SF_DW_MARCH=0 timeout 300 python tools/prof_dwconvs.py ghostnet 8) 2>&1 | grep -v amdgpu > $O/dwconv_per_shape_before.txt
+(echo "# python tools/prof_dwconvs.py ghostnet 8"; timeout 300 python tools/prof_dwconvs.py ghostnet 8) 2>&1 | grep -v amdgpu > $O/dwconv_per_shape_after.txt
+(for w in "ghostnet --batch 8" "ghostnet" "shufflenetv2"; do for v in "SF_DW_MARCH=0 SF_ATTN_SMALL_44=0 SF_GRAD_ARENA_MB=0 SF_BN_TICKET=0" "SF_DW_MARCH=1"; do echo -n "$w [$v]: "; env $v timeout 400 python bench.py --workload $w --steps 10 --no-cpu-baseline --no-extras 2>/dev/null | python3 -c "
+import sys, json
+for l in sys.stdin:
+    if l.startswith('{'):
+        d = json.loads(l); print(d['ms_per_step'], 'ms', d['value'], 'clips/s', d['config'].get('launch'))"; done; done) > $O/small_configs_ab.txt 2>&1
 tail -3 $O/serial_per_step.txt; tail -c 1500 $O/driver_cmd.jsonl
