@@ -634,7 +634,7 @@ def main():
     # the LAST timed step's own result (eager: the tensor it returned; replay: the capture's static output, which every
     # replay rewrites): train = the loss, eval = the probabilities
     assert bool(torch.isfinite(out).all()), "non-finite result in the timed region"
-    last_loss = float(out) if train else None
+    last_loss = float(out.detach()) if train else None
 
     # ---- secondary: eval-mode forward (inference) clips/s of the same model, hipGraph replay
     eval_fwd = None
