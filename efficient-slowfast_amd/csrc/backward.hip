@@ -1023,18 +1023,17 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_partial4_kernel(const sf_con
 
 __global__ void dwconv_wgrad_final_kernel(const float* __restrict__ partial, int n, int nblk, float* __restrict__ out,
                                           int C, int ntaps, int to_param, int accumulate) {
-  const int i = blockIdx.x * TPB + threadIdx.x;  // i over ntaps*C
-  if (i >= n) return;
+  // 16 lanes per output (i over ntaps*C): lane q sums the blocks q, q + 16, .. in fp64, the 16 sub-sums are combined by
+  // a fixed xor tree — one thread per output walked up to 512 partials in 64 dependent rounds (10 us per launch, 82
+  // launches per cfg #5 step)
+  const int i = (blockIdx.x * TPB + threadIdx.x) >> 4;
+  const int q = threadIdx.x & 15;
   double s = 0.0;
-  int b = 0;
-  for (; b + 8 <= nblk; b += 8) {  // 8 independent loads in flight, summed in block order
-    float v[8];
+  if (i < n)
+    for (int b = q; b < nblk; b += 16) s += (double)partial[(long)b * n + i];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) v[u] = partial[(long)(b + u) * n + i];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) s += (double)v[u];
-  }
-  for (; b < nblk; ++b) s += (double)partial[(long)b * n + i];
+  for (int m = 1; m < 16; m <<= 1) s += __shfl_xor(s, m, 64);
+  if (i >= n || q != 0) return;
   // to_param: nn.Conv3d's own depthwise layout [C][1][kT][kH][kW] = [c][tap] instead of the packed [tap][c]
   float* const o = out + (to_param ? (long)(i % C) * ntaps + i / C : (long)i);
   *o = accumulate ? *o + (float)s : (float)s;
@@ -1140,7 +1139,7 @@ static int dwconv_wgrad_impl(const sf_conv_desc* d, const float* x, const float*
   } else
     hipLaunchKernelGGL(dwconv_wgrad_partial_kernel, dim3(DW_P, sf_cdiv(C, CB)), dim3(TPB), 0, (hipStream_t)stream, *d, x,
                        dz, dz_cs, dz_coff, C, CB, rows, ws);
-  hipLaunchKernelGGL(dwconv_wgrad_final_kernel, dim3(sf_cdiv(ntaps * C, TPB)), dim3(TPB), 0, (hipStream_t)stream, ws,
+  hipLaunchKernelGGL(dwconv_wgrad_final_kernel, dim3(sf_cdiv((long)ntaps * C * 16, TPB)), dim3(TPB), 0, (hipStream_t)stream, ws,
                      ntaps * C, nblk, dw, C, ntaps, to_param, accumulate);
   SF_CHECK_LAUNCH();
   return SF_OK;

@@ -141,8 +141,10 @@ class Tape(object):
         """Launch-bound models (cfg #1: ~115 gradient buffers of a few KB each): the zero-initialised gradient buffers of
         one backward come out of ONE zero-filled tensor — one fill launch instead of one per buffer.  Sized by what the
         previous backward of the same model asked for; made here, on the stream the backward starts on and before any
-        side stream is forked, so every later use is ordered behind the fill.  Large models keep one fill per buffer
-        (the fills then overlap with the backward's kernels instead of delaying its first one)."""
+        side stream is forked, so every later use is ordered behind the fill.  Only models whose buffers total at most
+        64 MB (SF_GRAD_ARENA_MB) take it: a large model keeps one fill per buffer, which overlaps with the backward's
+        kernels instead of delaying its first one (an arena for just the SMALL buffers of a large model was tried: cfg #3
+        51.98 against 51.60 ms, two alternations on one box; cfg #5 at 2 clips unchanged)."""
         self.zero_floats = 0
         if self.model is None or ARENA_MAX_FLOATS <= 0 or self.out_act is None:
             return
