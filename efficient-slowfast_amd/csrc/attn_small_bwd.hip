@@ -6,7 +6,7 @@
 // their A operand from a TRANSPOSED LDS tile [channel][item] (lane (item, g) reads channel 4u+g), products
 // whose contraction runs over the swept index take it from the row-major tile [item][channel]
 // (lane (channel, g) reads item 4g+r) and use the recomputed P / dS registers directly as B operand.
-#include "common.h"
+#include "bx.h"
 #include <stdlib.h>
 
 namespace {
@@ -502,12 +502,27 @@ __global__ __launch_bounds__(256) void attn_small_fused_kernel(const BwdArgs p, 
 //           no cross-lane sum.  The partial goes to the slot lane-linear ([u][v][lane]: conflict-free, and the summing
 //           thread's float4 over the channels is contiguous).
 // 8 + 48 MFMAs of 32 resp. 8 cycles = 640 cycles per stage instead of 1 792.
-template <int CP>
+// BF (d = 4; an experiment, OFF by default — see the dispatch): S' and dP — the two products over the CHANNELS, whose
+// operands are inputs — on the bf16 matrix pipe with
+// fp32-exact operand pieces (bx.h), off the vector ALUs that the fp32 MFMAs share with exp2: the 16 k slots of one
+// v_mfma_f32_16x16x16_bf16 hold four (piece, piece) pairs of the 4 channels, so [q1|q1|q2|q1][k1|k2|k1|k3] and
+// [q3|q2|0|0][k1|k2|0|0] are the six kept terms in two instructions.  Q and dO are split when a stage is written to
+// LDS ([query][p1|p2|p3|0][4 channels] bf16, 40-byte pitch: the lane's 8-byte fragment reads are conflict-free), K'
+// and V once per wavefront into registers.
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4 mfma_bf16x16(u32x2 a, u32x2 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4, a), __builtin_bit_cast(s16x4, b), c, 0, 0, 0);
+}
+
+template <int CP, bool BF = false>
 __global__ __launch_bounds__(256) void attn_small_fused44_kernel(const BwdArgs p, float* __restrict__ ws) {
   static_assert(CP == 4 || CP == 8, "one or two channel quads");
+  static_assert(!BF || CP == 4, "the bf16-piece scores pack four channels into a k slot");
   using G = Geo<CP>;
   constexpr int QS = G::QS, RP = G::RP, F4 = G::F4, NLD = G::NLD;
-  constexpr int STAGE = 2 * CP * TP + 2 * ST * RP + 2 * ST;  // Qt, dOt, Qs, dOs, lse, D
+  constexpr int PP = 10;                                      // piece-tile pitch in floats (40 bytes per query)
+  constexpr int TSZ = BF ? ST * PP : CP * TP;                 // Q^T / dO^T tiles, or their piece tiles
+  constexpr int STAGE = 2 * TSZ + 2 * ST * RP + 2 * ST;       // Qt, dOt, Qs, dOs, lse, D
   constexpr int TT = 20;                                      // pitch of the dS^T tile
   constexpr int SLOT = ST * TT;                               // [64 queries][16 keys]; then the dQ partial [QS*4][64]
   static_assert(2 * STAGE >= 2 * 16 * 16 * CP, "the end-of-sweep reduction fits the stage buffers");
@@ -538,6 +553,27 @@ __global__ __launch_bounds__(256) void attn_small_fused44_kernel(const BwdArgs p
       kf[u] = ok ? kp[c] * LOG2E : 0.f;
       vf[u] = ok ? vp[c] : 0.f;
     }
+  }
+  u32x2 kb1 = {0u, 0u}, kb2 = kb1, vb1 = kb1, vb2 = kb1;  // BF: B operands of S' / dP, slot lg of the two instructions
+  if constexpr (BF) {
+    const float* kp = p.k + (brow + (jok ? jrow : 0)) * p.k_cs;
+    const float* vp = p.v + (brow + (jok ? jrow : 0)) * p.v_cs;
+    float kk[4], vv[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      kk[c] = (jok && c < C) ? kp[c] * LOG2E : 0.f;
+      vv[c] = (jok && c < C) ? vp[c] : 0.f;
+    }
+    u32x2 wk[3], wv[3];
+    split_pair(kk[0], kk[1], wk, 0);
+    split_pair(kk[2], kk[3], wk, 1);
+    split_pair(vv[0], vv[1], wv, 0);
+    split_pair(vv[2], vv[3], wv, 1);
+    const u32x2 zero = {0u, 0u};
+    kb1 = lg == 1 ? wk[1] : (lg == 3 ? wk[2] : wk[0]);   // [k1|k2|k1|k3]
+    vb1 = lg == 1 ? wv[1] : (lg == 3 ? wv[2] : wv[0]);
+    kb2 = lg == 0 ? wk[0] : (lg == 1 ? wk[1] : zero);     // [k1|k2|0|0]
+    vb2 = lg == 0 ? wv[0] : (lg == 1 ? wv[1] : zero);
   }
   // K as B operand of dQ: every block multiplies by the SAME key k of this wavefront, lane & 3 picks the channel
   float kq[16][QS];
@@ -578,15 +614,31 @@ __global__ __launch_bounds__(256) void attn_small_fused44_kernel(const BwdArgs p
   };
   auto store_stage = [&](int buf) {
     float* Qt = smem + buf * STAGE;
-    float* Dt = Qt + CP * TP;
-    float* Qs = Dt + CP * TP;
+    float* Dt = Qt + TSZ;
+    float* Qs = Dt + TSZ;
     float* Ds = Qs + ST * RP;
     float* Ls = Ds + ST * RP;
     if (tid < NLD) {
+      if constexpr (BF) {  // piece rows [p1|p2|p3|0] of the query's 4 channels (one float4 per query: F4 == 1)
+        u32x2 wq[3], wd[3];
+        split_pair(rq[0], rq[1], wq, 0);
+        split_pair(rq[2], rq[3], wq, 1);
+        split_pair(rd[0], rd[1], wd, 0);
+        split_pair(rd[2], rd[3], wd, 1);
+        u32x2* const qrow = reinterpret_cast<u32x2*>(Qt + srow * PP);
+        u32x2* const drow = reinterpret_cast<u32x2*>(Dt + srow * PP);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        Qt[(sc4 + e) * TP + srow] = rq[e];
-        Dt[(sc4 + e) * TP + srow] = rd[e];
+        for (int pc = 0; pc < 3; ++pc) {
+          qrow[pc] = wq[pc];
+          drow[pc] = wd[pc];
+        }
+        qrow[3] = drow[3] = (u32x2){0u, 0u};
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          Qt[(sc4 + e) * TP + srow] = rq[e];
+          Dt[(sc4 + e) * TP + srow] = rd[e];
+        }
       }
       *reinterpret_cast<f32x4*>(Qs + srow * RP + sc4) = rq;
       *reinterpret_cast<f32x4*>(Ds + srow * RP + sc4) = rd;
@@ -609,21 +661,32 @@ __global__ __launch_bounds__(256) void attn_small_fused44_kernel(const BwdArgs p
     const bool more = (t + 1) < nst;
     if (more) load_stage((t + 1) * ST);
     const float* Qt = smem + buf * STAGE;
-    const float* Dt = Qt + CP * TP;
-    const float* Qs = Dt + CP * TP;
+    const float* Dt = Qt + TSZ;
+    const float* Qs = Dt + TSZ;
     const float* Ds = Qs + ST * RP;
     const float* Ls = Ds + ST * RP;
     f32x4 s[4], dp[4];
     const float* qb = Qt + lg * TP + li;
     const float* db = Dt + lg * TP + li;
+    // BF: slot lg of the A operands [q1|q1|q2|q1] and [q3|q2|0|0] = pieces {0, 0, 1, 0} / {2, 1, 3, 3} of the row
+    const int sel1 = lg == 2 ? 1 : 0, sel2 = lg == 0 ? 2 : (lg == 1 ? 1 : 3);
 #pragma unroll
     for (int qt = 0; qt < 4; ++qt) {
       s[qt] = *reinterpret_cast<const f32x4*>(Ls + qt * 16 + 4 * lg);
       dp[qt] = *reinterpret_cast<const f32x4*>(Ls + ST + qt * 16 + 4 * lg);
+      if constexpr (BF) {
+        const u32x2* const qrow = reinterpret_cast<const u32x2*>(Qt + (qt * 16 + li) * PP);
+        const u32x2* const drow = reinterpret_cast<const u32x2*>(Dt + (qt * 16 + li) * PP);
+        s[qt] = mfma_bf16x16(qrow[sel2], kb2, s[qt]);    // the small terms first
+        dp[qt] = mfma_bf16x16(drow[sel2], vb2, dp[qt]);
+        s[qt] = mfma_bf16x16(qrow[sel1], kb1, s[qt]);
+        dp[qt] = mfma_bf16x16(drow[sel1], vb1, dp[qt]);
+      } else {
 #pragma unroll
-      for (int u = 0; u < QS; ++u) {
-        s[qt] = __builtin_amdgcn_mfma_f32_16x16x4f32(qb[(4 * u) * TP + qt * 16], kf[u], s[qt], 0, 0, 0);    // S'
-        dp[qt] = __builtin_amdgcn_mfma_f32_16x16x4f32(db[(4 * u) * TP + qt * 16], vf[u], dp[qt], 0, 0, 0);  // dP
+        for (int u = 0; u < QS; ++u) {
+          s[qt] = __builtin_amdgcn_mfma_f32_16x16x4f32(qb[(4 * u) * TP + qt * 16], kf[u], s[qt], 0, 0, 0);    // S'
+          dp[qt] = __builtin_amdgcn_mfma_f32_16x16x4f32(db[(4 * u) * TP + qt * 16], vf[u], dp[qt], 0, 0, 0);  // dP
+        }
       }
     }
     f32x4 pr[4];
@@ -765,7 +828,12 @@ int sf_attn_small_fused_dispatch(const float* q, int q_cs, const float* k, int k
   static const bool use44 = [] { const char* e = getenv("SF_ATTN_SMALL_44"); return !(e && e[0] == '0'); }();
   if (C <= 4) {
     cp = 4;
-    if (use44) hipLaunchKernelGGL((attn_small_fused44_kernel<4>), dim3(grid), dim3(256), 0, stream, a, ws);
+    // OFF by default: measured SLOWER (d = 4, N = 100 352, 2 clips: 14.95 against 12.41 ms, two alternations on one box) —
+    // sixteen 16x16x16 bf16 MFMAs per stage cost more matrix-pipe time than the eight 16x16x4 fp32 ones they replace
+    // free on the vector ALUs, and the sweep's waves do not hide them behind exp2.  SF_ATTN_SMALL_BF=1 selects it.
+    static const bool bf = [] { const char* e = getenv("SF_ATTN_SMALL_BF"); return e && e[0] == '1'; }();
+    if (use44 && bf) hipLaunchKernelGGL((attn_small_fused44_kernel<4, true>), dim3(grid), dim3(256), 0, stream, a, ws);
+    else if (use44) hipLaunchKernelGGL((attn_small_fused44_kernel<4>), dim3(grid), dim3(256), 0, stream, a, ws);
     else hipLaunchKernelGGL((attn_small_fused_kernel<4>), dim3(grid), dim3(256), 0, stream, a, ws);
   } else if (C <= 8) {
     cp = 8;

@@ -356,7 +356,11 @@ def test_fullsize_train_step_matches_oracle(workload, clips):
     _zero_grads.check_noise(got, ref, noise, gmax)
     # the class list takes exactly the parameters it is meant to: a pattern that starts to swallow real gradients, or a
     # renamed module dropping out of it, changes the count
-    assert len(noise) == _zero_grads.EXPECTED[workload], (len(noise), sorted(noise)[:8])
+    # (pinned at ONE clip, the shape bench.py's parity leg runs: with more clips a few of the listed parameters' oracle
+    # gradients rise above the 1e-5 noise line and are then compared relatively like every other one)
+    if clips == 1:
+        assert len(noise) == _zero_grads.EXPECTED[workload], (len(noise), sorted(noise)[:8])
+    assert len(noise) <= _zero_grads.EXPECTED[workload], (len(noise), sorted(noise)[:8])
     errs = sorted((l2(got[k], g), k) for k, g in ref.items() if k not in noise and float(g.norm()) > 0)
     e_in = [l2(a, b.grad) for a, b in zip(got_in, rx)]
     med, worst = errs[len(errs) // 2][0], errs[-1]
