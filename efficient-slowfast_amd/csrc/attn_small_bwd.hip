@@ -514,8 +514,8 @@ __device__ __forceinline__ f32x4 mfma_bf16x16(u32x2 a, u32x2 b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4, a), __builtin_bit_cast(s16x4, b), c, 0, 0, 0);
 }
 
-template <int CP, bool BF = false>
-__global__ __launch_bounds__(256) void attn_small_fused44_kernel(const BwdArgs p, float* __restrict__ ws) {
+template <int CP, bool BF = false, int NW = 4>
+__global__ __launch_bounds__(64 * NW) void attn_small_fused44_kernel(const BwdArgs p, float* __restrict__ ws) {
   static_assert(CP == 4 || CP == 8, "one or two channel quads");
   static_assert(!BF || CP == 4, "the bf16-piece scores pack four channels into a k slot");
   using G = Geo<CP>;
@@ -525,8 +525,10 @@ __global__ __launch_bounds__(256) void attn_small_fused44_kernel(const BwdArgs p
   constexpr int STAGE = 2 * TSZ + 2 * ST * RP + 2 * ST;       // Qt, dOt, Qs, dOs, lse, D
   constexpr int TT = 20;                                      // pitch of the dS^T tile
   constexpr int SLOT = ST * TT;                               // [64 queries][16 keys]; then the dQ partial [QS*4][64]
-  static_assert(2 * STAGE >= 2 * 16 * 16 * CP, "the end-of-sweep reduction fits the stage buffers");
-  __shared__ __attribute__((aligned(16))) float smem[2 * STAGE + 4 * SLOT];
+  static_assert(2 * STAGE >= NW * 2 * 4 * 16 * CP, "the end-of-sweep reduction fits the stage buffers");
+  // NW wavefronts = 16 NW keys per workgroup: the dQ planes (one per key block, N x CP floats each, written here and
+  // read back by attn_dq_reduce_kernel) halve with NW = 8
+  __shared__ __attribute__((aligned(16))) float smem[2 * STAGE + NW * SLOT];
   float* const slots = smem + 2 * STAGE;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -534,7 +536,7 @@ __global__ __launch_bounds__(256) void attn_small_fused44_kernel(const BwdArgs p
   const int bz = blockIdx.x / p.nt;  // workgroup -> (clip b, query part z, key block kb)
   const int kb = blockIdx.x - bz * p.nt;
   const int b = bz / p.zs, z = bz - b * p.zs;
-  const int j0 = kb * 64 + wave * 16;
+  const int j0 = kb * (16 * NW) + wave * 16;
   const int N = p.N, C = p.C;
   const long brow = (long)b * N;
   const float gamma = p.gamma[0];
@@ -738,7 +740,7 @@ __global__ __launch_bounds__(256) void attn_small_fused44_kernel(const BwdArgs p
       const int off = (u * 4 + (ql & 3)) * 64 + (ql >> 2) * 4;
       f32x4 v = *reinterpret_cast<const f32x4*>(slots + off);
 #pragma unroll
-      for (int w = 1; w < 4; ++w) v += *reinterpret_cast<const f32x4*>(slots + w * SLOT + off);
+      for (int w = 1; w < NW; ++w) v += *reinterpret_cast<const f32x4*>(slots + w * SLOT + off);
       const int qi = t * ST + ql;
       if (qi < N) *reinterpret_cast<f32x4*>(plane + (long)qi * CP + (e0 % CP)) = v;
     }
@@ -819,20 +821,24 @@ int sf_attn_small_fused_dispatch(const float* q, int q_cs, const float* k, int k
   a.q = q; a.k = k; a.v = v; a.dz = dz; a.lse = lse; a.dvec = dvec; a.gamma = gamma;
   a.dq = dq; a.dk = dk; a.dv = dv;
   a.q_cs = q_cs; a.k_cs = k_cs; a.v_cs = v_cs; a.dz_cs = dz_cs; a.dq_cs = dq_cs; a.dk_cs = dk_cs; a.dv_cs = dv_cs;
-  a.B = B; a.C = C; a.N = N; a.nt = sf_cdiv(N, 64);
+  static const bool use44 = [] { const char* e = getenv("SF_ATTN_SMALL_44"); return !(e && e[0] == '0'); }();
+  // 128 keys per workgroup (8 wavefronts) where that still leaves >= 2 workgroups per CU: half the dQ planes
+  static const int nw_env = [] { const char* e = getenv("SF_ATTN_SMALL_NW"); return e ? atoi(e) : 0; }();
+  const bool wide = use44 && C <= 4 && (nw_env == 8 || (nw_env != 4 && (long)B * sf_cdiv(N, 128) >= 2 * 256));
+  a.B = B; a.C = C; a.N = N; a.nt = sf_cdiv(N, wide ? 128 : 64);
   a.zs = sf_sweep_parts((long)B * a.nt, sf_cdiv(N, ST));
   const int grid = B * a.zs * a.nt;
   int cp = C <= 4 ? 4 : (C <= 8 ? 8 : 16);
   a.dkp = ws + (long)B * a.nt * N * cp;
   a.dvp = a.dkp + (long)B * a.zs * N * cp;
-  static const bool use44 = [] { const char* e = getenv("SF_ATTN_SMALL_44"); return !(e && e[0] == '0'); }();
   if (C <= 4) {
     cp = 4;
     // OFF by default: measured SLOWER (d = 4, N = 100 352, 2 clips: 14.95 against 12.41 ms, two alternations on one box) —
     // sixteen 16x16x16 bf16 MFMAs per stage cost more matrix-pipe time than the eight 16x16x4 fp32 ones they replace
     // free on the vector ALUs, and the sweep's waves do not hide them behind exp2.  SF_ATTN_SMALL_BF=1 selects it.
     static const bool bf = [] { const char* e = getenv("SF_ATTN_SMALL_BF"); return e && e[0] == '1'; }();
-    if (use44 && bf) hipLaunchKernelGGL((attn_small_fused44_kernel<4, true>), dim3(grid), dim3(256), 0, stream, a, ws);
+    if (wide) hipLaunchKernelGGL((attn_small_fused44_kernel<4, false, 8>), dim3(grid), dim3(512), 0, stream, a, ws);
+    else if (use44 && bf) hipLaunchKernelGGL((attn_small_fused44_kernel<4, true>), dim3(grid), dim3(256), 0, stream, a, ws);
     else if (use44) hipLaunchKernelGGL((attn_small_fused44_kernel<4>), dim3(grid), dim3(256), 0, stream, a, ws);
     else hipLaunchKernelGGL((attn_small_fused_kernel<4>), dim3(grid), dim3(256), 0, stream, a, ws);
   } else if (C <= 8) {

@@ -423,6 +423,8 @@ def test_attention_backward_query_parts(parts):
     env = dict(os.environ, SF_SWEEP_PARTS=str(parts))
     if parts == 3:  # also take the 16x16x4 forward kernel's d = 32 instantiation (off by default) through the suite
         env["SF_ATTN_FWD32"] = "small"
+    else:           # ... and the 8-wavefront (128 keys per workgroup) form of the d <= 4 backward, which only large
+        env["SF_ATTN_SMALL_NW"] = "8"   # problems take by themselves
     fwd = os.path.join(os.path.dirname(__file__), "test_ops_gpu.py")  # its forward tests cut the KEY sweep alike
     r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", __file__, fwd, "-k",
                         "(test_attention_backward and not query_parts) or test_attention"], env=env,
