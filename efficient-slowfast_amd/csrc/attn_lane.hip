@@ -63,7 +63,13 @@ __global__ __launch_bounds__(256) void attn_lane_kernel(const AttnArgs p) {
   for (int a = 0; a < NACC; ++a)
 #pragma unroll
     for (int c4 = 0; c4 < CG; ++c4) oa[a][c4] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  float m_run = NEG_BIG, l_run = 0.f;
+  // m_run = the reference maximum of the online softmax.  It is subtracted from the scores by the score MFMAs
+  // themselves: their accumulators start from negm = -m_run (the C operand of each group's first instruction; dst !=
+  // srcC costs nothing), which removes a v_sub per score from a loop whose vector instructions are wall time.  Until
+  // the first group has been seen (`first`) the reference is 0 and that group's own maximum replaces it.
+  float m_run = 0.f, l_run = 0.f;
+  f32x4 negm = {0.f, 0.f, 0.f, 0.f};
+  bool first = true;
 
   f32x4 rk[LIT], rv[LIT];
   auto load_tile = [&](int j0) {
@@ -117,8 +123,6 @@ __global__ __launch_bounds__(256) void attn_lane_kernel(const AttnArgs p) {
       // ---- scores of 16 keys: NG independent accumulators, channel-major issue order
       f32x4 s[NG];
 #pragma unroll
-      for (int g = 0; g < NG; ++g) s[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
       for (int c4 = 0; c4 < CG; ++c4) {
         f32x4 ka[NG];
 #pragma unroll
@@ -127,7 +131,8 @@ __global__ __launch_bounds__(256) void attn_lane_kernel(const AttnArgs p) {
         for (int e = 0; e < 4; ++e)
 #pragma unroll
           for (int g = 0; g < NG; ++g)
-            s[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(ka[g][e], qf[4 * c4 + e], s[g], 0, 0, 0);
+            s[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(ka[g][e], qf[4 * c4 + e], (c4 == 0 && e == 0) ? negm : s[g], 0, 0,
+                                                      0);  // s = score - m_run
       }
       if (ragged) {
 #pragma unroll
@@ -144,21 +149,29 @@ __global__ __launch_bounds__(256) void attn_lane_kernel(const AttnArgs p) {
       float mloc = fmaxf(fmaxf(s[0][0], s[0][1]), fmaxf(s[0][2], s[0][3]));
 #pragma unroll
       for (int g = 1; g < NG; ++g) mloc = fmaxf(mloc, fmaxf(fmaxf(s[g][0], s[g][1]), fmaxf(s[g][2], s[g][3])));
-      if (__any(mloc > m_run + 8.0f)) {
-        const float mnew = (mloc > m_run + 8.0f) ? mloc : m_run;
-        const float alpha = __builtin_amdgcn_exp2f(m_run - mnew);
-        l_run *= alpha;
-        m_run = mnew;
+      if (first || __any(mloc > 8.0f)) {   // (the scores are already relative to m_run)
+        const float delta = (first || mloc > 8.0f) ? mloc : 0.f;   // the reference moves by this much in this lane
+        if (!first) {
+          const float alpha = __builtin_amdgcn_exp2f(-delta);
+          l_run *= alpha;
 #pragma unroll
-        for (int a = 0; a < NACC; ++a)
+          for (int a = 0; a < NACC; ++a)
 #pragma unroll
-          for (int c4 = 0; c4 < CG; ++c4) oa[a][c4] *= alpha;
+            for (int c4 = 0; c4 < CG; ++c4) oa[a][c4] *= alpha;
+        }
+        m_run += delta;
+        negm = (f32x4){-m_run, -m_run, -m_run, -m_run};
+#pragma unroll
+        for (int g = 0; g < NG; ++g)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) s[g][i] -= delta;
+        first = false;
       }
       f32x4 l4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int g = 0; g < NG; ++g) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) s[g][i] = __builtin_amdgcn_exp2f(s[g][i] - m_run);
+        for (int i = 0; i < 4; ++i) s[g][i] = __builtin_amdgcn_exp2f(s[g][i]);
         l4 += s[g];
       }
       l_run += (l4[0] + l4[1]) + (l4[2] + l4[3]);
@@ -183,6 +196,7 @@ __global__ __launch_bounds__(256) void attn_lane_kernel(const AttnArgs p) {
   }
 
   // ---- epilogue: the lane holds its query's d outputs
+  if (first) m_run = NEG_BIG;   // a key part without tiles: its (m, l) = (-inf, 0) must not raise the merged maximum
   if (!qok) return;
   f32x4 o[CG];
 #pragma unroll
