@@ -63,6 +63,7 @@ class Tape(object):
         self.joins = set()  # companion streams with weight-gradient work in flight (joined at the end of backward)
         self.model = None   # the model whose forward this tape records (milestone hooks are bound to it)
         self.early = None   # backward: event a fusion region left for the next region's side stream (run_paths)
+        self.capturing = False  # the backward is being captured into a hipGraph (no companion-stream forks then)
         self.arena = None   # backward of a small model: ONE zero-filled tensor the gradient buffers are cut from
         self.arena_off = 0
         self.zero_floats = -1  # >= 0 while the backward runs: floats of zero-initialised buffers it has asked for
@@ -121,6 +122,7 @@ class Tape(object):
         """Replay in reverse.  Ops recorded inside run_paths on the side stream run there again; the region's
         join / fork markers become the backward pass's fork / join."""
         self._open_arena()
+        self.capturing = bool(torch.cuda.is_available() and torch.cuda.is_current_stream_capturing())
         for fn, side in reversed(self.ops):
             if side is None:
                 fn()
@@ -358,7 +360,21 @@ def _record_conv(x, conv_weight, conv_bias, wp_shape, gsrc, kernel, stride, padd
         if fold_kw == 0 and sfhip.bx_backward_wants_dz_planes(x, g, cout, kernel, stride, padding, dilation, cin=cin,
                                                                cin_pad=wp_shape[2], dgrad=x_needs_grad):
             zp = sfhip.act_planes(g)
-        if OVERLAP_PATHS and WGRAD_COMPANION and not t.serial and x_needs_grad and dev.type == "cuda":
+        # The fork costs two cross-stream hand-offs: ~15 us each on the device when launched eagerly
+        # (tools/microbench/stream_latency.py) — worth it even for the small layers of cfg #3 (52.9 ms forking every
+        # layer, 53.2 forking only those estimated above 30 .. 120 us) — but far more as edges of a captured hipGraph:
+        # cfg #1's replay went from 9.65 to 6.03 ms, cfg #5's from 43.3 to 34.9 ms and cfg #3's own from 56.6 to 54.1 ms
+        # without them.  So: no companion stream while the backward is being CAPTURED; eagerly, every layer whose
+        # estimated weight gradient (2 rows Cin Cout taps FLOP at 80 TFLOP/s + both operands once at 3 TB/s) reaches
+        # SF_WGRAD_FORK_US (default 0: all).
+        fork = OVERLAP_PATHS and WGRAD_COMPANION and not t.capturing and not t.serial and x_needs_grad and \
+            dev.type == "cuda"
+        if fork and WGRAD_FORK_US > 0:
+            rows_, cin_ = g.rows, (cin or x.C)
+            est_us = (2.0 * rows_ * cin_ * cout * (kernel[0] * kernel[1] * kernel[2])) / 80e6 + \
+                4.0 * (x.rows * cin_ + rows_ * cout) / 3e6
+            fork = est_us >= WGRAD_FORK_US
+        if fork:
             # the weight gradient only feeds the parameter's .grad: issue it on a companion stream so that it
             # overlaps the data gradient (both are short-grid GEMMs on the res4 / res5 layers); joined by
             # Tape.backward before the gradients are handed back
@@ -627,6 +643,7 @@ _PAIR_WEIGHTS = {}  # id(weight) -> weakref of the dense conv weights that have 
 # elementwise, so no WeakSet): repack_all's candidates
 BATCHED_REPACK = os.environ.get("SF_BATCH_REPACK", "1") != "0"
 WGRAD_COMPANION = os.environ.get("SF_WGRAD_COMPANION", "1") != "0"  # weight gradients on a companion stream
+WGRAD_FORK_US = float(os.environ.get("SF_WGRAD_FORK_US", "0"))       # ... when estimated to take at least this long
 
 
 def _packed_pair(weight):
