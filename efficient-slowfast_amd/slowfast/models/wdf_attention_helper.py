@@ -35,12 +35,16 @@ class SpatialAttention(nn.Module):
                 return t
             return torch.cat([t, t.new_zeros((rows - t.shape[0],) + tuple(t.shape[1:]))], 0)
 
-        def make():
+        def make():  # (forward pack, bias, data-gradient pack) of the merged projection, once per parameter version
             w = torch.cat([padded(cv.weight, c) for cv in convs], 0)
             b = torch.cat([padded(cv.bias, c) for cv in convs], 0)
-            return sfhip.pack_conv_weight(w), b.contiguous()
+            if w.is_cuda:  # both layouts by one launch
+                wp_, wtp_ = sfhip.pack_conv_weight_pair(w.detach())
+                return wp_, b.contiguous(), wtp_
+            return sfhip.pack_conv_weight(w), b.contiguous(), None
 
-        wp, b = engine._cached(self, "_sf_qkv", engine._key(*[t for cv in convs for t in (cv.weight, cv.bias)]), make)
+        wp, b, wtp = engine._cached(self, "_sf_qkv", engine._key(*[t for cv in convs for t in (cv.weight, cv.bias)]),
+                                    make)
         qkv = sfhip.conv(x, wp, (1, 1, 1), bias=b)
         t = engine.tape()
         if t is not None:
@@ -54,8 +58,6 @@ class SpatialAttention(nn.Module):
                 for i, cv in enumerate(convs):
                     t.add_pgrad(cv.weight, dw[i * c:i * c + nout[i]])
                     t.add_pgrad(cv.bias, db[i * c:i * c + nout[i]])
-                w_all = torch.cat([padded(cv.weight, c) for cv in convs], 0).detach()
-                wtp = sfhip.pack_conv_weight(w_all.transpose(0, 1).contiguous())
                 sfhip.conv_dgrad(g, wtp, x, (1, 1, 1), out=t.grad_of(x), accumulate=True)
 
             t.record(bwd)
