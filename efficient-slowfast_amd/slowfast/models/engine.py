@@ -367,8 +367,8 @@ def _record_conv(x, conv_weight, conv_bias, wp_shape, gsrc, kernel, stride, padd
         # without them.  So: no companion stream while the backward is being CAPTURED; eagerly, every layer whose
         # estimated weight gradient (2 rows Cin Cout taps FLOP at 80 TFLOP/s + both operands once at 3 TB/s) reaches
         # SF_WGRAD_FORK_US (default 0: all).
-        fork = OVERLAP_PATHS and WGRAD_COMPANION and not t.capturing and not t.serial and x_needs_grad and \
-            dev.type == "cuda"
+        fork = OVERLAP_PATHS and WGRAD_COMPANION and (WGRAD_FORK_IN_GRAPH or not t.capturing) and not t.serial and \
+            x_needs_grad and dev.type == "cuda"
         if fork and WGRAD_FORK_US > 0:
             rows_, cin_ = g.rows, (cin or x.C)
             est_us = (2.0 * rows_ * cin_ * cout * (kernel[0] * kernel[1] * kernel[2])) / 80e6 + \
@@ -644,6 +644,7 @@ _PAIR_WEIGHTS = {}  # id(weight) -> weakref of the dense conv weights that have 
 BATCHED_REPACK = os.environ.get("SF_BATCH_REPACK", "1") != "0"
 WGRAD_COMPANION = os.environ.get("SF_WGRAD_COMPANION", "1") != "0"  # weight gradients on a companion stream
 WGRAD_FORK_US = float(os.environ.get("SF_WGRAD_FORK_US", "0"))       # ... when estimated to take at least this long
+WGRAD_FORK_IN_GRAPH = os.environ.get("SF_WGRAD_FORK_IN_GRAPH", "0") == "1"  # A/B: fork also while a hipGraph is captured
 
 
 def _packed_pair(weight):
