@@ -1,1 +1,4 @@
 """Input step either side of the hot path (reference slowfast/datasets/utils.py, transform.py)."""
+from slowfast._overlay import chain_package as _chain_package
+
+_chain_package(globals())  # modules this repo does not carry resolve to the reference's slowfast/datasets/

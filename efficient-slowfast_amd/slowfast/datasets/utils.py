@@ -6,6 +6,9 @@ pathway's frame indices (`pack_pathway_output`, datasets/utils.py:73-112).  The 
 normalise (`tensor_normalize`, :298-315), bilinear short-side scale, crop, flip, frame selection — runs as one HIP
 kernel per pathway (`sf_clip_prologue`) that writes the stems' input layout directly, so the decoded clip crosses
 PCIe as uint8 once instead of as two float NCTHW tensors."""
+from slowfast._overlay import chain_module as _chain_module
+
+_chain_module(globals())  # the reference's namesake (when importable) supplies every name not defined below
 import collections
 import math
 

@@ -5,6 +5,9 @@ issued from autograd hooks.  The native design is ONE all-
 parameter's .grad is a view into one flat fp32 buffer (135.9 MB for SlowFastDualAttention R50), so after
 backward a single ncclAllReduce(sum) over the fully connected xGMI mesh plus one scale by 1/world replaces
 DDP's ~6 buckets and needs no gradient copies.  `build_model` still offers the DDP wrap for drop-in use."""
+from slowfast._overlay import chain_module as _chain_module
+
+_chain_module(globals())  # the reference's namesake (when importable) supplies every name not defined below
 import os
 
 import torch
@@ -47,6 +50,45 @@ def get_world_size():
 
 def get_rank():
     return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+
+
+def is_master_proc(num_gpus=8):
+    """True on the first process of every machine (utils/distributed.py:94-101); True when not distributed."""
+    return get_rank() % num_gpus == 0
+
+
+def synchronize():
+    """Barrier over the default group; nothing to do for one process (utils/distributed.py:126-139)."""
+    if get_world_size() > 1:
+        dist.barrier()
+
+
+def all_reduce(tensors, average=True):
+    """Sum (or mean) each tensor of the list over all processes, in place; returns the list
+    (utils/distributed.py:37-53).  The timed train step does not use this — gradients go through FlatGradients —
+    it serves the reference's logging path (`train_net.py:129-138`)."""
+    world = get_world_size()
+    if world > 1:
+        for t in tensors:
+            dist.all_reduce(t, async_op=False)
+        if average:
+            for t in tensors:
+                t.mul_(1.0 / world)
+    return tensors
+
+
+def all_gather(tensors):
+    """Concatenate every process's copy of each tensor along dim 0 (utils/distributed.py:15-34)."""
+    world = get_world_size()
+    out = []
+    for t in tensors:
+        parts = [torch.ones_like(t) for _ in range(world)]
+        if world > 1:
+            dist.all_gather(parts, t, async_op=False)
+        else:
+            parts = [t]
+        out.append(torch.cat(parts, dim=0))
+    return out
 
 
 def shard_sizes(global_batch, world):

@@ -3,7 +3,17 @@
 The reference copies every batch of predictions to the host and adds them to per-video rows one clip at a time in a
 Python loop.  Here the accumulators live on the model's device and one `index_add_` / `scatter_reduce_` per batch
 performs the ensemble, so the test loop never synchronises with the GPU until `finalize_metrics`."""
+from slowfast._overlay import chain_module as _chain_module
+
+_chain_module(globals())  # the reference's namesake (when importable) supplies every name not defined below
+import datetime
+import json
+import logging
+import time
+
 import torch
+
+_LOG = logging.getLogger(__name__)
 
 
 def topks_correct(preds, labels, ks):
@@ -25,6 +35,7 @@ class TestMeter(object):
             raise NotImplementedError("Ensemble Method {} is not supported".format(ensemble_method))
         self.num_clips = num_clips
         self.overall_iters = overall_iters
+        self._tic, self._lap = time.perf_counter(), 0.0
         self.multi_label = multi_label
         self.ensemble_method = ensemble_method
         self.video_preds = torch.zeros((num_videos, num_cls), device=device)
@@ -52,6 +63,21 @@ class TestMeter(object):
             self.video_preds.scatter_reduce_(0, vid.view(-1, 1).expand_as(preds), preds.to(self.video_preds.dtype),
                                              reduce="amax", include_self=True)
         self.clip_count.index_add_(0, vid, torch.ones_like(vid))
+
+    def iter_tic(self):
+        """Start timing one test iteration (utils/meters.py:337-338)."""
+        self._tic = time.perf_counter()
+
+    def iter_toc(self):
+        """Stop timing; the lap feeds `log_iter_stats` (utils/meters.py:340-341)."""
+        self._lap = time.perf_counter() - self._tic
+
+    def log_iter_stats(self, cur_iter):
+        """One `json_stats:` line per iteration with the remaining-time estimate (utils/meters.py:319-335)."""
+        eta = str(datetime.timedelta(seconds=int(self._lap * (self.overall_iters - cur_iter))))
+        stats = {"split": "test_iter", "cur_iter": "{}".format(cur_iter + 1), "eta": eta, "time_diff": self._lap}
+        _LOG.info("json_stats: {}".format(json.dumps(stats, sort_keys=True)))
+        return stats
 
     def finalize_metrics(self, ks=(1, 5)):
         """Returns {"split": "test_final", "top{k}_acc": "xx.xx", ...} (multi-label mAP is not on this path)."""

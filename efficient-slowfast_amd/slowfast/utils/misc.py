@@ -1,4 +1,7 @@
 """The BN-related helpers of the reference's utils/misc.py that sit on the training path (:241-274)."""
+from slowfast._overlay import chain_module as _chain_module
+
+_chain_module(globals())  # the reference's namesake (when importable) supplies every name not defined below
 import torch.nn as nn
 
 from slowfast.models.batchnorm_helper import SubBatchNorm3d
