@@ -190,7 +190,12 @@ def _check(rc, what):
         raise SfhipError("%s failed: %s" % (what, _ERR.get(rc, rc)))
 
 
+CALLS = 0  # C-ABI calls issued by this process (every entry point takes the stream: counted there; bench.py's launch_bound block)
+
+
 def _stream():
+    global CALLS
+    CALLS += 1
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 

@@ -103,3 +103,45 @@ def test_spawned_rank_runs_the_chunked_allreduce_on_rccl():
     assert chunked["allreduce"]["grad_hash"] == single["allreduce"]["grad_hash"]
     aff = chunked["rank0_cpu_affinity"]
     assert aff["cpus"] >= 1 and aff["last_cpu"] >= aff["first_cpu"]
+
+
+def test_two_ranks_through_bench_py_on_one_gpu():
+    """Every line of bench.py's N > 1 path except RCCL itself, on a 1-GPU box: `bench.py --gpus 2` (no launcher) spawns
+    two ranks; the TEST-ONLY environment puts both on device 0 over gloo (RCCL refuses two ranks on one device).  Checked:
+    both ranks joined (n_ranks_seen), the flat gradient went out in 3 chunks at the backward's milestones, BOTH ranks
+    hold the same reduced gradient buffer (bit for bit) and it equals the single-collective schedule's, and both ranks
+    left settle() after the same number of steps.  Reference: models/build.py:39-43 (DDP), utils/multiprocessing.py:9-50.
+    No scaling number comes out of this: the line says so itself (config.parallelism)."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    root = os.path.dirname(HERE)
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    env = dict(os.environ, SF_BENCH_BACKEND="gloo", SF_BENCH_ONE_DEVICE="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "SF_RANK_CPUS", "SF_FORCE_ALLREDUCE"):
+        env.pop(k, None)
+    lines = []
+    for extra in ([], ["--no-overlap-allreduce"]):
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                            "--workload", "dual", "--batch", "1", "--no-cpu-baseline", "--no-extras"] + extra,
+                           env=env, capture_output=True, text=True, timeout=900)
+        if r.returncode != 0:
+            try:
+                os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
+                with open(os.path.join(root, "gpurun_out", "two_rank_bench_stderr.txt"), "w") as f:
+                    f.write(r.stderr)
+            except OSError:
+                pass
+        assert r.returncode == 0, (r.stderr[:3000], r.stderr[-1500:])
+        lines.append(json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]))
+    chunked, single = lines
+    for ln in lines:
+        assert ln["n_ranks_seen"] == 2 and ln["n_gpus"] == 2
+        assert ln["config"]["global_batch"] == 2 and "TEST CONFIGURATION" in ln["config"]["parallelism"]
+        hashes = ln["allreduce"]["grad_hash_all_ranks"]
+        assert len(hashes) == 2 and hashes[0] == hashes[1] == ln["allreduce"]["grad_hash"], ln["allreduce"]
+        steps = ln["config"]["launch_probe"]["steady_state_steps_all_ranks"]
+        assert len(steps) == 2 and steps[0] == steps[1], steps
+    assert chunked["allreduce"]["chunks_per_step"] == 3 and single["allreduce"]["chunks_per_step"] == 1
+    assert chunked["allreduce"]["grad_hash"] == single["allreduce"]["grad_hash"]
+    assert chunked["config"]["launch_probe"]["timed"] == "eager"  # no hipGraph with a process group up
