@@ -210,7 +210,8 @@ def make_train_step(model, clips, labels, overlap_allreduce=True, lr=1e-3):
     zero the flat gradient buffer, train-mode forward, cross-entropy, backward through the tape (parameter gradients
     accumulated by the kernels straight into the flat buffer), ONE all-reduce of that buffer, torch.optim.SGD step.
     Returns (step, flat, opt); step() returns the loss tensor.  tests/test_graph_train_gpu.py replays exactly this
-    closure from a hipGraph against its eager form."""
+    closure from a hipGraph against its eager form.  A captured graph of it is replayed with engine.replay(graph) (or
+    followed by engine.parameters_changed()): the replayed optimizer kernel does not run torch's optimizer hooks."""
     from slowfast.models import engine
     from slowfast.utils.distributed import FlatGradients
     model.train()
@@ -631,11 +632,14 @@ def main():
     with torch.cuda.stream(side):
         for _ in range(args.steps):
             if graph is not None:
-                graph.replay()
+                graph.replay()   # (the epoch bump of engine.replay is hoisted: parameters_changed() right after the loop)
             else:
                 out = step()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    if graph is not None and train:
+        from slowfast.models import engine as _eng
+        _eng.parameters_changed()  # replayed optimizer kernels moved the parameters: every eager cache is stale
     barrier()
     elapsed = max_over_ranks(elapsed, device)
     # the LAST timed step's own result (eager: the tensor it returned; replay: the capture's static output, which every

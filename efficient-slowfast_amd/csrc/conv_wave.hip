@@ -818,10 +818,10 @@ static int wave_p(const WaveArgs& a, int nwg, hipStream_t s, bool launch) {
 }
 
 static int wave_p_dispatch(int best, const WaveArgs& a, int nwg, hipStream_t s, bool launch) {
+  // (the 13x2 and 7x4 tiles are not instantiated in the persistent form at all: at 256 registers they spill — 16 B and
+  //  188 B of scratch, tools/isa_audit.py — and the caller keeps those picks on the one-pass kernel)
   if (a.plain) {
     switch (best) {
-      case 1: return wave_p<13, 2, true>(a, nwg, s, launch);
-      case 3: return wave_p<7, 4, true>(a, nwg, s, launch);
       case 5: return wave_p<7, 2, true>(a, nwg, s, launch);
       default: return wave_p<13, 1, true>(a, nwg, s, launch);
     }
@@ -1022,8 +1022,8 @@ int sf_conv_wave_try(const sf_conv_desc* d, const float* in, const float* w_pack
     a.nwg = sf_cdiv(a.ntiles, 4);
   }
   const WaveCfg& cp = CFGS[best];
-  const bool take_p = persist_level() == 1 ? (a.plain || (best != 1 && best != 3)) : (persist_level() == 2 ? a.plain : short_k);
-  if (cp.ks == 1 && can_p && take_p) {
+  const bool take_p = persist_level() == 1 ? true : (persist_level() == 2 ? a.plain : short_k);
+  if (cp.ks == 1 && can_p && take_p && best != 1 && best != 3) {
     const int occ = wave_p_dispatch(best, a, 0, stream, false);
     int nwg = a.nwg < 256 * occ ? a.nwg : 256 * occ;
     if (a.stats) {

@@ -123,21 +123,29 @@ class Tape(object):
         join / fork markers become the backward pass's fork / join."""
         self._open_arena()
         self.capturing = bool(torch.cuda.is_available() and torch.cuda.is_current_stream_capturing())
-        for fn, side in reversed(self.ops):
-            if side is None:
-                fn()
-            else:
-                with torch.cuda.stream(side):
+        asked = -1
+        try:
+            for fn, side in reversed(self.ops):
+                if side is None:
                     fn()
-        for wg in self.joins:
-            _sync_streams(wg, torch.cuda.current_stream(wg.device))
-        self.joins = set()
-        self.ops = []
-        if self.model is not None and self.zero_floats >= 0:
-            self.model.__dict__["_sf_arena_floats"] = self.zero_floats
-        self.zero_floats = -1
-        self.gbuf = {}
-        self.arena = None
+                else:
+                    with torch.cuda.stream(side):
+                        fn()
+            for wg in self.joins:
+                _sync_streams(wg, torch.cuda.current_stream(wg.device))
+            asked = self.zero_floats
+        finally:
+            # also after a failed replay (SfhipError, OOM): no arena stays referenced, and no later grad_of outside a
+            # backward is counted against — or cut from — a partly used, no longer zero one
+            self.joins = set()
+            self.ops = []
+            self.zero_floats = -1
+            self.gbuf = {}
+            self.arena = None
+            self.arena_off = 0
+            self.capturing = False
+        if self.model is not None and asked >= 0:   # published only by a backward that ran to its end
+            self.model.__dict__["_sf_arena_floats"] = asked
 
     def _open_arena(self):
         """Launch-bound models (cfg #1: ~115 gradient buffers of a few KB each): the zero-initialised gradient buffers of
@@ -440,6 +448,17 @@ def parameters_changed(*_unused):
     """Invalidate every parameter-derived cache of the HIP path (packed weights, folded BN, ...)."""
     global _PARAM_EPOCH
     _PARAM_EPOCH += 1
+
+
+def replay(graph):
+    """graph.replay() for a hipGraph that holds a TRAINING step (forward, backward, optimizer update) — the form every
+    caller of such a graph must use.  A replayed optimizer kernel moves the parameters without running torch's Python
+    optimizer hooks and without touching version counters, and the re-pack launches captured in the graph refresh the
+    copies in the GRAPH's memory pool, not the ones eager code reads: without the epoch bump an eager forward after the
+    replays (an eval pass, a checkpoint's BN fold) would silently reuse packed weights, bf16 planes, folded BN and q/k/v
+    stacks from before them (tests/test_graph_train_gpu.py::test_eval_after_replays_sees_the_trained_weights)."""
+    graph.replay()
+    parameters_changed()
 
 
 try:

@@ -104,3 +104,66 @@ def _run(bench, workload, clips):
     assert changed > 0.9 * len(state), (changed, len(state))
     # and the replay is not a constant: the K losses differ from step to step
     assert len(set(eager[2].tolist())) == K
+
+
+def test_eval_after_replays_sees_the_trained_weights():
+    """eager eval -> K replays of a captured training step (engine.replay) -> eager eval must equal the
+    eval after K eager steps from the same snapshot; with a bare graph.replay() the second eval would run on the packed
+    weights / folded BN cached by the first one."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    sys.path.insert(0, ROOT)
+    import bench
+    from slowfast.models import engine
+    try:
+        dev = torch.device("cuda", 0)
+        with contextlib.redirect_stdout(io.StringIO()):
+            cfg, model, _, _ = bench.build("shufflenetv2", dev)
+        xs = bench.synthetic_clips(cfg, 2, dev, 11)
+        labels = torch.randint(0, cfg.MODEL.NUM_CLASSES, (2,), device=dev,
+                               generator=torch.Generator(device=dev).manual_seed(3))
+        step, flat, opt = bench.make_train_step(model, xs, labels, overlap_allreduce=False, lr=0.05)
+        side = torch.cuda.Stream()
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                step()
+        torch.cuda.synchronize()
+        state = _state(model, opt)
+        snap = [v.detach().clone() for _, v in state]
+
+        def restore():
+            with torch.no_grad():
+                for (_, v), s_ in zip(state, snap):
+                    v.copy_(s_)
+            torch.cuda.manual_seed(77)
+            torch.cuda.synchronize()
+
+        def evaluate():
+            model.eval()
+            with torch.no_grad(), torch.cuda.stream(side):
+                out = model([xs[0], xs[1]]).detach().clone()
+            torch.cuda.synchronize()
+            model.train()
+            return out
+
+        restore()
+        before = evaluate()
+        with torch.cuda.stream(side):
+            for _ in range(K):
+                step()
+        want = evaluate()
+        assert not torch.equal(before, want), "the steps must move the eval output"
+
+        restore()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side):
+            step()
+        restore()
+        assert torch.equal(evaluate(), before)          # fills the eager caches from the snapshot weights
+        with torch.cuda.stream(side):
+            for _ in range(K):
+                engine.replay(g)
+        got = evaluate()
+        assert torch.equal(got, want), float((got - want).abs().max())
+    finally:
+        engine.set_grad_sink(False)
