@@ -17,47 +17,56 @@ import slowfast.utils.distributed as du
 
 
 def get_norm(cfg):
-    """batchnorm_helper.py:15-34."""
-    if cfg.BN.NORM_TYPE == "batchnorm":
-        return nn.BatchNorm3d
-    elif cfg.BN.NORM_TYPE == "sub_batchnorm":
-        return partial(SubBatchNorm3d, num_splits=cfg.BN.NUM_SPLITS)
-    elif cfg.BN.NORM_TYPE == "sync_batchnorm":
-        return partial(NaiveSyncBatchNorm3d, num_sync_devices=cfg.BN.NUM_SYNC_DEVICES)
-    else:
-        raise NotImplementedError("Norm type {} is not supported".format(cfg.BN.NORM_TYPE))
+    """cfg.BN.NORM_TYPE -> the constructor every model passes its `num_features=..., eps=..., momentum=...` to
+    (reference batchnorm_helper.py:15-34; same three names, same NotImplementedError text for anything else)."""
+    kind = cfg.BN.NORM_TYPE
+    makers = {
+        "batchnorm": lambda: nn.BatchNorm3d,
+        "sub_batchnorm": lambda: partial(SubBatchNorm3d, num_splits=cfg.BN.NUM_SPLITS),
+        "sync_batchnorm": lambda: partial(NaiveSyncBatchNorm3d, num_sync_devices=cfg.BN.NUM_SYNC_DEVICES),
+    }
+    if kind not in makers:
+        raise NotImplementedError("Norm type {} is not supported".format(kind))
+    return makers[kind]()
 
 
 class SubBatchNorm3d(nn.Module):
-    """BN with statistics over 1/num_splits of the batch each (multigrid training); one shared affine; `bn`
-    holds the aggregated eval statistics, `split_bn` the per-split running statistics
-    (batchnorm_helper.py:37-109)."""
+    """BN whose batch statistics cover 1/num_splits of the batch each (multigrid training).  Checkpoint layout
+    (reference batchnorm_helper.py:37-109): one shared `weight` / `bias`; `split_bn` (affine-free, num_splits * C
+    features) carries the per-split running statistics that training updates; `bn` (affine-free, C features) the
+    statistics evaluation uses, filled from `split_bn` by aggregate_stats()."""
 
     def __init__(self, num_splits, **args):
         super(SubBatchNorm3d, self).__init__()
         self.num_splits = num_splits
-        num_features = args["num_features"]
-        if args.get("affine", True):  # keep only one set of weight and bias
-            self.affine = True
-            args["affine"] = False
-            self.weight = torch.nn.Parameter(torch.ones(num_features))
-            self.bias = torch.nn.Parameter(torch.zeros(num_features))
-        else:
-            self.affine = False
-        self.bn = nn.BatchNorm3d(**args)
-        args["num_features"] = num_features * num_splits
-        self.split_bn = nn.BatchNorm3d(**args)
+        feats = args["num_features"]
+        self.affine = bool(args.get("affine", True))
+        if self.affine:  # the two inner layers stay affine-free: the (one) affine pair lives on this module
+            self.weight = torch.nn.Parameter(torch.ones(feats))
+            self.bias = torch.nn.Parameter(torch.zeros(feats))
+        inner = dict(args, affine=False)
+        self.bn = nn.BatchNorm3d(**inner)
+        self.split_bn = nn.BatchNorm3d(**dict(inner, num_features=feats * num_splits))
 
     def _get_aggregated_mean_std(self, means, stds, n):
-        mean = means.view(n, -1).sum(0) / n
-        std = stds.view(n, -1).sum(0) / n + ((means.view(n, -1) - mean) ** 2).view(n, -1).sum(0) / n
-        return mean.detach(), std.detach()
+        """Statistics of the union of n equally sized splits from the per-split ones (law of total variance):
+        mean = average of the split means; variance = average split variance + variance of the split means.
+        `stds` holds variances (the reference's naming, batchnorm_helper.py:75-88)."""
+        per_split_mean = means.detach().reshape(n, -1)
+        per_split_var = stds.detach().reshape(n, -1)
+        mean = per_split_mean.sum(dim=0) / n
+        between = (per_split_mean - mean).pow(2).sum(dim=0) / n
+        return mean, per_split_var.sum(dim=0) / n + between
 
     def aggregate_stats(self):
-        """Fold the per-split running statistics into `bn` (call before eval)."""
-        if self.split_bn.track_running_stats:
-            self.bn.running_mean.data, self.bn.running_var.data = self._get_aggregated_mean_std(
-                self.split_bn.running_mean, self.split_bn.running_var, self.num_splits)
+        """Fill `bn`'s running statistics from the per-split ones (the training loop calls this before evaluating,
+        utils/misc.py:257-273)."""
+        if not self.split_bn.track_running_stats:
+            return
+        mean, var = self._get_aggregated_mean_std(self.split_bn.running_mean, self.split_bn.running_var,
+                                                  self.num_splits)
+        self.bn.running_mean.data = mean
+        self.bn.running_var.data = var
 
     def forward(self, x):
         from slowfast.models import engine

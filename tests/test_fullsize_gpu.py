@@ -93,8 +93,13 @@ def test_fast_stem_ring_kernels_at_full_size():
 
 
 @pytest.mark.parametrize("c,thw,B", [(32, (8, 56, 56), 1), (32, (8, 56, 56), 3), (8, (8, 56, 56), 1), (8, (8, 56, 56), 3),
-                                     (4, (8, 112, 112), 1)],
-                         ids=["d32_n25088", "d32_n25088_b3_nw8", "d8_n25088", "d8_n25088_b3", "d4_n100352_cfg5"])
+                                     (4, (8, 112, 112), 1),
+                                     # s3_fuse / s4_fuse of cfg #3 (custom_video_model_builder.py:317-358): d = 64 on the
+                                     # bf16-piece kernels (attn_*_bx2), d = 128 on the f32-input two-kernel backward
+                                     (64, (8, 28, 28), 1), (64, (8, 28, 28), 3), (128, (8, 14, 14), 1),
+                                     (128, (8, 14, 14), 3), (128, (8, 14, 14), 8)],
+                         ids=["d32_n25088", "d32_n25088_b3_nw8", "d8_n25088", "d8_n25088_b3", "d4_n100352_cfg5",
+                              "d64_n6272", "d64_n6272_b3", "d128_n1568", "d128_n1568_b3", "d128_n1568_b8"])
 def test_attention_at_production_size_against_exact_fp64(c, thw, B):
     """B = 3 at N = 25 088 is the smallest batch at which the d = 32 backward takes the 8-wavefront / 256-key form
     (attn_bwd_bx_kernel<0, 8>) that bench.py times at 8 clips; the sweep-part counts are batch-keyed as well."""

@@ -4,7 +4,7 @@ piecewise-linear function (its ReLU masks / max-pool winners are injected, as th
 What the two runs disagree by is the reference's own fp32 rounding noise on that parameter — the floor any fp32
 implementation of the step sits on.  CPU only (runs in the build container).
 
-    python tools/oracle_conditioning.py shufflenetv2 [clips]      -> profiles/r05_oracle_conditioning_<workload>.txt
+    python tools/oracle_conditioning.py shufflenetv2 [clips]      -> profiles/r06_oracle_conditioning_<workload>.txt
 """
 import collections
 import contextlib
@@ -77,9 +77,14 @@ def main():
            "gradients left out" % (l32, l64, len(errs), errs[len(errs) // 2][0], errs[len(errs) // 10][0], errs[0][0], len(noise))]
     for e, k in errs[:12]:
         out.append("    %-72s %.2e   |g| %.3e  n=%d" % (k, e, float(g64[k].norm()), g64[k].numel()))
+    attn = [(e, k) for e, k in errs if "attention_spatial" in k]
+    if attn:
+        out.append("SpatialAttention parameters (query / key / value convs, gamma) of every fusion:")
+        for e, k in sorted(attn, key=lambda t: t[1]):
+            out.append("    %-72s %.2e   |g| %.3e  n=%d" % (k, e, float(g64[k].norm()), g64[k].numel()))
     txt = "\n".join(out)
     print(txt)
-    with open(os.path.join(ROOT, "profiles", "r05_oracle_conditioning_%s.txt" % workload), "w") as f:
+    with open(os.path.join(ROOT, "profiles", "r06_oracle_conditioning_%s.txt" % workload), "w") as f:
         f.write(txt + "\n")
 
 
