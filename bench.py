@@ -115,16 +115,16 @@ def cpu_baseline(workload, cfg, model, train, device=None, hip_train_step=None, 
     label = torch.arange(nclip, dtype=torch.long) % cfg.MODEL.NUM_CLASSES
     keep = {}
 
-    def iteration(keep_grads=False):
+    def iteration(keep_grads=False, dtype=torch.float32):
         if not train:
             return oracle.forward(name, sd, xs, hp)["out"]
-        sdr = {k: (v.clone().requires_grad_(True) if v.dtype == torch.float32 and "running" not in k else v)
-               for k, v in sd.items()}
-        acts = oracle.FORWARDS[name](sdr, [x.clone() for x in xs], hp, training=True)
+        sdr = {k: (v.to(dtype).clone().requires_grad_(True) if v.dtype == torch.float32 and "running" not in k
+                   else (v.to(dtype) if v.dtype == torch.float32 else v)) for k, v in sd.items()}
+        acts = oracle.FORWARDS[name](sdr, [x.to(dtype).clone() for x in xs], hp, training=True)
         loss = torch.nn.functional.cross_entropy(acts["out"], label)
         loss.backward()
         if keep_grads:
-            keep["loss"], keep["logits"] = float(loss), acts["out"].detach()
+            keep["loss"], keep["logits"] = float(loss.detach()), acts["out"].detach()
             keep["grads"] = {k: v.grad for k, v in sdr.items() if getattr(v, "grad", None) is not None}
         return None
 
@@ -173,6 +173,30 @@ def cpu_baseline(workload, cfg, model, train, device=None, hip_train_step=None, 
             parity["bwd_params_compared"] = len(errs)
             parity["bwd_masks_injected"] = {"relu": masks.used, "max_pool": masks.pool_used,
                                             "missed": len(masks.missed)}
+            # the same step once more with the oracle in fp64 (same clip, parameters, masks): what the fp32 oracle itself
+            # is off by — the reference's own rounding noise, the floor of every number above (profiles/
+            # r06_oracle_conditioning_dual.txt: median 2.3e-4, 9.9e-4 on s4_fuse's key conv) — and the HIP gradients
+            # against that (near-)exact result, parameter by parameter
+            if os.environ.get("SF_BENCH_FP64_CHECK", "1") != "0":
+                g32 = keep["grads"]
+                with _masks.inject(masks):
+                    iteration(keep_grads=True, dtype=torch.float64)
+                g64 = keep["grads"]
+                e_hip, e_ref = [], []
+                for k, g in g64.items():
+                    if k in grads and k in g32 and float(g.norm()) > 0 and k not in noise:
+                        e_hip.append((float((grads[k].cpu().double() - g).norm() / g.norm()), k))
+                        e_ref.append((float((g32[k].double() - g).norm() / g.norm()), k))
+                e_hip.sort()
+                e_ref.sort()
+                parity["fwd_logits_max_rel_err_vs_fp64"] = float(
+                    (logits.cpu().double() - keep["logits"]).abs().max() / keep["logits"].abs().max())
+                parity["bwd_median_rel_err_vs_fp64"] = e_hip[len(e_hip) // 2][0]
+                parity["bwd_max_rel_err_vs_fp64"] = e_hip[-1][0]
+                parity["bwd_worst_param_vs_fp64"] = e_hip[-1][1]
+                parity["oracle_fp32_vs_fp64_bwd_median"] = e_ref[len(e_ref) // 2][0]
+                parity["oracle_fp32_vs_fp64_bwd_max"] = e_ref[-1][0]
+                parity["oracle_fp32_vs_fp64_worst_param"] = e_ref[-1][1]
             keep.clear()
     if parity_only:   # the checker alone (the trained-state comparison): nothing is timed
         return None, parity
@@ -955,7 +979,9 @@ def main():
             # L2 error of every parameter's gradient of the training step (north_star tolerance: 1e-3 on the forward)
             for k, v in parity.items():
                 res[k] = float("%.3e" % v) if isinstance(v, float) else v
-            for k in ("fwd_logits_max_rel_err", "bwd_median_rel_err", "bwd_max_rel_err", "bwd_worst_param"):
+            for k in ("fwd_logits_max_rel_err", "bwd_median_rel_err", "bwd_max_rel_err", "bwd_worst_param",
+                      "bwd_median_rel_err_vs_fp64", "bwd_max_rel_err_vs_fp64", "bwd_worst_param_vs_fp64",
+                      "oracle_fp32_vs_fp64_bwd_median", "oracle_fp32_vs_fp64_bwd_max"):
                 if after and k in after:
                     v = after[k]
                     res[k + "_after_steps"] = float("%.3e" % v) if isinstance(v, float) else v
@@ -965,14 +991,20 @@ def main():
                                  "per-parameter relative L2 of the train step's gradients, the oracle differentiating with " \
                                  "the HIP forward's ReLU masks / max-pool winners (tests/_masks.py); gradients that are zero " \
                                  "in exact arithmetic (tests/_zero_grads.py) are bounded absolutely: bwd_zero_class_*; " \
+                                 "*_vs_fp64 = the HIP step against the SAME oracle run in fp64 (same masks), " \
+                                 "oracle_fp32_vs_fp64_* = the fp32 oracle against it: the reference's own rounding noise, " \
+                                 "which is what bwd_max_rel_err sits on; " \
                                  "8-clip parity: tests/test_fullsize_gpu.py (eval rows vs 8 oracle forwards, 3-clip train step)"
     # ---- the gate: the line is printed either way, but a run whose forward or whose typical gradient is outside
     #      north_star's 1e-3 exits non-zero (bwd_max_rel_err is reported, not gated: single ill-conditioned parameters —
     #      DESIGN "Parity" — sit at the tolerance on the oracle's own fp32-vs-fp64 error)
     gate = []
     if rank == 0:
+        # (the trained state is gated against the fp64 run: there the fp32 oracle's own noise reaches the tolerance)
         for k, lim in (("fwd_max_rel_err", 1e-3), ("fwd_logits_max_rel_err", 1e-3), ("bwd_median_rel_err", 1e-3),
-                       ("bwd_median_rel_err_after_steps", 1e-3), ("fwd_logits_max_rel_err_after_steps", 1e-3)):
+                       ("bwd_median_rel_err_vs_fp64", 1e-3), ("fwd_logits_max_rel_err_after_steps", 1e-3),
+                       ("bwd_median_rel_err_vs_fp64_after_steps" if "bwd_median_rel_err_vs_fp64_after_steps" in res
+                        else "bwd_median_rel_err_after_steps", 1e-3)):
             if k in res and not (res[k] <= lim):
                 gate.append("%s = %.3e > %.0e" % (k, res[k], lim))
         res["parity_gate"] = "pass" if not gate else "FAIL: " + "; ".join(gate)

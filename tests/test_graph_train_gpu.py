@@ -122,7 +122,7 @@ def test_eval_after_replays_sees_the_trained_weights():
         xs = bench.synthetic_clips(cfg, 2, dev, 11)
         labels = torch.randint(0, cfg.MODEL.NUM_CLASSES, (2,), device=dev,
                                generator=torch.Generator(device=dev).manual_seed(3))
-        step, flat, opt = bench.make_train_step(model, xs, labels, overlap_allreduce=False, lr=0.05)
+        step, flat, opt = bench.make_train_step(model, xs, labels, overlap_allreduce=False, lr=0.002)
         side = torch.cuda.Stream()
         with torch.cuda.stream(side):
             for _ in range(3):
