@@ -147,7 +147,8 @@ def cpu_baseline(workload, cfg, model, train, device=None, hip_train_step=None, 
             import _masks
             with _masks.capture() as masks:
                 loss, logits, grads = hip_train_step([x.to(device) for x in xs], label.to(device))
-            with _masks.inject(masks):
+            m32 = masks.fork()   # (a replay cursor: every oracle run starts from the first captured layer)
+            with _masks.inject(m32):
                 iteration(keep_grads=True)
             rl = keep["logits"]
             parity["fwd_logits_max_rel_err"] = float((logits.cpu() - rl).abs().max() / rl.abs().max())
@@ -171,16 +172,18 @@ def cpu_baseline(workload, cfg, model, train, device=None, hip_train_step=None, 
             parity["bwd_median_rel_err"] = errs[len(errs) // 2][0]
             parity["bwd_worst_param"] = errs[-1][1]
             parity["bwd_params_compared"] = len(errs)
-            parity["bwd_masks_injected"] = {"relu": masks.used, "max_pool": masks.pool_used,
-                                            "missed": len(masks.missed)}
+            parity["bwd_masks_injected"] = {"relu": m32.used, "max_pool": m32.pool_used,
+                                            "missed": len(m32.missed)}
             # the same step once more with the oracle in fp64 (same clip, parameters, masks): what the fp32 oracle itself
             # is off by — the reference's own rounding noise, the floor of every number above (profiles/
             # r06_oracle_conditioning_dual.txt: median 2.3e-4, 9.9e-4 on s4_fuse's key conv) — and the HIP gradients
             # against that (near-)exact result, parameter by parameter
             if os.environ.get("SF_BENCH_FP64_CHECK", "1") != "0":
                 g32 = keep["grads"]
-                with _masks.inject(masks):
+                m64 = masks.fork()
+                with _masks.inject(m64):
                     iteration(keep_grads=True, dtype=torch.float64)
+                parity["fp64_masks_injected"] = {"relu": m64.used, "max_pool": m64.pool_used, "missed": len(m64.missed)}
                 g64 = keep["grads"]
                 e_hip, e_ref = [], []
                 for k, g in g64.items():

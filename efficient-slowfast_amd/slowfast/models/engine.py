@@ -420,6 +420,19 @@ def _record_conv(x, conv_weight, conv_bias, wp_shape, gsrc, kernel, stride, padd
 _PCACHE = {}
 
 
+# Parameter-derived tensors (packed weights, their planes, folded BN ...) that a hipGraph capture has read or written.
+# They are allocated EAGERLY (outside the graph's private pool) and live in per-parameter caches; an eager forward after
+# the capture that finds them stale (an eval pass between replays) replaces the cache entry, and without this table
+# the old tensors would go back to the allocator while the graph still reads and re-packs into them on every replay.
+_CAPTURE_KEEP = {}
+
+
+def _keep_if_capturing(obj):
+    if getattr(_tls, "capturing", False):
+        _CAPTURE_KEEP[id(obj)] = obj
+    return obj
+
+
 def _cached_t(tensor, slot, key, make):
     """cache keyed on a tensor (parameters are not nn.Modules).  The entry lives ON the tensor object, so it dies
     with it: a global table keyed by id() would hand a new parameter that re-uses a freed one's id, address and
@@ -430,7 +443,7 @@ def _cached_t(tensor, slot, key, make):
         with torch.no_grad():
             c = (key, make())
         store[slot] = c
-    return c[1]
+    return _keep_if_capturing(c[1])
 
 
 # Everything derived from parameters (packed conv weights and their bf16 planes, folded BN affines, q/k/v stacks, ...)
@@ -478,7 +491,7 @@ def _cached(mod, slot, key, make):
         with torch.no_grad():
             c = (key, make())
         mod.__dict__[slot] = c
-    return c[1]
+    return _keep_if_capturing(c[1])
 
 
 def check_bn(bn):
@@ -699,7 +712,7 @@ def repack_all(model):
     with torch.no_grad():
         new = sfhip.pack_conv_weight_pairs([w.detach() for w in stale], old)
     for w, o in zip(stale, new):
-        w.__dict__["_sf_cache"]["_sf_wpair"] = (_key(w), o)
+        w.__dict__["_sf_cache"]["_sf_wpair"] = (_key(w), _keep_if_capturing(o))
 
 
 def packed_weight(conv):
@@ -1057,6 +1070,8 @@ def run_model(model, x):
     else:
         serial = cached[1]
     outer_serial, _tls.serial = getattr(_tls, "serial", False), serial
+    outer_cap = getattr(_tls, "capturing", False)
+    _tls.capturing = bool(torch.cuda.is_available() and torch.cuda.is_current_stream_capturing())
     try:
         if model.training and torch.is_grad_enabled():
             if _GRAD_SINK and getattr(model, "_sf_ddp_wrapped", False):
@@ -1071,6 +1086,7 @@ def run_model(model, x):
         if x and hasattr(x[0], "device") and x[0].device.type == "cuda":
             join_pending(x[0].device)  # a fusion whose join was deferred and that no later region picked up
         _tls.serial = outer_serial
+        _tls.capturing = outer_cap
         counters, _NBT = _NBT, outer
         if counters:
             with torch.no_grad():

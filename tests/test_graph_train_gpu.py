@@ -154,6 +154,11 @@ def test_eval_after_replays_sees_the_trained_weights():
         want = evaluate()
         assert not torch.equal(before, want), "the steps must move the eval output"
 
+        # one eager step between the eval forward and the capture: the eval pass re-packed every conv weight one by one
+        # into fresh tensors, and the batched re-pack's device-side pointer table is rebuilt (a host-to-device copy,
+        # not capturable) the first time it sees them
+        with torch.cuda.stream(side):
+            step()
         restore()
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g, stream=side):
