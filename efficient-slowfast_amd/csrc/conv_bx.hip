@@ -148,7 +148,7 @@ __global__ __launch_bounds__(512, 2) void conv_bx_kernel(const BxArgs p) {
     return r * row_bytes + lchunk;
   };
   // B: BN = 256: wave w brings rows 32w .. 32w+31; BN = 128: waves 0..3 only
-  const bool b_loader = BN == 256 || wave < 4;
+  const bool b_loader = BN == 256 || wave < BN / 32;
   const int bn = n0 + 32 * wave + lrow;
   const unsigned kbytes = (unsigned)p.nk * (unsigned)BXC_ROWB;  // bytes of a weight row per plane
   const unsigned b_voff = (unsigned)((b_loader && bn < d.Cout) ? bn : d.Cout) * kbytes + lchunk;
@@ -404,7 +404,7 @@ __global__ __launch_bounds__(512, ST == 2 ? 4 : 2) void conv_pw_bx_kernel(const 
   // B loader (as conv_bx_kernel): BN = 256: wave w brings rows 32w .. 32w+31; BN = 128: waves 0..3 only
   const int lrow = lane >> 1;
   const unsigned lchunk = (unsigned)((lane & 1) ^ ((lrow >> 4) & 1)) * 16u;
-  const bool b_loader = BN == 256 || wave < 4;
+  const bool b_loader = BN == 256 || wave < BN / 32;
   const int bn = n0 + 32 * wave + lrow;
   const unsigned kbytes = (unsigned)p.nk * (unsigned)BXC_ROWB;
   const unsigned b_voff = (unsigned)((b_loader && bn < d.Cout) ? bn : d.Cout) * kbytes + lchunk;
@@ -935,7 +935,12 @@ bool pw_plan(const sf_conv_desc* d, PwPlan* pl, bool gate = true) {
   if (3L * (d->Cout + 1) * pl->nk * BXC_ROWB > 0xfffffff0L) return false;
   // 256 x 128 tiles on two LDS stages, two workgroups per CU (SF_PW_WIDE=1: 256 x 256 on three stages, one per CU)
   static const int wide = [] { const char* e = getenv("SF_PW_WIDE"); return e ? atoi(e) : 0; }();
-  pl->bn = (d->Cout >= 256 && wide) ? 256 : 128;
+  // 64-wide outputs (res2's 256 -> 64 / 72 -> 64 projections and the data gradients of its 64 -> 256 ones): 256 x 64
+  // tiles — the rows of a tile are read ONCE (one column block), 44 KB of LDS on two stages: SF_PW_64=0 keeps them on the
+  // f32 kernels
+  static const int n64 = [] { const char* e = getenv("SF_PW_64"); return e ? atoi(e) : 1; }();
+  pl->bn = (d->Cout >= 256 && wide) ? 256 : (d->Cout <= 64 ? 64 : 128);
+  if (pl->bn == 64 && !n64) return false;
   pl->nb_n = sf_cdiv(d->Cout, pl->bn);
   pl->tiles = sf_cdiv(M, BXC_BM) * pl->nb_n;
   if (gate && g_pw_enable < 2 && g_bx_enable < 2) {
@@ -949,8 +954,14 @@ bool pw_plan(const sf_conv_desc* d, PwPlan* pl, bool gate = true) {
     // stages — there is no split-K here, so few tiles with a long reduction lose: 1024 -> 256 at 12 544 rows, 98
     // tiles x 64 steps, 66 -> 88 us), never faster than its operands at ~4.5 TB/s; the f32 kernels run these layers
     // at ~95 TFLOP/s with half of their HBM time beside it.  64-wide outputs fill half a column block: left out.
-    if (d->Cout < 128) return false;
     const double mb = (double)M * (d->Cin + d->Cout) * 4e-6;
+    if (pl->bn == 64) {
+      // one column block: every row tile is read once; the layer is its operands' HBM time or its tiles' K steps
+      // (measured: tools/microbench/conv_pw_bench.py, profiles/r06_conv_pw64_ab.txt)
+      if (d->Cin < 128) return false;
+      return true;
+    }
+    if (d->Cout < 128) return false;
     double t_pw = 6.0 + (double)sf_cdiv(pl->tiles, 256) * pl->nk * 1.5;
     if (t_pw < mb / 4.5) t_pw = mb / 4.5;
     const double t_f32 = 6.0 + 2.0 * M * (double)d->Cin * d->Cout / 95e6 + 0.5 * mb / 4.5;
@@ -1103,6 +1114,7 @@ int sf_conv_pw_try(const sf_conv_desc* d, const float* in, const float* w_packed
   a.stats = stats;
   if (stats) *parts = (int)sf_cdiv(M, BXC_BM);
   if (pl.bn == 256) return launch_pw<256, 3>(a, pl.tiles, stream);
+  if (pl.bn == 64) return launch_pw<64, 2>(a, pl.tiles, stream);
   return launch_pw<128, 2>(a, pl.tiles, stream);
 }
 
@@ -1113,7 +1125,7 @@ extern "C" int sf_conv_fwd_pw(const sf_conv_desc* d, const float* in, const floa
                               float* out, float* ws, float* stats, int* parts, void* stream) {
   if (!d || !in || !w_packed || !out || !ws) return SF_EINVAL;
   const int rc = sf_conv_pw_try(d, in, w_packed, w_planes, scale, bias, res, out, ws, stats, parts, (hipStream_t)stream);
-  return rc == 1 ? SF_EINVAL : rc;
+  return rc == 1 ? SF_ENOTTAKEN : rc;
 }
 
 // workspace floats of sf_conv_fwd_bx: the planes the call has to make itself + the S partial tiles (0: shape not served)
@@ -1194,7 +1206,7 @@ extern "C" int sf_conv_fwd_bx(const sf_conv_desc* d, const float* in, const unsi
                               const float* bias, const float* res, float* out, float* ws, void* stream) {
   if (!d || !in || !w_packed || !out || !ws) return SF_EINVAL;
   const int rc = sf_conv_bx_try(d, in, in_planes, w_packed, w_planes, scale, bias, res, out, ws, (hipStream_t)stream);
-  return rc == 1 ? SF_EINVAL : rc;
+  return rc == 1 ? SF_ENOTTAKEN : rc;
 }
 
 // ---- weight gradient on the bf16 pipe ---------------------------------------------------------------------------------
@@ -1284,7 +1296,8 @@ extern "C" int sf_conv_wgrad_bx(const sf_conv_desc* d, const float* x, const uns
                                 int dz_cs, int dz_coff, const unsigned short* dz_planes, float* partial, float* ws,
                                 void* stream) {
   BxwPlan pl;
-  if (!d || !x || !dz || !partial || !ws || !bxw_plan(d, &pl)) return SF_EINVAL;
+  if (!d || !x || !dz || !partial || !ws) return SF_EINVAL;
+  if (!bxw_plan(d, &pl)) return SF_ENOTTAKEN;
   if (!sf_aligned16(x) || !sf_aligned16(dz) || !sf_aligned16(ws) || !sf_aligned16(partial) || (dz_cs % 4) || (dz_coff % 4))
     return SF_EALIGN;
   hipStream_t s = (hipStream_t)stream;

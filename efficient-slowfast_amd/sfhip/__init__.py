@@ -23,8 +23,9 @@ ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_SOFTMAX, ACT_HSIGMOID, ACT_RELU6 = 0, 1, 2,
 def _act(relu):
     """relu: False/True (ReLU) or 6 (ReLU6)."""
     return ACT_RELU6 if relu == 6 else (ACT_RELU if relu else ACT_NONE)
-SF_EINVAL, SF_EALIGN, SF_ELAUNCH = -1, -2, -3
-_ERR = {-1: "SF_EINVAL (inconsistent descriptor)", -2: "SF_EALIGN", -3: "SF_ELAUNCH (hip launch failed)"}
+SF_EINVAL, SF_EALIGN, SF_ELAUNCH, SF_ENOTTAKEN = -1, -2, -3, -4
+_ERR = {-1: "SF_EINVAL (inconsistent descriptor)", -2: "SF_EALIGN", -3: "SF_ELAUNCH (hip launch failed)",
+        -4: "SF_ENOTTAKEN (shape not served by this specialised entry point)"}
 
 
 class SfhipError(RuntimeError):
@@ -390,8 +391,8 @@ def _conv_launch(d, x_ptr, w_ptr, scale, bias, res_ptr, out_ptr, device, what, w
             ws = torch.empty((n,), dtype=torch.float32, device=device)
             rc = _traced(tag, lambda: lib().sf_conv_fwd_pw(ctypes.byref(d), x_ptr, w_ptr, _ptr(planes), scale, bias,
                                                            res_ptr, out_ptr, _ptr(ws), None, None, _stream()))
-            if rc not in (SF_EALIGN, SF_EINVAL):  # those two: refused before any launch -> the f32 kernels below
-                _check(rc, what)
+            if rc not in (SF_EALIGN, SF_ENOTTAKEN):  # those two: refused before any launch -> the f32 kernels below
+                _check(rc, what)      # (SF_EINVAL — a genuinely inconsistent descriptor or a null pointer — raises)
                 return
         if in_planes is None and keep is not None and x_act is not None and not BX_AF32 and \
                 lib().sf_conv_bx_ws_floats(ctypes.byref(d), 1, 1) > 0:
@@ -403,7 +404,7 @@ def _conv_launch(d, x_ptr, w_ptr, scale, bias, res_ptr, out_ptr, device, what, w
             rc = _traced(tag, lambda: lib().sf_conv_fwd_bx(ctypes.byref(d), x_ptr, _ptr(in_planes), w_ptr,
                                                            _ptr(planes), scale, bias, res_ptr, out_ptr, _ptr(ws),
                                                            _stream()))
-            if rc not in (SF_EALIGN, SF_EINVAL):
+            if rc not in (SF_EALIGN, SF_ENOTTAKEN):
                 _check(rc, what)
                 return
     n = lib().sf_conv_fwd_ws_floats(ctypes.byref(d)) if SPLIT_K else 0
@@ -487,6 +488,22 @@ def pack_conv_weight_pairs(weights, outs):
     key = tuple(r[:8] for r in recs)  # pointers AND dims: a freed buffer's address may come back with another shape
     dev = weights[0].device
     tab = _PACK_TABLES.get(dev)
+    if (tab is None or tab[0] != key) and torch.cuda.is_current_stream_capturing():
+        # a new pointer set while a hipGraph is being captured (e.g. the first training step after an eval pass re-packed
+        # the weights one by one): the device-side table would need a host-to-device copy, which a capture refuses —
+        # one launch per weight (and per plane set) instead, all of them capturable
+        for w, o in zip(weights, res):
+            cout, cin = w.shape[0], w.shape[1]
+            taps = w.shape[2] * w.shape[3] * w.shape[4]
+            _check(lib().sf_pack_conv_weight(_ptr(w), cout, cin, taps, _ptr(o[0]), o[0].shape[2], _ptr(o[1]),
+                                             o[1].shape[2], _stream()), "sf_pack_conv_weight")
+            for t in o:
+                pl = t.__dict__.get("_sf_bx")
+                if pl is not None:
+                    c = t.shape[1] * t.shape[2]
+                    _check(lib().sf_bx_split(_ptr(t), c, 0, t.shape[0], c, _ptr(pl), _stream()), "sf_bx_split")
+                t.__dict__.pop("_sf_classes", None)
+        return res
     if tab is None or tab[0] != key:
         raw = b"".join(struct.pack("<QQQiiiiiiqq", *r) for r in recs)
         items = torch.from_numpy(np.frombuffer(raw, dtype=np.uint8).copy()).to(dev)
@@ -899,7 +916,7 @@ def conv_wgrad(x, dz, cout, kernel, stride=(1, 1, 1), padding=(0, 0, 0), dilatio
         rc = _traced(("conv", dz.rows, kT * kH * kW * cin, cout), lambda: lib().sf_conv_wgrad_bx(
             ctypes.byref(d), x.ptr(), _ptr(x_planes), dz.ptr(), dz.cs, dz.coff, _ptr(dz_planes), _ptr(part), _ptr(ws),
             _stream()))
-        if rc in (SF_EALIGN, SF_EINVAL):  # a dz view the shape-only plan cannot see (odd channel offset / pitch)
+        if rc in (SF_EALIGN, SF_ENOTTAKEN):  # a dz view the shape-only plan cannot see (odd channel offset / pitch)
             nws = 0
         else:
             _check(rc, "sf_conv_wgrad_bx")

@@ -23,6 +23,9 @@ extern "C" {
 #define SF_EINVAL (-1)   /* inconsistent descriptor */
 #define SF_EALIGN (-2)   /* pointer / pitch alignment not supported by any kernel variant */
 #define SF_ELAUNCH (-3)  /* hipLaunch failed (hipGetLastError is left set) */
+#define SF_ENOTTAKEN (-4) /* a specialised entry point (sf_conv_fwd_pw / _bx, sf_conv_wgrad_bx) does not serve this shape
+                             or view: nothing was enqueued and the arguments are not at fault — call the general entry
+                             point (sf_conv_fwd_ws / sf_conv_wgrad) instead */
 
 #define SF_ACT_NONE 0
 #define SF_ACT_RELU 1
