@@ -577,6 +577,8 @@ int sf_conv_stem_fwd_try(const sf_conv_desc* d, const float* in, const float* w,
                          const float* bias, const float* res, float* out, hipStream_t stream);  // conv_stem.hip
 int sf_conv_small_try(const sf_conv_desc* d, const float* in, const float* w, const float* scale, const float* bias,
                       const float* res, float* out, hipStream_t stream, float* stats, int* stat_parts);  // conv_small.hip
+int sf_conv_rows_try(const sf_conv_desc* d, const float* in, const float* w, const float* scale, const float* bias,
+                     const float* res, float* out, hipStream_t stream, float* stats, int* stat_parts);   // conv_rows.hip
 
 static int conv_fwd_impl(const sf_conv_desc* d, const float* in, const float* w_packed, const float* scale,
                          const float* bias, const float* res, float* out, float* ws, void* stream,
@@ -599,6 +601,11 @@ static int conv_fwd_impl(const sf_conv_desc* d, const float* in, const float* w_
   }
   {  // the Fast pathway's stem: LDS-ring kernel instead of one L2 fetch per tap
     const int rc = sf_conv_stem_fwd_try(d, in, w_packed, scale, bias, res, out, (hipStream_t)stream);
+    if (rc != 1) return rc;
+  }
+  {  // small-channel stride-1 "same" layers (the Fast pathway, lateral / q|k|v projections) and their data gradients:
+     // whole rows through LDS, swapped-operand MFMAs, statistics in the epilogue (conv_rows.hip)
+    const int rc = sf_conv_rows_try(d, in, w_packed, scale, bias, res, out, (hipStream_t)stream, stats, stat_parts);
     if (rc != 1) return rc;
   }
   {  // the tiniest channel counts (8 -> 8 spatial layers of the Fast pathway): LDS-staged input, scalar-register weights, vector FMAs

@@ -1,0 +1,438 @@
+// conv_rows.hip — forward and data gradient of the small-channel stride-1 "same" convolutions (Cin <= 32 or Cout <= 32,
+// both <= 256 / 128): the Fast pathway's 1x1x1 / 3x1x1 / 1x3x3 layers, the lateral and q|k|v projections — gfx950.
+//
+//   out[m, co] = act(scale[co] * sum_tap sum_ci x[m + off(tap), ci] * W[co, tap, ci] + bias[co] + res[m, co])
+//
+// Replaces for these shapes nn.Conv3d of resnet_helper.py:182-223 at dim_inner 8 .. 64 (temp_kernel_size 3 on the Fast
+// pathway: custom_video_model_builder.py:155-162), wdf_attention_helper.py:21-29 (query / key / value convs) and their
+// autograd data gradients (desc.transposed: the same sum with mirrored offsets over the transposed pack).
+//
+// conv_wave.hip's per-wavefront implicit GEMM feeds every MFMA operand straight from L2 with 16-byte loads whose 64
+// lanes touch 16 different rows: with 8 .. 64-channel rows (32 .. 256 bytes) a 1 KiB wave-load is 16 partial cache
+// lines, every tap re-fetches its rows, and a 16-wide output tile gets ONE MFMA per fragment load — these layers ran at
+// 0.12 .. 0.45 of their operands' HBM time (profiles/r05_conv_per_shape.txt: 3.1 ms of forward + data gradient per step
+// against 0.84 ms).  Here, as in conv_wgrad_rows.hip, a workgroup owns a RUN of positions and walks it in stages of 64:
+//   * the stage's input rows — per kt ONE window of 64 (+ 2 halo, halo = W + 1 for 1x3x3) rows of <= 64 channels — arrive
+//     in LDS by direct-to-LDS buffer loads of whole contiguous rows (1 KiB per wave-instruction, no registers; rows
+//     outside the tensor read as zeros), double buffered; layers with 128 input channels take two channel blocks per
+//     position stage.  A row's 16-byte chunks are XOR-swizzled on the SOURCE address so that the 16 rows a quarter
+//     wavefront reads with ds_read_b128 land on 16 different bank groups;
+//   * the packed weights of the workgroup's <= 64 output channels sit in LDS for the whole launch (row pitch = 4 mod 64
+//     floats: conflict-free fragment reads);
+//   * operands SWAPPED (v_mfma_f32_16x16x4_f32, A = W[16 co][k], B = x^T[k][16 positions]): a lane's four accumulator
+//     registers are four consecutive output channels of one position = one 16-byte NDHWC store; the K index of the
+//     four MFMAs behind one pair of fragment reads is permuted (lane group g takes channels 16 q + 4 g + s at step s),
+//     so one ds_read_b128 per operand feeds four MFMAs;
+//   * taps that leave the clip in flat order (other row / frame / clip) are masked on the x operand by per-position
+//     validity bits the staging threads leave in LDS;
+//   * epilogue in registers: scale, bias, residual (which may BE the output: accumulating data gradients), activation,
+//     and — for training-mode forward convs — the BN batch statistics of what was stored, one [count, K, S1, S2] record
+//     per wavefront and channel quad in conv_wave.hip's format (K = the wavefront's first output row).
+#include "common.h"
+#include <stdlib.h>
+
+namespace {
+
+typedef __attribute__((address_space(3))) void lds_void;
+constexpr unsigned CR_OOB = 0x80000000u;
+constexpr int CR_L = 64;  // positions per stage: one 16-position MFMA column tile per wavefront
+
+struct CRowsArgs {
+  sf_conv_desc d;
+  const float* x;
+  const float* w;        // [Cout][ntaps][cin_pad]
+  const float* scale;
+  const float* bias;
+  const float* res;
+  float* out;
+  float* stats;          // [4 * S][Cout / 4][4][4] or NULL
+  int M, S, chunk;       // positions, workgroups along the positions, positions per workgroup (multiple of 64)
+  int KB;                // channel blocks of XW floats per position stage
+  int HW, halo, wrp;     // frame size, halo rows of a 1x3x3 window, rows of one x window in LDS
+  int wstride;           // floats per weight row in LDS
+  int sg;                // +1 forward, -1 data gradient (mirrored taps)
+  unsigned x_bytes;
+  unsigned w_mul, w_sh, h_mul, h_sh, t_mul, t_sh;
+};
+
+__device__ __forceinline__ unsigned cr_mdiv(unsigned n, unsigned mul, unsigned sh) {
+  return mul ? (__umulhi(n, mul) >> sh) : n;
+}
+
+// Swizzle of a row's 16-byte chunks: 16 consecutive rows read at the same chunk index must land on 16 different
+// 16-byte bank groups (the LDS serves 256 bytes per cycle).  XW floats per row = XW / 4 chunks.
+template <int XW>
+__device__ __forceinline__ int cr_swz(int row) {
+  if (XW == 8) return (row >> 3) & 1;
+  if (XW == 16) return (row >> 2) & 3;
+  if (XW == 32) return (row >> 1) & 7;
+  return row & 15;  // 64 floats: one row = one sweep of the banks
+}
+
+template <int NTAP, int XW, int NCT>
+__global__ __launch_bounds__(256) void conv_rows_kernel(const CRowsArgs p) {
+  constexpr int KT = (NTAP == 3) ? 3 : 1;
+  constexpr int BCO = 16 * NCT;
+  constexpr int NQ = XW >= 16 ? XW / 16 : 1;       // 16-channel chunks per row
+  constexpr int XSH = (XW == 8) ? 1 : (XW == 16 ? 2 : (XW == 32 ? 3 : 4));  // log2(chunks per row)
+  extern __shared__ __attribute__((aligned(16))) float cr_smem[];
+  const sf_conv_desc& d = p.d;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 15, g = lane >> 4;
+  const int co0 = blockIdx.y * BCO;
+  const int mb = blockIdx.x * p.chunk;
+  const int me = (mb + p.chunk < p.M) ? mb + p.chunk : p.M;
+  const int nps = (me > mb) ? (me - mb + CR_L - 1) / CR_L : 0;
+  const int KB = p.KB;
+  const int krow = NTAP * KB * XW;                 // floats of a weight row
+  const int win = p.wrp * XW;                      // floats of one x window
+  const int stage_floats = KT * win;
+  float* const Wl = cr_smem;
+  float* const stg = Wl + BCO * p.wstride;
+  unsigned* const vm = reinterpret_cast<unsigned*>(stg + 2 * stage_floats);  // [2][64]
+  const __amdgpu_buffer_rsrc_t x_rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
+  const int nxb = win >> 8;                        // 1 KiB pieces of one window
+  const int nblk = KT * nxb;
+
+  auto issue = [&](int st, int buf) {
+    const int ps = st / KB, cb = st - ps * KB;
+    const int m0 = mb + ps * CR_L;
+    float* const sb = stg + buf * stage_floats;
+    for (int b = wave; b < nblk; b += 4) {
+      const int kt = (KT == 1) ? 0 : b / nxb;
+      const int f = ((b - kt * nxb) << 6) + lane;  // 16-byte chunk index within the window
+      const int row = f >> XSH, slot = f - (row << XSH);
+      const int c = slot ^ cr_swz<XW>(row);
+      const int q = m0 + ((KT == 3) ? p.sg * (kt - 1) * p.HW : 0) - p.halo + row;
+      const int ch = cb * XW + 4 * c;
+      unsigned vo = CR_OOB;
+      if (q >= 0 && q < p.M && ch < d.Cin) vo = ((unsigned)q * (unsigned)d.in_cs + (unsigned)(d.in_coff + ch)) << 2;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rs, (lds_void*)(sb + (b << 8)), 16, vo, 0, 0, 0);
+    }
+    if (NTAP > 1 && cb == 0 && tid < CR_L) {  // which taps of position m0 + tid lie inside its clip
+      const unsigned m = (unsigned)(m0 + tid);
+      const unsigned q1 = cr_mdiv(m, p.w_mul, p.w_sh);
+      const int w = (int)(m - q1 * (unsigned)d.Wo);
+      const unsigned q2 = cr_mdiv(q1, p.h_mul, p.h_sh);
+      const int h = (int)(q1 - q2 * (unsigned)d.Ho);
+      const unsigned q3 = cr_mdiv(q2, p.t_mul, p.t_sh);
+      const int t = (int)(q2 - q3 * (unsigned)d.To);
+      unsigned bits = 0;
+      if (NTAP == 3) {
+#pragma unroll
+        for (int kt = 0; kt < 3; ++kt)
+          if ((unsigned)(t + p.sg * (kt - 1)) < (unsigned)d.To) bits |= 1u << kt;
+      } else {  // separable: bits 0..2 = row h + sg (kh - 1) inside, bits 4..6 = column w + sg (kw - 1) inside
+#pragma unroll
+        for (int kk = 0; kk < 3; ++kk) {
+          if ((unsigned)(h + p.sg * (kk - 1)) < (unsigned)d.Ho) bits |= 1u << kk;
+          if ((unsigned)(w + p.sg * (kk - 1)) < (unsigned)d.Wo) bits |= 16u << kk;
+        }
+      }
+      vm[(ps & 1) * CR_L + tid] = bits;
+    }
+  };
+
+  // ---- the workgroup's weights: rows co0 .. co0 + BCO - 1, [tap][KB * XW channels] each, zero where the layer ends
+  //      (the pad behind a row is zero-filled too: with 8-channel rows lane groups 2 and 3 read past a tap's channels,
+  //      and what they read is multiplied by zeros — it must be finite)
+  {
+    const int r4 = p.wstride >> 2;
+    for (int idx = tid; idx < BCO * r4; idx += 256) {
+      const int r = idx / r4, e = (idx - r * r4) << 2;
+      const int tap = e / (KB * XW), c = e - tap * (KB * XW);
+      const int co = co0 + r;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (e < krow && co < d.Cout && c + 3 < d.cin_pad)
+        v = *reinterpret_cast<const f32x4*>(p.w + ((long)co * NTAP + tap) * d.cin_pad + c);
+      *reinterpret_cast<f32x4*>(Wl + r * p.wstride + e) = v;
+    }
+  }
+
+  f32x4 acc[NCT], acc2[NCT];  // two chains per tile (K steps s = 0, 2 / 1, 3): no MFMA waits for the one in front of it
+  // statistics (per lane: the four channels co0 + 16 ct + 4 g .. + 3, its positions j of every stage)
+  f32x4 sk[NCT], s1[NCT], s2[NCT];
+  float cnt = 0.f;
+  bool have_k = false;
+#pragma unroll
+  for (int ct = 0; ct < NCT; ++ct) {
+    sk[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    s1[ct] = sk[ct];
+    s2[ct] = sk[ct];
+  }
+
+  const int nst = nps * KB;
+  if (nst > 0) issue(0, 0);
+  for (int st = 0; st < nst; ++st) {
+    const int buf = st & 1;
+    const int ps = st / KB, cb = st - ps * KB;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this thread's pieces of step st have landed ...
+    __syncthreads();                                   // ... and everybody's (and the weights); buffer buf ^ 1 is free
+    if (st + 1 < nst) issue(st + 1, buf ^ 1);
+    if (cb == 0) {
+#pragma unroll
+      for (int ct = 0; ct < NCT; ++ct) {
+        acc[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        acc2[ct] = acc[ct];
+      }
+    }
+    const float* const xs = stg + buf * stage_floats;
+    const unsigned vb = (NTAP > 1) ? vm[(ps & 1) * CR_L + 16 * wave + j] : 0u;
+    const float* const wl = Wl + j * p.wstride + cb * XW + 4 * g;
+#pragma unroll
+    for (int tap = 0; tap < NTAP; ++tap) {
+      int R;
+      bool ok = true;
+      const float* xw;
+      if (NTAP == 9) {
+        const int kh = tap / 3, kw = tap - 3 * kh;
+        R = p.halo + 16 * wave + j + p.sg * ((kh - 1) * d.Wi + (kw - 1));
+        ok = ((vb >> kh) & 1u) && ((vb >> (4 + kw)) & 1u);
+        xw = xs;
+      } else if (NTAP == 3) {
+        R = 16 * wave + j;
+        ok = (vb >> tap) & 1u;
+        xw = xs + tap * win;
+      } else {
+        R = 16 * wave + j;
+        xw = xs;
+      }
+      const int sw = cr_swz<XW>(R);
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        const int c = 4 * q + g;
+        f32x4 b = {0.f, 0.f, 0.f, 0.f};
+        if (ok && (XW >= 16 || g < XW / 4)) b = *reinterpret_cast<const f32x4*>(xw + R * XW + ((c ^ sw) << 2));
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) {
+          const f32x4 a = *reinterpret_cast<const f32x4*>(wl + (16 * ct) * p.wstride + tap * (KB * XW) + 16 * q);
+          acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], b[0], acc[ct], 0, 0, 0);
+          acc2[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], b[1], acc2[ct], 0, 0, 0);
+          acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], b[2], acc[ct], 0, 0, 0);
+          acc2[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], b[3], acc2[ct], 0, 0, 0);
+        }
+      }
+    }
+    if (cb != KB - 1) continue;
+    // ---- epilogue of position stage ps: lane = position m0 + 16 wave + j, channels co0 + 16 ct + 4 g .. + 3
+    const int m = mb + ps * CR_L + 16 * wave + j;
+    const bool mok = m < me;
+    const int m_first = mb + ps * CR_L + 16 * wave;  // this wavefront's first position of the stage (lane j = 0)
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) {
+      const int n = co0 + 16 * ct + 4 * g;
+      const bool nok = n < d.Cout;
+      f32x4 v = acc[ct] + acc2[ct];
+      if (nok) {
+        if (p.scale) v *= *reinterpret_cast<const f32x4*>(p.scale + n);
+        if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
+      }
+      if (mok && nok) {
+        if (p.res) v += *reinterpret_cast<const f32x4*>(p.res + (long)m * d.res_cs + d.res_coff + n);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = sf_act(v[r], d.act);
+        *reinterpret_cast<f32x4*>(p.out + (long)m * d.out_cs + d.out_coff + n) = v;
+      }
+      if (p.stats) {
+        if (!have_k && m_first < me) {  // K = the wavefront's first output row (a sample of the channel)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) sk[ct][r] = __shfl(v[r], lane & 48, 64);
+        }
+        if (mok) {
+          const f32x4 dv = v - sk[ct];
+          s1[ct] += dv;
+          s2[ct] += dv * dv;
+        }
+      }
+    }
+    if (p.stats) {
+      if (m_first < me) have_k = true;
+      if (mok) cnt += 1.f;
+    }
+  }
+
+  if (p.stats) {
+#pragma unroll
+    for (int off = 1; off < 16; off <<= 1) {
+      cnt += __shfl_xor(cnt, off, 64);
+#pragma unroll
+      for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          s1[ct][r] += __shfl_xor(s1[ct][r], off, 64);
+          s2[ct][r] += __shfl_xor(s2[ct][r], off, 64);
+        }
+    }
+    if (j == 0) {
+      const long part = (long)blockIdx.x * 4 + wave;
+#pragma unroll
+      for (int ct = 0; ct < NCT; ++ct) {
+        const int n = co0 + 16 * ct + 4 * g;
+        if (n < d.Cout) {
+          float* const o = p.stats + (part * (d.Cout >> 2) + (n >> 2)) * 16;
+          *reinterpret_cast<f32x4*>(o) = (f32x4){cnt, cnt, cnt, cnt};
+          *reinterpret_cast<f32x4*>(o + 4) = sk[ct];
+          *reinterpret_cast<f32x4*>(o + 8) = s1[ct];
+          *reinterpret_cast<f32x4*>(o + 12) = s2[ct];
+        }
+      }
+    }
+  }
+}
+
+void cr_magic(unsigned dv, unsigned* mul, unsigned* sh) {
+  if (dv <= 1) { *mul = 0; *sh = 0; return; }
+  unsigned l = 0;
+  while ((1u << l) < dv) ++l;
+  const unsigned long long num = 1ull << (31 + l);
+  *mul = (unsigned)((num + dv - 1) / dv);
+  *sh = l - 1;
+}
+
+int g_crows_enable = 1;  // sf_conv_tune(22, e): 0 off, 1 by rule, 2 every shape the kernel covers
+
+int crows_level() {
+  static const int env = [] {
+    const char* e = getenv("SF_CONV_ROWS");
+    return e ? atoi(e) : 1;
+  }();
+  return g_crows_enable == 1 ? env : g_crows_enable;
+}
+
+struct CRowsPlan { int ntap, xw, nct, nby; size_t lds; };
+
+// Geometry + schedule for a problem this kernel covers; false = leave it to the other dense kernels.
+bool crows_plan(const sf_conv_desc* d, CRowsArgs* a, CRowsPlan* pl) {
+  const int level = crows_level();
+  if (level <= 0) return false;
+  if (d->sT != 1 || d->sH != 1 || d->sW != 1 || d->dT != 1 || d->dH != 1 || d->dW != 1) return false;
+  if (d->To != d->Ti || d->Ho != d->Hi || d->Wo != d->Wi) return false;
+  if (d->out_cmul != 1 || d->os_T > 1 || d->os_H > 1 || d->os_W > 1) return false;
+  int ntap;
+  if (d->kT == 1 && d->kH == 1 && d->kW == 1 && d->pT == 0 && d->pH == 0 && d->pW == 0) ntap = 1;
+  else if (d->kT == 3 && d->kH == 1 && d->kW == 1 && d->pT == 1 && d->pH == 0 && d->pW == 0) ntap = 3;
+  else if (d->kT == 1 && d->kH == 3 && d->kW == 3 && d->pT == 0 && d->pH == 1 && d->pW == 1) ntap = 9;
+  else return false;
+  if (d->Cin > 32 && d->Cout > 32) return false;       // both wide: conv_wave / conv_bx / conv_pw_bx
+  if (d->Cin < 8 || d->Cout < 8 || d->Cin > 128 || d->Cout > 256) return false;
+  if (ntap == 9 && d->Cin > 32) return false;           // (a 1x3x3 window of wide rows would not fit beside the weights)
+  if (d->Cin % 4 || d->in_cs % 4 || d->in_coff % 4 || d->Cout % 4 || d->out_cs % 4 || d->out_coff % 4) return false;
+  if (d->cin_pad % 4) return false;
+  if (d->act != SF_ACT_NONE && d->act != SF_ACT_RELU && d->act != SF_ACT_RELU6) return false;
+  const long M = (long)d->N * d->To * d->Ho * d->Wo;
+  if (M < 4096 || M > 0x3fffffffL) return false;
+  const long xb = ((M - 1) * d->in_cs + d->in_coff + d->Cin) * 4L;
+  if (xb >= 0x7fffffffL) return false;
+  // 8 -> 8 spatial layers: conv_small.hip (vector FMAs from an LDS halo tile) unless forced
+  if (level < 2 && d->Cin <= 8 && d->Cout <= 8 && ntap == 9) return false;
+  int xw = 8;
+  while (xw < d->Cin && xw < 64) xw <<= 1;
+  a->d = *d;
+  a->M = (int)M;
+  a->x_bytes = (unsigned)xb;
+  a->KB = sf_cdiv(d->Cin, xw);
+  a->HW = d->Hi * d->Wi;
+  a->halo = (ntap == 9) ? d->Wi + 1 : 0;
+  const int gran = 256 / xw;  // window rows per 1 KiB piece
+  a->wrp = (CR_L + 2 * a->halo + gran - 1) / gran * gran;
+  const int nct = d->Cout <= 16 ? 1 : (d->Cout <= 32 ? 2 : 4);
+  if (xw > 32 && nct > 2) return false;
+  const int krow = ntap * a->KB * xw;
+  a->wstride = (krow + 63) / 64 * 64 + 4;  // = 4 (mod 64) floats: 16 consecutive rows on 16 different bank groups
+  a->sg = d->transposed ? -1 : 1;
+  const int KT = ntap == 3 ? 3 : 1;
+  pl->lds = ((size_t)16 * nct * a->wstride + 2 * (size_t)KT * a->wrp * xw + 2 * CR_L) * sizeof(float);
+  if (pl->lds > 150 * 1024) return false;
+  pl->ntap = ntap; pl->xw = xw; pl->nct = nct; pl->nby = sf_cdiv(d->Cout, 16 * nct);
+  cr_magic((unsigned)d->Wo, &a->w_mul, &a->w_sh);
+  cr_magic((unsigned)d->Ho, &a->h_mul, &a->h_sh);
+  cr_magic((unsigned)d->To, &a->t_mul, &a->t_sh);
+  // workgroups along the positions: ~1024 over the channel blocks, at least two stages each, at most 1024 (the
+  // statistics workspace holds >= 4096 records per channel: four per workgroup)
+  const long stages = (M + CR_L - 1) / CR_L;
+  long S = 1024 / pl->nby;
+  if (S > (stages + 1) / 2) S = (stages + 1) / 2;
+  if (S < 1) S = 1;
+  long chunk = ((M + S - 1) / S + CR_L - 1) / CR_L * CR_L;
+  S = (M + chunk - 1) / chunk;
+  a->S = (int)S;
+  a->chunk = (int)chunk;
+  return true;
+}
+
+template <int NTAP, int XW, int NCT>
+int launch_crows(const CRowsArgs& a, const CRowsPlan& pl, hipStream_t s) {
+  static SfLdsAttr attr;
+  if (!sf_ensure_dyn_lds(attr, reinterpret_cast<const void*>(conv_rows_kernel<NTAP, XW, NCT>), 152 * 1024))
+    return SF_ELAUNCH;
+  hipLaunchKernelGGL((conv_rows_kernel<NTAP, XW, NCT>), dim3(a.S, pl.nby), dim3(256), pl.lds, s, a);
+  SF_CHECK_LAUNCH();
+  return SF_OK;
+}
+
+template <int NTAP, int XW>
+int launch_crows_ct(const CRowsArgs& a, const CRowsPlan& pl, hipStream_t s) {
+  if (pl.nct == 1) return launch_crows<NTAP, XW, 1>(a, pl, s);
+  if (pl.nct == 2) return launch_crows<NTAP, XW, 2>(a, pl, s);
+  if constexpr (XW <= 32) return launch_crows<NTAP, XW, 4>(a, pl, s);
+  return 1;
+}
+
+template <int NTAP>
+int launch_crows_xw(const CRowsArgs& a, const CRowsPlan& pl, hipStream_t s) {
+  if (pl.xw == 8) return launch_crows_ct<NTAP, 8>(a, pl, s);
+  if (pl.xw == 16) return launch_crows_ct<NTAP, 16>(a, pl, s);
+  if (pl.xw == 32) return launch_crows_ct<NTAP, 32>(a, pl, s);
+  if constexpr (NTAP != 9) return launch_crows_ct<NTAP, 64>(a, pl, s);
+  return 1;
+}
+
+}  // namespace
+
+int sf_conv_rows_tune(int value) {
+  if (value < 0 || value > 2) return SF_EINVAL;
+  g_crows_enable = value;
+  return SF_OK;
+}
+
+// Shape-only decision; *parts = statistics records per channel the launch leaves (4 per workgroup).
+int sf_conv_rows_takes(const sf_conv_desc* d, int* parts) {
+  CRowsArgs a;
+  CRowsPlan pl;
+  if (parts) *parts = 0;
+  if (!crows_plan(d, &a, &pl)) return 0;
+  if (parts) *parts = 4 * a.S;
+  return 1;
+}
+
+extern "C" int sf_conv_rows_parts(const sf_conv_desc* d) {
+  int parts = 0;
+  return (d && sf_conv_rows_takes(d, &parts)) ? parts : 0;
+}
+
+long sf_conv_wave_max_parts(long M);  // conv_wave.hip: what sf_conv_stats_ws_floats sized the statistics rows for
+
+// Returns 1 when the shape is not taken (the caller goes on to its other kernels), else SF_OK / an error code.
+int sf_conv_rows_try(const sf_conv_desc* d, const float* in, const float* w_packed, const float* scale,
+                     const float* bias, const float* res, float* out, hipStream_t stream, float* stats,
+                     int* stat_parts) {
+  if (stat_parts) *stat_parts = 0;
+  CRowsArgs a;
+  CRowsPlan pl;
+  if (!crows_plan(d, &a, &pl)) return 1;
+  if (!sf_aligned16(in) || !sf_aligned16(out) || !sf_aligned16(w_packed)) return 1;
+  if ((scale && !sf_aligned16(scale)) || (bias && !sf_aligned16(bias))) return 1;
+  if (res && ((d->res_cs % 4) || (d->res_coff % 4) || !sf_aligned16(res))) return 1;
+  a.x = in; a.w = w_packed; a.scale = scale; a.bias = bias; a.res = res; a.out = out;
+  const bool want = stats && stat_parts && !scale && !res && d->act == SF_ACT_NONE && !d->transposed &&
+                    sf_aligned16(stats) && 4L * a.S <= sf_conv_wave_max_parts(a.M);
+  a.stats = want ? stats : nullptr;
+  if (want) *stat_parts = 4 * a.S;
+  int rc;
+  if (pl.ntap == 1) rc = launch_crows_xw<1>(a, pl, stream);
+  else if (pl.ntap == 3) rc = launch_crows_xw<3>(a, pl, stream);
+  else rc = launch_crows_xw<9>(a, pl, stream);
+  if (rc != SF_OK && stat_parts) *stat_parts = 0;
+  return rc;
+}

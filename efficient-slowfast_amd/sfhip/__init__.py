@@ -58,7 +58,7 @@ EXPORTS = [
     "sf_conv_fwd_ws", "sf_attn_fwd_ws_floats", "sf_attn_fwd_ws", "sf_affine_fwd_mask", "sf_bn_bwd_apply_first", "sf_maxpool_bwd_first",
     "sf_conv_tune", "sf_conv_stats_ws_floats", "sf_conv_fwd_stats", "sf_bn_train_stats_merge",
     "sf_attn_products_per_fp32", "sf_pack_conv_weights", "sf_attn_bwd_variant", "sf_attn_tune",
-    "sf_bx_planes_elems", "sf_bx_split", "sf_bx_split_batched", "sf_conv_pw_ws_floats", "sf_conv_pw_stats_floats", "sf_conv_fwd_pw", "sf_conv_bx_ws_floats", "sf_conv_fwd_bx", "sf_conv_wgrad_bx_splits",
+    "sf_bx_planes_elems", "sf_bx_split", "sf_bx_split_batched", "sf_conv_rows_parts", "sf_conv_pw_ws_floats", "sf_conv_pw_stats_floats", "sf_conv_fwd_pw", "sf_conv_bx_ws_floats", "sf_conv_fwd_bx", "sf_conv_wgrad_bx_splits",
     "sf_conv_wgrad_bx_ws_floats", "sf_conv_wgrad_bx",
     "sf_conv_fwd_grouped", "sf_conv_wgrad_grouped_splits", "sf_conv_wgrad_grouped", "sf_channel_shuffle",
     "sf_dwconv_wgrad_param",
@@ -158,6 +158,7 @@ def lib():
         L.sf_bx_split_batched.argtypes = [vp, vp, ci, ci, vp]
         L.sf_conv_pw_ws_floats.argtypes = [ctypes.POINTER(ConvDesc), ci]
         L.sf_conv_pw_ws_floats.restype = cl
+        L.sf_conv_rows_parts.argtypes = [ctypes.POINTER(ConvDesc)]
         L.sf_conv_pw_stats_floats.argtypes = [ctypes.POINTER(ConvDesc)]
         L.sf_conv_pw_stats_floats.restype = cl
         L.sf_conv_fwd_pw.argtypes = [ctypes.POINTER(ConvDesc)] + [vp] * 9 + [ctypes.POINTER(ctypes.c_int), vp]

@@ -136,6 +136,13 @@ int sf_bx_split(const float* x, int cs, int coff, long rows, int C, unsigned sho
  * records {const float* x; uint16_t* planes; int64_t rows; int32_t C; int32_t 0}; blk0[i] = first workgroup of item i
  * (a workgroup = 256 elements of 8 channels over (rows + 1) * C / 8), blk0[n] = nblocks.                           */
 int sf_bx_split_batched(const void* items, const int* blk0, int n, int nblocks, void* stream);
+/* Small-channel stride-1 "same" layers (Cin <= 32 or Cout <= 32; 1x1x1, 3x1x1, 1x3x3 — the Fast pathway's convs of
+ * resnet_helper.py:182-223, the lateral and query / key / value projections) and, with desc.transposed, their data
+ * gradients: conv_rows.hip (whole rows through LDS, swapped-operand MFMAs, BN statistics in the epilogue).  sf_conv_fwd
+ * / sf_conv_fwd_stats route there by themselves; sf_conv_rows_parts = the statistics records per channel such a launch
+ * leaves (4 per workgroup; 0: the shape is not served).  sf_conv_tune(22, 0 | 1 | 2) = off / by rule / every shape the
+ * kernel covers.                                                                                                     */
+int sf_conv_rows_parts(const sf_conv_desc* d);
 /* Pointwise layers — 1x1x1 stride-1 convs with >= 64 channels on both sides, forward and (desc.transposed) data
  * gradient: nn.Conv3d branch2a / branch2c of resnet_helper.py:182-223 — on the bf16 matrix pipe with the ACTIVATIONS
  * split in registers (no activation planes; conv_bx.hip conv_pw_bx_kernel).  sf_conv_pw_ws_floats: workspace floats

@@ -143,7 +143,10 @@ def test_launch_planning_queries_are_host_only_and_fill_the_chip():
     assert L.sf_conv_pw_ws_floats(ctypes.byref(dp), 1) == 4 and L.sf_conv_pw_ws_floats(ctypes.byref(dp), 0) == 4 + wpl
     assert L.sf_conv_fwd_ws_floats(ctypes.byref(dp)) == 4 + wpl
     assert L.sf_conv_pw_stats_floats(ctypes.byref(dp)) == 49 * 4 * 1024 and L.sf_conv_stats_ws_floats(ctypes.byref(dp)) == 0
-    assert L.sf_conv_pw_ws_floats(ctypes.byref(_conv_desc(8, 8, 56, 56, 256, 64, (1, 1, 1))), 1) == 0
+    # round 6: 64-wide outputs over >= 128 input channels take the 256 x 64 tile (conv_pw_bx_kernel<64, 2>); short
+    # reductions into 64 channels stay on the f32 kernels
+    assert L.sf_conv_pw_ws_floats(ctypes.byref(_conv_desc(8, 8, 56, 56, 256, 64, (1, 1, 1))), 1) == 4
+    assert L.sf_conv_pw_ws_floats(ctypes.byref(_conv_desc(8, 8, 56, 56, 64, 64, (1, 1, 1))), 1) == 0
     dt = _conv_desc(8, 8, 14, 14, 1024, 256, (1, 1, 1))
     dt.transposed = 1
     assert L.sf_conv_pw_ws_floats(ctypes.byref(dt), 1) == 0

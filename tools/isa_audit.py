@@ -21,7 +21,7 @@ import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "efficient-slowfast_amd", "csrc")
-HOT = ("conv_bx_kernel", "conv_pw_bx_kernel", "conv_bx_wgrad_kernel", "conv_wave_kernel", "conv_wgrad_wave_kernel",
+HOT = ("conv_rows_kernel", "conv_bx_kernel", "conv_pw_bx_kernel", "conv_bx_wgrad_kernel", "conv_wave_kernel", "conv_wgrad_wave_kernel",
        "attn_bwd_bx_kernel", "attn_bwd_bxp_kernel", "attn_bwd_bx2_kernel", "attn_fwd_bx_kernel", "attn_fwd_bxp_kernel",
        "attn_fwd_bx2_kernel", "conv_stem", "conv_wgrad_stem", "conv_wgrad_rows_kernel", "bn_bwd_", "affine_flat")
 # kernels that are allowed scratch (not launched by default / debug variants)
