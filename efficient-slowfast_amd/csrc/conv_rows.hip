@@ -69,12 +69,37 @@ __device__ __forceinline__ int cr_swz(int row) {
   return row & 15;  // 64 floats: one row = one sweep of the banks
 }
 
-template <int NTAP, int XW, int NCT>
+// ds_read_b128 as an instruction the compiler does not look into: its waitcnt pass drains vmcnt in front of every LDS
+// access that may read what an outstanding LDS-DMA writes, which would serialise the next step's loads with this step's
+// MFMAs.  The caller owns lgkmcnt: the data is there after cr_wait<N>() with N = LDS reads issued behind this one.
+__device__ __forceinline__ f32x4 cr_lds128(unsigned lds_byte_addr) {
+  f32x4 r;
+  asm volatile("ds_read_b128 %0, %1" : "=v"(r) : "v"(lds_byte_addr));
+  return r;
+}
+
+// One (tap, 16-channel chunk) of operands: the x fragment and the NCT weight fragments behind it.
+template <int NCT> struct CrFrag { f32x4 b; f32x4 a[NCT]; };
+
+// Wait until at most N LDS reads are outstanding; every register of `f` is an operand, so no MFMA on them can be
+// scheduled in front of the wait.
+template <int N, int NCT>
+__device__ __forceinline__ void cr_wait(CrFrag<NCT>& f) {
+  if constexpr (NCT == 1) asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(f.b), "+v"(f.a[0]) : "n"(N));
+  else if constexpr (NCT == 2) asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(f.b), "+v"(f.a[0]), "+v"(f.a[1]) : "n"(N));
+  else asm volatile("s_waitcnt lgkmcnt(%5)" : "+v"(f.b), "+v"(f.a[0]), "+v"(f.a[1]), "+v"(f.a[2]), "+v"(f.a[3]) : "n"(N));
+}
+
+// WPS: windows (kt taps) of a 3x1x1 layer staged per step — 3 for rows of <= 32 floats, 1 for 64-float rows.
+// RES: a residual operand exists (eval-mode shortcuts, accumulating data gradients).  Compile-time: its loads make the
+// compiler wait for vmcnt(0) in the epilogue — for the NEXT step's LDS-DMA loads too — whether or not they execute.
+template <int NTAP, int XW, int NCT, int WPS, bool RES>
 __global__ __launch_bounds__(256) void conv_rows_kernel(const CRowsArgs p) {
-  constexpr int KT = (NTAP == 3) ? 3 : 1;
   constexpr int BCO = 16 * NCT;
   constexpr int NQ = XW >= 16 ? XW / 16 : 1;       // 16-channel chunks per row
   constexpr int XSH = (XW == 8) ? 1 : (XW == 16 ? 2 : (XW == 32 ? 3 : 4));  // log2(chunks per row)
+  constexpr int TPS = (NTAP == 9) ? 9 : WPS;       // taps multiplied per step
+  constexpr int NI = TPS * NQ;                     // operand items per step
   extern __shared__ __attribute__((aligned(16))) float cr_smem[];
   const sf_conv_desc& d = p.d;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -85,32 +110,24 @@ __global__ __launch_bounds__(256) void conv_rows_kernel(const CRowsArgs p) {
   const int me = (mb + p.chunk < p.M) ? mb + p.chunk : p.M;
   const int nps = (me > mb) ? (me - mb + CR_L - 1) / CR_L : 0;
   const int KB = p.KB;
+  const int SPP = ((NTAP == 3) ? 3 / WPS : 1) * KB;  // steps per position stage: (window group, channel block)
   const int krow = NTAP * KB * XW;                 // floats of a weight row
   const int win = p.wrp * XW;                      // floats of one x window
-  const int stage_floats = KT * win;
+  const int stage_floats = WPS * win;
   float* const Wl = cr_smem;
   float* const stg = Wl + BCO * p.wstride;
   unsigned* const vm = reinterpret_cast<unsigned*>(stg + 2 * stage_floats);  // [2][64]
+  const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)cr_smem;
   const __amdgpu_buffer_rsrc_t x_rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
   const int nxb = win >> 8;                        // 1 KiB pieces of one window
-  const int nblk = KT * nxb;
+  const int nblk = WPS * nxb;
 
   auto issue = [&](int st, int buf) {
-    const int ps = st / KB, cb = st - ps * KB;
+    const int ps = st / SPP, r0 = st - ps * SPP;
+    const int wg0 = r0 / KB, cb = r0 - wg0 * KB;   // first window (kt) of the step, channel block
     const int m0 = mb + ps * CR_L;
     float* const sb = stg + buf * stage_floats;
-    for (int b = wave; b < nblk; b += 4) {
-      const int kt = (KT == 1) ? 0 : b / nxb;
-      const int f = ((b - kt * nxb) << 6) + lane;  // 16-byte chunk index within the window
-      const int row = f >> XSH, slot = f - (row << XSH);
-      const int c = slot ^ cr_swz<XW>(row);
-      const int q = m0 + ((KT == 3) ? p.sg * (kt - 1) * p.HW : 0) - p.halo + row;
-      const int ch = cb * XW + 4 * c;
-      unsigned vo = CR_OOB;
-      if (q >= 0 && q < p.M && ch < d.Cin) vo = ((unsigned)q * (unsigned)d.in_cs + (unsigned)(d.in_coff + ch)) << 2;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rs, (lds_void*)(sb + (b << 8)), 16, vo, 0, 0, 0);
-    }
-    if (NTAP > 1 && cb == 0 && tid < CR_L) {  // which taps of position m0 + tid lie inside its clip
+    if (NTAP > 1 && r0 == 0 && tid < CR_L) {  // which taps of position m0 + tid lie inside its clip
       const unsigned m = (unsigned)(m0 + tid);
       const unsigned q1 = cr_mdiv(m, p.w_mul, p.w_sh);
       const int w = (int)(m - q1 * (unsigned)d.Wo);
@@ -130,7 +147,19 @@ __global__ __launch_bounds__(256) void conv_rows_kernel(const CRowsArgs p) {
           if ((unsigned)(w + p.sg * (kk - 1)) < (unsigned)d.Wo) bits |= 16u << kk;
         }
       }
-      vm[(ps & 1) * CR_L + tid] = bits;
+      vm[(ps & 1) * CR_L + tid] = bits;  // (in front of the loads: an LDS store behind them would wait for them)
+    }
+    for (int b = wave; b < nblk; b += 4) {
+      const int wi = (WPS == 1) ? 0 : b / nxb;     // window within the step
+      const int kt = (NTAP == 3) ? wg0 * WPS + wi : 1;
+      const int f = ((b - wi * nxb) << 6) + lane;  // 16-byte chunk index within the window
+      const int row = f >> XSH, slot = f - (row << XSH);
+      const int c = slot ^ cr_swz<XW>(row);
+      const int q = m0 + p.sg * (kt - 1) * p.HW - p.halo + row;
+      const int ch = cb * XW + 4 * c;
+      unsigned vo = CR_OOB;
+      if (q >= 0 && q < p.M && ch < d.Cin) vo = ((unsigned)q * (unsigned)d.in_cs + (unsigned)(d.in_coff + ch)) << 2;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rs, (lds_void*)(sb + (b << 8)), 16, vo, 0, 0, 0);
     }
   };
 
@@ -161,60 +190,93 @@ __global__ __launch_bounds__(256) void conv_rows_kernel(const CRowsArgs p) {
     s1[ct] = sk[ct];
     s2[ct] = sk[ct];
   }
+  // per-channel epilogue vectors once, in front of the loop: a global load inside it would make the compiler wait for
+  // vmcnt(0), i.e. for the NEXT step's LDS-DMA loads as well
+  f32x4 esc[NCT], ebi[NCT];
+#pragma unroll
+  for (int ct = 0; ct < NCT; ++ct) {
+    const int n = co0 + 16 * ct + 4 * g;
+    esc[ct] = (f32x4){1.f, 1.f, 1.f, 1.f};
+    ebi[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (n < d.Cout) {
+      if (p.scale) esc[ct] = *reinterpret_cast<const f32x4*>(p.scale + n);
+      if (p.bias) ebi[ct] = *reinterpret_cast<const f32x4*>(p.bias + n);
+    }
+  }
+  const unsigned a_lane = lds_base + (unsigned)((j * p.wstride + 4 * g) << 2);  // this lane's weight row / K group
+  const unsigned wrow16 = (unsigned)((16 * p.wstride) << 2);                    // bytes between column tiles
 
-  const int nst = nps * KB;
+  const int nst = nps * SPP;
   if (nst > 0) issue(0, 0);
   for (int st = 0; st < nst; ++st) {
     const int buf = st & 1;
-    const int ps = st / KB, cb = st - ps * KB;
+    const int ps = st / SPP, r0 = st - ps * SPP;
+    const int wg0 = r0 / KB, cb = r0 - wg0 * KB;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this thread's pieces of step st have landed ...
     __syncthreads();                                   // ... and everybody's (and the weights); buffer buf ^ 1 is free
+    const unsigned vb = (NTAP > 1) ? vm[(ps & 1) * CR_L + 16 * wave + j] : 0u;  // (before the next loads are issued)
+    __builtin_amdgcn_sched_barrier(0);
     if (st + 1 < nst) issue(st + 1, buf ^ 1);
-    if (cb == 0) {
+    __builtin_amdgcn_sched_barrier(0);
+    if (r0 == 0) {
 #pragma unroll
       for (int ct = 0; ct < NCT; ++ct) {
         acc[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
         acc2[ct] = acc[ct];
       }
     }
-    const float* const xs = stg + buf * stage_floats;
-    const unsigned vb = (NTAP > 1) ? vm[(ps & 1) * CR_L + 16 * wave + j] : 0u;
-    const float* const wl = Wl + j * p.wstride + cb * XW + 4 * g;
-#pragma unroll
-    for (int tap = 0; tap < NTAP; ++tap) {
-      int R;
-      bool ok = true;
-      const float* xw;
+    const unsigned xs = lds_base + (unsigned)(((int)(stg - cr_smem) + buf * stage_floats) << 2);
+    // operand item it = (tap of the step, 16-channel chunk): reads issued one item ahead of the MFMAs
+    auto fetch = [&](int it, CrFrag<NCT>& f, bool& ok) {
+      const int tl = it / NQ, q = it - tl * NQ;   // tap within the step
+      int R, tap;
+      unsigned xw;
+      ok = true;
       if (NTAP == 9) {
-        const int kh = tap / 3, kw = tap - 3 * kh;
+        const int kh = tl / 3, kw = tl - 3 * kh;
+        tap = tl;
         R = p.halo + 16 * wave + j + p.sg * ((kh - 1) * d.Wi + (kw - 1));
         ok = ((vb >> kh) & 1u) && ((vb >> (4 + kw)) & 1u);
         xw = xs;
       } else if (NTAP == 3) {
+        tap = wg0 * WPS + tl;
         R = 16 * wave + j;
         ok = (vb >> tap) & 1u;
-        xw = xs + tap * win;
+        xw = xs + (unsigned)((tl * win) << 2);
       } else {
+        tap = 0;
         R = 16 * wave + j;
         xw = xs;
       }
-      const int sw = cr_swz<XW>(R);
+      const int c = 4 * q + g;
+      f.b = cr_lds128(xw + (unsigned)((R * XW + ((c ^ cr_swz<XW>(R)) << 2)) << 2));
+      const unsigned ao = a_lane + (unsigned)((tap * (KB * XW) + cb * XW + 16 * q) << 2);
 #pragma unroll
-      for (int q = 0; q < NQ; ++q) {
-        const int c = 4 * q + g;
-        f32x4 b = {0.f, 0.f, 0.f, 0.f};
-        if (ok && (XW >= 16 || g < XW / 4)) b = *reinterpret_cast<const f32x4*>(xw + R * XW + ((c ^ sw) << 2));
+      for (int ct = 0; ct < NCT; ++ct) f.a[ct] = cr_lds128(ao + ct * wrow16);
+    };
+    CrFrag<NCT> fr[2];
+    bool okv[2];
+    fetch(0, fr[0], okv[0]);
 #pragma unroll
-        for (int ct = 0; ct < NCT; ++ct) {
-          const f32x4 a = *reinterpret_cast<const f32x4*>(wl + (16 * ct) * p.wstride + tap * (KB * XW) + 16 * q);
-          acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], b[0], acc[ct], 0, 0, 0);
-          acc2[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], b[1], acc2[ct], 0, 0, 0);
-          acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], b[2], acc[ct], 0, 0, 0);
-          acc2[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], b[3], acc2[ct], 0, 0, 0);
-        }
+    for (int it = 0; it < NI; ++it) {
+      CrFrag<NCT>& f = fr[it & 1];
+      if (it + 1 < NI) {
+        fetch(it + 1, fr[(it + 1) & 1], okv[(it + 1) & 1]);
+        cr_wait<1 + NCT, NCT>(f);
+      } else {
+        cr_wait<0, NCT>(f);
+      }
+      f32x4 b = f.b;
+      if (!okv[it & 1] || (XW < 16 && g >= XW / 4)) b = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ct = 0; ct < NCT; ++ct) {
+        acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.a[ct][0], b[0], acc[ct], 0, 0, 0);
+        acc2[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.a[ct][1], b[1], acc2[ct], 0, 0, 0);
+        acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.a[ct][2], b[2], acc[ct], 0, 0, 0);
+        acc2[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.a[ct][3], b[3], acc2[ct], 0, 0, 0);
       }
     }
-    if (cb != KB - 1) continue;
+    if (r0 != SPP - 1) continue;
     // ---- epilogue of position stage ps: lane = position m0 + 16 wave + j, channels co0 + 16 ct + 4 g .. + 3
     const int m = mb + ps * CR_L + 16 * wave + j;
     const bool mok = m < me;
@@ -223,21 +285,21 @@ __global__ __launch_bounds__(256) void conv_rows_kernel(const CRowsArgs p) {
     for (int ct = 0; ct < NCT; ++ct) {
       const int n = co0 + 16 * ct + 4 * g;
       const bool nok = n < d.Cout;
-      f32x4 v = acc[ct] + acc2[ct];
-      if (nok) {
-        if (p.scale) v *= *reinterpret_cast<const f32x4*>(p.scale + n);
-        if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
-      }
+      f32x4 v = (acc[ct] + acc2[ct]) * esc[ct] + ebi[ct];
       if (mok && nok) {
-        if (p.res) v += *reinterpret_cast<const f32x4*>(p.res + (long)m * d.res_cs + d.res_coff + n);
+        if constexpr (RES) v += *reinterpret_cast<const f32x4*>(p.res + (long)m * d.res_cs + d.res_coff + n);
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = sf_act(v[r], d.act);
         *reinterpret_cast<f32x4*>(p.out + (long)m * d.out_cs + d.out_coff + n) = v;
       }
       if (p.stats) {
-        if (!have_k && m_first < me) {  // K = the wavefront's first output row (a sample of the channel)
+        if (!have_k && m_first < me) {  // K = the wavefront's first output row (a sample of the channel): lane 16 g
 #pragma unroll
-          for (int r = 0; r < 4; ++r) sk[ct][r] = __shfl(v[r], lane & 48, 64);
+          for (int r = 0; r < 4; ++r) {
+            const float k0 = __builtin_amdgcn_readlane(v[r], 0), k1 = __builtin_amdgcn_readlane(v[r], 16);
+            const float k2 = __builtin_amdgcn_readlane(v[r], 32), k3 = __builtin_amdgcn_readlane(v[r], 48);
+            sk[ct][r] = g == 0 ? k0 : (g == 1 ? k1 : (g == 2 ? k2 : k3));
+          }
         }
         if (mok) {
           const f32x4 dv = v - sk[ct];
@@ -321,7 +383,7 @@ bool crows_plan(const sf_conv_desc* d, CRowsArgs* a, CRowsPlan* pl) {
   if (d->cin_pad % 4) return false;
   if (d->act != SF_ACT_NONE && d->act != SF_ACT_RELU && d->act != SF_ACT_RELU6) return false;
   const long M = (long)d->N * d->To * d->Ho * d->Wo;
-  if (M < 4096 || M > 0x3fffffffL) return false;
+  if (M < 1024 || M > 0x3fffffffL) return false;
   const long xb = ((M - 1) * d->in_cs + d->in_coff + d->Cin) * 4L;
   if (xb >= 0x7fffffffL) return false;
   // 8 -> 8 spatial layers: conv_small.hip (vector FMAs from an LDS halo tile) unless forced
@@ -341,8 +403,8 @@ bool crows_plan(const sf_conv_desc* d, CRowsArgs* a, CRowsPlan* pl) {
   const int krow = ntap * a->KB * xw;
   a->wstride = (krow + 63) / 64 * 64 + 4;  // = 4 (mod 64) floats: 16 consecutive rows on 16 different bank groups
   a->sg = d->transposed ? -1 : 1;
-  const int KT = ntap == 3 ? 3 : 1;
-  pl->lds = ((size_t)16 * nct * a->wstride + 2 * (size_t)KT * a->wrp * xw + 2 * CR_L) * sizeof(float);
+  const int wps = (ntap == 3 && xw <= 32) ? 3 : 1;  // windows staged per step
+  pl->lds = ((size_t)16 * nct * a->wstride + 2 * (size_t)wps * a->wrp * xw + 2 * CR_L) * sizeof(float);
   if (pl->lds > 150 * 1024) return false;
   pl->ntap = ntap; pl->xw = xw; pl->nct = nct; pl->nby = sf_cdiv(d->Cout, 16 * nct);
   cr_magic((unsigned)d->Wo, &a->w_mul, &a->w_sh);
@@ -351,7 +413,9 @@ bool crows_plan(const sf_conv_desc* d, CRowsArgs* a, CRowsPlan* pl) {
   // workgroups along the positions: ~1024 over the channel blocks, at least two stages each, at most 1024 (the
   // statistics workspace holds >= 4096 records per channel: four per workgroup)
   const long stages = (M + CR_L - 1) / CR_L;
-  long S = 1024 / pl->nby;
+  static const int wgs = [] { const char* e = getenv("SF_CONV_ROWS_WGS"); return e ? atoi(e) : 768; }();
+  long S = wgs / pl->nby;
+  if (S > 1024) S = 1024;
   if (S > (stages + 1) / 2) S = (stages + 1) / 2;
   if (S < 1) S = 1;
   long chunk = ((M + S - 1) / S + CR_L - 1) / CR_L * CR_L;
@@ -363,10 +427,18 @@ bool crows_plan(const sf_conv_desc* d, CRowsArgs* a, CRowsPlan* pl) {
 
 template <int NTAP, int XW, int NCT>
 int launch_crows(const CRowsArgs& a, const CRowsPlan& pl, hipStream_t s) {
-  static SfLdsAttr attr;
-  if (!sf_ensure_dyn_lds(attr, reinterpret_cast<const void*>(conv_rows_kernel<NTAP, XW, NCT>), 152 * 1024))
+  constexpr int WPS = (NTAP == 3 && XW <= 32) ? 3 : 1;
+  static SfLdsAttr attr, attr_res;
+  if (a.res) {
+    if (!sf_ensure_dyn_lds(attr_res, reinterpret_cast<const void*>(conv_rows_kernel<NTAP, XW, NCT, WPS, true>), 152 * 1024))
+      return SF_ELAUNCH;
+    hipLaunchKernelGGL((conv_rows_kernel<NTAP, XW, NCT, WPS, true>), dim3(a.S, pl.nby), dim3(256), pl.lds, s, a);
+    SF_CHECK_LAUNCH();
+    return SF_OK;
+  }
+  if (!sf_ensure_dyn_lds(attr, reinterpret_cast<const void*>(conv_rows_kernel<NTAP, XW, NCT, WPS, false>), 152 * 1024))
     return SF_ELAUNCH;
-  hipLaunchKernelGGL((conv_rows_kernel<NTAP, XW, NCT>), dim3(a.S, pl.nby), dim3(256), pl.lds, s, a);
+  hipLaunchKernelGGL((conv_rows_kernel<NTAP, XW, NCT, WPS, false>), dim3(a.S, pl.nby), dim3(256), pl.lds, s, a);
   SF_CHECK_LAUNCH();
   return SF_OK;
 }
