@@ -48,10 +48,12 @@ struct CRowsArgs {
   float* stats;          // [4 * S][Cout / 4][4][4] or NULL
   int M, S, chunk;       // positions, workgroups along the positions, positions per workgroup (multiple of 64)
   int KB;                // channel blocks of XW floats per position stage
+  int NB;                // stage buffers of the ring (NB - 1 steps in flight)
+  int rows_needed;       // rows of a window that are read (64 + 2 halo); the rest of wrp is padding
   int HW, halo, wrp;     // frame size, halo rows of a 1x3x3 window, rows of one x window in LDS
   int wstride;           // floats per weight row in LDS
   int sg;                // +1 forward, -1 data gradient (mirrored taps)
-  unsigned x_bytes;
+  unsigned x_bytes, res_bytes;
   unsigned w_mul, w_sh, h_mul, h_sh, t_mul, t_sh;
 };
 
@@ -90,9 +92,32 @@ __device__ __forceinline__ void cr_wait(CrFrag<NCT>& f) {
   else asm volatile("s_waitcnt lgkmcnt(%5)" : "+v"(f.b), "+v"(f.a[0]), "+v"(f.a[1]), "+v"(f.a[2]), "+v"(f.a[3]) : "n"(N));
 }
 
+// s_waitcnt vmcnt(n) for a wavefront-uniform runtime n (the instruction takes an immediate).
+__device__ __forceinline__ void cr_vmwait(int n) {
+#define CR_VM(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); break;
+  switch (n) {
+    CR_VM(0) CR_VM(1) CR_VM(2) CR_VM(3) CR_VM(4) CR_VM(5) CR_VM(6) CR_VM(7) CR_VM(8) CR_VM(9) CR_VM(10) CR_VM(11)
+    CR_VM(12) CR_VM(13) CR_VM(14) CR_VM(15) CR_VM(16) CR_VM(17) CR_VM(18) CR_VM(19) CR_VM(20) CR_VM(21) CR_VM(22)
+    CR_VM(23) CR_VM(24) CR_VM(25) CR_VM(26) CR_VM(27) CR_VM(28) CR_VM(29) CR_VM(30) CR_VM(31) CR_VM(32) CR_VM(33)
+    CR_VM(34) CR_VM(35) CR_VM(36) CR_VM(37) CR_VM(38) CR_VM(39) CR_VM(40) CR_VM(41) CR_VM(42) CR_VM(43) CR_VM(44)
+    CR_VM(45) CR_VM(46) CR_VM(47) CR_VM(48)
+    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+  }
+#undef CR_VM
+}
+
 // WPS: windows (kt taps) of a 3x1x1 layer staged per step — 3 for rows of <= 32 floats, 1 for 64-float rows.
-// RES: a residual operand exists (eval-mode shortcuts, accumulating data gradients).  Compile-time: its loads make the
-// compiler wait for vmcnt(0) in the epilogue — for the NEXT step's LDS-DMA loads too — whether or not they execute.
+// RES: a residual operand exists (eval-mode shortcuts, accumulating data gradients); its loads are raw buffer loads
+// behind a counted wait, issued in front of the step's LDS-DMA loads.
+//
+// Pipeline: a ring of NB = D + 1 stage buffers, the loads of steps st + 1 .. st + D in flight while step st is
+// multiplied (a step's LDS-DMA round trip is ~2.7 us under load against 0.2 .. 0.8 us of MFMAs: with ONE step in flight
+// — round 6's first version — every workgroup ran at a DMA latency per step).  Every wavefront issues the same number
+// `nper` of LDS-DMA instructions per step (the window is padded to whole groups of four 1 KiB pieces; steps past the
+// end are issued with out-of-range offsets), so "step st has landed" is s_waitcnt vmcnt((D - 1) nper [+ residual
+// loads]): the count of YOUNGER LOADS only — stores complete in any order against loads, so they are not counted, and a
+// store that lingers only makes the wait longer.  No compiler-visible LDS access or global load sits inside the loop
+// (hipcc would put s_waitcnt vmcnt(0) in front of it: MI355X_MICROARCH.md), the barrier is the raw s_barrier.
 template <int NTAP, int XW, int NCT, int WPS, bool RES>
 __global__ __launch_bounds__(256) void conv_rows_kernel(const CRowsArgs p) {
   constexpr int BCO = 16 * NCT;
@@ -114,20 +139,23 @@ __global__ __launch_bounds__(256) void conv_rows_kernel(const CRowsArgs p) {
   const int krow = NTAP * KB * XW;                 // floats of a weight row
   const int win = p.wrp * XW;                      // floats of one x window
   const int stage_floats = WPS * win;
+  const int NB = p.NB, D = NB - 1;
   float* const Wl = cr_smem;
   float* const stg = Wl + BCO * p.wstride;
-  unsigned* const vm = reinterpret_cast<unsigned*>(stg + 2 * stage_floats);  // [2][64]
   const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)cr_smem;
+  const unsigned vm_base = lds_base + (unsigned)((BCO * p.wstride + NB * stage_floats) << 2);  // [NB][64] words
   const __amdgpu_buffer_rsrc_t x_rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
   const int nxb = win >> 8;                        // 1 KiB pieces of one window
-  const int nblk = WPS * nxb;
+  const int nper = (WPS * nxb) >> 2;               // LDS-DMA instructions per wavefront and step (launcher: exact)
+  const int nst = nps * SPP;
 
-  auto issue = [&](int st, int buf) {
+  auto issue = [&](int st) {
     const int ps = st / SPP, r0 = st - ps * SPP;
     const int wg0 = r0 / KB, cb = r0 - wg0 * KB;   // first window (kt) of the step, channel block
     const int m0 = mb + ps * CR_L;
-    float* const sb = stg + buf * stage_floats;
-    if (NTAP > 1 && r0 == 0 && tid < CR_L) {  // which taps of position m0 + tid lie inside its clip
+    const bool live = st < nst;
+    float* const sb = stg + (st % NB) * stage_floats;
+    if (NTAP > 1 && live && r0 == 0 && tid < CR_L) {  // which taps of position m0 + tid lie inside its clip
       const unsigned m = (unsigned)(m0 + tid);
       const unsigned q1 = cr_mdiv(m, p.w_mul, p.w_sh);
       const int w = (int)(m - q1 * (unsigned)d.Wo);
@@ -147,9 +175,10 @@ __global__ __launch_bounds__(256) void conv_rows_kernel(const CRowsArgs p) {
           if ((unsigned)(w + p.sg * (kk - 1)) < (unsigned)d.Wo) bits |= 16u << kk;
         }
       }
-      vm[(ps & 1) * CR_L + tid] = bits;  // (in front of the loads: an LDS store behind them would wait for them)
+      asm volatile("ds_write_b32 %0, %1" ::"v"(vm_base + (unsigned)((((ps % NB) << 6) + tid) << 2)), "v"(bits) : "memory");
     }
-    for (int b = wave; b < nblk; b += 4) {
+    for (int i = 0; i < nper; ++i) {
+      const int b = wave + 4 * i;
       const int wi = (WPS == 1) ? 0 : b / nxb;     // window within the step
       const int kt = (NTAP == 3) ? wg0 * WPS + wi : 1;
       const int f = ((b - wi * nxb) << 6) + lane;  // 16-byte chunk index within the window
@@ -158,7 +187,7 @@ __global__ __launch_bounds__(256) void conv_rows_kernel(const CRowsArgs p) {
       const int q = m0 + p.sg * (kt - 1) * p.HW - p.halo + row;
       const int ch = cb * XW + 4 * c;
       unsigned vo = CR_OOB;
-      if (q >= 0 && q < p.M && ch < d.Cin) vo = ((unsigned)q * (unsigned)d.in_cs + (unsigned)(d.in_coff + ch)) << 2;
+      if (live && row < p.rows_needed && q >= 0 && q < p.M && ch < d.Cin) vo = ((unsigned)q * (unsigned)d.in_cs + (unsigned)(d.in_coff + ch)) << 2;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rs, (lds_void*)(sb + (b << 8)), 16, vo, 0, 0, 0);
     }
   };
@@ -189,9 +218,10 @@ __global__ __launch_bounds__(256) void conv_rows_kernel(const CRowsArgs p) {
     sk[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
     s1[ct] = sk[ct];
     s2[ct] = sk[ct];
+    acc[ct] = sk[ct];
+    acc2[ct] = sk[ct];
   }
-  // per-channel epilogue vectors once, in front of the loop: a global load inside it would make the compiler wait for
-  // vmcnt(0), i.e. for the NEXT step's LDS-DMA loads as well
+  // per-channel epilogue vectors once, in front of the loop
   f32x4 esc[NCT], ebi[NCT];
 #pragma unroll
   for (int ct = 0; ct < NCT; ++ct) {
@@ -205,27 +235,41 @@ __global__ __launch_bounds__(256) void conv_rows_kernel(const CRowsArgs p) {
   }
   const unsigned a_lane = lds_base + (unsigned)((j * p.wstride + 4 * g) << 2);  // this lane's weight row / K group
   const unsigned wrow16 = (unsigned)((16 * p.wstride) << 2);                    // bytes between column tiles
+  const unsigned stg_base = lds_base + (unsigned)((BCO * p.wstride) << 2);
+  __amdgpu_buffer_rsrc_t r_rs = x_rs;
+  if constexpr (RES) r_rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.res, 0, p.res_bytes, 0x00020000);
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // weights, scale, bias: nothing of them is counted below
 
-  const int nst = nps * SPP;
-  if (nst > 0) issue(0, 0);
+  for (int i = 0; i < D; ++i) issue(i);
   for (int st = 0; st < nst; ++st) {
-    const int buf = st & 1;
     const int ps = st / SPP, r0 = st - ps * SPP;
     const int wg0 = r0 / KB, cb = r0 - wg0 * KB;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this thread's pieces of step st have landed ...
-    __syncthreads();                                   // ... and everybody's (and the weights); buffer buf ^ 1 is free
-    const unsigned vb = (NTAP > 1) ? vm[(ps & 1) * CR_L + 16 * wave + j] : 0u;  // (before the next loads are issued)
+    // step st has landed when at most the loads issued behind it are outstanding: D - 1 steps of LDS-DMA (+ residual
+    // loads of those steps' epilogues, issued in front of their DMA)
+    cr_vmwait((D - 1) * (nper + (RES ? NCT : 0)));
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (this thread's validity words / weight stores)
+    __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
-    if (st + 1 < nst) issue(st + 1, buf ^ 1);
-    __builtin_amdgcn_sched_barrier(0);
-    if (r0 == 0) {
+    const int m = mb + ps * CR_L + 16 * wave + j;
+    const bool mok = m < me;
+    f32x4 rv[NCT];
+    if constexpr (RES) {
+      if (r0 == SPP - 1) {
 #pragma unroll
-      for (int ct = 0; ct < NCT; ++ct) {
-        acc[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        acc2[ct] = acc[ct];
+        for (int ct = 0; ct < NCT; ++ct) {
+          const int n = co0 + 16 * ct + 4 * g;
+          const unsigned ro = (mok && n < d.Cout) ? ((unsigned)m * (unsigned)d.res_cs + (unsigned)(d.res_coff + n)) << 2 : CR_OOB;
+          asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(rv[ct]) : "v"(ro), "s"(r_rs) : "memory");
+        }
       }
     }
-    const unsigned xs = lds_base + (unsigned)(((int)(stg - cr_smem) + buf * stage_floats) << 2);
+    issue(st + D);
+    __builtin_amdgcn_sched_barrier(0);
+    unsigned vb = 0u;
+    if (NTAP > 1) {
+      asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(vb) : "v"(vm_base + (unsigned)((((ps % NB) << 6) + 16 * wave + j) << 2)));
+    }
+    const unsigned xs = stg_base + (unsigned)(((st % NB) * stage_floats) << 2);
     // operand item it = (tap of the step, 16-channel chunk): reads issued one item ahead of the MFMAs
     auto fetch = [&](int it, CrFrag<NCT>& f, bool& ok) {
       const int tl = it / NQ, q = it - tl * NQ;   // tap within the step
@@ -277,17 +321,22 @@ __global__ __launch_bounds__(256) void conv_rows_kernel(const CRowsArgs p) {
       }
     }
     if (r0 != SPP - 1) continue;
-    // ---- epilogue of position stage ps: lane = position m0 + 16 wave + j, channels co0 + 16 ct + 4 g .. + 3
-    const int m = mb + ps * CR_L + 16 * wave + j;
-    const bool mok = m < me;
+    // ---- epilogue of position stage ps: lane = position m, channels co0 + 16 ct + 4 g .. + 3
     const int m_first = mb + ps * CR_L + 16 * wave;  // this wavefront's first position of the stage (lane j = 0)
+    if constexpr (RES) {  // the residual loads sit in front of this step's nper LDS-DMA loads
+      cr_vmwait(nper);
+#pragma unroll
+      for (int ct = 0; ct < NCT; ++ct) asm volatile("" : "+v"(rv[ct]));
+    }
 #pragma unroll
     for (int ct = 0; ct < NCT; ++ct) {
       const int n = co0 + 16 * ct + 4 * g;
       const bool nok = n < d.Cout;
       f32x4 v = (acc[ct] + acc2[ct]) * esc[ct] + ebi[ct];
+      acc[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      acc2[ct] = acc[ct];
+      if constexpr (RES) v += rv[ct];
       if (mok && nok) {
-        if constexpr (RES) v += *reinterpret_cast<const f32x4*>(p.res + (long)m * d.res_cs + d.res_coff + n);
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = sf_act(v[r], d.act);
         *reinterpret_cast<f32x4*>(p.out + (long)m * d.out_cs + d.out_coff + n) = v;
@@ -313,6 +362,7 @@ __global__ __launch_bounds__(256) void conv_rows_kernel(const CRowsArgs p) {
       if (mok) cnt += 1.f;
     }
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the out-of-range tail loads still write (zeros) into LDS
 
   if (p.stats) {
 #pragma unroll
@@ -396,16 +446,27 @@ bool crows_plan(const sf_conv_desc* d, CRowsArgs* a, CRowsPlan* pl) {
   a->KB = sf_cdiv(d->Cin, xw);
   a->HW = d->Hi * d->Wi;
   a->halo = (ntap == 9) ? d->Wi + 1 : 0;
-  const int gran = 256 / xw;  // window rows per 1 KiB piece
+  const int wps = (ntap == 3 && xw <= 32) ? 3 : 1;  // windows staged per step
+  // window rows: whole 1 KiB pieces, and a step's pieces a multiple of four (every wavefront issues the same number)
+  const int gran = 256 / xw * (wps == 3 ? 4 : 4);
   a->wrp = (CR_L + 2 * a->halo + gran - 1) / gran * gran;
+  a->rows_needed = CR_L + 2 * a->halo;
   const int nct = d->Cout <= 16 ? 1 : (d->Cout <= 32 ? 2 : 4);
   if (xw > 32 && nct > 2) return false;
   const int krow = ntap * a->KB * xw;
   a->wstride = (krow + 63) / 64 * 64 + 4;  // = 4 (mod 64) floats: 16 consecutive rows on 16 different bank groups
   a->sg = d->transposed ? -1 : 1;
-  const int wps = (ntap == 3 && xw <= 32) ? 3 : 1;  // windows staged per step
-  pl->lds = ((size_t)16 * nct * a->wstride + 2 * (size_t)wps * a->wrp * xw + 2 * CR_L) * sizeof(float);
+  // ring depth: as many stage buffers as fit beside the weights in ~72 KB (two workgroups per CU), 3 .. 8
+  const size_t wbytes = (size_t)16 * nct * a->wstride * 4, sbytes = (size_t)wps * a->wrp * xw * 4 + CR_L * 4;
+  static const int nb_env = [] { const char* e = getenv("SF_CONV_ROWS_NB"); return e ? atoi(e) : 0; }();
+  int nb = nb_env > 0 ? nb_env : (int)((72 * 1024 - (long)wbytes) / (long)sbytes);
+  if (nb < 3) nb = 3;
+  if (nb > 8) nb = 8;
+  while (nb > 2 && wbytes + nb * sbytes > 150 * 1024) --nb;
+  a->NB = nb;
+  pl->lds = wbytes + nb * sbytes;
   if (pl->lds > 150 * 1024) return false;
+  if ((nb - 1) * (((wps * a->wrp * xw) >> 10) + 4) > 48) return false;  // the counted wait's immediate
   pl->ntap = ntap; pl->xw = xw; pl->nct = nct; pl->nby = sf_cdiv(d->Cout, 16 * nct);
   cr_magic((unsigned)d->Wo, &a->w_mul, &a->w_sh);
   cr_magic((unsigned)d->Ho, &a->h_mul, &a->h_sh);
@@ -497,6 +558,12 @@ int sf_conv_rows_try(const sf_conv_desc* d, const float* in, const float* w_pack
   if ((scale && !sf_aligned16(scale)) || (bias && !sf_aligned16(bias))) return 1;
   if (res && ((d->res_cs % 4) || (d->res_coff % 4) || !sf_aligned16(res))) return 1;
   a.x = in; a.w = w_packed; a.scale = scale; a.bias = bias; a.res = res; a.out = out;
+  a.res_bytes = 0;
+  if (res) {
+    const long rb = ((long)(a.M - 1) * d->res_cs + d->res_coff + d->Cout) * 4L;
+    if (rb >= 0x7fffffffL) return 1;
+    a.res_bytes = (unsigned)rb;
+  }
   const bool want = stats && stat_parts && !scale && !res && d->act == SF_ACT_NONE && !d->transposed &&
                     sf_aligned16(stats) && 4L * a.S <= sf_conv_wave_max_parts(a.M);
   a.stats = want ? stats : nullptr;
