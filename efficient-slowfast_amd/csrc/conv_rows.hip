@@ -106,6 +106,25 @@ __device__ __forceinline__ void cr_vmwait(int n) {
 #undef CR_VM
 }
 
+// Where a step sits: position stage, window group, channel block, ring buffer, validity slot — advanced by increments
+// (a runtime integer division costs ~30 vector instructions even for uniform values; the first version spent more issue
+// cycles on st / SPP, st % NB ... than on its MFMAs).
+struct CrCursor {
+  int st, ps, wg0, cb, buf, vslot;
+  __device__ __forceinline__ void next(int KB, int NWG, int NB) {
+    ++st;
+    if (++buf == NB) buf = 0;
+    if (++cb == KB) {
+      cb = 0;
+      if (++wg0 == NWG) {
+        wg0 = 0;
+        ++ps;
+        if (++vslot == NB) vslot = 0;
+      }
+    }
+  }
+};
+
 // WPS: windows (kt taps) of a 3x1x1 layer staged per step — 3 for rows of <= 32 floats, 1 for 64-float rows.
 // RES: a residual operand exists (eval-mode shortcuts, accumulating data gradients); its loads are raw buffer loads
 // behind a counted wait, issued in front of the step's LDS-DMA loads.
@@ -135,7 +154,8 @@ __global__ __launch_bounds__(256) void conv_rows_kernel(const CRowsArgs p) {
   const int me = (mb + p.chunk < p.M) ? mb + p.chunk : p.M;
   const int nps = (me > mb) ? (me - mb + CR_L - 1) / CR_L : 0;
   const int KB = p.KB;
-  const int SPP = ((NTAP == 3) ? 3 / WPS : 1) * KB;  // steps per position stage: (window group, channel block)
+  constexpr int NWG = (NTAP == 3) ? 3 / WPS : 1;     // window groups per position stage
+  const int SPP = NWG * KB;                        // steps per position stage: (window group, channel block)
   const int krow = NTAP * KB * XW;                 // floats of a weight row
   const int win = p.wrp * XW;                      // floats of one x window
   const int stage_floats = WPS * win;
@@ -149,13 +169,12 @@ __global__ __launch_bounds__(256) void conv_rows_kernel(const CRowsArgs p) {
   const int nper = (WPS * nxb) >> 2;               // LDS-DMA instructions per wavefront and step (launcher: exact)
   const int nst = nps * SPP;
 
-  auto issue = [&](int st) {
-    const int ps = st / SPP, r0 = st - ps * SPP;
-    const int wg0 = r0 / KB, cb = r0 - wg0 * KB;   // first window (kt) of the step, channel block
+  auto issue = [&](const CrCursor& c) {
+    const int ps = c.ps, wg0 = c.wg0, cb = c.cb;   // position stage, first window (kt) of the step, channel block
     const int m0 = mb + ps * CR_L;
-    const bool live = st < nst;
-    float* const sb = stg + (st % NB) * stage_floats;
-    if (NTAP > 1 && live && r0 == 0 && tid < CR_L) {  // which taps of position m0 + tid lie inside its clip
+    const bool live = c.st < nst;
+    float* const sb = stg + c.buf * stage_floats;
+    if (NTAP > 1 && live && wg0 == 0 && cb == 0 && tid < CR_L) {  // which taps of position m0 + tid lie inside its clip
       const unsigned m = (unsigned)(m0 + tid);
       const unsigned q1 = cr_mdiv(m, p.w_mul, p.w_sh);
       const int w = (int)(m - q1 * (unsigned)d.Wo);
@@ -175,17 +194,17 @@ __global__ __launch_bounds__(256) void conv_rows_kernel(const CRowsArgs p) {
           if ((unsigned)(w + p.sg * (kk - 1)) < (unsigned)d.Wo) bits |= 16u << kk;
         }
       }
-      asm volatile("ds_write_b32 %0, %1" ::"v"(vm_base + (unsigned)((((ps % NB) << 6) + tid) << 2)), "v"(bits) : "memory");
+      asm volatile("ds_write_b32 %0, %1" ::"v"(vm_base + (unsigned)(((c.vslot << 6) + tid) << 2)), "v"(bits) : "memory");
     }
     for (int i = 0; i < nper; ++i) {
       const int b = wave + 4 * i;
-      const int wi = (WPS == 1) ? 0 : b / nxb;     // window within the step
+      const int wi = (WPS == 1) ? 0 : (b >= 2 * nxb ? 2 : (b >= nxb ? 1 : 0));  // window within the step
       const int kt = (NTAP == 3) ? wg0 * WPS + wi : 1;
       const int f = ((b - wi * nxb) << 6) + lane;  // 16-byte chunk index within the window
       const int row = f >> XSH, slot = f - (row << XSH);
-      const int c = slot ^ cr_swz<XW>(row);
+      const int cc = slot ^ cr_swz<XW>(row);
       const int q = m0 + p.sg * (kt - 1) * p.HW - p.halo + row;
-      const int ch = cb * XW + 4 * c;
+      const int ch = cb * XW + 4 * cc;
       unsigned vo = CR_OOB;
       if (live && row < p.rows_needed && q >= 0 && q < p.M && ch < d.Cin) vo = ((unsigned)q * (unsigned)d.in_cs + (unsigned)(d.in_coff + ch)) << 2;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rs, (lds_void*)(sb + (b << 8)), 16, vo, 0, 0, 0);
@@ -240,10 +259,14 @@ __global__ __launch_bounds__(256) void conv_rows_kernel(const CRowsArgs p) {
   if constexpr (RES) r_rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.res, 0, p.res_bytes, 0x00020000);
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // weights, scale, bias: nothing of them is counted below
 
-  for (int i = 0; i < D; ++i) issue(i);
-  for (int st = 0; st < nst; ++st) {
-    const int ps = st / SPP, r0 = st - ps * SPP;
-    const int wg0 = r0 / KB, cb = r0 - wg0 * KB;
+  CrCursor ic = {0, 0, 0, 0, 0, 0}, cc = {0, 0, 0, 0, 0, 0};  // issue / consume positions
+  for (int i = 0; i < D; ++i) {
+    issue(ic);
+    ic.next(KB, NWG, NB);
+  }
+  for (int st = 0; st < nst; ++st, cc.next(KB, NWG, NB)) {
+    const int ps = cc.ps, wg0 = cc.wg0, cb = cc.cb;
+    const bool last_of_stage = (wg0 == NWG - 1) && (cb == KB - 1);
     // step st has landed when at most the loads issued behind it are outstanding: D - 1 steps of LDS-DMA (+ residual
     // loads of those steps' epilogues, issued in front of their DMA)
     cr_vmwait((D - 1) * (nper + (RES ? NCT : 0)));
@@ -254,7 +277,7 @@ __global__ __launch_bounds__(256) void conv_rows_kernel(const CRowsArgs p) {
     const bool mok = m < me;
     f32x4 rv[NCT];
     if constexpr (RES) {
-      if (r0 == SPP - 1) {
+      if (last_of_stage) {
 #pragma unroll
         for (int ct = 0; ct < NCT; ++ct) {
           const int n = co0 + 16 * ct + 4 * g;
@@ -263,13 +286,14 @@ __global__ __launch_bounds__(256) void conv_rows_kernel(const CRowsArgs p) {
         }
       }
     }
-    issue(st + D);
+    issue(ic);
+    ic.next(KB, NWG, NB);
     __builtin_amdgcn_sched_barrier(0);
     unsigned vb = 0u;
     if (NTAP > 1) {
-      asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(vb) : "v"(vm_base + (unsigned)((((ps % NB) << 6) + 16 * wave + j) << 2)));
+      asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(vb) : "v"(vm_base + (unsigned)(((cc.vslot << 6) + 16 * wave + j) << 2)));
     }
-    const unsigned xs = stg_base + (unsigned)(((st % NB) * stage_floats) << 2);
+    const unsigned xs = stg_base + (unsigned)((cc.buf * stage_floats) << 2);
     // operand item it = (tap of the step, 16-channel chunk): reads issued one item ahead of the MFMAs
     auto fetch = [&](int it, CrFrag<NCT>& f, bool& ok) {
       const int tl = it / NQ, q = it - tl * NQ;   // tap within the step
@@ -320,7 +344,7 @@ __global__ __launch_bounds__(256) void conv_rows_kernel(const CRowsArgs p) {
         acc2[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.a[ct][3], b[3], acc2[ct], 0, 0, 0);
       }
     }
-    if (r0 != SPP - 1) continue;
+    if (!last_of_stage) continue;
     // ---- epilogue of position stage ps: lane = position m, channels co0 + 16 ct + 4 g .. + 3
     const int m_first = mb + ps * CR_L + 16 * wave;  // this wavefront's first position of the stage (lane j = 0)
     if constexpr (RES) {  // the residual loads sit in front of this step's nper LDS-DMA loads
