@@ -49,6 +49,7 @@ struct CRowsArgs {
   int M, S, chunk;       // positions, workgroups along the positions, positions per workgroup (multiple of 64)
   int KB;                // channel blocks of XW floats per position stage
   int NB;                // stage buffers of the ring (NB - 1 steps in flight)
+  int dbg;               // SF_CONV_ROWS_DBG timing ablations (results invalid): 1 no loads, 2 no MFMA loop, 4 no stores
   int rows_needed;       // rows of a window that are read (64 + 2 halo); the rest of wrp is padding
   int HW, halo, wrp;     // frame size, halo rows of a 1x3x3 window, rows of one x window in LDS
   int wstride;           // floats per weight row in LDS
@@ -163,51 +164,48 @@ __global__ __launch_bounds__(256) void conv_rows_kernel(const CRowsArgs p) {
   float* const Wl = cr_smem;
   float* const stg = Wl + BCO * p.wstride;
   const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)cr_smem;
-  const unsigned vm_base = lds_base + (unsigned)((BCO * p.wstride + NB * stage_floats) << 2);  // [NB][64] words
+  const unsigned stg_base = lds_base + (unsigned)((BCO * p.wstride) << 2);
   const __amdgpu_buffer_rsrc_t x_rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
   const int nxb = win >> 8;                        // 1 KiB pieces of one window
   const int nper = (WPS * nxb) >> 2;               // LDS-DMA instructions per wavefront and step (launcher: exact)
   const int nst = nps * SPP;
 
+  // Per-lane constants of this wavefront's LDS-DMA pieces (piece b = wave + 4 i of every step): byte offset of the lane's
+  // 16-byte chunk within the step's source rows, or out of range for the padding rows of a window.  A step then costs
+  // one add per piece: source offset = wavefront-uniform base of the step's window + this constant.  (Offsets past the
+  // tensor — rows behind the last position, rows in front of the first: negative bases wrap to > 2^31 — read as zeros
+  // through the buffer's bounds check; the launcher keeps the tensor below 2^30 bytes so that base + 2^31 stays out.)
+  constexpr int MAXP = 6;
+  unsigned lc[MAXP];
+  int chlim[MAXP];  // channels of the row left at this lane's chunk (a channel block reads while cb * XW < chlim)
+#pragma unroll
+  for (int i = 0; i < MAXP; ++i) {
+    const int b = wave + 4 * i;
+    const int wi = (WPS == 1) ? 0 : (b >= 2 * nxb ? 2 : (b >= nxb ? 1 : 0));
+    const int f = ((b - wi * nxb) << 6) + lane;  // 16-byte chunk index within the window
+    const int row = f >> XSH, slot = f - (row << XSH);
+    const int c4 = 4 * (slot ^ cr_swz<XW>(row));
+    lc[i] = (row < p.rows_needed && i < nper) ? (unsigned)((row * d.in_cs + c4) << 2) : CR_OOB;
+    chlim[i] = d.Cin - c4;
+  }
   auto issue = [&](const CrCursor& c) {
-    const int ps = c.ps, wg0 = c.wg0, cb = c.cb;   // position stage, first window (kt) of the step, channel block
-    const int m0 = mb + ps * CR_L;
-    const bool live = c.st < nst;
-    float* const sb = stg + c.buf * stage_floats;
-    if (NTAP > 1 && live && wg0 == 0 && cb == 0 && tid < CR_L) {  // which taps of position m0 + tid lie inside its clip
-      const unsigned m = (unsigned)(m0 + tid);
-      const unsigned q1 = cr_mdiv(m, p.w_mul, p.w_sh);
-      const int w = (int)(m - q1 * (unsigned)d.Wo);
-      const unsigned q2 = cr_mdiv(q1, p.h_mul, p.h_sh);
-      const int h = (int)(q1 - q2 * (unsigned)d.Ho);
-      const unsigned q3 = cr_mdiv(q2, p.t_mul, p.t_sh);
-      const int t = (int)(q2 - q3 * (unsigned)d.To);
-      unsigned bits = 0;
-      if (NTAP == 3) {
+    const int m0 = mb + c.ps * CR_L;
+    const bool live = c.st < nst && !(p.dbg & 1);
+    const unsigned lds0 = stg_base + (unsigned)((c.buf * stage_floats) << 2);
+    const int cbx = c.cb * XW;
 #pragma unroll
-        for (int kt = 0; kt < 3; ++kt)
-          if ((unsigned)(t + p.sg * (kt - 1)) < (unsigned)d.To) bits |= 1u << kt;
-      } else {  // separable: bits 0..2 = row h + sg (kh - 1) inside, bits 4..6 = column w + sg (kw - 1) inside
-#pragma unroll
-        for (int kk = 0; kk < 3; ++kk) {
-          if ((unsigned)(h + p.sg * (kk - 1)) < (unsigned)d.Ho) bits |= 1u << kk;
-          if ((unsigned)(w + p.sg * (kk - 1)) < (unsigned)d.Wo) bits |= 16u << kk;
-        }
+    for (int i = 0; i < MAXP; ++i) {
+      if (i < nper) {
+        const int b = wave + 4 * i;
+        const int wi = (WPS == 1) ? 0 : (b >= 2 * nxb ? 2 : (b >= nxb ? 1 : 0));  // window within the step
+        const int kt = (NTAP == 3) ? c.wg0 * WPS + wi : 1;
+        // wavefront-uniform base of the window: row (m0 - halo + sg (kt - 1) HW), channel block cb
+        const unsigned base = live ? (unsigned)(((m0 - p.halo + p.sg * (kt - 1) * p.HW) * d.in_cs + d.in_coff + cbx) << 2)
+                                   : CR_OOB;
+        const unsigned vo = (cbx < chlim[i]) ? base + lc[i] : CR_OOB;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(
+            x_rs, (lds_void*)(__attribute__((address_space(3))) char*)(uintptr_t)(lds0 + (unsigned)(b << 10)), 16, vo, 0, 0, 0);
       }
-      asm volatile("ds_write_b32 %0, %1" ::"v"(vm_base + (unsigned)(((c.vslot << 6) + tid) << 2)), "v"(bits) : "memory");
-    }
-    for (int i = 0; i < nper; ++i) {
-      const int b = wave + 4 * i;
-      const int wi = (WPS == 1) ? 0 : (b >= 2 * nxb ? 2 : (b >= nxb ? 1 : 0));  // window within the step
-      const int kt = (NTAP == 3) ? wg0 * WPS + wi : 1;
-      const int f = ((b - wi * nxb) << 6) + lane;  // 16-byte chunk index within the window
-      const int row = f >> XSH, slot = f - (row << XSH);
-      const int cc = slot ^ cr_swz<XW>(row);
-      const int q = m0 + p.sg * (kt - 1) * p.HW - p.halo + row;
-      const int ch = cb * XW + 4 * cc;
-      unsigned vo = CR_OOB;
-      if (live && row < p.rows_needed && q >= 0 && q < p.M && ch < d.Cin) vo = ((unsigned)q * (unsigned)d.in_cs + (unsigned)(d.in_coff + ch)) << 2;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rs, (lds_void*)(sb + (b << 8)), 16, vo, 0, 0, 0);
     }
   };
 
@@ -254,12 +252,12 @@ __global__ __launch_bounds__(256) void conv_rows_kernel(const CRowsArgs p) {
   }
   const unsigned a_lane = lds_base + (unsigned)((j * p.wstride + 4 * g) << 2);  // this lane's weight row / K group
   const unsigned wrow16 = (unsigned)((16 * p.wstride) << 2);                    // bytes between column tiles
-  const unsigned stg_base = lds_base + (unsigned)((BCO * p.wstride) << 2);
   __amdgpu_buffer_rsrc_t r_rs = x_rs;
   if constexpr (RES) r_rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.res, 0, p.res_bytes, 0x00020000);
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // weights, scale, bias: nothing of them is counted below
 
   CrCursor ic = {0, 0, 0, 0, 0, 0}, cc = {0, 0, 0, 0, 0, 0};  // issue / consume positions
+  unsigned vb = 0u;
   for (int i = 0; i < D; ++i) {
     issue(ic);
     ic.next(KB, NWG, NB);
@@ -270,7 +268,7 @@ __global__ __launch_bounds__(256) void conv_rows_kernel(const CRowsArgs p) {
     // step st has landed when at most the loads issued behind it are outstanding: D - 1 steps of LDS-DMA (+ residual
     // loads of those steps' epilogues, issued in front of their DMA)
     cr_vmwait((D - 1) * (nper + (RES ? NCT : 0)));
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (this thread's validity words / weight stores)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
     const int m = mb + ps * CR_L + 16 * wave + j;
@@ -289,9 +287,26 @@ __global__ __launch_bounds__(256) void conv_rows_kernel(const CRowsArgs p) {
     issue(ic);
     ic.next(KB, NWG, NB);
     __builtin_amdgcn_sched_barrier(0);
-    unsigned vb = 0u;
-    if (NTAP > 1) {
-      asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(vb) : "v"(vm_base + (unsigned)(((cc.vslot << 6) + 16 * wave + j) << 2)));
+    if (NTAP > 1 && wg0 == 0 && cb == 0) {  // which taps of this lane's position lie inside its clip (once per stage)
+      const unsigned mm = (unsigned)(mb + ps * CR_L + 16 * wave + j);
+      const unsigned q1 = cr_mdiv(mm, p.w_mul, p.w_sh);
+      const int w = (int)(mm - q1 * (unsigned)d.Wo);
+      const unsigned q2 = cr_mdiv(q1, p.h_mul, p.h_sh);
+      const int h = (int)(q1 - q2 * (unsigned)d.Ho);
+      const unsigned q3 = cr_mdiv(q2, p.t_mul, p.t_sh);
+      const int t = (int)(q2 - q3 * (unsigned)d.To);
+      vb = 0u;
+      if (NTAP == 3) {
+#pragma unroll
+        for (int kt = 0; kt < 3; ++kt)
+          if ((unsigned)(t + p.sg * (kt - 1)) < (unsigned)d.To) vb |= 1u << kt;
+      } else {  // separable: bits 0..2 = row h + sg (kh - 1) inside, bits 4..6 = column w + sg (kw - 1) inside
+#pragma unroll
+        for (int kk = 0; kk < 3; ++kk) {
+          if ((unsigned)(h + p.sg * (kk - 1)) < (unsigned)d.Ho) vb |= 1u << kk;
+          if ((unsigned)(w + p.sg * (kk - 1)) < (unsigned)d.Wo) vb |= 16u << kk;
+        }
+      }
     }
     const unsigned xs = stg_base + (unsigned)((cc.buf * stage_floats) << 2);
     // operand item it = (tap of the step, 16-channel chunk): reads issued one item ahead of the MFMAs
@@ -324,6 +339,7 @@ __global__ __launch_bounds__(256) void conv_rows_kernel(const CRowsArgs p) {
     };
     CrFrag<NCT> fr[2];
     bool okv[2];
+    if (!(p.dbg & 2)) {
     fetch(0, fr[0], okv[0]);
 #pragma unroll
     for (int it = 0; it < NI; ++it) {
@@ -344,6 +360,7 @@ __global__ __launch_bounds__(256) void conv_rows_kernel(const CRowsArgs p) {
         acc2[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.a[ct][3], b[3], acc2[ct], 0, 0, 0);
       }
     }
+    }
     if (!last_of_stage) continue;
     // ---- epilogue of position stage ps: lane = position m, channels co0 + 16 ct + 4 g .. + 3
     const int m_first = mb + ps * CR_L + 16 * wave;  // this wavefront's first position of the stage (lane j = 0)
@@ -360,7 +377,7 @@ __global__ __launch_bounds__(256) void conv_rows_kernel(const CRowsArgs p) {
       acc[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
       acc2[ct] = acc[ct];
       if constexpr (RES) v += rv[ct];
-      if (mok && nok) {
+      if (mok && nok && !(p.dbg & 4)) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = sf_act(v[r], d.act);
         *reinterpret_cast<f32x4*>(p.out + (long)m * d.out_cs + d.out_coff + n) = v;
@@ -459,7 +476,7 @@ bool crows_plan(const sf_conv_desc* d, CRowsArgs* a, CRowsPlan* pl) {
   const long M = (long)d->N * d->To * d->Ho * d->Wo;
   if (M < 1024 || M > 0x3fffffffL) return false;
   const long xb = ((M - 1) * d->in_cs + d->in_coff + d->Cin) * 4L;
-  if (xb >= 0x7fffffffL) return false;
+  if (xb >= 0x3fffffffL) return false;  // (see the kernel's offset arithmetic)
   // 8 -> 8 spatial layers: conv_small.hip (vector FMAs from an LDS halo tile) unless forced
   if (level < 2 && d->Cin <= 8 && d->Cout <= 8 && ntap == 9) return false;
   int xw = 8;
@@ -481,16 +498,19 @@ bool crows_plan(const sf_conv_desc* d, CRowsArgs* a, CRowsPlan* pl) {
   a->wstride = (krow + 63) / 64 * 64 + 4;  // = 4 (mod 64) floats: 16 consecutive rows on 16 different bank groups
   a->sg = d->transposed ? -1 : 1;
   // ring depth: as many stage buffers as fit beside the weights in ~72 KB (two workgroups per CU), 3 .. 8
-  const size_t wbytes = (size_t)16 * nct * a->wstride * 4, sbytes = (size_t)wps * a->wrp * xw * 4 + CR_L * 4;
+  const size_t wbytes = (size_t)16 * nct * a->wstride * 4, sbytes = (size_t)wps * a->wrp * xw * 4;
   static const int nb_env = [] { const char* e = getenv("SF_CONV_ROWS_NB"); return e ? atoi(e) : 0; }();
   int nb = nb_env > 0 ? nb_env : (int)((72 * 1024 - (long)wbytes) / (long)sbytes);
   if (nb < 3) nb = 3;
   if (nb > 8) nb = 8;
   while (nb > 2 && wbytes + nb * sbytes > 150 * 1024) --nb;
   a->NB = nb;
+  static const int dbg_env = [] { const char* e = getenv("SF_CONV_ROWS_DBG"); return e ? atoi(e) : 0; }();
+  a->dbg = dbg_env;
   pl->lds = wbytes + nb * sbytes;
   if (pl->lds > 150 * 1024) return false;
-  if ((nb - 1) * (((wps * a->wrp * xw) >> 10) + 4) > 48) return false;  // the counted wait's immediate
+  if (((wps * a->wrp * xw) >> 10) > 24) return false;                   // at most 6 pieces per wavefront and step
+  if ((nb - 1) * (((wps * a->wrp * xw) >> 12) + 4) > 48) return false;  // the counted wait's immediate
   pl->ntap = ntap; pl->xw = xw; pl->nct = nct; pl->nby = sf_cdiv(d->Cout, 16 * nct);
   cr_magic((unsigned)d->Wo, &a->w_mul, &a->w_sh);
   cr_magic((unsigned)d->Ho, &a->h_mul, &a->h_sh);
