@@ -443,12 +443,23 @@ void cr_magic(unsigned dv, unsigned* mul, unsigned* sh) {
   *sh = l - 1;
 }
 
-int g_crows_enable = 1;  // sf_conv_tune(22, e): 0 off, 1 by rule, 2 every shape the kernel covers
+// sf_conv_tune(22, e): 0 off, 1 = the environment's level (SF_CONV_ROWS, default 0: OFF), 2 every shape the kernel covers.
+// OFF by default — measured on MI355X (profiles/r06_conv_rows_ab.txt, tools/microbench/conv_rows_bench.py, cold operands,
+// launch counts of cfg #3 at 8 clips): 3.72 ms per step against 2.52 ms for the kernels it would replace.  What the
+// ablations (SF_CONV_ROWS_DBG) showed: with loads, MFMAs and stores all switched off the launches still take 40 .. 50 % of
+// their time, and that time scales with the number of 1 KiB LDS-DMA pieces issued, in range or not — the chip moves
+// ~2.8 TB/s through `buffer_load ... lds` whatever the shape (conv_bx.hip's operand-delivery bound is the same number),
+// i.e. ~80 .. 200 cycles per piece and CU.  A design that stages every activation row in LDS by LDS-DMA is capped there:
+// the 3x1x1 layers stage three windows (3x the input), the 1x3x3 layers 64 + 2 (W + 1) rows per 64 outputs (2.8x), and
+// both lose to conv_wave.hip's L2-fed fragments.  What would change it: one window per frame in a ring over t (1x), 256
+// positions per stage for the spatial layers (1.45x), or rows staged through registers (global loads + ds_write) instead
+// of LDS-DMA.  Kept: correct for every shape it covers (tests/test_conv_rows_gpu.py), selectable for A/B runs.
+int g_crows_enable = 1;
 
 int crows_level() {
   static const int env = [] {
     const char* e = getenv("SF_CONV_ROWS");
-    return e ? atoi(e) : 1;
+    return e ? atoi(e) : 0;
   }();
   return g_crows_enable == 1 ? env : g_crows_enable;
 }
