@@ -446,14 +446,17 @@ void cr_magic(unsigned dv, unsigned* mul, unsigned* sh) {
 // sf_conv_tune(22, e): 0 off, 1 = the environment's level (SF_CONV_ROWS, default 0: OFF), 2 every shape the kernel covers.
 // OFF by default — measured on MI355X (profiles/r06_conv_rows_ab.txt, tools/microbench/conv_rows_bench.py, cold operands,
 // launch counts of cfg #3 at 8 clips): 3.72 ms per step against 2.52 ms for the kernels it would replace.  What the
-// ablations (SF_CONV_ROWS_DBG) showed: with loads, MFMAs and stores all switched off the launches still take 40 .. 50 % of
-// their time, and that time scales with the number of 1 KiB LDS-DMA pieces issued, in range or not — the chip moves
-// ~2.8 TB/s through `buffer_load ... lds` whatever the shape (conv_bx.hip's operand-delivery bound is the same number),
-// i.e. ~80 .. 200 cycles per piece and CU.  A design that stages every activation row in LDS by LDS-DMA is capped there:
-// the 3x1x1 layers stage three windows (3x the input), the 1x3x3 layers 64 + 2 (W + 1) rows per 64 outputs (2.8x), and
-// both lose to conv_wave.hip's L2-fed fragments.  What would change it: one window per frame in a ring over t (1x), 256
-// positions per stage for the spatial layers (1.45x), or rows staged through registers (global loads + ds_write) instead
-// of LDS-DMA.  Kept: correct for every shape it covers (tests/test_conv_rows_gpu.py), selectable for A/B runs.
+// ablations say (SF_CONV_ROWS_DBG, true kernel durations by rocprofv3): with loads, MFMAs and stores all switched off a
+// launch keeps 40 .. 50 % of its time, and neither the ring depth (2 .. 8 steps in flight) nor the number of workgroups
+// moves it — it is the step SKELETON: ~100 .. 400 instructions per wavefront and step (piece addressing, the validity
+// bits' three divisions by multiplication, cursor, counted wait, barrier, epilogue) around 4 .. 48 MFMAs, issued by ONE
+// wavefront per SIMD wherever the windows + weights need > 80 KB of LDS, so every instruction's latency is exposed.
+// It is NOT the LDS-DMA path: tools/microbench/lds_delivery.hip measures 7.2 TB/s (HBM) .. 14 TB/s (L2) of contiguous
+// 1 KiB direct-to-LDS pieces, the same as register loads (profiles/r06_lds_delivery.txt).  What would change it: 256
+// positions per stage (four column tiles per wavefront: a quarter of the skeleton per position, and 1.45x instead of
+// 2.8x halo rows for 1x3x3), a ring over t for 3x1x1 (one window per frame instead of three: a third of the LDS, two
+// workgroups per CU), validity bits advanced incrementally.  Kept: correct for every shape it covers
+// (tests/test_conv_rows_gpu.py), selectable for A/B runs.
 int g_crows_enable = 1;
 
 int crows_level() {
