@@ -326,7 +326,7 @@ PW_SHAPES = [
     ("pw_512_320", 512, 320, (3, 4, 14, 14)),
     ("pw_1024_256", 1024, 256, (3, 4, 14, 13)),
     ("pw_80_72", 80, 72, (3, 3, 17, 19)),
-    ("pw_320_48", 320, 48, (2, 3, 21, 19)),   # 256 x 64 tile (round 6), three quarters of its columns used
+    ("pw_320_64", 320, 64, (2, 3, 21, 19)),   # 256 x 64 tile (round 6) under a 20-step reduction, ragged rows
 ]
 
 
