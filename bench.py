@@ -235,6 +235,22 @@ def cpu_baseline(workload, cfg, model, train, device=None, hip_train_step=None, 
              "sample": "oracle (torch CPU restatement of the reference), same model / clip shape: " + sample}, parity)
 
 
+GATED = (("fwd_max_rel_err", 1e-3), ("fwd_logits_max_rel_err", 1e-3), ("bwd_median_rel_err", 1e-3))
+
+
+def parity_gate(res):
+    """The violations that make bench.py exit 3 (the line is printed either way): the SEEDED state's forward — eval
+    probabilities and train-mode logits — and its typical parameter gradient against the oracle, north_star's 1e-3.
+    Deterministic figures with a 4x margin (2.2e-6, 4.5e-6, 2.6e-4 on cfg #3).  Not gated: bwd_max_rel_err (single
+    ill-conditioned parameters sit at the tolerance on the oracle's own fp32-vs-fp64 error) and the trained
+    state's *_after_steps fields (they depend on how many steps a box's steady-state search ran)."""
+    out = []
+    for k, lim in GATED:
+        if k in res and not (res[k] <= lim):   # (NaN fails)
+            out.append("%s = %.3e > %.0e" % (k, res[k], lim))
+    return out
+
+
 def make_train_step(model, clips, labels, overlap_allreduce=True, lr=1e-3):
     """The benchmark's training step (the reference loop: tools/train_net.py:78-96) as a closure over resident clips:
     zero the flat gradient buffer, train-mode forward, cross-entropy, backward through the tape (parameter gradients
@@ -1006,11 +1022,7 @@ def main():
     #      DESIGN "Parity" — sit at the tolerance on the oracle's own fp32-vs-fp64 error)
     gate = []
     if rank == 0:
-        # (gated: the SEEDED state's forward and typical gradient — deterministic figures with a 4x margin; the trained
-        #  state's *_after_steps fields depend on how many steps a box's steady-state search ran and are reported only)
-        for k, lim in (("fwd_max_rel_err", 1e-3), ("fwd_logits_max_rel_err", 1e-3), ("bwd_median_rel_err", 1e-3)):
-            if k in res and not (res[k] <= lim):
-                gate.append("%s = %.3e > %.0e" % (k, res[k], lim))
+        gate = parity_gate(res)
         res["parity_gate"] = "pass" if not gate else "FAIL: " + "; ".join(gate)
     if dist.is_initialized():
         dist.destroy_process_group()

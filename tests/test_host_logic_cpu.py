@@ -215,3 +215,20 @@ def test_rank_cpu_sets_follow_the_pci_address_not_the_render_minor(tmp_path, mon
     # no KFD topology at all (this container): even split
     assert bench.rank_cpu_sets(2, str(tmp_path / "nothing")) == [(-1, [0, 1, 2, 3]), (-1, [4, 5, 6, 7])]
     assert bench._fmt_cpulist([0, 1, 2, 3, 8, 9, 12]) == "0-3,8-9,12"
+
+
+def test_bench_parity_gate_contract():
+    """bench.py exits non-zero (after printing its line) exactly when the seeded state's forward or typical gradient
+    leaves north_star's 1e-3; worst single gradients and the trained-state fields are reported, not gated."""
+    import math
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    ok = {"fwd_max_rel_err": 2.2e-6, "fwd_logits_max_rel_err": 4.5e-6, "bwd_median_rel_err": 2.6e-4,
+          "bwd_max_rel_err": 1.04e-3, "bwd_median_rel_err_after_steps": 1.2e-3, "bwd_median_rel_err_vs_fp64": 2e-4}
+    assert bench.parity_gate(ok) == []
+    assert bench.parity_gate({}) == []                      # eval-only / --no-cpu-baseline lines carry no parity fields
+    for k in ("fwd_max_rel_err", "fwd_logits_max_rel_err", "bwd_median_rel_err"):
+        bad = dict(ok, **{k: 1.5e-3})
+        assert len(bench.parity_gate(bad)) == 1 and k in bench.parity_gate(bad)[0]
+        assert len(bench.parity_gate(dict(ok, **{k: math.nan}))) == 1
