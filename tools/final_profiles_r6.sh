@@ -1,4 +1,6 @@
 # round 6 evidence set -> gpurun_out/final_r6 (copy what is to be judged into profiles/ as r06_*).
+# NOTE (round 6): this full list lost its GPU box six minutes in; the round's evidence came from tools/final_profiles_r6_lean.sh
+# (short, bounded commands only).  Kept for the command list; prefer the lean script.
 # gpurun -- bash tools/final_profiles_r6.sh     (the FIRST command is the driver's, on the fresh box)
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/final_r6; mkdir -p $O
 cd $R
