@@ -187,3 +187,14 @@ def test_launch_planning_queries_are_host_only_and_fill_the_chip():
     assert L.sf_attn_products_per_fp32(128) == 0 and L.sf_attn_products_per_fp32(16) == 0
     assert L.sf_attn_products_per_fp32(8) in (0, 6) and L.sf_attn_products_per_fp32(4) == 0
     assert L.sf_attn_fwd_ws_floats(0, N, 32) == 0 and L.sf_attn_fwd_ws_floats(B, N, 129) == 0
+
+
+def test_error_codes_match_header(repo_root):
+    """The binding's SF_E* constants are the header's (SF_ENOTTAKEN, round 6: "not this entry point's shape" — the only
+    code besides SF_EALIGN on which the binding falls back to a general entry point)."""
+    import sfhip
+    txt = open(os.path.join(repo_root, "include", "sfhip.h")).read()
+    codes = {m.group(1): int(m.group(2)) for m in re.finditer(r"#define (SF_E[A-Z]+) \((-\d+)\)", txt)}
+    assert codes == {"SF_EINVAL": sfhip.SF_EINVAL, "SF_EALIGN": sfhip.SF_EALIGN, "SF_ELAUNCH": sfhip.SF_ELAUNCH,
+                     "SF_ENOTTAKEN": sfhip.SF_ENOTTAKEN}
+    assert set(sfhip._ERR) == set(codes.values())
