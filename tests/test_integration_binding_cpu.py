@@ -303,3 +303,29 @@ def test_against_the_real_reference_tree(tmp_path):
     p = subprocess.run([sys.executable, "-c", code], env=env, cwd=str(tmp_path), stdout=subprocess.PIPE,
                        stderr=subprocess.PIPE, universal_newlines=True, timeout=600)
     assert p.returncode == 0 and "OK" in p.stdout, p.stderr[-3000:]
+
+
+def test_namesake_with_a_missing_dependency_warns_and_keeps_this_repos_names(tmp_path):
+    """A reference namesake whose own third-party import is missing (cv2, fvcore ... in a bare environment) is skipped
+    with a RuntimeWarning; the names this repo defines are there, the ones only the namesake defines are not."""
+    _write_tree(tmp_path)
+    with open(os.path.join(str(tmp_path), "slowfast", "utils", "misc.py"), "w") as f:
+        f.write("import a_module_that_is_not_installed_anywhere\ndef launch_job(cfg, init_method, func, daemon=False):\n    return 1\n")
+    code = textwrap.dedent("""
+        import warnings
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            import slowfast.utils.misc as misc
+        msgs = [str(x.message) for x in w if issubclass(x.category, RuntimeWarning)]
+        assert any("not chained" in m and "a_module_that_is_not_installed_anywhere" in m for m in msgs), msgs
+        assert hasattr(misc, "frozen_bn_stats") and hasattr(misc, "aggregate_sub_bn_stats")
+        assert not hasattr(misc, "launch_job") and getattr(misc, "__chained_from__", None) is None
+        import slowfast.utils.lr_policy as lp        # the rest of the other tree is still there
+        assert lp.get_lr_at_epoch is not None
+        print("OK")
+        """)
+    env = {k: v for k, v in os.environ.items() if k != "PYTHONPATH"}
+    env.update({"PYTHONPATH": PKG + os.pathsep + str(tmp_path), "PYTHONDONTWRITEBYTECODE": "1"})
+    p = subprocess.run([sys.executable, "-c", code], env=env, cwd="/", stdout=subprocess.PIPE,  # (not tmp_path: -c puts the cwd first)
+                       stderr=subprocess.PIPE, universal_newlines=True, timeout=300)
+    assert p.returncode == 0 and "OK" in p.stdout, p.stderr[-3000:]
