@@ -889,6 +889,7 @@ int sf_conv_bxw_tune(int value);              // conv_bx.hip
 int sf_wgrad_rows_tune(int value);            // conv_wgrad_rows.hip
 int sf_conv_pw_tune(int value);               // conv_bx.hip
 int sf_conv_rows_tune(int value);             // conv_rows.hip
+int sf_wgrad_tring_tune(int value);           // conv_wgrad_rows.hip
 
 // Runtime knobs for microbenchmarks / A-B runs (not used by the model code).
 int sf_dwm_tune(int value);  // dwconv_march.hip
@@ -898,6 +899,7 @@ extern "C" int sf_conv_tune(int knob, int value) {
   if (knob == 20) return sf_wgrad_rows_tune(value);
   if (knob == 21) return sf_conv_pw_tune(value);
   if (knob == 22) return sf_conv_rows_tune(value);
+  if (knob == 23) return sf_wgrad_tring_tune(value);
   if (knob >= 10) return sf_wgrad_wave_tune(knob, value);
   if (knob == 0) g_enable = value;
   else if (knob == 1) g_force_cfg = value;

@@ -219,6 +219,194 @@ __global__ __launch_bounds__(256) void conv_wgrad_rows_kernel(const RowsArgs p) 
   }
 }
 
+// ---- 3x1x1 layers as a RING OVER t ---------------------------------------------------------------------------------------
+// The rows kernel above stages, for a 3x1x1 layer, three windows of x per run of positions (rows m - HW, m, m + HW): every
+// x row travels HBM/L2 -> LDS three times, and the launch is bound by exactly that traffic (3x1x1 32 -> 8 at 802 816
+// positions: 334 MB in 77 us, profiles/r05_conv_per_shape.txt rows at 0.12 .. 0.21 of their operands' time).  Here a
+// workgroup owns a COLUMN — one clip, one block of L positions of the frame — and walks a segment of t: per step it loads
+// frame t + 1 + PD of x once (and dz of frame t + PD), keeps the frames t - 1, t, t + 1 in a ring of 3 + PD LDS slots, and
+// multiplies dz[t] with all three — every x row is read once (+ one halo frame at either end of a segment).  Frames
+// outside the clip and rows past the frame are out-of-range offsets: they land as zeros, so the loop needs NO validity
+// masks.  Loads are LDS-DMA pieces, PD steps ahead, behind a counted s_waitcnt vmcnt (every load of the loop is an
+// LDS-DMA and the loop stores nothing: the count is exact), raw s_barrier.
+struct TringArgs {
+  sf_conv_desc d;
+  const float* x;
+  const float* dz;
+  float* part;           // [S][Cout][3][cin_pad], S = workgroups along x
+  int dz_cs, dz_coff;
+  int L, nhb, nseg, tseg, PD;  // positions per block, blocks per frame, t segments, frames per segment, prefetch distance
+  int nb_ci, HW;
+  unsigned x_bytes, z_bytes;
+};
+
+__device__ __forceinline__ void tring_vmwait(int n) {
+#define TR_VM(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); break;
+  switch (n) {
+    TR_VM(0) TR_VM(1) TR_VM(2) TR_VM(3) TR_VM(4) TR_VM(5) TR_VM(6) TR_VM(7) TR_VM(8) TR_VM(9) TR_VM(10) TR_VM(11)
+    TR_VM(12) TR_VM(13) TR_VM(14) TR_VM(15) TR_VM(16) TR_VM(17) TR_VM(18) TR_VM(19) TR_VM(20)
+    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+  }
+#undef TR_VM
+}
+
+template <int NCO, int ZW, int NCI, int XW>
+__global__ __launch_bounds__(256) void conv_wgrad_tring_kernel(const TringArgs p) {
+  constexpr int BCO = 16 * NCO, BCI = 16 * NCI;
+  constexpr int zq_sh = (ZW == 8) ? 1 : (ZW == 16 ? 2 : 3);  // log2(16-byte chunks per row)
+  constexpr int xq_sh = (XW == 8) ? 1 : (XW == 16 ? 2 : 3);
+  extern __shared__ __attribute__((aligned(16))) float rows_smem[];
+  const sf_conv_desc& d = p.d;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int unit = blockIdx.x;
+  const int seg = unit % p.nseg, col = unit / p.nseg;
+  const int hb = col % p.nhb, n = col / p.nhb;
+  const int bco = blockIdx.y / p.nb_ci, bci = blockIdx.y - bco * p.nb_ci;
+  const int co0 = bco * BCO, ci0 = bci * BCI;
+  const int L = p.L, PD = p.PD, T = d.To;
+  const int t0 = seg * p.tseg, t1 = (t0 + p.tseg < T) ? t0 + p.tseg : T;
+  const int NXS = 3 + PD, NZS = 1 + PD;             // ring slots
+  const int xslot = L * XW, zslot = L * ZW;         // floats
+  float* const xring = rows_smem;
+  float* const zring = rows_smem + NXS * xslot;
+  const int nxb = xslot >> 8, nzb = zslot >> 8;     // 1 KiB pieces
+  const __amdgpu_buffer_rsrc_t x_rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t z_rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.dz, 0, p.z_bytes, 0x00020000);
+  const int r_base = hb * L;                        // first row of the block within its frame
+  // pieces this wavefront issues per step (x frame + dz frame): wave, wave + 4, ...
+  const int nper = ((nxb > wave) ? (nxb - wave + 3) / 4 : 0) + ((nzb > wave) ? (nzb - wave + 3) / 4 : 0);
+
+  // frame f of x into ring slot (f + 1) % NXS (f >= -1); frame t of dz into slot t % NZS; f / t outside their ranges: zeros
+  auto issue = [&](int fx, int xs, int tz, int zs) {
+    const bool fok = (unsigned)fx < (unsigned)T && fx <= t1;  // (frames past the segment's halo are never read)
+    const long frow = ((long)n * T + fx) * p.HW + r_base;
+    for (int b = wave; b < nxb; b += 4) {
+      const int c = (b << 6) + lane;
+      const int row = c >> xq_sh, colx = (c - (row << xq_sh)) << 2;
+      unsigned vo = ROWS_OOB;
+      if (fok && r_base + row < p.HW && ci0 + colx < d.Cin)
+        vo = ((unsigned)(frow + row) * (unsigned)d.in_cs + (unsigned)(d.in_coff + ci0 + colx)) << 2;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rs, (lds_void*)(xring + xs * xslot + (b << 8)), 16, vo, 0, 0, 0);
+    }
+    const bool tok = tz < t1;
+    const long zrow = ((long)n * T + tz) * p.HW + r_base;
+    for (int b = wave; b < nzb; b += 4) {
+      const int c = (b << 6) + lane;
+      const int row = c >> zq_sh, colz = (c - (row << zq_sh)) << 2;
+      unsigned vo = ROWS_OOB;
+      if (tok && r_base + row < p.HW && co0 + colz < d.Cout)
+        vo = ((unsigned)(zrow + row) * (unsigned)p.dz_cs + (unsigned)(p.dz_coff + co0 + colz)) << 2;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(z_rs, (lds_void*)(zring + zs * zslot + (b << 8)), 16, vo, 0, 0, 0);
+    }
+  };
+
+  f32x4 acc[3][NCO][NCI];
+#pragma unroll
+  for (int t = 0; t < 3; ++t)
+#pragma unroll
+    for (int i = 0; i < NCO; ++i)
+#pragma unroll
+      for (int j = 0; j < NCI; ++j) acc[t][i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const int m16 = lane & 15, k4 = lane >> 4;
+
+  // prologue: x frames t0 - 1, t0 (alone, without dz), then per prefetch step one x frame + one dz frame, so that
+  // every "step" of loads has the same number of pieces except the first two (drained by the first wait: see below)
+  int xs_next = 0, zs_next = 0;                     // slots of the next frames to issue
+  int fx_next = t0 - 1, tz_next = t0;
+  {
+    // x(t0 - 1), x(t0): two x-only issues
+    for (int k = 0; k < 2; ++k) {
+      const bool fok = (unsigned)fx_next < (unsigned)T;
+      const long frow = ((long)n * T + fx_next) * p.HW + r_base;
+      for (int b = wave; b < nxb; b += 4) {
+        const int c = (b << 6) + lane;
+        const int row = c >> xq_sh, colx = (c - (row << xq_sh)) << 2;
+        unsigned vo = ROWS_OOB;
+        if (fok && r_base + row < p.HW && ci0 + colx < d.Cin)
+          vo = ((unsigned)(frow + row) * (unsigned)d.in_cs + (unsigned)(d.in_coff + ci0 + colx)) << 2;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rs, (lds_void*)(xring + xs_next * xslot + (b << 8)), 16, vo, 0, 0, 0);
+      }
+      ++fx_next;
+      if (++xs_next == NXS) xs_next = 0;
+    }
+    // x(t0 + 1 .. t0 + PD) with dz(t0 .. t0 + PD - 1): the loads of steps t0 .. t0 + PD - 1
+    for (int k = 0; k < PD; ++k) {
+      issue(fx_next, xs_next, tz_next, zs_next);
+      ++fx_next; ++tz_next;
+      if (++xs_next == NXS) xs_next = 0;
+      if (++zs_next == NZS) zs_next = 0;
+    }
+  }
+  int xs_lo = 0;   // ring slot of frame t - 1
+  int zs_cur = 0;  // ring slot of dz frame t
+  for (int t = t0; t < t1; ++t) {
+    // frames t - 1, t, t + 1 of x and frame t of dz have landed when only the loads of the PD - 1 younger steps remain
+    tring_vmwait((PD - 1) * nper);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    issue(fx_next, xs_next, tz_next, zs_next);       // x(t + 1 + PD), dz(t + PD): the loads of step t + PD
+    ++fx_next; ++tz_next;
+    if (++xs_next == NXS) xs_next = 0;
+    if (++zs_next == NZS) zs_next = 0;
+    __builtin_amdgcn_sched_barrier(0);
+    const float* const zs = zring + zs_cur * zslot;
+    const float* xs[3];
+    {
+      int s0 = xs_lo;
+#pragma unroll
+      for (int kt = 0; kt < 3; ++kt) {
+        xs[kt] = xring + s0 * xslot;
+        if (++s0 == NXS) s0 = 0;
+      }
+    }
+    const int ngroups = L >> 2;
+    for (int g = wave; g < ngroups; g += 4) {
+      const int pp = 4 * g + k4;
+      float a[NCO];
+#pragma unroll
+      for (int i = 0; i < NCO; ++i) a[i] = zs[pp * ZW + 16 * i + m16];
+      float bv[3][NCI];
+#pragma unroll
+      for (int kt = 0; kt < 3; ++kt)
+#pragma unroll
+        for (int j = 0; j < NCI; ++j) bv[kt][j] = xs[kt][pp * XW + 16 * j + m16];
+#pragma unroll
+      for (int kt = 0; kt < 3; ++kt)
+#pragma unroll
+        for (int i = 0; i < NCO; ++i)
+#pragma unroll
+          for (int j = 0; j < NCI; ++j)
+            acc[kt][i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], bv[kt][j], acc[kt][i][j], 0, 0, 0);
+    }
+    if (++xs_lo == NXS) xs_lo = 0;
+    if (++zs_cur == NZS) zs_cur = 0;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the tail's (out-of-range) loads still write zeros into the rings
+  // cross-wavefront sum, tap by tap (the rings are free now)
+  float* const red = rows_smem;  // [4][BCO][BCI]
+  float* const base = p.part + (long)unit * d.Cout * 3 * d.cin_pad;
+#pragma unroll
+  for (int t = 0; t < 3; ++t) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NCO; ++i)
+#pragma unroll
+      for (int j = 0; j < NCI; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[(wave * BCO + 16 * i + 4 * k4 + r) * BCI + 16 * j + m16] = acc[t][i][j][r];
+    __syncthreads();
+    for (int e = tid; e < BCO * BCI; e += 256) {
+      const int co = co0 + e / BCI, ci = ci0 + e % BCI;
+      if (co < d.Cout && ci < d.cin_pad) {
+        const float v = (red[e] + red[BCO * BCI + e]) + (red[2 * BCO * BCI + e] + red[3 * BCO * BCI + e]);
+        base[((long)co * 3 + t) * d.cin_pad + ci] = (ci < d.Cin) ? v : 0.f;
+      }
+    }
+  }
+}
+
 void magic(unsigned dv, unsigned* mul, unsigned* sh) {
   if (dv <= 1) { *mul = 0; *sh = 0; return; }
   unsigned l = 0;
@@ -295,6 +483,79 @@ bool rows_plan(const sf_conv_desc* d, RowsArgs* a) {
   return true;
 }
 
+int g_tring_enable = -1;  // sf_conv_tune(23, e): -1 = SF_WGRAD_TRING (default 1), 0 off, 1 on
+
+bool tring_enabled() {
+  static const int env_on = [] {
+    const char* e = getenv("SF_WGRAD_TRING");
+    return e ? atoi(e) : 1;
+  }();
+  return g_tring_enable < 0 ? env_on != 0 : g_tring_enable != 0;
+}
+
+// Schedule of the ring-over-t form for a 3x1x1 problem rows_plan accepted (a holds its widths); false = not taken.
+bool tring_plan(const sf_conv_desc* d, const RowsArgs& a, TringArgs* t, size_t* lds) {
+  if (!tring_enabled()) return false;
+  if (!(d->kT == 3 && d->kH == 1 && d->kW == 1)) return false;
+  const int HW = d->Hi * d->Wi, T = d->To, N = d->N;
+  if (T < 2 || HW < 32) return false;
+  const int bco = d->Cout <= 16 ? 16 : 32, bci = d->cin_pad <= 16 ? 16 : 32;
+  const int blocks = sf_cdiv(d->Cout, bco) * a.nb_ci;
+  // positions per block: 128 for large frames, 64 otherwise (fewer padded rows in the last block of a frame)
+  int L = (HW >= 1024 && HW % 128 < 64 && HW % 128 != 0) ? 64 : (HW >= 1024 ? 128 : 64);
+  if (L * a.xw * 4 < 1024 || L * a.zw * 4 < 1024) L = 128;    // whole 1 KiB pieces (8-float rows)
+  if ((L * a.xw) % 256 || (L * a.zw) % 256) return false;
+  const int nhb = sf_cdiv(HW, L);
+  // segments of t: ~768 workgroups over the channel blocks, at least 2 frames each, at most 1024 partials
+  int nseg = 1;
+  while (nseg * 2 <= T / 2 && (long)N * nhb * nseg * blocks < 600 && (long)N * nhb * nseg * 2 <= 1024) nseg *= 2;
+  const int tseg = sf_cdiv(T, nseg);
+  nseg = sf_cdiv(T, tseg);
+  const long S = (long)N * nhb * nseg;
+  if (S > 1024 || S < 1) return false;
+  t->d = *d;
+  t->L = L; t->nhb = nhb; t->nseg = nseg; t->tseg = tseg;
+  t->nb_ci = a.nb_ci; t->HW = HW;
+  t->x_bytes = a.x_bytes;
+  static const int pd_env = [] { const char* e = getenv("SF_WGRAD_TRING_PD"); return e ? atoi(e) : 2; }();
+  int PD = pd_env < 1 ? 1 : (pd_env > 3 ? 3 : pd_env);
+  size_t bytes;
+  for (;; --PD) {
+    bytes = ((size_t)(3 + PD) * L * a.xw + (size_t)(1 + PD) * L * a.zw) * sizeof(float);
+    if (bytes <= 76 * 1024 || PD == 1) break;
+  }
+  if (bytes > 150 * 1024) return false;
+  const size_t red = (size_t)4 * bco * bci * sizeof(float);
+  t->PD = PD;
+  *lds = bytes > red ? bytes : red;
+  return true;
+}
+
+template <int NCO, int ZW, int NCI, int XW>
+int launch_tring(const TringArgs& t, size_t lds, hipStream_t s) {
+  static SfLdsAttr attr;
+  if (!sf_ensure_dyn_lds(attr, reinterpret_cast<const void*>(conv_wgrad_tring_kernel<NCO, ZW, NCI, XW>), 152 * 1024))
+    return SF_ELAUNCH;
+  const int nb_co = sf_cdiv(t.d.Cout, 16 * NCO);
+  hipLaunchKernelGGL((conv_wgrad_tring_kernel<NCO, ZW, NCI, XW>), dim3(t.d.N * t.nhb * t.nseg, nb_co * t.nb_ci),
+                     dim3(256), lds, s, t);
+  SF_CHECK_LAUNCH();
+  return SF_OK;
+}
+
+template <int NCO, int ZW>
+int launch_tring_x(const TringArgs& t, int xw, size_t lds, hipStream_t s) {
+  if (xw == 8) return launch_tring<NCO, ZW, 1, 8>(t, lds, s);
+  if (xw == 16) return launch_tring<NCO, ZW, 1, 16>(t, lds, s);
+  return launch_tring<NCO, ZW, 2, 32>(t, lds, s);
+}
+
+int launch_tring_tiles(const TringArgs& t, int zw, int xw, size_t lds, hipStream_t s) {
+  if (zw == 8) return launch_tring_x<1, 8>(t, xw, lds, s);
+  if (zw == 16) return launch_tring_x<1, 16>(t, xw, lds, s);
+  return launch_tring_x<2, 32>(t, xw, lds, s);
+}
+
 template <int NTAP, int NCO, int ZW, int NCI, int XW>
 int launch_rows(const RowsArgs& a, hipStream_t s) {
   const size_t lds = (size_t)a.stage_floats * 8;
@@ -333,7 +594,16 @@ int sf_wgrad_rows_tune(int value) {
 // Split count of the rows kernel for this problem, 0 = not covered.
 int sf_wgrad_rows_splits(const sf_conv_desc* d) {
   RowsArgs a;
-  return rows_plan(d, &a) ? a.S : 0;
+  if (!rows_plan(d, &a)) return 0;
+  TringArgs t;
+  size_t lds;
+  if (tring_plan(d, a, &t, &lds)) return d->N * t.nhb * t.nseg;
+  return a.S;
+}
+
+int sf_wgrad_tring_tune(int value) {
+  g_tring_enable = value;
+  return SF_OK;
 }
 
 // 1 = not covered (the caller goes on to its other kernels), else SF_OK / an error.
@@ -346,6 +616,14 @@ int sf_wgrad_rows_try(const sf_conv_desc* d, const float* x, const float* dz, in
   if (zb >= 0x7fffffffL) return 1;
   a.z_bytes = (unsigned)zb;
   a.x = x; a.dz = dz; a.part = partial; a.dz_cs = dz_cs; a.dz_coff = dz_coff;
+  {
+    TringArgs t;
+    size_t lds;
+    if (tring_plan(d, a, &t, &lds)) {  // 3x1x1: every x frame once, through a ring over t
+      t.x = x; t.dz = dz; t.part = partial; t.dz_cs = dz_cs; t.dz_coff = dz_coff; t.z_bytes = a.z_bytes;
+      return launch_tring_tiles(t, a.zw, a.xw, lds, stream);
+    }
+  }
   const int ntap = d->kT * d->kH * d->kW;
   if (ntap == 1) return launch_rows_tiles<1>(a, stream);
   if (ntap == 3) return launch_rows_tiles<3>(a, stream);

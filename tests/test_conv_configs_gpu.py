@@ -35,7 +35,7 @@ def tune():
     L = sfhip.lib()
     yield L
     for knob, v in ((0, 1), (1, -1), (2, 0), (3, 0), (4, 1), (5, 0), (6, 1), (7, 1), (8, 0), (9, 1), (10, 1), (11, -1),
-                    (12, 0), (20, 1), (21, 1)):
+                    (12, 0), (20, 1), (21, 1), (22, 1), (23, -1)):
         L.sf_conv_tune(knob, v)
 
 
@@ -314,6 +314,44 @@ def test_small_channel_wgrad_rows_kernel(shape, sliced, tune):
     dwp0 = sfhip.conv_wgrad(xa, dya, cout, k, (1, 1, 1), p)
     assert _rel(sfhip.unpack_conv_weight_grad(dwp0, wt.shape), wd.grad) < 2e-6, name
     assert (s_on, s_off) != (0, 0)
+
+
+# ---- the ring over t of the 3x1x1 weight gradients (conv_wgrad_tring_kernel, round 6): several t segments per column,
+# 128- and 64-position blocks with a partly filled last block, frames at both ends of the clip, prefetch distance 1 / 2
+TRING_SHAPES = [
+    ("tr_32_8_hw1600", 32, 8, (3, 1, 1), (1, 0, 0), (2, 8, 40, 40)),
+    ("tr_64_16_hw784", 64, 16, (3, 1, 1), (1, 0, 0), (2, 6, 28, 28)),
+    ("tr_8_32_hw3136", 8, 32, (3, 1, 1), (1, 0, 0), (1, 4, 56, 56)),
+    ("tr_128_32_hw196", 128, 32, (3, 1, 1), (1, 0, 0), (3, 5, 14, 14)),
+    ("tr_16_8_T2", 16, 8, (3, 1, 1), (1, 0, 0), (4, 2, 23, 21)),
+]
+
+
+@pytest.mark.parametrize("shape", TRING_SHAPES, ids=[s[0] for s in TRING_SHAPES])
+def test_wgrad_ring_over_t(shape, tune):
+    import ctypes
+    import sfhip
+    name, cin, cout, k, p, dims = shape
+    x, wt, bias, dy = _case(shape)
+    xa, dya = _act(x), _act(dy)
+    wd = wt.double().requires_grad_(True)
+    F.conv3d(x.double(), wd, None, 1, p).backward(dy.double())
+    d = sfhip.ConvDesc(xa.N, xa.T, xa.H, xa.W, cin, xa.cs, xa.coff, dya.T, dya.H, dya.W, cout, 0, 0, 1, k[0], k[1], k[2],
+                       1, 1, 1, p[0], p[1], p[2], 1, 1, 1, (cin + 15) // 16 * 16, 0, 0, 0, 0)
+    assert tune.sf_conv_tune(23, 1) == 0
+    s_ring = tune.sf_conv_wgrad_splits(ctypes.byref(d))
+    a = sfhip.conv_wgrad(xa, dya, cout, k, (1, 1, 1), p)
+    b = sfhip.conv_wgrad(xa, dya, cout, k, (1, 1, 1), p)
+    assert torch.equal(a, b), "bit-reproducible"
+    assert _rel(sfhip.unpack_conv_weight_grad(a, wt.shape), wd.grad) < 2e-6, name
+    acc = torch.ones_like(wt)
+    sfhip.conv_wgrad(xa, dya, cout, k, (1, 1, 1), p, finish_into=(acc, cin, 0))
+    assert _rel(acc - 1.0, wd.grad) < 2e-6, name
+    assert tune.sf_conv_tune(23, 0) == 0
+    s_rows = tune.sf_conv_wgrad_splits(ctypes.byref(d))
+    c = sfhip.conv_wgrad(xa, dya, cout, k, (1, 1, 1), p)
+    assert _rel(sfhip.unpack_conv_weight_grad(c, wt.shape), wd.grad) < 2e-6, name
+    assert s_ring != s_rows and s_ring > 0, (s_ring, s_rows)   # the launcher really switched forms
 
 
 # ---- conv_pw_bx_kernel: pointwise layers on the bf16 pipe with the activations split in registers (sf_conv_tune(21, 2)
