@@ -502,7 +502,11 @@ bool tring_plan(const sf_conv_desc* d, const RowsArgs& a, TringArgs* t, size_t* 
   const int bco = d->Cout <= 16 ? 16 : 32, bci = d->cin_pad <= 16 ? 16 : 32;
   const int blocks = sf_cdiv(d->Cout, bco) * a.nb_ci;
   // positions per block: 128 for large frames, 64 otherwise (fewer padded rows in the last block of a frame)
-  int L = (HW >= 1024 && HW % 128 < 64 && HW % 128 != 0) ? 64 : (HW >= 1024 ? 128 : 64);
+  static const int l_env = [] { const char* e = getenv("SF_WGRAD_TRING_L"); return e ? atoi(e) : 0; }();
+  // positions per block: 64 (measured, profiles/r06_wgrad_tring_ab.txt: 128-position blocks 50.5 / 33.6 / 43.5 us where
+  // 64-position ones take 45.0 / 28.8 / 31.0 — more workgroups per CU, fewer padded rows in a frame's last block)
+  int L = 64;
+  if (l_env == 64 || l_env == 128) L = l_env;
   if (L * a.xw * 4 < 1024 || L * a.zw * 4 < 1024) L = 128;    // whole 1 KiB pieces (8-float rows)
   if ((L * a.xw) % 256 || (L * a.zw) % 256) return false;
   const int nhb = sf_cdiv(HW, L);
@@ -517,12 +521,13 @@ bool tring_plan(const sf_conv_desc* d, const RowsArgs& a, TringArgs* t, size_t* 
   t->L = L; t->nhb = nhb; t->nseg = nseg; t->tseg = tseg;
   t->nb_ci = a.nb_ci; t->HW = HW;
   t->x_bytes = a.x_bytes;
-  static const int pd_env = [] { const char* e = getenv("SF_WGRAD_TRING_PD"); return e ? atoi(e) : 2; }();
-  int PD = pd_env < 1 ? 1 : (pd_env > 3 ? 3 : pd_env);
+  static const int pd_env = [] { const char* e = getenv("SF_WGRAD_TRING_PD"); return e ? atoi(e) : 1; }();  // (1: deeper rings measured no faster)
+  int PD = pd_env < 1 ? 1 : (pd_env > 4 ? 4 : pd_env);
   size_t bytes;
   for (;; --PD) {
     bytes = ((size_t)(3 + PD) * L * a.xw + (size_t)(1 + PD) * L * a.zw) * sizeof(float);
-    if (bytes <= 76 * 1024 || PD == 1) break;
+    static const int cap_kb = [] { const char* e = getenv("SF_WGRAD_TRING_KB"); return e ? atoi(e) : 76; }();
+    if (bytes <= (size_t)cap_kb * 1024 || PD == 1) break;
   }
   if (bytes > 150 * 1024) return false;
   const size_t red = (size_t)4 * bco * bci * sizeof(float);
