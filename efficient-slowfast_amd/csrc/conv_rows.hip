@@ -49,6 +49,7 @@ struct CRowsArgs {
   int M, S, chunk;       // positions, workgroups along the positions, positions per workgroup (multiple of 64)
   int KB;                // channel blocks of XW floats per position stage
   int NB;                // stage buffers of the ring (NB - 1 steps in flight)
+  int nhb, nseg, tseg;   // ring over t (3x1x1): 64-position blocks per frame, t segments, frames per segment
   int dbg;               // SF_CONV_ROWS_DBG timing ablations (results invalid): 1 no loads, 2 no MFMA loop, 4 no stores
   int rows_needed;       // rows of a window that are read (64 + 2 halo); the rest of wrp is padding
   int HW, halo, wrp;     // frame size, halo rows of a 1x3x3 window, rows of one x window in LDS
@@ -434,6 +435,229 @@ __global__ __launch_bounds__(256) void conv_rows_kernel(const CRowsArgs p) {
   }
 }
 
+// ---- 3x1x1 layers as a RING OVER t ---------------------------------------------------------------------------------------
+// (as conv_wgrad_rows.hip's conv_wgrad_tring_kernel) A workgroup owns a COLUMN — one clip, one block of 64 positions of
+// the frame — and walks a segment of t: per step it loads frame t + 2 of x ONCE into a ring of four LDS slots and
+// multiplies the frames t - 1, t, t + 1 with the three taps' weights — a third of the staged bytes of the window form
+// above, a third of its LDS (two .. four workgroups per CU), and NO validity bits: frames outside the clip and rows past
+// the frame are out-of-range offsets that land as zeros.  Everything else (swizzled rows, weights in LDS, swapped-operand
+// MFMAs, raw LDS reads behind counted waits, epilogue with scale / bias / residual / activation / statistics) is the
+// kernel above.  One step in flight (deeper rings measured no faster for the weight gradient's ring).
+template <int XW, int NCT, bool RES>
+__global__ __launch_bounds__(256) void conv_rows_tring_kernel(const CRowsArgs p) {
+  constexpr int BCO = 16 * NCT;
+  constexpr int NQ = XW >= 16 ? XW / 16 : 1;
+  constexpr int XSH = (XW == 8) ? 1 : (XW == 16 ? 2 : (XW == 32 ? 3 : 4));
+  constexpr int NXB = CR_L * XW / 256;             // 1 KiB pieces of a frame's block
+  constexpr int MAXP = (NXB + 3) / 4;
+  constexpr int SLOT = CR_L * XW;                  // floats
+  extern __shared__ __attribute__((aligned(16))) float cr_smem[];
+  const sf_conv_desc& d = p.d;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 15, g = lane >> 4;
+  const int co0 = blockIdx.y * BCO;
+  const int unit = blockIdx.x;
+  const int seg = unit % p.nseg, col = unit / p.nseg;
+  const int hb = col % p.nhb, n = col / p.nhb;
+  const int T = d.To;
+  const int t0 = seg * p.tseg, t1 = (t0 + p.tseg < T) ? t0 + p.tseg : T;
+  const int r_base = hb * CR_L;
+  const int krow = 3 * XW;
+  float* const Wl = cr_smem;
+  const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)cr_smem;
+  const unsigned ring_base = lds_base + (unsigned)((BCO * p.wstride) << 2);
+  const __amdgpu_buffer_rsrc_t x_rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
+  const int nper = (NXB > wave) ? (NXB - wave + 3) / 4 : 0;   // pieces this wavefront issues per frame
+
+  unsigned lc[MAXP];
+#pragma unroll
+  for (int i = 0; i < MAXP; ++i) {
+    const int b = wave + 4 * i;
+    const int f = (b << 6) + lane;
+    const int row = f >> XSH, slot = f - (row << XSH);
+    const int c4 = 4 * (slot ^ cr_swz<XW>(row));
+    lc[i] = (b < NXB && r_base + row < p.HW && c4 < d.Cin) ? (unsigned)((row * d.in_cs + c4) << 2) : CR_OOB;
+  }
+  auto issue = [&](int fx, int slot) {
+    const bool fok = (unsigned)fx < (unsigned)T && fx >= t0 - 1 && fx <= t1 && !(p.dbg & 1);
+    const unsigned base = fok ? (unsigned)(((((long)n * T + fx) * p.HW + r_base) * d.in_cs + d.in_coff) << 2) : CR_OOB;
+    const unsigned lds0 = ring_base + (unsigned)((slot * SLOT) << 2);
+#pragma unroll
+    for (int i = 0; i < MAXP; ++i) {
+      const int b = wave + 4 * i;
+      if (b < NXB)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(
+            x_rs, (lds_void*)(__attribute__((address_space(3))) char*)(uintptr_t)(lds0 + (unsigned)(b << 10)), 16,
+            base + lc[i], 0, 0, 0);
+    }
+  };
+
+  {  // weights: rows co0 .. co0 + BCO - 1, [tap][XW channels], zero where the layer ends (and in the pad)
+    const int r4 = p.wstride >> 2;
+    for (int idx = tid; idx < BCO * r4; idx += 256) {
+      const int r = idx / r4, e = (idx - r * r4) << 2;
+      const int tap = e / XW, c = e - tap * XW;
+      const int co = co0 + r;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (e < krow && co < d.Cout && c + 3 < d.cin_pad)
+        v = *reinterpret_cast<const f32x4*>(p.w + ((long)co * 3 + tap) * d.cin_pad + c);
+      *reinterpret_cast<f32x4*>(Wl + r * p.wstride + e) = v;
+    }
+  }
+  f32x4 sk[NCT], s1[NCT], s2[NCT], esc[NCT], ebi[NCT];
+  float cnt = 0.f;
+  bool have_k = false;
+#pragma unroll
+  for (int ct = 0; ct < NCT; ++ct) {
+    sk[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    s1[ct] = sk[ct];
+    s2[ct] = sk[ct];
+    const int nn = co0 + 16 * ct + 4 * g;
+    esc[ct] = (f32x4){1.f, 1.f, 1.f, 1.f};
+    ebi[ct] = sk[ct];
+    if (nn < d.Cout) {
+      if (p.scale) esc[ct] = *reinterpret_cast<const f32x4*>(p.scale + nn);
+      if (p.bias) ebi[ct] = *reinterpret_cast<const f32x4*>(p.bias + nn);
+    }
+  }
+  const unsigned a_lane = lds_base + (unsigned)((j * p.wstride + 4 * g) << 2);
+  const unsigned wrow16 = (unsigned)((16 * p.wstride) << 2);
+  const int R = 16 * wave + j;                                  // this lane's row within the block
+  __amdgpu_buffer_rsrc_t r_rs = x_rs;
+  if constexpr (RES) r_rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.res, 0, p.res_bytes, 0x00020000);
+  const bool rok = r_base + R < p.HW;
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+
+  issue(t0 - 1, 0);
+  issue(t0, 1);
+  issue(t0 + 1, 2);
+  int s_lo = 0;  // ring slot of frame t - 1; frame t + 2 goes to (s_lo + 3) & 3
+  for (int t = t0; t < t1; ++t) {
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // frame t + 1 (issued a step ago) has landed
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    const long m = ((long)n * T + t) * p.HW + r_base + R;
+    f32x4 rv[NCT];
+    if constexpr (RES) {
+#pragma unroll
+      for (int ct = 0; ct < NCT; ++ct) {
+        const int nn = co0 + 16 * ct + 4 * g;
+        const unsigned ro = (rok && nn < d.Cout) ? ((unsigned)m * (unsigned)d.res_cs + (unsigned)(d.res_coff + nn)) << 2 : CR_OOB;
+        asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(rv[ct]) : "v"(ro), "s"(r_rs) : "memory");
+      }
+    }
+    issue(t + 2, (s_lo + 3) & 3);
+    __builtin_amdgcn_sched_barrier(0);
+    f32x4 acc[NCT], acc2[NCT];
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) {
+      acc[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      acc2[ct] = acc[ct];
+    }
+    if (!(p.dbg & 2)) {
+      auto fetch = [&](int it, CrFrag<NCT>& f) {
+        const int tap = it / NQ, q = it - tap * NQ;
+        const int slot = (s_lo + 1 + p.sg * (tap - 1)) & 3;   // frame t + sg (tap - 1)
+        const int c = 4 * q + g;
+        f.b = cr_lds128(ring_base + (unsigned)((slot * SLOT + R * XW + ((c ^ cr_swz<XW>(R)) << 2)) << 2));
+        const unsigned ao = a_lane + (unsigned)((tap * XW + 16 * q) << 2);
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) f.a[ct] = cr_lds128(ao + ct * wrow16);
+      };
+      constexpr int NI = 3 * NQ;
+      CrFrag<NCT> fr[2];
+      fetch(0, fr[0]);
+#pragma unroll
+      for (int it = 0; it < NI; ++it) {
+        CrFrag<NCT>& f = fr[it & 1];
+        if (it + 1 < NI) {
+          fetch(it + 1, fr[(it + 1) & 1]);
+          cr_wait<1 + NCT, NCT>(f);
+        } else {
+          cr_wait<0, NCT>(f);
+        }
+        f32x4 b = f.b;
+        if (XW < 16 && g >= XW / 4) b = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) {
+          acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.a[ct][0], b[0], acc[ct], 0, 0, 0);
+          acc2[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.a[ct][1], b[1], acc2[ct], 0, 0, 0);
+          acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.a[ct][2], b[2], acc[ct], 0, 0, 0);
+          acc2[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.a[ct][3], b[3], acc2[ct], 0, 0, 0);
+        }
+      }
+    }
+    // ---- epilogue of frame t: lane = position m, channels co0 + 16 ct + 4 g .. + 3
+    const bool first_ok = r_base + 16 * wave < p.HW;  // this wavefront's first row of the block exists
+    if constexpr (RES) {
+      cr_vmwait(nper);  // the residual loads sit in front of this step's LDS-DMA pieces
+#pragma unroll
+      for (int ct = 0; ct < NCT; ++ct) asm volatile("" : "+v"(rv[ct]));
+    }
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) {
+      const int nn = co0 + 16 * ct + 4 * g;
+      const bool nok = nn < d.Cout;
+      f32x4 v = (acc[ct] + acc2[ct]) * esc[ct] + ebi[ct];
+      if constexpr (RES) v += rv[ct];
+      if (rok && nok && !(p.dbg & 4)) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = sf_act(v[r], d.act);
+        *reinterpret_cast<f32x4*>(p.out + m * d.out_cs + d.out_coff + nn) = v;
+      }
+      if (p.stats) {
+        if (!have_k && first_ok) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float k0 = __builtin_amdgcn_readlane(v[r], 0), k1 = __builtin_amdgcn_readlane(v[r], 16);
+            const float k2 = __builtin_amdgcn_readlane(v[r], 32), k3 = __builtin_amdgcn_readlane(v[r], 48);
+            sk[ct][r] = g == 0 ? k0 : (g == 1 ? k1 : (g == 2 ? k2 : k3));
+          }
+        }
+        if (rok) {
+          const f32x4 dv = v - sk[ct];
+          s1[ct] += dv;
+          s2[ct] += dv * dv;
+        }
+      }
+    }
+    if (p.stats) {
+      if (first_ok) have_k = true;
+      if (rok) cnt += 1.f;
+    }
+    s_lo = (s_lo + 1) & 3;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (p.stats) {
+#pragma unroll
+    for (int off = 1; off < 16; off <<= 1) {
+      cnt += __shfl_xor(cnt, off, 64);
+#pragma unroll
+      for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          s1[ct][r] += __shfl_xor(s1[ct][r], off, 64);
+          s2[ct][r] += __shfl_xor(s2[ct][r], off, 64);
+        }
+    }
+    if (j == 0) {
+      const long part = (long)unit * 4 + wave;
+#pragma unroll
+      for (int ct = 0; ct < NCT; ++ct) {
+        const int nn = co0 + 16 * ct + 4 * g;
+        if (nn < d.Cout) {
+          float* const o = p.stats + (part * (d.Cout >> 2) + (nn >> 2)) * 16;
+          *reinterpret_cast<f32x4*>(o) = (f32x4){cnt, cnt, cnt, cnt};
+          *reinterpret_cast<f32x4*>(o + 4) = sk[ct];
+          *reinterpret_cast<f32x4*>(o + 8) = s1[ct];
+          *reinterpret_cast<f32x4*>(o + 12) = s2[ct];
+        }
+      }
+    }
+  }
+}
+
 void cr_magic(unsigned dv, unsigned* mul, unsigned* sh) {
   if (dv <= 1) { *mul = 0; *sh = 0; return; }
   unsigned l = 0;
@@ -467,7 +691,7 @@ int crows_level() {
   return g_crows_enable == 1 ? env : g_crows_enable;
 }
 
-struct CRowsPlan { int ntap, xw, nct, nby; size_t lds; };
+struct CRowsPlan { int ntap, xw, nct, nby; size_t lds; bool ring; };
 
 // Geometry + schedule for a problem this kernel covers; false = leave it to the other dense kernels.
 bool crows_plan(const sf_conv_desc* d, CRowsArgs* a, CRowsPlan* pl) {
@@ -526,6 +750,24 @@ bool crows_plan(const sf_conv_desc* d, CRowsArgs* a, CRowsPlan* pl) {
   if (((wps * a->wrp * xw) >> 10) > 24) return false;                   // at most 6 pieces per wavefront and step
   if ((nb - 1) * (((wps * a->wrp * xw) >> 12) + 4) > 48) return false;  // the counted wait's immediate
   pl->ntap = ntap; pl->xw = xw; pl->nct = nct; pl->nby = sf_cdiv(d->Cout, 16 * nct);
+  pl->ring = false;
+  a->nhb = a->nseg = a->tseg = 0;
+  static const int ring_env = [] { const char* e = getenv("SF_CONV_ROWS_RING"); return e ? atoi(e) : 1; }();
+  if (ntap == 3 && a->KB == 1 && ring_env && d->To >= 2 && a->HW >= 32) {  // 3x1x1 over <= 64 channels: the ring over t
+    const int nhb = sf_cdiv(a->HW, CR_L);
+    int nseg = 1;
+    while (nseg * 2 <= d->To / 2 && (long)d->N * nhb * nseg * pl->nby < 600 && (long)d->N * nhb * nseg * 2 <= 1024) nseg *= 2;
+    const int tseg = sf_cdiv(d->To, nseg);
+    nseg = sf_cdiv(d->To, tseg);
+    const long units = (long)d->N * nhb * nseg;
+    const size_t ring_lds = wbytes + (size_t)4 * CR_L * xw * sizeof(float);
+    if (units <= 1024 && ring_lds <= 150 * 1024) {
+      pl->ring = true;
+      pl->lds = ring_lds;
+      a->nhb = nhb; a->nseg = nseg; a->tseg = tseg;
+      a->S = (int)units;
+    }
+  }
   cr_magic((unsigned)d->Wo, &a->w_mul, &a->w_sh);
   cr_magic((unsigned)d->Ho, &a->h_mul, &a->h_sh);
   cr_magic((unsigned)d->To, &a->t_mul, &a->t_sh);
@@ -539,7 +781,7 @@ bool crows_plan(const sf_conv_desc* d, CRowsArgs* a, CRowsPlan* pl) {
   if (S < 1) S = 1;
   long chunk = ((M + S - 1) / S + CR_L - 1) / CR_L * CR_L;
   S = (M + chunk - 1) / chunk;
-  a->S = (int)S;
+  if (!pl->ring) a->S = (int)S;  // (the ring's grid is its columns x t segments)
   a->chunk = (int)chunk;
   return true;
 }
@@ -577,6 +819,37 @@ int launch_crows_xw(const CRowsArgs& a, const CRowsPlan& pl, hipStream_t s) {
   if (pl.xw == 32) return launch_crows_ct<NTAP, 32>(a, pl, s);
   if constexpr (NTAP != 9) return launch_crows_ct<NTAP, 64>(a, pl, s);
   return 1;
+}
+
+template <int XW, int NCT>
+int launch_cring(const CRowsArgs& a, const CRowsPlan& pl, hipStream_t s) {
+  static SfLdsAttr attr, attr_res;
+  if (a.res) {
+    if (!sf_ensure_dyn_lds(attr_res, reinterpret_cast<const void*>(conv_rows_tring_kernel<XW, NCT, true>), 152 * 1024))
+      return SF_ELAUNCH;
+    hipLaunchKernelGGL((conv_rows_tring_kernel<XW, NCT, true>), dim3(a.S, pl.nby), dim3(256), pl.lds, s, a);
+  } else {
+    if (!sf_ensure_dyn_lds(attr, reinterpret_cast<const void*>(conv_rows_tring_kernel<XW, NCT, false>), 152 * 1024))
+      return SF_ELAUNCH;
+    hipLaunchKernelGGL((conv_rows_tring_kernel<XW, NCT, false>), dim3(a.S, pl.nby), dim3(256), pl.lds, s, a);
+  }
+  SF_CHECK_LAUNCH();
+  return SF_OK;
+}
+
+template <int XW>
+int launch_cring_ct(const CRowsArgs& a, const CRowsPlan& pl, hipStream_t s) {
+  if (pl.nct == 1) return launch_cring<XW, 1>(a, pl, s);
+  if (pl.nct == 2) return launch_cring<XW, 2>(a, pl, s);
+  if constexpr (XW <= 32) return launch_cring<XW, 4>(a, pl, s);
+  return 1;
+}
+
+int launch_cring_xw(const CRowsArgs& a, const CRowsPlan& pl, hipStream_t s) {
+  if (pl.xw == 8) return launch_cring_ct<8>(a, pl, s);
+  if (pl.xw == 16) return launch_cring_ct<16>(a, pl, s);
+  if (pl.xw == 32) return launch_cring_ct<32>(a, pl, s);
+  return launch_cring_ct<64>(a, pl, s);
 }
 
 }  // namespace
@@ -627,7 +900,8 @@ int sf_conv_rows_try(const sf_conv_desc* d, const float* in, const float* w_pack
   a.stats = want ? stats : nullptr;
   if (want) *stat_parts = 4 * a.S;
   int rc;
-  if (pl.ntap == 1) rc = launch_crows_xw<1>(a, pl, stream);
+  if (pl.ring) rc = launch_cring_xw(a, pl, stream);
+  else if (pl.ntap == 1) rc = launch_crows_xw<1>(a, pl, stream);
   else if (pl.ntap == 3) rc = launch_crows_xw<3>(a, pl, stream);
   else rc = launch_crows_xw<9>(a, pl, stream);
   if (rc != SF_OK && stat_parts) *stat_parts = 0;

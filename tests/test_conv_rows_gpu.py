@@ -26,7 +26,11 @@ SHAPES = [
     ("t_64_16", 64, 16, (3, 1, 1), (2, 7, 19, 17)),
     ("t_128_32", 128, 32, (3, 1, 1), (2, 5, 14, 13)),   # two channel blocks per position stage
     ("t_16_64", 16, 64, (3, 1, 1), (2, 5, 15, 14)),
-    ("t_8_16_T1", 8, 16, (3, 1, 1), (5, 1, 33, 31)),    # T = 1: both temporal neighbours outside
+    ("t_8_16_T1", 8, 16, (3, 1, 1), (5, 1, 33, 31)),    # T = 1: both temporal neighbours outside (window form)
+    ("t_32_8_ring", 32, 8, (3, 1, 1), (2, 8, 40, 40)),  # ring over t: several t segments, 25 blocks of 64 per frame
+    ("t_8_32_ring", 8, 32, (3, 1, 1), (1, 5, 56, 56)),
+    ("t_64_16_ring", 64, 16, (3, 1, 1), (2, 6, 28, 28)),  # 64-float rows
+    ("t_16_64_T2", 16, 64, (3, 1, 1), (3, 2, 23, 21)),    # T = 2: every frame is a border frame
     ("s_16_16", 16, 16, (1, 3, 3), (3, 4, 23, 21)),
     ("s_32_32", 32, 32, (1, 3, 3), (2, 5, 14, 14)),
     ("s_8_8", 8, 8, (1, 3, 3), (2, 6, 29, 27)),
