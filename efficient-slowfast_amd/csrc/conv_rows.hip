@@ -486,10 +486,9 @@ __global__ __launch_bounds__(256) void conv_rows_tring_kernel(const CRowsArgs p)
 #pragma unroll
     for (int i = 0; i < MAXP; ++i) {
       const int b = wave + 4 * i;
-      if (b < NXB)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(
-            x_rs, (lds_void*)(__attribute__((address_space(3))) char*)(uintptr_t)(lds0 + (unsigned)(b << 10)), 16,
-            base + lc[i], 0, 0, 0);
+      const unsigned vo = base + lc[i];  // (named: with the sum written inline in the call, hipcc's HOST pass emitted no
+                                         //  stub for this kernel — no diagnostic, an undefined symbol at dlopen)
+      if (b < NXB) __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rs, (lds_void*)(__attribute__((address_space(3))) char*)(uintptr_t)(lds0 + (unsigned)(b << 10)), 16, vo, 0, 0, 0);
     }
   };
 
