@@ -666,8 +666,11 @@ void cr_magic(unsigned dv, unsigned* mul, unsigned* sh) {
   *sh = l - 1;
 }
 
-// sf_conv_tune(22, e): 0 off, 1 = the environment's level (SF_CONV_ROWS, default 0: OFF), 2 every shape the kernel covers.
-// OFF by default — measured on MI355X (profiles/r06_conv_rows_ab.txt, tools/microbench/conv_rows_bench.py, cold operands,
+// sf_conv_tune(22, e): 0 off, 1 = the environment's level (SF_CONV_ROWS, default 1), 2 every shape the kernels cover.
+// Level 1 takes ONLY the 3x1x1 layers with <= 16 output channels over <= 64 input channels, on the ring over t
+// (conv_rows_tring_kernel): the one form that beats what it replaces (profiles/r06_conv_rows_ab.txt: 32 -> 8 65 -> 51 us,
+// 16 -> 8 40 -> 31, 64 -> 16 127 -> 82 / 41.5 -> 34; wider outputs — the data gradients 16 -> 64, 32 -> 128 — lose 10-25 %).
+// The window form (conv_rows_kernel: every other shape) stays OFF — measured on MI355X (profiles/r06_conv_rows_ab.txt, tools/microbench/conv_rows_bench.py, cold operands,
 // launch counts of cfg #3 at 8 clips): 3.72 ms per step against 2.52 ms for the kernels it would replace.  What the
 // ablations say (SF_CONV_ROWS_DBG, true kernel durations by rocprofv3): with loads, MFMAs and stores all switched off a
 // launch keeps 40 .. 50 % of its time, and neither the ring depth (2 .. 8 steps in flight) nor the number of workgroups
@@ -685,7 +688,7 @@ int g_crows_enable = 1;
 int crows_level() {
   static const int env = [] {
     const char* e = getenv("SF_CONV_ROWS");
-    return e ? atoi(e) : 0;
+    return e ? atoi(e) : 1;
   }();
   return g_crows_enable == 1 ? env : g_crows_enable;
 }
@@ -767,6 +770,7 @@ bool crows_plan(const sf_conv_desc* d, CRowsArgs* a, CRowsPlan* pl) {
       a->S = (int)units;
     }
   }
+  if (level < 2 && !(pl->ring && d->Cout <= 16)) return false;  // level 1: the ring over t where it measured faster
   cr_magic((unsigned)d->Wo, &a->w_mul, &a->w_sh);
   cr_magic((unsigned)d->Ho, &a->h_mul, &a->h_sh);
   cr_magic((unsigned)d->To, &a->t_mul, &a->t_sh);
