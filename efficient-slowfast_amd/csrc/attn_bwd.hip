@@ -1283,10 +1283,10 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_bxpp_kernel(const BwdArgs p, 
           for (int m = 0; m < 2; ++m)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-              s[8 * m + 2 * e] -= __builtin_bit_cast(float, pf[m][st][e] << 16);
-              s[8 * m + 2 * e + 1] -= __builtin_bit_cast(float, pf[m][st][e] & 0xffff0000u);
-              dp[8 * m + 2 * e] -= __builtin_bit_cast(float, sf[m][st][e] << 16);
-              dp[8 * m + 2 * e + 1] -= __builtin_bit_cast(float, sf[m][st][e] & 0xffff0000u);
+              s[8 * m + 2 * e] = bx_res_lo(s[8 * m + 2 * e], pf[m][st][e]);
+              s[8 * m + 2 * e + 1] = bx_res_hi(s[8 * m + 2 * e + 1], pf[m][st][e]);
+              dp[8 * m + 2 * e] = bx_res_lo(dp[8 * m + 2 * e], sf[m][st][e]);
+              dp[8 * m + 2 * e + 1] = bx_res_hi(dp[8 * m + 2 * e + 1], sf[m][st][e]);
             }
           PP_PIN();
         }

@@ -659,14 +659,14 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bx_kernel(const AttnArgs p, c
       const float a = s[8 * m + 2 * e], b = s[8 * m + 2 * e + 1];
       const unsigned p1 = cvt_pk_bf16(a, b);
       pf[m][0][e] = p1;
-      xa[4 * m + e] = a - __builtin_bit_cast(float, p1 << 16);
-      xb[4 * m + e] = b - __builtin_bit_cast(float, p1 & 0xffff0000u);
+      xa[4 * m + e] = bx_res_lo(a, p1);
+      xb[4 * m + e] = bx_res_hi(b, p1);
     };
     auto SB = [&](int m, int e) {
       const unsigned p2 = cvt_pk_bf16(xa[4 * m + e], xb[4 * m + e]);
       pf[m][1][e] = p2;
-      xa[4 * m + e] -= __builtin_bit_cast(float, p2 << 16);
-      xb[4 * m + e] -= __builtin_bit_cast(float, p2 & 0xffff0000u);
+      xa[4 * m + e] = bx_res_lo(xa[4 * m + e], p2);
+      xb[4 * m + e] = bx_res_hi(xb[4 * m + e], p2);
       pf[m][2][e] = cvt_pk_bf16(xa[4 * m + e], xb[4 * m + e]);
     };
     auto QK = [&](int i) {  // MFMA i of the first product of the next block

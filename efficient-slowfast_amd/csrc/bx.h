@@ -18,15 +18,43 @@ typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {  // v_cvt_pk_bf16_f32: a -> bits 0..15, b -> 16..31
   return __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){a, b}, bf16x2));
 }
-// (a, b) -> element `idx` of the three packed piece vectors (11 vector instructions per pair)
+// Residual of a split step: a - (low half of p as a float), b - (high half of p).  v_dot2c_f32_bf16 (acc += p.lo * m.lo +
+// p.hi * m.hi) with m = (-1, 0) / (0, -1) does the unpack and the subtraction in ONE vector instruction, and the residual
+// of a round-to-nearest bf16 conversion is exactly representable, so both forms return the same bits — measured in round
+// 6 (profiles/r06_dot2_ab.txt, tools/microbench/split_dot2.hip): bit-identical over 2^25 pairs of every exponent class,
+// 1.1x the split rate in isolation (the instruction issues at half rate: 7 instructions cost what 11 did), and inside
+// the kernels NOT faster — attention d = 32 forward 3.74 vs 3.45 ms, backward 8.98 vs 8.83, d = 8 equal, step 53.9 vs
+// 53.4 ms.  The shift / mask + subtract form stays the default; -DSF_BX_DOT2=1 builds the other.
+#ifndef SF_BX_DOT2
+#define SF_BX_DOT2 0
+#endif
+__device__ __forceinline__ float bx_res_lo(float a, unsigned p) {
+#if SF_BX_DOT2
+  // the multiplier (-1, 0) = 0x0000bf80 must not reach the instruction as the inline constant "-1.0": hipcc 7.2 folds it
+  // to that, and the hardware reads the inline constant as the FLOAT -1.0 = (0, -1) (split_dot2.hip: low halves wrong)
+  unsigned m;
+  asm("s_mov_b32 %0, 0xbf80" : "=s"(m));
+  return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, p), __builtin_bit_cast(bf16x2, m), a, false);
+#else
+  return a - __builtin_bit_cast(float, p << 16);
+#endif
+}
+__device__ __forceinline__ float bx_res_hi(float b, unsigned p) {
+#if SF_BX_DOT2
+  return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, p), (bf16x2){(__bf16)0.0f, (__bf16)-1.0f}, b, false);
+#else
+  return b - __builtin_bit_cast(float, p & 0xffff0000u);
+#endif
+}
+// (a, b) -> element `idx` of the three packed piece vectors (11 vector instructions per pair; 7 in the dot2 form)
 template <class V>
 __device__ __forceinline__ void split_pair(float a, float b, V (&dst)[3], int idx) {
   const unsigned p1 = cvt_pk_bf16(a, b);
-  a -= __builtin_bit_cast(float, p1 << 16);
-  b -= __builtin_bit_cast(float, p1 & 0xffff0000u);
+  a = bx_res_lo(a, p1);
+  b = bx_res_hi(b, p1);
   const unsigned p2 = cvt_pk_bf16(a, b);
-  a -= __builtin_bit_cast(float, p2 << 16);
-  b -= __builtin_bit_cast(float, p2 & 0xffff0000u);
+  a = bx_res_lo(a, p2);
+  b = bx_res_hi(b, p2);
   dst[0][idx] = p1;
   dst[1][idx] = p2;
   dst[2][idx] = cvt_pk_bf16(a, b);
