@@ -1654,8 +1654,15 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_bx2_kernel(const BwdArgs p, f
 // are three per k-step (the packed operand times each piece of P / dS; row or column groups 0-7 / 8-15 / 16-23 summed
 // at the end).  24 MFMAs per 32 x 32 block instead of 60, a third of the LDS row traffic, and dQ planes of 8 columns.
 constexpr int bxbp_lds_bytes(int nw) { return 2 * BXB_PL * 2 + 2 * BXB_QT * 4 + nw * BXB_QT * 32 * 4; }
+// -DSF_BXP_OCC3=1: three workgroups of four wavefronts per CU (168 registers; the kernel needs 177, so 8 dwords go to
+// scratch, touched once per tile).  Round 6, d = 8 N = 25 088 B = 8: backward 4.64-4.66 ms against 4.78-4.90 (-4 %);
+// not the default because a hot kernel with scratch fails the build's ISA audit and 0.2 ms is not worth a waiver.
+#ifndef SF_BXP_OCC3
+#define SF_BXP_OCC3 0
+#endif
+#define BXP_WGS(nw) ((SF_BXP_OCC3 && (nw) == 4) ? 3 : 8 / (nw))
 template <int NW>
-__global__ __launch_bounds__(64 * NW, 8 / NW) void attn_bwd_bxp_kernel(const BwdArgs p, float* __restrict__ ws,
+__global__ __launch_bounds__(64 * NW, BXP_WGS(NW)) void attn_bwd_bxp_kernel(const BwdArgs p, float* __restrict__ ws,
                                                                        const unsigned short* __restrict__ qb,
                                                                        const unsigned short* __restrict__ db, int n64) {
   constexpr int CP = 8, NT = 64 * NW, QT = BXB_QT, KP = BX_KP, PL = BXB_PL, TP = BXB_TP;
