@@ -671,6 +671,7 @@ def norm_forward(bn, x):
 
 
 ARENA_MAX_FLOATS = int(float(os.environ.get("SF_GRAD_ARENA_MB", "64")) * (1 << 18))  # 0: off
+_GROUPS_OF = {}  # id(weight) -> groups, for the grouped convs (1 < groups < channels) packed by _group_pairs
 _PAIR_WEIGHTS = {}  # id(weight) -> weakref of the dense conv weights that have been packed as a pair (tensors compare
 # elementwise, so no WeakSet): repack_all's candidates
 BATCHED_REPACK = os.environ.get("SF_BATCH_REPACK", "1") != "0"
@@ -691,8 +692,9 @@ def _packed_pair(weight):
 
 
 def repack_all(model):
-    """Re-pack, in ONE launch, every dense conv weight of `model` whose packed pair is stale (after an optimizer step:
-    all of them — ~108 launches of ~6 us and 216 allocations otherwise).  The packed tensors are overwritten in place:
+    """Re-pack, in ONE launch, every dense, depthwise and grouped conv weight of `model` whose packed pair is stale
+    (after an optimizer step: all of them — ~108 launches of ~6 us and 216 allocations otherwise; a grouped conv alone
+    was G launches and two allocations).  The packed tensors are overwritten in place:
     the previous step's kernels that read them were joined before the optimizer ran."""
     if not BATCHED_REPACK:
         return
@@ -701,18 +703,36 @@ def repack_all(model):
         cand = (len(_PAIR_WEIGHTS), [p for p in model.parameters()
                                      if id(p) in _PAIR_WEIGHTS and _PAIR_WEIGHTS[id(p)]() is p])
         model.__dict__["_sf_pair_params"] = cand
-    stale, old = [], []
+    stale, old, slots = [], [], []
     for w in cand[1]:
-        c = w.__dict__.get("_sf_cache", {}).get("_sf_wpair")
+        store = w.__dict__.get("_sf_cache", {})
+        c = store.get("_sf_wpair")
         if c is not None and c[0] != _key(w) and w.is_cuda and w.is_contiguous():
-            stale.append(w)
+            stale.append(w.detach())
             old.append(c[1])
+            slots.append((w, "_sf_wpair", None))
+        c = store.get("_sf_wgroups")
+        G = _GROUPS_OF.get(id(w))
+        if c is not None and G and c[0] != _key(w) and w.is_cuda and w.is_contiguous():
+            # a grouped conv's pair = its G per-group packs one after the other: G more records of the same launch,
+            # written into the slices of the two tensors the previous version lives in (no allocation)
+            wd, (wp, wtp) = w.detach(), c[1]
+            cout_g, cin_g = wd.shape[0] // G, wd.shape[1]
+            for g in range(G):
+                stale.append(wd[g * cout_g:(g + 1) * cout_g])
+                old.append((wp[g * cout_g:(g + 1) * cout_g], wtp[g * cin_g:(g + 1) * cin_g]))
+                slots.append((w, "_sf_wgroups", (wp, wtp)) if g == 0 else None)
     if len(stale) < 2:
         return
     with torch.no_grad():
-        new = sfhip.pack_conv_weight_pairs([w.detach() for w in stale], old)
-    for w, o in zip(stale, new):
-        w.__dict__["_sf_cache"]["_sf_wpair"] = (_key(w), _keep_if_capturing(o))
+        new = sfhip.pack_conv_weight_pairs(stale, old)
+    for sl, o, prev in zip(slots, new, old):
+        if sl is None:
+            continue
+        w, name, whole = sl
+        if whole is not None and (o[0].data_ptr() != prev[0].data_ptr() or o[1].data_ptr() != prev[1].data_ptr()):
+            continue  # a slice was re-allocated (foreign device / dtype): leave the entry stale, _group_pairs re-packs
+        w.__dict__["_sf_cache"][name] = (_key(w), _keep_if_capturing(o if whole is None else whole))
 
 
 def packed_weight(conv):
@@ -736,6 +756,10 @@ def _group_pairs(conv):
     if conv.in_channels % G or conv.out_channels % G:
         raise ValueError("grouped conv: %d -> %d channels are not divisible by %d groups" % (
             conv.in_channels, conv.out_channels, G))
+    if w.is_cuda and id(w) not in _PAIR_WEIGHTS:  # repack_all's candidate list (it re-packs the groups in its one launch)
+        wid = id(w)
+        _PAIR_WEIGHTS[wid] = weakref.ref(w, lambda _r, wid=wid: (_PAIR_WEIGHTS.pop(wid, None), _GROUPS_OF.pop(wid, None)))
+        _GROUPS_OF[wid] = G
     return _cached_t(w, "_sf_wgroups", _key(w), lambda: sfhip.pack_grouped_weight_pair(w, G))
 
 

@@ -228,3 +228,35 @@ def test_wide_head_spatial_attention(c, red, thw):
             assert float(got.abs().max()) < 1e-5 * gmax, k
         else:
             assert _rel(got, pr.grad) < 2e-4, k
+
+
+def test_grouped_weights_ride_in_the_batched_repack():
+    """After an optimizer step engine.repack_all re-packs a grouped conv's G per-group packs as G records of its ONE
+    launch, in place in the two tensors of the previous version (round 5 advice: it used to be G launches and two
+    allocations per grouped conv per step): same bytes as sfhip.pack_grouped_weight_pair, same storage, one C-ABI call
+    for two grouped convs and a dense one together."""
+    import sfhip
+    from slowfast.models import engine
+    dev = torch.device("cuda:0")
+    torch.manual_seed(3)
+    model = nn.Sequential(nn.Conv3d(24, 36, (1, 3, 3), padding=(0, 1, 1), groups=3, bias=False),
+                          nn.Conv3d(36, 40, 1, groups=4, bias=False), nn.Conv3d(40, 16, 1, bias=False)).to(dev)
+    g1, g2, dense = model[0], model[1], model[2]
+    before = [engine._group_pairs(g1), engine._group_pairs(g2), engine._packed_pair(dense.weight)]
+    ptrs = [(a.data_ptr(), b.data_ptr()) for a, b in before]
+    with torch.no_grad():
+        for p in model.parameters():
+            p.mul_(1.25).add_(0.01)  # what an optimizer step does: new values, same storage, new version
+    engine.parameters_changed()
+    calls = sfhip.CALLS
+    engine.repack_all(model)
+    assert sfhip.CALLS - calls == 1, "grouped + dense re-packs are one launch"
+    calls = sfhip.CALLS
+    after = [engine._group_pairs(g1), engine._group_pairs(g2), engine._packed_pair(dense.weight)]
+    assert sfhip.CALLS == calls, "the cache entries are fresh after repack_all: nothing re-packs"
+    assert [(a.data_ptr(), b.data_ptr()) for a, b in after] == ptrs, "in place"
+    for conv, (wp, wtp) in ((g1, after[0]), (g2, after[1])):
+        rp, rt = sfhip.pack_grouped_weight_pair(conv.weight, conv.groups)
+        assert torch.equal(rp, wp) and torch.equal(rt, wtp)
+    rp, rt = sfhip.pack_conv_weight_pair(dense.weight)
+    assert torch.equal(rp, after[2][0]) and torch.equal(rt, after[2][1])
