@@ -455,17 +455,46 @@ def spawn_ranks(n, argv):
     return rc
 
 
+def pin_rank(local):
+    """Pin this rank's threads to the CPUs next to its GPU BEFORE anything touches the GPU; -> the `affinity` block of
+    the JSON line, or None.  spawn_ranks hands the set over in SF_RANK_CPUS; under torch.distributed.run (the driver's
+    N > 1 form), which pins nothing, the rank takes the set spawn_ranks would have given its LOCAL_RANK (sysfs only).
+    SF_BENCH_PIN=0 switches the pinning off."""
+    if os.environ.get("SF_BENCH_PIN", "1") == "0":
+        return None
+    if "SF_RANK_CPUS" not in os.environ and "RANK" in os.environ and int(os.environ.get("LOCAL_WORLD_SIZE", "1")) > 1:
+        try:
+            node, cpus = rank_cpu_sets(int(os.environ["LOCAL_WORLD_SIZE"]))[local]
+            os.environ["SF_RANK_CPUS"] = ",".join(str(c) for c in cpus)
+            os.environ["SF_RANK_NUMA"] = str(node)
+        except (OSError, ValueError, IndexError):
+            return None
+    if not os.environ.get("SF_RANK_CPUS"):
+        return None
+    try:
+        cpus = sorted(int(c) for c in os.environ["SF_RANK_CPUS"].split(",") if c)
+        os.sched_setaffinity(0, cpus)
+        return {"numa_node": int(os.environ.get("SF_RANK_NUMA", "-1")), "cpus": len(cpus), "first_cpu": cpus[0],
+                "last_cpu": cpus[-1]}
+    except (OSError, ValueError, IndexError):
+        return None
+
+
 def spawn_selftest(rank, world):
     """--spawn-selftest: the launcher's contract without a GPU (tests/test_distributed_cpu.py)."""
     import torch.distributed as dist
     if os.environ.get("SF_SELFTEST_FAIL_RANK") == str(rank):
         raise SystemExit(3)
+    affinity = pin_rank(int(os.environ.get("LOCAL_RANK", "0")))
     if "RANK" in os.environ:
         dist.init_process_group(backend="gloo", rank=rank, world_size=world)
     ones = torch.ones(1)
+    pinned = torch.tensor([1.0 if affinity and len(os.sched_getaffinity(0)) == affinity["cpus"] else 0.0])
     if dist.is_initialized():
         dist.all_reduce(ones)
+        dist.all_reduce(pinned)
     if rank == 0:
+        print("[bench] selftest: %d of %d ranks pinned themselves" % (int(pinned.item()), world), file=sys.stderr)
         print(json.dumps({"selftest": True, "n_gpus": world, "n_ranks_seen": int(ones.item())}))
     if dist.is_initialized():
         dist.destroy_process_group()
@@ -528,15 +557,7 @@ def main():
         raise SystemExit(spawn_ranks(args.gpus, sys.argv[1:]))
     if args.gpus != world:
         raise SystemExit("--gpus %d but the launcher started %d ranks" % (args.gpus, world))
-    affinity = None
-    if os.environ.get("SF_RANK_CPUS"):  # set by spawn_ranks: pin this rank's threads before anything touches the GPU
-        try:
-            cpus = sorted(int(c) for c in os.environ["SF_RANK_CPUS"].split(",") if c)
-            os.sched_setaffinity(0, cpus)
-            affinity = {"numa_node": int(os.environ.get("SF_RANK_NUMA", "-1")), "cpus": len(cpus),
-                        "first_cpu": cpus[0], "last_cpu": cpus[-1]}
-        except (OSError, ValueError):
-            affinity = None
+    affinity = pin_rank(local)
     assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback for the hot path)"
     # TEST-ONLY overrides (tests/test_multigpu_gpu.py runs the whole N = 2 path of this file on a 1-GPU box):
     # SF_BENCH_ONE_DEVICE=1 puts every rank on device 0, SF_BENCH_BACKEND=gloo replaces RCCL (which refuses two ranks on

@@ -249,6 +249,32 @@ def test_bench_starts_its_own_ranks():
     assert json.loads(line) == {"selftest": True, "n_gpus": 2, "n_ranks_seen": 2}
 
 
+def test_bench_ranks_pin_themselves_under_torch_distributed_run():
+    """The driver's N > 1 form: `python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2 ...` starts the
+    ranks itself and pins nothing — every rank then takes the CPU set bench.py's own launcher would have handed its
+    LOCAL_RANK (rank_cpu_sets: sysfs only, before any GPU call); the launcher-started ranks do the same."""
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    e = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "SF_RANK_CPUS", "SF_RANK_NUMA"):
+        e.pop(k, None)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"),
+                        "--gpus", "2", "--spawn-selftest"], env=e, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    assert json.loads(line) == {"selftest": True, "n_gpus": 2, "n_ranks_seen": 2}
+    assert "2 of 2 ranks pinned themselves" in r.stderr, r.stderr
+    r = _run_bench(["--gpus", "2", "--spawn-selftest"])
+    assert "2 of 2 ranks pinned themselves" in r.stderr, r.stderr
+    r = _run_bench(["--gpus", "2", "--spawn-selftest"], env={"SF_BENCH_PIN": "0"})
+    assert "0 of 2 ranks pinned themselves" in r.stderr, r.stderr
+
+
 def test_bench_launcher_reports_a_failed_rank():
     r = _run_bench(["--gpus", "2", "--spawn-selftest"], env={"SF_SELFTEST_FAIL_RANK": "1"})
     assert r.returncode == 3
