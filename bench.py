@@ -55,6 +55,7 @@ WORKLOADS = {
     "shufflenetv2": ("SLOWFAST_SHUFFLENETV2_4x16.yaml", 2, "SlowFastShuffleNetV2 w0.25, 4x16, 32^2"),
 }
 PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense f32-in MFMA = vector peak
+PEAK_SCLK_MHZ = 2400.0        # MI355X_MICROARCH.md peak engine clock (pp_dpm_sclk top level on the pool's boxes): what the peaks above assume
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA
 PARAM_SEED = 7
 
@@ -455,6 +456,78 @@ def spawn_ranks(n, argv):
     return rc
 
 
+def gpu_hwmon_dir(device_index, sysfs="/sys"):
+    """hwmon directory (sclk `freq1_input` in Hz, package power `power1_input` in uW) of HIP device `device_index`, by
+    its PCI address; the only GPU hwmon of the box when torch does not expose the address; None when there is none."""
+    import glob
+    cands = []
+    try:
+        pr = torch.cuda.get_device_properties(device_index)
+        addr = "%04x:%02x:%02x.0" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+        cands = glob.glob(os.path.join(sysfs, "bus/pci/devices", addr, "hwmon/hwmon*"))
+    except (AttributeError, RuntimeError):
+        cands = []
+    if not cands:
+        every = [d for d in glob.glob(os.path.join(sysfs, "class/drm/card*/device/hwmon/hwmon*"))
+                 if os.path.exists(os.path.join(d, "freq1_input"))]
+        cands = every if len(every) == 1 else []
+    cands = [d for d in cands if os.path.exists(os.path.join(d, "freq1_input"))]
+    return cands[0] if cands else None
+
+
+class ClockSampler:
+    """Shader clock and package power of one GPU, read from its hwmon files every `period` s by a daemon thread while
+    the timed steps run (two small sysfs reads per sample: the launch thread stays 17-40 ms ahead of the GPU, it does
+    not notice).  summary() -> the `clocks` block of the JSON line, or None when the box exposes no hwmon.  Why it is
+    there: the step is clock limited — the part sustains ~2.2 of its 2.4 GHz under this load (profiles/
+    r06_power_during_step.txt) and the rooflines of this file are quoted at the peak clock."""
+
+    def __init__(self, hwmon, period=0.05):
+        import threading
+        self.dir, self.period, self.sclk, self.power = hwmon, period, [], []
+        self._stop = threading.Event()
+        self._thread = threading.Thread(target=self._run, daemon=True) if hwmon else None
+
+    def _read(self, name):
+        try:
+            with open(os.path.join(self.dir, name)) as f:
+                return float(f.read().strip())
+        except (OSError, ValueError):
+            return None
+
+    def _run(self):
+        while not self._stop.is_set():
+            f, p = self._read("freq1_input"), self._read("power1_input")
+            if f:
+                self.sclk.append(f * 1e-6)
+            if p:
+                self.power.append(p * 1e-6)
+            self._stop.wait(self.period)
+
+    def start(self):
+        if self._thread:
+            self._thread.start()
+
+    def stop(self):
+        if self._thread:
+            self._stop.set()
+            self._thread.join(timeout=1.0)
+
+    def summary(self):
+        if not self.sclk:
+            return None
+        cap = self._read("power1_cap")
+        out = {"sclk_mhz_mean": round(sum(self.sclk) / len(self.sclk), 1), "sclk_mhz_min": round(min(self.sclk), 1),
+               "sclk_mhz_max": round(max(self.sclk), 1), "peak_sclk_mhz": PEAK_SCLK_MHZ, "samples": len(self.sclk),
+               "source": "hwmon freq1_input / power1_input of rank 0's GPU every %d ms during the timed steps"
+                         % int(self.period * 1e3)}
+        if self.power:
+            out["power_w_mean"] = round(sum(self.power) / len(self.power), 1)
+        if cap:
+            out["power_cap_w"] = round(cap * 1e-6, 1)
+        return out
+
+
 def pin_rank(local):
     """Pin this rank's threads to the CPUs next to its GPU BEFORE anything touches the GPU; -> the `affinity` block of
     the JSON line, or None.  spawn_ranks hands the set over in SF_RANK_CPUS; under torch.distributed.run (the driver's
@@ -694,7 +767,9 @@ def main():
     gc.freeze()
 
     # ---- timed region: exactly K steps
+    clock_sampler = ClockSampler(gpu_hwmon_dir(local) if rank == 0 else None)
     barrier()
+    clock_sampler.start()
     t0 = time.perf_counter()
     with torch.cuda.stream(side):
         for _ in range(args.steps):
@@ -704,6 +779,7 @@ def main():
                 out = step()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    clock_sampler.stop()
     if graph is not None and train:
         from slowfast.models import engine as _eng
         _eng.parameters_changed()  # replayed optimizer kernels moved the parameters: every eager cache is stale
@@ -980,6 +1056,12 @@ def main():
             res["step_roofline"] = {"algorithmic_gflop_per_clip": per_clip[1 if train else 0] / 1e9,
                                     "achieved_tflops": round(ach, 2), "peak_tflops": PEAK_FP32_MFMA_TFLOPS * world,
                                     "frac": round(ach / (PEAK_FP32_MFMA_TFLOPS * world), 4)}
+        clocks = clock_sampler.summary()
+        if clocks is not None:
+            res["clocks"] = clocks
+            if "step_roofline" in res:  # the same fraction against the ceiling at the clock the part actually held
+                res["step_roofline"]["frac_at_sustained_clock"] = round(
+                    res["step_roofline"]["frac"] * PEAK_SCLK_MHZ / clocks["sclk_mhz_mean"], 4)
         if eval_fwd is not None:
             res["eval_forward"] = eval_fwd
         if roofline is not None:

@@ -232,3 +232,29 @@ def test_bench_parity_gate_contract():
         bad = dict(ok, **{k: 1.5e-3})
         assert len(bench.parity_gate(bad)) == 1 and k in bench.parity_gate(bad)[0]
         assert len(bench.parity_gate(dict(ok, **{k: math.nan}))) == 1
+
+
+def test_clock_sampler_reads_the_hwmon_files(tmp_path):
+    """bench.py's `clocks` block: sclk / package power of rank 0's GPU sampled from its hwmon files while the timed steps
+    run (the rooflines are quoted at the peak clock; the part holds ~2.2 of 2.4 GHz under the step).  Fake hwmon here;
+    no hwmon -> no block, never an error."""
+    import time
+    import bench
+    hw = tmp_path / "class" / "drm" / "card0" / "device" / "hwmon" / "hwmon4"
+    hw.mkdir(parents=True)
+    (hw / "freq1_input").write_text("2200000000\n")
+    (hw / "power1_input").write_text("1200000000\n")
+    (hw / "power1_cap").write_text("1400000000\n")
+    # the PCI-address route fails without a GPU: the only GPU hwmon of the box is taken
+    assert bench.gpu_hwmon_dir(0, sysfs=str(tmp_path)) == str(hw)
+    s = bench.ClockSampler(str(hw), period=0.005)
+    s.start()
+    time.sleep(0.08)
+    s.stop()
+    out = s.summary()
+    assert out["sclk_mhz_mean"] == 2200.0 and out["power_w_mean"] == 1200.0 and out["power_cap_w"] == 1400.0
+    assert out["samples"] >= 3 and out["peak_sclk_mhz"] == bench.PEAK_SCLK_MHZ
+    none = bench.ClockSampler(bench.gpu_hwmon_dir(0, sysfs=str(tmp_path / "nothing")))
+    none.start()
+    none.stop()
+    assert none.summary() is None
