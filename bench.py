@@ -767,7 +767,8 @@ def main():
     gc.freeze()
 
     # ---- timed region: exactly K steps
-    clock_sampler = ClockSampler(gpu_hwmon_dir(local) if rank == 0 else None)
+    clock_sampler = ClockSampler(gpu_hwmon_dir(local) if rank == 0 and os.environ.get("SF_BENCH_CLOCKS", "1") != "0" else None,
+                                 period=float(os.environ.get("SF_BENCH_CLOCKS_PERIOD", "0.05")))
     barrier()
     clock_sampler.start()
     t0 = time.perf_counter()
