@@ -893,9 +893,11 @@ int sf_wgrad_tring_tune(int value);           // conv_wgrad_rows.hip
 
 // Runtime knobs for microbenchmarks / A-B runs (not used by the model code).
 int sf_dwm_tune(int value);  // dwconv_march.hip
+int sf_dwm2_tune(int value);
 
 extern "C" int sf_conv_tune(int knob, int value) {
   if (knob == 30) return sf_dwm_tune(value);
+  if (knob == 31) return sf_dwm2_tune(value);
   if (knob == 20) return sf_wgrad_rows_tune(value);
   if (knob == 21) return sf_conv_pw_tune(value);
   if (knob == 22) return sf_conv_rows_tune(value);

@@ -45,6 +45,7 @@ struct DwmArgs {
   unsigned x_bytes, g_bytes, res_bytes, out_bytes;
   int x_cs, x_coff, g_cs, g_coff, res_cs, res_coff, out_cs, out_coff, wpitch;
   int N, T, H, W, C;     // C = channels computed (forward: Cout <= Cin)
+  int Ho, Wo;            // strided kernels: output rows / columns (H, W = the input's)
   int act, accumulate, flip;
   int HC, nhc;           // rows per march, marches per column
   int CQ;                // channel groups per workgroup (power of two <= 64)
@@ -257,6 +258,238 @@ __global__ __launch_bounds__(DWM_TPB) void dwm_wgrad_kernel(const DwmArgs p) {
   }
 }
 
+// ------------------------------------------------------------------ stride (1, 2, 2): 1 x K x K, K = 3 | 5, padding K / 2
+// GhostNet's down-sampling depthwise layers (ghostnet_helper.py:114-120: conv_dw with stride 2, kernel 3 or 5) and
+// ShuffleNetV2's stride-2 branches.  Same idea as above — a thread owns a column and marches down it with its window in
+// registers — with the row step of the window doubled:
+//   forward / weight gradient: the thread owns an OUTPUT column (n, t, wo, channel group); per output row the K x K input
+//     window moves down two rows, so two rows of K values are loaded and K - 2 rows are kept;
+//   data gradient: the thread owns an INPUT column (n, t, wi, channel group).  Input rows 2b - p and 2b - p + 1 read the
+//     SAME rows b, b - 1, .. of dz — the first with the even taps kh = 2i, the second with the odd ones — so a step loads
+//     one row of dz and writes two rows of dx; which columns of dz (and which kw) a thread needs follows from the parity
+//     of wi alone and is fixed for the march: (K + 1) / 2 columns, taps outside the kernel carry a zero weight.
+// Unit -> (n, t, first row of the march, column); the column runs fastest.
+struct Col2 { int n, t, r0, w; };
+__device__ __forceinline__ Col2 decode2(const DwmArgs& p, unsigned u, int wn) {
+  Col2 c;
+  const unsigned q1 = u / (unsigned)wn;
+  c.w = (int)(u - q1 * (unsigned)wn);
+  const unsigned q2 = q1 / (unsigned)p.nhc;
+  c.r0 = (int)(q1 - q2 * (unsigned)p.nhc) * p.HC;
+  const unsigned q3 = q2 / (unsigned)p.T;
+  c.t = (int)(q2 - q3 * (unsigned)p.T);
+  c.n = (int)q3;
+  return c;
+}
+
+template <int K, int V>
+__global__ __launch_bounds__(DWM_TPB) void dwm2_fwd_kernel(const DwmArgs p) {
+  typedef typename Vec<V>::T VT;
+  constexpr int P = K / 2;
+  const int ql = threadIdx.x % p.CQ, rl = threadIdx.x / p.CQ, rpi = DWM_TPB / p.CQ;
+  const int ch = ((int)blockIdx.y * p.CQ + ql) * V;
+  const long uu = (long)blockIdx.x * rpi + rl;
+  if (ch >= p.C || uu >= p.units) return;
+  const Col2 c = decode2(p, (unsigned)uu, p.Wo);
+  const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)p.x_bytes, 0x00020000);
+  unsigned col[K];
+  const unsigned plane0 = (unsigned)((c.n * p.T + c.t) * p.H) * (unsigned)p.W;
+#pragma unroll
+  for (int kw = 0; kw < K; ++kw) {
+    const int wi = 2 * c.w - P + kw;
+    col[kw] = (unsigned)wi < (unsigned)p.W ? ((plane0 + (unsigned)wi) * (unsigned)p.x_cs + (unsigned)(p.x_coff + ch)) * 4u
+                                           : DWM_OOB;
+  }
+  VT wt[K][K];
+#pragma unroll
+  for (int kh = 0; kh < K; ++kh)
+#pragma unroll
+    for (int kw = 0; kw < K; ++kw) wt[kh][kw] = Vec<V>::ldp(p.w + (long)(kh * K + kw) * p.wpitch + ch);
+  const unsigned rowb = (unsigned)p.W * (unsigned)p.x_cs * 4u;
+  VT win[K][K];
+  auto load_row = [&](int h, int slot) {
+    const bool okh = (unsigned)h < (unsigned)p.H;
+    const unsigned ro = (unsigned)h * rowb;
+#pragma unroll
+    for (int kw = 0; kw < K; ++kw) win[slot][kw] = Vec<V>::ld(xr, (okh && col[kw] != DWM_OOB) ? col[kw] + ro : DWM_OOB);
+  };
+#pragma unroll
+  for (int kh = 0; kh < K - 2; ++kh) load_row(2 * c.r0 - P + kh, kh + 2);
+  const int h1 = c.r0 + p.HC < p.Ho ? c.r0 + p.HC : p.Ho;
+  VT sc = Vec<V>::zero(), bi = Vec<V>::zero();
+  if (p.scale) {
+    sc = Vec<V>::ldp(p.scale + ch);
+    bi = Vec<V>::ldp(p.bias + ch);
+  }
+  const long m0 = (((long)c.n * p.T + c.t) * p.Ho) * p.Wo + c.w;
+  for (int ho = c.r0; ho < h1; ++ho) {
+#pragma unroll
+    for (int kh = 0; kh < K - 2; ++kh)
+#pragma unroll
+      for (int kw = 0; kw < K; ++kw) win[kh][kw] = win[kh + 2][kw];
+    load_row(2 * ho - P + K - 2, K - 2);
+    load_row(2 * ho - P + K - 1, K - 1);
+    VT acc = Vec<V>::zero();
+#pragma unroll
+    for (int kh = 0; kh < K; ++kh)
+#pragma unroll
+      for (int kw = 0; kw < K; ++kw) acc += win[kh][kw] * wt[kh][kw];
+    const long m = m0 + (long)ho * p.Wo;
+    if (p.scale) acc = acc * sc + bi;
+    float* const o = p.out + m * p.out_cs + p.out_coff + ch;
+    if (p.res) acc += Vec<V>::ldp(p.res + m * p.res_cs + p.res_coff + ch);
+#pragma unroll
+    for (int e = 0; e < V; ++e) set_elem(acc, e, sf_act(elem(acc, e), p.act));
+    Vec<V>::stp(o, acc);
+  }
+}
+
+// dx[n, t, hi, wi, c] (+)= sum over (kh, kw) with hi + p - kh and wi + p - kw even of
+//                          dz[n, t, (hi + p - kh) / 2, (wi + p - kw) / 2, c] w[kh, kw, c]
+template <int K, int V>
+__global__ __launch_bounds__(DWM_TPB) void dwm2_dgrad_kernel(const DwmArgs p) {
+  typedef typename Vec<V>::T VT;
+  constexpr int P = K / 2, J = (K + 1) / 2;
+  const int ql = threadIdx.x % p.CQ, rl = threadIdx.x / p.CQ, rpi = DWM_TPB / p.CQ;
+  const int ch = ((int)blockIdx.y * p.CQ + ql) * V;
+  const long uu = (long)blockIdx.x * rpi + rl;
+  if (ch >= p.C || uu >= p.units) return;
+  const Col2 c = decode2(p, (unsigned)uu, p.W);   // p.x = dz [N][T][Ho][Wo], p.out = dx [N][T][H][W]
+  const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)p.x_bytes, 0x00020000);
+  const int par = (c.w + P) & 1;
+  const unsigned plane0 = (unsigned)((c.n * p.T + c.t) * p.Ho) * (unsigned)p.Wo;
+  unsigned col[J];
+  VT we[J][J], wo[J][J];  // rows: dz row b - i; even taps kh = 2i, odd taps kh = 2i + 1
+#pragma unroll
+  for (int j = 0; j < J; ++j) {
+    const int kw = par + 2 * j;
+    const int num = c.w + P - kw;  // even
+    const bool ok = kw < K && num >= 0 && (num >> 1) < p.Wo;
+    col[j] = ok ? ((plane0 + (unsigned)(num >> 1)) * (unsigned)p.x_cs + (unsigned)(p.x_coff + ch)) * 4u : DWM_OOB;
+#pragma unroll
+    for (int i = 0; i < J; ++i) {
+      we[i][j] = (kw < K) ? Vec<V>::ldp(p.w + (long)((2 * i) * K + kw) * p.wpitch + ch) : Vec<V>::zero();
+      wo[i][j] = (kw < K && 2 * i + 1 < K) ? Vec<V>::ldp(p.w + (long)((2 * i + 1) * K + kw) * p.wpitch + ch)
+                                           : Vec<V>::zero();
+    }
+  }
+  const unsigned rowb = (unsigned)p.Wo * (unsigned)p.x_cs * 4u;
+  VT win[J][J];
+  auto load_row = [&](int b, int slot) {
+    const bool okh = (unsigned)b < (unsigned)p.Ho;
+    const unsigned ro = (unsigned)b * rowb;
+#pragma unroll
+    for (int j = 0; j < J; ++j) win[slot][j] = Vec<V>::ld(xr, (okh && col[j] != DWM_OOB) ? col[j] + ro : DWM_OOB);
+  };
+#pragma unroll
+  for (int i = 0; i < J - 1; ++i) load_row(c.r0 - 1 - i, i);
+  const int nb = (p.H - 1 + P) / 2 + 1;
+  const int b1 = c.r0 + p.HC < nb ? c.r0 + p.HC : nb;
+  const long m0 = (((long)c.n * p.T + c.t) * p.H) * p.W + c.w;
+  for (int b = c.r0; b < b1; ++b) {
+#pragma unroll
+    for (int i = J - 1; i > 0; --i)
+#pragma unroll
+      for (int j = 0; j < J; ++j) win[i][j] = win[i - 1][j];
+    load_row(b, 0);
+    VT ae = Vec<V>::zero(), ao = Vec<V>::zero();
+#pragma unroll
+    for (int i = 0; i < J; ++i)
+#pragma unroll
+      for (int j = 0; j < J; ++j) {
+        ae += win[i][j] * we[i][j];
+        if (2 * i + 1 < K) ao += win[i][j] * wo[i][j];
+      }
+    const int he = 2 * b - P;
+    if ((unsigned)he < (unsigned)p.H) {
+      float* const o = p.out + (m0 + (long)he * p.W) * p.out_cs + p.out_coff + ch;
+      if (p.accumulate) ae += Vec<V>::ldp(o);
+      Vec<V>::stp(o, ae);
+    }
+    if ((unsigned)(he + 1) < (unsigned)p.H) {
+      float* const o = p.out + (m0 + (long)(he + 1) * p.W) * p.out_cs + p.out_coff + ch;
+      if (p.accumulate) ao += Vec<V>::ldp(o);
+      Vec<V>::stp(o, ao);
+    }
+  }
+}
+
+template <int K, int V>
+__global__ __launch_bounds__(DWM_TPB) void dwm2_wgrad_kernel(const DwmArgs p) {
+  typedef typename Vec<V>::T VT;
+  constexpr int P = K / 2;
+  __shared__ VT red[K][DWM_TPB];
+  const int ql = threadIdx.x % p.CQ, rl = threadIdx.x / p.CQ, rpi = DWM_TPB / p.CQ;
+  const int ch = ((int)blockIdx.y * p.CQ + ql) * V;
+  const bool cok = ch < p.C;
+  const long per = (p.units + p.nblk - 1) / p.nblk;
+  const long u0 = (long)blockIdx.x * per;
+  const long u1 = (u0 + per < p.units) ? u0 + per : p.units;
+  const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)p.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t gr = __builtin_amdgcn_make_buffer_rsrc((void*)p.g, 0, (int)p.g_bytes, 0x00020000);
+  const unsigned rowb = (unsigned)p.W * (unsigned)p.x_cs * 4u;
+  const unsigned growb = (unsigned)p.Wo * (unsigned)p.g_cs * 4u;
+  VT acc[K][K];
+#pragma unroll
+  for (int kh = 0; kh < K; ++kh)
+#pragma unroll
+    for (int kw = 0; kw < K; ++kw) acc[kh][kw] = Vec<V>::zero();
+  if (cok) {
+    for (long uu = u0 + rl; uu < u1; uu += rpi) {
+      const Col2 c = decode2(p, (unsigned)uu, p.Wo);
+      unsigned col[K];
+      const unsigned plane0 = (unsigned)((c.n * p.T + c.t) * p.H) * (unsigned)p.W;
+#pragma unroll
+      for (int kw = 0; kw < K; ++kw) {
+        const int wi = 2 * c.w - P + kw;
+        col[kw] = (unsigned)wi < (unsigned)p.W
+                      ? ((plane0 + (unsigned)wi) * (unsigned)p.x_cs + (unsigned)(p.x_coff + ch)) * 4u : DWM_OOB;
+      }
+      VT win[K][K];
+      auto load_row = [&](int h, int slot) {
+        const bool okh = (unsigned)h < (unsigned)p.H;
+        const unsigned ro = (unsigned)h * rowb;
+#pragma unroll
+        for (int kw = 0; kw < K; ++kw)
+          win[slot][kw] = Vec<V>::ld(xr, (okh && col[kw] != DWM_OOB) ? col[kw] + ro : DWM_OOB);
+      };
+#pragma unroll
+      for (int kh = 0; kh < K - 2; ++kh) load_row(2 * c.r0 - P + kh, kh + 2);
+      const int h1 = c.r0 + p.HC < p.Ho ? c.r0 + p.HC : p.Ho;
+      unsigned goff = ((unsigned)(((c.n * p.T + c.t) * p.Ho + c.r0) * p.Wo + c.w) * (unsigned)p.g_cs +
+                       (unsigned)(p.g_coff + ch)) * 4u;
+      for (int ho = c.r0; ho < h1; ++ho, goff += growb) {
+#pragma unroll
+        for (int kh = 0; kh < K - 2; ++kh)
+#pragma unroll
+          for (int kw = 0; kw < K; ++kw) win[kh][kw] = win[kh + 2][kw];
+        load_row(2 * ho - P + K - 2, K - 2);
+        load_row(2 * ho - P + K - 1, K - 1);
+        const VT g = Vec<V>::ld(gr, goff);
+#pragma unroll
+        for (int kh = 0; kh < K; ++kh)
+#pragma unroll
+          for (int kw = 0; kw < K; ++kw) acc[kh][kw] += g * win[kh][kw];
+      }
+    }
+  }
+  // the lanes rl = 0 .. rpi-1 of a channel group, summed in lane order, one kernel row (K taps) per round through LDS
+#pragma unroll
+  for (int kh = 0; kh < K; ++kh) {
+#pragma unroll
+    for (int kw = 0; kw < K; ++kw) red[kw][threadIdx.x] = acc[kh][kw];
+    __syncthreads();
+    if (rl == 0 && cok) {
+      for (int u = 0; u < K; ++u) {
+        VT tot = Vec<V>::zero();
+        for (int i = 0; i < rpi; ++i) tot += red[u][i * p.CQ + ql];
+        Vec<V>::stp(p.partial + ((long)blockIdx.x * (K * K) + kh * K + u) * p.C + ch, tot);
+      }
+    }
+    __syncthreads();
+  }
+}
+
 inline int pow2ceil_m(int v) {
   int p = 1;
   while (p < v) p <<= 1;
@@ -287,6 +520,25 @@ bool shape_ok(const sf_conv_desc* d) {
   return true;
 }
 
+// 1 x K x K (K = 3 | 5), stride (1, 2, 2), padding K / 2: the down-sampling depthwise layers
+bool g_dwm2_on = [] {
+  const char* e = getenv("SF_DW_MARCH_S2");
+  return !(e && e[0] == '0');
+}();
+bool shape2_ok(const sf_conv_desc* d) {
+  if (!g_dwm_on || !g_dwm2_on) return false;
+  if (d->kT != 1 || d->kH != d->kW || !(d->kH == 3 || d->kH == 5)) return false;
+  if (d->sT != 1 || d->sH != 2 || d->sW != 2 || d->dT != 1 || d->dH != 1 || d->dW != 1) return false;
+  if (d->pT != 0 || d->pH != d->kH / 2 || d->pW != d->kW / 2) return false;
+  if (d->To != d->Ti || d->Ho != (d->Hi + 2 * d->pH - d->kH) / 2 + 1 || d->Wo != (d->Wi + 2 * d->pW - d->kW) / 2 + 1)
+    return false;
+  if (d->N <= 0 || d->Ti <= 0 || d->Hi <= 0 || d->Wi <= 0 || d->Ho <= 0 || d->Wo <= 0) return false;
+  return true;
+}
+bool fits32o(const sf_conv_desc* d, int cs) {
+  return (long)d->N * d->To * d->Ho * d->Wo * cs * 4 < 0x7fffffffL;
+}
+
 bool fits32(const sf_conv_desc* d, int cs) {
   return (long)d->N * d->Ti * d->Hi * d->Wi * cs * 4 < 0x7fffffffL;
 }
@@ -298,6 +550,34 @@ void fill_geometry(DwmArgs& a, const sf_conv_desc* d, int C, int V) {
   a.HC = march_rows(a.H, (long)a.N * a.T * a.W, groups);
   a.nhc = sf_cdiv(a.H, a.HC);
   a.units = (long)a.N * a.T * a.nhc * a.W;
+}
+
+// marched rows / columns of a strided launch: forward and weight gradient march over the OUTPUT rows of output columns,
+// the data gradient over the row pairs b of input columns
+void fill_geometry2(DwmArgs& a, const sf_conv_desc* d, int C, int V, bool dgrad) {
+  a.N = d->N; a.T = d->Ti; a.H = d->Hi; a.W = d->Wi; a.Ho = d->Ho; a.Wo = d->Wo; a.C = C;
+  const int groups = sf_cdiv(C, V);
+  a.CQ = pow2ceil_m(groups) < 64 ? pow2ceil_m(groups) : 64;
+  const int rows = dgrad ? (d->Hi - 1 + d->pH) / 2 + 1 : d->Ho;
+  const int wn = dgrad ? d->Wi : d->Wo;
+  a.HC = march_rows(rows, (long)a.N * a.T * wn, groups);
+  a.nhc = sf_cdiv(rows, a.HC);
+  a.units = (long)a.N * a.T * a.nhc * wn;
+}
+
+template <int V>
+int launch2_fwd(const DwmArgs& a, int K, bool dgrad, hipStream_t s) {
+  const int rpi = DWM_TPB / a.CQ;
+  const dim3 grid(sf_cdiv(a.units, rpi), sf_cdiv(sf_cdiv(a.C, V), a.CQ));
+  if (dgrad) {
+    if (K == 5) hipLaunchKernelGGL((dwm2_dgrad_kernel<5, V>), grid, dim3(DWM_TPB), 0, s, a);
+    else hipLaunchKernelGGL((dwm2_dgrad_kernel<3, V>), grid, dim3(DWM_TPB), 0, s, a);
+  } else {
+    if (K == 5) hipLaunchKernelGGL((dwm2_fwd_kernel<5, V>), grid, dim3(DWM_TPB), 0, s, a);
+    else hipLaunchKernelGGL((dwm2_fwd_kernel<3, V>), grid, dim3(DWM_TPB), 0, s, a);
+  }
+  SF_CHECK_LAUNCH();
+  return SF_OK;
 }
 
 template <int V>
@@ -320,11 +600,17 @@ int sf_dwm_tune(int value) {
   g_dwm_on = value != 0;
   return SF_OK;
 }
+// sf_conv_tune(31, 0 | 1): the stride-2 marches alone
+int sf_dwm2_tune(int value) {
+  g_dwm2_on = value != 0;
+  return SF_OK;
+}
 
 // 1: not taken (the caller runs its generic kernel).  Forward with the conv epilogue.
 int sf_dwm_fwd_try(const sf_conv_desc* d, const float* in, const float* w, const float* scale, const float* bias,
                    const float* res, float* out, hipStream_t s) {
-  if (!shape_ok(d) || d->out_cmul != 1 || d->Cout > d->Cin) return 1;
+  const bool s2 = shape2_ok(d);
+  if ((!shape_ok(d) && !s2) || d->out_cmul != 1 || d->Cout > d->Cin) return 1;
   if (!fits32(d, d->in_cs) || !fits32(d, d->out_cs) || (res && !fits32(d, d->res_cs))) return 1;
   if (d->N * d->Ti * d->Hi * d->Wi <= 0) return 1;
   DwmArgs a = {};
@@ -337,6 +623,10 @@ int sf_dwm_fwd_try(const sf_conv_desc* d, const float* in, const float* w, const
                   (d->out_cs % 4 == 0) && (d->out_coff % 4 == 0) && (d->cin_pad % 4 == 0) && sf_aligned16(in) &&
                   sf_aligned16(w) && sf_aligned16(out) && (!scale || (sf_aligned16(scale) && sf_aligned16(bias))) &&
                   (!res || ((d->res_cs % 4 == 0) && (d->res_coff % 4 == 0) && sf_aligned16(res)));
+  if (s2) {
+    fill_geometry2(a, d, d->Cout, v4 ? 4 : 1, false);
+    return v4 ? launch2_fwd<4>(a, d->kH, false, s) : launch2_fwd<1>(a, d->kH, false, s);
+  }
   fill_geometry(a, d, d->Cout, v4 ? 4 : 1);   // channels >= Cout are not stored: not computed either
   return v4 ? launch_fwd<4>(a, d->kT, s) : launch_fwd<1>(a, d->kT, s);
 }
@@ -344,14 +634,19 @@ int sf_dwm_fwd_try(const sf_conv_desc* d, const float* in, const float* w, const
 // dx (+)= the transposed conv of dz.  `d` is the forward descriptor.
 int sf_dwm_dgrad_try(const sf_conv_desc* d, const float* dz, int dz_cs, int dz_coff, const float* w, float* dx,
                      int dx_cs, int dx_coff, int C, int accumulate, hipStream_t s) {
-  if (!shape_ok(d) || !fits32(d, dz_cs) || !fits32(d, dx_cs)) return 1;
+  const bool s2 = shape2_ok(d);
+  if ((!shape_ok(d) && !s2) || !fits32(d, dz_cs) || !fits32(d, dx_cs)) return 1;
   DwmArgs a = {};
   a.x = dz; a.w = w; a.out = dx;
   a.x_cs = dz_cs; a.x_coff = dz_coff; a.out_cs = dx_cs; a.out_coff = dx_coff; a.wpitch = d->cin_pad;
-  a.x_bytes = (unsigned)((long)d->N * d->Ti * d->Hi * d->Wi * dz_cs * 4);
+  a.x_bytes = (unsigned)((long)d->N * d->To * d->Ho * d->Wo * dz_cs * 4);
   a.act = SF_ACT_NONE; a.accumulate = accumulate; a.flip = 1;
   const bool v4 = (C % 4 == 0) && (dz_cs % 4 == 0) && (dz_coff % 4 == 0) && (dx_cs % 4 == 0) && (dx_coff % 4 == 0) &&
                   (d->cin_pad % 4 == 0) && sf_aligned16(dz) && sf_aligned16(dx) && sf_aligned16(w);
+  if (s2) {
+    fill_geometry2(a, d, C, v4 ? 4 : 1, true);
+    return v4 ? launch2_fwd<4>(a, d->kH, true, s) : launch2_fwd<1>(a, d->kH, true, s);
+  }
   fill_geometry(a, d, C, v4 ? 4 : 1);
   return v4 ? launch_fwd<4>(a, d->kT, s) : launch_fwd<1>(a, d->kT, s);
 }
@@ -359,15 +654,17 @@ int sf_dwm_dgrad_try(const sf_conv_desc* d, const float* dz, int dz_cs, int dz_c
 // partial[*nblk][taps][C] of the weight gradient into ws (room for `max_blk` blocks); the caller sums the blocks.
 int sf_dwm_wgrad_try(const sf_conv_desc* d, const float* x, const float* dz, int dz_cs, int dz_coff, int C, float* ws,
                      int max_blk, int* nblk, hipStream_t s) {
-  if (!shape_ok(d) || !fits32(d, d->in_cs) || !fits32(d, dz_cs) || max_blk < 1) return 1;
+  const bool s2 = shape2_ok(d);
+  if ((!shape_ok(d) && !s2) || !fits32(d, d->in_cs) || !fits32(d, dz_cs) || max_blk < 1) return 1;
   DwmArgs a = {};
   a.x = x; a.g = dz; a.partial = ws;
   a.x_cs = d->in_cs; a.x_coff = d->in_coff; a.g_cs = dz_cs; a.g_coff = dz_coff;
   a.x_bytes = (unsigned)((long)d->N * d->Ti * d->Hi * d->Wi * d->in_cs * 4);
-  a.g_bytes = (unsigned)((long)d->N * d->Ti * d->Hi * d->Wi * dz_cs * 4);
+  a.g_bytes = (unsigned)((long)d->N * d->To * d->Ho * d->Wo * dz_cs * 4);
   const bool v4 = (C % 4 == 0) && (d->in_cs % 4 == 0) && (d->in_coff % 4 == 0) && (dz_cs % 4 == 0) &&
                   (dz_coff % 4 == 0) && sf_aligned16(x) && sf_aligned16(dz) && sf_aligned16(ws);
-  fill_geometry(a, d, C, v4 ? 4 : 1);
+  if (s2) fill_geometry2(a, d, C, v4 ? 4 : 1, false);
+  else fill_geometry(a, d, C, v4 ? 4 : 1);
   const int V = v4 ? 4 : 1;
   const int ncb = sf_cdiv(sf_cdiv(C, V), a.CQ);
   const int rpi = DWM_TPB / a.CQ;
@@ -378,6 +675,17 @@ int sf_dwm_wgrad_try(const sf_conv_desc* d, const float* x, const float* dz, int
   a.nblk = (int)nb;
   *nblk = a.nblk;
   const dim3 grid(a.nblk, ncb);
+  if (s2) {
+    if (d->kH == 5) {
+      if (v4) hipLaunchKernelGGL((dwm2_wgrad_kernel<5, 4>), grid, dim3(DWM_TPB), 0, s, a);
+      else hipLaunchKernelGGL((dwm2_wgrad_kernel<5, 1>), grid, dim3(DWM_TPB), 0, s, a);
+    } else {
+      if (v4) hipLaunchKernelGGL((dwm2_wgrad_kernel<3, 4>), grid, dim3(DWM_TPB), 0, s, a);
+      else hipLaunchKernelGGL((dwm2_wgrad_kernel<3, 1>), grid, dim3(DWM_TPB), 0, s, a);
+    }
+    SF_CHECK_LAUNCH();
+    return SF_OK;
+  }
   if (d->kT == 3) {
     if (v4) hipLaunchKernelGGL((dwm_wgrad_kernel<3, 4>), grid, dim3(DWM_TPB), 0, s, a);
     else hipLaunchKernelGGL((dwm_wgrad_kernel<3, 1>), grid, dim3(DWM_TPB), 0, s, a);
