@@ -116,7 +116,9 @@ int sf_conv_fwd_stats(const sf_conv_desc* d, const float* in, const float* w_pac
  * 1 where it wins, 2 every shape it covers); knob 8: its timing ablations; knobs 10 / 11 / 12: the weight-gradient kernels of
  * conv_wgrad_wave.hip — 10: value 0 routes every weight gradient to conv_wgrad.hip, 11: force the blocks per
  * wavefront (-1: planner), 12: workgroups to aim at (0: default); knob 30: the row-march depthwise kernels
- * (dwconv_march.hip) off / on.  Returns SF_EINVAL for an unknown knob.                                           */
+ * (dwconv_march.hip) off / on, knob 31: its stride-(1,2,2) 1x3x3 / 1x5x5 marches alone; knobs 22 / 23: conv_rows.hip
+ * (0 off, 1 the ring over t for 3x1x1 layers with <= 16 output channels, 2 every shape it covers) / the weight-gradient
+ * ring over t of conv_wgrad_rows.hip (0 off, 1 on, -1 the environment's default).  Returns SF_EINVAL for an unknown knob. */
 int sf_conv_tune(int knob, int value);
 /* ---- long reductions on the bf16 matrix pipe with fp32-exact operands (conv_bx.hip) --------------------------------
  * gfx950's f32-input MFMA runs at the vector rate, its bf16 MFMA at 16x that.  Every fp32 value is the EXACT sum of
