@@ -3,6 +3,7 @@
 // reduction; max-pool backward; ECA (temporal max + channel gate) backward; broadcast / row-dot helpers.
 // Per-channel reductions go through a fixed number of fp32 partials combined in fp64 (bit-reproducible).
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -225,7 +226,53 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ dy, int dy_cs, int
                                     const float* __restrict__ mean, const float* __restrict__ invstd,
                                     const float* __restrict__ gamma, const float* __restrict__ dbeta,
                                     const float* __restrict__ dgamma, float inv_m, float* dz, int dz_cs, int dz_coff,
-                                    float* __restrict__ dres, int dres_cs, int dres_coff, int dres_acc, long total) {
+                                    float* __restrict__ dres, int dres_cs, int dres_coff, int dres_acc, long total,
+                                    int unroll4) {
+  if constexpr (VEC == 4) if (unroll4) {
+    // four elements per thread, a quarter of the tensor apart (each wave-load stays one contiguous run), every load
+    // issued before the first use: 8-12 x 16 bytes in flight per thread instead of 2-3 (launcher: rep == 1, relu 0 | 3)
+    const long q = (total + 3) / 4;
+    const long i0 = (long)blockIdx.x * TPB + threadIdx.x;
+    if (i0 >= q) return;
+    const int cv = C / 4;
+    const unsigned char* const mk = reinterpret_cast<const unsigned char*>(y);
+    f32x4 gv[4], zq[4], rv[4];
+    unsigned mb[4];
+    long rr[4];
+    int cc[4];
+    bool ok[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const long idx = i0 + (long)u * q;
+      ok[u] = idx < total;
+      const long id = ok[u] ? idx : 0;
+      cc[u] = (int)(id % cv) * 4;
+      rr[u] = id / cv;
+      gv[u] = *reinterpret_cast<const f32x4*>(dy + rr[u] * dy_cs + dy_coff + cc[u]);
+      zq[u] = *reinterpret_cast<const f32x4*>(z + rr[u] * z_cs + z_coff + cc[u]);
+      mb[u] = relu == 3 ? mk[rr[u] * y_cs + (cc[u] >> 2)] : 0xFu;
+      if (dres && dres_acc) rv[u] = *reinterpret_cast<const f32x4*>(dres + rr[u] * dres_cs + dres_coff + cc[u]);
+      else rv[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (!ok[u]) continue;
+      const int so = (int)((rr[u] / THW) % S) * C + cc[u];
+      const f32x4 is = *reinterpret_cast<const f32x4*>(invstd + so), mu = *reinterpret_cast<const f32x4*>(mean + so);
+      const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + so), db = *reinterpret_cast<const f32x4*>(dbeta + so);
+      const f32x4 dg = *reinterpret_cast<const f32x4*>(dgamma + so);
+      f32x4 ov, gg;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        gg[e] = ((mb[u] >> e) & 1u) ? gv[u][e] : 0.f;
+        const float xh = (zq[u][e] - mu[e]) * is[e];
+        ov[e] = ga[e] * is[e] * (gg[e] - db[e] * inv_m - xh * dg[e] * inv_m);
+      }
+      *reinterpret_cast<f32x4*>(dz + rr[u] * dz_cs + dz_coff + cc[u]) = ov;
+      if (dres) *reinterpret_cast<f32x4*>(dres + rr[u] * dres_cs + dres_coff + cc[u]) = rv[u] + gg;
+    }
+    return;
+  }
   const long idx = (long)blockIdx.x * TPB + threadIdx.x;
   if (idx >= total) return;
   const int cv = C / VEC;
@@ -563,16 +610,23 @@ static int bn_bwd_apply_launch(const float* dy, int dy_cs, int dy_coff, const fl
                     (!dres || ((dres_cs % 4 == 0) && (dres_coff % 4 == 0) && sf_aligned16(dres)));
   if (relu == 3 && !vec4) return SF_EINVAL;  // the byte mask only exists on the float4 path
   const long total = rows * (vec4 ? C / 4 : C);
+  // four elements per thread where the tensor is large enough to keep every CU busy that way (SF_BN_APPLY_UNROLL=0: off).
+  // dz may alias z and dres may alias dy element for element: a thread reads its four elements before it writes any, and
+  // no other thread touches them
+  static const int unroll_env = [] { const char* e = getenv("SF_BN_APPLY_UNROLL"); return e ? atoi(e) : 1; }();
+  const int unroll4 = (unroll_env && vec4 && rep == 1 && (relu == 0 || relu == 3) && total >= 4L * TPB * 1024 &&
+                       sf_aligned16(mean) && sf_aligned16(invstd) && sf_aligned16(gamma) && sf_aligned16(dbeta) &&
+                       sf_aligned16(dgamma)) ? 1 : 0;
   if (vec4)
-    hipLaunchKernelGGL(bn_bwd_apply_kernel<4>, dim3(sf_cdiv(total, TPB)), dim3(TPB), 0, (hipStream_t)stream, dy, dy_cs,
-                       dy_coff, y, y_cs, y_coff, z, z_cs, z_coff, rows, (long)T * H * W, H * W, C, S, rep, relu, mean,
-                       invstd, gamma, dbeta, dgamma, (float)S / (float)rows, dz, dz_cs, dz_coff, dres, dres_cs,
-                       dres_coff, dres_acc, total);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<4>, dim3(sf_cdiv(unroll4 ? (total + 3) / 4 : total, TPB)), dim3(TPB), 0,
+                       (hipStream_t)stream, dy, dy_cs, dy_coff, y, y_cs, y_coff, z, z_cs, z_coff, rows, (long)T * H * W,
+                       H * W, C, S, rep, relu, mean, invstd, gamma, dbeta, dgamma, (float)S / (float)rows, dz, dz_cs,
+                       dz_coff, dres, dres_cs, dres_coff, dres_acc, total, unroll4);
   else
     hipLaunchKernelGGL(bn_bwd_apply_kernel<1>, dim3(sf_cdiv(total, TPB)), dim3(TPB), 0, (hipStream_t)stream, dy, dy_cs,
                        dy_coff, y, y_cs, y_coff, z, z_cs, z_coff, rows, (long)T * H * W, H * W, C, S, rep, relu, mean,
                        invstd, gamma, dbeta, dgamma, (float)S / (float)rows, dz, dz_cs, dz_coff, dres, dres_cs,
-                       dres_coff, dres_acc, total);
+                       dres_coff, dres_acc, total, 0);
   SF_CHECK_LAUNCH();
   return SF_OK;
 }
