@@ -614,7 +614,8 @@ static int bn_bwd_apply_launch(const float* dy, int dy_cs, int dy_coff, const fl
   // dz may alias z and dres may alias dy element for element: a thread reads its four elements before it writes any, and
   // no other thread touches them
   static const int unroll_env = [] { const char* e = getenv("SF_BN_APPLY_UNROLL"); return e ? atoi(e) : 1; }();
-  const int unroll4 = (unroll_env && vec4 && rep == 1 && (relu == 0 || relu == 3) && total >= 4L * TPB * 1024 &&
+  static const long unroll_min = [] { const char* e = getenv("SF_BN_APPLY_UNROLL_MIN"); return e ? atol(e) : 262144L; }();
+  const int unroll4 = (unroll_env && vec4 && rep == 1 && (relu == 0 || relu == 3) && total >= unroll_min &&
                        sf_aligned16(mean) && sf_aligned16(invstd) && sf_aligned16(gamma) && sf_aligned16(dbeta) &&
                        sf_aligned16(dgamma)) ? 1 : 0;
   if (vec4)
