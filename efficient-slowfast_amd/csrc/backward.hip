@@ -231,10 +231,14 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ dy, int dy_cs, int
   if constexpr (VEC == 4) if (unroll4) {
     // four elements per thread, a quarter of the tensor apart (each wave-load stays one contiguous run), every load
     // issued before the first use: 8-12 x 16 bytes in flight per thread instead of 2-3 (launcher: rep == 1, relu 0 | 3)
-    const long q = (total + 3) / 4;
-    const long i0 = (long)blockIdx.x * TPB + threadIdx.x;
+    // (32-bit index arithmetic: the launcher takes this path only below 2^31 elements; three 64-bit divisions per
+    // element were what the one-element form spent its issue slots on)
+    const unsigned tot = (unsigned)total;
+    const unsigned q = (tot + 3u) / 4u;
+    const unsigned i0 = blockIdx.x * (unsigned)TPB + threadIdx.x;
     if (i0 >= q) return;
-    const int cv = C / 4;
+    const unsigned cv = (unsigned)C / 4u;
+    const int cv_shift = (cv & (cv - 1u)) == 0u ? __builtin_ctz(cv) : -1;
     const unsigned char* const mk = reinterpret_cast<const unsigned char*>(y);
     f32x4 gv[4], zq[4], rv[4];
     unsigned mb[4];
@@ -243,11 +247,12 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ dy, int dy_cs, int
     bool ok[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      const long idx = i0 + (long)u * q;
-      ok[u] = idx < total;
-      const long id = ok[u] ? idx : 0;
-      cc[u] = (int)(id % cv) * 4;
-      rr[u] = id / cv;
+      const unsigned idx = i0 + (unsigned)u * q;
+      ok[u] = idx < tot;
+      const unsigned id = ok[u] ? idx : 0u;
+      const unsigned row = cv_shift >= 0 ? id >> cv_shift : id / cv;
+      cc[u] = (int)(id - row * cv) * 4;
+      rr[u] = (long)row;
       gv[u] = *reinterpret_cast<const f32x4*>(dy + rr[u] * dy_cs + dy_coff + cc[u]);
       zq[u] = *reinterpret_cast<const f32x4*>(z + rr[u] * z_cs + z_coff + cc[u]);
       mb[u] = relu == 3 ? mk[rr[u] * y_cs + (cc[u] >> 2)] : 0xFu;
@@ -257,7 +262,7 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ dy, int dy_cs, int
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       if (!ok[u]) continue;
-      const int so = (int)((rr[u] / THW) % S) * C + cc[u];
+      const int so = (S > 1 ? (int)(((unsigned)rr[u] / (unsigned)THW) % (unsigned)S) * C : 0) + cc[u];
       const f32x4 is = *reinterpret_cast<const f32x4*>(invstd + so), mu = *reinterpret_cast<const f32x4*>(mean + so);
       const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + so), db = *reinterpret_cast<const f32x4*>(dbeta + so);
       const f32x4 dg = *reinterpret_cast<const f32x4*>(dgamma + so);
@@ -616,6 +621,7 @@ static int bn_bwd_apply_launch(const float* dy, int dy_cs, int dy_coff, const fl
   static const int unroll_env = [] { const char* e = getenv("SF_BN_APPLY_UNROLL"); return e ? atoi(e) : 1; }();
   static const long unroll_min = [] { const char* e = getenv("SF_BN_APPLY_UNROLL_MIN"); return e ? atol(e) : 262144L; }();
   const int unroll4 = (unroll_env && vec4 && rep == 1 && (relu == 0 || relu == 3) && total >= unroll_min &&
+                       total < 0x7fffffffL && rows < 0x7fffffffL &&
                        sf_aligned16(mean) && sf_aligned16(invstd) && sf_aligned16(gamma) && sf_aligned16(dbeta) &&
                        sf_aligned16(dgamma)) ? 1 : 0;
   if (vec4)

@@ -27,7 +27,8 @@ def timed(fn, reps=20):
     return e0.elapsed_time(e1) / reps * 1e-3
 
 
-print("%-22s %10s %10s %10s %10s   (GB/s of algorithmic bytes; us)" % ("shape", "stats", "affine+res", "bwd_reduce", "bwd_apply"))
+print("%-22s %10s %10s %10s %10s %10s %10s   (GB/s of algorithmic bytes; us; m = byte-mask form, as in the step)" % (
+    "shape", "stats", "affine+res", "bwd_reduce", "bwd_apply", "reduce(m)", "apply(m)"))
 for shp in SHAPES:
     n, t, h, w, c = shp
     z = sfhip.Act(torch.randn(*shp, device=dev))
@@ -55,5 +56,21 @@ for shp in SHAPES:
         sfhip._check(lib.sf_bn_bwd_apply(*head, *tail, sfhip._ptr(g), sfhip._ptr(dbeta), sfhip._ptr(dgamma), dz.ptr(),
                                          dz.cs, dz.coff, res.ptr(), res.cs, res.coff, st()), "a")
     t_red, t_app = timed(red), timed(app)
-    row = [(t_stats, 1), (t_aff, 3), (t_red, 3), (t_app, 5)]  # tensors touched per pass
+    # the form the training step runs: the ReLU decision as one byte per 4 channels (sf_affine_fwd_mask), relu = 3
+    mk = {}
+    sfhip.affine(z, scale, shift, res=res, relu=True, out=out, mask=mk)
+    t_redm = t_appm = float("nan")
+    if "bytes" in mk:
+        mb = mk["bytes"]
+        headm = (dy.ptr(), dy.cs, dy.coff, sfhip._ptr(mb), c // 4, 0, z.ptr(), z.cs, z.coff, n, t, h, w, c)
+        tailm = (1, 3, sfhip._ptr(mean), sfhip._ptr(invstd))
+
+        def redm():
+            sfhip._check(lib.sf_bn_bwd_reduce(*headm, *tailm, sfhip._ptr(dbeta), sfhip._ptr(dgamma), sfhip._ptr(ws), st()), "r")
+
+        def appm():
+            sfhip._check(lib.sf_bn_bwd_apply(*headm, *tailm, sfhip._ptr(g), sfhip._ptr(dbeta), sfhip._ptr(dgamma),
+                                             dz.ptr(), dz.cs, dz.coff, res.ptr(), res.cs, res.coff, st()), "a")
+        t_redm, t_appm = timed(redm), timed(appm)
+    row = [(t_stats, 1), (t_aff, 3), (t_red, 3), (t_app, 5), (t_redm, 2.0625), (t_appm, 4.0625)]  # tensors touched per pass
     print("%-22s " % (shp,) + " ".join("%5.0f/%-4.0f" % (k * nbytes / tt / 1e9, tt * 1e6) for tt, k in row))
