@@ -229,40 +229,35 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ dy, int dy_cs, int
                                     float* __restrict__ dres, int dres_cs, int dres_coff, int dres_acc, long total,
                                     int unroll4) {
   if constexpr (VEC == 4) if (unroll4) {
-    // four elements per thread, a quarter of the tensor apart (each wave-load stays one contiguous run), every load
-    // issued before the first use: 8-12 x 16 bytes in flight per thread instead of 2-3 (launcher: rep == 1, relu 0 | 3)
-    // (32-bit index arithmetic: the launcher takes this path only below 2^31 elements; three 64-bit divisions per
-    // element were what the one-element form spent its issue slots on)
-    const unsigned tot = (unsigned)total;
-    const unsigned q = (tot + 3u) / 4u;
-    const unsigned i0 = blockIdx.x * (unsigned)TPB + threadIdx.x;
-    if (i0 >= q) return;
+    // four elements per thread: the SAME channel vector of four rows a quarter of the tensor apart (the launcher takes
+    // this path when rows % 4 == 0), so each wave-load is one contiguous run, the per-channel coefficients are loaded
+    // and folded once per thread, and every load (dy, z, mask byte, dres) is issued before the first use: 8-12 x 16
+    // bytes in flight per thread instead of 2-3.  32-bit index arithmetic (below 2^31 elements): three 64-bit
+    // divisions per element were what the one-element form spent its issue slots on.
     const unsigned cv = (unsigned)C / 4u;
+    const unsigned qrows = (unsigned)rows / 4u;
+    const unsigned i0 = blockIdx.x * (unsigned)TPB + threadIdx.x;
+    if (i0 >= qrows * cv) return;
     const int cv_shift = (cv & (cv - 1u)) == 0u ? __builtin_ctz(cv) : -1;
+    const unsigned row0 = cv_shift >= 0 ? i0 >> cv_shift : i0 / cv;
+    const int c = (int)(i0 - row0 * cv) * 4;
     const unsigned char* const mk = reinterpret_cast<const unsigned char*>(y);
     f32x4 gv[4], zq[4], rv[4];
     unsigned mb[4];
-    long rr[4];
-    int cc[4];
-    bool ok[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      const unsigned idx = i0 + (unsigned)u * q;
-      ok[u] = idx < tot;
-      const unsigned id = ok[u] ? idx : 0u;
-      const unsigned row = cv_shift >= 0 ? id >> cv_shift : id / cv;
-      cc[u] = (int)(id - row * cv) * 4;
-      rr[u] = (long)row;
-      gv[u] = *reinterpret_cast<const f32x4*>(dy + rr[u] * dy_cs + dy_coff + cc[u]);
-      zq[u] = *reinterpret_cast<const f32x4*>(z + rr[u] * z_cs + z_coff + cc[u]);
-      mb[u] = relu == 3 ? mk[rr[u] * y_cs + (cc[u] >> 2)] : 0xFu;
-      if (dres && dres_acc) rv[u] = *reinterpret_cast<const f32x4*>(dres + rr[u] * dres_cs + dres_coff + cc[u]);
+      const long r = (long)(row0 + (unsigned)u * qrows);
+      gv[u] = *reinterpret_cast<const f32x4*>(dy + r * dy_cs + dy_coff + c);
+      zq[u] = *reinterpret_cast<const f32x4*>(z + r * z_cs + z_coff + c);
+      mb[u] = relu == 3 ? mk[r * y_cs + (c >> 2)] : 0xFu;
+      if (dres && dres_acc) rv[u] = *reinterpret_cast<const f32x4*>(dres + r * dres_cs + dres_coff + c);
       else rv[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      if (!ok[u]) continue;
-      const int so = (S > 1 ? (int)(((unsigned)rr[u] / (unsigned)THW) % (unsigned)S) * C : 0) + cc[u];
+      const unsigned row = row0 + (unsigned)u * qrows;
+      const long r = (long)row;
+      const int so = (S > 1 ? (int)((row / (unsigned)THW) % (unsigned)S) * C : 0) + c;
       const f32x4 is = *reinterpret_cast<const f32x4*>(invstd + so), mu = *reinterpret_cast<const f32x4*>(mean + so);
       const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + so), db = *reinterpret_cast<const f32x4*>(dbeta + so);
       const f32x4 dg = *reinterpret_cast<const f32x4*>(dgamma + so);
@@ -273,8 +268,8 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ dy, int dy_cs, int
         const float xh = (zq[u][e] - mu[e]) * is[e];
         ov[e] = ga[e] * is[e] * (gg[e] - db[e] * inv_m - xh * dg[e] * inv_m);
       }
-      *reinterpret_cast<f32x4*>(dz + rr[u] * dz_cs + dz_coff + cc[u]) = ov;
-      if (dres) *reinterpret_cast<f32x4*>(dres + rr[u] * dres_cs + dres_coff + cc[u]) = rv[u] + gg;
+      *reinterpret_cast<f32x4*>(dz + r * dz_cs + dz_coff + c) = ov;
+      if (dres) *reinterpret_cast<f32x4*>(dres + r * dres_cs + dres_coff + c) = rv[u] + gg;
     }
     return;
   }
@@ -621,7 +616,7 @@ static int bn_bwd_apply_launch(const float* dy, int dy_cs, int dy_coff, const fl
   static const int unroll_env = [] { const char* e = getenv("SF_BN_APPLY_UNROLL"); return e ? atoi(e) : 1; }();
   static const long unroll_min = [] { const char* e = getenv("SF_BN_APPLY_UNROLL_MIN"); return e ? atol(e) : 262144L; }();
   const int unroll4 = (unroll_env && vec4 && rep == 1 && (relu == 0 || relu == 3) && total >= unroll_min &&
-                       total < 0x7fffffffL && rows < 0x7fffffffL &&
+                       total < 0x7fffffffL && rows < 0x7fffffffL && (rows % 4) == 0 &&
                        sf_aligned16(mean) && sf_aligned16(invstd) && sf_aligned16(gamma) && sf_aligned16(dbeta) &&
                        sf_aligned16(dgamma)) ? 1 : 0;
   if (vec4)
