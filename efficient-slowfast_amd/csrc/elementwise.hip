@@ -744,28 +744,72 @@ struct PackItem {
   int Cout, Cin, taps, cin_pad, cout_pad, pad_;
   long n_wp, total;
 };
-__global__ void pack_weights_batched_kernel(const PackItem* __restrict__ items, const int* __restrict__ blk0, int n) {
+// Workgroups of item i (the binding computes the same number, sfhip.h): the forward layout's (below), then one per
+// 32 x 32 tile of the transposed layout.
+// * wp [Cout][taps][cin_pad]: taps == 1 is a padded copy; 2 <= taps <= 9 (the 3x1x1 / 1x3x3 layers: most of the bytes)
+//   goes through LDS per (8 output channels, 32 input channels): ceil(Cout / 8) * ceil(cin_pad / 32) workgroups;
+//   the stems' 7 / 35 taps gather element-wise.  32-bit index arithmetic.
+// * wtp [Cin][taps][cout_pad] is the plain transpose of the weight seen as W[Cout][Q = Cin * taps] (q = ci * taps + tap
+//   is contiguous in the parameter, and (q, co) -> q * cout_pad + co in the packed copy): 32 x 32 tiles through LDS,
+//   reads and writes both in 128-byte runs.  (One element per thread with the source at stride Cin * taps * 4 bytes
+//   — every lane its own cache line and DRAM page — ran the 137 MB of cfg #3's weights at 1.6 TB/s: 0.26 ms at the
+//   head of every training step, in front of the first conv.)
+__global__ __launch_bounds__(256) void pack_weights_batched_kernel(const PackItem* __restrict__ items,
+                                                                   const int* __restrict__ blk0, int n) {
+  __shared__ float lds_buf[8 * (32 * 9 + 1)];  // the forward layout's 8 x (32 * taps + 1) rows, or the 32 x 33 transpose tile
+  float (*const tile)[33] = reinterpret_cast<float (*)[33]>(lds_buf);
   int lo = 0, hi = n;  // the item whose block range holds blockIdx.x
   while (hi - lo > 1) {
     const int mid = (lo + hi) >> 1;
     if (blk0[mid] <= (int)blockIdx.x) lo = mid; else hi = mid;
   }
   const PackItem it = items[lo];
-  const long idx = (long)((int)blockIdx.x - blk0[lo]) * TPB + threadIdx.x;
-  if (idx >= it.total) return;
-  if (idx < it.n_wp) {
-    const int c = (int)(idx % it.cin_pad);
-    const long r = idx / it.cin_pad;
-    const int tap = (int)(r % it.taps);
-    const int co = (int)(r / it.taps);
-    it.wp[idx] = c < it.Cin ? it.w[((long)co * it.Cin + c) * it.taps + tap] : 0.f;
-  } else {
-    const long j = idx - it.n_wp;
-    const int co = (int)(j % it.cout_pad);
-    const long r = j / it.cout_pad;
-    const int tap = (int)(r % it.taps);
-    const int ci = (int)(r / it.taps);
-    it.wtp[j] = co < it.Cout ? it.w[((long)co * it.Cin + ci) * it.taps + tap] : 0.f;
+  const unsigned b = blockIdx.x - (unsigned)blk0[lo];
+  const unsigned n_wp = (unsigned)it.n_wp;
+  const bool rows = it.taps > 1 && it.taps <= 9;
+  const unsigned ctiles = ((unsigned)it.cin_pad + 31u) / 32u;
+  const unsigned nbw = rows ? (((unsigned)it.Cout + 7u) / 8u) * ctiles : (n_wp + 255u) / 256u;
+  if (b < nbw) {
+    if (!rows) {  // taps == 1: a padded copy; stems (taps 7 / 35): element-wise gather
+      const unsigned idx = b * 256u + threadIdx.x;
+      if (idx >= n_wp) return;
+      const unsigned r = idx / (unsigned)it.cin_pad, c = idx - r * (unsigned)it.cin_pad;
+      const unsigned co = r / (unsigned)it.taps, tap = r - co * (unsigned)it.taps;
+      it.wp[idx] = c < (unsigned)it.Cin ? it.w[((long)co * it.Cin + c) * it.taps + tap] : 0.f;
+      return;
+    }
+    // 8 output channels x 32 input channels x taps: the 32 * taps source floats of an output channel are ONE contiguous
+    // run; through LDS (row pitch 32 * taps + 1) they leave as `taps` runs of 32 floats
+    float* const seg = lds_buf;
+    const unsigned cob = b / ctiles, ct = b - cob * ctiles;
+    const unsigned lx = threadIdx.x & 31u, ly = threadIdx.x >> 5;
+    const unsigned co = cob * 8u + ly, c0 = ct * 32u, taps = (unsigned)it.taps;
+    const unsigned pitch = 32u * taps + 1u;
+    const unsigned nsrc = (c0 < (unsigned)it.Cin ? ((unsigned)it.Cin - c0 < 32u ? (unsigned)it.Cin - c0 : 32u) : 0u) * taps;
+    for (unsigned e = lx; e < 32u * taps; e += 32u)
+      seg[ly * pitch + e] = (co < (unsigned)it.Cout && e < nsrc) ? it.w[((long)co * it.Cin + c0) * taps + e] : 0.f;
+    __syncthreads();
+    if (co < (unsigned)it.Cout && c0 + lx < (unsigned)it.cin_pad)
+      for (unsigned tap = 0; tap < taps; ++tap)
+        it.wp[((long)co * taps + tap) * it.cin_pad + c0 + lx] = seg[ly * pitch + lx * taps + tap];
+    return;
+  }
+  const unsigned Q = (unsigned)it.Cin * (unsigned)it.taps;
+  const unsigned tq = (Q + 31u) / 32u;
+  const unsigned t = b - nbw;
+  const unsigned tco = t / tq, tqi = t - tco * tq;
+  const unsigned q0 = tqi * 32u, co0 = tco * 32u;
+  const unsigned lx = threadIdx.x & 31u, ly = threadIdx.x >> 5;  // 32 x 8 threads, four rows each
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const unsigned co = co0 + ly + 8u * k, q = q0 + lx;
+    tile[ly + 8 * k][lx] = (co < (unsigned)it.Cout && q < Q) ? it.w[(long)co * Q + q] : 0.f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const unsigned q = q0 + ly + 8u * k, co = co0 + lx;
+    if (q < Q && co < (unsigned)it.cout_pad) it.wtp[(long)q * it.cout_pad + co] = tile[lx][ly + 8 * k];
   }
 }
 

@@ -484,7 +484,9 @@ def pack_conv_weight_pairs(weights, outs):
         n_wp = cout * taps * cin_pad
         total = n_wp + cin * taps * cout_pad
         recs.append((w.data_ptr(), o[0].data_ptr(), o[1].data_ptr(), cout, cin, taps, cin_pad, cout_pad, 0, n_wp, total))
-        nb += (total + 255) // 256
+        # workgroups of this weight (sfhip.h): the forward layout element-wise, the transposed one in 32 x 32 tiles
+        nbw = ((cout + 7) // 8) * ((cin_pad + 31) // 32) if 1 < taps <= 9 else (n_wp + 255) // 256
+        nb += nbw + ((cin * taps + 31) // 32) * ((cout_pad + 31) // 32)
         blk0.append(nb)
     key = tuple(r[:8] for r in recs)  # pointers AND dims: a freed buffer's address may come back with another shape
     dev = weights[0].device

@@ -169,7 +169,9 @@ int sf_pack_conv_weight(const float* w, int Cout, int Cin, int taps, float* wp, 
 /* The same for n weights in ONE launch (a training step re-packs every conv after the optimizer step).  items: device
  * array of n records { const float* w; float* wp; float* wtp; int Cout, Cin, taps, cin_pad, cout_pad, pad; long n_wp
  * (= Cout*taps*cin_pad), total (= n_wp + Cin*taps*cout_pad, or n_wp when wtp is NULL) } (64 bytes each); blk0: device
- * array of n + 1 ints, blk0[i] = first 256-thread workgroup of weight i, blk0[n] = nblocks.                     */
+ * array of n + 1 ints, blk0[i] = first 256-thread workgroup of weight i, blk0[n] = nblocks.  Weight i takes, for the
+ * forward layout, ceil(Cout / 8) * ceil(cin_pad / 32) workgroups when 2 <= taps <= 9 and ceil(n_wp / 256) otherwise,
+ * plus ceil(Cin*taps / 32) * ceil(cout_pad / 32) for the transposed one (32 x 32 tiles through LDS; wtp required).  */
 int sf_pack_conv_weights(const void* items, const int* blk0, int n, int nblocks, void* stream);
 
 /* ---- depthwise convolution (groups == channels) ----------------------------------------------
