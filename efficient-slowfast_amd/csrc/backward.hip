@@ -193,21 +193,41 @@ __global__ void pair_final_kernel(const float* __restrict__ partial, int C, int 
   const int o = blockIdx.x;  // split * C + channel
   const int sp = o / C, c = o - sp * C;
   double s1 = 0.0, s2 = 0.0;
-  for (int i = threadIdx.x; i < P; i += 64) {
+  int i = threadIdx.x;
+  if (S == 1) {
+    // four partials of this lane per trip, the eight loads issued before the first add (one pair per trip left this
+    // 64-thread workgroup at one L2 round trip per 64 partials: ~7 us for P = 1024, on the path between the two BN
+    // backward passes of every layer)
+    double a1[4] = {0.0, 0.0, 0.0, 0.0}, a2[4] = {0.0, 0.0, 0.0, 0.0};
+    for (; i + 192 < P; i += 256) {
+      float t1[4], t2[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        t1[u] = partial[((long)(i + 64 * u) * 2 + 0) * C + c];
+        t2[u] = partial[((long)(i + 64 * u) * 2 + 1) * C + c];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        a1[u] += (double)t1[u];
+        a2[u] += (double)t2[u];
+      }
+    }
+    s1 = (a1[0] + a1[1]) + (a1[2] + a1[3]);
+    s2 = (a2[0] + a2[1]) + (a2[2] + a2[3]);
+  }
+  for (; i < P; i += 64) {
     if ((i / chunks) % S != sp) continue;
     s1 += (double)partial[((long)i * 2 + 0) * C + c];
     s2 += (double)partial[((long)i * 2 + 1) * C + c];
   }
-  r1[threadIdx.x] = s1;
-  r2[threadIdx.x] = s2;
-  __syncthreads();
-  for (int s = 32; s > 0; s >>= 1) {
-    if (threadIdx.x < s) {
-      r1[threadIdx.x] += r1[threadIdx.x + s];
-      r2[threadIdx.x] += r2[threadIdx.x + s];
-    }
-    __syncthreads();
+  // lanes combined in a fixed order without leaving the wavefront (the workgroup is one wavefront)
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    s1 += __shfl_xor(s1, off, 64);
+    s2 += __shfl_xor(s2, off, 64);
   }
+  r1[0] = s1;
+  r2[0] = s2;
   if (threadIdx.x == 0) {
     o1[o] = (float)r1[0];
     o2[o] = (float)r2[0];
