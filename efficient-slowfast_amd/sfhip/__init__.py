@@ -819,6 +819,39 @@ def _residue_taps(k, s, p, a):
 _TAP_INDEX = {}
 
 
+def _class_weights(wt_packed, store, kernel, stride, padding):
+    """The tap-subset copies of a packed data-gradient weight [Cin][taps][cout_pad] for EVERY residue class of a strided
+    layer, by ONE gather launch per weight and optimizer step: the rows (ci, tap) of all classes are gathered class by
+    class into one tensor, and a class's weight [Cin][its taps][cout_pad] is a contiguous slice of it (a gather per
+    class was 30 small launches per step of cfg #3, each in front of its class's conv; a torch.stack of tap slices ~190
+    copy kernels).  The row index is built once per (Cin, layer geometry, device) — during warm-up, so nothing is copied
+    from the host inside a hipGraph capture.  Fills `store` (key = (a_t, a_h, a_w, kernel, stride, padding))."""
+    cin, taps, cout_pad = wt_packed.shape
+    kT, kH, kW = kernel
+    fam = (tuple(kernel), tuple(stride), tuple(padding))
+    classes = []
+    for at in range(stride[0]):
+        tt = _residue_taps(kT, stride[0], padding[0], at)[1]
+        for ah in range(stride[1]):
+            th = _residue_taps(kH, stride[1], padding[1], ah)[1]
+            for aw in range(stride[2]):
+                tw = _residue_taps(kW, stride[2], padding[2], aw)[1]
+                if tt and th and tw:
+                    classes.append(((at, ah, aw) + fam, [(a * kH + b) * kW + c for a in tt for b in th for c in tw]))
+    ikey = (cin, taps, fam, str(wt_packed.device))
+    idx = _TAP_INDEX.get(ikey)
+    if idx is None:
+        rows = [ci * taps + t for _, sel in classes for ci in range(cin) for t in sel]
+        idx = _TAP_INDEX[ikey] = torch.tensor(rows, dtype=torch.long, device=wt_packed.device)
+    allrows = wt_packed.view(cin * taps, cout_pad).index_select(0, idx)
+    off = 0
+    for key, sel in classes:
+        n = cin * len(sel)
+        store[key] = allrows[off:off + n].view(cin, len(sel), cout_pad)
+        off += n
+    return store
+
+
 def _conv_dgrad_strided(dz, wt_packed, out, kernel, stride, padding, accumulate, dz_planes=None):
     """Data gradient of a strided conv as one DENSE small conv over dL/dz per residue class of the input position
     (the transposed-gather formulation evaluates every tap at every input position and predicates s^2-1 of s^2
@@ -848,15 +881,7 @@ def _conv_dgrad_strided(dz, wt_packed, out, kernel, stride, padding, accumulate,
                 key = (at, ah, aw, tuple(kernel), tuple(stride), tuple(padding))
                 wsub = store.get(key)
                 if wsub is None:
-                    # ONE gather launch per class and optimizer step (a torch.stack of the tap slices was a burst of
-                    # ~190 small copy kernels per step); the index tensor is built once per (taps, device) — during
-                    # warm-up, so nothing is copied from the host inside a hipGraph capture
-                    taps_sel = tuple((a * kH + b) * kW + c for a in tt for b in th for c in tw)
-                    ikey = (taps_sel, str(wt_packed.device))
-                    idx = _TAP_INDEX.get(ikey)
-                    if idx is None:
-                        idx = _TAP_INDEX[ikey] = torch.tensor(taps_sel, dtype=torch.long, device=wt_packed.device)
-                    wsub = store[key] = wt_packed.index_select(1, idx)
+                    wsub = _class_weights(wt_packed, store, kernel, stride, padding)[key]
                 d = ConvDesc(dz.N, dz.T, dz.H, dz.W, dz.C, dz.cs, dz.coff, dims[0], dims[1], dims[2], cin, out.cs,
                              out.coff, 1, len(tt), len(th), len(tw), 1, 1, 1, -ot[0], -oh[0], -ow[0], 1, 1, 1,
                              cout_pad, ACT_NONE, out.cs, out.coff, 0, stride[0], stride[1], stride[2], at, ah, aw,

@@ -118,6 +118,17 @@ class Tape(object):
         cur = self.pgrads.get(param)
         self.pgrads[param] = g if cur is None else cur + g
 
+    def add_pgrads(self, params, grads):
+        """add_pgrad for several parameters at once: with a gradient sink (FlatGradients) the accumulations are ONE
+        multi-tensor launch instead of one small add per parameter (the q | k | v projections of an attention: six adds on
+        the path between its weight gradient and its data gradient)."""
+        tgts = [self.sink.get(p) if self.sink is not None else None for p in params]
+        if all(t is not None for t in tgts) and len(tgts) > 1:
+            torch._foreach_add_(tgts, [g.reshape(p.shape) for p, g in zip(params, grads)])
+            return
+        for p, g in zip(params, grads):
+            self.add_pgrad(p, g)
+
     def backward(self):
         """Replay in reverse.  Ops recorded inside run_paths on the side stream run there again; the region's
         join / fork markers become the backward pass's fork / join."""

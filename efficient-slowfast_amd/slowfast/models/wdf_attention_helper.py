@@ -55,9 +55,8 @@ class SpatialAttention(nn.Module):
                 dwp = sfhip.conv_wgrad(x, g, 3 * c, (1, 1, 1), cin_pad=wp.shape[2])
                 dw = sfhip.unpack_conv_weight_grad(dwp, (3 * c, c, 1, 1, 1))
                 db = engine._colsum(g)
-                for i, cv in enumerate(convs):
-                    t.add_pgrad(cv.weight, dw[i * c:i * c + nout[i]])
-                    t.add_pgrad(cv.bias, db[i * c:i * c + nout[i]])
+                t.add_pgrads([cv.weight for cv in convs] + [cv.bias for cv in convs],
+                             [dw[i * c:i * c + nout[i]] for i in range(3)] + [db[i * c:i * c + nout[i]] for i in range(3)])
                 sfhip.conv_dgrad(g, wtp, x, (1, 1, 1), out=t.grad_of(x), accumulate=True)
 
             t.record(bwd)
