@@ -880,6 +880,13 @@ def _conv_dgrad_strided(dz, wt_packed, out, kernel, stride, padding, accumulate,
                 store = wt_packed.__dict__.setdefault("_sf_classes", {})
                 key = (at, ah, aw, tuple(kernel), tuple(stride), tuple(padding))
                 wsub = store.get(key)
+                if wsub is None and os.environ.get("SF_CLASS_GATHER", "1") == "0":
+                    taps_sel = tuple((a * kH + b) * kW + c for a in tt for b in th for c in tw)
+                    ikey = (taps_sel, str(wt_packed.device))
+                    idx = _TAP_INDEX.get(ikey)
+                    if idx is None:
+                        idx = _TAP_INDEX[ikey] = torch.tensor(taps_sel, dtype=torch.long, device=wt_packed.device)
+                    wsub = store[key] = wt_packed.index_select(1, idx)
                 if wsub is None:
                     wsub = _class_weights(wt_packed, store, kernel, stride, padding)[key]
                 d = ConvDesc(dz.N, dz.T, dz.H, dz.W, dz.C, dz.cs, dz.coff, dims[0], dims[1], dims[2], cin, out.cs,

@@ -123,7 +123,7 @@ class Tape(object):
         multi-tensor launch instead of one small add per parameter (the q | k | v projections of an attention: six adds on
         the path between its weight gradient and its data gradient)."""
         tgts = [self.sink.get(p) if self.sink is not None else None for p in params]
-        if all(t is not None for t in tgts) and len(tgts) > 1:
+        if all(t is not None for t in tgts) and len(tgts) > 1 and os.environ.get("SF_FOREACH_PGRAD", "1") != "0":
             torch._foreach_add_(tgts, [g.reshape(p.shape) for p, g in zip(params, grads)])
             return
         for p, g in zip(params, grads):

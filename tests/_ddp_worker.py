@@ -122,6 +122,41 @@ def main():
         want = (mine + other) / 2
         rep["flat_err"] = float((flat.flat - want).abs().max() / want.abs().max())
         rep["flat_err_host"] = float((host.cuda() / world - want).abs().max() / want.abs().max())
+        if rep["flat_err"] > 1e-6:  # which parameters: the ranges of the flat buffer that disagree
+            names = [n for n, p in model.named_parameters() if p.requires_grad]
+            off, bad = 0, []
+            for n, p in zip(names, flat.params):
+                k = p.numel()
+                e = float((flat.flat[off:off + k] - want[off:off + k]).abs().max())
+                if e > 1e-6 * float(want.abs().max()):
+                    bad.append((n, e))
+                off += k
+            rep["bad_params"] = bad[:12]
+            rep["n_bad_params"] = len(bad)
+            try:  # keep the evidence where a gpurun call brings it back
+                root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+                os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
+                with open(os.path.join(root, "gpurun_out", "flat_fail_rank%d.json" % rank), "w") as f:
+                    json.dump({"bad": bad, "flat_err": rep["flat_err"], "flat_err_host": rep["flat_err_host"],
+                               "mine_vs_flat2": float((flat.flat * 2 - mine - other).abs().max())}, f)
+            except OSError:
+                pass
+        # diagnostics of a disagreement (round 6: ~3 % of runs with two processes time-sharing the GPU): repeat both
+        # passes and say which of the four was the outlier
+        other2 = shard_grad(1 - rank)
+        mine2 = shard_grad(rank)
+        rep["repeat_other_diff"] = float((other2 - other).abs().max())
+        rep["repeat_mine_diff"] = float((mine2 - mine).abs().max())
+        if rep["repeat_other_diff"] > 0 or rep["repeat_mine_diff"] > 0:
+            try:
+                root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+                os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
+                with open(os.path.join(root, "gpurun_out", "flat_repeat_rank%d.json" % rank), "w") as f:
+                    json.dump({"first_pass_other_vs_repeat": rep["repeat_other_diff"],
+                               "second_pass_mine_vs_repeat": rep["repeat_mine_diff"],
+                               "repeats_agree_with_each_other": float((other2 + mine2 - other - mine).abs().max())}, f)
+            except OSError:
+                pass
         rep["grad_norm"] = float(want.norm())
         rep["differs_from_local"] = float((want - mine).abs().max() / want.abs().max())
         engine.set_grad_sink(False)
